@@ -1,0 +1,335 @@
+"""ctypes binding of include/awm_hip.h.  Names follow the reference's operators:
+add_watermark / get_watermark (wmcommon.hh:226-228), SyncFinder.search, fft_range, ..."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+N_BANDS = 81
+BLOCK_FRAMES = 2226
+SOFT_BITS = 858
+
+
+class AwmError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libawm_hip.so")
+
+
+def _load():
+    path = library_path()
+    if not os.path.exists(path):
+        raise AwmError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                       "or `make -C audiowmark_amd/csrc` (there is no CPU fallback)")
+    return C.CDLL(path)
+
+
+class Pattern(C.Structure):
+    _fields_ = [("time", C.c_double), ("sync_index", C.c_uint64), ("sync_quality", C.c_double),
+                ("block_type", C.c_int), ("type", C.c_int), ("decode_error", C.c_float), ("speed", C.c_double),
+                ("bits", C.c_int * 128), ("n_bits", C.c_int)]
+
+    def hex(self):
+        b = list(self.bits[:self.n_bits])
+        return "".join("%x" % (b[i] * 8 + b[i + 1] * 4 + b[i + 2] * 2 + b[i + 3]) for i in range(0, len(b) - 3, 4))
+
+    def as_dict(self):
+        return dict(time=self.time, sync_index=int(self.sync_index), sync_quality=self.sync_quality,
+                    block_type=self.block_type, type=self.type, decode_error=self.decode_error, speed=self.speed,
+                    bits=self.hex())
+
+
+lib = _load()
+_u8p = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+lib.awm_last_error.restype = C.c_char_p
+lib.awm_version.restype = C.c_char_p
+lib.awm_ctx_stream.restype = C.c_void_p
+lib.awm_search_approx_d.restype = C.c_long
+lib.awm_set_params.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]
+lib.awm_set_params.restype = None
+lib.awm_ctx_create.argtypes = [C.c_int, C.POINTER(_vp)]
+lib.awm_ctx_destroy.argtypes = [_vp]
+lib.awm_ctx_destroy.restype = None
+lib.awm_ctx_synchronize.argtypes = [_vp]
+lib.awm_ctx_stream.argtypes = [_vp]
+lib.awm_ctx_set_stream.argtypes = [_vp, _vp]
+lib.awm_stft_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, _vp]
+lib.awm_add_init_block_max_d.argtypes = [_vp, _vp, C.c_size_t]
+lib.awm_add_mix_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C.c_double, C.c_size_t, _vp, _vp, _vp,
+                              C.c_size_t, C.c_size_t]
+lib.awm_add_limit_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_size_t, _vp, C.c_size_t, C.c_size_t]
+lib.awm_add_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C.c_double, C.c_int]
+lib.awm_sync_fft_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_size_t, C.c_size_t, _vp, C.c_size_t, C.c_size_t, _vp, _vp]
+lib.awm_sync_search_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp]
+lib.awm_search_approx_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _vp, _vp, _vp]
+lib.awm_block_soft_bits_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, _vp, _vp]
+lib.awm_viterbi_decode.argtypes = [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, _vp]
+lib.awm_add_watermark_d.argtypes = [_vp, _vp, C.c_char_p, _vp, _vp, C.c_size_t, C.c_int, C.c_int]
+lib.awm_get_watermark_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_size_t, _vp]
+lib.awm_decode_chunk_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _vp]
+lib.awm_tab_up_down.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
+lib.awm_tab_bit_pos.argtypes = [_vp, _vp]
+lib.awm_tab_mix_entries.argtypes = [_vp, _vp]
+lib.awm_tab_bit_order.argtypes = [_vp, C.c_size_t, _vp]
+lib.awm_tab_frame_mod.argtypes = [_vp, C.c_char_p, _vp]
+lib.awm_tab_sync_bits.argtypes = [_vp, C.c_int, _vp]
+lib.awm_tab_window.argtypes = [C.c_size_t, _vp]
+lib.awm_tab_synth_window.argtypes = [_vp]
+lib.awm_conv_encode.argtypes = [C.c_int, _vp, C.c_size_t, _vp]
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise AwmError(f"{what} failed (rc={rc}): {lib.awm_last_error().decode(errors='replace')}")
+    return rc
+
+
+def key_bytes(key=None):
+    """16-byte AES key: None -> the all-zero default key, bytes/hex -> as given."""
+    if key is None:
+        return bytes(16)
+    if isinstance(key, str):
+        key = bytes.fromhex(key)
+    key = bytes(key)
+    if len(key) != 16:
+        raise ValueError("key must be 16 bytes")
+    return key
+
+
+def test_key(n):
+    """Key::set_test_key (reference random.cc:204-209): big-endian u64 in the first 8 bytes."""
+    return int(n).to_bytes(8, "big") + bytes(8)
+
+
+def _np(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def set_params(water_delta=0.01, mix=True, frames_per_bit=2, test_no_limiter=False, sync_threshold2=0.35, n_best=8,
+               chunk_size_min=30.0):
+    lib.awm_set_params(water_delta, int(mix), frames_per_bit, int(test_no_limiter), sync_threshold2, n_best,
+                       chunk_size_min)
+
+
+# ---- key-derived tables (host only) ---------------------------------------------------------
+def tab_up_down(key, stream, frame):
+    up = np.zeros(30, np.int32)
+    down = np.zeros(30, np.int32)
+    lib.awm_tab_up_down(key_bytes(key), stream, frame, _np(up), _np(down))
+    return up, down
+
+
+def tab_bit_pos(key):
+    pos = np.zeros(BLOCK_FRAMES, np.int32)
+    lib.awm_tab_bit_pos(key_bytes(key), _np(pos))
+    return pos
+
+
+def tab_mix_entries(key):
+    out = np.zeros((51480, 3), np.int32)
+    n = lib.awm_tab_mix_entries(key_bytes(key), _np(out))
+    return out[:n]
+
+
+def tab_bit_order(key, n):
+    out = np.zeros(n, np.uint32)
+    lib.awm_tab_bit_order(key_bytes(key), n, _np(out))
+    return out
+
+
+def tab_frame_mod(key, payload_hex):
+    out = np.zeros((2, BLOCK_FRAMES, N_BANDS), np.int8)
+    _check(lib.awm_tab_frame_mod(key_bytes(key), payload_hex.encode(), _np(out)), "awm_tab_frame_mod")
+    return out
+
+
+def tab_sync_bits(key, clip_mode=False):
+    rows = 170 if clip_mode else 85
+    out = np.zeros((6, rows, 61), np.int32)
+    r = lib.awm_tab_sync_bits(key_bytes(key), int(clip_mode), _np(out))
+    assert r == rows
+    return out
+
+
+def tab_window(n=1024):
+    out = np.zeros(n, np.float32)
+    lib.awm_tab_window(n, _np(out))
+    return out
+
+
+def tab_synth_window():
+    out = np.zeros(3072, np.float32)
+    lib.awm_tab_synth_window(_np(out))
+    return out
+
+
+def conv_encode(block_type, bits):
+    bits = np.ascontiguousarray(bits, np.int32)
+    out = np.zeros((len(bits) + 15) * 12, np.int32)
+    n = lib.awm_conv_encode(block_type, _np(bits), len(bits), _np(out))
+    return out[:n]
+
+
+# ---- device side ---------------------------------------------------------------------------
+def _dev_ptr(t):
+    import torch
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()
+    return C.c_void_p(t.data_ptr())
+
+
+def _pcm_shape(pcm):
+    """(n_frames, n_channels) of an interleaved float32 CUDA tensor shaped [frames, channels] or [frames]."""
+    import torch
+    assert pcm.dtype == torch.float32 and pcm.is_cuda and pcm.is_contiguous()
+    if pcm.dim() == 1:
+        return pcm.shape[0], 1
+    return pcm.shape[0], pcm.shape[1]
+
+
+class Context:
+    """One awm_ctx: a GPU, its stream and workspaces.  Work is enqueued on torch's current stream
+    of that device so that torch.cuda events/synchronisation bracket it."""
+
+    def __init__(self, device=0, use_torch_stream=True):
+        import torch
+        self.device = device
+        h = C.c_void_p()
+        _check(lib.awm_ctx_create(device, C.byref(h)), "awm_ctx_create")
+        self._h = h
+        if use_torch_stream:
+            s = torch.cuda.current_stream(device)
+            _check(lib.awm_ctx_set_stream(self._h, C.c_void_p(s.cuda_stream)), "awm_ctx_set_stream")
+
+    def close(self):
+        if self._h:
+            lib.awm_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib.awm_ctx_synchronize(self._h), "awm_ctx_synchronize")
+
+    # FFTAnalyzer::fft_range
+    def fft_range(self, pcm, start_index, frame_count, hop=1024):
+        import torch
+        n, ch = _pcm_shape(pcm)
+        out = torch.empty((frame_count, ch, 513, 2), dtype=torch.float32, device=pcm.device)
+        _check(lib.awm_stft_d(self._h, _dev_ptr(pcm), n, ch, start_index, hop, frame_count, _dev_ptr(out)), "awm_stft_d")
+        return out
+
+    # add_watermark on resident PCM
+    def add_watermark(self, key, payload_hex, pcm, out=None, sample_rate=44100):
+        import torch
+        n, ch = _pcm_shape(pcm)
+        if out is None:
+            out = torch.empty_like(pcm)
+        _check(lib.awm_add_watermark_d(self._h, key_bytes(key), payload_hex.encode(), _dev_ptr(pcm), _dev_ptr(out), n, ch,
+                                       sample_rate), "awm_add_watermark_d")
+        return out
+
+    def add_d(self, pcm, frame_mod, water_delta=0.01, use_limiter=True, out=None):
+        import torch
+        n, ch = _pcm_shape(pcm)
+        if out is None:
+            out = torch.empty_like(pcm)
+        fm = np.ascontiguousarray(frame_mod, np.int8)
+        _check(lib.awm_add_d(self._h, _dev_ptr(pcm), _dev_ptr(out), n, ch, _np(fm), water_delta, int(use_limiter)), "awm_add_d")
+        return out
+
+    def add_mix(self, pcm, out, frame_mod, water_delta, first_frame, halo_before, halo_after, block_max, first_block=0):
+        n, ch = _pcm_shape(pcm)
+        fm = np.ascontiguousarray(frame_mod, np.int8)
+        _check(lib.awm_add_mix_d(self._h, _dev_ptr(pcm), _dev_ptr(out), n, ch, _np(fm), water_delta, first_frame,
+                                 _dev_ptr(halo_before) if halo_before is not None else None,
+                                 _dev_ptr(halo_after) if halo_after is not None else None,
+                                 _dev_ptr(block_max) if block_max is not None else None, first_block,
+                                 block_max.numel() if block_max is not None else 0), "awm_add_mix_d")
+
+    def add_init_block_max(self, block_max):
+        _check(lib.awm_add_init_block_max_d(self._h, _dev_ptr(block_max), block_max.numel()), "awm_add_init_block_max_d")
+
+    def add_limit(self, out, first_sample, block_max, first_block=0):
+        n, ch = _pcm_shape(out)
+        _check(lib.awm_add_limit_d(self._h, _dev_ptr(out), n, ch, first_sample, _dev_ptr(block_max), first_block,
+                                   block_max.numel()), "awm_add_limit_d")
+
+    # SyncFinder::sync_fft
+    def sync_fft(self, pcm, index, frame_count, want_frames=None, first=0, last=None):
+        import torch
+        n, ch = _pcm_shape(pcm)
+        if last is None:
+            last = n * ch
+        db = torch.zeros((frame_count, N_BANDS), dtype=torch.float32, device=pcm.device)
+        have = torch.zeros(frame_count, dtype=torch.int8, device=pcm.device)
+        want = None
+        if want_frames is not None:
+            want = np.ascontiguousarray(want_frames, np.int8)
+        _check(lib.awm_sync_fft_d(self._h, _dev_ptr(pcm), n, ch, index, frame_count, _np(want) if want is not None else None,
+                                  first, last, _dev_ptr(db), _dev_ptr(have)), "awm_sync_fft_d")
+        return db, have
+
+    # SyncFinder::search
+    def sync_search(self, key, pcm, clip_mode=False, max_out=4096):
+        n, ch = _pcm_shape(pcm)
+        idx = np.zeros(max_out, np.uint64)
+        q = np.zeros(max_out, np.float64)
+        bt = np.zeros(max_out, np.int32)
+        cnt = _check(lib.awm_sync_search_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, int(clip_mode), max_out, _np(idx),
+                                           _np(q), _np(bt)), "awm_sync_search_d")
+        return idx[:cnt], q[:cnt], bt[:cnt]
+
+    def search_approx(self, key, pcm, clip_mode=False):
+        n, ch = _pcm_shape(pcm)
+        max_out = 4 * (n // 1024 + 1)
+        idx = np.zeros(max_out, np.uint64)
+        raw = np.zeros(max_out, np.float64)
+        mean = np.zeros(max_out, np.float64)
+        cnt = _check(lib.awm_search_approx_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, int(clip_mode), max_out, _np(idx),
+                                             _np(raw), _np(mean)), "awm_search_approx_d")
+        return idx[:cnt], raw[:cnt], mean[:cnt]
+
+    # fft_range + mix_decode
+    def block_soft_bits(self, key, pcm, indices):
+        n, ch = _pcm_shape(pcm)
+        idx = np.ascontiguousarray(indices, np.uint64)
+        out = np.zeros((len(idx), SOFT_BITS), np.float32)
+        ok = np.zeros(len(idx), np.int32)
+        _check(lib.awm_block_soft_bits_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, _np(idx), len(idx), _np(out), _np(ok)),
+               "awm_block_soft_bits_d")
+        return out, ok
+
+    # conv_decode_soft
+    def viterbi_decode(self, block_type, soft):
+        soft = np.ascontiguousarray(soft, np.float32)
+        if soft.ndim == 1:
+            soft = soft[None, :]
+        n, coded_len = soft.shape
+        rate = 12 if block_type == 2 else 6
+        bits = np.zeros((n, coded_len // rate - 15), np.int32)
+        err = np.zeros(n, np.float32)
+        _check(lib.awm_viterbi_decode(self._h, block_type, _np(soft), coded_len, n, _np(bits), _np(err)), "awm_viterbi_decode")
+        return bits, err
+
+    def _patterns(self, fn, what, *args, max_out=4096):
+        buf = (Pattern * max_out)()
+        cnt = _check(fn(*args, max_out, C.cast(buf, C.c_void_p)), what)
+        return [buf[i].as_dict() for i in range(min(cnt, max_out))]
+
+    # get_watermark on resident PCM (chunk loop, BlockDecoder, ClipDecoder, merge, sort)
+    def get_watermark(self, key, pcm):
+        n, ch = _pcm_shape(pcm)
+        return self._patterns(lib.awm_get_watermark_d, "awm_get_watermark_d", self._h, key_bytes(key), _dev_ptr(pcm), n, ch)
+
+    def decode_chunk(self, key, pcm, first_chunk=True):
+        n, ch = _pcm_shape(pcm)
+        return self._patterns(lib.awm_decode_chunk_d, "awm_decode_chunk_d", self._h, key_bytes(key), _dev_ptr(pcm), n, ch,
+                              int(first_chunk))

@@ -1,0 +1,179 @@
+// awm_fft.hip.h -- wave-level 1024-point real FFT for gfx950 (CDNA4), used by every kernel
+// of the watermark path.  Replaces reference src/fft.cc (FFTW r2c / c2r, N = 1024).
+//
+// Design (one 64-lane wavefront == one frame-channel):
+//   * the 1024 real samples are packed as 512 complex z[n] = x[2n] + i x[2n+1];
+//     lane l holds z[l + 64 j], j = 0..7  -> global loads are fully coalesced
+//     (8 B / 16 B per lane, 512 B / 1 KiB per wave instruction).
+//   * complex FFT-512 = radix-8 x radix-8 x radix-8, each radix-8 entirely in registers;
+//     between the passes the wave transposes through a private 4.5 KiB LDS tile whose
+//     row stride (72 complex) and inner stride (9 complex) make every ds_read_b64 /
+//     ds_write_b64 bank-conflict free (banks: MI355X_MICROARCH.md, LDS table).
+//   * no workgroup barrier anywhere: the tile is private to the wave, ordering is by
+//     wave-scope fences only.
+//   * the real split X[k] = (Z[k] + conj Z[512-k])/2 - i/2 W^k (Z[k] - conj Z[512-k]) is
+//     evaluated only for the bins a kernel needs (81 watermark bands, or all 513).
+//   * inverse (c2r, unnormalised like FFTW) runs the mirrored flow: spectrum in the
+//     transposed lane order, time samples out in natural lane order -> coalesced stores.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace awmk {
+
+constexpr int XROW = 72;              // complex elements per exchange row (64 + 8 pad)
+constexpr int XBUF_ELEMS = 8 * XROW;  // 576 complex = 4608 B per wave
+
+__device__ __forceinline__ void
+wave_sync()
+{
+  // LDS hand-off between lanes of ONE wave: DS ops of a wave execute in order, so only the
+  // compiler has to be kept from reordering across this point.
+  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ float2 cadd (float2 a, float2 b) { return make_float2 (a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub (float2 a, float2 b) { return make_float2 (a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul (float2 a, float2 b) { return make_float2 (a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+// a * conj (b)
+__device__ __forceinline__ float2 cmulc (float2 a, float2 b) { return make_float2 (a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }
+
+template<bool INV> __device__ __forceinline__ void
+radix4 (float2& x0, float2& x1, float2& x2, float2& x3)
+{
+  const float2 t0 = cadd (x0, x2), t1 = csub (x0, x2), t2 = cadd (x1, x3), t3 = csub (x1, x3);
+  // forward: t3 * (-i); inverse: t3 * (+i)
+  const float2 t3r = INV ? make_float2 (-t3.y, t3.x) : make_float2 (t3.y, -t3.x);
+  x0 = cadd (t0, t2);
+  x2 = csub (t0, t2);
+  x1 = cadd (t1, t3r);
+  x3 = csub (t1, t3r);
+}
+
+// in-place 8-point DFT, natural order in and out: a[k] <- sum_j a[j] e^{-+ 2 pi i j k / 8}
+template<bool INV> __device__ __forceinline__ void
+radix8 (float2 (&a)[8])
+{
+  radix4<INV> (a[0], a[2], a[4], a[6]);   // even samples -> F0[0..3] in a0,a2,a4,a6
+  radix4<INV> (a[1], a[3], a[5], a[7]);   // odd samples  -> F1[0..3] in a1,a3,a5,a7
+  constexpr float r = 0.70710678118654752440f;
+  float2 f1 = a[3], f2 = a[5], f3 = a[7];
+  if (INV)
+    {
+      f1 = make_float2 ((f1.x - f1.y) * r, (f1.x + f1.y) * r);      // * (1 + i) / sqrt 2
+      f2 = make_float2 (-f2.y, f2.x);                               // * i
+      f3 = make_float2 ((-f3.x - f3.y) * r, (f3.x - f3.y) * r);     // * (-1 + i) / sqrt 2
+    }
+  else
+    {
+      f1 = make_float2 ((f1.x + f1.y) * r, (f1.y - f1.x) * r);      // * (1 - i) / sqrt 2
+      f2 = make_float2 (f2.y, -f2.x);                               // * -i
+      f3 = make_float2 ((f3.y - f3.x) * r, (-f3.x - f3.y) * r);     // * (-1 - i) / sqrt 2
+    }
+  const float2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6], o0 = a[1];
+  a[0] = cadd (e0, o0); a[4] = csub (e0, o0);
+  a[1] = cadd (e1, f1); a[5] = csub (e1, f1);
+  a[2] = cadd (e2, f2); a[6] = csub (e2, f2);
+  a[3] = cadd (e3, f3); a[7] = csub (e3, f3);
+}
+
+// Forward complex FFT-512 of one wave.
+//   in : z[j]  = element (lane + 64 j)
+//   out: z[kc] = Z[64 kc + 8 (lane & 7) + (lane >> 3)]
+// tw512[k] = e^{-2 pi i k / 512} (LDS or global, 512 entries); xbuf: wave-private LDS tile.
+__device__ __forceinline__ void
+fft512_forward (float2 (&z)[8], float2 *xbuf, const float2 *tw512, int lane)
+{
+  radix8<false> (z);
+#pragma unroll
+  for (int kb = 1; kb < 8; kb++)
+    z[kb] = cmul (z[kb], tw512[lane * kb]);
+#pragma unroll
+  for (int kb = 0; kb < 8; kb++)
+    xbuf[kb * XROW + lane] = z[kb];
+  wave_sync();
+  const int lo = lane & 7, hi = lane >> 3;
+#pragma unroll
+  for (int nd = 0; nd < 8; nd++)
+    z[nd] = xbuf[hi * XROW + nd * 8 + lo];
+  wave_sync();
+  radix8<false> (z);
+#pragma unroll
+  for (int kd = 1; kd < 8; kd++)
+    z[kd] = cmul (z[kd], tw512[8 * lo * kd]);
+#pragma unroll
+  for (int kd = 0; kd < 8; kd++)
+    xbuf[hi * XROW + 9 * kd + lo] = z[kd];
+  wave_sync();
+#pragma unroll
+  for (int nc = 0; nc < 8; nc++)
+    z[nc] = xbuf[hi * XROW + 9 * lo + nc];
+  wave_sync();
+  radix8<false> (z);
+}
+
+// Inverse (exponent +, unnormalised) complex FFT-512 of one wave.
+//   in : z[kc] = Zd[64 kc + 8 (lane & 7) + (lane >> 3)]
+//   out: z[j]  = time element (lane + 64 j)
+__device__ __forceinline__ void
+fft512_inverse (float2 (&z)[8], float2 *xbuf, const float2 *tw512, int lane)
+{
+  const int lo = lane & 7, hi = lane >> 3;
+  radix8<true> (z);
+#pragma unroll
+  for (int nc = 1; nc < 8; nc++)
+    z[nc] = cmulc (z[nc], tw512[8 * nc * lo]);
+#pragma unroll
+  for (int nc = 0; nc < 8; nc++)
+    xbuf[hi * XROW + 9 * lo + nc] = z[nc];
+  wave_sync();
+#pragma unroll
+  for (int kd = 0; kd < 8; kd++)
+    z[kd] = xbuf[hi * XROW + 9 * kd + lo];
+  wave_sync();
+  radix8<true> (z);
+#pragma unroll
+  for (int nd = 0; nd < 8; nd++)
+    z[nd] = cmulc (z[nd], tw512[(lo + 8 * nd) * hi]);
+#pragma unroll
+  for (int nd = 0; nd < 8; nd++)
+    xbuf[hi * XROW + nd * 8 + lo] = z[nd];
+  wave_sync();
+#pragma unroll
+  for (int kb = 0; kb < 8; kb++)
+    z[kb] = xbuf[kb * XROW + lane];
+  wave_sync();
+  radix8<true> (z);
+}
+
+// position of complex bin k (0..511) in the [kc][lane] layout produced by fft512_forward
+// and consumed by fft512_inverse
+__device__ __forceinline__ int
+zpos (int k)
+{
+  return (k >> 6) * 64 + ((k >> 3) & 7) + 8 * (k & 7);
+}
+
+// real split for one bin: X[k] from Z[k], Z[512-k] and W = e^{-2 pi i k / 1024}
+__device__ __forceinline__ float2
+real_split (float2 zk, float2 zm, float2 w)
+{
+  const float2 a = make_float2 (zk.x + zm.x, zk.y - zm.y);     // Z[k] + conj Z[512-k]
+  const float2 b = make_float2 (zk.x - zm.x, zk.y + zm.y);     // Z[k] - conj Z[512-k]
+  const float2 t = cmul (w, b);
+  return make_float2 (0.5f * (a.x + t.y), 0.5f * (a.y - t.x));
+}
+
+// db_from_complex (reference wmcommon.hh:204-224): float arithmetic, products and sum rounded
+// separately (the reference is built without FMA contraction), -96 only for an exact zero
+__device__ __forceinline__ float
+db_from_complex (float2 v)
+{
+  const float abs2 = __fadd_rn (__fmul_rn (v.x, v.x), __fmul_rn (v.y, v.y));
+  if (abs2 > 0)
+    return __fmul_rn (log2f (abs2), 3.01029995663981f);
+  return -96.f;
+}
+
+} // namespace awmk

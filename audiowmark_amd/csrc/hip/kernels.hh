@@ -1,0 +1,136 @@
+// kernels.hh -- host-callable launchers of the gfx950 kernels (kernels.hip, viterbi.hip).
+// Everything here works on device pointers and enqueues on the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include <cstdint>
+
+namespace awmk {
+
+// constant tables resident in HBM for the lifetime of a context
+struct DevTables
+{
+  const float2 *tw512;    // e^{-2 pi i k / 512},  k < 512
+  const float2 *tw1024;   // e^{-2 pi i k / 1024}, k <= 512
+  const float  *window;   // normalised von Hann analysis window, 1024 (reference wmcommon.cc:68-89)
+  const float  *synth;    // synthesis window, 3072 (reference wmadd.cc:177-206)
+};
+
+/* K1: FFTAnalyzer::run_fft / fft_range */
+hipError_t launch_stft_full (hipStream_t st, const DevTables& t, const float *pcm, int n_channels,
+                             long long start_index, long long hop, long long frame_count, float2 *out);
+
+/* K2: fused STFT -> band edit -> inverse -> overlap-add -> mix (+ per-limiter-block maxima) */
+struct AddMixArgs
+{
+  const float *pcm_in;
+  float       *out;
+  long long    n_frames;          // samples per channel in this span
+  int          n_channels;
+  const int8_t *frame_mod;        // device, [4452][81]
+  float        neg_delta_up;      // (float) (-water_delta * +1)
+  float        neg_delta_down;    // (float) (-water_delta * -1)
+  long long    first_frame;       // global frame index of local frame 0
+  const float *halo_before;       // 1024*C samples or nullptr
+  const float *halo_after;        // 1024*C samples or nullptr
+  unsigned int *block_max;        // float bits, or nullptr
+  long long    first_block;
+  long long    n_blocks;
+  int          limiter_block;     // samples per limiter block (44100)
+  int          frames_per_span;   // frames each wave streams through
+};
+hipError_t launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a);
+
+/* K3: limiter ramp, in place */
+hipError_t launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels, long long first_sample,
+                           const float *block_max, long long first_block, long long n_blocks,
+                           int limiter_block, float ceiling);
+hipError_t launch_fill_u32 (hipStream_t st, unsigned int *p, unsigned int v, size_t n);
+
+/* K4: STFT -> dB of the 81 bands, written band-major ("transposed") so that scans over the
+ * frame axis are coalesced.  Stream s (0 <= s < n_streams) consists of count(s) frames starting
+ * at base(s) + f * hop.  out[s * out_stream_stride + (plane * 81 + band) * ld + f]. */
+struct SyncDbArgs
+{
+  const float *pcm;
+  long long    n_frames;          // samples per channel available (bounds)
+  int          n_channels;
+  int          per_channel;       // 0: channels summed into one plane; 1: one plane per channel
+  long long    base0, base_stride;      // base(s) = base0 + s * base_stride     (if stream_base == nullptr)
+  const long long *stream_base;         // device array [n_streams] or nullptr
+  int          count0;                  // count(s) = count0                      (if stream_count == nullptr)
+  const int   *stream_count;            // device array [n_streams] or nullptr
+  long long    n_streams;
+  long long    hop;
+  float       *out;
+  long long    out_stream_stride;
+  long long    ld;
+  char        *have;                    // have[s * have_stream_stride + f] or nullptr
+  long long    have_stream_stride;
+  long long    first, last;             // non-silent value range [first, last) (syncfinder.cc:155-169)
+  int          tile_frames;             // frames per workgroup tile (<= 72)
+};
+hipError_t launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a);
+
+/* K5: sync_decode (syncfinder.cc:116-153) for many candidates.
+ * value(cand, row, band) = db[plane(cand) + row * row_stride + band * band_stride + lane(cand)],
+ * have(cand, row)        = have[hplane(cand) + row * have_row_stride + lane(cand)]
+ * where cand = group * 64 + lane-in-wave, plane(cand) = group_plane[...] see kernels.hip. */
+struct SyncTableDev
+{
+  // [6][rows][64] int32: [0..29] up bands, [30..59] down bands (band - 20), [60] row index
+  // (frame for the approximate search, want-list position for the refinement); wave-uniform -> scalar loads
+  const int *packed;
+  int        rows_per_bit;
+};
+struct SyncScanArgs
+{
+  const float *db;
+  const char  *have;            // nullptr: every frame present
+  long long    plane_stride;    // between blockIdx.y planes (shifts / candidates)
+  long long    have_plane_stride;
+  long long    row_stride, band_stride, have_row_stride;
+  long long    n_lanes;         // candidates per plane (start frames, or fine offsets)
+  const int   *lane_count;      // optional per-plane valid lane count (refine), else n_lanes
+  long long    n_planes;
+  double       min_delta;       // min (water_delta, 0.080), reference syncfinder.cc:80-92
+  double      *quality;         // [plane][q_stride]
+  long long    q_stride;
+  SyncTableDev table;
+};
+hipError_t launch_sync_scan (hipStream_t st, const SyncScanArgs& a);
+
+/* K5b: local mean over the index-sorted scores (syncfinder.cc:234-254); q is [4][q_stride] by shift,
+ * sorted position p = 4 * start_frame + shift.  Writes raw[p], mean[p]. */
+hipError_t launch_local_mean (hipStream_t st, const double *q, long long q_stride, long long n_start_frames,
+                              double *raw_sorted, double *local_mean);
+
+/* K7: mix_decode (wmget.cc:67-108): db is [n_blocks][C][81][ld] (band-major), out [n_blocks][858] */
+struct SoftBitsArgs
+{
+  const float   *db;
+  long long      block_stride, ld;
+  int            n_channels;
+  const int16_t *mix_frame;     // [n_entries]
+  const uint8_t *mix_up, *mix_down;
+  int            n_data_frames; // 1716
+  int            frames_per_bit;
+  int            block_frames;  // 2226
+  long long      n_blocks;
+  float         *out;
+};
+hipError_t launch_soft_bits (hipStream_t st, const SoftBitsArgs& a);
+
+/* K8: soft Viterbi (convcode.cc:128-213), one workgroup per coded block */
+hipError_t launch_viterbi (hipStream_t st, const float *soft, int rate, const unsigned *generators /* host */,
+                           long long coded_len, long long n_blocks, unsigned char *decisions_ws,
+                           int *bits_out, float *error_out);
+size_t viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks);
+
+} // namespace awmk
+
+namespace awmk {
+/* first / one-past-last non-zero value of an interleaved buffer (SyncFinder::scan_silence,
+ * reference syncfinder.cc:155-169); result[0] = first (n_values if all zero), result[1] = last */
+hipError_t launch_nonzero_range (hipStream_t st, const float *data, long long n_values, unsigned long long *result);
+}

@@ -1,0 +1,913 @@
+// kernels.hip -- hand-written gfx950 kernels of the audiowmark spectral path.
+//
+//   K1 stft_full_kernel    FFTAnalyzer::run_fft / fft_range        (reference wmcommon.cc:91-141)
+//   K2 add_mix_kernel      run_fft + apply_frame_mod + c2r + 3-frame windowed overlap-add + mix
+//                          + per-second max|x|                     (reference wmadd.cc:61-84,215-250,297-317,564-565; limiter.cc:90-97)
+//   K3 limiter_kernel      Limiter::process_block ramp             (reference limiter.cc:99-124)
+//   K4 sync_db_kernel      SyncFinder::sync_fft (STFT -> dB, 81 bands) (reference syncfinder.cc:560-605)
+//   K5 sync_scan_kernel    SyncFinder::sync_decode + bit_quality   (reference syncfinder.cc:80-153)
+//   K5b local_mean_kernel  local mean of search_approx             (reference syncfinder.cc:234-254)
+//   K7 soft_bits_kernel    mix_decode                              (reference wmget.cc:67-108)
+//
+// All FFT work is "one wavefront per frame-channel" (awm_fft.hip.h); workgroups are 4 independent
+// waves that only share read-only LDS tables, so there is no barrier in any steady-state loop.
+// Arithmetic whose rounding is visible in decisions downstream (dB conversion, the sequential
+// float/double accumulations of sync_decode / mix_decode, the overlap-add and limiter expressions)
+// follows the reference's operation order with explicit __fmul_rn/__fadd_rn (the reference is
+// compiled for baseline x86-64: no FMA contraction).
+#include "kernels.hh"
+#include "awm_fft.hip.h"
+
+namespace awmk {
+
+constexpr int NB = 81;          // watermark bands: bins 20..100
+constexpr int MIN_BAND = 20;
+constexpr int WAVES = 4;        // waves per workgroup
+
+__device__ __forceinline__ void
+load_shared_tables (const DevTables& t, float2 *s_tw, float *s_win, float2 *s_twb)
+{
+  for (int i = threadIdx.x; i < 512; i += blockDim.x)
+    s_tw[i] = t.tw512[i];
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x)
+    s_win[i] = t.window[i];
+  if (s_twb)
+    for (int i = threadIdx.x; i < NB; i += blockDim.x)
+      s_twb[i] = t.tw1024[MIN_BAND + i];
+}
+
+/* ------------------------------------------------------------------------------------------
+ * sample fetch: lane owns x[2 (lane + 64 j)] and x[2 (lane + 64 j) + 1], j = 0..7
+ * ------------------------------------------------------------------------------------------ */
+
+// stereo, `idx` = first sample (per channel) of the frame; avail = valid samples from idx (<= 1024)
+__device__ __forceinline__ void
+fetch_stereo (const float *pcm, long long idx, int avail, int lane, float (&l)[16], float (&r)[16])
+{
+  const float *p = pcm + idx * 2;
+  if (avail >= 1024 && ((reinterpret_cast<uintptr_t> (p) & 15) == 0))
+    {
+      const float4 *p4 = reinterpret_cast<const float4 *> (p);
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        {
+          const float4 v = p4[lane + 64 * j];
+          l[2 * j] = v.x; r[2 * j] = v.y; l[2 * j + 1] = v.z; r[2 * j + 1] = v.w;
+        }
+    }
+  else if (avail >= 1024)
+    {
+      const float2 *p2 = reinterpret_cast<const float2 *> (p);
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        {
+          const float2 a = p2[2 * (lane + 64 * j)], b = p2[2 * (lane + 64 * j) + 1];
+          l[2 * j] = a.x; r[2 * j] = a.y; l[2 * j + 1] = b.x; r[2 * j + 1] = b.y;
+        }
+    }
+  else
+    {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        {
+          const int x = 2 * (lane + 64 * j);
+          l[2 * j]     = x < avail     ? p[2 * x]     : 0.f;
+          r[2 * j]     = x < avail     ? p[2 * x + 1] : 0.f;
+          l[2 * j + 1] = x + 1 < avail ? p[2 * x + 2] : 0.f;
+          r[2 * j + 1] = x + 1 < avail ? p[2 * x + 3] : 0.f;
+        }
+    }
+}
+
+// one channel `ch` of a C-channel interleaved stream
+__device__ __forceinline__ void
+fetch_channel (const float *pcm, long long idx, int avail, int C, int ch, int lane, float (&v)[16])
+{
+  const float *p = pcm + idx * C + ch;
+  if (C == 1 && avail >= 1024 && ((reinterpret_cast<uintptr_t> (p) & 7) == 0))
+    {
+      const float2 *p2 = reinterpret_cast<const float2 *> (p);
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        {
+          const float2 a = p2[lane + 64 * j];
+          v[2 * j] = a.x; v[2 * j + 1] = a.y;
+        }
+    }
+  else
+    {
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        {
+          const int x = 2 * (lane + 64 * j);
+          v[2 * j]     = x < avail     ? p[(long long) x * C]       : 0.f;
+          v[2 * j + 1] = x + 1 < avail ? p[(long long) (x + 1) * C] : 0.f;
+        }
+    }
+}
+
+// window + pack: frame[x] = sample * window[x] (float multiply, reference wmcommon.cc:106-110)
+__device__ __forceinline__ void
+window_pack (const float (&v)[16], const float *s_win, int lane, float2 (&z)[8])
+{
+  const float2 *w2 = reinterpret_cast<const float2 *> (s_win);
+#pragma unroll
+  for (int j = 0; j < 8; j++)
+    {
+      const float2 w = w2[lane + 64 * j];
+      z[j] = make_float2 (__fmul_rn (v[2 * j], w.x), __fmul_rn (v[2 * j + 1], w.y));
+    }
+}
+
+/* ==========================================================================================
+ * K1: full 513-bin STFT
+ * ========================================================================================== */
+__global__ void __launch_bounds__ (64 * WAVES)
+stft_full_kernel (DevTables t, const float *pcm, int C, long long start_index, long long hop, long long frame_count, float2 *out)
+{
+  __shared__ float2 s_tw[512];
+  __shared__ float  s_win[1024];
+  __shared__ float2 s_x[WAVES][XBUF_ELEMS];
+  load_shared_tables (t, s_tw, s_win, nullptr);
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long item = (long long) blockIdx.x * WAVES + wave;
+  if (item >= frame_count * C)
+    return;
+  const long long f = item / C;
+  const int ch = int (item % C);
+  float2 *xbuf = s_x[wave];
+
+  float v[16];
+  fetch_channel (pcm, start_index + f * hop, 1024, C, ch, lane, v);
+  float2 z[8];
+  window_pack (v, s_win, lane, z);
+  fft512_forward (z, xbuf, s_tw, lane);
+#pragma unroll
+  for (int kc = 0; kc < 8; kc++)
+    xbuf[kc * 64 + lane] = z[kc];
+  wave_sync();
+  float2 *o = out + item * 513;
+  for (int k = lane; k <= 512; k += 64)
+    {
+      const float2 zk = xbuf[zpos (k & 511)], zm = xbuf[zpos ((512 - k) & 511)];
+      o[k] = real_split (zk, zm, t.tw1024[k]);
+    }
+}
+
+hipError_t
+launch_stft_full (hipStream_t st, const DevTables& t, const float *pcm, int n_channels,
+                  long long start_index, long long hop, long long frame_count, float2 *out)
+{
+  const long long items = frame_count * n_channels;
+  if (items <= 0)
+    return hipSuccess;
+  const unsigned grid = unsigned ((items + WAVES - 1) / WAVES);
+  hipLaunchKernelGGL (stft_full_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, pcm, n_channels, start_index, hop, frame_count, out);
+  return hipGetLastError();
+}
+
+/* ==========================================================================================
+ * K2: fused add
+ * ========================================================================================== */
+
+__device__ __forceinline__ int
+zdpos (int k)
+{
+  const int kc = k >> 6;                      // 0, 1, 6, 7 for the watermark bands and their mirrors
+  return (kc < 2 ? kc : kc - 4) * 64 + ((k >> 3) & 7) + 8 * (k & 7);
+}
+
+// one frame-channel: windowed samples -> delta signal d (time domain, unnormalised c2r like FFTW)
+__device__ __forceinline__ void
+frame_delta (float2 (&z)[8], const int8_t *mod_row, float nd_up, float nd_down,
+             float2 *xbuf, float2 *zd, const float2 *s_tw, const float2 *s_twb, int lane)
+{
+  fft512_forward (z, xbuf, s_tw, lane);
+  xbuf[0 * 64 + lane] = z[0];
+  xbuf[1 * 64 + lane] = z[1];
+  xbuf[6 * 64 + lane] = z[6];
+  xbuf[7 * 64 + lane] = z[7];
+  wave_sync();
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++)
+    {
+      const int k = MIN_BAND + lane + 64 * pass;
+      if (k <= 100)
+        {
+          const float2 w = s_twb[k - MIN_BAND];
+          const float2 X = real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], w);
+          const int mod = mod_row[k - MIN_BAND];
+          float2 D = make_float2 (0.f, 0.f);
+          if (mod)
+            {
+              // apply_frame_mod (reference wmadd.cc:61-84)
+              const float mag = hypotf (X.x, X.y);
+              if (mag > 1e-7f)
+                {
+                  const float s = powf (mag, mod == 1 ? nd_up : nd_down) - 1.0f;
+                  D = make_float2 (X.x * s, X.y * s);
+                }
+            }
+          // half-length spectrum of the c2r transform: Zd[k] = D + i D conj(W^k), Zd[512-k] = conj(D) + i conj(D conj(W^k))
+          const float2 O = cmulc (D, w);
+          zd[zdpos (k)]       = make_float2 (D.x - O.y, D.y + O.x);
+          zd[zdpos (512 - k)] = make_float2 (D.x + O.y, O.x - D.y);
+        }
+    }
+  wave_sync();
+  const float2 zero = make_float2 (0.f, 0.f);
+  z[0] = zd[0 * 64 + lane];
+  z[1] = zd[1 * 64 + lane];
+  z[2] = zero; z[3] = zero; z[4] = zero; z[5] = zero;
+  z[6] = zd[2 * 64 + lane];
+  z[7] = zd[3 * 64 + lane];
+  wave_sync();
+  fft512_inverse (z, xbuf, s_tw, lane);
+}
+
+__device__ __forceinline__ float
+wave_max (float v)
+{
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    v = fmaxf (v, __shfl_xor (v, off));
+  return v;
+}
+
+template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
+add_mix_kernel (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
+{
+  __shared__ float2 s_tw[512];
+  __shared__ float  s_win[1024];
+  __shared__ float2 s_twb[NB];
+  __shared__ float2 s_x[WAVES][XBUF_ELEMS];
+  __shared__ float2 s_zd[WAVES][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_shared_tables (t, s_tw, s_win, s_twb);
+  for (int i = lane; i < 256; i += 64)
+    s_zd[wave][i] = make_float2 (0.f, 0.f);
+  __syncthreads();
+
+  const int C = a.n_channels;
+  const int n_cg = CV == 2 ? 1 : C;
+  const long long F = (a.n_frames + 1023) / 1024;
+  const int L = a.frames_per_span;
+  const long long n_spans = (F + L - 1) / L;
+  const long long item = (long long) blockIdx.x * WAVES + wave;
+  if (item >= n_spans * n_cg)
+    return;
+  const long long span = item / n_cg;
+  const int ch0 = int (item % n_cg);
+  const long long s = span * L, e = (s + L < F) ? s + L : F;
+  float2 *xbuf = s_x[wave], *zd = s_zd[wave];
+
+  // synthesis window pieces this lane needs (reference wmadd.cc:177-206): head = samples 2 lane, 2 lane + 1
+  // of a frame (slots W1, W2); tail = samples 896 + 2 lane (+1) (slots W1, W0).  In between W1 == 1, W0 == W2 == 0.
+  const float2 w1_head = reinterpret_cast<const float2 *> (t.synth + 1024)[lane];
+  const float2 w2_head = reinterpret_cast<const float2 *> (t.synth + 2048)[lane];
+  const float2 w1_tail = reinterpret_cast<const float2 *> (t.synth + 1024 + 896)[lane];
+  const float2 w0_tail = reinterpret_cast<const float2 *> (t.synth + 896)[lane];
+
+  float head2[CV][2], tail_s1[CV][2], tail_in[CV][2];
+#pragma unroll
+  for (int c = 0; c < CV; c++)
+    head2[c][0] = head2[c][1] = tail_s1[c][0] = tail_s1[c][1] = tail_in[c][0] = tail_in[c][1] = 0.f;
+
+  const int BS = a.limiter_block;
+  const long long total_rows = 2LL * block_frames;
+
+  for (long long m = s - 1; m <= e; m++)
+    {
+      const float *src;
+      int avail;
+      if (m < 0)
+        {
+          src = a.halo_before;
+          avail = src ? 1024 : 0;
+        }
+      else if (m >= F)
+        {
+          src = a.halo_after;
+          avail = src ? 1024 : 0;
+        }
+      else
+        {
+          src = a.pcm_in + m * 1024 * C;
+          const long long left = a.n_frames - m * 1024;
+          avail = left < 1024 ? int (left) : 1024;
+        }
+      float in[CV][16];
+      float2 d[CV][8];
+      if (avail > 0)
+        {
+          if constexpr (CV == 2)
+            fetch_stereo (src, 0, avail, lane, in[0], in[1]);
+          else
+            fetch_channel (src, 0, avail, C, ch0, lane, in[0]);
+          const long long g = a.first_frame + m;                       // frame index in the whole stream
+          const long long row = (frame_number0 + g) % total_rows;      // reference wmadd.cc:326-344
+          const int8_t *mod_row = a.frame_mod + row * NB;
+#pragma unroll
+          for (int c = 0; c < CV; c++)
+            {
+              window_pack (in[c], s_win, lane, d[c]);
+              frame_delta (d[c], mod_row, a.neg_delta_up, a.neg_delta_down, xbuf, zd, s_tw, s_twb, lane);
+            }
+        }
+      else
+        {
+#pragma unroll
+          for (int c = 0; c < CV; c++)
+            {
+#pragma unroll
+              for (int j = 0; j < 16; j++)
+                in[c][j] = 0.f;
+#pragma unroll
+              for (int j = 0; j < 8; j++)
+                d[c][j] = make_float2 (0.f, 0.f);
+            }
+        }
+
+      const bool own = m >= s && m < e;
+      const bool own_prev = m - 1 >= s && m - 1 < e;
+      float max0 = 0.f, max1 = 0.f, pmax0 = 0.f, pmax1 = 0.f;
+      // limiter blocks touched by frame m / m - 1: offset inside the frame where the next block begins
+      const long long gs_m = (a.first_frame + m) * 1024;
+      const long long b0 = gs_m >= 0 ? gs_m / BS : 0;
+      const long long bound = (b0 + 1) * BS - gs_m;
+      const long long gs_p = gs_m - 1024;
+      const long long pb0 = gs_p >= 0 ? gs_p / BS : 0;
+      const long long pbound = (pb0 + 1) * BS - gs_p;
+
+      // output frame m = d[m-1] W2 + d[m] W1 + d[m+1] W0 + in[m]   (reference wmadd.cc:228-238, 564-565)
+      float o[CV][16];
+#pragma unroll
+      for (int c = 0; c < CV; c++)
+        {
+          // j = 0: head region, W1/W2 ramps
+          const float s1x = __fadd_rn (head2[c][0], __fmul_rn (d[c][0].x, w1_head.x));
+          const float s1y = __fadd_rn (head2[c][1], __fmul_rn (d[c][0].y, w1_head.y));
+          o[c][0] = __fadd_rn (s1x, in[c][0]);
+          o[c][1] = __fadd_rn (s1y, in[c][1]);
+          head2[c][0] = __fmul_rn (d[c][0].x, w2_head.x);
+          head2[c][1] = __fmul_rn (d[c][0].y, w2_head.y);
+#pragma unroll
+          for (int j = 1; j < 7; j++)
+            {
+              o[c][2 * j]     = __fadd_rn (d[c][j].x, in[c][2 * j]);
+              o[c][2 * j + 1] = __fadd_rn (d[c][j].y, in[c][2 * j + 1]);
+            }
+          // j = 7 of the PREVIOUS frame gets its W0 contribution now
+          o[c][14] = __fadd_rn (__fadd_rn (tail_s1[c][0], __fmul_rn (d[c][7].x, w0_tail.x)), tail_in[c][0]);
+          o[c][15] = __fadd_rn (__fadd_rn (tail_s1[c][1], __fmul_rn (d[c][7].y, w0_tail.y)), tail_in[c][1]);
+          tail_s1[c][0] = __fmul_rn (d[c][7].x, w1_tail.x);
+          tail_s1[c][1] = __fmul_rn (d[c][7].y, w1_tail.y);
+          tail_in[c][0] = in[c][14];
+          tail_in[c][1] = in[c][15];
+        }
+
+      // stores (bounded by the span's sample count) + maxima
+      if (own)
+        {
+          const long long base = m * 1024;
+#pragma unroll
+          for (int j = 0; j < 7; j++)
+            {
+              const int x = 2 * (lane + 64 * j);
+              const long long ls = base + x;
+              if (CV == 2)
+                {
+                  float *p = a.out + ls * 2;
+                  if (ls + 1 < a.n_frames)
+                    *reinterpret_cast<float4 *> (p) = make_float4 (o[0][2 * j], o[CV - 1][2 * j], o[0][2 * j + 1], o[CV - 1][2 * j + 1]);
+                  else if (ls < a.n_frames)
+                    *reinterpret_cast<float2 *> (p) = make_float2 (o[0][2 * j], o[CV - 1][2 * j]);
+                }
+              else
+                {
+                  float *p = a.out + ls * C + ch0;
+                  if (ls < a.n_frames)
+                    p[0] = o[0][2 * j];
+                  if (ls + 1 < a.n_frames)
+                    p[C] = o[0][2 * j + 1];
+                }
+#pragma unroll
+              for (int c = 0; c < CV; c++)
+                {
+                  const float v0 = ls < a.n_frames ? fabsf (o[c][2 * j]) : 0.f;
+                  const float v1 = ls + 1 < a.n_frames ? fabsf (o[c][2 * j + 1]) : 0.f;
+                  if (x < bound) max0 = fmaxf (max0, v0); else max1 = fmaxf (max1, v0);
+                  if (x + 1 < bound) max0 = fmaxf (max0, v1); else max1 = fmaxf (max1, v1);
+                }
+            }
+        }
+      if (own_prev)
+        {
+          const int x = 896 + 2 * lane;
+          const long long ls = (m - 1) * 1024 + x;
+          if (CV == 2)
+            {
+              float *p = a.out + ls * 2;
+              if (ls + 1 < a.n_frames)
+                *reinterpret_cast<float4 *> (p) = make_float4 (o[0][14], o[CV - 1][14], o[0][15], o[CV - 1][15]);
+              else if (ls < a.n_frames)
+                *reinterpret_cast<float2 *> (p) = make_float2 (o[0][14], o[CV - 1][14]);
+            }
+          else
+            {
+              float *p = a.out + ls * C + ch0;
+              if (ls < a.n_frames)
+                p[0] = o[0][14];
+              if (ls + 1 < a.n_frames)
+                p[C] = o[0][15];
+            }
+#pragma unroll
+          for (int c = 0; c < CV; c++)
+            {
+              const float v0 = ls < a.n_frames ? fabsf (o[c][14]) : 0.f;
+              const float v1 = ls + 1 < a.n_frames ? fabsf (o[c][15]) : 0.f;
+              if (x < pbound) pmax0 = fmaxf (pmax0, v0); else pmax1 = fmaxf (pmax1, v0);
+              if (x + 1 < pbound) pmax0 = fmaxf (pmax0, v1); else pmax1 = fmaxf (pmax1, v1);
+            }
+        }
+      if (a.block_max)
+        {
+          // Limiter::block_max (reference limiter.cc:90-97): max |x| per limiter block; non-negative
+          // floats order like their bit patterns, so an integer atomic max does it
+          if (own)
+            {
+              max0 = wave_max (max0);
+              max1 = wave_max (max1);
+              if (lane == 0)
+                {
+                  const long long i0 = b0 - a.first_block, i1 = i0 + 1;
+                  if (i0 >= 0 && i0 < a.n_blocks && max0 > 0.f) atomicMax (a.block_max + i0, __float_as_uint (max0));
+                  if (i1 >= 0 && i1 < a.n_blocks && max1 > 0.f) atomicMax (a.block_max + i1, __float_as_uint (max1));
+                }
+            }
+          if (own_prev)
+            {
+              pmax0 = wave_max (pmax0);
+              pmax1 = wave_max (pmax1);
+              if (lane == 0)
+                {
+                  const long long i0 = pb0 - a.first_block, i1 = i0 + 1;
+                  if (i0 >= 0 && i0 < a.n_blocks && pmax0 > 0.f) atomicMax (a.block_max + i0, __float_as_uint (pmax0));
+                  if (i1 >= 0 && i1 < a.n_blocks && pmax1 > 0.f) atomicMax (a.block_max + i1, __float_as_uint (pmax1));
+                }
+            }
+        }
+    }
+}
+
+hipError_t
+launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
+{
+  if (a.n_frames <= 0)
+    return hipSuccess;
+  const long long F = (a.n_frames + 1023) / 1024;
+  const long long n_spans = (F + a.frames_per_span - 1) / a.frames_per_span;
+  const bool stereo = a.n_channels == 2;
+  const long long items = n_spans * (stereo ? 1 : a.n_channels);
+  const unsigned grid = unsigned ((items + WAVES - 1) / WAVES);
+  const int block_frames = 2226;   // TODO(params): derive from payload size / frames_per_bit
+  const long long frame_number0 = 2LL * block_frames - 250;          // reference wmadd.cc:293-294
+  if (stereo)
+    hipLaunchKernelGGL (add_mix_kernel<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
+  else
+    hipLaunchKernelGGL (add_mix_kernel<1>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
+  return hipGetLastError();
+}
+
+/* ==========================================================================================
+ * K3: limiter ramp (reference limiter.cc:99-124)
+ * ========================================================================================== */
+__global__ void __launch_bounds__ (256)
+limiter_kernel (float *data, long long n_frames, int C, long long first_sample, const float *block_max,
+                long long first_block, long long n_blocks, int BS, float ceiling)
+{
+  const long long n_values = n_frames * C;
+  const long long stride = (long long) gridDim.x * blockDim.x;
+  for (long long v = (long long) blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += stride)
+    {
+      const long long gs = first_sample + v / C;
+      const long long b = gs / BS;
+      const int i = int (gs - b * BS);
+      auto M = [&] (long long bb) -> float {
+        const long long k = bb - first_block;
+        if (bb < 0 || k < 0 || k >= n_blocks)
+          return ceiling;                       // block_max_last starts at the ceiling; blocks past the end are silent
+        return fmaxf (block_max[k], ceiling);
+      };
+      const float m_last = M (b - 1), m_cur = M (b), m_next = M (b + 1);
+      const float scale_start = __fdiv_rn (ceiling, fmaxf (m_last, m_cur));
+      const float scale_end   = __fdiv_rn (ceiling, fmaxf (m_cur, m_next));
+      const float scale_step  = __fdiv_rn (__fsub_rn (scale_end, scale_start), float (BS));
+      const float scale = __fadd_rn (scale_start, __fmul_rn (float (i), scale_step));
+      data[v] = __fmul_rn (data[v], scale);
+    }
+}
+
+hipError_t
+launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels, long long first_sample,
+                const float *block_max, long long first_block, long long n_blocks, int limiter_block, float ceiling)
+{
+  const long long n_values = n_frames * n_channels;
+  if (n_values <= 0)
+    return hipSuccess;
+  long long blocks = (n_values + 255) / 256;
+  if (blocks > 256 * 32)
+    blocks = 256 * 32;
+  hipLaunchKernelGGL (limiter_kernel, dim3 (unsigned (blocks)), dim3 (256), 0, st, data, n_frames, n_channels, first_sample,
+                      block_max, first_block, n_blocks, limiter_block, ceiling);
+  return hipGetLastError();
+}
+
+__global__ void
+fill_u32_kernel (unsigned int *p, unsigned int v, size_t n)
+{
+  const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    p[i] = v;
+}
+hipError_t
+launch_fill_u32 (hipStream_t st, unsigned int *p, unsigned int v, size_t n)
+{
+  if (!n)
+    return hipSuccess;
+  hipLaunchKernelGGL (fill_u32_kernel, dim3 (unsigned ((n + 255) / 256)), dim3 (256), 0, st, p, v, n);
+  return hipGetLastError();
+}
+
+/* ==========================================================================================
+ * K4: STFT -> dB of 81 bands, band-major output tiles
+ * ========================================================================================== */
+constexpr int TILE_MAX = 72;
+constexpr int TILE_LD = TILE_MAX + 1;
+
+template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
+sync_db_kernel (DevTables t, SyncDbArgs a)
+{
+  __shared__ float2 s_tw[512];
+  __shared__ float  s_win[1024];
+  __shared__ float2 s_twb[NB];
+  __shared__ float2 s_x[WAVES][XBUF_ELEMS];
+  __shared__ float  s_tile[NB * TILE_LD];
+  __shared__ char   s_have[TILE_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  load_shared_tables (t, s_tw, s_win, s_twb);
+  __syncthreads();
+
+  const long long stream = blockIdx.y;
+  const int plane_ch = blockIdx.z;                       // only used in per-channel mode
+  const long long base = a.stream_base ? a.stream_base[stream] : a.base0 + stream * a.base_stride;
+  const int count = a.stream_count ? a.stream_count[stream] : a.count0;
+  const int TF = a.tile_frames;
+  const long long tile0 = (long long) blockIdx.x * TF;
+  if (tile0 >= count)
+    return;
+  const int C = a.n_channels;
+  float2 *xbuf = s_x[wave];
+  const int n_here = (count - tile0) < TF ? int (count - tile0) : TF;
+
+  for (int ff = wave; ff < n_here; ff += WAVES)
+    {
+      const long long idx = base + (tile0 + ff) * a.hop;
+      // skip rules of sync_fft (reference syncfinder.cc:578-590)
+      const long long f_first = idx * C, f_last = (idx + 1024) * C;
+      const bool skip = (f_last < a.first) || (f_first > a.last) || idx < 0 || idx + 1024 > a.n_frames;
+      float acc0 = 0.f, acc1 = 0.f;                      // bins 20 + lane, 84 + lane
+      if (!skip)
+        {
+          if (CV == 2)
+            {
+              float in[2][16];
+              fetch_stereo (a.pcm, idx, 1024, lane, in[0], in[1]);
+#pragma unroll
+              for (int c = 0; c < 2; c++)
+                {
+                  float2 z[8];
+                  window_pack (in[c], s_win, lane, z);
+                  fft512_forward (z, xbuf, s_tw, lane);
+                  xbuf[0 * 64 + lane] = z[0];
+                  xbuf[1 * 64 + lane] = z[1];
+                  xbuf[6 * 64 + lane] = z[6];
+                  xbuf[7 * 64 + lane] = z[7];
+                  wave_sync();
+                  {
+                    const int k = MIN_BAND + lane;
+                    acc0 = __fadd_rn (acc0, db_from_complex (real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], s_twb[lane])));
+                  }
+                  if (lane < NB - 64)
+                    {
+                      const int k = MIN_BAND + 64 + lane;
+                      acc1 = __fadd_rn (acc1, db_from_complex (real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], s_twb[64 + lane])));
+                    }
+                  wave_sync();
+                }
+            }
+          else
+            {
+              const int c_begin = a.per_channel ? plane_ch : 0, c_end = a.per_channel ? plane_ch + 1 : C;
+              for (int c = c_begin; c < c_end; c++)
+                {
+                  float in[16];
+                  fetch_channel (a.pcm, idx, 1024, C, c, lane, in);
+                  float2 z[8];
+                  window_pack (in, s_win, lane, z);
+                  fft512_forward (z, xbuf, s_tw, lane);
+                  xbuf[0 * 64 + lane] = z[0];
+                  xbuf[1 * 64 + lane] = z[1];
+                  xbuf[6 * 64 + lane] = z[6];
+                  xbuf[7 * 64 + lane] = z[7];
+                  wave_sync();
+                  {
+                    const int k = MIN_BAND + lane;
+                    acc0 = __fadd_rn (acc0, db_from_complex (real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], s_twb[lane])));
+                  }
+                  if (lane < NB - 64)
+                    {
+                      const int k = MIN_BAND + 64 + lane;
+                      acc1 = __fadd_rn (acc1, db_from_complex (real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], s_twb[64 + lane])));
+                    }
+                  wave_sync();
+                }
+            }
+        }
+      s_tile[lane * TILE_LD + ff] = acc0;
+      if (lane < NB - 64)
+        s_tile[(64 + lane) * TILE_LD + ff] = acc1;
+      if (lane == 0)
+        s_have[ff] = skip ? 0 : 1;
+    }
+  __syncthreads();
+  const long long plane = a.per_channel ? plane_ch : 0;
+  float *out = a.out + stream * a.out_stream_stride + plane * NB * a.ld + tile0;
+  for (int i = threadIdx.x; i < NB * n_here; i += blockDim.x)
+    {
+      const int band = i / n_here, ff = i - band * n_here;
+      out[band * a.ld + ff] = s_tile[band * TILE_LD + ff];
+    }
+  if (a.have && plane_ch == 0)
+    for (int i = threadIdx.x; i < n_here; i += blockDim.x)
+      a.have[stream * a.have_stream_stride + tile0 + i] = s_have[i];
+}
+
+hipError_t
+launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
+{
+  if (a.n_streams <= 0 || a.tile_frames <= 0 || a.tile_frames > TILE_MAX)
+    return a.n_streams <= 0 ? hipSuccess : hipErrorInvalidValue;
+  int max_count = a.count0;
+  // with per-stream counts the caller passes the maximum in count0
+  if (max_count <= 0)
+    return hipSuccess;
+  const unsigned tiles = unsigned ((max_count + a.tile_frames - 1) / a.tile_frames);
+  // grid.y is limited to 65535: fold streams
+  if (a.n_streams > 65535LL * 1)
+    {
+      // split into several launches over stream ranges
+      SyncDbArgs b = a;
+      long long done = 0;
+      while (done < a.n_streams)
+        {
+          const long long n = (a.n_streams - done) > 65535 ? 65535 : (a.n_streams - done);
+          b.n_streams = n;
+          b.base0 = a.base0 + done * a.base_stride;
+          b.stream_base = a.stream_base ? a.stream_base + done : nullptr;
+          b.stream_count = a.stream_count ? a.stream_count + done : nullptr;
+          b.out = a.out + done * a.out_stream_stride;
+          b.have = a.have ? a.have + done * a.have_stream_stride : nullptr;
+          hipError_t e = launch_sync_db (st, t, b);
+          if (e != hipSuccess)
+            return e;
+          done += n;
+        }
+      return hipSuccess;
+    }
+  const unsigned planes = a.per_channel ? unsigned (a.n_channels) : 1u;
+  const dim3 grid (tiles, unsigned (a.n_streams), planes);
+  if (a.n_channels == 2 && !a.per_channel)
+    hipLaunchKernelGGL (sync_db_kernel<2>, grid, dim3 (64 * WAVES), 0, st, t, a);
+  else
+    hipLaunchKernelGGL (sync_db_kernel<1>, grid, dim3 (64 * WAVES), 0, st, t, a);
+  return hipGetLastError();
+}
+
+/* ==========================================================================================
+ * K5: sync_decode for 64 candidates x 6 sync bits per workgroup
+ * ========================================================================================== */
+__global__ void __launch_bounds__ (384)
+sync_scan_kernel (SyncScanArgs a)
+{
+  __shared__ float s_u[6][64], s_d[6][64];
+  __shared__ int   s_n[6][64];
+  const int lane = threadIdx.x;
+  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);     // one wave == one sync bit
+  const long long plane = blockIdx.y;
+  const long long cand = (long long) blockIdx.x * 64 + lane;
+  const long long n_valid = a.lane_count ? a.lane_count[plane] : a.n_lanes;
+  const bool active = cand < n_valid;
+  const float *db = a.db + plane * a.plane_stride + (active ? cand : 0);
+  const char *have = a.have ? a.have + plane * a.have_plane_stride + (active ? cand : 0) : nullptr;
+  const int R = a.table.rows_per_bit;
+  const int *tab = a.table.packed + (size_t) bit * R * 64;
+
+  // float accumulators, strictly sequential adds in the reference's order (syncfinder.cc:129-145)
+  float umag = 0.f, dmag = 0.f;
+  int n = 0;
+  for (int r = 0; r < R; r++)
+    {
+      const int *tr = tab + r * 64;
+      const long long row = tr[60];
+      const bool present = have ? have[row * a.have_row_stride] != 0 : true;
+      const float *p = db + row * a.row_stride;
+      float uv[30], dv[30];
+#pragma unroll
+      for (int i = 0; i < 30; i++)
+        {
+          uv[i] = p[tr[i] * a.band_stride];
+          dv[i] = p[tr[30 + i] * a.band_stride];
+        }
+      if (present)
+        {
+#pragma unroll
+          for (int i = 0; i < 30; i++)
+            {
+              umag = __fadd_rn (umag, uv[i]);
+              dmag = __fadd_rn (dmag, dv[i]);
+            }
+          n++;
+        }
+    }
+  s_u[bit][lane] = umag;
+  s_d[bit][lane] = dmag;
+  s_n[bit][lane] = n;
+  __syncthreads();
+  if (bit == 0 && active)
+    {
+      double q = 0;
+      int total = 0;
+      for (int b = 0; b < 6; b++)
+        {
+          const float um = s_u[b][lane], dm = s_d[b][lane];
+          // SyncFinder::bit_quality (reference syncfinder.cc:94-114): float division and subtraction
+          float raw;
+          if (um == 0 || dm == 0)
+            raw = 0;
+          else if (um < dm)
+            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
+          else
+            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
+          const double rb = (b & 1) ? double (raw) : -double (raw);
+          q += rb * s_n[b][lane];
+          total += s_n[b][lane];
+        }
+      if (total)
+        q /= total;
+      q = q / a.min_delta / 2.9;
+      a.quality[plane * a.q_stride + cand] = q;
+    }
+}
+
+hipError_t
+launch_sync_scan (hipStream_t st, const SyncScanArgs& a)
+{
+  if (a.n_lanes <= 0 || a.n_planes <= 0)
+    return hipSuccess;
+  SyncScanArgs b = a;
+  long long done = 0;
+  while (done < a.n_planes)      // grid.y <= 65535
+    {
+      const long long n = (a.n_planes - done) > 65535 ? 65535 : (a.n_planes - done);
+      b.db = a.db + done * a.plane_stride;
+      b.have = a.have ? a.have + done * a.have_plane_stride : nullptr;
+      b.lane_count = a.lane_count ? a.lane_count + done : nullptr;
+      b.quality = a.quality + done * a.q_stride;
+      const dim3 grid (unsigned ((a.n_lanes + 63) / 64), unsigned (n));
+      hipLaunchKernelGGL (sync_scan_kernel, grid, dim3 (64, 6), 0, st, b);
+      hipError_t e = hipGetLastError();
+      if (e != hipSuccess)
+        return e;
+      done += n;
+    }
+  return hipSuccess;
+}
+
+/* K5b: local mean (reference syncfinder.cc:234-254): 41-tap window without the 7 centre taps */
+__global__ void __launch_bounds__ (256)
+local_mean_kernel (const double *q, long long q_stride, long long S, double *raw_sorted, double *local_mean)
+{
+  const long long p = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  const long long n_scores = 4 * S;
+  if (p >= n_scores)
+    return;
+  double avg = 0;
+  int n = 0;
+  for (int j = -20; j <= 20; j++)
+    {
+      if (j > -4 && j < 4)
+        continue;
+      const long long idx = p + j;
+      if (idx >= 0 && idx < n_scores)
+        {
+          avg += q[(idx & 3) * q_stride + (idx >> 2)];
+          n++;
+        }
+    }
+  if (n > 0)
+    avg /= n;
+  raw_sorted[p] = q[(p & 3) * q_stride + (p >> 2)];
+  local_mean[p] = avg;
+}
+
+hipError_t
+launch_local_mean (hipStream_t st, const double *q, long long q_stride, long long n_start_frames, double *raw_sorted, double *local_mean)
+{
+  const long long n = 4 * n_start_frames;
+  if (n <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (local_mean_kernel, dim3 (unsigned ((n + 255) / 256)), dim3 (256), 0, st, q, q_stride, n_start_frames, raw_sorted, local_mean);
+  return hipGetLastError();
+}
+
+/* ==========================================================================================
+ * K7: mix_decode -- one thread per soft bit, double accumulators in the reference's order
+ * ========================================================================================== */
+__global__ void __launch_bounds__ (128)
+soft_bits_kernel (SoftBitsArgs a)
+{
+  const long long blk = blockIdx.y;
+  const int bit = blockIdx.x * blockDim.x + threadIdx.x;
+  const int n_bits = a.n_data_frames / a.frames_per_bit;
+  if (bit >= n_bits)
+    return;
+  const float *db = a.db + blk * a.block_stride;
+  const int C = a.n_channels;
+  double umag = 0, dmag = 0;
+  for (int f = bit * a.frames_per_bit; f < (bit + 1) * a.frames_per_bit; f++)
+    for (int ch = 0; ch < C; ch++)
+      {
+        const float *plane = db + (long long) ch * NB * a.ld;
+        for (int j = 0; j < 30; j++)
+          {
+            const int b = f * 30 + j;
+            const int frame = a.mix_frame[b];
+            // neighbours reflected at the block edges (reference wmget.cc:87-88)
+            const int next = frame + 1 < a.block_frames ? frame + 1 : frame - 1;
+            const int prev = frame - 1 >= 0 ? frame - 1 : frame + 1;
+            const float *pu = plane + (long long) (a.mix_up[b] - MIN_BAND) * a.ld;
+            const float *pd = plane + (long long) (a.mix_down[b] - MIN_BAND) * a.ld;
+            umag += pu[frame];
+            umag -= double (__fadd_rn (pu[prev], pu[next])) * 0.5;
+            dmag += pd[frame];
+            dmag -= double (__fadd_rn (pd[prev], pd[next])) * 0.5;
+          }
+      }
+  a.out[blk * n_bits + bit] = float (umag - dmag);
+}
+
+hipError_t
+launch_soft_bits (hipStream_t st, const SoftBitsArgs& a)
+{
+  if (a.n_blocks <= 0)
+    return hipSuccess;
+  const int n_bits = a.n_data_frames / a.frames_per_bit;
+  const dim3 grid (unsigned ((n_bits + 127) / 128), unsigned (a.n_blocks));
+  hipLaunchKernelGGL (soft_bits_kernel, grid, dim3 (128), 0, st, a);
+  return hipGetLastError();
+}
+
+/* scan_silence (reference syncfinder.cc:155-169) */
+__global__ void __launch_bounds__ (256)
+nonzero_range_kernel (const float *data, long long n_values, unsigned long long *result)
+{
+  const long long stride = (long long) gridDim.x * blockDim.x;
+  unsigned long long first = ~0ULL, last = 0;
+  for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride)
+    if (data[i] != 0.f)
+      {
+        if ((unsigned long long) i < first) first = i;
+        if ((unsigned long long) i + 1 > last) last = i + 1;
+      }
+  if (first != ~0ULL)
+    {
+      atomicMin (result, first);
+      atomicMax (result + 1, last);
+    }
+}
+
+hipError_t
+launch_nonzero_range (hipStream_t st, const float *data, long long n_values, unsigned long long *result)
+{
+  const unsigned long long init[2] = { (unsigned long long) n_values, 0 };
+  hipError_t e = hipMemcpyAsync (result, init, sizeof (init), hipMemcpyHostToDevice, st);
+  if (e != hipSuccess || n_values <= 0)
+    return e;
+  hipLaunchKernelGGL (nonzero_range_kernel, dim3 (1024), dim3 (256), 0, st, data, n_values, result);
+  return hipGetLastError();
+}
+
+} // namespace awmk

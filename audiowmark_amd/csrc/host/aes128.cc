@@ -1,0 +1,78 @@
+#include "aes128.hh"
+
+namespace awm {
+
+const uint8_t *
+Aes128::sbox()
+{
+  // S-box built from the multiplicative inverse in GF(2^8) followed by the affine map.
+  static uint8_t table[256];
+  static const bool ready = [] {
+    uint8_t p = 1, q = 1;
+    do
+      {
+        p = uint8_t (p ^ (p << 1) ^ ((p & 0x80) ? 0x1B : 0));      // p *= 3
+        q ^= uint8_t (q << 1); q ^= uint8_t (q << 2); q ^= uint8_t (q << 4);
+        if (q & 0x80) q ^= 0x09;                                    // q /= 3
+        auto rotl = [] (uint8_t v, int n) { return uint8_t ((v << n) | (v >> (8 - n))); };
+        table[p] = uint8_t (q ^ rotl (q, 1) ^ rotl (q, 2) ^ rotl (q, 3) ^ rotl (q, 4) ^ 0x63);
+      }
+    while (p != 1);
+    table[0] = 0x63;
+    return true;
+  }();
+  (void) ready;
+  return table;
+}
+
+void
+Aes128::set_key (const uint8_t key[16])
+{
+  const uint8_t *S = sbox();
+  std::memcpy (m_rk, key, 16);
+  uint8_t rcon = 1;
+  for (int i = 16; i < 176; i += 4)
+    {
+      uint8_t t[4] = { m_rk[i - 4], m_rk[i - 3], m_rk[i - 2], m_rk[i - 1] };
+      if (i % 16 == 0)
+        {
+          const uint8_t t0 = t[0];
+          t[0] = S[t[1]] ^ rcon; t[1] = S[t[2]]; t[2] = S[t[3]]; t[3] = S[t0];
+          rcon = xtime (rcon);
+        }
+      for (int j = 0; j < 4; j++)
+        m_rk[i + j] = m_rk[i - 16 + j] ^ t[j];
+    }
+}
+
+void
+Aes128::encrypt_block (const uint8_t in[16], uint8_t out[16]) const
+{
+  const uint8_t *S = sbox();
+  uint8_t st[16], t[16];
+  for (int i = 0; i < 16; i++)
+    st[i] = in[i] ^ m_rk[i];
+  for (int round = 1; round <= 10; round++)
+    {
+      for (int c = 0; c < 4; c++)            // SubBytes + ShiftRows, column-major state
+        for (int r = 0; r < 4; r++)
+          t[4 * c + r] = S[st[4 * ((c + r) & 3) + r]];
+      if (round < 10)
+        for (int c = 0; c < 4; c++)          // MixColumns
+          {
+            const uint8_t a0 = t[4 * c], a1 = t[4 * c + 1], a2 = t[4 * c + 2], a3 = t[4 * c + 3];
+            const uint8_t all = a0 ^ a1 ^ a2 ^ a3;
+            st[4 * c + 0] = a0 ^ all ^ xtime (a0 ^ a1);
+            st[4 * c + 1] = a1 ^ all ^ xtime (a1 ^ a2);
+            st[4 * c + 2] = a2 ^ all ^ xtime (a2 ^ a3);
+            st[4 * c + 3] = a3 ^ all ^ xtime (a3 ^ a0);
+          }
+      else
+        std::memcpy (st, t, 16);
+      for (int i = 0; i < 16; i++)
+        st[i] ^= m_rk[16 * round + i];
+    }
+  std::memcpy (out, st, 16);
+}
+
+} // namespace awm

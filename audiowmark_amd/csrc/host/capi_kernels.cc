@@ -1,0 +1,422 @@
+// C ABI: kernel-level and pipeline-level entry points -- see include/awm_hip.h
+#include "context.hh"
+#include "syncfinder.hh"
+#include "wmget.hh"
+#include "utils.hh"
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+using namespace awm;
+namespace awm { Key capi_key (const uint8_t key[16]); }
+
+namespace {
+
+constexpr int LIMITER_BLOCK = Params::mark_sample_rate * int (Params::limiter_block_size_ms) / 1000;   // Limiter::set_block_size_ms
+const float LIMITER_CEILING = float (Params::limiter_ceiling);
+
+int
+check_ctx (awm_ctx *ctx)
+{
+  if (!ctx)
+    {
+      set_error ("null context");
+      return AWM_ERR_ARG;
+    }
+  hipError_t e = hipSetDevice (ctx->device);
+  if (e != hipSuccess)
+    {
+      set_error ("hipSetDevice: " + hip_error_string (e));
+      return AWM_ERR_HIP;
+    }
+  return 0;
+}
+
+int
+frames_per_span (long long n_frames1024)
+{
+  if (const char *env = getenv ("AWM_ADD_SPAN"))
+    {
+      const int v = atoi (env);
+      if (v >= 1)
+        return v;
+    }
+  // enough waves to fill 256 CUs several times over, long enough spans to amortise the 2 halo frames
+  if (n_frames1024 >= 64 * 1024)
+    return 16;
+  if (n_frames1024 >= 8 * 1024)
+    return 8;
+  return 4;
+}
+
+void
+fill_pattern (const ResultSet::Pattern& p, awm_pattern& o)
+{
+  o.time = p.time;
+  o.sync_index = p.sync_score.index;
+  o.sync_quality = p.sync_score.quality;
+  o.block_type = int (p.sync_score.block_type);
+  o.type = int (p.type);
+  o.decode_error = p.decode_error;
+  o.speed = p.speed;
+  o.n_bits = std::min<int> (p.bit_vec.size(), 128);
+  for (int b = 0; b < o.n_bits; b++)
+    o.bits[b] = p.bit_vec[b];
+}
+
+DeviceWav
+make_wav (const float *pcm_d, size_t n_frames, int n_channels)
+{
+  DeviceWav w;
+  w.data = pcm_d;
+  w.n_frames = n_frames;
+  w.n_channels = n_channels;
+  w.sample_rate = Params::mark_sample_rate;
+  return w;
+}
+
+} // namespace
+
+extern "C" {
+
+int
+awm_stft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, size_t start_index, size_t hop,
+            size_t frame_count, float *out_d)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (!pcm_d || !out_d || n_channels < 1)
+    {
+      set_error ("awm_stft_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  if (frame_count && n_frames < start_index + (frame_count - 1) * hop + Params::frame_size)
+    {
+      set_error ("awm_stft_d: range exceeds the data");
+      return AWM_ERR_ARG;
+    }
+  AWM_HIP_CHECK (awmk::launch_stft_full (ctx->stream, ctx->tabs, pcm_d, n_channels, (long long) start_index, (long long) hop,
+                                         (long long) frame_count, reinterpret_cast<float2 *> (out_d)));
+  return 0;
+}
+
+int
+awm_add_init_block_max_d (awm_ctx *ctx, float *block_max_d, size_t n_blocks)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  unsigned int bits;
+  std::memcpy (&bits, &LIMITER_CEILING, sizeof (bits));
+  AWM_HIP_CHECK (awmk::launch_fill_u32 (ctx->stream, reinterpret_cast<unsigned int *> (block_max_d), bits, n_blocks));
+  return 0;
+}
+
+static int
+add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
+              const int8_t *frame_mod_dev, double water_delta, size_t first_frame,
+              const float *halo_before_d, const float *halo_after_d, float *block_max_d, size_t first_block, size_t n_blocks)
+{
+  awmk::AddMixArgs a {};
+  a.pcm_in = pcm_in_d;
+  a.out = out_d;
+  a.n_frames = (long long) n_frames;
+  a.n_channels = n_channels;
+  a.frame_mod = frame_mod_dev;
+  // powf (mag, -Params::water_delta * data_bit_sign): double product converted to float (reference wmadd.cc:79)
+  a.neg_delta_up = float (-water_delta * 1);
+  a.neg_delta_down = float (-water_delta * -1);
+  a.first_frame = (long long) first_frame;
+  a.halo_before = halo_before_d;
+  a.halo_after = halo_after_d;
+  a.block_max = reinterpret_cast<unsigned int *> (block_max_d);
+  a.first_block = (long long) first_block;
+  a.n_blocks = (long long) n_blocks;
+  a.limiter_block = LIMITER_BLOCK;
+  a.frames_per_span = frames_per_span ((long long) (n_frames + 1023) / 1024);
+  AWM_HIP_CHECK (awmk::launch_add_mix (ctx->stream, ctx->tabs, a));
+  return 0;
+}
+
+int
+awm_add_mix_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
+               const int8_t *frame_mod, double water_delta, size_t first_frame,
+               const float *halo_before_d, const float *halo_after_d,
+               float *block_max_d, size_t first_block, size_t n_blocks)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (!pcm_in_d || !out_d || !frame_mod || n_channels < 1)
+    {
+      set_error ("awm_add_mix_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  const size_t table_bytes = 2 * mark_block_frame_count() * Params::n_bands;
+  if (int rc = ctx->ws_misc.reserve (table_bytes)) return rc;
+  AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_misc.ptr, frame_mod, table_bytes, hipMemcpyHostToDevice, ctx->stream));
+  return add_mix_impl (ctx, pcm_in_d, out_d, n_frames, n_channels, ctx->ws_misc.as<int8_t>(), water_delta, first_frame,
+                       halo_before_d, halo_after_d, block_max_d, first_block, n_blocks);
+}
+
+int
+awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels, size_t first_sample,
+                 const float *block_max_d, size_t first_block, size_t n_blocks)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  AWM_HIP_CHECK (awmk::launch_limiter (ctx->stream, out_d, (long long) n_frames, n_channels, (long long) first_sample, block_max_d,
+                                       (long long) first_block, (long long) n_blocks, LIMITER_BLOCK, LIMITER_CEILING));
+  return 0;
+}
+
+static int
+add_full (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
+          const int8_t *frame_mod_dev, double water_delta, int use_limiter)
+{
+  float *block_max = nullptr;
+  const size_t n_blocks = n_frames / LIMITER_BLOCK + 2;
+  if (use_limiter)
+    {
+      if (int rc = ctx->ws_block_max.reserve (n_blocks * sizeof (float))) return rc;
+      block_max = ctx->ws_block_max.as<float>();
+      if (int rc = awm_add_init_block_max_d (ctx, block_max, n_blocks)) return rc;
+    }
+  if (int rc = add_mix_impl (ctx, pcm_in_d, out_d, n_frames, n_channels, frame_mod_dev, water_delta, 0, nullptr, nullptr,
+                             block_max, 0, n_blocks))
+    return rc;
+  if (use_limiter)
+    return awm_add_limit_d (ctx, out_d, n_frames, n_channels, 0, block_max, 0, n_blocks);
+  return 0;
+}
+
+int
+awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
+           const int8_t *frame_mod, double water_delta, int use_limiter)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (!pcm_in_d || !out_d || !frame_mod || n_channels < 1)
+    {
+      set_error ("awm_add_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  const size_t table_bytes = 2 * mark_block_frame_count() * Params::n_bands;
+  if (int rc = ctx->ws_misc.reserve (table_bytes)) return rc;
+  AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_misc.ptr, frame_mod, table_bytes, hipMemcpyHostToDevice, ctx->stream));
+  return add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, ctx->ws_misc.as<int8_t>(), water_delta, use_limiter);
+}
+
+int
+awm_sync_fft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, size_t index, size_t frame_count,
+                const char *want_frames, size_t first, size_t last, float *db_out_d, char *have_out_d)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (n_frames < index + frame_count * Params::frame_size)
+    {
+      set_error ("awm_sync_fft_d: read past end");       // the reference returns empty vectors here
+      return AWM_ERR_ARG;
+    }
+  if (!frame_count)
+    return 0;
+  // band-major scratch, then transposed into the reference's [frame][81] layout by a strided copy
+  const long long ld = (long long) ((frame_count + 63) & ~size_t (63));
+  if (int rc = ctx->ws_db.reserve (size_t (ld) * Params::n_bands * sizeof (float))) return rc;
+  if (int rc = ctx->ws_have.reserve (ld)) return rc;
+  hipStream_t st = ctx->stream;
+  std::vector<long long> bases;
+  std::vector<int> counts;
+  awmk::SyncDbArgs da {};
+  da.pcm = pcm_d;
+  da.n_frames = (long long) n_frames;
+  da.n_channels = n_channels;
+  da.per_channel = 0;
+  da.hop = Params::frame_size;
+  da.out = ctx->ws_db.as<float>();
+  da.ld = ld;
+  da.have = ctx->ws_have.as<char>();
+  da.first = (long long) first;
+  da.last = (long long) last;
+  da.tile_frames = 64;
+  AWM_HIP_CHECK (hipMemsetAsync (ctx->ws_db.ptr, 0, size_t (ld) * Params::n_bands * sizeof (float), st));
+  AWM_HIP_CHECK (hipMemsetAsync (ctx->ws_have.ptr, 0, ld, st));
+  if (!want_frames)
+    {
+      da.base0 = (long long) index;
+      da.base_stride = 0;
+      da.count0 = int (frame_count);
+      da.n_streams = 1;
+      da.out_stream_stride = 0;
+      da.have_stream_stride = 0;
+      AWM_HIP_CHECK (awmk::launch_sync_db (st, ctx->tabs, da));
+    }
+  else
+    {
+      // one single-frame stream per wanted frame, written at its own column
+      for (size_t f = 0; f < frame_count; f++)
+        if (want_frames[f])
+          bases.push_back ((long long) (index + f * Params::frame_size));
+      if (!bases.empty())
+        {
+          // process wanted frames one launch per contiguous run to keep column addressing simple
+          size_t f = 0;
+          while (f < frame_count)
+            {
+              if (!want_frames[f])
+                {
+                  f++;
+                  continue;
+                }
+              size_t g = f;
+              while (g < frame_count && want_frames[g])
+                g++;
+              awmk::SyncDbArgs run = da;
+              run.base0 = (long long) (index + f * Params::frame_size);
+              run.base_stride = 0;
+              run.count0 = int (g - f);
+              run.n_streams = 1;
+              run.out = da.out + f;
+              run.have = da.have + f;
+              run.out_stream_stride = 0;
+              run.have_stream_stride = 0;
+              AWM_HIP_CHECK (awmk::launch_sync_db (st, ctx->tabs, run));
+              f = g;
+            }
+        }
+    }
+  // transpose [81][ld] -> [frame_count][81]
+  AWM_HIP_CHECK (hipMemcpy2DAsync (have_out_d, 1, ctx->ws_have.ptr, 1, 1, frame_count, hipMemcpyDeviceToDevice, st));
+  for (int b = 0; b < Params::n_bands; b++)
+    AWM_HIP_CHECK (hipMemcpy2DAsync (db_out_d + b, Params::n_bands * sizeof (float), ctx->ws_db.as<float>() + (long long) b * ld,
+                                     sizeof (float), sizeof (float), frame_count, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+
+int
+awm_sync_search_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int clip_mode,
+                   size_t max_out, uint64_t *index, double *quality, int *block_type)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  SyncFinder sf (ctx);
+  std::vector<SyncFinder::Score> scores;
+  if (int rc = sf.search (capi_key (key), make_wav (pcm_d, n_frames, n_channels),
+                          clip_mode ? SyncFinder::Mode::CLIP : SyncFinder::Mode::BLOCK, scores))
+    return rc;
+  for (size_t i = 0; i < scores.size() && i < max_out; i++)
+    {
+      index[i] = scores[i].index;
+      quality[i] = scores[i].quality;
+      block_type[i] = int (scores[i].block_type);
+    }
+  return int (scores.size());
+}
+
+long
+awm_search_approx_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int clip_mode,
+                     size_t max_out, uint64_t *index, double *raw_quality, double *local_mean)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  KeyTables *kt = ctx->get_key_tables (capi_key (key));
+  if (!kt)
+    return AWM_ERR_HIP;
+  SyncFinder sf (ctx);
+  std::vector<SyncFinder::SearchScore> scores;
+  const DeviceWav wav = make_wav (pcm_d, n_frames, n_channels);
+  if (int rc = sf.prepare (wav, clip_mode ? SyncFinder::Mode::CLIP : SyncFinder::Mode::BLOCK))
+    return rc;
+  if (int rc = sf.search_approx (kt, wav, clip_mode ? SyncFinder::Mode::CLIP : SyncFinder::Mode::BLOCK, scores))
+    return rc;
+  for (size_t i = 0; i < scores.size() && i < max_out; i++)
+    {
+      index[i] = scores[i].index;
+      raw_quality[i] = scores[i].raw_quality;
+      local_mean[i] = scores[i].local_mean;
+    }
+  return long (scores.size());
+}
+
+int
+awm_block_soft_bits_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
+                       const uint64_t *index, size_t n_blocks, float *out, int *ok)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  KeyTables *kt = ctx->get_key_tables (capi_key (key));
+  if (!kt)
+    return AWM_ERR_HIP;
+  std::vector<size_t> idx (index, index + n_blocks);
+  std::vector<std::vector<float>> raw;
+  std::vector<char> okv;
+  if (int rc = block_soft_bits (ctx, kt, make_wav (pcm_d, n_frames, n_channels), idx, raw, okv))
+    return rc;
+  const size_t n_bits = mark_data_frame_count() / Params::frames_per_bit;
+  for (size_t i = 0; i < n_blocks; i++)
+    {
+      ok[i] = okv[i];
+      if (okv[i])
+        std::copy (raw[i].begin(), raw[i].end(), out + i * n_bits);
+      else
+        std::fill (out + i * n_bits, out + (i + 1) * n_bits, 0.f);
+    }
+  return 0;
+}
+
+int
+awm_viterbi_decode (awm_ctx *ctx, int block_type, const float *soft, size_t coded_len, size_t n, int *bits_out, float *error_out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (block_type < 0 || block_type > 2)
+    return AWM_ERR_ARG;
+  std::vector<std::vector<float>> in (n);
+  for (size_t i = 0; i < n; i++)
+    in[i].assign (soft + i * coded_len, soft + (i + 1) * coded_len);
+  std::vector<std::vector<int>> bits;
+  std::vector<float> errors;
+  if (int rc = viterbi_decode (ctx, ConvBlockType (block_type), in, bits, errors))
+    return rc;
+  for (size_t i = 0; i < n; i++)
+    {
+      std::copy (bits[i].begin(), bits[i].end(), bits_out + i * bits[i].size());
+      error_out[i] = errors[i];
+    }
+  return 0;
+}
+
+int
+awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const float *pcm_in_d, float *out_d,
+                     size_t n_frames, int n_channels, int sample_rate)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (sample_rate != Params::mark_sample_rate)
+    {
+      // the reference resamples to 44.1 kHz and back with zita-resampler (wmadd.cc:358-431); not part of this path yet
+      set_error ("awm_add_watermark_d: only 44100 Hz input is supported");
+      return AWM_ERR_ARG;
+    }
+  FrameModTable *fm = ctx->get_frame_mod (capi_key (key), payload_hex ? payload_hex : "");
+  if (!fm)
+    return AWM_ERR_ARG;
+  return add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter);
+}
+
+int
+awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
+                     size_t max_out, awm_pattern *out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  ResultSet rs;
+  if (int rc = get_watermark_device (ctx, { capi_key (key) }, make_wav (pcm_d, n_frames, n_channels), rs))
+    return rc;
+  for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
+    fill_pattern (rs.patterns[i], out[i]);
+  return int (rs.patterns.size());
+}
+
+int
+awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
+                    int first_chunk, size_t max_out, awm_pattern *out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  ResultSet rs;
+  if (int rc = decode_chunk (ctx, rs, { capi_key (key) }, make_wav (pcm_d, n_frames, n_channels), first_chunk != 0))
+    return rc;
+  std::stable_sort (rs.patterns.begin(), rs.patterns.end(), [] (const ResultSet::Pattern& a, const ResultSet::Pattern& b) { return a.time < b.time; });
+  for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
+    fill_pattern (rs.patterns[i], out[i]);
+  return int (rs.patterns.size());
+}
+
+} // extern "C"

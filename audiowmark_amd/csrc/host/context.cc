@@ -1,0 +1,257 @@
+#include "context.hh"
+#include "utils.hh"
+#include <cmath>
+#include <cstring>
+
+namespace awm {
+
+static thread_local std::string g_last_error;
+void set_error (const std::string& msg) { g_last_error = msg; }
+const std::string& last_error() { return g_last_error; }
+std::string hip_error_string (hipError_t e) { return std::string (hipGetErrorName (e)) + " (" + hipGetErrorString (e) + ")"; }
+
+int
+DevBuffer::reserve (size_t want)
+{
+  if (want <= bytes)
+    return 0;
+  release();
+  // round up generously: workspaces are reused across calls, HBM is plentiful
+  size_t cap = size_t (1) << 20;
+  while (cap < want)
+    cap += cap / 2 > (size_t (1) << 30) ? (size_t (1) << 30) : cap / 2 + 1;
+  cap = (cap + 255) & ~size_t (255);
+  hipError_t e = hipMalloc (&ptr, cap);
+  if (e != hipSuccess)
+    {
+      ptr = nullptr;
+      set_error ("hipMalloc of " + std::to_string (cap) + " bytes failed: " + hip_error_string (e));
+      return AWM_ERR_HIP;
+    }
+  bytes = cap;
+  return 0;
+}
+
+void
+DevBuffer::release()
+{
+  if (ptr)
+    (void) hipFree (ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
+} // namespace awm
+
+using namespace awm;
+
+static int
+upload (DevBuffer& buf, const void *src, size_t bytes, hipStream_t st)
+{
+  if (int rc = buf.reserve (bytes ? bytes : 1))
+    return rc;
+  AWM_HIP_CHECK (hipMemcpyAsync (buf.ptr, src, bytes, hipMemcpyHostToDevice, st));
+  AWM_HIP_CHECK (hipStreamSynchronize (st));   // source vectors are temporaries
+  return 0;
+}
+
+static std::vector<int>
+pack_sync_table (const SyncTable& t, const std::vector<int>& want_pos /* empty: use frame */)
+{
+  const int R = t.rows_per_bit;
+  std::vector<int> packed (size_t (6) * R * 64, 0);
+  for (int bit = 0; bit < 6; bit++)
+    for (int r = 0; r < R; r++)
+      {
+        int *row = &packed[(size_t (bit) * R + r) * 64];
+        const size_t src = size_t (bit) * R + r;
+        for (int i = 0; i < 30; i++)
+          {
+            row[i] = t.up[src * 30 + i];
+            row[30 + i] = t.down[src * 30 + i];
+          }
+        row[60] = want_pos.empty() ? t.frame[src] : want_pos[t.frame[src]];
+      }
+  return packed;
+}
+
+KeyTables *
+awm_ctx::get_key_tables (const Key& key)
+{
+  std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
+  for (auto& kt : key_tables)
+    if (kt->key == kb)
+      return kt.get();
+  auto kt = std::make_unique<KeyTables>();
+  kt->key = kb;
+  for (int clip = 0; clip < 2; clip++)
+    {
+      auto& s = kt->sync[clip];
+      s.host = build_sync_table (key, clip);
+      const int total = mark_block_frame_count() * (clip ? 2 : 1);
+      std::vector<int> want_pos (total, -1);
+      std::vector<char> want (total, 0);
+      for (int f : s.host.frame)
+        want[f] = 1;
+      for (int f = 0; f < total; f++)
+        if (want[f])
+          {
+            want_pos[f] = s.want_list.size();
+            s.want_list.push_back (f);
+          }
+      auto pa = pack_sync_table (s.host, {});
+      auto pr = pack_sync_table (s.host, want_pos);
+      if (upload (s.packed_approx, pa.data(), pa.size() * sizeof (int), stream)) return nullptr;
+      if (upload (s.packed_refine, pr.data(), pr.size() * sizeof (int), stream)) return nullptr;
+      if (upload (s.want_list_dev, s.want_list.data(), s.want_list.size() * sizeof (int), stream)) return nullptr;
+    }
+  kt->mix_host = build_mix_table (key);
+  if (upload (kt->mix_frame, kt->mix_host.frame.data(), kt->mix_host.frame.size() * sizeof (int16_t), stream)) return nullptr;
+  if (upload (kt->mix_up, kt->mix_host.up.data(), kt->mix_host.up.size(), stream)) return nullptr;
+  if (upload (kt->mix_down, kt->mix_host.down.data(), kt->mix_host.down.size(), stream)) return nullptr;
+  kt->bit_order_a = bit_order (key, code_size (ConvBlockType::a, Params::payload_size));
+  key_tables.push_back (std::move (kt));
+  return key_tables.back().get();
+}
+
+FrameModTable *
+awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
+{
+  std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
+  for (auto& t : frame_mod_tables)
+    if (t->key == kb && t->payload == payload_hex)
+      return t.get();
+  auto bits = parse_payload (payload_hex);
+  if (bits.empty())
+    {
+      set_error ("cannot parse payload '" + payload_hex + "'");
+      return nullptr;
+    }
+  auto table = build_frame_mod_table (key, bits);
+  auto t = std::make_unique<FrameModTable>();
+  t->key = kb;
+  t->payload = payload_hex;
+  if (upload (t->dev, table.data(), table.size(), stream))
+    return nullptr;
+  if (frame_mod_tables.size() > 64)     // bounded cache
+    {
+      frame_mod_tables.front()->dev.release();
+      frame_mod_tables.erase (frame_mod_tables.begin());
+    }
+  frame_mod_tables.push_back (std::move (t));
+  return frame_mod_tables.back().get();
+}
+
+extern "C" {
+
+const char *awm_last_error (void) { return awm::last_error().c_str(); }
+const char *awm_version (void) { return "audiowmark_amd 0.1 (gfx950)"; }
+
+int
+awm_ctx_create (int device, awm_ctx **ctx_out)
+{
+  if (!ctx_out)
+    return AWM_ERR_ARG;
+  *ctx_out = nullptr;
+  int n_dev = 0;
+  hipError_t e = hipGetDeviceCount (&n_dev);
+  if (e != hipSuccess || n_dev <= 0)
+    {
+      set_error ("no HIP device available (" + hip_error_string (e) + "); this library has no CPU fallback");
+      return AWM_ERR_NO_DEVICE;
+    }
+  if (device < 0 || device >= n_dev)
+    {
+      set_error ("device index out of range");
+      return AWM_ERR_ARG;
+    }
+  AWM_HIP_CHECK (hipSetDevice (device));
+  auto ctx = std::make_unique<awm_ctx>();
+  ctx->device = device;
+  AWM_HIP_CHECK (hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking));
+  ctx->own_stream = true;
+
+  // constant tables, evaluated in double and rounded once
+  std::vector<float> blob;
+  auto push_c = [&] (double re, double im) { blob.push_back (float (re)); blob.push_back (float (im)); };
+  const size_t off_tw512 = blob.size();
+  for (int k = 0; k < 512; k++)
+    push_c (std::cos (-2 * M_PI * k / 512), std::sin (-2 * M_PI * k / 512));
+  const size_t off_tw1024 = blob.size();
+  for (int k = 0; k <= 512; k++)
+    push_c (std::cos (-2 * M_PI * k / 1024), std::sin (-2 * M_PI * k / 1024));
+  while (blob.size() % 4) blob.push_back (0);
+  const size_t off_win = blob.size();
+  auto win = gen_normalized_window (Params::frame_size);
+  blob.insert (blob.end(), win.begin(), win.end());
+  const size_t off_synth = blob.size();
+  auto synth = gen_synth_window();
+  blob.insert (blob.end(), synth.begin(), synth.end());
+  if (int rc = upload (ctx->tab_mem, blob.data(), blob.size() * sizeof (float), ctx->stream))
+    return rc;
+  const float *base = ctx->tab_mem.as<float>();
+  ctx->tabs.tw512 = reinterpret_cast<const float2 *> (base + off_tw512);
+  ctx->tabs.tw1024 = reinterpret_cast<const float2 *> (base + off_tw1024);
+  ctx->tabs.window = base + off_win;
+  ctx->tabs.synth = base + off_synth;
+  *ctx_out = ctx.release();
+  return 0;
+}
+
+void
+awm_ctx_destroy (awm_ctx *ctx)
+{
+  if (!ctx)
+    return;
+  (void) hipSetDevice (ctx->device);
+  (void) hipStreamSynchronize (ctx->stream);
+  for (auto& kt : ctx->key_tables)
+    {
+      for (auto& s : kt->sync)
+        {
+          s.packed_approx.release();
+          s.packed_refine.release();
+          s.want_list_dev.release();
+        }
+      kt->mix_frame.release();
+      kt->mix_up.release();
+      kt->mix_down.release();
+    }
+  for (auto& t : ctx->frame_mod_tables)
+    t->dev.release();
+  for (DevBuffer *b : { &ctx->tab_mem, &ctx->ws_db, &ctx->ws_have, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_mean, &ctx->ws_misc,
+                        &ctx->ws_refine, &ctx->ws_refine_have, &ctx->ws_soft, &ctx->ws_viterbi, &ctx->ws_viterbi_in,
+                        &ctx->ws_viterbi_bits, &ctx->ws_viterbi_err, &ctx->ws_block_max, &ctx->ws_clip, &ctx->ws_idx })
+    b->release();
+  if (ctx->own_stream && ctx->stream)
+    (void) hipStreamDestroy (ctx->stream);
+  delete ctx;
+}
+
+int awm_ctx_device (const awm_ctx *ctx) { return ctx ? ctx->device : -1; }
+
+int
+awm_ctx_synchronize (awm_ctx *ctx)
+{
+  if (!ctx)
+    return AWM_ERR_ARG;
+  AWM_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  return 0;
+}
+
+void *awm_ctx_stream (awm_ctx *ctx) { return ctx ? (void *) ctx->stream : nullptr; }
+
+int
+awm_ctx_set_stream (awm_ctx *ctx, void *hip_stream)
+{
+  if (!ctx)
+    return AWM_ERR_ARG;
+  AWM_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  if (ctx->own_stream && ctx->stream)
+    (void) hipStreamDestroy (ctx->stream);
+  ctx->stream = (hipStream_t) hip_stream;
+  ctx->own_stream = false;
+  return 0;
+}
+
+} // extern "C"

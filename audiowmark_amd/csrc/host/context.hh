@@ -1,0 +1,75 @@
+// awm_ctx: per-GPU state of the watermark path -- HIP stream, constant tables in HBM,
+// per-key device tables (cached) and grow-only workspaces sized for 288 GB parts.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+#include "../hip/kernels.hh"
+#include "wmcommon.hh"
+
+namespace awm { void set_error (const std::string& msg); std::string hip_error_string (hipError_t e); }
+
+#define AWM_HIP_CHECK(expr) \
+  do { hipError_t e__ = (expr); if (e__ != hipSuccess) { awm::set_error (std::string (#expr) + ": " + awm::hip_error_string (e__)); return AWM_ERR_HIP; } } while (0)
+
+namespace awm {
+
+// grow-only device buffer
+struct DevBuffer
+{
+  void  *ptr = nullptr;
+  size_t bytes = 0;
+  int reserve (size_t want);     // 0 ok
+  void release();
+  template<class T> T *as() const { return static_cast<T *> (ptr); }
+};
+
+// device copies of the key-derived tables
+struct KeyTables
+{
+  std::vector<unsigned char> key;
+  // sync tables, BLOCK and CLIP flavour
+  struct Sync
+  {
+    SyncTable host;
+    DevBuffer packed_approx;       // [6][rows][64] row = frame
+    DevBuffer packed_refine;       // [6][rows][64] row = position in the want list
+    std::vector<int> want_list;    // sorted sync frames (510 or 1020)
+    DevBuffer want_list_dev;
+  } sync[2];
+  MixTable  mix_host;
+  DevBuffer mix_frame, mix_up, mix_down;
+  std::vector<unsigned> bit_order_a;        // randomize_bit_order permutation for 858 bits
+};
+
+struct FrameModTable
+{
+  std::vector<unsigned char> key;
+  std::string payload;
+  DevBuffer   dev;                 // [2*2226][81] int8
+};
+
+} // namespace awm
+
+struct awm_ctx
+{
+  int            device = -1;
+  hipStream_t    stream = nullptr;
+  bool           own_stream = false;
+  awmk::DevTables tabs {};
+  awm::DevBuffer tab_mem;
+
+  std::vector<std::unique_ptr<awm::KeyTables>>     key_tables;
+  std::vector<std::unique_ptr<awm::FrameModTable>> frame_mod_tables;
+
+  // workspaces
+  awm::DevBuffer ws_db, ws_have, ws_q, ws_raw, ws_mean, ws_misc, ws_refine, ws_refine_have, ws_soft,
+                 ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx;
+
+  awm::KeyTables     *get_key_tables (const awm::Key& key);
+  awm::FrameModTable *get_frame_mod (const awm::Key& key, const std::string& payload_hex);
+};
+
+#include "../../../include/awm_hip.h"

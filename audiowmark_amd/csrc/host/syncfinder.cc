@@ -1,0 +1,351 @@
+#include "syncfinder.hh"
+#include "utils.hh"
+#include <algorithm>
+#include <cmath>
+
+namespace awm {
+
+static inline int
+total_frames (SyncFinder::Mode mode)
+{
+  return int (mark_block_frame_count()) * (mode == SyncFinder::Mode::CLIP ? 2 : 1);
+}
+
+int
+SyncFinder::scan_silence (const DeviceWav& wav)
+{
+  if (int rc = m_ctx->ws_misc.reserve (64))
+    return rc;
+  auto *res = m_ctx->ws_misc.as<unsigned long long>();
+  AWM_HIP_CHECK (awmk::launch_nonzero_range (m_ctx->stream, wav.data, (long long) wav.n_values(), res));
+  unsigned long long h[2];
+  AWM_HIP_CHECK (hipMemcpyAsync (h, res, sizeof (h), hipMemcpyDeviceToHost, m_ctx->stream));
+  AWM_HIP_CHECK (hipStreamSynchronize (m_ctx->stream));
+  m_first = h[0];
+  m_last = h[0] >= wav.n_values() ? wav.n_values() : h[1];
+  return 0;
+}
+
+/* reference syncfinder.cc:171-256 */
+int
+SyncFinder::search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& out)
+{
+  out.clear();
+  const int clip = mode == Mode::CLIP;
+  const long long frame_count = wav.n_frames / Params::frame_size;
+  const long long n_db = frame_count - 1;          // sync_fft_parallel drops the last frame (syncfinder.cc:632)
+  const long long S = n_db - total_frames (mode);  // start frames with (start + total) * 81 < db.size()
+  if (n_db <= 0 || S <= 0)
+    return 0;
+  hipStream_t st = m_ctx->stream;
+  const int n_shifts = Params::frame_size / Params::sync_search_step;
+  const long long ld = (n_db + 63) & ~63LL;
+  const long long plane = ld * Params::n_bands;
+  const long long q_stride = (S + 63) & ~63LL;
+  if (int rc = m_ctx->ws_db.reserve (size_t (n_shifts) * plane * sizeof (float))) return rc;
+  if (int rc = m_ctx->ws_have.reserve (size_t (n_shifts) * ld)) return rc;
+  if (int rc = m_ctx->ws_q.reserve (size_t (n_shifts) * q_stride * sizeof (double))) return rc;
+  if (int rc = m_ctx->ws_raw.reserve (size_t (n_shifts) * S * sizeof (double))) return rc;
+  if (int rc = m_ctx->ws_mean.reserve (size_t (n_shifts) * S * sizeof (double))) return rc;
+
+  awmk::SyncDbArgs da {};
+  da.pcm = wav.data;
+  da.n_frames = wav.n_frames;
+  da.n_channels = wav.n_channels;
+  da.per_channel = 0;
+  da.base0 = 0;
+  da.base_stride = Params::sync_search_step;
+  da.count0 = int (n_db);
+  da.n_streams = n_shifts;
+  da.hop = Params::frame_size;
+  da.out = m_ctx->ws_db.as<float>();
+  da.out_stream_stride = plane;
+  da.ld = ld;
+  da.have = m_ctx->ws_have.as<char>();
+  da.have_stream_stride = ld;
+  da.first = (long long) m_first;
+  da.last = (long long) m_last;
+  da.tile_frames = 64;
+  AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+
+  awmk::SyncScanArgs sa {};
+  sa.db = m_ctx->ws_db.as<float>();
+  sa.have = clip ? m_ctx->ws_have.as<char>() : nullptr;     // BLOCK mode never skips a frame
+  sa.plane_stride = plane;
+  sa.have_plane_stride = ld;
+  sa.row_stride = 1;
+  sa.band_stride = ld;
+  sa.have_row_stride = 1;
+  sa.n_lanes = S;
+  sa.n_planes = n_shifts;
+  sa.min_delta = std::min (Params::water_delta, 0.080);
+  sa.quality = m_ctx->ws_q.as<double>();
+  sa.q_stride = q_stride;
+  sa.table.packed = kt->sync[clip].packed_approx.as<int>();
+  sa.table.rows_per_bit = kt->sync[clip].host.rows_per_bit;
+  AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+  AWM_HIP_CHECK (awmk::launch_local_mean (st, m_ctx->ws_q.as<double>(), q_stride, S, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>()));
+
+  std::vector<double> raw (n_shifts * S), mean (n_shifts * S);
+  AWM_HIP_CHECK (hipMemcpyAsync (raw.data(), m_ctx->ws_raw.ptr, raw.size() * sizeof (double), hipMemcpyDeviceToHost, st));
+  AWM_HIP_CHECK (hipMemcpyAsync (mean.data(), m_ctx->ws_mean.ptr, mean.size() * sizeof (double), hipMemcpyDeviceToHost, st));
+  AWM_HIP_CHECK (hipStreamSynchronize (st));
+  out.resize (raw.size());
+  for (size_t p = 0; p < raw.size(); p++)
+    {
+      // sorted by index: index = start_frame * 1024 + shift * 256
+      out[p].index = (p >> 2) * Params::frame_size + (p & 3) * Params::sync_search_step;
+      out[p].raw_quality = raw[p];
+      out[p].local_mean = mean[p];
+    }
+  return 0;
+}
+
+/* reference syncfinder.cc:258-281 */
+void
+SyncFinder::select_local_maxima (std::vector<SearchScore>& scores)
+{
+  std::vector<SearchScore> selected;
+  for (size_t i = 0; i < scores.size(); i++)
+    {
+      const double q = scores[i].abs_quality();
+      const double q_last = i > 0 ? scores[i - 1].abs_quality() : 0;
+      const double q_next = i + 1 < scores.size() ? scores[i + 1].abs_quality() : 0;
+      if (q >= q_last && q >= q_next)
+        {
+          selected.push_back (scores[i]);
+          i++;                       // the neighbour cannot be a local maximum as well
+        }
+    }
+  scores.swap (selected);
+}
+
+/* reference syncfinder.cc:292-332 */
+void
+SyncFinder::mask_avg_false_positives (std::vector<SearchScore>& scores)
+{
+  constexpr int    mask_distance = local_mean_distance + 3;
+  constexpr double mask_factor = 3;
+  auto sign = [] (const SearchScore& s) { return s.raw_quality - s.local_mean < 0 ? -1 : 1; };
+  std::vector<SearchScore> kept;
+  const int n = int (scores.size());
+  for (int i = 0; i < n; i++)
+    {
+      bool mask = false;
+      for (int d = -mask_distance; d <= mask_distance; d++)
+        {
+          const int j = i + d;
+          if (j == i || j < 0 || j >= n)
+            continue;
+          const int distance = std::abs (int (scores[i].index) - int (scores[j].index)) / Params::sync_search_step;
+          if (distance <= mask_distance
+              && scores[j].abs_quality() > scores[i].abs_quality() * mask_factor
+              && sign (scores[j]) != sign (scores[i]))
+            mask = true;
+        }
+      if (!mask)
+        kept.push_back (scores[i]);
+    }
+  scores.swap (kept);
+}
+
+/* reference syncfinder.cc:364-383 */
+void
+SyncFinder::select_threshold_and_n_best (std::vector<SearchScore>& scores, double threshold)
+{
+  std::sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.abs_quality() > b.abs_quality(); });
+  int i = 0;
+  while (i < int (scores.size()) && scores[i].abs_quality() > threshold)
+    i++;
+  if (i >= Params::get_n_best)
+    scores.resize (i);
+  else if (int (scores.size()) > Params::get_n_best)
+    scores.resize (Params::get_n_best);
+}
+
+/* reference syncfinder.cc:385-391 */
+void
+SyncFinder::select_truncate_n (std::vector<SearchScore>& scores, size_t n)
+{
+  std::sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.abs_quality() > b.abs_quality(); });
+  if (scores.size() > n)
+    scores.resize (n);
+}
+
+/* reference syncfinder.cc:393-458: every candidate is re-scored on the fine grid
+ * [index - 256, index + 256] step 8 using only the sync frames */
+int
+SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& scores)
+{
+  const int clip = mode == Mode::CLIP;
+  const auto& sync = kt->sync[clip];
+  const int NW = int (sync.want_list.size());
+  const long long total = total_frames (mode);
+  const int TP = 72;                       // padded fine-offset axis (<= 65 used)
+  const int QS = 128;
+  hipStream_t st = m_ctx->stream;
+  const size_t n_cand = scores.size();
+  if (!n_cand)
+    return 0;
+
+  const size_t per_cand = size_t (NW) * Params::n_bands * TP;
+  size_t batch = std::max<size_t> (1, (size_t (3) << 30) / (per_cand * sizeof (float)));    // <= 3 GiB of dB rows at a time
+  batch = std::min (batch, n_cand);
+  if (int rc = m_ctx->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
+  if (int rc = m_ctx->ws_refine_have.reserve (batch * NW * TP)) return rc;
+  if (int rc = m_ctx->ws_q.reserve (batch * QS * sizeof (double))) return rc;
+  if (int rc = m_ctx->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + batch * sizeof (int))) return rc;
+
+  std::vector<SearchScore> refined;
+  for (size_t c0 = 0; c0 < n_cand; c0 += batch)
+    {
+      const size_t nb = std::min (batch, n_cand - c0);
+      std::vector<long long> stream_base (nb * NW);
+      std::vector<int> stream_count (nb * NW), lane_count (nb), starts (nb);
+      int max_count = 0;
+      for (size_t c = 0; c < nb; c++)
+        {
+          const SearchScore& s = scores[c0 + c];
+          const int start = std::max (int (s.index) - Params::sync_search_step, 0);
+          const int end = int (s.index) + Params::sync_search_step;
+          // fine offsets for which sync_fft does not read past the end (syncfinder.cc:566-568)
+          const long long limit = (long long) wav.n_frames - total * Params::frame_size;
+          int count = 0;
+          for (int fine = start; fine <= end; fine += Params::sync_search_fine)
+            if (fine <= limit)
+              count++;
+          starts[c] = start;
+          lane_count[c] = count;
+          max_count = std::max (max_count, count);
+          for (int w = 0; w < NW; w++)
+            {
+              stream_base[c * NW + w] = start + (long long) sync.want_list[w] * Params::frame_size;
+              stream_count[c * NW + w] = count;
+            }
+        }
+      auto *d_base = m_ctx->ws_idx.as<long long>();
+      int *d_count = reinterpret_cast<int *> (d_base + batch * NW);
+      int *d_lanes = d_count + batch * NW;
+      AWM_HIP_CHECK (hipMemcpyAsync (d_base, stream_base.data(), stream_base.size() * sizeof (long long), hipMemcpyHostToDevice, st));
+      AWM_HIP_CHECK (hipMemcpyAsync (d_count, stream_count.data(), stream_count.size() * sizeof (int), hipMemcpyHostToDevice, st));
+      AWM_HIP_CHECK (hipMemcpyAsync (d_lanes, lane_count.data(), lane_count.size() * sizeof (int), hipMemcpyHostToDevice, st));
+
+      std::vector<double> q (nb * QS, 0.0);
+      if (max_count > 0)
+        {
+          awmk::SyncDbArgs da {};
+          da.pcm = wav.data;
+          da.n_frames = wav.n_frames;
+          da.n_channels = wav.n_channels;
+          da.per_channel = 0;
+          da.stream_base = d_base;
+          da.stream_count = d_count;
+          da.count0 = max_count;
+          da.n_streams = (long long) nb * NW;
+          da.hop = Params::sync_search_fine;
+          da.out = m_ctx->ws_refine.as<float>();
+          da.out_stream_stride = (long long) Params::n_bands * TP;
+          da.ld = TP;
+          da.have = m_ctx->ws_refine_have.as<char>();
+          da.have_stream_stride = TP;
+          da.first = (long long) m_first;
+          da.last = (long long) m_last;
+          da.tile_frames = TP;
+          AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+
+          awmk::SyncScanArgs sa {};
+          sa.db = m_ctx->ws_refine.as<float>();
+          sa.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
+          sa.plane_stride = (long long) per_cand;
+          sa.have_plane_stride = (long long) NW * TP;
+          sa.row_stride = (long long) Params::n_bands * TP;
+          sa.band_stride = TP;
+          sa.have_row_stride = TP;
+          sa.n_lanes = max_count;
+          sa.lane_count = d_lanes;
+          sa.n_planes = (long long) nb;
+          sa.min_delta = std::min (Params::water_delta, 0.080);
+          sa.quality = m_ctx->ws_q.as<double>();
+          sa.q_stride = QS;
+          sa.table.packed = sync.packed_refine.as<int>();
+          sa.table.rows_per_bit = sync.host.rows_per_bit;
+          AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+          AWM_HIP_CHECK (hipMemcpyAsync (q.data(), m_ctx->ws_q.ptr, q.size() * sizeof (double), hipMemcpyDeviceToHost, st));
+        }
+      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      for (size_t c = 0; c < nb; c++)
+        {
+          const SearchScore& s = scores[c0 + c];
+          double best_quality = s.raw_quality;
+          size_t best_index = s.index;
+          for (int t = 0; t < lane_count[c]; t++)
+            {
+              const double qt = q[c * QS + t];
+              if (std::fabs (qt - s.local_mean) > std::fabs (best_quality - s.local_mean))
+                {
+                  best_quality = qt;
+                  best_index = starts[c] + t * Params::sync_search_fine;
+                }
+            }
+          refined.push_back ({ best_index, best_quality, s.local_mean });
+        }
+    }
+  std::stable_sort (refined.begin(), refined.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
+  scores.swap (refined);
+  return 0;
+}
+
+int
+SyncFinder::prepare (const DeviceWav& wav, Mode mode)
+{
+  if (mode == Mode::CLIP)
+    return scan_silence (wav);       // padding is not transformed and does not count (reference syncfinder.cc:491-502)
+  m_first = 0;
+  m_last = wav.n_values();
+  return 0;
+}
+
+/* reference syncfinder.cc:487-558 */
+int
+SyncFinder::search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out)
+{
+  out.clear();
+  KeyTables *kt = m_ctx->get_key_tables (key);
+  if (!kt)
+    return AWM_ERR_HIP;
+  if (Params::test_no_sync)
+    {
+      if (mode == Mode::BLOCK)       // fake_sync, reference syncfinder.cc:460-485
+        {
+          const size_t expect0 = Params::frames_pad_start * Params::frame_size;
+          const size_t step = mark_block_frame_count() * Params::frame_size;
+          const size_t end = (wav.n_frames / Params::frame_size) * Params::frame_size;
+          int ab = 0;
+          for (size_t idx = expect0; idx + step < end; idx += step)
+            out.push_back ({ idx, 1.0, (ab++ & 1) ? ConvBlockType::b : ConvBlockType::a });
+        }
+      return 0;
+    }
+  if (int rc = prepare (wav, mode))
+    return rc;
+  std::vector<SearchScore> scores;
+  if (int rc = search_approx (kt, wav, mode, scores))
+    return rc;
+  select_local_maxima (scores);
+  mask_avg_false_positives (scores);
+  select_threshold_and_n_best (scores, Params::sync_threshold2 * 0.75);
+  if (mode == Mode::CLIP)
+    select_truncate_n (scores, std::max (Params::get_n_best, 5));
+  if (int rc = search_refine (kt, wav, mode, scores))
+    return rc;
+  select_threshold_and_n_best (scores, Params::sync_threshold2);
+  std::sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
+  for (const auto& s : scores)
+    {
+      const double q = s.raw_quality - s.local_mean;
+      out.push_back ({ s.index, std::fabs (q), q > 0 ? ConvBlockType::a : ConvBlockType::b });
+    }
+  return 0;
+}
+
+} // namespace awm

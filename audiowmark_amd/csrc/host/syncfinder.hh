@@ -1,0 +1,56 @@
+// SyncFinder -- GPU-resident counterpart of reference src/syncfinder.{hh,cc}.
+// Same decisions as the reference (search_approx on 4 shifts, local mean, local maxima,
+// false-positive masking, threshold / n_best selection, search_refine on a +-256 / step 8
+// grid); the heavy loops run as HIP kernels (K4 sync_db, K5 sync_scan, K5b local_mean).
+#pragma once
+#include "context.hh"
+
+namespace awm {
+
+// PCM resident in HBM (the device-side WavData, reference wavdata.hh:27-74)
+struct DeviceWav
+{
+  const float *data = nullptr;
+  size_t       n_frames = 0;      // samples per channel
+  int          n_channels = 0;
+  int          sample_rate = 44100;
+  size_t n_values() const { return n_frames * n_channels; }
+};
+
+class SyncFinder
+{
+public:
+  enum class Mode { BLOCK, CLIP };
+  struct Score
+  {
+    size_t        index;
+    double        quality;
+    ConvBlockType block_type;
+  };
+  struct SearchScore
+  {
+    size_t index;
+    double raw_quality;
+    double local_mean;
+    double abs_quality() const { return std::fabs (raw_quality - local_mean); }
+  };
+  static constexpr int local_mean_distance = 20;
+
+  explicit SyncFinder (awm_ctx *ctx) : m_ctx (ctx) {}
+
+  int search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out);
+  int prepare (const DeviceWav& wav, Mode mode);     // silence scan (CLIP) / full range (BLOCK)
+  int search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& out);
+  int search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& scores);
+
+  static void select_local_maxima (std::vector<SearchScore>& scores);
+  static void mask_avg_false_positives (std::vector<SearchScore>& scores);
+  static void select_threshold_and_n_best (std::vector<SearchScore>& scores, double threshold);
+  static void select_truncate_n (std::vector<SearchScore>& scores, size_t n);
+private:
+  awm_ctx *m_ctx;
+  size_t   m_first = 0, m_last = 0;     // non-silent value range [first, last)
+  int scan_silence (const DeviceWav& wav);
+};
+
+} // namespace awm

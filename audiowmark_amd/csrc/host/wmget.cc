@@ -1,0 +1,757 @@
+#include "wmget.hh"
+#include "utils.hh"
+#include <algorithm>
+#include <cmath>
+#include <map>
+
+namespace awm {
+
+/* ---- ResultSet (reference wmget.cc:163-474) ------------------------------------------- */
+
+bool
+ResultSet::Pattern::approx_match (const Pattern& p) const
+{
+  const double time_delta = Params::frame_size / double (Params::mark_sample_rate);
+  const double speed_delta = 0.01;
+  return key == p.key
+      && (std::fabs (time - p.time) < time_delta || type == Type::ALL)
+      && bit_vec == p.bit_vec
+      && sync_score.block_type == p.sync_score.block_type
+      && type == p.type
+      && std::fabs (speed - p.speed) < speed_delta;
+}
+
+void
+ResultSet::add_pattern (const Key& key, double time, SyncFinder::Score sync_score, const std::vector<int>& bit_vec,
+                        float decode_error, Type type, double speed)
+{
+  Pattern p;
+  p.key = key;
+  p.time = time;
+  p.sync_score = sync_score;
+  p.bit_vec = bit_vec;
+  p.decode_error = decode_error;
+  p.type = type;
+  p.speed = speed;
+  patterns.push_back (p);
+}
+
+void
+ResultSet::apply_time_offset (double time_offset)
+{
+  for (auto& p : patterns)
+    p.time += time_offset;
+}
+
+void
+ResultSet::rate_patterns (const Key& key)
+{
+  // sum of sync qualities per distinct payload, "all" patterns count twice; float accumulation
+  std::map<std::string, float> rating;
+  for (const auto& p : patterns)
+    if (p.key == key)
+      rating[bit_vec_to_str (p.bit_vec)] += p.sync_score.quality * (p.type == Type::ALL ? 2.f : 1.f);
+  for (auto& p : patterns)
+    if (p.key == key)
+      p.rating = rating[bit_vec_to_str (p.bit_vec)];
+}
+
+static int
+ab_rank (const ResultSet::Pattern& p)
+{
+  switch (p.sync_score.block_type)
+    {
+    case ConvBlockType::a:  return 0;
+    case ConvBlockType::b:  return 1;
+    case ConvBlockType::ab: return 2;
+    }
+  return 99;
+}
+
+void
+ResultSet::sort (const std::vector<Key>& key_list)
+{
+  for (const auto& key : key_list)
+    rate_patterns (key);
+  std::sort (patterns.begin(), patterns.end(), [] (const Pattern& p1, const Pattern& p2) {
+    const int all1 = p1.type == Type::ALL, all2 = p2.type == Type::ALL;
+    if (p1.key.name() != p2.key.name())
+      return p1.key.name() < p2.key.name();
+    if (p1.rating != p2.rating)
+      return p1.rating > p2.rating;
+    if (all1 != all2)
+      return all1 < all2;
+    if (p1.time != p2.time)
+      return p1.time < p2.time;
+    if (ab_rank (p1) != ab_rank (p2))
+      return ab_rank (p1) < ab_rank (p2);
+    return bit_vec_to_str (p1.bit_vec) < bit_vec_to_str (p2.bit_vec);
+  });
+}
+
+void
+ResultSet::merge (ResultSet& other)
+{
+  std::vector<Pattern> to_merge = other.patterns;
+  std::stable_sort (to_merge.begin(), to_merge.end(), [] (const Pattern& a, const Pattern& b) { return a.time < b.time; });
+  for (const auto& p : to_merge)
+    {
+      bool is_new = true;
+      for (const auto& mine : patterns)
+        if (mine.approx_match (p))
+          is_new = false;
+      if (is_new)
+        patterns.push_back (p);
+    }
+  if (m_debug_sync.empty())
+    m_debug_sync = other.m_debug_sync;
+}
+
+static std::string
+block_label (const ResultSet::Pattern& p)
+{
+  std::string s;
+  switch (p.sync_score.block_type)
+    {
+    case ConvBlockType::a:  s = "A";  break;
+    case ConvBlockType::b:  s = "B";  break;
+    case ConvBlockType::ab: s = "AB"; break;
+    }
+  return s;
+}
+
+void
+ResultSet::print() const
+{
+  std::string last_key_name;
+  bool print_speed = true;
+  for (const auto& pattern : patterns)
+    {
+      if (pattern.key.name() != last_key_name)
+        {
+          printf ("key %s\n", pattern.key.name().c_str());
+          last_key_name = pattern.key.name();
+          print_speed = true;
+        }
+      if (print_speed)
+        {
+          for (const auto& p : patterns)
+            if (p.key == pattern.key && p.speed != 1)
+              {
+                printf ("speed %.6f\n", p.speed);
+                break;
+              }
+          print_speed = false;
+        }
+      if (pattern.type == Type::ALL)
+        printf ("pattern   all %s %.3f %.3f%s\n", bit_vec_to_str (pattern.bit_vec).c_str(), pattern.sync_score.quality,
+                pattern.decode_error, pattern.speed != 1 ? " SPEED" : "");
+      else
+        {
+          std::string block_str = block_label (pattern);
+          if (pattern.type == Type::CLIP)
+            block_str = "CLIP-" + block_str;
+          if (pattern.speed != 1)
+            block_str += "-SPEED";
+          const int seconds = pattern.time;
+          printf ("pattern %2d:%02d %s %.3f %.3f %s\n", seconds / 60, seconds % 60, bit_vec_to_str (pattern.bit_vec).c_str(),
+                  pattern.sync_score.quality, pattern.decode_error, block_str.c_str());
+        }
+    }
+}
+
+static std::string
+json_escape (const std::string& s)
+{
+  std::string r;
+  for (unsigned char ch : s)
+    {
+      if (ch == '"' || ch == '\\')
+        {
+          r += '\\';
+          r += char (ch);
+        }
+      else if (ch < 32)
+        r += string_printf ("\\u%04x", ch);
+      else
+        r += char (ch);
+    }
+  return r;
+}
+
+void
+ResultSet::print_json (size_t time_length, const std::string& json_file) const
+{
+  FILE *out = fopen (json_file == "-" ? "/dev/stdout" : json_file.c_str(), "w");
+  if (!out)
+    {
+      perror (("audiowmark: failed to open \"" + json_file + "\":").c_str());
+      exit (127);
+    }
+  fprintf (out, "{ \"length\": \"%ld:%02ld\",\n", long (time_length / 60), long (time_length % 60));
+  fprintf (out, "  \"matches\": [\n");
+  int nth = 0;
+  for (const auto& p : patterns)
+    {
+      if (nth++)
+        fprintf (out, ",\n");
+      std::string btype = block_label (p);
+      if (p.type == Type::ALL)
+        btype = "ALL";
+      if (p.type == Type::CLIP)
+        btype = "CLIP-" + btype;
+      if (p.speed != 1)
+        btype += "-SPEED";
+      const int seconds = p.time;
+      fprintf (out, "    { \"key\": \"%s\", \"pos\": \"%d:%02d\", \"bits\": \"%s\", \"quality\": %.5f, \"error\": %.6f, \"rating\": %.5f, \"type\": \"%s\", \"speed\": %.6f }",
+               json_escape (p.key.name()).c_str(), seconds / 60, seconds % 60, bit_vec_to_str (p.bit_vec).c_str(),
+               p.sync_score.quality, p.decode_error, p.rating, btype.c_str(), p.speed);
+    }
+  fprintf (out, " ]\n}\n");
+  fclose (out);
+}
+
+int
+ResultSet::print_match_count (const std::vector<int>& orig_bits) const
+{
+  int match_count = 0;
+  for (const auto& p : patterns)
+    if (p.bit_vec == orig_bits)
+      match_count++;
+  printf ("match_count %d %zd\n", match_count, patterns.size());
+  return match_count;
+}
+
+/* ---- soft bits ------------------------------------------------------------------------ */
+
+/* reference wmget.cc:40-65 */
+std::vector<float>
+normalize_soft_bits (const std::vector<float>& soft_bits)
+{
+  std::vector<float> norm;
+  norm.reserve (soft_bits.size());
+  if (Params::hard)
+    {
+      for (float v : soft_bits)
+        norm.push_back (v > 0 ? 1.0 : 0.0);
+      return norm;
+    }
+  double mean = 0;
+  for (float v : soft_bits)
+    mean += std::fabs (v);
+  mean /= soft_bits.size();
+  for (float v : soft_bits)
+    norm.push_back (0.5 * (v / mean + 1));
+  return norm;
+}
+
+/* FFTAnalyzer::fft_range (index, 2226 frames) + mix_decode for a batch of block starts */
+int
+block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
+                 std::vector<std::vector<float>>& raw_bits, std::vector<char>& ok)
+{
+  const size_t count = mark_block_frame_count();
+  const int n_bits = mark_data_frame_count() / Params::frames_per_bit;
+  const int C = wav.n_channels;
+  raw_bits.assign (index.size(), {});
+  ok.assign (index.size(), 0);
+  std::vector<long long> bases;
+  std::vector<size_t> slot;
+  for (size_t i = 0; i < index.size(); i++)
+    if (wav.n_values() >= (index[i] + count * Params::frame_size) * C)    // fft_range bound, reference wmcommon.cc:128-130
+      {
+        ok[i] = 1;
+        bases.push_back ((long long) index[i]);
+        slot.push_back (i);
+      }
+  if (bases.empty())
+    return 0;
+  hipStream_t st = ctx->stream;
+  const long long ld = (count + 63) & ~size_t (63);
+  const long long block_stride = (long long) C * Params::n_bands * ld;
+  const size_t max_batch = std::max<size_t> (1, (size_t (2) << 30) / (block_stride * sizeof (float)));
+  for (size_t b0 = 0; b0 < bases.size(); b0 += max_batch)
+    {
+      const size_t nb = std::min (max_batch, bases.size() - b0);
+      if (int rc = ctx->ws_db.reserve (nb * block_stride * sizeof (float))) return rc;
+      if (int rc = ctx->ws_idx.reserve (nb * sizeof (long long))) return rc;
+      if (int rc = ctx->ws_soft.reserve (nb * n_bits * sizeof (float))) return rc;
+      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_idx.ptr, bases.data() + b0, nb * sizeof (long long), hipMemcpyHostToDevice, st));
+      awmk::SyncDbArgs da {};
+      da.pcm = wav.data;
+      da.n_frames = wav.n_frames;
+      da.n_channels = C;
+      da.per_channel = 1;
+      da.stream_base = ctx->ws_idx.as<long long>();
+      da.count0 = int (count);
+      da.n_streams = (long long) nb;
+      da.hop = Params::frame_size;
+      da.out = ctx->ws_db.as<float>();
+      da.out_stream_stride = block_stride;
+      da.ld = ld;
+      da.have = nullptr;
+      da.first = 0;
+      da.last = (long long) wav.n_values();      // mix_decode uses plain run_fft: no silence skipping
+      da.tile_frames = 64;
+      AWM_HIP_CHECK (awmk::launch_sync_db (st, ctx->tabs, da));
+
+      awmk::SoftBitsArgs sb {};
+      sb.db = ctx->ws_db.as<float>();
+      sb.block_stride = block_stride;
+      sb.ld = ld;
+      sb.n_channels = C;
+      sb.mix_frame = kt->mix_frame.as<int16_t>();
+      sb.mix_up = kt->mix_up.as<uint8_t>();
+      sb.mix_down = kt->mix_down.as<uint8_t>();
+      sb.n_data_frames = mark_data_frame_count();
+      sb.frames_per_bit = Params::frames_per_bit;
+      sb.block_frames = int (count);
+      sb.n_blocks = (long long) nb;
+      sb.out = ctx->ws_soft.as<float>();
+      AWM_HIP_CHECK (awmk::launch_soft_bits (st, sb));
+      std::vector<float> host (nb * n_bits);
+      AWM_HIP_CHECK (hipMemcpyAsync (host.data(), ctx->ws_soft.ptr, host.size() * sizeof (float), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      for (size_t i = 0; i < nb; i++)
+        raw_bits[slot[b0 + i]].assign (host.begin() + i * n_bits, host.begin() + (i + 1) * n_bits);
+    }
+  return 0;
+}
+
+int
+viterbi_decode (awm_ctx *ctx, ConvBlockType block_type, const std::vector<std::vector<float>>& soft,
+                std::vector<std::vector<int>>& bits, std::vector<float>& errors)
+{
+  bits.assign (soft.size(), {});
+  errors.assign (soft.size(), 0.f);
+  if (soft.empty())
+    return 0;
+  const auto gens = conv_generators (block_type);
+  const int rate = int (gens.size());
+  const size_t coded_len = soft[0].size();
+  const size_t n_out = coded_len / rate - conv_order;
+  hipStream_t st = ctx->stream;
+  const size_t max_batch = 256;
+  for (size_t b0 = 0; b0 < soft.size(); b0 += max_batch)
+    {
+      const size_t nb = std::min (max_batch, soft.size() - b0);
+      std::vector<float> flat (nb * coded_len);
+      for (size_t i = 0; i < nb; i++)
+        {
+          if (soft[b0 + i].size() != coded_len)
+            {
+              set_error ("viterbi_decode: ragged batch");
+              return AWM_ERR_ARG;
+            }
+          std::copy (soft[b0 + i].begin(), soft[b0 + i].end(), flat.begin() + i * coded_len);
+        }
+      if (int rc = ctx->ws_viterbi_in.reserve (flat.size() * sizeof (float))) return rc;
+      if (int rc = ctx->ws_viterbi.reserve (awmk::viterbi_workspace_bytes (coded_len, rate, nb))) return rc;
+      if (int rc = ctx->ws_viterbi_bits.reserve (nb * n_out * sizeof (int))) return rc;
+      if (int rc = ctx->ws_viterbi_err.reserve (nb * sizeof (float))) return rc;
+      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_viterbi_in.ptr, flat.data(), flat.size() * sizeof (float), hipMemcpyHostToDevice, st));
+      AWM_HIP_CHECK (awmk::launch_viterbi (st, ctx->ws_viterbi_in.as<float>(), rate, gens.data(), coded_len, nb,
+                                           ctx->ws_viterbi.as<unsigned char>(), ctx->ws_viterbi_bits.as<int>(), ctx->ws_viterbi_err.as<float>()));
+      std::vector<int> hbits (nb * n_out);
+      AWM_HIP_CHECK (hipMemcpyAsync (hbits.data(), ctx->ws_viterbi_bits.ptr, hbits.size() * sizeof (int), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipMemcpyAsync (errors.data() + b0, ctx->ws_viterbi_err.ptr, nb * sizeof (float), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      for (size_t i = 0; i < nb; i++)
+        bits[b0 + i].assign (hbits.begin() + i * n_out, hbits.begin() + (i + 1) * n_out);
+    }
+  return 0;
+}
+
+/* ---- BlockDecoder (reference wmget.cc:492-735) ---------------------------------------- */
+
+namespace {
+
+struct PatternRawBits
+{
+  size_t             index;
+  double             quality;
+  std::vector<float> raw_bit_vec;
+  ConvBlockType      block_type;
+};
+
+struct PendingDecode       // one Viterbi job and what to do with its result
+{
+  ConvBlockType      code_type;
+  std::vector<float> soft;
+  double             time;
+  SyncFinder::Score  score;
+  ResultSet::Type    type;
+};
+
+int
+run_pending (awm_ctx *ctx, const Key& key, std::vector<PendingDecode>& pending, ResultSet& result_set, double speed)
+{
+  for (ConvBlockType ct : { ConvBlockType::a, ConvBlockType::b, ConvBlockType::ab })
+    {
+      std::vector<std::vector<float>> soft;
+      std::vector<size_t> which;
+      for (size_t i = 0; i < pending.size(); i++)
+        if (pending[i].code_type == ct)
+          {
+            soft.push_back (pending[i].soft);
+            which.push_back (i);
+          }
+      std::vector<std::vector<int>> bits;
+      std::vector<float> errors;
+      if (int rc = viterbi_decode (ctx, ct, soft, bits, errors))
+        return rc;
+      for (size_t j = 0; j < which.size(); j++)
+        {
+          const PendingDecode& p = pending[which[j]];
+          if (!bits[j].empty())
+            result_set.add_pattern (key, p.time, p.score, bits[j], errors[j], p.type, speed);
+        }
+    }
+  return 0;
+}
+
+int
+block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set,
+                   double speed, std::string *debug_sync)
+{
+  SyncFinder sync_finder (ctx);
+  const size_t count = mark_block_frame_count();
+  const size_t block_len = count * Params::frame_size;
+  std::vector<SyncFinder::Score> first_key_scores;
+  for (size_t ki = 0; ki < key_list.size(); ki++)
+    {
+      const Key& key = key_list[ki];
+      KeyTables *kt = ctx->get_key_tables (key);
+      if (!kt)
+        return AWM_ERR_HIP;
+      std::vector<SyncFinder::Score> sync_scores;
+      if (int rc = sync_finder.search (key, wav, SyncFinder::Mode::BLOCK, sync_scores))
+        return rc;
+      if (ki == 0)
+        first_key_scores = sync_scores;
+
+      std::vector<size_t> index;
+      for (const auto& s : sync_scores)
+        index.push_back (s.index);
+      std::vector<std::vector<float>> raw;
+      std::vector<char> ok;
+      if (int rc = block_soft_bits (ctx, kt, wav, index, raw, ok))
+        return rc;
+
+      std::vector<PatternRawBits> pattern_raw_vec;
+      std::vector<PendingDecode> pending;
+      for (size_t i = 0; i < sync_scores.size(); i++)
+        {
+          if (!ok[i])
+            continue;
+          PatternRawBits rb;
+          rb.index = sync_scores[i].index;
+          rb.quality = sync_scores[i].quality;
+          rb.raw_bit_vec = randomize_bit_order (key, raw[i], /* encode */ false);
+          rb.block_type = sync_scores[i].block_type;
+          pattern_raw_vec.push_back (rb);
+          pending.push_back ({ rb.block_type, normalize_soft_bits (rb.raw_bit_vec),
+                               double (rb.index) / wav.sample_rate, sync_scores[i], ResultSet::Type::BLOCK });
+        }
+      /* AB: a B block preceded by an A block one block length earlier */
+      for (size_t i = 0; i < pattern_raw_vec.size(); i++)
+        {
+          if (pattern_raw_vec[i].block_type != ConvBlockType::b)
+            continue;
+          int best_j = -1;
+          int best_abs_dist = Params::frame_size / 2;
+          for (size_t j = 0; j < i; j++)
+            if (pattern_raw_vec[j].block_type == ConvBlockType::a)
+              {
+                const int abs_dist = std::abs (int (pattern_raw_vec[i].index - pattern_raw_vec[j].index) - int (block_len));
+                if (abs_dist < best_abs_dist)
+                  {
+                    best_j = j;
+                    best_abs_dist = abs_dist;
+                  }
+              }
+          if (best_j < 0)
+            continue;
+          const auto& a_pattern = pattern_raw_vec[best_j];
+          const auto& b_pattern = pattern_raw_vec[i];
+          std::vector<float> ab_bits (a_pattern.raw_bit_vec.size() * 2);
+          for (size_t k = 0; k < a_pattern.raw_bit_vec.size(); k++)
+            {
+              ab_bits[2 * k] = a_pattern.raw_bit_vec[k];
+              ab_bits[2 * k + 1] = b_pattern.raw_bit_vec[k];
+            }
+          SyncFinder::Score score_ab { b_pattern.index, (a_pattern.quality + b_pattern.quality) / 2, ConvBlockType::ab };
+          pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (ab_bits), double (b_pattern.index) / wav.sample_rate,
+                               score_ab, ResultSet::Type::BLOCK });
+        }
+      /* all: best chain of consecutive, alternating blocks */
+      std::vector<size_t> best_all_blocks;
+      auto sync_sum = [&] (const std::vector<size_t>& blocks) {
+        float sum = 0;
+        for (auto b : blocks)
+          sum += pattern_raw_vec[b].quality;
+        return sum;
+      };
+      for (size_t i = 0; i < pattern_raw_vec.size(); i++)
+        {
+          const size_t max_block_idx = lrint (pattern_raw_vec.back().index / double (block_len) + 0.5);
+          std::vector<size_t> all_blocks { i };
+          size_t block_idx = 1;
+          while (block_idx <= max_block_idx)
+            {
+              const size_t expect_start = pattern_raw_vec[all_blocks.back()].index + block_idx * block_len;
+              int best_j = -1;
+              int best_abs_dist = block_idx * Params::frame_size / 2;
+              auto expect_type = pattern_raw_vec[all_blocks.back()].block_type;
+              if (block_idx & 1)
+                expect_type = expect_type == ConvBlockType::a ? ConvBlockType::b : ConvBlockType::a;
+              for (size_t j = all_blocks.back(); j < pattern_raw_vec.size(); j++)
+                {
+                  const int abs_dist = std::abs (int (expect_start) - int (pattern_raw_vec[j].index));
+                  if (abs_dist < best_abs_dist && pattern_raw_vec[j].block_type == expect_type)
+                    {
+                      best_j = j;
+                      best_abs_dist = abs_dist;
+                    }
+                }
+              if (best_j >= 0)
+                {
+                  all_blocks.push_back (best_j);
+                  block_idx = 1;
+                }
+              else
+                block_idx++;
+            }
+          if (sync_sum (all_blocks) > sync_sum (best_all_blocks))
+            best_all_blocks = all_blocks;
+        }
+      if (best_all_blocks.size() > 1)
+        {
+          std::vector<float> all_bits (code_size (ConvBlockType::ab, Params::payload_size));
+          int norm[2] = { 0, 0 };
+          SyncFinder::Score score_all { 0, 0, ConvBlockType::a };
+          for (auto bi : best_all_blocks)
+            {
+              const auto& pattern = pattern_raw_vec[bi];
+              score_all.quality += pattern.quality;
+              const int ab = pattern.block_type == ConvBlockType::b ? 1 : 0;
+              for (size_t k = 0; k < pattern.raw_bit_vec.size(); k++)
+                all_bits[2 * k + ab] += pattern.raw_bit_vec[k];
+              norm[ab]++;
+            }
+          for (size_t k = 0; k < all_bits.size(); k += 2)
+            {
+              all_bits[k]     /= std::max (norm[0], 1);
+              all_bits[k + 1] /= std::max (norm[1], 1);
+            }
+          score_all.quality /= norm[0] + norm[1];
+          pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (all_bits), 0.0, score_all, ResultSet::Type::ALL });
+        }
+      if (int rc = run_pending (ctx, key, pending, result_set, speed))
+        return rc;
+    }
+  if (debug_sync)
+    {
+      debug_sync->clear();
+      if (key_list.size() == 1)
+        {
+          const int expect0 = Params::frames_pad_start * Params::frame_size;
+          const int expect_step = block_len;
+          const int expect_end = int (wav.n_frames / Params::frame_size) * Params::frame_size;
+          int sync_match = 0;
+          for (int expect_index = expect0; expect_index + expect_step < expect_end; expect_index += expect_step)
+            for (const auto& s : first_key_scores)
+              if (std::abs (int (s.index + Params::test_cut) - expect_index) < int (Params::frame_size / 2))
+                {
+                  sync_match++;
+                  break;
+                }
+          *debug_sync = string_printf ("sync_match %d %zd\n", sync_match, first_key_scores.size());
+        }
+    }
+  return 0;
+}
+
+/* ---- ClipDecoder (reference wmget.cc:764-884) ----------------------------------------- */
+
+int
+clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set,
+                 double time_offset_sec, double speed)
+{
+  SyncFinder sync_finder (ctx);
+  const size_t count = mark_block_frame_count();
+  for (const Key& key : key_list)
+    {
+      KeyTables *kt = ctx->get_key_tables (key);
+      if (!kt)
+        return AWM_ERR_HIP;
+      std::vector<SyncFinder::Score> sync_scores;
+      if (int rc = sync_finder.search (key, wav, SyncFinder::Mode::CLIP, sync_scores))
+        return rc;
+      std::vector<size_t> index;
+      for (const auto& s : sync_scores)
+        {
+          index.push_back (s.index);
+          index.push_back (s.index + count * Params::frame_size);
+        }
+      std::vector<std::vector<float>> raw;
+      std::vector<char> ok;
+      if (int rc = block_soft_bits (ctx, kt, wav, index, raw, ok))
+        return rc;
+      std::vector<PendingDecode> pending;
+      for (size_t i = 0; i < sync_scores.size(); i++)
+        {
+          if (!ok[2 * i] || !ok[2 * i + 1])
+            continue;
+          const auto bits1 = randomize_bit_order (key, raw[2 * i], false);
+          const auto bits2 = randomize_bit_order (key, raw[2 * i + 1], false);
+          std::vector<float> ab;
+          ab.reserve (bits1.size() * 2);
+          for (size_t k = 0; k < bits1.size(); k++)
+            {
+              if (sync_scores[i].block_type == ConvBlockType::a)
+                {
+                  ab.push_back (bits1[k]);
+                  ab.push_back (bits2[k]);
+                }
+              else
+                {
+                  ab.push_back (bits2[k]);
+                  ab.push_back (bits1[k]);
+                }
+            }
+          SyncFinder::Score nopad = sync_scores[i];
+          nopad.index = time_offset_sec * wav.sample_rate;
+          pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (ab), time_offset_sec, nopad, ResultSet::Type::CLIP });
+        }
+      if (int rc = run_pending (ctx, key, pending, result_set, speed))
+        return rc;
+    }
+  return 0;
+}
+
+enum class ClipPos { START, END };
+
+int
+clip_run_block (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set, ClipPos pos, double speed)
+{
+  const size_t C = wav.n_channels;
+  const size_t n = (mark_block_frame_count() + 5) * Params::frame_size * C;      // in values
+  size_t first_sample, last_sample, pad_start = n, pad_end = n;
+  if (pos == ClipPos::START)
+    {
+      first_sample = 0;
+      last_sample = std::min (n, wav.n_values());
+      if (last_sample < n)
+        pad_start += n - last_sample;            // data + padding must always cover one long block
+    }
+  else
+    {
+      if (wav.n_values() <= n)
+        return 0;
+      first_sample = wav.n_values() - n;
+      last_sample = wav.n_values();
+    }
+  const double time_offset = double (first_sample) / wav.sample_rate / C;
+  const size_t total = pad_start + (last_sample - first_sample) + pad_end;
+  if (int rc = ctx->ws_clip.reserve (total * sizeof (float)))
+    return rc;
+  float *ext = ctx->ws_clip.as<float>();
+  hipStream_t st = ctx->stream;
+  AWM_HIP_CHECK (hipMemsetAsync (ext, 0, pad_start * sizeof (float), st));
+  AWM_HIP_CHECK (hipMemcpyAsync (ext + pad_start, wav.data + first_sample, (last_sample - first_sample) * sizeof (float), hipMemcpyDeviceToDevice, st));
+  AWM_HIP_CHECK (hipMemsetAsync (ext + pad_start + (last_sample - first_sample), 0, pad_end * sizeof (float), st));
+  DeviceWav l_wav;
+  l_wav.data = ext;
+  l_wav.n_frames = total / C;
+  l_wav.n_channels = wav.n_channels;
+  l_wav.sample_rate = wav.sample_rate;
+  return clip_run_padded (ctx, key_list, l_wav, result_set, time_offset, speed);
+}
+
+int
+clip_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set, double speed)
+{
+  const int wav_frames = wav.n_values() / (Params::frame_size * wav.n_channels);
+  if (wav_frames < int (mark_block_frame_count()) * 3.1)       // only short files
+    {
+      if (int rc = clip_run_block (ctx, key_list, wav, result_set, ClipPos::START, speed))
+        return rc;
+      if (int rc = clip_run_block (ctx, key_list, wav, result_set, ClipPos::END, speed))
+        return rc;
+    }
+  return 0;
+}
+
+} // namespace
+
+int
+decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav, bool first_chunk)
+{
+  std::string debug_sync;
+  if (int rc = block_decoder_run (ctx, key_list, wav, result_set, 1, &debug_sync))
+    return rc;
+  if (first_chunk)
+    if (int rc = clip_decoder_run (ctx, key_list, wav, result_set, 1))
+      return rc;
+  result_set.set_debug_sync (debug_sync);
+  return 0;
+}
+
+/* chunking of WavChunkLoader (reference wavchunkloader.cc:54-163), in samples per channel */
+std::vector<ChunkRange>
+plan_chunks (size_t n_frames, int n_channels)
+{
+  const size_t rate = Params::mark_sample_rate;
+  const size_t max_size = size_t (lrint (Params::get_chunk_size * 60 * rate));
+  const double block_seconds = mark_block_frame_count() * Params::frame_size / double (rate);
+  const size_t overlap = size_t (lrint (2 * block_seconds * 1.3 * rate));
+  (void) n_channels;
+  std::vector<ChunkRange> chunks;
+  size_t buf_start = 0, buf_len = 0;
+  double time_offset = 0;
+  bool last = false;
+  while (!last)
+    {
+      if (buf_len)
+        {
+          time_offset += double (buf_len - overlap) / double (rate);
+          buf_start += buf_len - overlap;
+          buf_len = overlap;
+        }
+      const size_t avail = n_frames - (buf_start + buf_len);
+      const size_t take = std::min (max_size - buf_len, avail);
+      buf_len += take;
+      const bool eof = buf_len < max_size;         // the loader only notices EOF when a read comes back empty
+      if (eof)
+        {
+          last = true;
+          if (!buf_len)
+            break;
+        }
+      chunks.push_back ({ buf_start, buf_len, time_offset });
+    }
+  return chunks;
+}
+
+int
+get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set)
+{
+  bool first_chunk = true;
+  for (const auto& chunk : plan_chunks (wav.n_frames, wav.n_channels))
+    {
+      DeviceWav cw = wav;
+      cw.data = wav.data + chunk.first_frame * wav.n_channels;
+      cw.n_frames = chunk.n_frames;
+      ResultSet chunk_set;
+      if (int rc = decode_chunk (ctx, chunk_set, key_list, cw, first_chunk))
+        return rc;
+      chunk_set.apply_time_offset (chunk.time_offset);
+      result_set.merge (chunk_set);
+      first_chunk = false;
+    }
+  result_set.sort (key_list);
+  return 0;
+}
+
+} // namespace awm

@@ -1,0 +1,162 @@
+/* awm_hip.h -- C ABI of the MI355X (gfx950) spectral watermark path.
+ *
+ * The reference (swesterfeld/audiowmark 0.6.5) has no FFI layer; the seams this library
+ * replaces are C++ member functions.  Each entry point below names the reference
+ * interface it stands in for (file:line relative to the reference's src/).
+ *
+ * Conventions
+ *   - plain C, pointers + sizes only.  Pointers suffixed _d are DEVICE pointers (HBM),
+ *     everything else is host memory.
+ *   - return 0 on success, negative on error; awm_last_error() gives the message
+ *     (thread-local).  There is NO CPU fallback: without a usable gfx950 device every
+ *     compute entry point fails with AWM_ERR_NO_DEVICE.
+ *   - PCM is interleaved float32, `n_frames` = samples per channel (reference WavData,
+ *     wavdata.hh:27-74); all watermark arithmetic is at 44100 Hz (wmcommon.hh:68).
+ *   - work is enqueued on the context's HIP stream; entry points that return host data
+ *     synchronise that stream before returning, the *_async ones do not.
+ */
+#ifndef AWM_HIP_H
+#define AWM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AWM_ERR_GENERIC    (-1)
+#define AWM_ERR_NO_DEVICE  (-2)
+#define AWM_ERR_ARG        (-3)
+#define AWM_ERR_HIP        (-4)
+
+#define AWM_FRAME_SIZE      1024
+#define AWM_N_BANDS         81      /* bins 20..100, wmcommon.hh:39-40 */
+#define AWM_BLOCK_FRAMES    2226    /* 510 sync + 1716 data frames at the default payload */
+#define AWM_SOFT_BITS       858     /* conv_code_size(a,128), convcode.cc:65-75 */
+
+typedef struct awm_ctx awm_ctx;
+
+const char *awm_last_error (void);
+const char *awm_version (void);
+
+/* ---- context: one per GPU / per rank ------------------------------------------------ */
+int   awm_ctx_create (int device, awm_ctx **ctx_out);
+void  awm_ctx_destroy (awm_ctx *ctx);
+int   awm_ctx_device (const awm_ctx *ctx);
+int   awm_ctx_synchronize (awm_ctx *ctx);
+/* opaque hipStream_t of the context (for callers that bracket work with HIP events) */
+void *awm_ctx_stream (awm_ctx *ctx);
+/* run all work of this context on an externally owned hipStream_t (e.g. torch's current stream) */
+int   awm_ctx_set_stream (awm_ctx *ctx, void *hip_stream);
+
+/* ---- key-derived tables (pure host, callable without a GPU) -------------------------- */
+/* replaces: UpDownGen::get wmcommon.hh:107-122; BitPosGen wmcommon.cc:143-165;
+ *           gen_mix_entries wmcommon.cc:179-202; init_frame_mod_vec wmadd.cc:148-162;
+ *           SyncFinder::get_sync_bits syncfinder.cc:30-77; randomize_bit_order wmcommon.hh:165-185 */
+int awm_tab_up_down (const uint8_t key[16], int stream, int frame, int up[30], int down[30]);
+int awm_tab_bit_pos (const uint8_t key[16], int pos[AWM_BLOCK_FRAMES]);
+int awm_tab_mix_entries (const uint8_t key[16], int *frame_up_down /* [51480*3] */);
+int awm_tab_bit_order (const uint8_t key[16], size_t n, unsigned *order);
+/* out[2][2226][81]: 0 KEEP / 1 UP / 2 DOWN for the A and the B block */
+int awm_tab_frame_mod (const uint8_t key[16], const char *payload_hex, int8_t *out);
+/* out rows: frame, up[30], down[30] (band-20, ascending); returns rows per bit (85 / 170) */
+int awm_tab_sync_bits (const uint8_t key[16], int clip_mode, int *out /* [6*rows*61] */);
+int awm_tab_window (size_t n, float *out);                    /* FFTAnalyzer::gen_normalized_window wmcommon.cc:68-89 */
+int awm_tab_synth_window (float *out /* [3072] */);           /* WatermarkSynth::generate_window wmadd.cc:177-206 */
+int awm_conv_encode (int block_type, const int *bits, size_t n, int *out); /* conv_encode convcode.cc:100-125 */
+
+/* ---- kernel level (device pointers) --------------------------------------------------- */
+
+/* FFTAnalyzer::run_fft / fft_range (wmcommon.cc:91-141): `frame_count` windowed 1024-point
+ * r2c transforms per channel, frame f starting at sample start_index + f*hop.
+ * out_d: [frame_count][n_channels][513] complex64 (re,im).  Fails if the range exceeds n_frames. */
+int awm_stft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels,
+                size_t start_index, size_t hop, size_t frame_count, float *out_d);
+
+/* add: WatermarkGen::run + WatermarkSynth::run + mix + Limiter (wmadd.cc:61-84,215-250,297-317,
+ * 564-568; limiter.cc:90-124) for a contiguous span of the stream.
+ *   frame_mod:        host table from awm_tab_frame_mod ([2][2226][81])
+ *   first_frame:      index (in 1024-sample frames) of pcm_in_d[0] inside the whole stream; spans
+ *                     are how awm shards `add` across GPUs.  The span must start on a frame boundary.
+ *   halo_before_d / halo_after_d: the 1024*C samples preceding / following the span (NULL = stream
+ *                     start / zeros after the end), needed for the 3-frame overlap-add (wmadd.cc:228-238)
+ *   use_limiter:      0 = Params::test_no_limiter
+ * awm_add_mix_d writes the un-limited mix to out_d and accumulates per-limiter-block maxima into
+ * block_max_d[b] (b = global limiter block index - first_block, float32, pre-initialised by
+ * awm_add_init_block_max_d); awm_add_limit_d applies the limiter ramp in place.  Between the two a
+ * multi-GPU caller all-reduces (max) block_max_d.  awm_add_d = both, single GPU. */
+int awm_add_init_block_max_d (awm_ctx *ctx, float *block_max_d, size_t n_blocks);
+int awm_add_mix_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
+                   const int8_t *frame_mod, double water_delta, size_t first_frame,
+                   const float *halo_before_d, const float *halo_after_d,
+                   float *block_max_d /* may be NULL: no limiter */, size_t first_block, size_t n_blocks);
+int awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels, size_t first_sample,
+                     const float *block_max_d, size_t first_block, size_t n_blocks);
+int awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
+               const int8_t *frame_mod, double water_delta, int use_limiter);
+
+/* SyncFinder::sync_fft (syncfinder.cc:560-605): dB magnitudes of bins 20..100, channels summed.
+ * db_out_d: [frame_count][81] float32, have_out_d: [frame_count] bytes.
+ * want_frames (host, may be NULL) and [first,last) (value indices of the non-silent range,
+ * syncfinder.cc:155-169) reproduce the reference's skip rules. */
+int awm_sync_fft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels,
+                    size_t index, size_t frame_count, const char *want_frames,
+                    size_t first, size_t last, float *db_out_d, char *have_out_d);
+
+/* SyncFinder::search (syncfinder.cc:487-558) for one key: search_approx on the 4 shifts,
+ * local mean, peak selection, search_refine, final selection.  Returns the number of scores
+ * (<= max_out), sorted by index.  block_type: 0 = A, 1 = B. */
+int awm_sync_search_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
+                       int n_channels, int clip_mode, size_t max_out,
+                       uint64_t *index, double *quality, int *block_type);
+/* search_approx only (syncfinder.cc:171-256): all candidate scores in index order */
+long awm_search_approx_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
+                          int n_channels, int clip_mode, size_t max_out,
+                          uint64_t *index, double *raw_quality, double *local_mean);
+
+/* FFTAnalyzer::fft_range(index, 2226) + mix_decode (wmget.cc:67-108) for `n_blocks` block
+ * start indices: raw soft bits in mix order, out[n_blocks][858].  ok[i] = 0 where the block
+ * would read past the end (fft_range returns empty, wmcommon.cc:128-130). */
+int awm_block_soft_bits_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
+                           int n_channels, const uint64_t *index, size_t n_blocks, float *out, int *ok);
+
+/* conv_decode_soft (convcode.cc:128-213) for a batch of equally typed blocks.
+ * soft: [n][coded_len] normalised soft bits; bits_out: [n][coded_len/rate - 15]; error_out[n]. */
+int awm_viterbi_decode (awm_ctx *ctx, int block_type, const float *soft, size_t coded_len, size_t n,
+                        int *bits_out, float *error_out);
+
+/* ---- pipeline level ------------------------------------------------------------------- */
+typedef struct
+{
+  double   time;           /* seconds, incl. chunk offset */
+  uint64_t sync_index;     /* sample index inside its chunk */
+  double   sync_quality;
+  int      block_type;     /* 0 A, 1 B, 2 AB */
+  int      type;           /* 0 BLOCK, 1 CLIP, 2 ALL */
+  float    decode_error;
+  double   speed;
+  int      bits[128];
+  int      n_bits;
+} awm_pattern;
+
+/* add_watermark core (wmadd.cc:448-618) on resident PCM: out_d gets n_frames*C samples */
+int awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex,
+                         const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
+                         int sample_rate);
+/* get_watermark core (wmget.cc:886-1013) on resident 44.1 kHz PCM: chunk loop, BlockDecoder,
+ * ClipDecoder, merge + sort.  Returns the pattern count (<= max_out filled). */
+int awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
+                         int n_channels, size_t max_out, awm_pattern *out);
+/* decode() of one chunk only (wmget.cc:886-939) -- the unit `get` is sharded by */
+int awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
+                        int n_channels, int first_chunk, size_t max_out, awm_pattern *out);
+
+/* global parameters (reference Params, wmcommon.hh:33-89) */
+void awm_set_params (double water_delta, int mix, int frames_per_bit, int test_no_limiter,
+                     double sync_threshold2, int n_best, double chunk_size_min);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AWM_HIP_H */
