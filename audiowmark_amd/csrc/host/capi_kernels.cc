@@ -95,6 +95,7 @@ awm_stft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, s
       set_error ("awm_stft_d: range exceeds the data");
       return AWM_ERR_ARG;
     }
+  ProfScope ps (ctx, PROF_STFT, double (frame_count) * n_channels * 8200.0);
   AWM_HIP_CHECK (awmk::launch_stft_full (ctx->stream, ctx->tabs, pcm_d, n_channels, (long long) start_index, (long long) hop,
                                          (long long) frame_count, reinterpret_cast<float2 *> (out_d)));
   return 0;
@@ -132,6 +133,7 @@ add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames
   a.n_blocks = (long long) n_blocks;
   a.limiter_block = LIMITER_BLOCK;
   a.frames_per_span = frames_per_span ((long long) (n_frames + 1023) / 1024);
+  ProfScope ps (ctx, PROF_ADD_MIX, double (n_frames) * n_channels * 8.0);     // read + write every sample once
   AWM_HIP_CHECK (awmk::launch_add_mix (ctx->stream, ctx->tabs, a));
   return 0;
 }
@@ -160,6 +162,7 @@ awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels, si
                  const float *block_max_d, size_t first_block, size_t n_blocks)
 {
   if (int rc = check_ctx (ctx)) return rc;
+  ProfScope ps (ctx, PROF_LIMITER, double (n_frames) * n_channels * 8.0);
   AWM_HIP_CHECK (awmk::launch_limiter (ctx->stream, out_d, (long long) n_frames, n_channels, (long long) first_sample, block_max_d,
                                        (long long) first_block, (long long) n_blocks, LIMITER_BLOCK, LIMITER_CEILING));
   return 0;

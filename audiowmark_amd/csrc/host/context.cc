@@ -142,7 +142,64 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
   return frame_mod_tables.back().get();
 }
 
+void
+awm_ctx::prof_collect()
+{
+  for (auto& p : prof_pending)
+    {
+      float ms = 0;
+      if (hipEventSynchronize (p.stop) == hipSuccess && hipEventElapsedTime (&ms, p.start, p.stop) == hipSuccess)
+        prof_ms[p.id] += ms;
+      (void) hipEventDestroy (p.start);
+      (void) hipEventDestroy (p.stop);
+    }
+  prof_pending.clear();
+}
+
+static const char *prof_names[awm::PROF_COUNT] = {
+  "add_mix_kernel", "limiter_kernel", "sync_db_kernel(approx)", "sync_scan_kernel(approx)", "local_mean_kernel",
+  "sync_db_kernel(refine)", "sync_scan_kernel(refine)", "sync_db_kernel(block)", "soft_bits_kernel", "viterbi_kernel",
+  "stft_full_kernel"
+};
+
 extern "C" {
+
+int
+awm_prof_enable (awm_ctx *ctx, int on)
+{
+  if (!ctx) return AWM_ERR_ARG;
+  ctx->prof_collect();
+  ctx->prof_enabled = on != 0;
+  return 0;
+}
+
+int
+awm_prof_reset (awm_ctx *ctx)
+{
+  if (!ctx) return AWM_ERR_ARG;
+  ctx->prof_collect();
+  for (int i = 0; i < awm::PROF_COUNT; i++)
+    {
+      ctx->prof_ms[i] = 0;
+      ctx->prof_launches[i] = 0;
+      ctx->prof_bytes[i] = 0;
+    }
+  return 0;
+}
+
+int awm_prof_count (void) { return awm::PROF_COUNT; }
+const char *awm_prof_name (int id) { return id >= 0 && id < awm::PROF_COUNT ? prof_names[id] : ""; }
+
+int
+awm_prof_read (awm_ctx *ctx, int id, double *ms, long *launches, double *algorithmic_bytes)
+{
+  if (!ctx || id < 0 || id >= awm::PROF_COUNT) return AWM_ERR_ARG;
+  ctx->prof_collect();
+  if (ms) *ms = ctx->prof_ms[id];
+  if (launches) *launches = ctx->prof_launches[id];
+  if (algorithmic_bytes) *algorithmic_bytes = ctx->prof_bytes[id];
+  return 0;
+}
 
 const char *awm_last_error (void) { return awm::last_error().c_str(); }
 const char *awm_version (void) { return "audiowmark_amd 0.1 (gfx950)"; }

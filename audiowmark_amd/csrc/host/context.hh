@@ -53,6 +53,13 @@ struct FrameModTable
 
 } // namespace awm
 
+namespace awm {
+// per-kernel timing with HIP events on the context's stream (awm_prof_* in awm_hip.h)
+enum ProfId { PROF_ADD_MIX, PROF_LIMITER, PROF_SYNC_DB, PROF_SYNC_SCAN, PROF_LOCAL_MEAN, PROF_REFINE_DB, PROF_REFINE_SCAN,
+              PROF_BLOCK_DB, PROF_SOFT_BITS, PROF_VITERBI, PROF_STFT, PROF_COUNT };
+struct ProfPending { int id; hipEvent_t start, stop; };
+}
+
 struct awm_ctx
 {
   int            device = -1;
@@ -68,8 +75,44 @@ struct awm_ctx
   awm::DevBuffer ws_db, ws_have, ws_q, ws_raw, ws_mean, ws_misc, ws_refine, ws_refine_have, ws_soft,
                  ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx;
 
+  // profiling
+  bool   prof_enabled = false;
+  std::vector<awm::ProfPending> prof_pending;
+  double prof_ms[awm::PROF_COUNT] = { 0 };
+  long   prof_launches[awm::PROF_COUNT] = { 0 };
+  double prof_bytes[awm::PROF_COUNT] = { 0 };
+  void   prof_collect();
+
   awm::KeyTables     *get_key_tables (const awm::Key& key);
   awm::FrameModTable *get_frame_mod (const awm::Key& key, const std::string& payload_hex);
 };
 
 #include "../../../include/awm_hip.h"
+
+namespace awm {
+// brackets the launches issued during its lifetime with two events (only when profiling is on)
+struct ProfScope
+{
+  awm_ctx *ctx;
+  int      id;
+  hipEvent_t start = nullptr;
+  ProfScope (awm_ctx *c, int i, double algorithmic_bytes) : ctx (c), id (i)
+  {
+    if (!ctx->prof_enabled)
+      return;
+    ctx->prof_bytes[id] += algorithmic_bytes;
+    ctx->prof_launches[id]++;
+    if (hipEventCreate (&start) != hipSuccess) { start = nullptr; return; }
+    (void) hipEventRecord (start, ctx->stream);
+  }
+  ~ProfScope()
+  {
+    if (!start)
+      return;
+    hipEvent_t stop = nullptr;
+    if (hipEventCreate (&stop) != hipSuccess) { (void) hipEventDestroy (start); return; }
+    (void) hipEventRecord (stop, ctx->stream);
+    ctx->prof_pending.push_back ({ id, start, stop });
+  }
+};
+}

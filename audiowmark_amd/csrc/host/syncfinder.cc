@@ -66,7 +66,10 @@ SyncFinder::search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
   da.first = (long long) m_first;
   da.last = (long long) m_last;
   da.tile_frames = 64;
-  AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+  {
+    ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_shifts) * n_db * (4096.0 * wav.n_channels + 324.0));
+    AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+  }
 
   awmk::SyncScanArgs sa {};
   sa.db = m_ctx->ws_db.as<float>();
@@ -83,8 +86,15 @@ SyncFinder::search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
   sa.q_stride = q_stride;
   sa.table.packed = kt->sync[clip].packed_approx.as<int>();
   sa.table.rows_per_bit = kt->sync[clip].host.rows_per_bit;
-  AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
-  AWM_HIP_CHECK (awmk::launch_local_mean (st, m_ctx->ws_q.as<double>(), q_stride, S, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>()));
+  {
+    // algorithmic HBM bytes of the scan: the dB matrix once, candidates re-read it from cache
+    ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0);
+    AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+  }
+  {
+    ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_shifts) * S * 24.0);
+    AWM_HIP_CHECK (awmk::launch_local_mean (st, m_ctx->ws_q.as<double>(), q_stride, S, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>()));
+  }
 
   std::vector<double> raw (n_shifts * S), mean (n_shifts * S);
   AWM_HIP_CHECK (hipMemcpyAsync (raw.data(), m_ctx->ws_raw.ptr, raw.size() * sizeof (double), hipMemcpyDeviceToHost, st));
@@ -251,7 +261,18 @@ SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
           da.first = (long long) m_first;
           da.last = (long long) m_last;
           da.tile_frames = TP;
-          AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+          long long n_items = 0;
+          for (size_t c = 0; c < nb; c++)
+            n_items += (long long) lane_count[c] * NW;
+          {
+            // per (candidate, sync frame): a (1024 + 8 (T - 1))-sample window read once, T rows of 81 dB values written
+            double bytes = 0;
+            for (size_t c = 0; c < nb; c++)
+              if (lane_count[c])
+                bytes += double (NW) * ((1024.0 + 8.0 * (lane_count[c] - 1)) * 4 * wav.n_channels + 324.0 * lane_count[c]);
+            ProfScope ps (m_ctx, PROF_REFINE_DB, bytes);
+            AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+          }
 
           awmk::SyncScanArgs sa {};
           sa.db = m_ctx->ws_refine.as<float>();
@@ -269,7 +290,10 @@ SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
           sa.q_stride = QS;
           sa.table.packed = sync.packed_refine.as<int>();
           sa.table.rows_per_bit = sync.host.rows_per_bit;
-          AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+          {
+            ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 324.0);
+            AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+          }
           AWM_HIP_CHECK (hipMemcpyAsync (q.data(), m_ctx->ws_q.ptr, q.size() * sizeof (double), hipMemcpyDeviceToHost, st));
         }
       AWM_HIP_CHECK (hipStreamSynchronize (st));

@@ -293,7 +293,10 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
       da.first = 0;
       da.last = (long long) wav.n_values();      // mix_decode uses plain run_fft: no silence skipping
       da.tile_frames = 64;
-      AWM_HIP_CHECK (awmk::launch_sync_db (st, ctx->tabs, da));
+      {
+        ProfScope ps (ctx, PROF_BLOCK_DB, double (nb) * count * C * (4096.0 + 324.0));
+        AWM_HIP_CHECK (awmk::launch_sync_db (st, ctx->tabs, da));
+      }
 
       awmk::SoftBitsArgs sb {};
       sb.db = ctx->ws_db.as<float>();
@@ -308,7 +311,10 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
       sb.block_frames = int (count);
       sb.n_blocks = (long long) nb;
       sb.out = ctx->ws_soft.as<float>();
-      AWM_HIP_CHECK (awmk::launch_soft_bits (st, sb));
+      {
+        ProfScope ps (ctx, PROF_SOFT_BITS, double (nb) * count * C * 324.0);
+        AWM_HIP_CHECK (awmk::launch_soft_bits (st, sb));
+      }
       std::vector<float> host (nb * n_bits);
       AWM_HIP_CHECK (hipMemcpyAsync (host.data(), ctx->ws_soft.ptr, host.size() * sizeof (float), hipMemcpyDeviceToHost, st));
       AWM_HIP_CHECK (hipStreamSynchronize (st));
@@ -350,8 +356,11 @@ viterbi_decode (awm_ctx *ctx, ConvBlockType block_type, const std::vector<std::v
       if (int rc = ctx->ws_viterbi_bits.reserve (nb * n_out * sizeof (int))) return rc;
       if (int rc = ctx->ws_viterbi_err.reserve (nb * sizeof (float))) return rc;
       AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_viterbi_in.ptr, flat.data(), flat.size() * sizeof (float), hipMemcpyHostToDevice, st));
-      AWM_HIP_CHECK (awmk::launch_viterbi (st, ctx->ws_viterbi_in.as<float>(), rate, gens.data(), coded_len, nb,
-                                           ctx->ws_viterbi.as<unsigned char>(), ctx->ws_viterbi_bits.as<int>(), ctx->ws_viterbi_err.as<float>()));
+      {
+        ProfScope ps (ctx, PROF_VITERBI, double (nb) * (coded_len * 4.0 + 2.0 * awmk::viterbi_workspace_bytes (coded_len, rate, 1)));
+        AWM_HIP_CHECK (awmk::launch_viterbi (st, ctx->ws_viterbi_in.as<float>(), rate, gens.data(), coded_len, nb,
+                                             ctx->ws_viterbi.as<unsigned char>(), ctx->ws_viterbi_bits.as<int>(), ctx->ws_viterbi_err.as<float>()));
+      }
       std::vector<int> hbits (nb * n_out);
       AWM_HIP_CHECK (hipMemcpyAsync (hbits.data(), ctx->ws_viterbi_bits.ptr, hbits.size() * sizeof (int), hipMemcpyDeviceToHost, st));
       AWM_HIP_CHECK (hipMemcpyAsync (errors.data() + b0, ctx->ws_viterbi_err.ptr, nb * sizeof (float), hipMemcpyDeviceToHost, st));

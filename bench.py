@@ -1,0 +1,187 @@
+#!/usr/bin/env python3
+"""bench.py -- audio seconds watermarked + decoded per wall-second (xRT), 44.1 kHz stereo.
+
+One step = `add` (STFT -> band edit -> inverse -> overlap-add -> mix -> limiter) followed by `get`
+(chunked SyncFinder search + refine, soft-bit extraction, Viterbi, merge) over one synthetic
+60-minute stereo stream that is already resident in HBM (BASELINE.json configs[1]).
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+With N > 1 the stream is N x 60 minutes long and sharded across the ranks (audiowmark_amd.sharded:
+frame spans for `add` with a 1-frame halo exchange and an all-reduce(max) of the limiter maxima,
+reference chunks for `get` with an overlap exchange and a gather of the found patterns) -> weak scaling.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest share of GPU time,
+timed live with HIP events on the context's stream; `cpu_baseline` times the compiled reference
+(oracle/_ref, kind "reference") or the restatement (oracle/, kind "port") on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+PAYLOAD = "0123456789abcdef0011223344556677"
+RATE = 44100
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def cpu_baseline(sample_seconds):
+    """Reference CPU path on a bounded sample of the same workload (stereo white noise)."""
+    import numpy as np
+    try:
+        import _ref
+        have_ref = _ref.available()
+    except Exception:
+        have_ref = False
+    kind = None
+    if have_ref:
+        impl, kind = _ref, "reference"
+    else:
+        try:
+            import _oracle
+            impl, kind = _oracle, "port"
+        except Exception:
+            return None
+    rng = np.random.default_rng(7)
+    n = int(sample_seconds * RATE)
+    x = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    t0 = time.perf_counter()
+    w = impl.add(None, x, 2, PAYLOAD)
+    t1 = time.perf_counter()
+    pats = impl.get(None, w, 2)
+    t2 = time.perf_counter()
+    ok = any(p["bits"] == PAYLOAD for p in pats)
+    cores = os.cpu_count() if kind == "reference" else 1
+    return {"value": round(sample_seconds / (t2 - t0), 2), "unit": "xRT", "cores": cores, "kind": kind,
+            "sample": f"{sample_seconds:.0f} s stereo 44.1 kHz white noise, add {t1 - t0:.2f} s (1 thread) + get {t2 - t1:.2f} s "
+                      f"({cores} threads), payload recovered={ok}; FFTW replaced by the oracle's double-precision FFT"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per GPU")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=200.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import audiowmark_amd as awm
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the watermark path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = int(args.minutes * 60 * RATE)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    x = torch.rand((n, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1   # test-gen-noise distribution
+    out = torch.empty_like(x)
+    ctx = awm.Context(local_rank)
+
+    if world > 1:
+        from audiowmark_amd import sharded
+        pipe = sharded.ShardedStream(ctx, dist, n_frames_local=n, n_channels=2)
+
+        def step():
+            pipe.add_watermark(None, PAYLOAD, x, out)
+            return pipe.get_watermark(None, out)
+    else:
+        def step():
+            ctx.add_watermark(None, PAYLOAD, x, out=out)
+            return ctx.get_watermark(None, out)
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    awm.lib.awm_prof_reset(ctx._h)
+    awm.lib.awm_prof_enable(ctx._h, 1)
+    sync()
+    t0 = time.perf_counter()
+    pats = None
+    for _ in range(args.steps):
+        pats = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    awm.lib.awm_prof_enable(ctx._h, 0)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel HIP-event times of the timed region (this rank)
+    import ctypes as C
+    prof = []
+    for i in range(awm.lib.awm_prof_count()):
+        ms, launches, nbytes = C.c_double(), C.c_long(), C.c_double()
+        awm.lib.awm_prof_read(ctx._h, i, C.byref(ms), C.byref(launches), C.byref(nbytes))
+        if launches.value:
+            prof.append((i, ms.value, launches.value, nbytes.value))
+    awm.lib.awm_prof_name.restype = C.c_char_p
+    prof = [(awm.lib.awm_prof_name(i).decode(), ms, l, b) for (i, ms, l, b) in prof]
+
+    if rank == 0:
+        audio_seconds = args.minutes * 60 * world
+        matches = sum(1 for p in (pats or []) if p["bits"] == PAYLOAD)
+        total_ms = sum(p[1] for p in prof) or 1.0
+        dom = max(prof, key=lambda p: p[1]) if prof else None
+        roofline = None
+        if dom:
+            name, ms, launches, nbytes = dom
+            achieved = nbytes / (ms * 1e-3) / 1e9        # algorithmic GB/s: sum(bytes)/sum(time) == per-launch bytes / avg duration
+            roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "launches": launches, "avg_ms": round(ms / launches, 4),
+                        "share_of_gpu_time": round(ms / total_ms, 3)}
+        res = {
+            "metric": "audio seconds watermarked+decoded per wall-second (xRT), 44.1 kHz stereo",
+            "value": round(audio_seconds * args.steps / elapsed, 1),
+            "unit": "xRT",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"{args.minutes:g} min stereo 44.1 kHz white noise per GPU resident in HBM, add+get incl. payload decode, "
+                                   f"payload {PAYLOAD}, strength 10", "parallelism": f"stream sharded over {world} GPU(s)" if world > 1 else "1 GPU",
+                       "patterns": len(pats or []), "payload_matches": matches},
+            "roofline": roofline,
+            "kernels_ms_per_step": {p[0]: round(p[1] / args.steps, 3) for p in prof},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds)
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -50,6 +50,15 @@ void *awm_ctx_stream (awm_ctx *ctx);
 /* run all work of this context on an externally owned hipStream_t (e.g. torch's current stream) */
 int   awm_ctx_set_stream (awm_ctx *ctx, void *hip_stream);
 
+/* ---- per-kernel timing: HIP events recorded on the context's stream around every launch.
+ * ids 0..awm_prof_count()-1, awm_prof_name(id) is the kernel name as rocprofv3 shows it (plus the
+ * call site in brackets); algorithmic_bytes = SURVEY.md section 8(d) bytes summed over the launches. */
+int         awm_prof_enable (awm_ctx *ctx, int on);
+int         awm_prof_reset (awm_ctx *ctx);
+int         awm_prof_count (void);
+const char *awm_prof_name (int id);
+int         awm_prof_read (awm_ctx *ctx, int id, double *ms, long *launches, double *algorithmic_bytes);
+
 /* ---- key-derived tables (pure host, callable without a GPU) -------------------------- */
 /* replaces: UpDownGen::get wmcommon.hh:107-122; BitPosGen wmcommon.cc:143-165;
  *           gen_mix_entries wmcommon.cc:179-202; init_frame_mod_vec wmadd.cc:148-162;
