@@ -82,6 +82,11 @@ lib.awm_tab_synth_window.argtypes = [_vp]
 lib.awm_conv_encode.argtypes = [C.c_int, _vp, C.c_size_t, _vp]
 
 
+lib.awm_plan_chunks.argtypes = [C.c_size_t, C.c_size_t, _vp, _vp, _vp]
+lib.awm_merge_patterns.argtypes = [_vp, _vp, _vp, C.c_int, C.c_size_t, _vp]
+lib.awm_prof_name.restype = C.c_char_p
+
+
 def _check(rc, what):
     if rc < 0:
         raise AwmError(f"{what} failed (rc={rc}): {lib.awm_last_error().decode(errors='replace')}")
@@ -113,6 +118,46 @@ def set_params(water_delta=0.01, mix=True, frames_per_bit=2, test_no_limiter=Fal
                chunk_size_min=30.0):
     lib.awm_set_params(water_delta, int(mix), frames_per_bit, int(test_no_limiter), sync_threshold2, n_best,
                        chunk_size_min)
+
+
+def plan_chunks(n_frames):
+    """WavChunkLoader chunking (host only): list of (first_frame, n_frames, time_offset_seconds)."""
+    mx = 4096
+    a = np.zeros(mx, np.uint64)
+    b = np.zeros(mx, np.uint64)
+    t = np.zeros(mx, np.float64)
+    n = lib.awm_plan_chunks(n_frames, mx, _np(a), _np(b), _np(t))
+    return [(int(a[i]), int(b[i]), float(t[i])) for i in range(n)]
+
+
+def _pattern_from_dict(d):
+    p = Pattern()
+    p.time = d["time"]
+    p.sync_index = d["sync_index"]
+    p.sync_quality = d["sync_quality"]
+    p.block_type = d["block_type"]
+    p.type = d["type"]
+    p.decode_error = d["decode_error"]
+    p.speed = d["speed"]
+    bits = []
+    for ch in d["bits"]:
+        v = int(ch, 16)
+        bits += [(v >> 3) & 1, (v >> 2) & 1, (v >> 1) & 1, v & 1]
+    p.n_bits = len(bits)
+    for i, b in enumerate(bits):
+        p.bits[i] = b
+    return p
+
+
+def merge_patterns(key, per_chunk):
+    """ResultSet.merge + sort over per-chunk pattern lists (times already offset), host only."""
+    flat = [_pattern_from_dict(d) for chunk in per_chunk for d in chunk]
+    counts = np.array([len(c) for c in per_chunk], np.int32)
+    arr = (Pattern * max(1, len(flat)))(*flat)
+    mx = max(1, len(flat))
+    out = (Pattern * mx)()
+    n = lib.awm_merge_patterns(key_bytes(key), C.cast(arr, C.c_void_p), _np(counts), len(per_chunk), mx, C.cast(out, C.c_void_p))
+    return [out[i].as_dict() for i in range(min(n, mx))]
 
 
 # ---- key-derived tables (host only) ---------------------------------------------------------

@@ -409,6 +409,44 @@ awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, si
 }
 
 int
+awm_plan_chunks (size_t n_frames, size_t max_out, uint64_t *first_frame, uint64_t *chunk_frames, double *time_offset)
+{
+  const auto chunks = plan_chunks (n_frames, 1);
+  for (size_t i = 0; i < chunks.size() && i < max_out; i++)
+    {
+      first_frame[i] = chunks[i].first_frame;
+      chunk_frames[i] = chunks[i].n_frames;
+      time_offset[i] = chunks[i].time_offset;
+    }
+  return int (chunks.size());
+}
+
+int
+awm_merge_patterns (const uint8_t key[16], const awm_pattern *patterns, const int *chunk_count, int n_chunks,
+                    size_t max_out, awm_pattern *out)
+{
+  const Key k = capi_key (key);
+  ResultSet result;
+  size_t pos = 0;
+  for (int c = 0; c < n_chunks; c++)
+    {
+      ResultSet chunk;
+      for (int i = 0; i < chunk_count[c]; i++, pos++)
+        {
+          const awm_pattern& p = patterns[pos];
+          SyncFinder::Score score { size_t (p.sync_index), p.sync_quality, ConvBlockType (p.block_type) };
+          chunk.add_pattern (k, p.time, score, std::vector<int> (p.bits, p.bits + p.n_bits), p.decode_error,
+                             ResultSet::Type (p.type), p.speed);
+        }
+      result.merge (chunk);
+    }
+  result.sort ({ k });
+  for (size_t i = 0; i < result.patterns.size() && i < max_out; i++)
+    fill_pattern (result.patterns[i], out[i]);
+  return int (result.patterns.size());
+}
+
+int
 awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
                     int first_chunk, size_t max_out, awm_pattern *out)
 {

@@ -161,6 +161,17 @@ int awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d
 int awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
                         int n_channels, int first_chunk, size_t max_out, awm_pattern *out);
 
+/* chunk plan of WavChunkLoader (wavchunkloader.cc:54-163) for a stream of n_frames samples per channel:
+ * chunk i covers [first_frame[i], first_frame[i] + chunk_frames[i]) and reports times offset by
+ * time_offset[i] seconds.  Pure host.  Returns the chunk count (<= max_out filled).  The chunks are the
+ * unit `get` is sharded by across GPUs. */
+int awm_plan_chunks (size_t n_frames, size_t max_out, uint64_t *first_frame, uint64_t *chunk_frames, double *time_offset);
+/* ResultSet::merge + sort (wmget.cc:215-316) over per-chunk pattern lists that were decoded elsewhere
+ * (other ranks): `patterns` holds the chunks' patterns back to back in chunk order with times already
+ * offset, chunk_count[i] patterns for chunk i.  Result written to out (<= max_out), count returned. */
+int awm_merge_patterns (const uint8_t key[16], const awm_pattern *patterns, const int *chunk_count, int n_chunks,
+                        size_t max_out, awm_pattern *out);
+
 /* global parameters (reference Params, wmcommon.hh:33-89) */
 void awm_set_params (double water_delta, int mix, int frames_per_bit, int test_no_limiter,
                      double sync_threshold2, int n_best, double chunk_size_min);

@@ -1,0 +1,238 @@
+"""ctypes view of oracle/libawm_oracle.so -- the CPU restatement (oracle/awm_oracle.cc) built by
+oracle/Makefile.  TEST INFRASTRUCTURE ONLY.  Built on demand with `make -C oracle restate` (g++ only)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PATH = os.path.join(ROOT, "oracle", "libawm_oracle.so")
+
+_lib = None
+
+
+def available():
+    if not os.path.exists(PATH):
+        import subprocess
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "restate"], check=False, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+    return os.path.exists(PATH)
+
+
+class Pattern(C.Structure):
+    _fields_ = [("time", C.c_double), ("sync_index", C.c_uint64), ("sync_quality", C.c_double),
+                ("block_type", C.c_int), ("type", C.c_int), ("decode_error", C.c_float), ("speed", C.c_double),
+                ("bits", C.c_int * 128), ("n_bits", C.c_int)]
+
+    def hex(self):
+        b = list(self.bits[:self.n_bits])
+        return "".join("%x" % (b[i] * 8 + b[i + 1] * 4 + b[i + 2] * 2 + b[i + 3]) for i in range(0, len(b) - 3, 4))
+
+    def as_dict(self):
+        return dict(time=self.time, sync_index=int(self.sync_index), sync_quality=self.sync_quality,
+                    block_type=self.block_type, type=self.type, decode_error=self.decode_error, speed=self.speed,
+                    bits=self.hex())
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not available():
+            raise RuntimeError("oracle/libawm_oracle.so cannot be built")
+        _lib = C.CDLL(PATH)
+        _lib.orc_sync_decode.restype = C.c_double
+        _lib.orc_mix_entries.restype = C.c_size_t
+        _lib.orc_conv_encode.restype = C.c_size_t
+        _lib.orc_conv_decode_soft.restype = C.c_size_t
+        _lib.orc_search_approx.restype = C.c_size_t
+        _lib.orc_set_params.argtypes = [C.c_double, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_double]
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _key(key):
+    return bytes(16) if key is None else bytes(key)
+
+
+def set_params(water_delta=0.01, mix=True, frames_per_bit=2, test_no_limiter=False, sync_threshold2=0.35, n_best=8,
+               chunk_size_min=30.0):
+    lib().orc_set_params(water_delta, int(mix), frames_per_bit, int(test_no_limiter), sync_threshold2, n_best, chunk_size_min)
+
+
+def random_u64(key, seed, stream, n):
+    out = np.zeros(n, np.uint64)
+    lib().orc_random_u64(_key(key), C.c_uint64(seed), stream, C.c_size_t(n), _p(out))
+    return out
+
+
+def random_double(key, seed, stream, n):
+    out = np.zeros(n, np.float64)
+    lib().orc_random_double(_key(key), C.c_uint64(seed), stream, C.c_size_t(n), _p(out))
+    return out
+
+
+def gen_noise(key, n_values):
+    out = np.zeros(n_values, np.float32)
+    lib().orc_gen_noise(_key(key), C.c_size_t(n_values), _p(out))
+    return out
+
+
+def up_down(key, stream, f):
+    up = np.zeros(30, np.int32)
+    down = np.zeros(30, np.int32)
+    lib().orc_up_down(_key(key), stream, f, _p(up), _p(down))
+    return up, down
+
+
+def bit_pos(key):
+    out = np.zeros(2226, np.int32)
+    lib().orc_bit_pos(_key(key), _p(out))
+    return out
+
+
+def mix_entries(key):
+    out = np.zeros((51480, 3), np.int32)
+    n = lib().orc_mix_entries(_key(key), _p(out))
+    return out[:n]
+
+
+def window(n):
+    out = np.zeros(n, np.float32)
+    lib().orc_window(C.c_size_t(n), _p(out))
+    return out
+
+
+def synth_window():
+    out = np.zeros(3072, np.float32)
+    lib().orc_synth_window(_p(out))
+    return out
+
+
+def bit_order(key, n):
+    out = np.zeros(n, np.uint32)
+    lib().orc_bit_order(_key(key), C.c_size_t(n), _p(out))
+    return out
+
+
+def conv_encode(block_type, bits):
+    bits = np.ascontiguousarray(bits, np.int32)
+    out = np.zeros((len(bits) + 15) * 12, np.int32)
+    n = lib().orc_conv_encode(block_type, _p(bits), C.c_size_t(len(bits)), _p(out))
+    return out[:n]
+
+
+def conv_decode_soft(block_type, coded):
+    coded = np.ascontiguousarray(coded, np.float32)
+    out = np.zeros(len(coded), np.int32)
+    err = C.c_float()
+    n = lib().orc_conv_decode_soft(block_type, _p(coded), C.c_size_t(len(coded)), _p(out), C.byref(err))
+    return out[:n], err.value
+
+
+def frame_mod(key, payload_hex, ab):
+    out = np.zeros((2226, 101), np.uint8)
+    n = lib().orc_frame_mod(_key(key), payload_hex.encode(), ab, _p(out))
+    assert n == 2226
+    return out
+
+
+def sync_bits(key, clip_mode=False):
+    rows = 170 if clip_mode else 85
+    out = np.zeros((6, rows, 61), np.int32)
+    r = lib().orc_sync_bits(_key(key), int(clip_mode), _p(out))
+    assert r == rows
+    return out
+
+
+def fft_range(samples, n_channels, start_index, frame_count):
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    out = np.zeros((frame_count, n_channels, 513, 2), np.float32)
+    r = lib().orc_fft_range(_p(samples), C.c_size_t(samples.size), n_channels, C.c_size_t(start_index),
+                            C.c_size_t(frame_count), _p(out))
+    return out if r else None
+
+
+def ifft(spect):
+    spect = np.ascontiguousarray(spect, np.float32)
+    n = (spect.shape[0] - 1) * 2
+    out = np.zeros(n, np.float32)
+    lib().orc_ifft(C.c_size_t(n), _p(spect), _p(out))
+    return out
+
+
+def add(key, samples, n_channels, payload_hex, sample_rate=44100):
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    n_frames = samples.size // n_channels
+    out = np.zeros(samples.size + 4096 * n_channels, np.float32)
+    of = C.c_size_t()
+    rc = lib().orc_add(_key(key), _p(samples), C.c_size_t(n_frames), n_channels, sample_rate, payload_hex.encode(), _p(out),
+                       C.byref(of), None)
+    assert rc == 0
+    return out[:of.value * n_channels]
+
+
+def sync_fft(samples, n_channels, index, frame_count, want_frames=None, first=0, last=None):
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    if last is None:
+        last = samples.size
+    db = np.zeros((frame_count, 81), np.float32)
+    have = np.zeros(frame_count, np.int8)
+    want = None if want_frames is None else np.ascontiguousarray(want_frames, np.int8)
+    n = lib().orc_sync_fft(_p(samples), C.c_size_t(samples.size), n_channels, C.c_size_t(index), C.c_size_t(frame_count),
+                           _p(want) if want is not None else None, C.c_size_t(first), C.c_size_t(last), _p(db), _p(have))
+    return (db, have) if n else (None, None)
+
+
+def sync_decode(key, clip_mode, start_frame, db, have):
+    db = np.ascontiguousarray(db, np.float32).ravel()
+    have = np.ascontiguousarray(have, np.int8)
+    return lib().orc_sync_decode(_key(key), int(clip_mode), C.c_size_t(start_frame), _p(db), C.c_size_t(db.size), _p(have),
+                                 C.c_size_t(have.size))
+
+
+def sync_search(key, samples, n_channels, clip_mode=False, max_out=4096):
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    idx = np.zeros(max_out, np.uint64)
+    q = np.zeros(max_out, np.float64)
+    bt = np.zeros(max_out, np.int32)
+    n = lib().orc_sync_search(_key(key), _p(samples), C.c_size_t(samples.size), n_channels, int(clip_mode), C.c_size_t(max_out),
+                              _p(idx), _p(q), _p(bt))
+    return idx[:n], q[:n], bt[:n]
+
+
+def search_approx(key, samples, n_channels, clip_mode=False):
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    max_out = 4 * (samples.size // n_channels // 1024 + 1)
+    idx = np.zeros(max_out, np.uint64)
+    raw = np.zeros(max_out, np.float64)
+    mean = np.zeros(max_out, np.float64)
+    n = lib().orc_search_approx(_key(key), _p(samples), C.c_size_t(samples.size), n_channels, int(clip_mode),
+                                C.c_size_t(max_out), _p(idx), _p(raw), _p(mean))
+    return idx[:n], raw[:n], mean[:n]
+
+
+def mix_decode(key, samples, n_channels, index):
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    out = np.zeros(858, np.float32)
+    n = lib().orc_mix_decode(_key(key), _p(samples), C.c_size_t(samples.size), n_channels, C.c_size_t(index), _p(out))
+    return out if n else None
+
+
+def _patterns(fn, *args, max_out=4096):
+    buf = (Pattern * max_out)()
+    n = fn(*args, C.c_size_t(max_out), C.cast(buf, C.c_void_p))
+    assert n >= 0
+    return [buf[i].as_dict() for i in range(min(n, max_out))]
+
+
+def decode_chunk(key, samples, n_channels, first_chunk=True):
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    return _patterns(lib().orc_decode_chunk, _key(key), _p(samples), C.c_size_t(samples.size), n_channels, int(first_chunk))
+
+
+def get(key, samples, n_channels):
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    return _patterns(lib().orc_get, _key(key), _p(samples), C.c_size_t(samples.size), n_channels)

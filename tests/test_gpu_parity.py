@@ -1,0 +1,305 @@
+"""Parity of the HIP path (through the C ABI) against the oracle on seeded inputs, against the golden
+fixtures, and -- at BASELINE.json's full size -- through size independent properties.
+
+Tolerances (north_star): decoded payload bits and sync positions bit exact; embedded PCM within
+1e-5 RMS of the reference's float output (the tests enforce 1e-6, SURVEY.md Appendix C calibration);
+sync qualities within 1e-5.  Integer / bit results (Viterbi output, tables) are compared exactly."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+PAY1 = "0123456789abcdef0011223344556677"
+PAY2 = "f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0"
+RMS_TOL = 1e-6
+QUALITY_TOL = 1e-5
+
+
+def noise(seed, n, ch):
+    return np.random.default_rng(seed).uniform(-1, 1, (n, ch)).astype(np.float32)
+
+
+def rms(a, b):
+    d = np.asarray(a, np.float64).ravel() - np.asarray(b, np.float64).ravel()
+    return float(np.sqrt(np.mean(d * d))) if d.size else 0.0
+
+
+def pkey(p):
+    return (round(p["time"], 9), p["sync_index"], p["type"], p["block_type"], p["bits"])
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import audiowmark_amd as awm
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    ctx = awm.Context(0)
+
+    class G:
+        pass
+    g = G()
+    g.torch, g.awm, g.ctx = torch, awm, ctx
+    g.dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    yield g
+    awm.set_params()
+    orc.set_params()
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "golden_v1.json")) as f:
+        j = json.load(f)
+    return j, np.load(os.path.join(HERE, "golden", "golden_v1.npz"))
+
+
+@pytest.fixture(scope="module")
+def stream70():
+    n = 70 * 44100
+    return orc.add(None, noise(41, n, 2), 2, PAY1).reshape(n, 2)
+
+
+# ---- K1: FFTAnalyzer::fft_range ----------------------------------------------------------------
+@pytest.mark.parametrize("ch,start", [(1, 0), (1, 77), (2, 100), (2, 333), (3, 5)])
+def test_fft_range(gpu, ch, start):
+    x = noise(21 + ch, 12000, ch)
+    got = gpu.ctx.fft_range(gpu.dev(x), start, 8).cpu().numpy()
+    want = orc.fft_range(x, ch, start, 8)
+    assert np.abs(got - want).max() < 1e-6 * np.abs(want).max()
+    with pytest.raises(gpu.awm.AwmError):                      # reading past the end is refused
+        gpu.ctx.fft_range(gpu.dev(x), 12000 - 1000, 1)
+
+
+def test_fft_range_golden(gpu, golden):
+    _, z = golden
+    got = gpu.ctx.fft_range(gpu.dev(noise(21, 8000, 2)), 100, 3).cpu().numpy()
+    assert np.abs(got - z["fft_range_s21"]).max() < 1e-6 * np.abs(z["fft_range_s21"]).max()
+
+
+# ---- K2/K3: add ---------------------------------------------------------------------------------
+@pytest.mark.parametrize("ch,n,limiter,key", [
+    (2, 70 * 44100 + 13, True, None), (2, 30 * 44100, False, "t42"), (1, 20 * 44100 + 1, True, None),
+    (2, 1024, True, None), (2, 700, True, None), (1, 1025, False, None), (3, 4 * 44100 + 5, True, None),
+    (2, 1, True, None)])
+def test_add_parity(gpu, ch, n, limiter, key):
+    key = gpu.awm.test_key(42) if key else None
+    x = noise(100 + ch + n % 97, n, ch)
+    gpu.awm.set_params(test_no_limiter=not limiter)
+    orc.set_params(test_no_limiter=not limiter)
+    want = orc.add(key, x, ch, PAY1).reshape(n, ch)
+    got = gpu.ctx.add_watermark(key, PAY1, gpu.dev(x)).cpu().numpy()
+    assert got.shape == x.shape                                # output length == input length (wmadd.cc:570-572)
+    assert rms(got, want) < RMS_TOL
+    assert np.abs(got - want).max() < 2e-6
+    if n >= 44100:
+        assert 0.005 < rms(want, x) < 0.05                     # a watermark was actually embedded
+    gpu.awm.set_params()
+    orc.set_params()
+
+
+def test_add_empty(gpu):
+    x = gpu.torch.zeros((0, 2), dtype=gpu.torch.float32, device="cuda")
+    assert gpu.ctx.add_watermark(None, PAY1, x).shape == (0, 2)
+
+
+def test_add_golden(gpu, golden):
+    _, z = golden
+    got = gpu.ctx.add_watermark(None, PAY1, gpu.dev(noise(31, 2 * 44100 + 77, 1))).cpu().numpy().ravel()
+    assert rms(got, z["add_mono_s31"]) < RMS_TOL
+    gpu.awm.set_params(test_no_limiter=True)
+    got = gpu.ctx.add_watermark(gpu.awm.test_key(42), PAY2, gpu.dev(noise(32, 44100 + 500, 2))).cpu().numpy().ravel()
+    gpu.awm.set_params()
+    assert rms(got, z["add_stereo_s32_nolimiter"]) < RMS_TOL
+
+
+def test_add_snr_bound(gpu):
+    # tests/block-decoder-test.sh:18 of the reference: SNR >= 32.4 dB on white noise without limiter
+    x = noise(7, 200 * 44100, 2)
+    gpu.awm.set_params(test_no_limiter=True)
+    w = gpu.ctx.add_watermark(None, PAY2, gpu.dev(x)).cpu().numpy()
+    gpu.awm.set_params()
+    d = w.astype(np.float64) - x
+    snr = 10 * np.log10((x.astype(np.float64) ** 2).sum() / (d ** 2).sum())
+    assert snr >= 32.4
+
+
+def test_add_sharded_spans_equal_whole(gpu):
+    """Two frame spans with halo frames + a max-combined limiter table reproduce the single launch bit for bit
+    (this is the multi-GPU decomposition of `add`, run here on one device)."""
+    t = gpu.torch
+    n, split = 12 * 44100 + 321, 200 * 1024
+    x = gpu.dev(noise(55, n, 2))
+    fm = gpu.awm.tab_frame_mod(None, PAY1)
+    whole = gpu.ctx.add_d(x, fm, 0.01, True)
+    n_blocks = n // 44100 + 2
+    bm = t.empty(n_blocks, dtype=t.float32, device="cuda")
+    gpu.ctx.add_init_block_max(bm)
+    out = t.empty_like(x)
+    a, b = x[:split], x[split:]
+    halo_after = x[split:split + 1024].contiguous()
+    halo_before = x[split - 1024:split].contiguous()
+    gpu.ctx.add_mix(a, out[:split], fm, 0.01, 0, None, halo_after, bm)
+    gpu.ctx.add_mix(b, out[split:], fm, 0.01, split // 1024, halo_before, None, bm)
+    gpu.ctx.add_limit(out[:split], 0, bm)
+    gpu.ctx.add_limit(out[split:], split, bm)
+    assert t.equal(out, whole)
+
+
+# ---- K4: SyncFinder::sync_fft --------------------------------------------------------------------
+def test_sync_fft(gpu, stream70):
+    w = stream70
+    got_db, got_have = gpu.ctx.sync_fft(gpu.dev(w), 264, 40)
+    want_db, want_have = orc.sync_fft(w, 2, 264, 40)
+    assert np.array_equal(got_have.cpu().numpy(), want_have)
+    assert np.abs(got_db.cpu().numpy() - want_db).max() < 2e-4             # sums of dB values ~ -60
+    want = np.zeros(40, np.int8)
+    want[[1, 2, 3, 17, 39]] = 1
+    first, last = 2 * (264 + 10 * 1024) + 1, 2 * (264 + 30 * 1024)
+    got_db, got_have = gpu.ctx.sync_fft(gpu.dev(w), 264, 40, want, first, last)
+    want_db, want_have = orc.sync_fft(w, 2, 264, 40, want, first, last)
+    assert np.array_equal(got_have.cpu().numpy(), want_have) and want_have.sum() == 1
+    assert np.abs(got_db.cpu().numpy() - want_db).max() < 2e-4
+
+
+# ---- K5: search_approx / search --------------------------------------------------------------------
+def test_search_approx(gpu, golden, stream70):
+    j, _ = golden
+    gi, graw, gmean = gpu.ctx.search_approx(None, gpu.dev(stream70))
+    oi, oraw, omean = orc.search_approx(None, stream70, 2)
+    assert np.array_equal(gi, oi) and len(gi) == j["approx70"]["n"]
+    assert np.abs(graw - oraw).max() < 5e-5 and np.abs(gmean - omean).max() < 1e-5
+    top = np.argsort(-np.abs(graw - gmean))[:8]
+    assert sorted(gi[top].tolist()) == sorted(j["approx70"]["top_index"][:8])
+
+
+@pytest.mark.parametrize("ch", [1, 2])
+def test_sync_search_block(gpu, ch):
+    n = 115 * 44100
+    w = orc.add(None, noise(60 + ch, n, ch), ch, PAY2).reshape(n, ch)
+    gi, gq, gb = gpu.ctx.sync_search(None, gpu.dev(w))
+    oi, oq, ob = orc.sync_search(None, w, ch)
+    assert gi.tolist() == oi.tolist() and gb.tolist() == ob.tolist()       # positions and block types: exact
+    assert np.abs(gq - oq).max() < QUALITY_TOL
+    assert 250 * 1024 in gi.tolist()                                       # first A block after the 250 frame pad
+
+
+def test_sync_search_golden(gpu, golden, stream70):
+    j, _ = golden
+    gi, gq, gb = gpu.ctx.sync_search(None, gpu.dev(stream70))
+    assert gi.tolist() == j["sync70"]["index"] and gb.tolist() == j["sync70"]["block_type"]
+    assert np.abs(gq - np.array(j["sync70"]["quality"])).max() < QUALITY_TOL
+
+
+def test_sync_search_cut_start(gpu, stream70):
+    # reference tests/sync-test.sh: cutting an arbitrary (odd) number of samples only moves the sync positions
+    cut = 12345
+    w = np.ascontiguousarray(stream70[cut:])
+    gi, gq, gb = gpu.ctx.sync_search(None, gpu.dev(w))
+    oi, oq, ob = orc.sync_search(None, w, 2)
+    assert gi.tolist() == oi.tolist() and gb.tolist() == ob.tolist()
+    assert np.abs(gq - oq).max() < QUALITY_TOL
+
+
+# ---- K7: soft bits, K8: Viterbi -------------------------------------------------------------------
+def test_block_soft_bits(gpu, golden, stream70):
+    j, z = golden
+    idx = j["mix_decode70_index"]
+    got, ok = gpu.ctx.block_soft_bits(None, gpu.dev(stream70), [idx, idx + 8, len(stream70) - 1000])
+    assert ok.tolist() == [1, 1, 0]                                        # fft_range refuses to read past the end
+    assert np.abs(got[0] - z["mix_decode70"]).max() < 5e-3 and np.abs(z["mix_decode70"]).mean() > 50
+    want = orc.mix_decode(None, stream70, 2, idx + 8)
+    assert np.abs(got[1] - want).max() < 5e-3
+
+
+@pytest.mark.parametrize("bt", [0, 1, 2])
+def test_viterbi_bit_exact(gpu, bt):
+    rng = np.random.default_rng(200 + bt)
+    soft, want_bits, want_err = [], [], []
+    for sigma in (0.0, 0.3, 0.5, 0.7, 1.5):
+        bits = rng.integers(0, 2, 128)
+        coded = orc.conv_encode(bt, bits).astype(np.float32)
+        s = (coded + rng.normal(0, sigma, coded.shape)).astype(np.float32)
+        b, e = orc.conv_decode_soft(bt, s)
+        soft.append(s)
+        want_bits.append(b)
+        want_err.append(e)
+    got_bits, got_err = gpu.ctx.viterbi_decode(bt, np.stack(soft))
+    assert np.array_equal(got_bits, np.stack(want_bits))
+    assert np.array_equal(got_err, np.array(want_err, np.float32))         # path metric: same float operations, same order
+
+
+# ---- whole decode -----------------------------------------------------------------------------------
+def test_decode_chunk_golden(gpu, golden, stream70):
+    j, _ = golden
+    got = sorted(gpu.ctx.decode_chunk(None, gpu.dev(stream70), True), key=lambda p: (p["time"], p["type"], p["block_type"], p["bits"]))
+    want = j["decode_chunk70"]
+    assert [pkey(p) for p in got] == [pkey(p) for p in want]
+    for g, w in zip(got, want):
+        assert abs(g["sync_quality"] - w["sync_quality"]) < QUALITY_TOL and abs(g["decode_error"] - w["decode_error"]) < 1e-5
+
+
+def test_get_clip(gpu, golden, stream70):
+    j, _ = golden
+    clip = np.ascontiguousarray(stream70[20 * 44100: 44 * 44100])
+    got = gpu.ctx.get_watermark(None, gpu.dev(clip))
+    assert [pkey(p) for p in got] == [pkey(p) for p in j["get_clip24"]]
+    assert got[0]["bits"] == PAY1 and got[0]["type"] == 1                  # CLIP pattern first
+    mono = np.ascontiguousarray(clip[:, :1])
+    want = orc.get(None, mono, 1)
+    assert [pkey(p) for p in gpu.ctx.get_watermark(None, gpu.dev(mono))] == [pkey(p) for p in want]
+
+
+def test_wrong_key_finds_nothing(gpu, stream70):
+    # reference tests/key-test.sh
+    pats = gpu.ctx.get_watermark(gpu.awm.test_key(2), gpu.dev(stream70))
+    assert all(p["bits"] != PAY1 for p in pats)
+
+
+def test_add_then_get_end_to_end_vs_oracle(gpu):
+    n = 118 * 44100 + 999
+    x = noise(77, n, 2)
+    key = gpu.awm.test_key(7)
+    w = gpu.ctx.add_watermark(key, PAY2, gpu.dev(x))
+    got = gpu.ctx.get_watermark(key, w)
+    want = orc.get(key, orc.add(key, x, 2, PAY2).reshape(n, 2), 2)
+    assert [pkey(p) for p in got] == [pkey(p) for p in want]
+    assert sum(p["bits"] == PAY2 for p in got) >= 4                        # A, B, AB, all (block-decoder-test.sh)
+
+
+# ---- full size (BASELINE.json configs[1]): size independent properties ------------------------------
+def test_full_size_60min_roundtrip(gpu):
+    t = gpu.torch
+    n = 60 * 60 * 44100
+    g = t.Generator(device="cuda")
+    g.manual_seed(5)
+    x = t.rand((n, 2), generator=g, device="cuda", dtype=t.float32) * 2 - 1
+    w = gpu.ctx.add_watermark(None, PAY1, x)
+    assert w.shape == x.shape
+    assert float(w.abs().max()) <= 0.99 * (1 + 1e-6)                       # limiter ceiling
+    delta = (w - x)
+    assert 0.01 < float(delta.double().pow(2).mean().sqrt()) < 0.06
+    # idempotence of the deterministic pipeline
+    assert t.equal(gpu.ctx.add_watermark(None, PAY1, x), w)
+    pats = gpu.ctx.get_watermark(None, w)
+    matches = [p for p in pats if p["bits"] == PAY1]
+    assert len(matches) >= 100                                             # 69 blocks + AB pairs + per-chunk "all"
+    block = 2226 * 1024
+    found = sorted({round(p["time"] * 44100) for p in matches if p["type"] == 0 and p["block_type"] < 2})
+    expected = [250 * 1024 + i * block for i in range(69)]
+    hit = sum(any(abs(f - e) < 512 for f in found) for e in expected)
+    assert hit >= 66                                                       # every full block located within half a frame
+    # each 30 min reference chunk decodes on its own to the same patterns that the merged result holds
+    chunks = gpu.awm.plan_chunks(n)
+    assert len(chunks) == 3
+    first, count, off = chunks[1]
+    sub = gpu.ctx.decode_chunk(None, w[first:first + count], False)
+    merged = {(round(p["time"], 3), p["block_type"], p["bits"]) for p in pats if p["type"] == 0}
+    for p in sub:
+        if p["type"] == 0 and p["bits"] == PAY1:
+            assert (round(p["time"] + off, 3), p["block_type"], p["bits"]) in merged

@@ -1,0 +1,96 @@
+"""CPU-side checks of the product: the C-ABI library loads and exports every symbol include/awm_hip.h
+declares, the pure-host table builders agree bit for bit with the oracle, compute entry points fail
+loudly without a GPU (no CPU fallback), chunk planning / pattern merging match the reference semantics."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+import audiowmark_amd as awm
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PAY = "0123456789abcdef0011223344556677"
+KEYS = [None, awm.test_key(42), bytes(range(16))]
+
+
+def test_every_declared_symbol_is_exported():
+    with open(os.path.join(ROOT, "include", "awm_hip.h")) as f:
+        text = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    names = set(re.findall(r"\b(awm_[a-z0-9_]+)\s*\(", text))
+    assert len(names) >= 30
+    missing = [n for n in sorted(names) if not hasattr(awm.lib, n)]
+    assert not missing, missing
+
+
+@pytest.mark.parametrize("key", KEYS)
+def test_host_tables_match_oracle(key):
+    assert np.array_equal(awm.tab_bit_pos(key), orc.bit_pos(key))
+    assert np.array_equal(awm.tab_mix_entries(key), orc.mix_entries(key))
+    assert np.array_equal(awm.tab_bit_order(key, 858), orc.bit_order(key, 858))
+    for stream in (1, 2):
+        for f in (0, 7, 509, 1715):
+            for a, b in zip(awm.tab_up_down(key, stream, f), orc.up_down(key, stream, f)):
+                assert np.array_equal(a, b)
+    for clip in (False, True):
+        assert np.array_equal(awm.tab_sync_bits(key, clip), orc.sync_bits(key, clip))
+    for pay in (PAY, "f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0", "a"):
+        fm = awm.tab_frame_mod(key, pay)
+        for ab in (0, 1):
+            want = orc.frame_mod(key, pay, ab)
+            assert not want[:, :20].any()
+            assert np.array_equal(fm[ab], want[:, 20:101])
+            assert ((fm[ab] != 0).sum(axis=1) == 60).all()            # 30 up + 30 down bands in every frame
+
+
+def test_windows_and_conv_encode_match_oracle():
+    assert np.array_equal(awm.tab_window(1024), orc.window(1024))
+    assert np.array_equal(awm.tab_synth_window(), orc.synth_window())
+    bits = np.random.default_rng(3).integers(0, 2, 128)
+    for bt in (0, 1, 2):
+        assert np.array_equal(awm.conv_encode(bt, bits), orc.conv_encode(bt, bits))
+
+
+def test_bad_payload_is_an_error():
+    with pytest.raises(awm.AwmError):
+        awm.tab_frame_mod(None, "xyz")
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    h = C.c_void_p()
+    rc = awm.lib.awm_ctx_create(0, C.byref(h))
+    assert rc == -2                                                        # AWM_ERR_NO_DEVICE
+    assert b"no CPU fallback" in awm.lib.awm_last_error()
+    with pytest.raises(awm.AwmError):
+        awm.Context(0)
+
+
+def test_plan_chunks_reference_semantics():
+    # wavchunkloader.cc:75-84: 30 min chunks, overlap lrint(2 * 51.69 s * 1.3 * 44100) samples
+    L, O = 79380000, 5926502
+    assert awm.plan_chunks(0) == []
+    assert awm.plan_chunks(100) == [(0, 100, 0.0)]
+    c = awm.plan_chunks(60 * 60 * 44100)
+    assert [(a, b) for a, b, _ in c] == [(0, L), (L - O, L), (2 * (L - O), 60 * 60 * 44100 - 2 * (L - O))]
+    assert abs(c[1][2] - (L - O) / 44100) < 1e-9
+    # a stream that ends exactly on a chunk boundary yields one more chunk made of the overlap only
+    assert awm.plan_chunks(L) == [(0, L, 0.0), (L - O, O, (L - O) / 44100)]
+
+
+def test_merge_patterns_dedup_and_sort():
+    def pat(time, bits, q, bt=0, typ=0):
+        return dict(time=time, sync_index=int(time * 44100), sync_quality=q, block_type=bt, type=typ, decode_error=0.1,
+                    speed=1.0, bits=bits)
+    good, junk = PAY, "ffffffffffffffffffffffffffffffff"
+    chunk0 = [pat(5.8, good, 1.3), pat(57.4, good, 1.4, 1), pat(57.4, good, 1.35, 2), pat(20.0, junk, 0.2)]
+    chunk1 = [pat(57.4 + 0.001, good, 1.39, 1), pat(109.1, good, 1.2), pat(0.0, good, 1.3, 0, 2)]
+    out = awm.merge_patterns(None, [chunk0, chunk1])
+    # the B block seen by both chunks is kept once; best-rated payload first, ALL pattern last within it
+    assert len(out) == 6
+    assert [p["bits"] for p in out[:5]] == [good] * 5 and out[5]["bits"] == junk
+    assert out[4]["type"] == 2 and [round(p["time"], 1) for p in out[:4]] == [5.8, 57.4, 57.4, 109.1]
