@@ -19,11 +19,30 @@ def library_path():
     return os.path.join(_HERE, "libawm_hip.so")
 
 
+def _load_hip_runtime():
+    """libawm_hip.so has no DT_NEEDED on a HIP runtime: bind it to the runtime of this process.  PyTorch
+    ships its own libamdhip64.so (no SONAME) next to libtorch_hip.so; a second runtime in the same process
+    cannot open the KFD device, so torch's copy is preferred and made global before our library is loaded."""
+    candidates = []
+    try:
+        import torch
+        candidates.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    candidates += [os.path.join(rocm, "lib", "libamdhip64.so.7"), os.path.join(rocm, "lib", "libamdhip64.so")]
+    for c in candidates:
+        if os.path.exists(c):
+            return C.CDLL(c, mode=C.RTLD_GLOBAL)
+    raise AwmError("no HIP runtime (libamdhip64) found for libawm_hip.so")
+
+
 def _load():
     path = library_path()
     if not os.path.exists(path):
         raise AwmError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                        "or `make -C audiowmark_amd/csrc` (there is no CPU fallback)")
+    _load_hip_runtime()
     return C.CDLL(path)
 
 

@@ -186,7 +186,7 @@ def test_sync_search_block(gpu, ch):
     oi, oq, ob = orc.sync_search(None, w, ch)
     assert gi.tolist() == oi.tolist() and gb.tolist() == ob.tolist()       # positions and block types: exact
     assert np.abs(gq - oq).max() < QUALITY_TOL
-    assert 250 * 1024 in gi.tolist()                                       # first A block after the 250 frame pad
+    assert any(abs(int(i) - 250 * 1024) < 512 for i in gi)                 # first A block after the 250 frame pad
 
 
 def test_sync_search_golden(gpu, golden, stream70):
