@@ -99,11 +99,19 @@ struct SyncScanArgs
   SyncTableDev table;
 };
 hipError_t launch_sync_scan (hipStream_t st, const SyncScanArgs& a);
+/* K5w: same result for band-major planes (row_stride == 1, band_stride % 64 == 0): dB matrix streamed through an LDS ring.
+ * total_frames = frames a candidate spans (2226 BLOCK / 4452 CLIP). */
+hipError_t launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames);
 
 /* K5b: local mean over the index-sorted scores (syncfinder.cc:234-254); q is [4][q_stride] by shift,
  * sorted position p = 4 * start_frame + shift.  Writes raw[p], mean[p]. */
 hipError_t launch_local_mean (hipStream_t st, const double *q, long long q_stride, long long n_start_frames,
                               double *raw_sorted, double *local_mean);
+
+/* K5c: local maxima + false-positive mask + threshold on the device (syncfinder.cc:258-332, 364-383) */
+struct PeakOut { long long p; double raw, mean; };
+hipError_t launch_peak_select (hipStream_t st, const double *raw_sorted, const double *local_mean, long long n, double threshold,
+                               unsigned int *count, PeakOut *out, unsigned int cap);
 
 /* K7: mix_decode (wmget.cc:67-108): db is [n_blocks][C][81][ld] (band-major), out [n_blocks][858] */
 struct SoftBitsArgs
@@ -122,7 +130,7 @@ struct SoftBitsArgs
 hipError_t launch_soft_bits (hipStream_t st, const SoftBitsArgs& a);
 
 /* K8: soft Viterbi (convcode.cc:128-213), one workgroup per coded block */
-hipError_t launch_viterbi (hipStream_t st, const float *soft, int rate, const unsigned *generators /* host */,
+hipError_t launch_viterbi (hipStream_t st, const float *soft, int block_type /* 0 a, 1 b, 2 ab */,
                            long long coded_len, long long n_blocks, unsigned char *decisions_ws,
                            int *bits_out, float *error_out);
 size_t viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks);

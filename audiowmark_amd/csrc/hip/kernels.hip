@@ -24,6 +24,10 @@ constexpr int NB = 81;          // watermark bands: bins 20..100
 constexpr int MIN_BAND = 20;
 constexpr int WAVES = 4;        // waves per workgroup
 
+// read-only, wave-uniform tables are addressed through the constant address space so that the compiler emits
+// scalar loads (s_load_dwordx16) instead of 64 identical vector loads
+typedef const int __attribute__ ((address_space (4))) *const_int_ptr;
+
 __device__ __forceinline__ void
 load_shared_tables (const DevTables& t, float2 *s_tw, float *s_win, float2 *s_twb)
 {
@@ -484,6 +488,25 @@ launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
 /* ==========================================================================================
  * K3: limiter ramp (reference limiter.cc:99-124)
  * ========================================================================================== */
+__device__ __forceinline__ float
+limiter_scale (long long gs, const float *block_max, long long first_block, long long n_blocks, int BS, float ceiling)
+{
+  const long long b = gs / BS;
+  const int i = int (gs - b * BS);
+  auto M = [&] (long long bb) -> float {
+    const long long k = bb - first_block;
+    if (bb < 0 || k < 0 || k >= n_blocks)
+      return ceiling;                       // block_max_last starts at the ceiling; blocks past the end are silent
+    return fmaxf (block_max[k], ceiling);
+  };
+  const float m_last = M (b - 1), m_cur = M (b), m_next = M (b + 1);
+  const float scale_start = __fdiv_rn (ceiling, fmaxf (m_last, m_cur));
+  const float scale_end   = __fdiv_rn (ceiling, fmaxf (m_cur, m_next));
+  const float scale_step  = __fdiv_rn (__fsub_rn (scale_end, scale_start), float (BS));
+  return __fadd_rn (scale_start, __fmul_rn (float (i), scale_step));
+}
+
+// generic: one value per thread
 __global__ void __launch_bounds__ (256)
 limiter_kernel (float *data, long long n_frames, int C, long long first_sample, const float *block_max,
                 long long first_block, long long n_blocks, int BS, float ceiling)
@@ -491,22 +514,33 @@ limiter_kernel (float *data, long long n_frames, int C, long long first_sample, 
   const long long n_values = n_frames * C;
   const long long stride = (long long) gridDim.x * blockDim.x;
   for (long long v = (long long) blockIdx.x * blockDim.x + threadIdx.x; v < n_values; v += stride)
+    data[v] = __fmul_rn (data[v], limiter_scale (first_sample + v / C, block_max, first_block, n_blocks, BS, ceiling));
+}
+
+// 16 bytes per thread: C == 1 -> 4 frames, C == 2 -> 2 frames per float4
+template<int C> __global__ void __launch_bounds__ (256)
+limiter_kernel_v4 (float4 *data, long long n_vec, long long first_sample, const float *block_max,
+                   long long first_block, long long n_blocks, int BS, float ceiling)
+{
+  const long long stride = (long long) gridDim.x * blockDim.x;
+  for (long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x; q < n_vec; q += stride)
     {
-      const long long gs = first_sample + v / C;
-      const long long b = gs / BS;
-      const int i = int (gs - b * BS);
-      auto M = [&] (long long bb) -> float {
-        const long long k = bb - first_block;
-        if (bb < 0 || k < 0 || k >= n_blocks)
-          return ceiling;                       // block_max_last starts at the ceiling; blocks past the end are silent
-        return fmaxf (block_max[k], ceiling);
-      };
-      const float m_last = M (b - 1), m_cur = M (b), m_next = M (b + 1);
-      const float scale_start = __fdiv_rn (ceiling, fmaxf (m_last, m_cur));
-      const float scale_end   = __fdiv_rn (ceiling, fmaxf (m_cur, m_next));
-      const float scale_step  = __fdiv_rn (__fsub_rn (scale_end, scale_start), float (BS));
-      const float scale = __fadd_rn (scale_start, __fmul_rn (float (i), scale_step));
-      data[v] = __fmul_rn (data[v], scale);
+      float4 v = data[q];
+      const long long gs = first_sample + q * (4 / C);
+      if (C == 2)
+        {
+          const float s0 = limiter_scale (gs, block_max, first_block, n_blocks, BS, ceiling);
+          const float s1 = limiter_scale (gs + 1, block_max, first_block, n_blocks, BS, ceiling);
+          v = make_float4 (__fmul_rn (v.x, s0), __fmul_rn (v.y, s0), __fmul_rn (v.z, s1), __fmul_rn (v.w, s1));
+        }
+      else
+        {
+          v = make_float4 (__fmul_rn (v.x, limiter_scale (gs, block_max, first_block, n_blocks, BS, ceiling)),
+                           __fmul_rn (v.y, limiter_scale (gs + 1, block_max, first_block, n_blocks, BS, ceiling)),
+                           __fmul_rn (v.z, limiter_scale (gs + 2, block_max, first_block, n_blocks, BS, ceiling)),
+                           __fmul_rn (v.w, limiter_scale (gs + 3, block_max, first_block, n_blocks, BS, ceiling)));
+        }
+      data[q] = v;
     }
 }
 
@@ -517,11 +551,31 @@ launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels,
   const long long n_values = n_frames * n_channels;
   if (n_values <= 0)
     return hipSuccess;
-  long long blocks = (n_values + 255) / 256;
-  if (blocks > 256 * 32)
-    blocks = 256 * 32;
-  hipLaunchKernelGGL (limiter_kernel, dim3 (unsigned (blocks)), dim3 (256), 0, st, data, n_frames, n_channels, first_sample,
-                      block_max, first_block, n_blocks, limiter_block, ceiling);
+  const bool vec = (n_channels == 1 || n_channels == 2) && (reinterpret_cast<uintptr_t> (data) & 15) == 0;
+  const long long n_vec = vec ? n_values / 4 : 0;
+  if (n_vec)
+    {
+      long long blocks = (n_vec + 255) / 256;
+      if (blocks > 256 * 16)
+        blocks = 256 * 16;
+      if (n_channels == 2)
+        hipLaunchKernelGGL (limiter_kernel_v4<2>, dim3 (unsigned (blocks)), dim3 (256), 0, st, reinterpret_cast<float4 *> (data), n_vec,
+                            first_sample, block_max, first_block, n_blocks, limiter_block, ceiling);
+      else
+        hipLaunchKernelGGL (limiter_kernel_v4<1>, dim3 (unsigned (blocks)), dim3 (256), 0, st, reinterpret_cast<float4 *> (data), n_vec,
+                            first_sample, block_max, first_block, n_blocks, limiter_block, ceiling);
+    }
+  const long long done = n_vec * 4;
+  if (done < n_values)
+    {
+      // tail (or generic channel counts): scalar kernel on the remaining whole frames
+      const long long done_frames = done / n_channels;
+      long long blocks = (n_values - done + 255) / 256;
+      if (blocks > 256 * 32)
+        blocks = 256 * 32;
+      hipLaunchKernelGGL (limiter_kernel, dim3 (unsigned (blocks)), dim3 (256), 0, st, data + done, n_frames - done_frames, n_channels,
+                          first_sample + done_frames, block_max, first_block, n_blocks, limiter_block, ceiling);
+    }
   return hipGetLastError();
 }
 
@@ -707,20 +761,26 @@ sync_scan_kernel (SyncScanArgs a)
   const int lane = threadIdx.x;
   const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);     // one wave == one sync bit
   const long long plane = blockIdx.y;
-  const long long cand = (long long) blockIdx.x * 64 + lane;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (MI355X_MICROARCH.md), so give every XCD one contiguous
+  // range of candidate tiles -- the dB rows its resident workgroups re-read then stay inside that XCD's 4 MiB L2
+  const long long n_tiles = (a.n_lanes + 63) / 64;
+  const long long per_xcd = (n_tiles + 7) / 8;
+  const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  const bool tile_ok = (blockIdx.x >> 3) < per_xcd && tile < n_tiles;
+  const long long cand = tile * 64 + lane;
   const long long n_valid = a.lane_count ? a.lane_count[plane] : a.n_lanes;
-  const bool active = cand < n_valid;
+  const bool active = tile_ok && cand < n_valid;
   const float *db = a.db + plane * a.plane_stride + (active ? cand : 0);
   const char *have = a.have ? a.have + plane * a.have_plane_stride + (active ? cand : 0) : nullptr;
   const int R = a.table.rows_per_bit;
-  const int *tab = a.table.packed + (size_t) bit * R * 64;
+  const_int_ptr tab = (const_int_ptr) (a.table.packed + (size_t) bit * R * 64);
 
   // float accumulators, strictly sequential adds in the reference's order (syncfinder.cc:129-145)
   float umag = 0.f, dmag = 0.f;
   int n = 0;
   for (int r = 0; r < R; r++)
     {
-      const int *tr = tab + r * 64;
+      const_int_ptr tr = tab + r * 64;
       const long long row = tr[60];
       const bool present = have ? have[row * a.have_row_stride] != 0 : true;
       const float *p = db + row * a.row_stride;
@@ -772,6 +832,131 @@ sync_scan_kernel (SyncScanArgs a)
     }
 }
 
+/* K5w: the same computation for the approximate search, where the planes are band-major dB matrices
+ * (row_stride == 1): every candidate of a 64-candidate tile walks frames tile .. tile + 2226 (+ 64), and so do its
+ * five sibling waves (one per sync bit).  The workgroup therefore streams the 81-band matrix through a 2 x 64 frame
+ * ring in LDS exactly once (coalesced 256 B rows), and all 30 600 gathers per candidate are served from LDS
+ * instead of the L2 -- 16x less L2 traffic than K5 while keeping every accumulation in the reference's order. */
+constexpr int SCAN_RING = 128;
+
+__global__ void __launch_bounds__ (384)
+sync_scan_window_kernel (SyncScanArgs a, int total_frames)
+{
+  __shared__ __attribute__ ((aligned (16))) float s_win[NB * SCAN_RING];
+  __shared__ float s_u[6][64], s_d[6][64];
+  __shared__ int   s_n[6][64];
+  const int lane = threadIdx.x;
+  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const long long plane = blockIdx.y;
+  const long long n_tiles = (a.n_lanes + 63) / 64;
+  const long long per_xcd = (n_tiles + 7) / 8;
+  const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
+    return;                                               // uniform for the workgroup
+  const long long sf0 = tile * 64;
+  const long long cand = sf0 + lane;
+  const bool active = cand < a.n_lanes;
+  const float *db = a.db + plane * a.plane_stride;
+  const long long ld = a.band_stride;
+  const char *have = a.have ? a.have + plane * a.have_plane_stride + (active ? cand : 0) : nullptr;
+  const int R = a.table.rows_per_bit;
+
+  const_int_ptr tab = (const_int_ptr) (a.table.packed + (size_t) bit * R * 64);
+
+  auto load_half = [&] (int h) {
+    const long long base = sf0 + 64LL * h;
+    float *dst = s_win + 64 * (h & 1);
+    const bool in_range = base + 64 <= ld;
+    for (int idx = tid; idx < NB * 16; idx += 384)
+      {
+        const int band = idx >> 4, q = idx & 15;
+        float4 v = make_float4 (0.f, 0.f, 0.f, 0.f);
+        if (in_range)
+          v = *reinterpret_cast<const float4 *> (db + band * ld + base + 4 * q);
+        *reinterpret_cast<float4 *> (dst + band * SCAN_RING + 4 * q) = v;
+      }
+  };
+
+  float umag = 0.f, dmag = 0.f;
+  int n = 0, r = 0;
+  load_half (0);
+  for (int k = 0; 64 * k < total_frames; k++)
+    {
+      load_half (k + 1);
+      __syncthreads();
+      const int ring0 = 64 * (k & 1);
+      while (r < R)
+        {
+          const_int_ptr tr = tab + r * 64;
+          const int fr = tr[60];
+          if (fr >= 64 * (k + 1))
+            break;
+          const int phys = (fr - 64 * k + lane + ring0) & (SCAN_RING - 1);
+          const bool present = have ? have[fr] != 0 : true;
+          float uv[30], dv[30];
+#pragma unroll
+          for (int i = 0; i < 30; i++)
+            {
+              uv[i] = s_win[tr[i] * SCAN_RING + phys];
+              dv[i] = s_win[tr[30 + i] * SCAN_RING + phys];
+            }
+          if (present)
+            {
+#pragma unroll
+              for (int i = 0; i < 30; i++)
+                {
+                  umag = __fadd_rn (umag, uv[i]);
+                  dmag = __fadd_rn (dmag, dv[i]);
+                }
+              n++;
+            }
+          r++;
+        }
+      __syncthreads();
+    }
+  s_u[bit][lane] = umag;
+  s_d[bit][lane] = dmag;
+  s_n[bit][lane] = n;
+  __syncthreads();
+  if (bit == 0 && active)
+    {
+      double q = 0;
+      int total = 0;
+      for (int b = 0; b < 6; b++)
+        {
+          const float um = s_u[b][lane], dm = s_d[b][lane];
+          float raw;
+          if (um == 0 || dm == 0)
+            raw = 0;
+          else if (um < dm)
+            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
+          else
+            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
+          const double rb = (b & 1) ? double (raw) : -double (raw);
+          q += rb * s_n[b][lane];
+          total += s_n[b][lane];
+        }
+      if (total)
+        q /= total;
+      q = q / a.min_delta / 2.9;
+      a.quality[plane * a.q_stride + cand] = q;
+    }
+}
+
+hipError_t
+launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames)
+{
+  if (a.n_lanes <= 0 || a.n_planes <= 0)
+    return hipSuccess;
+  if (a.row_stride != 1 || a.n_planes > 65535 || (a.band_stride & 63) || a.lane_count)
+    return hipErrorInvalidValue;
+  const long long per_xcd = ((a.n_lanes + 63) / 64 + 7) / 8;
+  const dim3 grid ((unsigned) (per_xcd * 8), (unsigned) a.n_planes);
+  hipLaunchKernelGGL (sync_scan_window_kernel, grid, dim3 (64, 6), 0, st, a, total_frames);
+  return hipGetLastError();
+}
+
 hipError_t
 launch_sync_scan (hipStream_t st, const SyncScanArgs& a)
 {
@@ -786,7 +971,8 @@ launch_sync_scan (hipStream_t st, const SyncScanArgs& a)
       b.have = a.have ? a.have + done * a.have_plane_stride : nullptr;
       b.lane_count = a.lane_count ? a.lane_count + done : nullptr;
       b.quality = a.quality + done * a.q_stride;
-      const dim3 grid (unsigned ((a.n_lanes + 63) / 64), unsigned (n));
+      const long long per_xcd = ((a.n_lanes + 63) / 64 + 7) / 8;
+      const dim3 grid (unsigned (per_xcd * 8), unsigned (n));
       hipLaunchKernelGGL (sync_scan_kernel, grid, dim3 (64, 6), 0, st, b);
       hipError_t e = hipGetLastError();
       if (e != hipSuccess)
@@ -907,6 +1093,78 @@ launch_nonzero_range (hipStream_t st, const float *data, long long n_values, uns
   if (e != hipSuccess || n_values <= 0)
     return e;
   hipLaunchKernelGGL (nonzero_range_kernel, dim3 (1024), dim3 (256), 0, st, data, n_values, result);
+  return hipGetLastError();
+}
+
+/* K5c: sync_select_local_maxima + sync_mask_avg_false_positives + the threshold part of
+ * sync_select_threshold_and_n_best (reference syncfinder.cc:258-332, 364-383) evaluated per score.
+ *
+ * The reference walks the index-sorted scores sequentially ("a selected score makes its successor
+ * ineligible"); since a successor can only qualify as a local maximum when it TIES with the selected
+ * score, that rule is equivalent to: inside a run of consecutive qualifying positions take every
+ * second one, starting with the first.  The false-positive mask looks at the selected maxima within
+ * 23 search steps (index / 256) on either side -- exactly the scores p - 23 .. p + 23.
+ * Survivors above `threshold` are appended (in no particular order) to `out`. */
+__device__ __forceinline__ double
+psel_absq (const double *raw, const double *mean, long long i)
+{
+  return fabs (raw[i] - mean[i]);
+}
+__device__ __forceinline__ bool
+psel_cand (const double *raw, const double *mean, long long n, long long i)
+{
+  const double q = psel_absq (raw, mean, i);
+  const double q_last = i > 0 ? psel_absq (raw, mean, i - 1) : 0;
+  const double q_next = i + 1 < n ? psel_absq (raw, mean, i + 1) : 0;
+  return q >= q_last && q >= q_next;
+}
+__device__ __forceinline__ bool
+psel_is_max (const double *raw, const double *mean, long long n, long long i)
+{
+  if (!psel_cand (raw, mean, n, i))
+    return false;
+  int k = 0;
+  while (i - 1 - k >= 0 && psel_cand (raw, mean, n, i - 1 - k))
+    k++;
+  return (k & 1) == 0;
+}
+
+__global__ void __launch_bounds__ (256)
+peak_select_kernel (const double *raw, const double *mean, long long n, double threshold, unsigned int *count,
+                    PeakOut *out, unsigned int cap)
+{
+  const long long p = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n || !psel_is_max (raw, mean, n, p))
+    return;
+  const double q = psel_absq (raw, mean, p);
+  if (!(q > threshold))
+    return;
+  const int sign = raw[p] - mean[p] < 0 ? -1 : 1;
+  for (int d = -23; d <= 23; d++)
+    {
+      const long long j = p + d;
+      if (d == 0 || j < 0 || j >= n)
+        continue;
+      if (psel_absq (raw, mean, j) > q * 3 && (raw[j] - mean[j] < 0 ? -1 : 1) != sign && psel_is_max (raw, mean, n, j))
+        return;                                  // masked by a much larger peak of the opposite sign
+    }
+  const unsigned int slot = atomicAdd (count, 1u);
+  if (slot < cap)
+    {
+      out[slot].p = p;
+      out[slot].raw = raw[p];
+      out[slot].mean = mean[p];
+    }
+}
+
+hipError_t
+launch_peak_select (hipStream_t st, const double *raw, const double *mean, long long n, double threshold,
+                    unsigned int *count, PeakOut *out, unsigned int cap)
+{
+  hipError_t e = hipMemsetAsync (count, 0, sizeof (unsigned int), st);
+  if (e != hipSuccess || n <= 0)
+    return e;
+  hipLaunchKernelGGL (peak_select_kernel, dim3 (unsigned ((n + 255) / 256)), dim3 (256), 0, st, raw, mean, n, threshold, count, out, cap);
   return hipGetLastError();
 }
 

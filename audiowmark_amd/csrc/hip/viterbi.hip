@@ -23,14 +23,25 @@ constexpr int V_STATES = 1 << V_ORDER;       // 32768
 constexpr int V_THREADS = 1024;
 constexpr int V_PER_THREAD = V_STATES / 2 / V_THREADS;   // 16 butterflies
 
-struct ViterbiGen { unsigned g[12]; };
+// generator polynomials (reference convcode.cc:42-46), A and B interleaved
+__device__ constexpr unsigned V_GEN_AB[12] = { 066561, 075211, 071545, 054435, 063635, 052475, 063543, 075307, 052547, 045627, 067657, 051757 };
 
-template<int RATE> __global__ void __launch_bounds__ (V_THREADS)
-viterbi_kernel (const float *soft, ViterbiGen gen, int n_steps, unsigned int *decisions, int *bits_out, float *error_out)
+// BT: 0 = A block (even generators), 1 = B block (odd generators), 2 = AB (all twelve)
+template<int BT> __device__ constexpr unsigned v_gen (int g) { return BT == 2 ? V_GEN_AB[g] : V_GEN_AB[2 * g + BT]; }
+__device__ constexpr unsigned v_parity (unsigned v) { v ^= v >> 16; v ^= v >> 8; v ^= v >> 4; v ^= v >> 2; v ^= v >> 1; return v & 1; }
+
+typedef float v2f __attribute__ ((ext_vector_type (2)));
+
+// The successor state owned by (thread t, butterfly i, bit b) is ns = b | t << 1 | i << 11, so its expected code bit
+// for generator g splits into a lane dependent part parity ((t << 1) & G) and a part that is a compile time constant
+// after unrolling: parity ((i << 11 | b) & G).  Per trellis step a lane therefore needs just two candidate costs per
+// generator (own parity / flipped parity); which one a given (i, b) takes is decided by the compiler.
+template<int BT> __global__ void __launch_bounds__ (V_THREADS)
+viterbi_kernel (const float *soft, int n_steps, unsigned int *decisions, int *bits_out, float *error_out)
 {
   extern __shared__ __attribute__ ((aligned (16))) float s_metric[];   // V_STATES floats
   __shared__ float s_e0[12], s_e1[12];
-  constexpr int rate = RATE;
+  constexpr int rate = BT == 2 ? 12 : 6;
   const int t = threadIdx.x;
   const long long blk = blockIdx.x;
   const float *coded = soft + blk * (long long) n_steps * rate;
@@ -38,6 +49,10 @@ viterbi_kernel (const float *soft, ViterbiGen gen, int n_steps, unsigned int *de
 
   for (int i = t; i < V_STATES; i += V_THREADS)
     s_metric[i] = i == 0 ? 0.f : -1.f;
+  unsigned int lane_parity = 0;                     // bit g: parity ((t << 1) & G_g)
+#pragma unroll
+  for (int g = 0; g < rate; g++)
+    lane_parity |= (unsigned (__popc ((unsigned (t) << 1) & v_gen<BT> (g)) & 1)) << g;
   __syncthreads();
 
   for (int step = 0; step < n_steps; step++)
@@ -57,46 +72,42 @@ viterbi_kernel (const float *soft, ViterbiGen gen, int n_steps, unsigned int *de
           old1[i] = s_metric[t + V_THREADS * i + V_STATES / 2];
         }
       __syncthreads();                         // all reads done (and s_e0/s_e1 visible)
+      float cost_same[rate], cost_flip[rate];  // branch cost if the constant part of the parity is 0 / 1
+#pragma unroll
+      for (int g = 0; g < rate; g++)
+        {
+          const float e0 = s_e0[g], e1 = s_e1[g];
+          const bool lp = (lane_parity >> g) & 1;
+          cost_same[g] = lp ? e1 : e0;
+          cost_flip[g] = lp ? e0 : e1;
+        }
       unsigned int word = 0;
 #pragma unroll
       for (int i = 0; i < V_PER_THREAD; i++)
         {
           const unsigned p = t + V_THREADS * i;
-          float out[2];
+          // running sums for predecessors {low, high}: .x / .y; one pair per successor bit; term by term like the reference
+          v2f d0 = { old0[i], old1[i] }, d1 = d0;
 #pragma unroll
-          for (int b = 0; b < 2; b++)
+          for (int g = 0; g < rate; g++)
             {
-              const unsigned ns = 2 * p + b;
-              float d0 = old0[i], d1 = old1[i];
-#pragma unroll
-              for (int g = 0; g < rate; g++)
-                {
-                  const float e = (__popc (ns & gen.g[g]) & 1) ? s_e1[g] : s_e0[g];
-                  d0 = __fadd_rn (d0, e);
-                  d1 = __fadd_rn (d1, e);
-                }
-              const bool r0 = old0[i] >= 0.f, r1 = old1[i] >= 0.f;
-              float best;
-              unsigned choose1;
-              if (r0 && r1)
-                {
-                  choose1 = d1 < d0;
-                  best = choose1 ? d1 : d0;
-                }
-              else if (r1)
-                {
-                  choose1 = 1;
-                  best = d1;
-                }
-              else
-                {
-                  choose1 = 0;
-                  best = r0 ? d0 : -1.f;
-                }
-              out[b] = best;
-              word |= choose1 << (2 * i + b);
+              constexpr unsigned G = 0;   // placeholder to keep the loop body uniform
+              (void) G;
+              const bool c0 = v_parity ((unsigned (i) << 11) & v_gen<BT> (g));
+              const bool c1 = v_parity (((unsigned (i) << 11) | 1u) & v_gen<BT> (g));
+              const float ea = c0 ? cost_flip[g] : cost_same[g];
+              const float eb = c1 ? cost_flip[g] : cost_same[g];
+              d0 += (v2f) { ea, ea };
+              d1 += (v2f) { eb, eb };
             }
-          reinterpret_cast<float2 *> (s_metric)[p] = make_float2 (out[0], out[1]);
+          const bool r0 = old0[i] >= 0.f, r1 = old1[i] >= 0.f;
+          // strict "<": the low predecessor is visited first by the reference and keeps ties
+          const unsigned c0 = r0 ? (r1 && d0.y < d0.x) : (r1 ? 1u : 0u);
+          const unsigned c1 = r0 ? (r1 && d1.y < d1.x) : (r1 ? 1u : 0u);
+          const float best0 = c0 ? d0.y : (r0 ? d0.x : -1.f);
+          const float best1 = c1 ? d1.y : (r0 ? d1.x : -1.f);
+          word |= (c0 << (2 * i)) | (c1 << (2 * i + 1));
+          reinterpret_cast<float2 *> (s_metric)[p] = make_float2 (best0, best1);
         }
       dec[(long long) step * V_THREADS + t] = word;
       __syncthreads();
@@ -128,27 +139,29 @@ viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks)
 }
 
 hipError_t
-launch_viterbi (hipStream_t st, const float *soft, int rate, const unsigned *generators,
-                long long coded_len, long long n_blocks, unsigned char *decisions_ws, int *bits_out, float *error_out)
+launch_viterbi (hipStream_t st, const float *soft, int block_type, long long coded_len, long long n_blocks,
+                unsigned char *decisions_ws, int *bits_out, float *error_out)
 {
   if (n_blocks <= 0)
     return hipSuccess;
-  if ((rate != 6 && rate != 12) || coded_len % rate)
+  const int rate = block_type == 2 ? 12 : 6;
+  if (block_type < 0 || block_type > 2 || coded_len % rate)
     return hipErrorInvalidValue;
-  ViterbiGen gen;
-  for (int i = 0; i < 12; i++)
-    gen.g[i] = i < rate ? generators[i] : 0;
   const size_t lds = V_STATES * sizeof (float);
-  hipError_t e = hipFuncSetAttribute (reinterpret_cast<const void *> (viterbi_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize, int (lds));
-  if (e == hipSuccess)
-    e = hipFuncSetAttribute (reinterpret_cast<const void *> (viterbi_kernel<12>), hipFuncAttributeMaxDynamicSharedMemorySize, int (lds));
+  const void *fn[3] = { reinterpret_cast<const void *> (viterbi_kernel<0>), reinterpret_cast<const void *> (viterbi_kernel<1>),
+                        reinterpret_cast<const void *> (viterbi_kernel<2>) };
+  hipError_t e = hipFuncSetAttribute (fn[block_type], hipFuncAttributeMaxDynamicSharedMemorySize, int (lds));
   if (e != hipSuccess)
     return e;
   unsigned int *dec = reinterpret_cast<unsigned int *> (decisions_ws);
-  if (rate == 6)
-    hipLaunchKernelGGL (viterbi_kernel<6>, dim3 (unsigned (n_blocks)), dim3 (V_THREADS), lds, st, soft, gen, int (coded_len / rate), dec, bits_out, error_out);
+  const int n_steps = int (coded_len / rate);
+  const dim3 grid = dim3 ((unsigned) n_blocks), block = dim3 (V_THREADS);
+  if (block_type == 0)
+    hipLaunchKernelGGL (viterbi_kernel<0>, grid, block, lds, st, soft, n_steps, dec, bits_out, error_out);
+  else if (block_type == 1)
+    hipLaunchKernelGGL (viterbi_kernel<1>, grid, block, lds, st, soft, n_steps, dec, bits_out, error_out);
   else
-    hipLaunchKernelGGL (viterbi_kernel<12>, dim3 (unsigned (n_blocks)), dim3 (V_THREADS), lds, st, soft, gen, int (coded_len / rate), dec, bits_out, error_out);
+    hipLaunchKernelGGL (viterbi_kernel<2>, grid, block, lds, st, soft, n_steps, dec, bits_out, error_out);
   return hipGetLastError();
 }
 

@@ -2,6 +2,7 @@
 #include "utils.hh"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace awm {
 
@@ -31,6 +32,38 @@ int
 SyncFinder::search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& out)
 {
   out.clear();
+  long long n_scores = 0;
+  if (int rc = approx_device (kt, wav, mode, n_scores))
+    return rc;
+  return fetch_scores (n_scores, out);
+}
+
+int
+SyncFinder::fetch_scores (long long n_scores, std::vector<SearchScore>& out)
+{
+  out.clear();
+  if (n_scores <= 0)
+    return 0;
+  hipStream_t st = m_ctx->stream;
+  std::vector<double> raw (n_scores), mean (n_scores);
+  AWM_HIP_CHECK (hipMemcpyAsync (raw.data(), m_ctx->ws_raw.ptr, raw.size() * sizeof (double), hipMemcpyDeviceToHost, st));
+  AWM_HIP_CHECK (hipMemcpyAsync (mean.data(), m_ctx->ws_mean.ptr, mean.size() * sizeof (double), hipMemcpyDeviceToHost, st));
+  AWM_HIP_CHECK (hipStreamSynchronize (st));
+  out.resize (raw.size());
+  for (size_t p = 0; p < raw.size(); p++)
+    {
+      // sorted by index: index = start_frame * 1024 + shift * 256
+      out[p].index = (p >> 2) * Params::frame_size + (p & 3) * Params::sync_search_step;
+      out[p].raw_quality = raw[p];
+      out[p].local_mean = mean[p];
+    }
+  return 0;
+}
+
+int
+SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores)
+{
+  n_scores = 0;
   const int clip = mode == Mode::CLIP;
   const long long frame_count = wav.n_frames / Params::frame_size;
   const long long n_db = frame_count - 1;          // sync_fft_parallel drops the last frame (syncfinder.cc:632)
@@ -89,25 +122,61 @@ SyncFinder::search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
   {
     // algorithmic HBM bytes of the scan: the dB matrix once, candidates re-read it from cache
     ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0);
-    AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+    if (getenv ("AWM_SCAN_DIRECT"))
+      AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+    else
+      AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));
   }
   {
     ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_shifts) * S * 24.0);
     AWM_HIP_CHECK (awmk::launch_local_mean (st, m_ctx->ws_q.as<double>(), q_stride, S, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>()));
   }
 
-  std::vector<double> raw (n_shifts * S), mean (n_shifts * S);
-  AWM_HIP_CHECK (hipMemcpyAsync (raw.data(), m_ctx->ws_raw.ptr, raw.size() * sizeof (double), hipMemcpyDeviceToHost, st));
-  AWM_HIP_CHECK (hipMemcpyAsync (mean.data(), m_ctx->ws_mean.ptr, mean.size() * sizeof (double), hipMemcpyDeviceToHost, st));
+  n_scores = (long long) n_shifts * S;
+  return 0;
+}
+
+/* sync_select_local_maxima + sync_mask_avg_false_positives + sync_select_threshold_and_n_best
+ * (reference syncfinder.cc:519-526).  Fast path: the three steps run on the device (K5c) and only the
+ * survivors above the threshold come back; if fewer than n_best survive, the reference keeps the n_best
+ * largest maxima regardless of the threshold -- that rare case (unmarked or very short material) pulls all
+ * scores to the host and runs the sequential formulation. */
+int
+SyncFinder::select_candidates (long long n_scores, double threshold, std::vector<SearchScore>& out)
+{
+  out.clear();
+  if (n_scores <= 0)
+    return 0;
+  hipStream_t st = m_ctx->stream;
+  const unsigned int cap = 16384;
+  if (int rc = m_ctx->ws_misc.reserve (256 + cap * sizeof (awmk::PeakOut))) return rc;
+  auto *d_count = m_ctx->ws_misc.as<unsigned int>();
+  auto *d_out = reinterpret_cast<awmk::PeakOut *> (m_ctx->ws_misc.as<char>() + 256);
+  {
+    ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_scores) * 16.0);
+    AWM_HIP_CHECK (awmk::launch_peak_select (st, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>(), n_scores, threshold, d_count, d_out, cap));
+  }
+  unsigned int count = 0;
+  AWM_HIP_CHECK (hipMemcpyAsync (&count, d_count, sizeof (count), hipMemcpyDeviceToHost, st));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
-  out.resize (raw.size());
-  for (size_t p = 0; p < raw.size(); p++)
+  if (int (count) >= Params::get_n_best && count <= cap)
     {
-      // sorted by index: index = start_frame * 1024 + shift * 256
-      out[p].index = (p >> 2) * Params::frame_size + (p & 3) * Params::sync_search_step;
-      out[p].raw_quality = raw[p];
-      out[p].local_mean = mean[p];
+      std::vector<awmk::PeakOut> peaks (count);
+      AWM_HIP_CHECK (hipMemcpyAsync (peaks.data(), d_out, count * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      for (const auto& pk : peaks)
+        out.push_back ({ size_t (pk.p >> 2) * Params::frame_size + size_t (pk.p & 3) * Params::sync_search_step, pk.raw, pk.mean });
+      // same order the reference continues with: descending quality (atomics delivered them unordered)
+      std::sort (out.begin(), out.end(), [] (const SearchScore& a, const SearchScore& b) {
+        return a.abs_quality() != b.abs_quality() ? a.abs_quality() > b.abs_quality() : a.index < b.index;
+      });
+      return 0;
     }
+  if (int rc = fetch_scores (n_scores, out))
+    return rc;
+  select_local_maxima (out);
+  mask_avg_false_positives (out);
+  select_threshold_and_n_best (out, threshold);
   return 0;
 }
 
@@ -353,11 +422,11 @@ SyncFinder::search (const Key& key, const DeviceWav& wav, Mode mode, std::vector
   if (int rc = prepare (wav, mode))
     return rc;
   std::vector<SearchScore> scores;
-  if (int rc = search_approx (kt, wav, mode, scores))
+  long long n_scores = 0;
+  if (int rc = approx_device (kt, wav, mode, n_scores))
     return rc;
-  select_local_maxima (scores);
-  mask_avg_false_positives (scores);
-  select_threshold_and_n_best (scores, Params::sync_threshold2 * 0.75);
+  if (int rc = select_candidates (n_scores, Params::sync_threshold2 * 0.75, scores))
+    return rc;
   if (mode == Mode::CLIP)
     select_truncate_n (scores, std::max (Params::get_n_best, 5));
   if (int rc = search_refine (kt, wav, mode, scores))

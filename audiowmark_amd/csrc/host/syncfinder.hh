@@ -41,6 +41,10 @@ public:
   int search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out);
   int prepare (const DeviceWav& wav, Mode mode);     // silence scan (CLIP) / full range (BLOCK)
   int search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& out);
+  // kernels of search_approx only: scores stay on the device (ws_raw / ws_mean, index order); n_scores = 4 * start frames
+  int approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores);
+  // local maxima + mask + threshold (+ n_best fallback): the candidate list search_refine works on
+  int select_candidates (long long n_scores, double threshold, std::vector<SearchScore>& out);
   int search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& scores);
 
   static void select_local_maxima (std::vector<SearchScore>& scores);
@@ -51,6 +55,7 @@ private:
   awm_ctx *m_ctx;
   size_t   m_first = 0, m_last = 0;     // non-silent value range [first, last)
   int scan_silence (const DeviceWav& wav);
+  int fetch_scores (long long n_scores, std::vector<SearchScore>& out);
 };
 
 } // namespace awm

@@ -86,6 +86,20 @@ std::vector<MixEntry> gen_mix_entries (const Key& key);
 std::vector<unsigned> bit_order (const Key& key, size_t n);     // the permutation behind randomize_bit_order
 
 template<class T> std::vector<T>
+apply_bit_order (const std::vector<unsigned>& order, const std::vector<T>& bit_vec, bool encode)
+{
+  std::vector<T> out (bit_vec.size());
+  for (size_t i = 0; i < bit_vec.size(); i++)
+    {
+      if (encode)
+        out[i] = bit_vec[order[i]];
+      else
+        out[order[i]] = bit_vec[i];
+    }
+  return out;
+}
+
+template<class T> std::vector<T>
 randomize_bit_order (const Key& key, const std::vector<T>& bit_vec, bool encode)
 {
   const auto order = bit_order (key, bit_vec.size());

@@ -358,7 +358,7 @@ viterbi_decode (awm_ctx *ctx, ConvBlockType block_type, const std::vector<std::v
       AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_viterbi_in.ptr, flat.data(), flat.size() * sizeof (float), hipMemcpyHostToDevice, st));
       {
         ProfScope ps (ctx, PROF_VITERBI, double (nb) * (coded_len * 4.0 + 2.0 * awmk::viterbi_workspace_bytes (coded_len, rate, 1)));
-        AWM_HIP_CHECK (awmk::launch_viterbi (st, ctx->ws_viterbi_in.as<float>(), rate, gens.data(), coded_len, nb,
+        AWM_HIP_CHECK (awmk::launch_viterbi (st, ctx->ws_viterbi_in.as<float>(), int (block_type), coded_len, nb,
                                              ctx->ws_viterbi.as<unsigned char>(), ctx->ws_viterbi_bits.as<int>(), ctx->ws_viterbi_err.as<float>()));
       }
       std::vector<int> hbits (nb * n_out);
@@ -390,10 +390,12 @@ struct PendingDecode       // one Viterbi job and what to do with its result
   double             time;
   SyncFinder::Score  score;
   ResultSet::Type    type;
+  size_t             chunk = 0;       // which chunk's ResultSet receives the pattern
 };
 
+// all decodes of one code type go to the GPU in one launch, whatever chunk they belong to
 int
-run_pending (awm_ctx *ctx, const Key& key, std::vector<PendingDecode>& pending, ResultSet& result_set, double speed)
+run_pending (awm_ctx *ctx, const Key& key, std::vector<PendingDecode>& pending, const std::vector<ResultSet *>& result_sets, double speed)
 {
   for (ConvBlockType ct : { ConvBlockType::a, ConvBlockType::b, ConvBlockType::ab })
     {
@@ -402,7 +404,7 @@ run_pending (awm_ctx *ctx, const Key& key, std::vector<PendingDecode>& pending, 
       for (size_t i = 0; i < pending.size(); i++)
         if (pending[i].code_type == ct)
           {
-            soft.push_back (pending[i].soft);
+            soft.push_back (std::move (pending[i].soft));
             which.push_back (i);
           }
       std::vector<std::vector<int>> bits;
@@ -413,169 +415,197 @@ run_pending (awm_ctx *ctx, const Key& key, std::vector<PendingDecode>& pending, 
         {
           const PendingDecode& p = pending[which[j]];
           if (!bits[j].empty())
-            result_set.add_pattern (key, p.time, p.score, bits[j], errors[j], p.type, speed);
+            result_sets[p.chunk]->add_pattern (key, p.time, p.score, bits[j], errors[j], p.type, speed);
         }
     }
   return 0;
 }
 
+/* AB pairing and "all" pattern of BlockDecoder::run (reference wmget.cc:554-701) for the blocks of one chunk */
+void
+combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const DeviceWav& wav, size_t chunk, std::vector<PendingDecode>& pending)
+{
+  const size_t block_len = mark_block_frame_count() * Params::frame_size;
+  /* AB: a B block preceded by an A block one block length earlier */
+  for (size_t i = 0; i < pattern_raw_vec.size(); i++)
+    {
+      if (pattern_raw_vec[i].block_type != ConvBlockType::b)
+        continue;
+      int best_j = -1;
+      int best_abs_dist = Params::frame_size / 2;
+      for (size_t j = 0; j < i; j++)
+        if (pattern_raw_vec[j].block_type == ConvBlockType::a)
+          {
+            const int abs_dist = std::abs (int (pattern_raw_vec[i].index - pattern_raw_vec[j].index) - int (block_len));
+            if (abs_dist < best_abs_dist)
+              {
+                best_j = j;
+                best_abs_dist = abs_dist;
+              }
+          }
+      if (best_j < 0)
+        continue;
+      const auto& a_pattern = pattern_raw_vec[best_j];
+      const auto& b_pattern = pattern_raw_vec[i];
+      std::vector<float> ab_bits (a_pattern.raw_bit_vec.size() * 2);
+      for (size_t k = 0; k < a_pattern.raw_bit_vec.size(); k++)
+        {
+          ab_bits[2 * k] = a_pattern.raw_bit_vec[k];
+          ab_bits[2 * k + 1] = b_pattern.raw_bit_vec[k];
+        }
+      SyncFinder::Score score_ab { b_pattern.index, (a_pattern.quality + b_pattern.quality) / 2, ConvBlockType::ab };
+      pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (ab_bits), double (b_pattern.index) / wav.sample_rate,
+                           score_ab, ResultSet::Type::BLOCK, chunk });
+    }
+  /* all: best chain of consecutive, alternating blocks */
+  std::vector<size_t> best_all_blocks;
+  auto sync_sum = [&] (const std::vector<size_t>& blocks) {
+    float sum = 0;
+    for (auto b : blocks)
+      sum += pattern_raw_vec[b].quality;
+    return sum;
+  };
+  for (size_t i = 0; i < pattern_raw_vec.size(); i++)
+    {
+      const size_t max_block_idx = lrint (pattern_raw_vec.back().index / double (block_len) + 0.5);
+      std::vector<size_t> all_blocks { i };
+      size_t block_idx = 1;
+      while (block_idx <= max_block_idx)
+        {
+          const size_t expect_start = pattern_raw_vec[all_blocks.back()].index + block_idx * block_len;
+          int best_j = -1;
+          int best_abs_dist = block_idx * Params::frame_size / 2;
+          auto expect_type = pattern_raw_vec[all_blocks.back()].block_type;
+          if (block_idx & 1)
+            expect_type = expect_type == ConvBlockType::a ? ConvBlockType::b : ConvBlockType::a;
+          for (size_t j = all_blocks.back(); j < pattern_raw_vec.size(); j++)
+            {
+              const int abs_dist = std::abs (int (expect_start) - int (pattern_raw_vec[j].index));
+              if (abs_dist < best_abs_dist && pattern_raw_vec[j].block_type == expect_type)
+                {
+                  best_j = j;
+                  best_abs_dist = abs_dist;
+                }
+            }
+          if (best_j >= 0)
+            {
+              all_blocks.push_back (best_j);
+              block_idx = 1;
+            }
+          else
+            block_idx++;
+        }
+      if (sync_sum (all_blocks) > sync_sum (best_all_blocks))
+        best_all_blocks = all_blocks;
+    }
+  if (best_all_blocks.size() > 1)
+    {
+      std::vector<float> all_bits (code_size (ConvBlockType::ab, Params::payload_size));
+      int norm[2] = { 0, 0 };
+      SyncFinder::Score score_all { 0, 0, ConvBlockType::a };
+      for (auto bi : best_all_blocks)
+        {
+          const auto& pattern = pattern_raw_vec[bi];
+          score_all.quality += pattern.quality;
+          const int ab = pattern.block_type == ConvBlockType::b ? 1 : 0;
+          for (size_t k = 0; k < pattern.raw_bit_vec.size(); k++)
+            all_bits[2 * k + ab] += pattern.raw_bit_vec[k];
+          norm[ab]++;
+        }
+      for (size_t k = 0; k < all_bits.size(); k += 2)
+        {
+          all_bits[k]     /= std::max (norm[0], 1);
+          all_bits[k + 1] /= std::max (norm[1], 1);
+        }
+      score_all.quality /= norm[0] + norm[1];
+      pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (all_bits), 0.0, score_all, ResultSet::Type::ALL, chunk });
+    }
+}
+
+/* BlockDecoder::run (reference wmget.cc:502-706) for several chunks of one resident stream at once.  Every chunk
+ * is searched and combined on its own exactly like the reference does; only the device work is batched across
+ * chunks (soft bits in one pass, one Viterbi launch per code type). */
 int
-block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set,
-                   double speed, std::string *debug_sync)
+block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& stream, const std::vector<ChunkRange>& chunks,
+                   const std::vector<ResultSet *>& result_sets, double speed, std::string *debug_sync_first_chunk)
 {
   SyncFinder sync_finder (ctx);
   const size_t count = mark_block_frame_count();
-  const size_t block_len = count * Params::frame_size;
-  std::vector<SyncFinder::Score> first_key_scores;
+  std::vector<SyncFinder::Score> first_scores;
   for (size_t ki = 0; ki < key_list.size(); ki++)
     {
       const Key& key = key_list[ki];
       KeyTables *kt = ctx->get_key_tables (key);
       if (!kt)
         return AWM_ERR_HIP;
-      std::vector<SyncFinder::Score> sync_scores;
-      if (int rc = sync_finder.search (key, wav, SyncFinder::Mode::BLOCK, sync_scores))
-        return rc;
-      if (ki == 0)
-        first_key_scores = sync_scores;
-
-      std::vector<size_t> index;
-      for (const auto& s : sync_scores)
-        index.push_back (s.index);
+      std::vector<std::vector<SyncFinder::Score>> scores (chunks.size());
+      std::vector<size_t> abs_index;
+      for (size_t c = 0; c < chunks.size(); c++)
+        {
+          DeviceWav cw = stream;
+          cw.data = stream.data + chunks[c].first_frame * stream.n_channels;
+          cw.n_frames = chunks[c].n_frames;
+          if (int rc = sync_finder.search (key, cw, SyncFinder::Mode::BLOCK, scores[c]))
+            return rc;
+          if (ki == 0 && c == 0)
+            first_scores = scores[c];
+          for (const auto& s : scores[c])
+            {
+              // fft_range refuses blocks that run past the end OF THE CHUNK (reference wmcommon.cc:128-130)
+              const bool ok = cw.n_frames >= s.index + count * Params::frame_size;
+              abs_index.push_back (ok ? chunks[c].first_frame + s.index : size_t (-1));
+            }
+        }
+      std::vector<size_t> wanted;
+      for (size_t v : abs_index)
+        if (v != size_t (-1))
+          wanted.push_back (v);
       std::vector<std::vector<float>> raw;
       std::vector<char> ok;
-      if (int rc = block_soft_bits (ctx, kt, wav, index, raw, ok))
+      if (int rc = block_soft_bits (ctx, kt, stream, wanted, raw, ok))
         return rc;
 
-      std::vector<PatternRawBits> pattern_raw_vec;
       std::vector<PendingDecode> pending;
-      for (size_t i = 0; i < sync_scores.size(); i++)
+      size_t flat = 0, got = 0;
+      for (size_t c = 0; c < chunks.size(); c++)
         {
-          if (!ok[i])
-            continue;
-          PatternRawBits rb;
-          rb.index = sync_scores[i].index;
-          rb.quality = sync_scores[i].quality;
-          rb.raw_bit_vec = randomize_bit_order (key, raw[i], /* encode */ false);
-          rb.block_type = sync_scores[i].block_type;
-          pattern_raw_vec.push_back (rb);
-          pending.push_back ({ rb.block_type, normalize_soft_bits (rb.raw_bit_vec),
-                               double (rb.index) / wav.sample_rate, sync_scores[i], ResultSet::Type::BLOCK });
-        }
-      /* AB: a B block preceded by an A block one block length earlier */
-      for (size_t i = 0; i < pattern_raw_vec.size(); i++)
-        {
-          if (pattern_raw_vec[i].block_type != ConvBlockType::b)
-            continue;
-          int best_j = -1;
-          int best_abs_dist = Params::frame_size / 2;
-          for (size_t j = 0; j < i; j++)
-            if (pattern_raw_vec[j].block_type == ConvBlockType::a)
-              {
-                const int abs_dist = std::abs (int (pattern_raw_vec[i].index - pattern_raw_vec[j].index) - int (block_len));
-                if (abs_dist < best_abs_dist)
-                  {
-                    best_j = j;
-                    best_abs_dist = abs_dist;
-                  }
-              }
-          if (best_j < 0)
-            continue;
-          const auto& a_pattern = pattern_raw_vec[best_j];
-          const auto& b_pattern = pattern_raw_vec[i];
-          std::vector<float> ab_bits (a_pattern.raw_bit_vec.size() * 2);
-          for (size_t k = 0; k < a_pattern.raw_bit_vec.size(); k++)
+          std::vector<PatternRawBits> pattern_raw_vec;
+          for (const auto& s : scores[c])
             {
-              ab_bits[2 * k] = a_pattern.raw_bit_vec[k];
-              ab_bits[2 * k + 1] = b_pattern.raw_bit_vec[k];
+              if (abs_index[flat++] == size_t (-1))
+                continue;
+              const std::vector<float>& bits = raw[got++];
+              PatternRawBits rb;
+              rb.index = s.index;
+              rb.quality = s.quality;
+              rb.raw_bit_vec = apply_bit_order (kt->bit_order_a, bits, /* encode */ false);   // randomize_bit_order, permutation cached per key
+              rb.block_type = s.block_type;
+              pending.push_back ({ rb.block_type, normalize_soft_bits (rb.raw_bit_vec), double (rb.index) / stream.sample_rate,
+                                   s, ResultSet::Type::BLOCK, c });
+              pattern_raw_vec.push_back (std::move (rb));
             }
-          SyncFinder::Score score_ab { b_pattern.index, (a_pattern.quality + b_pattern.quality) / 2, ConvBlockType::ab };
-          pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (ab_bits), double (b_pattern.index) / wav.sample_rate,
-                               score_ab, ResultSet::Type::BLOCK });
+          combine_blocks (pattern_raw_vec, stream, c, pending);
         }
-      /* all: best chain of consecutive, alternating blocks */
-      std::vector<size_t> best_all_blocks;
-      auto sync_sum = [&] (const std::vector<size_t>& blocks) {
-        float sum = 0;
-        for (auto b : blocks)
-          sum += pattern_raw_vec[b].quality;
-        return sum;
-      };
-      for (size_t i = 0; i < pattern_raw_vec.size(); i++)
-        {
-          const size_t max_block_idx = lrint (pattern_raw_vec.back().index / double (block_len) + 0.5);
-          std::vector<size_t> all_blocks { i };
-          size_t block_idx = 1;
-          while (block_idx <= max_block_idx)
-            {
-              const size_t expect_start = pattern_raw_vec[all_blocks.back()].index + block_idx * block_len;
-              int best_j = -1;
-              int best_abs_dist = block_idx * Params::frame_size / 2;
-              auto expect_type = pattern_raw_vec[all_blocks.back()].block_type;
-              if (block_idx & 1)
-                expect_type = expect_type == ConvBlockType::a ? ConvBlockType::b : ConvBlockType::a;
-              for (size_t j = all_blocks.back(); j < pattern_raw_vec.size(); j++)
-                {
-                  const int abs_dist = std::abs (int (expect_start) - int (pattern_raw_vec[j].index));
-                  if (abs_dist < best_abs_dist && pattern_raw_vec[j].block_type == expect_type)
-                    {
-                      best_j = j;
-                      best_abs_dist = abs_dist;
-                    }
-                }
-              if (best_j >= 0)
-                {
-                  all_blocks.push_back (best_j);
-                  block_idx = 1;
-                }
-              else
-                block_idx++;
-            }
-          if (sync_sum (all_blocks) > sync_sum (best_all_blocks))
-            best_all_blocks = all_blocks;
-        }
-      if (best_all_blocks.size() > 1)
-        {
-          std::vector<float> all_bits (code_size (ConvBlockType::ab, Params::payload_size));
-          int norm[2] = { 0, 0 };
-          SyncFinder::Score score_all { 0, 0, ConvBlockType::a };
-          for (auto bi : best_all_blocks)
-            {
-              const auto& pattern = pattern_raw_vec[bi];
-              score_all.quality += pattern.quality;
-              const int ab = pattern.block_type == ConvBlockType::b ? 1 : 0;
-              for (size_t k = 0; k < pattern.raw_bit_vec.size(); k++)
-                all_bits[2 * k + ab] += pattern.raw_bit_vec[k];
-              norm[ab]++;
-            }
-          for (size_t k = 0; k < all_bits.size(); k += 2)
-            {
-              all_bits[k]     /= std::max (norm[0], 1);
-              all_bits[k + 1] /= std::max (norm[1], 1);
-            }
-          score_all.quality /= norm[0] + norm[1];
-          pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (all_bits), 0.0, score_all, ResultSet::Type::ALL });
-        }
-      if (int rc = run_pending (ctx, key, pending, result_set, speed))
+      if (int rc = run_pending (ctx, key, pending, result_sets, speed))
         return rc;
     }
-  if (debug_sync)
+  if (debug_sync_first_chunk)
     {
-      debug_sync->clear();
-      if (key_list.size() == 1)
+      debug_sync_first_chunk->clear();
+      if (key_list.size() == 1 && !chunks.empty())
         {
           const int expect0 = Params::frames_pad_start * Params::frame_size;
-          const int expect_step = block_len;
-          const int expect_end = int (wav.n_frames / Params::frame_size) * Params::frame_size;
+          const int expect_step = count * Params::frame_size;
+          const int expect_end = int (chunks[0].n_frames / Params::frame_size) * Params::frame_size;
           int sync_match = 0;
           for (int expect_index = expect0; expect_index + expect_step < expect_end; expect_index += expect_step)
-            for (const auto& s : first_key_scores)
+            for (const auto& s : first_scores)
               if (std::abs (int (s.index + Params::test_cut) - expect_index) < int (Params::frame_size / 2))
                 {
                   sync_match++;
                   break;
                 }
-          *debug_sync = string_printf ("sync_match %d %zd\n", sync_match, first_key_scores.size());
+          *debug_sync_first_chunk = string_printf ("sync_match %d %zd\n", sync_match, first_scores.size());
         }
     }
   return 0;
@@ -612,8 +642,8 @@ clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav
         {
           if (!ok[2 * i] || !ok[2 * i + 1])
             continue;
-          const auto bits1 = randomize_bit_order (key, raw[2 * i], false);
-          const auto bits2 = randomize_bit_order (key, raw[2 * i + 1], false);
+          const auto bits1 = apply_bit_order (kt->bit_order_a, raw[2 * i], false);
+          const auto bits2 = apply_bit_order (kt->bit_order_a, raw[2 * i + 1], false);
           std::vector<float> ab;
           ab.reserve (bits1.size() * 2);
           for (size_t k = 0; k < bits1.size(); k++)
@@ -631,9 +661,9 @@ clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav
             }
           SyncFinder::Score nopad = sync_scores[i];
           nopad.index = time_offset_sec * wav.sample_rate;
-          pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (ab), time_offset_sec, nopad, ResultSet::Type::CLIP });
+          pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (ab), time_offset_sec, nopad, ResultSet::Type::CLIP, 0 });
         }
-      if (int rc = run_pending (ctx, key, pending, result_set, speed))
+      if (int rc = run_pending (ctx, key, pending, { &result_set }, speed))
         return rc;
     }
   return 0;
@@ -698,7 +728,7 @@ int
 decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav, bool first_chunk)
 {
   std::string debug_sync;
-  if (int rc = block_decoder_run (ctx, key_list, wav, result_set, 1, &debug_sync))
+  if (int rc = block_decoder_run (ctx, key_list, wav, { ChunkRange { 0, wav.n_frames, 0.0 } }, { &result_set }, 1, &debug_sync))
     return rc;
   if (first_chunk)
     if (int rc = clip_decoder_run (ctx, key_list, wav, result_set, 1))
@@ -746,18 +776,27 @@ plan_chunks (size_t n_frames, int n_channels)
 int
 get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set)
 {
-  bool first_chunk = true;
-  for (const auto& chunk : plan_chunks (wav.n_frames, wav.n_channels))
+  const auto chunks = plan_chunks (wav.n_frames, wav.n_channels);
+  std::vector<ResultSet> chunk_sets (chunks.size());
+  std::vector<ResultSet *> ptrs;
+  for (auto& cs : chunk_sets)
+    ptrs.push_back (&cs);
+  std::string debug_sync;
+  if (int rc = block_decoder_run (ctx, key_list, wav, chunks, ptrs, 1, &debug_sync))
+    return rc;
+  if (!chunks.empty())
     {
+      // ClipDecoder only looks at the first chunk (reference wmget.cc:932-936)
       DeviceWav cw = wav;
-      cw.data = wav.data + chunk.first_frame * wav.n_channels;
-      cw.n_frames = chunk.n_frames;
-      ResultSet chunk_set;
-      if (int rc = decode_chunk (ctx, chunk_set, key_list, cw, first_chunk))
+      cw.n_frames = chunks[0].n_frames;
+      if (int rc = clip_decoder_run (ctx, key_list, cw, chunk_sets[0], 1))
         return rc;
-      chunk_set.apply_time_offset (chunk.time_offset);
-      result_set.merge (chunk_set);
-      first_chunk = false;
+      chunk_sets[0].set_debug_sync (debug_sync);
+    }
+  for (size_t c = 0; c < chunks.size(); c++)
+    {
+      chunk_sets[c].apply_time_offset (chunks[c].time_offset);
+      result_set.merge (chunk_sets[c]);
     }
   result_set.sort (key_list);
   return 0;
