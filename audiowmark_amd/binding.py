@@ -101,6 +101,7 @@ lib.awm_tab_synth_window.argtypes = [_vp]
 lib.awm_conv_encode.argtypes = [C.c_int, _vp, C.c_size_t, _vp]
 
 
+lib.awm_decode_chunks_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_size_t, _vp, _vp]
 lib.awm_plan_chunks.argtypes = [C.c_size_t, C.c_size_t, _vp, _vp, _vp]
 lib.awm_merge_patterns.argtypes = [_vp, _vp, _vp, C.c_int, C.c_size_t, _vp]
 lib.awm_prof_name.restype = C.c_char_p
@@ -392,6 +393,22 @@ class Context:
     def get_watermark(self, key, pcm):
         n, ch = _pcm_shape(pcm)
         return self._patterns(lib.awm_get_watermark_d, "awm_get_watermark_d", self._h, key_bytes(key), _dev_ptr(pcm), n, ch)
+
+    def decode_chunks(self, key, pcm, chunks, first_is_stream_start, max_out=8192):
+        """decode() of several chunks [(first_frame, n_frames), ...] of one resident buffer; returns one pattern list per
+        chunk (times relative to the chunk)."""
+        n, ch = _pcm_shape(pcm)
+        first = np.array([c[0] for c in chunks], np.uint64)
+        count = np.array([c[1] for c in chunks], np.uint64)
+        buf = (Pattern * max_out)()
+        which = np.zeros(max_out, np.int32)
+        cnt = _check(lib.awm_decode_chunks_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, len(chunks), _np(first), _np(count),
+                                             int(first_is_stream_start), max_out, C.cast(buf, C.c_void_p), _np(which)),
+                     "awm_decode_chunks_d")
+        out = [[] for _ in chunks]
+        for i in range(min(cnt, max_out)):
+            out[which[i]].append(buf[i].as_dict())
+        return out
 
     def decode_chunk(self, key, pcm, first_chunk=True):
         n, ch = _pcm_shape(pcm)

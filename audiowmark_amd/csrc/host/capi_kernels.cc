@@ -409,6 +409,43 @@ awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, si
 }
 
 int
+awm_decode_chunks_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
+                     int n_chunks, const uint64_t *first_frame, const uint64_t *chunk_frames, int first_is_stream_start,
+                     size_t max_out, awm_pattern *out, int *chunk_of_pattern)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  std::vector<ChunkRange> chunks;
+  for (int i = 0; i < n_chunks; i++)
+    {
+      if (first_frame[i] + chunk_frames[i] > n_frames)
+        {
+          set_error ("awm_decode_chunks_d: chunk exceeds the buffer");
+          return AWM_ERR_ARG;
+        }
+      chunks.push_back ({ size_t (first_frame[i]), size_t (chunk_frames[i]), 0.0 });
+    }
+  std::vector<ResultSet> sets;
+  if (int rc = decode_chunks (ctx, { capi_key (key) }, make_wav (pcm_d, n_frames, n_channels), chunks, first_is_stream_start != 0, sets))
+    return rc;
+  size_t n = 0;
+  for (size_t c = 0; c < sets.size(); c++)
+    {
+      auto& pats = sets[c].patterns;
+      std::stable_sort (pats.begin(), pats.end(), [] (const ResultSet::Pattern& a, const ResultSet::Pattern& b) { return a.time < b.time; });
+      for (const auto& p : pats)
+        {
+          if (n < max_out)
+            {
+              fill_pattern (p, out[n]);
+              chunk_of_pattern[n] = int (c);
+            }
+          n++;
+        }
+    }
+  return int (n);
+}
+
+int
 awm_plan_chunks (size_t n_frames, size_t max_out, uint64_t *first_frame, uint64_t *chunk_frames, double *time_offset)
 {
   const auto chunks = plan_chunks (n_frames, 1);

@@ -774,25 +774,37 @@ plan_chunks (size_t n_frames, int n_channels)
 }
 
 int
-get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set)
+decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
+               bool first_is_stream_start, std::vector<ResultSet>& chunk_sets)
 {
-  const auto chunks = plan_chunks (wav.n_frames, wav.n_channels);
-  std::vector<ResultSet> chunk_sets (chunks.size());
+  chunk_sets.clear();
+  chunk_sets.resize (chunks.size());
   std::vector<ResultSet *> ptrs;
   for (auto& cs : chunk_sets)
     ptrs.push_back (&cs);
   std::string debug_sync;
   if (int rc = block_decoder_run (ctx, key_list, wav, chunks, ptrs, 1, &debug_sync))
     return rc;
-  if (!chunks.empty())
+  if (!chunks.empty() && first_is_stream_start)
     {
-      // ClipDecoder only looks at the first chunk (reference wmget.cc:932-936)
+      // ClipDecoder only looks at the first chunk of the stream (reference wmget.cc:932-936)
       DeviceWav cw = wav;
+      cw.data = wav.data + chunks[0].first_frame * wav.n_channels;
       cw.n_frames = chunks[0].n_frames;
       if (int rc = clip_decoder_run (ctx, key_list, cw, chunk_sets[0], 1))
         return rc;
       chunk_sets[0].set_debug_sync (debug_sync);
     }
+  return 0;
+}
+
+int
+get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set)
+{
+  const auto chunks = plan_chunks (wav.n_frames, wav.n_channels);
+  std::vector<ResultSet> chunk_sets;
+  if (int rc = decode_chunks (ctx, key_list, wav, chunks, true, chunk_sets))
+    return rc;
   for (size_t c = 0; c < chunks.size(); c++)
     {
       chunk_sets[c].apply_time_offset (chunks[c].time_offset);

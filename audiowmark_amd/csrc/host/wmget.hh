@@ -46,6 +46,10 @@ int decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& k
 struct ChunkRange { size_t first_frame, n_frames; double time_offset; };
 std::vector<ChunkRange> plan_chunks (size_t n_frames, int n_channels);
 
+// decode() for several chunks of one resident buffer (batched device work); result_sets[i] receives chunk i's patterns
+int decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
+                   bool first_is_stream_start, std::vector<ResultSet>& result_sets);
+
 // whole detect pass over resident PCM: chunks, merge, sort
 int get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set);
 

@@ -1,0 +1,201 @@
+"""Long streams sharded over the GPUs of one node -- one process per GPU, torch.distributed (RCCL over xGMI).
+
+The stream is the concatenation of the ranks' local spans (rank order).  Nothing here touches sample data on the
+host; the only traffic between ranks is what the algorithm itself couples:
+
+  add   every span needs the one 1024-sample frame before and after it (3-frame overlap-add, reference
+        wmadd.cc:228-238) and the limiter needs max|x| of the seconds straddling span edges (limiter.cc:99-124)
+        -> one all_gather of the edge frames (16 KB per rank) + one all_reduce(MAX) of the per-second maxima.
+  get   the reference's own chunks (wavchunkloader.cc:54-163) are the shard unit; a chunk is decoded by the rank
+        that holds its midpoint, the part of it that lives on a neighbour is fetched point-to-point (the "overlap
+        stitch"), found patterns are gathered on rank 0 and merged with ResultSet semantics (wmget.cc:288-316).
+
+`Partition` and the exchange helpers are backend agnostic (they are exercised with gloo / CPU tensors in
+tests/test_sharded_gloo.py); the compute calls need a GPU.
+"""
+from dataclasses import dataclass
+from typing import List, Tuple
+
+import numpy as np
+
+from . import binding as awm
+
+FRAME = 1024
+LIMITER_BLOCK = 44100
+
+
+@dataclass
+class Partition:
+    """Contiguous spans of a stream, one per rank; every span but the last must be a whole number of frames."""
+    lengths: List[int]
+
+    def __post_init__(self):
+        for n in self.lengths[:-1]:
+            if n % FRAME:
+                raise ValueError("every span except the last one must be a multiple of 1024 samples")
+        self.starts = [0]
+        for n in self.lengths:
+            self.starts.append(self.starts[-1] + n)
+
+    @property
+    def total(self):
+        return self.starts[-1]
+
+    def span(self, rank):
+        return self.starts[rank], self.starts[rank + 1]
+
+    def owner_of(self, sample):
+        for r in range(len(self.lengths)):
+            if self.starts[r] <= sample < self.starts[r + 1]:
+                return r
+        return len(self.lengths) - 1
+
+    # ---- get: reference chunks ----------------------------------------------------------------
+    def chunk_plan(self):
+        """[(first_frame, n_frames, time_offset, owner_rank)] for the whole stream."""
+        out = []
+        for first, count, off in awm.plan_chunks(self.total):
+            out.append((first, count, off, self.owner_of(first + count // 2)))
+        return out
+
+    def chunk_range(self, rank):
+        """(lo, hi, chunks) -- the global sample range rank must hold to decode its chunks; chunks are consecutive."""
+        mine = [(i, c) for i, c in enumerate(self.chunk_plan()) if c[3] == rank]
+        if not mine:
+            return 0, 0, []
+        lo = min(c[0] for _, c in mine)
+        hi = max(c[0] + c[1] for _, c in mine)
+        return lo, hi, mine
+
+    def transfers(self):
+        """All point-to-point copies needed before `get`: (src_rank, dst_rank, global_lo, global_hi)."""
+        out = []
+        for dst in range(len(self.lengths)):
+            lo, hi, _ = self.chunk_range(dst)
+            for src in range(len(self.lengths)):
+                if src == dst:
+                    continue
+                s, e = self.span(src)
+                a, b = max(lo, s), min(hi, e)
+                if a < b:
+                    out.append((src, dst, a, b))
+        return out
+
+
+def exchange_edge_frames(dist, local, n_channels):
+    """all_gather of each rank's first and last frame -> (halo_before, halo_after) for this rank (None at the ends).
+    A last frame shorter than 1024 samples is zero padded (it can only be the end of the stream)."""
+    import torch
+    rank, world = dist.get_rank(), dist.get_world_size()
+    n = local.shape[0]
+    edge = torch.zeros((2, FRAME, n_channels), dtype=local.dtype, device=local.device)
+    view = local.reshape(n, n_channels)
+    edge[0, :min(FRAME, n)] = view[:FRAME]
+    last_start = max(0, ((n - 1) // FRAME) * FRAME) if n else 0
+    tail = view[last_start:]
+    edge[1, :tail.shape[0]] = tail
+    gathered = [torch.empty_like(edge) for _ in range(world)]
+    dist.all_gather(gathered, edge)
+    before = gathered[rank - 1][1].contiguous() if rank > 0 else None
+    after = gathered[rank + 1][0].contiguous() if rank + 1 < world else None
+    return before, after
+
+
+def fetch_range(dist, part: Partition, local, n_channels):
+    """Assemble the global sample range this rank needs for its chunks: own samples are copied, the rest arrives
+    point-to-point from the neighbours.  Returns (buffer, lo)."""
+    import torch
+    rank = dist.get_rank()
+    lo, hi, _ = part.chunk_range(rank)
+    my_s, my_e = part.span(rank)
+    view = local.reshape(local.shape[0], n_channels)
+    buf = torch.empty((max(0, hi - lo), n_channels), dtype=local.dtype, device=local.device)
+    a, b = max(lo, my_s), min(hi, my_e)
+    if a < b:
+        buf[a - lo:b - lo] = view[a - my_s:b - my_s]
+    ops, keep = [], []
+    for src, dst, g_lo, g_hi in part.transfers():
+        if src == rank:
+            t = view[g_lo - my_s:g_hi - my_s].contiguous()
+            keep.append(t)
+            ops.append(dist.P2POp(dist.isend, t, dst))
+        elif dst == rank:
+            t = torch.empty((g_hi - g_lo, n_channels), dtype=local.dtype, device=local.device)
+            keep.append((t, g_lo))
+            ops.append(dist.P2POp(dist.irecv, t, src))
+    if ops:
+        for req in dist.batch_isend_irecv(ops):
+            req.wait()
+    for item in keep:
+        if isinstance(item, tuple):
+            t, g_lo = item
+            buf[g_lo - lo:g_lo - lo + t.shape[0]] = t
+    return buf, lo
+
+
+def gather_and_merge(dist, part: Partition, key, my_chunk_patterns):
+    """my_chunk_patterns: {global chunk index: [pattern dicts with chunk relative times]} -> merged list on rank 0."""
+    plan = part.chunk_plan()
+    payload = {}
+    for ci, pats in my_chunk_patterns.items():
+        off = plan[ci][2]
+        payload[ci] = [dict(p, time=p["time"] + off) for p in pats]          # ResultSet::apply_time_offset
+    world = dist.get_world_size()
+    gathered = [None] * world if dist.get_rank() == 0 else None
+    dist.gather_object(payload, gathered, dst=0)
+    if dist.get_rank() != 0:
+        return None
+    per_chunk = [[] for _ in plan]
+    for d in gathered:
+        for ci, pats in d.items():
+            per_chunk[ci] = pats
+    return awm.merge_patterns(key, per_chunk)
+
+
+class ShardedStream:
+    """add / get on a stream whose spans live on the ranks of `dist` (one GPU each)."""
+
+    def __init__(self, ctx, dist, n_frames_local, n_channels):
+        import torch
+        self.ctx, self.dist, self.n_channels = ctx, dist, n_channels
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        lens = [torch.zeros(1, dtype=torch.int64, device=self._device()) for _ in range(self.world)]
+        dist.all_gather(lens, torch.tensor([n_frames_local], dtype=torch.int64, device=self._device()))
+        self.part = Partition([int(t.item()) for t in lens])
+        self._fm_cache = {}
+
+    def _device(self):
+        import torch
+        return torch.device("cuda", self.ctx.device)
+
+    def _frame_mod(self, key, payload_hex):
+        k = (awm.key_bytes(key), payload_hex)
+        if k not in self._fm_cache:
+            self._fm_cache[k] = awm.tab_frame_mod(key, payload_hex)
+        return self._fm_cache[k]
+
+    def add_watermark(self, key, payload_hex, local, out, water_delta=0.01, use_limiter=True):
+        import torch
+        dist = self.dist
+        start, _ = self.part.span(self.rank)
+        before, after = exchange_edge_frames(dist, local, self.n_channels)
+        block_max = None
+        if use_limiter:
+            n_blocks = self.part.total // LIMITER_BLOCK + 2
+            block_max = torch.empty(n_blocks, dtype=torch.float32, device=local.device)
+            self.ctx.add_init_block_max(block_max)
+        self.ctx.add_mix(local, out, self._frame_mod(key, payload_hex), water_delta, start // FRAME, before, after, block_max)
+        if use_limiter:
+            dist.all_reduce(block_max, op=dist.ReduceOp.MAX)      # seconds that straddle span edges
+            self.ctx.add_limit(out, start, block_max)
+        return out
+
+    def get_watermark(self, key, local):
+        buf, lo = fetch_range(self.dist, self.part, local, self.n_channels)
+        _, _, mine = self.part.chunk_range(self.rank)
+        found = {}
+        if mine:
+            rel = [(c[0] - lo, c[1]) for _, c in mine]
+            lists = self.ctx.decode_chunks(key, buf, rel, first_is_stream_start=(mine[0][0] == 0))
+            found = {ci: pats for (ci, _), pats in zip(mine, lists)}
+        return gather_and_merge(self.dist, self.part, key, found)

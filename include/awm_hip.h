@@ -161,6 +161,15 @@ int awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d
 int awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
                         int n_channels, int first_chunk, size_t max_out, awm_pattern *out);
 
+/* decode() for several chunks that live in one resident buffer (chunk i = frames [first_frame[i], first_frame[i] +
+ * chunk_frames[i]) of pcm_d); device work is batched across the chunks, every chunk is searched / combined on its own
+ * exactly like awm_decode_chunk_d.  first_is_stream_start != 0 runs the ClipDecoder on chunk 0.  Pattern times are
+ * relative to their chunk; chunk_of_pattern[j] tells which chunk pattern j belongs to (patterns are ordered by chunk,
+ * then time).  This is the per-rank unit of a sharded `get`. */
+int awm_decode_chunks_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
+                         int n_chunks, const uint64_t *first_frame, const uint64_t *chunk_frames, int first_is_stream_start,
+                         size_t max_out, awm_pattern *out, int *chunk_of_pattern);
+
 /* chunk plan of WavChunkLoader (wavchunkloader.cc:54-163) for a stream of n_frames samples per channel:
  * chunk i covers [first_frame[i], first_frame[i] + chunk_frames[i]) and reports times offset by
  * time_offset[i] seconds.  Pure host.  Returns the chunk count (<= max_out filled).  The chunks are the

@@ -303,3 +303,29 @@ def test_full_size_60min_roundtrip(gpu):
     for p in sub:
         if p["type"] == 0 and p["bits"] == PAY1:
             assert (round(p["time"] + off, 3), p["block_type"], p["bits"]) in merged
+
+
+def test_sharded_stream_world1(gpu):
+    """The torch.distributed (RCCL) code path with a single rank gives the same PCM / patterns as the plain calls."""
+    import torch.distributed as dist
+    from audiowmark_amd import sharded
+    t = gpu.torch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=t.device("cuda", 0))
+        created = True
+    try:
+        n = 75 * 44100 + 5
+        x = gpu.dev(noise(91, n, 2))
+        pipe = sharded.ShardedStream(gpu.ctx, dist, n, 2)
+        out = t.empty_like(x)
+        pipe.add_watermark(None, PAY1, x, out)
+        assert t.equal(out, gpu.ctx.add_watermark(None, PAY1, x))
+        got = pipe.get_watermark(None, out)
+        want = gpu.ctx.get_watermark(None, out)
+        assert [pkey(p) for p in got] == [pkey(p) for p in want]
+    finally:
+        if created:
+            dist.destroy_process_group()
