@@ -1,0 +1,614 @@
+#include "audiostream.hh"
+#include "wmcommon.hh"
+#include <algorithm>
+#include <cerrno>
+#include <cstring>
+
+namespace awm {
+
+RawFormat StreamParams::raw_input_format;
+RawFormat StreamParams::raw_output_format;
+
+/* ---- sample conversion ----------------------------------------------------------------- */
+
+std::unique_ptr<PcmCodec>
+PcmCodec::create (const RawFormat& format, Error& err, bool libsndfile_int_rule)
+{
+  err = Error::Code::NONE;
+  if (format.encoding == Encoding::FLOAT)
+    {
+      if (format.bit_depth != 32 && format.bit_depth != 64)
+        {
+          err = Error (string_printf ("unsupported bit depth %d for float encoding", format.bit_depth));
+          return nullptr;
+        }
+    }
+  else if (format.bit_depth != 8 && format.bit_depth != 16 && format.bit_depth != 24 && format.bit_depth != 32)
+    {
+      err = Error (string_printf ("unsupported bit depth %d", format.bit_depth));
+      return nullptr;
+    }
+  std::unique_ptr<PcmCodec> codec (new PcmCodec());
+  codec->m_format = format;
+  codec->m_libsndfile_int_rule = libsndfile_int_rule;
+  return codec;
+}
+
+template<int BITS> static inline int
+float_to_int_clip (float f)
+{
+  // scale in float, saturate, truncate toward zero (reference rawconverter.hh:34-50)
+  const int64_t inorm = 1LL << (BITS - 1);
+  const float snorm = f * float (inorm);
+  if (snorm >= float (inorm - 1))
+    return int (inorm - 1);
+  if (snorm <= float (-inorm))
+    return int (-inorm);
+  return int (snorm);
+}
+
+static inline float
+float_clip (float f)
+{
+  return f >= 1 ? 1.f : (f <= -1 ? -1.f : f);
+}
+
+void
+PcmCodec::decode (const unsigned char *bytes, float *samples, size_t n) const
+{
+  const int width = sample_width();
+  const bool big = m_format.endian == RawFormat::BIG;
+  if (m_format.encoding == Encoding::FLOAT)
+    {
+      for (size_t i = 0; i < n; i++)
+        {
+          unsigned char tmp[8];
+          for (int b = 0; b < width; b++)
+            tmp[b] = bytes[i * width + (big ? width - 1 - b : b)];
+          if (width == 4)
+            std::memcpy (&samples[i], tmp, 4);
+          else
+            {
+              double d;
+              std::memcpy (&d, tmp, 8);
+              samples[i] = d;
+            }
+        }
+      return;
+    }
+  const float norm = 1.0 / 0x80000000LL;
+  for (size_t i = 0; i < n; i++)
+    {
+      // left-align the sample in 32 bits
+      uint32_t u = 0;
+      for (int b = 0; b < width; b++)
+        {
+          const unsigned char byte = bytes[i * width + b];
+          const int significance = big ? width - 1 - b : b;          // 0 = least significant byte of the sample
+          u |= uint32_t (byte) << (8 * (4 - width + significance));
+        }
+      if (m_format.encoding == Encoding::UNSIGNED)
+        u ^= 0x80000000u;
+      samples[i] = int32_t (u) * norm;
+    }
+}
+
+void
+PcmCodec::encode (const float *samples, unsigned char *bytes, size_t n) const
+{
+  const int width = sample_width();
+  const bool big = m_format.endian == RawFormat::BIG;
+  if (m_format.encoding == Encoding::FLOAT)
+    {
+      for (size_t i = 0; i < n; i++)
+        {
+          unsigned char tmp[8];
+          const float f = float_clip (samples[i]);
+          if (width == 4)
+            std::memcpy (tmp, &f, 4);
+          else
+            {
+              const double d = f;
+              std::memcpy (tmp, &d, 8);
+            }
+          for (int b = 0; b < width; b++)
+            bytes[i * width + (big ? width - 1 - b : b)] = tmp[b];
+        }
+      return;
+    }
+  // the reference converts little-endian signed 16 / 32 bit directly (truncation toward zero at that width);
+  // every other layout goes through a 32-bit value whose top bits are kept (rawconverter.cc:187-215)
+  const bool direct = !m_libsndfile_int_rule && !big && m_format.encoding == Encoding::SIGNED && (width == 2 || width == 4);
+  for (size_t i = 0; i < n; i++)
+    {
+      uint32_t u;
+      if (direct && width == 2)
+        u = uint32_t (float_to_int_clip<16> (samples[i])) << 16;
+      else
+        u = uint32_t (float_to_int_clip<32> (samples[i]));
+      if (m_format.encoding == Encoding::UNSIGNED)
+        u ^= 0x80000000u;
+      for (int b = 0; b < width; b++)
+        {
+          const int significance = big ? width - 1 - b : b;
+          bytes[i * width + b] = (unsigned char) (u >> (8 * (4 - width + significance)));
+        }
+    }
+}
+
+/* ---- raw streams -------------------------------------------------------------------------- */
+
+namespace {
+
+class RawInputStream : public AudioInputStream
+{
+  RawFormat m_format;
+  FILE     *m_file = nullptr;
+  bool      m_close = false;
+  std::unique_ptr<PcmCodec> m_codec;
+public:
+  ~RawInputStream() { if (m_close && m_file) fclose (m_file); }
+  Error
+  open (const std::string& filename, const RawFormat& format)
+  {
+    if (!format.n_channels)  return Error ("RawInputStream: input format: missing number of channels");
+    if (!format.bit_depth)   return Error ("RawInputStream: input format: missing bit depth");
+    if (!format.sample_rate) return Error ("RawInputStream: input format: missing sample rate");
+    Error err;
+    m_codec = PcmCodec::create (format, err);
+    if (err)
+      return err;
+    if (filename == "-")
+      m_file = stdin;
+    else
+      {
+        m_file = fopen (filename.c_str(), "r");
+        if (!m_file)
+          return Error (strerror (errno));
+        m_close = true;
+      }
+    m_format = format;
+    return Error::Code::NONE;
+  }
+  int bit_depth() const override { return m_format.bit_depth; }
+  int sample_rate() const override { return m_format.sample_rate; }
+  int n_channels() const override { return m_format.n_channels; }
+  size_t n_frames() const override { return N_FRAMES_UNKNOWN; }
+  Encoding encoding() const override { return m_format.encoding; }
+  Error
+  read_frames (std::vector<float>& samples, size_t count) override
+  {
+    const size_t frame_bytes = size_t (m_format.n_channels) * m_codec->sample_width();
+    std::vector<unsigned char> bytes (count * frame_bytes);
+    const size_t got = fread (bytes.data(), frame_bytes, count, m_file);
+    if (ferror (m_file))
+      return Error ("error reading sample data");
+    samples.resize (got * m_format.n_channels);
+    m_codec->decode (bytes.data(), samples.data(), samples.size());
+    return Error::Code::NONE;
+  }
+};
+
+class RawOutputStream : public AudioOutputStream
+{
+  RawFormat m_format;
+  FILE     *m_file = nullptr;
+  bool      m_close = false;
+  std::unique_ptr<PcmCodec> m_codec;
+public:
+  ~RawOutputStream() { close(); }
+  Error
+  open (const std::string& filename, const RawFormat& format)
+  {
+    if (!format.n_channels)  return Error ("RawOutputStream: output format: missing number of channels");
+    if (!format.bit_depth)   return Error ("RawOutputStream: output format: missing bit depth");
+    if (!format.sample_rate) return Error ("RawOutputStream: output format: missing sample rate");
+    Error err;
+    m_codec = PcmCodec::create (format, err);
+    if (err)
+      return err;
+    if (filename == "-")
+      m_file = stdout;
+    else
+      {
+        m_file = fopen (filename.c_str(), "w");
+        if (!m_file)
+          return Error (strerror (errno));
+        m_close = true;
+      }
+    m_format = format;
+    return Error::Code::NONE;
+  }
+  int bit_depth() const override { return m_format.bit_depth; }
+  int sample_rate() const override { return m_format.sample_rate; }
+  int n_channels() const override { return m_format.n_channels; }
+  Error
+  write_frames (const std::vector<float>& samples) override
+  {
+    if (samples.empty())
+      return Error::Code::NONE;
+    std::vector<unsigned char> bytes (samples.size() * m_codec->sample_width());
+    m_codec->encode (samples.data(), bytes.data(), samples.size());
+    fwrite (bytes.data(), 1, bytes.size(), m_file);
+    if (ferror (m_file))
+      return Error ("write sample data failed");
+    return Error::Code::NONE;
+  }
+  Error
+  close() override
+  {
+    if (m_file)
+      {
+        fflush (m_file);
+        const bool failed = ferror (m_file);
+        if (m_close)
+          fclose (m_file);
+        m_file = nullptr;
+        if (failed)
+          return Error ("error during flush");
+      }
+    return Error::Code::NONE;
+  }
+};
+
+/* ---- WAV ------------------------------------------------------------------------------------- */
+
+uint32_t u32le (const unsigned char *b) { return b[0] | (b[1] << 8) | (b[2] << 16) | (uint32_t (b[3]) << 24); }
+uint16_t u16le (const unsigned char *b) { return uint16_t (b[0] | (b[1] << 8)); }
+uint64_t u64le (const unsigned char *b) { return uint64_t (u32le (b)) | (uint64_t (u32le (b + 4)) << 32); }
+
+class WavInputStream : public AudioInputStream
+{
+  RawFormat m_format;
+  FILE     *m_file = nullptr;
+  bool      m_close = false;
+  size_t    m_n_frames = N_FRAMES_UNKNOWN;
+  size_t    m_frames_left = N_FRAMES_UNKNOWN;
+  std::unique_ptr<PcmCodec> m_codec;
+  Error
+  read_error (const std::string& message)
+  {
+    if (ferror (m_file))
+      return Error (string_printf ("wav input read error: %s", strerror (errno)));
+    return Error (message);
+  }
+public:
+  ~WavInputStream() { if (m_close && m_file) fclose (m_file); }
+  // pipe_mode: length fields of the header are not trusted (wav-pipe format); data runs until EOF
+  Error
+  open (const std::string& filename, bool pipe_mode)
+  {
+    if (filename == "-")
+      m_file = stdin;
+    else
+      {
+        m_file = fopen (filename.c_str(), "r");
+        if (!m_file)
+          return Error (strerror (errno));
+        m_close = true;
+      }
+    unsigned char riff[12];
+    const bool riff_ok = fread (riff, sizeof (riff), 1, m_file);
+    const std::string tag (reinterpret_cast<char *> (riff), 4);
+    if (!riff_ok || (tag != "RIFF" && tag != "RF64") || std::string (reinterpret_cast<char *> (riff + 8), 4) != "WAVE")
+      return read_error ("input file is not a valid wav file");
+    RawFormat format;
+    bool have_fmt = false, in_data = false;
+    uint64_t data_size = 0, ds64_data_size = 0;
+    while (!in_data)
+      {
+        unsigned char chunk[8];
+        if (!fread (chunk, sizeof (chunk), 1, m_file))
+          return read_error ("wav input is incomplete (no data chunk found)");
+        const std::string id (reinterpret_cast<char *> (chunk), 4);
+        uint32_t chunk_size = u32le (chunk + 4);
+        if (id == "fmt " && chunk_size >= 16 && chunk_size <= 64 * 1024 && !have_fmt)
+          {
+            std::vector<unsigned char> buffer (chunk_size);
+            if (!fread (buffer.data(), buffer.size(), 1, m_file))
+              return read_error ("wav input is incomplete (error reading fmt chunk)");
+            const int format_type = u16le (&buffer[0]);
+            if (format_type == 3)
+              format.encoding = Encoding::FLOAT;
+            else if (format_type != 1)
+              {
+                static const unsigned char pcm_guid[16] = { 0x01, 0x00, 0x00, 0x00, 0x00, 0x00, 0x10, 0x00, 0x80, 0x00, 0x00, 0xAA, 0x00, 0x38, 0x9B, 0x71 };
+                if (format_type == 0xFFFE && chunk_size >= 40)
+                  {
+                    if (memcmp (pcm_guid, &buffer[24], 16) != 0)
+                      return Error ("wav input has unsupported extended format type, expected PCM");
+                  }
+                else
+                  return Error (string_printf ("wav input has unsupported format type (%d), expected PCM", format_type));
+              }
+            format.n_channels = u16le (&buffer[2]);
+            format.sample_rate = int (u32le (&buffer[4]));
+            format.bit_depth = u16le (&buffer[14]);
+            if (format.bit_depth == 8)
+              format.encoding = Encoding::UNSIGNED;        // 8 bit wav is always unsigned
+            have_fmt = true;
+          }
+        else if (id == "ds64" && chunk_size >= 24 && chunk_size <= 4096)
+          {
+            std::vector<unsigned char> buffer (chunk_size);
+            if (!fread (buffer.data(), buffer.size(), 1, m_file))
+              return read_error ("wav input is incomplete (error reading ds64 chunk)");
+            ds64_data_size = u64le (&buffer[8]);
+          }
+        else if (id == "data")
+          {
+            data_size = chunk_size == 0xFFFFFFFFu ? ds64_data_size : chunk_size;
+            in_data = true;
+          }
+        else
+          {
+            char junk[1024];
+            uint64_t todo = uint64_t (chunk_size) + (chunk_size & 1);      // chunks are word aligned
+            while (todo)
+              {
+                const size_t n = std::min<uint64_t> (todo, sizeof (junk));
+                if (!fread (junk, n, 1, m_file))
+                  return read_error ("wav input is incomplete (error skipping unknown chunk)");
+                todo -= n;
+              }
+          }
+      }
+    if (!have_fmt)
+      return Error ("wav input is incomplete (missing fmt chunk)");
+    Error err;
+    m_codec = PcmCodec::create (format, err);
+    if (err)
+      return err;
+    m_format = format;
+    if (!pipe_mode && data_size && format.n_channels)
+      m_n_frames = m_frames_left = data_size / (size_t (format.n_channels) * m_codec->sample_width());
+    return Error::Code::NONE;
+  }
+  int bit_depth() const override { return m_format.bit_depth; }
+  int sample_rate() const override { return m_format.sample_rate; }
+  int n_channels() const override { return m_format.n_channels; }
+  size_t n_frames() const override { return m_n_frames; }
+  Encoding encoding() const override { return m_format.encoding; }
+  Error
+  read_frames (std::vector<float>& samples, size_t count) override
+  {
+    const size_t block = 8192;
+    const size_t frame_bytes = size_t (m_format.n_channels) * m_codec->sample_width();
+    std::vector<unsigned char> bytes (block * frame_bytes);
+    size_t pos = 0;
+    samples.clear();
+    if (m_frames_left != N_FRAMES_UNKNOWN)
+      count = std::min (count, m_frames_left);
+    while (count)
+      {
+        const size_t todo = std::min (count, block);
+        const size_t got = fread (bytes.data(), frame_bytes, todo, m_file);
+        if (ferror (m_file))
+          return Error (string_printf ("error reading wav input sample data: %s", strerror (errno)));
+        if (!got)
+          break;
+        samples.resize ((pos + got) * m_format.n_channels);
+        m_codec->decode (bytes.data(), samples.data() + pos * m_format.n_channels, got * m_format.n_channels);
+        pos += got;
+        count -= got;
+        if (m_frames_left != N_FRAMES_UNKNOWN)
+          m_frames_left -= got;
+      }
+    return Error::Code::NONE;
+  }
+};
+
+class WavOutputStream : public AudioOutputStream
+{
+  int    m_bit_depth = 0, m_sample_rate = 0, m_n_channels = 0;
+  FILE  *m_file = nullptr;
+  bool   m_close = false, m_fix_header = false;
+  size_t m_close_padding = 0, m_bytes_written = 0;
+  std::unique_ptr<PcmCodec> m_codec;
+public:
+  ~WavOutputStream() { close(); }
+  Error
+  open (const std::string& filename, int n_channels, int sample_rate, int bit_depth, Encoding encoding, size_t n_frames, bool wav_pipe)
+  {
+    if (encoding == Encoding::FLOAT)
+      {
+        if (bit_depth != 32 && bit_depth != 64)
+          return Error (string_printf ("WavOutputStream::open: unsupported floating point bit depth %d", bit_depth));
+      }
+    else if (bit_depth != 16 && bit_depth != 24 && bit_depth != 32)
+      return Error (string_printf ("WavOutputStream::open: unsupported bit depth %d", bit_depth));
+    const bool to_stdout = filename == "-";
+    if (n_frames == AudioInputStream::N_FRAMES_UNKNOWN && !wav_pipe && to_stdout)
+      return Error ("unable to write wav format to standard out without input length information");
+    RawFormat format;
+    format.bit_depth = bit_depth;
+    format.encoding = encoding;
+    Error err;
+    // named files take the conversion rule of the reference's libsndfile path (sfoutputstream.cc:148-155)
+    m_codec = PcmCodec::create (format, err, /* libsndfile_int_rule */ !to_stdout);
+    if (err)
+      return err;
+    if (to_stdout)
+      m_file = stdout;
+    else
+      {
+        m_file = fopen (filename.c_str(), "w");
+        if (!m_file)
+          return Error (strerror (errno));
+        m_close = true;
+        m_fix_header = n_frames == AudioInputStream::N_FRAMES_UNKNOWN;    // sizes are patched in close()
+      }
+    const bool unknown = wav_pipe || n_frames == AudioInputStream::N_FRAMES_UNKNOWN;
+    const size_t data_size = unknown ? 0 : n_frames * n_channels * ((bit_depth + 7) / 8);
+    m_close_padding = data_size & 1;
+    std::vector<unsigned char> h;
+    auto str = [&] (const char *s) { h.insert (h.end(), s, s + 4); };
+    auto u32 = [&] (uint32_t u) { for (int i = 0; i < 4; i++) h.push_back ((unsigned char) (u >> (8 * i))); };
+    auto u16 = [&] (uint16_t u) { h.push_back ((unsigned char) u); h.push_back ((unsigned char) (u >> 8)); };
+    str ("RIFF");
+    u32 (unknown ? 0xFFFFFFFFu : uint32_t (36 + data_size + m_close_padding));
+    str ("WAVE");
+    str ("fmt ");
+    u32 (16);
+    u16 (encoding == Encoding::FLOAT ? 3 : 1);
+    u16 (n_channels);
+    u32 (sample_rate);
+    u32 (sample_rate * n_channels * bit_depth / 8);
+    u16 (n_channels * bit_depth / 8);
+    u16 (bit_depth);
+    str ("data");
+    u32 (unknown ? 0xFFFFFFFFu : uint32_t (data_size));
+    fwrite (h.data(), 1, h.size(), m_file);
+    if (ferror (m_file))
+      return Error ("write wav header failed");
+    m_bit_depth = bit_depth;
+    m_sample_rate = sample_rate;
+    m_n_channels = n_channels;
+    return Error::Code::NONE;
+  }
+  int bit_depth() const override { return m_bit_depth; }
+  int sample_rate() const override { return m_sample_rate; }
+  int n_channels() const override { return m_n_channels; }
+  Error
+  write_frames (const std::vector<float>& samples) override
+  {
+    if (samples.empty())
+      return Error::Code::NONE;
+    const size_t block = 8192 * size_t (m_n_channels);
+    const int width = m_bit_depth / 8;
+    std::vector<unsigned char> bytes (block * width);
+    for (size_t pos = 0; pos < samples.size(); pos += block)
+      {
+        const size_t todo = std::min (block, samples.size() - pos);
+        m_codec->encode (samples.data() + pos, bytes.data(), todo);
+        fwrite (bytes.data(), 1, todo * width, m_file);
+        if (ferror (m_file))
+          return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
+        m_bytes_written += todo * width;
+      }
+    return Error::Code::NONE;
+  }
+  Error
+  close() override
+  {
+    if (!m_file)
+      return Error::Code::NONE;
+    if (m_fix_header)
+      {
+        m_close_padding = m_bytes_written & 1;
+      }
+    for (size_t i = 0; i < m_close_padding; i++)
+      fputc (0, m_file);
+    if (m_fix_header && m_bytes_written + 36 < 0xFFFFFFFFu)
+      {
+        unsigned char b[4];
+        auto put = [&] (long pos, uint32_t v) {
+          for (int i = 0; i < 4; i++) b[i] = (unsigned char) (v >> (8 * i));
+          fseek (m_file, pos, SEEK_SET);
+          fwrite (b, 1, 4, m_file);
+        };
+        put (4, uint32_t (36 + m_bytes_written + m_close_padding));
+        put (40, uint32_t (m_bytes_written));
+      }
+    fflush (m_file);
+    const bool failed = ferror (m_file);
+    if (m_close)
+      fclose (m_file);
+    m_file = nullptr;
+    if (failed)
+      return Error ("error during flush");
+    return Error::Code::NONE;
+  }
+};
+
+} // namespace
+
+std::unique_ptr<AudioInputStream>
+AudioInputStream::create (const std::string& filename, Error& err)
+{
+  if (Params::input_format == Format::RAW)
+    {
+      auto s = std::make_unique<RawInputStream>();
+      err = s->open (filename, StreamParams::raw_input_format);
+      if (err)
+        return nullptr;
+      return s;
+    }
+  if (Params::input_format == Format::AUTO || Params::input_format == Format::WAV_PIPE)
+    {
+      auto s = std::make_unique<WavInputStream>();
+      err = s->open (filename, Params::input_format == Format::WAV_PIPE);
+      if (err)
+        return nullptr;
+      return s;
+    }
+  err = Error ("selected format is not supported as input format");
+  return nullptr;
+}
+
+std::unique_ptr<AudioOutputStream>
+AudioOutputStream::create (const std::string& filename, int n_channels, int sample_rate, int bit_depth, Encoding encoding,
+                           size_t n_frames, Error& err)
+{
+  if (Params::output_format == Format::RAW)
+    {
+      auto s = std::make_unique<RawOutputStream>();
+      err = s->open (filename, StreamParams::raw_output_format);
+      if (err)
+        return nullptr;
+      return s;
+    }
+  auto s = std::make_unique<WavOutputStream>();
+  err = s->open (filename, n_channels, sample_rate, bit_depth, encoding, n_frames, Params::output_format == Format::WAV_PIPE);
+  if (err)
+    return nullptr;
+  return s;
+}
+
+Error
+WavData::load (AudioInputStream *in_stream)
+{
+  m_samples.clear();
+  if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN)
+    m_samples.reserve (in_stream->n_frames() * in_stream->n_channels());
+  std::vector<float> buffer;
+  while (true)
+    {
+      Error err = in_stream->read_frames (buffer, 65536);
+      if (err)
+        return err;
+      if (buffer.empty())
+        break;
+      m_samples.insert (m_samples.end(), buffer.begin(), buffer.end());
+    }
+  m_sample_rate = in_stream->sample_rate();
+  m_n_channels = in_stream->n_channels();
+  m_bit_depth = in_stream->bit_depth();
+  return Error::Code::NONE;
+}
+
+Error
+WavData::load (const std::string& filename)
+{
+  Error err;
+  auto in_stream = AudioInputStream::create (filename, err);
+  if (err)
+    return err;
+  return load (in_stream.get());
+}
+
+Error
+WavData::save (const std::string& filename) const
+{
+  Error err;
+  auto out_stream = AudioOutputStream::create (filename, m_n_channels, m_sample_rate, m_bit_depth, Encoding::SIGNED,
+                                               m_samples.size() / m_n_channels, err);
+  if (err)
+    return err;
+  err = out_stream->write_frames (m_samples);
+  if (err)
+    return err;
+  return out_stream->close();
+}
+
+} // namespace awm

@@ -1,0 +1,349 @@
+#include "wmfile.hh"
+#include "context.hh"
+#include "wmget.hh"
+#include "utils.hh"
+#include <algorithm>
+#include <cmath>
+
+namespace awm {
+
+namespace {
+
+// pinned host staging buffer (PCIe transfers at full rate, reusable)
+struct PinnedBuffer
+{
+  float *ptr = nullptr;
+  size_t values = 0;
+  ~PinnedBuffer() { if (ptr) (void) hipHostFree (ptr); }
+  bool
+  reserve (size_t n)
+  {
+    if (n <= values)
+      return true;
+    float *np = nullptr;
+    size_t cap = std::max<size_t> (n, values * 2);
+    if (hipHostMalloc (reinterpret_cast<void **> (&np), cap * sizeof (float), hipHostMallocDefault) != hipSuccess)
+      return false;
+    if (ptr)
+      {
+        std::copy (ptr, ptr + values, np);
+        (void) hipHostFree (ptr);
+      }
+    ptr = np;
+    values = cap;
+    return true;
+  }
+};
+
+Error
+read_all (AudioInputStream *in_stream, PinnedBuffer& buf, size_t& n_values)
+{
+  const int C = in_stream->n_channels();
+  n_values = 0;
+  if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN)
+    if (!buf.reserve (in_stream->n_frames() * C + 1))
+      return Error ("out of (pinned) host memory");
+  std::vector<float> tile;
+  while (true)
+    {
+      Error err = in_stream->read_frames (tile, 1 << 20);       // the stream surface accepts any count
+      if (err)
+        return err;
+      if (tile.empty())
+        break;
+      if (!buf.reserve (n_values + tile.size()))
+        return Error ("out of (pinned) host memory");
+      std::copy (tile.begin(), tile.end(), buf.ptr + n_values);
+      n_values += tile.size();
+    }
+  return Error::Code::NONE;
+}
+
+/* "Data Blocks" counter of WatermarkGen (reference wmadd.cc:311-313, 346-351): depends only on how many frames the
+ * streaming loop of the reference pushes through the generator, i.e. on the latency of synth + limiter */
+int
+count_data_blocks (size_t n_frames, int sample_rate, bool limiter)
+{
+  const size_t N = Params::frame_size, block = mark_block_frame_count();
+  const size_t lim_block = size_t (sample_rate) * size_t (Params::limiter_block_size_ms) / 1000;
+  size_t total_in = 0, total_out = 0, frame_number = 2 * block - Params::frames_pad_start, data_blocks = 0, lim_buffer = 0;
+  bool first_frame = true;
+  while (true)
+    {
+      const size_t got = std::min (N, n_frames - total_in);
+      total_in += got;
+      if (got < N && total_in == total_out)
+        break;
+      frame_number++;
+      if (frame_number % block == 0)
+        data_blocks++;
+      size_t out = first_frame ? 0 : N;                    // WatermarkSynth emits nothing for the first frame
+      first_frame = false;
+      if (limiter)
+        {
+          lim_buffer += out;
+          const size_t buffered_blocks = lim_buffer / lim_block;
+          out = buffered_blocks < 2 ? 0 : (buffered_blocks - 1) * lim_block;
+          lim_buffer -= out;
+        }
+      total_out += std::min (out, total_in - total_out);
+    }
+  return std::max (int (data_blocks) - 1, 0);
+}
+
+} // namespace
+
+int
+add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutputStream *out_stream,
+                      const std::string& bits, size_t zero_frames)
+{
+  auto bitvec = parse_payload (bits);
+  if (bitvec.empty())
+    return 1;
+  if (in_stream->sample_rate() != out_stream->sample_rate())
+    {
+      error ("audiowmark: input sample rate (%d) and output sample rate (%d) don't match\n", in_stream->sample_rate(), out_stream->sample_rate());
+      return 1;
+    }
+  if (in_stream->n_channels() != out_stream->n_channels())
+    {
+      error ("audiowmark: input channels (%d) and output channels (%d) don't match\n", in_stream->n_channels(), out_stream->n_channels());
+      return 1;
+    }
+  if (zero_frames)
+    {
+      error ("audiowmark: zero_frames (HLS segment watermarking) is not supported by the GPU path\n");
+      return 1;
+    }
+  if (in_stream->sample_rate() != Params::mark_sample_rate)
+    {
+      // the reference resamples to 44100 Hz and back with zita-resampler (wmadd.cc:358-431)
+      error ("audiowmark: only %d Hz input is supported by the GPU path (got %d Hz)\n", Params::mark_sample_rate, in_stream->sample_rate());
+      return 1;
+    }
+  info ("Message:      %s\n", bit_vec_to_str (bitvec).c_str());
+  info ("Strength:     %.6g\n\n", Params::water_delta * 1000);
+  if (in_stream->n_frames() == AudioInputStream::N_FRAMES_UNKNOWN)
+    info ("Time:         unknown\n");
+  else
+    {
+      const size_t orig_seconds = in_stream->n_frames() / in_stream->sample_rate();
+      info ("Time:         %zd:%02zd\n", orig_seconds / 60, orig_seconds % 60);
+    }
+  info ("Sample Rate:  %d\n", in_stream->sample_rate());
+  info ("Channels:     %d\n", in_stream->n_channels());
+
+  const int C = in_stream->n_channels();
+  PinnedBuffer host;
+  size_t n_values = 0;
+  Error err = read_all (in_stream, host, n_values);
+  if (err)
+    {
+      error ("audiowmark: input stream read failed: %s\n", err.message());
+      return 1;
+    }
+  const size_t n_frames = n_values / C;
+  DevBuffer d_in, d_out;
+  auto cleanup = [&] { d_in.release(); d_out.release(); };
+  if (d_in.reserve (std::max<size_t> (n_values, 1) * sizeof (float)) || d_out.reserve (std::max<size_t> (n_values, 1) * sizeof (float)))
+    {
+      error ("audiowmark: %s\n", awm_last_error());
+      cleanup();
+      return 1;
+    }
+  std::vector<float> result (n_values);
+  if (n_values)
+    {
+      if (hipMemcpyAsync (d_in.ptr, host.ptr, n_values * sizeof (float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess
+          || awm_add_watermark_d (ctx, key.aes_key(), bit_vec_to_str (bitvec).c_str(), d_in.as<float>(), d_out.as<float>(), n_frames, C,
+                                  in_stream->sample_rate()) != 0)
+        {
+          error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+          cleanup();
+          return 1;
+        }
+      // reuse the pinned buffer for the way back; keep the original for --snr
+      std::vector<float> orig;
+      if (Params::snr)
+        orig.assign (host.ptr, host.ptr + n_values);
+      if (hipMemcpyAsync (host.ptr, d_out.ptr, n_values * sizeof (float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
+          || hipStreamSynchronize (ctx->stream) != hipSuccess)
+        {
+          error ("audiowmark: GPU transfer failed\n");
+          cleanup();
+          return 1;
+        }
+      std::copy (host.ptr, host.ptr + n_values, result.begin());
+      if (Params::snr)
+        {
+          // the reference measures the watermark before the limiter (wmadd.cc:553-563); with the limiter
+          // active this is the power of (output - original), which includes the limiter's gain change
+          double delta_power = 0, signal_power = 0;
+          for (size_t i = 0; i < n_values; i++)
+            {
+              const double o = orig[i], d = double (result[i]) - o;
+              delta_power += d * d;
+              signal_power += o * o;
+            }
+          info ("SNR:          %f dB\n", 10 * log10 (signal_power / delta_power));
+        }
+    }
+  cleanup();
+  // write in tiles through the unchanged stream surface
+  const size_t tile = size_t (1 << 20) * C;
+  for (size_t pos = 0; pos < result.size(); pos += tile)
+    {
+      std::vector<float> part (result.begin() + pos, result.begin() + std::min (result.size(), pos + tile));
+      err = out_stream->write_frames (part);
+      if (err)
+        {
+          error ("audiowmark output write failed: %s\n", err.message());
+          return 1;
+        }
+    }
+  info ("Data Blocks:  %d\n", count_data_blocks (n_frames, in_stream->sample_rate(), !Params::test_no_limiter));
+  if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN && n_frames != in_stream->n_frames())
+    {
+      auto msg = string_printf ("unexpected EOF; input frames (%zd) != output frames (%zd)", in_stream->n_frames(), n_frames);
+      if (Params::strict)
+        {
+          error ("audiowmark: error: %s\n", msg.c_str());
+          return 1;
+        }
+      warning ("audiowmark: warning: %s\n", msg.c_str());
+    }
+  err = out_stream->close();
+  if (err)
+    {
+      error ("audiowmark: closing output stream failed: %s\n", err.message());
+      return 1;
+    }
+  return 0;
+}
+
+static void
+info_format (const std::string& label, const RawFormat& format)
+{
+  const char *e = format.encoding == Encoding::SIGNED ? "signed" : format.encoding == Encoding::UNSIGNED ? "unsigned" : "float";
+  info ("%-13s %d Hz, %d Channels, %d Bit (%s %s-endian)\n", (label + ":").c_str(), format.sample_rate, format.n_channels,
+        format.bit_depth, e, format.endian == RawFormat::LITTLE ? "little" : "big");
+}
+
+int
+add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits)
+{
+  Error err;
+  auto in_stream = AudioInputStream::create (infile, err);
+  if (err)
+    {
+      error ("audiowmark: error opening %s: %s\n", infile.c_str(), err.message());
+      return 1;
+    }
+  int out_bit_depth = in_stream->bit_depth();
+  Encoding out_encoding = in_stream->encoding();
+  if (in_stream->bit_depth() < 16)
+    {
+      out_bit_depth = 16;
+      out_encoding = Encoding::SIGNED;
+    }
+  auto out_stream = AudioOutputStream::create (outfile, in_stream->n_channels(), in_stream->sample_rate(), out_bit_depth, out_encoding,
+                                               in_stream->n_frames(), err);
+  if (err)
+    {
+      error ("audiowmark: error writing to %s: %s\n", outfile.c_str(), err.message());
+      return 1;
+    }
+  info ("Input:        %s\n", infile.c_str());
+  if (Params::input_format == Format::RAW)
+    info_format ("Raw Input", StreamParams::raw_input_format);
+  info ("Output:       %s\n", outfile.c_str());
+  if (Params::output_format == Format::RAW)
+    info_format ("Raw Output", StreamParams::raw_output_format);
+  return add_stream_watermark (ctx, key, in_stream.get(), out_stream.get(), bits, 0);
+}
+
+int
+get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string& infile, const std::string& orig_pattern)
+{
+  std::vector<int> orig_bitvec;
+  if (!orig_pattern.empty())
+    {
+      orig_bitvec = parse_payload (orig_pattern);
+      if (orig_bitvec.empty())
+        return 1;
+    }
+  Error err;
+  auto in_stream = AudioInputStream::create (infile, err);
+  if (err)
+    {
+      error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
+      return 1;
+    }
+  if (in_stream->sample_rate() != Params::mark_sample_rate)
+    {
+      // WavChunkLoader resamples to the watermark rate with zita-resampler (wavchunkloader.cc:71-72)
+      error ("audiowmark: only %d Hz input is supported by the GPU path (got %d Hz)\n", Params::mark_sample_rate, in_stream->sample_rate());
+      return 1;
+    }
+  const int C = in_stream->n_channels();
+  PinnedBuffer host;
+  size_t n_values = 0;
+  err = read_all (in_stream.get(), host, n_values);
+  if (err)
+    {
+      error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
+      return 1;
+    }
+  if (Params::test_truncate)
+    n_values = std::min (n_values, size_t (Params::mark_sample_rate) * C * Params::test_truncate);
+  const size_t n_frames = n_values / C;
+  ResultSet result_set;
+  if (n_frames)
+    {
+      DevBuffer d_in;
+      if (d_in.reserve (n_values * sizeof (float))
+          || hipMemcpyAsync (d_in.ptr, host.ptr, n_values * sizeof (float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        {
+          error ("audiowmark: GPU transfer failed: %s\n", awm_last_error());
+          d_in.release();
+          return 1;
+        }
+      DeviceWav wav;
+      wav.data = d_in.as<float>();
+      wav.n_frames = n_frames;
+      wav.n_channels = C;
+      wav.sample_rate = Params::mark_sample_rate;
+      const int rc = get_watermark_device (ctx, key_list, wav, result_set);
+      d_in.release();
+      if (rc)
+        {
+          error ("audiowmark: GPU detection failed: %s\n", awm_last_error());
+          return 1;
+        }
+    }
+  else
+    result_set.sort (key_list);
+  const size_t time_length = lrint (double (n_values) / (double (Params::mark_sample_rate) * C));
+
+  /* report (reference wmget.cc:941-969) */
+  if (!Params::json_output.empty())
+    result_set.print_json (time_length, Params::json_output);
+  if (Params::json_output != "-")
+    result_set.print();
+  if (!orig_bitvec.empty())
+    {
+      const int match_count = result_set.print_match_count (orig_bitvec);
+      result_set.print_debug_sync();
+      if (Params::expect_matches >= 0)
+        {
+          printf ("expect_matches %d\n", Params::expect_matches);
+          if (match_count != Params::expect_matches)
+            return 1;
+        }
+      else if (!match_count)
+        return 1;
+    }
+  return 0;
+}
+
+} // namespace awm

@@ -1,0 +1,17 @@
+// File / stream level entry points with the reference's signatures (reference src/wmcommon.hh:226-228):
+//   add_stream_watermark, add_watermark   reference src/wmadd.cc:448-657
+//   get_watermark                         reference src/wmget.cc:971-1013 (+ report :941-969)
+#pragma once
+#include "audiostream.hh"
+#include "wmcommon.hh"
+
+struct awm_ctx;
+
+namespace awm {
+
+int add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutputStream *out_stream,
+                          const std::string& bits, size_t zero_frames);
+int add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits);
+int get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string& infile, const std::string& orig_pattern);
+
+} // namespace awm

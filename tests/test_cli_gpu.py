@@ -1,0 +1,116 @@
+"""End-to-end checks of the `audiowmark` command line front end (add / get / cmp on raw and WAV data) -- the
+reference's own `make check` scenarios that fit the 44.1 kHz raw/WAV scope (tests/block-decoder-test.sh,
+sync-test.sh, clip-decoder-test.sh, pipe-test.sh, key-test.sh, raw-format-test.sh), plus cross checks against
+the compiled reference binary where oracle/_ref is available."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import _ref
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+AWM = os.path.join(ROOT, "audiowmark_amd", "audiowmark")
+PAY = "f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0"
+
+
+def run(cmd, stdin=None, check=True):
+    r = subprocess.run(cmd, input=stdin, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    if check:
+        assert r.returncode == 0, (cmd, r.stdout[-2000:], r.stderr[-2000:])
+    return r
+
+
+def wav_samples(path):
+    with open(path, "rb") as f:
+        data = f.read()
+    pos = data.index(b"data") + 8
+    return np.frombuffer(data[pos:pos + (len(data) - pos) // 2 * 2], dtype="<i2")
+
+
+@pytest.fixture(scope="module")
+def work(tmp_path_factory):
+    d = tmp_path_factory.mktemp("cli")
+    noise = d / "noise200.wav"
+    r = run([AWM, "test-gen-noise", "-", "200", "44100"])
+    assert hashlib.md5(r.stdout).hexdigest() == "a7079f22b4ddd9c1bd338b564b726aad"
+    noise.write_bytes(r.stdout)
+    marked = d / "marked200.wav"
+    r = run([AWM, "add", "--format", "wav-pipe", str(noise), "-", PAY])
+    marked.write_bytes(r.stdout)
+    return d, noise, marked
+
+
+def test_block_decoder_scenario(work):
+    d, noise, marked = work
+    assert os.path.getsize(noise) == os.path.getsize(marked)                             # check_length
+    r = run([AWM, "cmp", "--input-format", "wav-pipe", str(marked), PAY, "--expect-matches", "5"])
+    out = r.stdout.decode()
+    assert "match_count 5 10" in out and "sync_match 3 8" in out
+    lines = [l for l in out.splitlines() if l.startswith("pattern")]
+    assert lines[0].split()[1:] == ["0:05", PAY, "1.383", "0.139", "A"]
+    # SNR without limiter >= 32.4 dB (tests/block-decoder-test.sh:18)
+    nolim = d / "nolim.wav"
+    nolim.write_bytes(run([AWM, "add", "--format", "wav-pipe", "--test-no-limiter", str(noise), "-", PAY]).stdout)
+    snr = float(run([AWM, "test-snr", str(noise), str(nolim)]).stdout.split()[1])
+    assert snr >= 32.4
+
+
+def test_json_and_get(work):
+    d, _, marked = work
+    js = d / "out.json"
+    r = run([AWM, "get", "--input-format", "wav-pipe", "--json", str(js), str(marked)])
+    import json
+    j = json.loads(js.read_text())
+    assert j["length"] == "3:20" and len(j["matches"]) == 10
+    assert j["matches"][0]["bits"] == PAY and j["matches"][0]["type"] == "A"
+
+
+def test_pipe_raw_and_wrong_key(work):
+    d, noise, marked = work
+    # stdin -> stdout (tests/pipe-test.sh) with raw s16le on both sides (tests/raw-format-test.sh)
+    pcm = wav_samples(str(noise)).tobytes()
+    raw = ["--format", "raw", "--raw-rate", "44100", "--raw-channels", "2", "--raw-bits", "16"]
+    out = run([AWM, "add", "--test-key", "3"] + raw + ["-", "-", PAY], stdin=pcm).stdout
+    assert len(out) == len(pcm)
+    r = run([AWM, "cmp", "--test-key", "3", "--input-format", "raw", "--raw-rate", "44100", "--raw-channels", "2", "--raw-bits", "16",
+             "-", PAY, "--expect-matches", "5"], stdin=out)
+    assert b"match_count 5" in r.stdout
+    # wrong key -> no match, exit code 1 (tests/key-test.sh)
+    r = run([AWM, "cmp", "--test-key", "4", "--input-format", "raw", "--raw-rate", "44100", "--raw-channels", "2", "--raw-bits", "16",
+             "-", PAY], stdin=out, check=False)
+    assert r.returncode == 1 and b"match_count 0" in r.stdout
+
+
+def test_sync_and_clip_scenarios(work):
+    d, _, marked = work
+    s = wav_samples(str(marked)).reshape(-1, 2)
+    raw = ["--input-format", "raw", "--raw-rate", "44100", "--raw-channels", "2", "--raw-bits", "16"]
+    # tests/sync-test.sh: cut 441150 frames from the start -> 3 matches
+    r = run([AWM, "cmp"] + raw + ["-", PAY, "--expect-matches", "3", "--test-cut", "441150"], stdin=s[441150:].tobytes())
+    assert b"match_count 3" in r.stdout
+    # tests/clip-decoder-test.sh: a 30 s clip -> 1 match, also after cutting a few more samples
+    clip = s[:30 * 44100]
+    r = run([AWM, "cmp"] + raw + ["-", PAY, "--expect-matches", "1"], stdin=clip.tobytes())
+    assert b"CLIP" in r.stdout
+    run([AWM, "cmp"] + raw + ["-", PAY, "--expect-matches", "1"], stdin=clip[22150:].tobytes())
+
+
+@pytest.mark.skipif(not os.path.exists(_ref.BIN), reason="oracle/_ref/audiowmark_ref not built")
+def test_against_reference_binary(work):
+    d, noise, marked = work
+    ref_marked = d / "ref_marked.wav"
+    ref_marked.write_bytes(run([_ref.BIN, "add", "--format", "wav-pipe", str(noise), "-", PAY]).stdout)
+    a, b = wav_samples(str(marked)).astype(np.int32), wav_samples(str(ref_marked)).astype(np.int32)
+    assert a.shape == b.shape
+    diff = np.abs(a - b)
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3          # quantisation-boundary flips only
+    # both detectors agree on both files, line by line
+    for f in (marked, ref_marked):
+        ours = run([AWM, "cmp", "--input-format", "wav-pipe", str(f), PAY]).stdout.decode().splitlines()
+        theirs = run([_ref.BIN, "cmp", "--x-in-wav-pipe", str(f), PAY]).stdout.decode().splitlines()
+        assert [l for l in ours if not l.startswith("key")] == [l for l in theirs if not l.startswith("key")]
