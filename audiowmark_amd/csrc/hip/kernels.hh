@@ -130,9 +130,9 @@ struct SoftBitsArgs
 hipError_t launch_soft_bits (hipStream_t st, const SoftBitsArgs& a);
 
 /* K8: soft Viterbi (convcode.cc:128-213), one workgroup per coded block */
-hipError_t launch_viterbi (hipStream_t st, const float *soft, int block_type /* 0 a, 1 b, 2 ab */,
-                           long long coded_len, long long n_blocks, unsigned char *decisions_ws,
-                           int *bits_out, float *error_out);
+/* index 0 / 1 / 2 = A / B / AB coded blocks (rate 6 / 6 / 12); every block has n_steps = payload + 15 trellis steps */
+hipError_t launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_blocks[3], long long n_steps,
+                           unsigned char *const decisions_ws[3], int *const bits_out[3], float *const error_out[3]);
 size_t viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks);
 
 } // namespace awmk

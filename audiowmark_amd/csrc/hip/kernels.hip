@@ -17,6 +17,7 @@
 // compiled for baseline x86-64: no FMA contraction).
 #include "kernels.hh"
 #include "awm_fft.hip.h"
+#include <cstdlib>
 
 namespace awmk {
 
@@ -240,15 +241,16 @@ wave_max (float v)
   return v;
 }
 
-template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
-add_mix_kernel (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
+template<int CV, bool OPAQUE> __device__ __forceinline__ void
+add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, int block_frames)
 {
   __shared__ float2 s_tw[512];
   __shared__ float  s_win[1024];
   __shared__ float2 s_twb[NB];
   __shared__ float2 s_x[WAVES][XBUF_ELEMS];
   __shared__ float2 s_zd[WAVES][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int lane = lane0;
   load_shared_tables (t, s_tw, s_win, s_twb);
   for (int i = lane; i < 256; i += 64)
     s_zd[wave][i] = make_float2 (0.f, 0.f);
@@ -284,6 +286,13 @@ add_mix_kernel (DevTables t, AddMixArgs a, long long frame_number0, int block_fr
 
   for (long long m = s - 1; m <= e; m++)
     {
+      if (OPAQUE)
+        {
+          // make the lane index opaque per frame: the ~60 lane-dependent twiddle factors are then re-read from LDS
+          // for every transform instead of being hoisted into registers for the whole span (occupancy over reuse)
+          lane = lane0;
+          asm volatile ("" : "+v" (lane));
+        }
       const float *src;
       int avail;
       if (m < 0)
@@ -466,6 +475,22 @@ add_mix_kernel (DevTables t, AddMixArgs a, long long frame_number0, int block_fr
     }
 }
 
+template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
+add_mix_kernel (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
+{
+  add_mix_body<CV, false> (t, a, frame_number0, block_frames);
+}
+template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
+add_mix_kernel_w3 (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
+{
+  add_mix_body<CV, true> (t, a, frame_number0, block_frames);
+}
+template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+add_mix_kernel_w4 (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
+{
+  add_mix_body<CV, true> (t, a, frame_number0, block_frames);
+}
+
 hipError_t
 launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
 {
@@ -478,7 +503,12 @@ launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
   const unsigned grid = unsigned ((items + WAVES - 1) / WAVES);
   const int block_frames = 2226;   // TODO(params): derive from payload size / frames_per_bit
   const long long frame_number0 = 2LL * block_frames - 250;          // reference wmadd.cc:293-294
-  if (stereo)
+  static const int variant = getenv ("AWM_ADD_VARIANT") ? atoi (getenv ("AWM_ADD_VARIANT")) : 3;   // 3 waves/SIMD measured fastest
+  if (stereo && variant == 3)
+    hipLaunchKernelGGL (add_mix_kernel_w3<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
+  else if (stereo && variant == 4)
+    hipLaunchKernelGGL (add_mix_kernel_w4<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
+  else if (stereo)
     hipLaunchKernelGGL (add_mix_kernel<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
   else
     hipLaunchKernelGGL (add_mix_kernel<1>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);

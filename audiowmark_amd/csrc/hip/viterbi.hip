@@ -36,14 +36,12 @@ typedef float v2f __attribute__ ((ext_vector_type (2)));
 // for generator g splits into a lane dependent part parity ((t << 1) & G) and a part that is a compile time constant
 // after unrolling: parity ((i << 11 | b) & G).  Per trellis step a lane therefore needs just two candidate costs per
 // generator (own parity / flipped parity); which one a given (i, b) takes is decided by the compiler.
-template<int BT> __global__ void __launch_bounds__ (V_THREADS)
-viterbi_kernel (const float *soft, int n_steps, unsigned int *decisions, int *bits_out, float *error_out)
+template<int BT> __device__ __forceinline__ void
+viterbi_body (const float *soft, int n_steps, unsigned int *decisions, int *bits_out, float *error_out, long long blk,
+              float *s_metric, float *s_e0, float *s_e1)
 {
-  extern __shared__ __attribute__ ((aligned (16))) float s_metric[];   // V_STATES floats
-  __shared__ float s_e0[12], s_e1[12];
   constexpr int rate = BT == 2 ? 12 : 6;
   const int t = threadIdx.x;
-  const long long blk = blockIdx.x;
   const float *coded = soft + blk * (long long) n_steps * rate;
   unsigned int *dec = decisions + blk * (long long) n_steps * V_THREADS;
 
@@ -132,6 +130,31 @@ viterbi_kernel (const float *soft, int n_steps, unsigned int *decisions, int *bi
     }
 }
 
+// one launch for all three code types: blocks [0, n0) decode A blocks, [n0, n0 + n1) B blocks, the rest AB blocks
+struct ViterbiBatch
+{
+  const float  *soft[3];
+  unsigned int *decisions[3];
+  int          *bits[3];
+  float        *error[3];
+  int           n[3];
+  int           n_steps;
+};
+
+__global__ void __launch_bounds__ (V_THREADS)
+viterbi_kernel (ViterbiBatch b)
+{
+  extern __shared__ __attribute__ ((aligned (16))) float s_metric[];   // V_STATES floats
+  __shared__ float s_e0[12], s_e1[12];
+  int blk = blockIdx.x;
+  if (blk < b.n[0])
+    viterbi_body<0> (b.soft[0], b.n_steps, b.decisions[0], b.bits[0], b.error[0], blk, s_metric, s_e0, s_e1);
+  else if (blk < b.n[0] + b.n[1])
+    viterbi_body<1> (b.soft[1], b.n_steps, b.decisions[1], b.bits[1], b.error[1], blk - b.n[0], s_metric, s_e0, s_e1);
+  else
+    viterbi_body<2> (b.soft[2], b.n_steps, b.decisions[2], b.bits[2], b.error[2], blk - b.n[0] - b.n[1], s_metric, s_e0, s_e1);
+}
+
 size_t
 viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks)
 {
@@ -139,29 +162,27 @@ viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks)
 }
 
 hipError_t
-launch_viterbi (hipStream_t st, const float *soft, int block_type, long long coded_len, long long n_blocks,
-                unsigned char *decisions_ws, int *bits_out, float *error_out)
+launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_blocks[3], long long n_steps,
+                unsigned char *const decisions_ws[3], int *const bits_out[3], float *const error_out[3])
 {
-  if (n_blocks <= 0)
+  const long long total = n_blocks[0] + n_blocks[1] + n_blocks[2];
+  if (total <= 0)
     return hipSuccess;
-  const int rate = block_type == 2 ? 12 : 6;
-  if (block_type < 0 || block_type > 2 || coded_len % rate)
-    return hipErrorInvalidValue;
+  ViterbiBatch b;
+  for (int i = 0; i < 3; i++)
+    {
+      b.soft[i] = soft[i];
+      b.decisions[i] = reinterpret_cast<unsigned int *> (decisions_ws[i]);
+      b.bits[i] = bits_out[i];
+      b.error[i] = error_out[i];
+      b.n[i] = int (n_blocks[i]);
+    }
+  b.n_steps = int (n_steps);
   const size_t lds = V_STATES * sizeof (float);
-  const void *fn[3] = { reinterpret_cast<const void *> (viterbi_kernel<0>), reinterpret_cast<const void *> (viterbi_kernel<1>),
-                        reinterpret_cast<const void *> (viterbi_kernel<2>) };
-  hipError_t e = hipFuncSetAttribute (fn[block_type], hipFuncAttributeMaxDynamicSharedMemorySize, int (lds));
+  hipError_t e = hipFuncSetAttribute (reinterpret_cast<const void *> (viterbi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int (lds));
   if (e != hipSuccess)
     return e;
-  unsigned int *dec = reinterpret_cast<unsigned int *> (decisions_ws);
-  const int n_steps = int (coded_len / rate);
-  const dim3 grid = dim3 ((unsigned) n_blocks), block = dim3 (V_THREADS);
-  if (block_type == 0)
-    hipLaunchKernelGGL (viterbi_kernel<0>, grid, block, lds, st, soft, n_steps, dec, bits_out, error_out);
-  else if (block_type == 1)
-    hipLaunchKernelGGL (viterbi_kernel<1>, grid, block, lds, st, soft, n_steps, dec, bits_out, error_out);
-  else
-    hipLaunchKernelGGL (viterbi_kernel<2>, grid, block, lds, st, soft, n_steps, dec, bits_out, error_out);
+  hipLaunchKernelGGL (viterbi_kernel, dim3 ((unsigned) total), dim3 (V_THREADS), lds, st, b);
   return hipGetLastError();
 }
 

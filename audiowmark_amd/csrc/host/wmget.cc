@@ -324,50 +324,107 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
   return 0;
 }
 
+/* conv_decode_soft for up to three batches (A, B, AB blocks) in ONE launch */
 int
-viterbi_decode (awm_ctx *ctx, ConvBlockType block_type, const std::vector<std::vector<float>>& soft,
-                std::vector<std::vector<int>>& bits, std::vector<float>& errors)
+viterbi_decode_all (awm_ctx *ctx, const std::vector<std::vector<float>> soft[3], std::vector<std::vector<int>> bits[3],
+                    std::vector<float> errors[3])
 {
-  bits.assign (soft.size(), {});
-  errors.assign (soft.size(), 0.f);
-  if (soft.empty())
-    return 0;
-  const auto gens = conv_generators (block_type);
-  const int rate = int (gens.size());
-  const size_t coded_len = soft[0].size();
-  const size_t n_out = coded_len / rate - conv_order;
-  hipStream_t st = ctx->stream;
-  const size_t max_batch = 256;
-  for (size_t b0 = 0; b0 < soft.size(); b0 += max_batch)
+  size_t n_steps = 0;
+  for (int t = 0; t < 3; t++)
     {
-      const size_t nb = std::min (max_batch, soft.size() - b0);
-      std::vector<float> flat (nb * coded_len);
-      for (size_t i = 0; i < nb; i++)
+      bits[t].assign (soft[t].size(), {});
+      errors[t].assign (soft[t].size(), 0.f);
+      const size_t rate = t == 2 ? 12 : 6;
+      for (const auto& v : soft[t])
         {
-          if (soft[b0 + i].size() != coded_len)
+          if (v.size() % rate || (n_steps && v.size() / rate != n_steps))
             {
               set_error ("viterbi_decode: ragged batch");
               return AWM_ERR_ARG;
             }
-          std::copy (soft[b0 + i].begin(), soft[b0 + i].end(), flat.begin() + i * coded_len);
+          n_steps = v.size() / rate;
         }
-      if (int rc = ctx->ws_viterbi_in.reserve (flat.size() * sizeof (float))) return rc;
-      if (int rc = ctx->ws_viterbi.reserve (awmk::viterbi_workspace_bytes (coded_len, rate, nb))) return rc;
-      if (int rc = ctx->ws_viterbi_bits.reserve (nb * n_out * sizeof (int))) return rc;
-      if (int rc = ctx->ws_viterbi_err.reserve (nb * sizeof (float))) return rc;
-      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_viterbi_in.ptr, flat.data(), flat.size() * sizeof (float), hipMemcpyHostToDevice, st));
-      {
-        ProfScope ps (ctx, PROF_VITERBI, double (nb) * (coded_len * 4.0 + 2.0 * awmk::viterbi_workspace_bytes (coded_len, rate, 1)));
-        AWM_HIP_CHECK (awmk::launch_viterbi (st, ctx->ws_viterbi_in.as<float>(), int (block_type), coded_len, nb,
-                                             ctx->ws_viterbi.as<unsigned char>(), ctx->ws_viterbi_bits.as<int>(), ctx->ws_viterbi_err.as<float>()));
-      }
-      std::vector<int> hbits (nb * n_out);
-      AWM_HIP_CHECK (hipMemcpyAsync (hbits.data(), ctx->ws_viterbi_bits.ptr, hbits.size() * sizeof (int), hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (hipMemcpyAsync (errors.data() + b0, ctx->ws_viterbi_err.ptr, nb * sizeof (float), hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (hipStreamSynchronize (st));
-      for (size_t i = 0; i < nb; i++)
-        bits[b0 + i].assign (hbits.begin() + i * n_out, hbits.begin() + (i + 1) * n_out);
     }
+  if (!n_steps)
+    return 0;
+  hipStream_t st = ctx->stream;
+  const size_t n_out = n_steps - conv_order;
+  const size_t max_batch = 512;            // decodes per launch and code type
+  size_t done[3] = { 0, 0, 0 };
+  while (done[0] < soft[0].size() || done[1] < soft[1].size() || done[2] < soft[2].size())
+    {
+      size_t nb[3], in_off[3], ws_off[3], bits_off[3], err_off[3];
+      size_t in_total = 0, ws_total = 0, bits_total = 0, err_total = 0;
+      for (int t = 0; t < 3; t++)
+        {
+          const size_t rate = t == 2 ? 12 : 6;
+          nb[t] = std::min (max_batch, soft[t].size() - done[t]);
+          in_off[t] = in_total;    in_total += nb[t] * n_steps * rate;
+          ws_off[t] = ws_total;    ws_total += awmk::viterbi_workspace_bytes (n_steps * rate, rate, nb[t]);
+          bits_off[t] = bits_total; bits_total += nb[t] * n_out;
+          err_off[t] = err_total;  err_total += nb[t];
+        }
+      std::vector<float> flat (in_total);
+      for (int t = 0; t < 3; t++)
+        {
+          const size_t len = n_steps * (t == 2 ? 12 : 6);
+          for (size_t i = 0; i < nb[t]; i++)
+            std::copy (soft[t][done[t] + i].begin(), soft[t][done[t] + i].end(), flat.begin() + in_off[t] + i * len);
+        }
+      if (int rc = ctx->ws_viterbi_in.reserve (std::max<size_t> (1, flat.size()) * sizeof (float))) return rc;
+      if (int rc = ctx->ws_viterbi.reserve (std::max<size_t> (1, ws_total))) return rc;
+      if (int rc = ctx->ws_viterbi_bits.reserve (std::max<size_t> (1, bits_total) * sizeof (int))) return rc;
+      if (int rc = ctx->ws_viterbi_err.reserve (std::max<size_t> (1, err_total) * sizeof (float))) return rc;
+      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_viterbi_in.ptr, flat.data(), flat.size() * sizeof (float), hipMemcpyHostToDevice, st));
+      const float *d_soft[3];
+      unsigned char *d_ws[3];
+      int *d_bits[3];
+      float *d_err[3];
+      long long n_blocks[3];
+      double bytes = 0;
+      for (int t = 0; t < 3; t++)
+        {
+          d_soft[t] = ctx->ws_viterbi_in.as<float>() + in_off[t];
+          d_ws[t] = ctx->ws_viterbi.as<unsigned char>() + ws_off[t];
+          d_bits[t] = ctx->ws_viterbi_bits.as<int>() + bits_off[t];
+          d_err[t] = ctx->ws_viterbi_err.as<float>() + err_off[t];
+          n_blocks[t] = (long long) nb[t];
+          bytes += double (nb[t]) * n_steps * (t == 2 ? 12 : 6) * 4.0;
+        }
+      {
+        ProfScope ps (ctx, PROF_VITERBI, bytes + 2.0 * ws_total);
+        AWM_HIP_CHECK (awmk::launch_viterbi (st, d_soft, n_blocks, (long long) n_steps, d_ws, d_bits, d_err));
+      }
+      std::vector<int> hbits (bits_total);
+      std::vector<float> herr (err_total);
+      AWM_HIP_CHECK (hipMemcpyAsync (hbits.data(), ctx->ws_viterbi_bits.ptr, hbits.size() * sizeof (int), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipMemcpyAsync (herr.data(), ctx->ws_viterbi_err.ptr, herr.size() * sizeof (float), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      for (int t = 0; t < 3; t++)
+        {
+          for (size_t i = 0; i < nb[t]; i++)
+            {
+              bits[t][done[t] + i].assign (hbits.begin() + bits_off[t] + i * n_out, hbits.begin() + bits_off[t] + (i + 1) * n_out);
+              errors[t][done[t] + i] = herr[err_off[t] + i];
+            }
+          done[t] += nb[t];
+        }
+    }
+  return 0;
+}
+
+int
+viterbi_decode (awm_ctx *ctx, ConvBlockType block_type, const std::vector<std::vector<float>>& soft,
+                std::vector<std::vector<int>>& bits, std::vector<float>& errors)
+{
+  std::vector<std::vector<float>> in[3];
+  std::vector<std::vector<int>> out_bits[3];
+  std::vector<float> out_err[3];
+  in[int (block_type)] = soft;
+  if (int rc = viterbi_decode_all (ctx, in, out_bits, out_err))
+    return rc;
+  bits = out_bits[int (block_type)];
+  errors = out_err[int (block_type)];
   return 0;
 }
 
@@ -393,30 +450,35 @@ struct PendingDecode       // one Viterbi job and what to do with its result
   size_t             chunk = 0;       // which chunk's ResultSet receives the pattern
 };
 
-// all decodes of one code type go to the GPU in one launch, whatever chunk they belong to
+// every pending decode of a stream goes to the GPU in ONE launch (A, B and AB blocks side by side)
 int
 run_pending (awm_ctx *ctx, const Key& key, std::vector<PendingDecode>& pending, const std::vector<ResultSet *>& result_sets, double speed)
 {
-  for (ConvBlockType ct : { ConvBlockType::a, ConvBlockType::b, ConvBlockType::ab })
+  std::vector<std::vector<float>> soft[3];
+  std::vector<size_t> which[3];
+  for (size_t i = 0; i < pending.size(); i++)
     {
-      std::vector<std::vector<float>> soft;
-      std::vector<size_t> which;
-      for (size_t i = 0; i < pending.size(); i++)
-        if (pending[i].code_type == ct)
-          {
-            soft.push_back (std::move (pending[i].soft));
-            which.push_back (i);
-          }
-      std::vector<std::vector<int>> bits;
-      std::vector<float> errors;
-      if (int rc = viterbi_decode (ctx, ct, soft, bits, errors))
-        return rc;
-      for (size_t j = 0; j < which.size(); j++)
-        {
-          const PendingDecode& p = pending[which[j]];
-          if (!bits[j].empty())
-            result_sets[p.chunk]->add_pattern (key, p.time, p.score, bits[j], errors[j], p.type, speed);
-        }
+      const int t = int (pending[i].code_type);
+      soft[t].push_back (std::move (pending[i].soft));
+      which[t].push_back (i);
+    }
+  std::vector<std::vector<int>> bits[3];
+  std::vector<float> errors[3];
+  if (int rc = viterbi_decode_all (ctx, soft, bits, errors))
+    return rc;
+  // patterns are added in submission order (A/B block patterns first, then AB, then "all" -- like the reference's job order)
+  std::vector<std::pair<size_t, std::pair<int, size_t>>> order;
+  for (int t = 0; t < 3; t++)
+    for (size_t j = 0; j < which[t].size(); j++)
+      order.push_back ({ which[t][j], { t, j } });
+  std::sort (order.begin(), order.end());
+  for (const auto& o : order)
+    {
+      const PendingDecode& p = pending[o.first];
+      const int t = o.second.first;
+      const size_t j = o.second.second;
+      if (!bits[t][j].empty())
+        result_sets[p.chunk]->add_pattern (key, p.time, p.score, bits[t][j], errors[t][j], p.type, speed);
     }
   return 0;
 }

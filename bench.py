@@ -172,6 +172,8 @@ def main():
                        "patterns": len(pats or []), "payload_matches": matches},
             "roofline": roofline,
             "kernels_ms_per_step": {p[0]: round(p[1] / args.steps, 3) for p in prof},
+            # algorithmic GB/s (SURVEY.md 8d bytes / HIP-event time) of every kernel, same definition as roofline.achieved
+            "kernels_algorithmic_GBps": {p[0]: round(p[3] / (p[1] * 1e-3) / 1e9, 1) for p in prof if p[1] > 0},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds)
