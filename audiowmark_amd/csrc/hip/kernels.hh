@@ -14,6 +14,7 @@ struct DevTables
   const float2 *tw1024;   // e^{-2 pi i k / 1024}, k <= 512
   const float  *window;   // normalised von Hann analysis window, 1024 (reference wmcommon.cc:68-89)
   const float  *synth;    // synthesis window, 3072 (reference wmadd.cc:177-206)
+  const double2 *slide;   // [84 bins 19..102][9]: e^{-2 pi i k j / 1024}, j = 0..7, and e^{+2 pi i 8 k / 1024} at j = 8
 };
 
 /* K1: FFTAnalyzer::run_fft / fft_range */
@@ -71,6 +72,9 @@ struct SyncDbArgs
   int          tile_frames;             // frames per workgroup tile (<= 72)
 };
 hipError_t launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a);
+/* K4s: same output as K4 for streams whose frames advance by 8 samples (search_refine): instead of one FFT per fine
+ * offset the 83 needed bins are carried from offset to offset by a sliding DFT in double precision. n_channels <= 2. */
+hipError_t launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a);
 
 /* K5: sync_decode (syncfinder.cc:116-153) for many candidates.
  * value(cand, row, band) = db[plane(cand) + row * row_stride + band * band_stride + lane(cand)],

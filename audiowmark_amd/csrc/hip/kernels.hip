@@ -781,6 +781,203 @@ launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
 }
 
 /* ==========================================================================================
+ * K4s: refinement STFT by sliding DFT
+ *
+ * search_refine evaluates, for every candidate and every one of the 510 sync frames, the SAME 1024-sample window
+ * advanced 65 times by 8 samples.  With the periodic von Hann window  w[n] = (1/256) (1/2 - 1/2 cos (2 pi n / N))
+ * the windowed spectrum is  X[k] = (R[k]/2 - (R[k-1] + R[k+1])/4) / 256  where R is the plain DFT of the segment, and
+ *   R'[k] = (R[k] + sum_{j<8} (x[s + N + j] - x[s + j]) e^{-2 pi i k j / N}) e^{+2 pi i 8 k / N}
+ * advances R by 8 samples.  One wave carries bins 19..102 (two adjacent bins per lane, 42 lanes) of one stream through
+ * all its fine offsets: one FFT at the first offset, then ~40 FP64 FMAs per lane, channel and offset instead of an
+ * FFT.  The recursion runs in double precision (MI355X FP64 vector rate is half the FP32 rate), so no drift builds up:
+ * the result is the double-precision DFT rounded to float -- the same definition the oracle's FFT uses.
+ * dB conversion, channel sum, skip rules and output layout are exactly those of sync_db_kernel.
+ * ========================================================================================== */
+constexpr int SL_TILE = 16;                                   // fine offsets buffered in LDS between flushes
+
+template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
+sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
+{
+  __shared__ float2 s_tw[512];
+  __shared__ __attribute__ ((aligned (16))) float s_scratch[WAVES][NB * SL_TILE];      // FFT exchange tile (>= 576 float2) / dB tile
+  static_assert (NB * SL_TILE * sizeof (float) >= XBUF_ELEMS * sizeof (float2), "scratch too small for the FFT tile");
+  for (int i = threadIdx.x; i < 512; i += blockDim.x)
+    s_tw[i] = t.tw512[i];
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long stream = (long long) blockIdx.x * WAVES + wave;
+  if (stream >= a.n_streams)
+    return;
+  const long long base = a.stream_base ? a.stream_base[stream] : a.base0 + stream * a.base_stride;
+  const int count = a.stream_count ? a.stream_count[stream] : a.count0;
+  if (count <= 0)
+    return;
+  float2 *xbuf = reinterpret_cast<float2 *> (s_scratch[wave]);
+  float *tile = s_scratch[wave];
+  const int C = CV;
+  const bool bins = lane < 42;                                // lane holds bins kA = 19 + 2 lane, kB = kA + 1
+  const int kA = 19 + 2 * (bins ? lane : 0);
+
+  // ---- first offset: plain (unwindowed) DFT bins from the wave FFT
+  double2 R[CV][2];
+  {
+    float in[2][16];
+    if (CV == 2)
+      fetch_stereo (a.pcm, base, 1024, lane, in[0], in[1]);
+    else
+      fetch_channel (a.pcm, base, 1024, 1, 0, lane, in[0]);
+#pragma unroll
+    for (int c = 0; c < CV; c++)
+      {
+        float2 z[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          z[j] = make_float2 (in[c][2 * j], in[c][2 * j + 1]);
+        fft512_forward (z, xbuf, s_tw, lane);
+        xbuf[0 * 64 + lane] = z[0];
+        xbuf[1 * 64 + lane] = z[1];
+        xbuf[6 * 64 + lane] = z[6];
+        xbuf[7 * 64 + lane] = z[7];
+        wave_sync();
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+          {
+            const int k = kA + b;
+            const float2 r = real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], t.tw1024[k]);
+            R[c][b] = make_double2 (double (r.x), double (r.y));
+          }
+        wave_sync();
+      }
+  }
+  // per-lane rotation constants
+  double2 tw[2][9];
+#pragma unroll
+  for (int b = 0; b < 2; b++)
+#pragma unroll
+    for (int j = 0; j < 9; j++)
+      tw[b][j] = t.slide[(kA + b - 19) * 9 + j];
+
+  // sample feed: lanes [0, 8 C) hold the 8 C samples entering the window at the next step, lanes [8 C, 16 C) those leaving
+  auto feed = [&] (int step) -> float {
+    // samples for the transition step -> step + 1
+    const long long s0 = base + 8LL * step;
+    float v = 0.f;
+    if (lane < 8 * C)
+      v = a.pcm[(s0 + 1024) * C + lane];
+    else if (lane < 16 * C)
+      v = a.pcm[s0 * C + (lane - 8 * C)];
+    return v;
+  };
+  float next_feed = count > 1 ? feed (0) : 0.f;
+  unsigned long long have_mask = 0;      // offsets 0..63
+  bool have_64 = false;                  // offset 64 (a candidate has at most 65 fine offsets)
+
+  for (int step = 0; step < count; step++)
+    {
+      // ---- output for this fine offset
+      const long long idx = base + 8LL * step;
+      const long long f_first = idx * C, f_last = (idx + 1024) * C;
+      const bool skip = (f_last < a.first) || (f_first > a.last);
+      float dbA = 0.f, dbB = 0.f;
+      if (!skip)
+        {
+          if (step < 64)
+            have_mask |= 1ULL << step;
+          else
+            have_64 = true;
+#pragma unroll
+          for (int c = 0; c < CV; c++)
+            {
+              // neighbours: R[kA - 1] lives in lane - 1 (its kB), R[kB + 1] in lane + 1 (its kA)
+              const double2 up = make_double2 (__shfl_up (R[c][1].x, 1), __shfl_up (R[c][1].y, 1));
+              const double2 dn = make_double2 (__shfl_down (R[c][0].x, 1), __shfl_down (R[c][0].y, 1));
+              const double s = 1.0 / 256;
+              const float xa_re = float ((0.5 * R[c][0].x - 0.25 * (up.x + R[c][1].x)) * s);
+              const float xa_im = float ((0.5 * R[c][0].y - 0.25 * (up.y + R[c][1].y)) * s);
+              const float xb_re = float ((0.5 * R[c][1].x - 0.25 * (R[c][0].x + dn.x)) * s);
+              const float xb_im = float ((0.5 * R[c][1].y - 0.25 * (R[c][0].y + dn.y)) * s);
+              dbA = __fadd_rn (dbA, db_from_complex (make_float2 (xa_re, xa_im)));
+              dbB = __fadd_rn (dbB, db_from_complex (make_float2 (xb_re, xb_im)));
+            }
+        }
+      const int col = step % SL_TILE;
+      if (bins)
+        {
+          const int bandA = kA - MIN_BAND, bandB = bandA + 1;           // -1 .. 80 / 0 .. 82
+          if (bandA >= 0 && bandA < NB)
+            tile[bandA * SL_TILE + col] = dbA;
+          if (bandB < NB)
+            tile[bandB * SL_TILE + col] = dbB;
+        }
+      if (col == SL_TILE - 1 || step == count - 1)
+        {
+          wave_sync();
+          const int t0 = step - col, n_cols = col + 1;
+          float *out = a.out + stream * a.out_stream_stride + t0;
+          for (int i = lane; i < NB * SL_TILE; i += 64)
+            {
+              const int band = i / SL_TILE, cc = i % SL_TILE;
+              if (cc < n_cols)
+                out[band * a.ld + cc] = tile[i];
+            }
+          wave_sync();
+        }
+      // ---- advance by 8 samples
+      if (step + 1 < count)
+        {
+          const float v = next_feed;
+          if (step + 2 < count)
+            next_feed = feed (step + 1);
+          const double delta = double (v) - double (__shfl_down (v, 8 * C));    // lanes [0, 8 C): entering - leaving
+#pragma unroll
+          for (int c = 0; c < CV; c++)
+            {
+              double2 acc[2] = { R[c][0], R[c][1] };
+#pragma unroll
+              for (int j = 0; j < 8; j++)
+                {
+                  const int src = j * C + c;
+                  const double d = __hiloint2double (__builtin_amdgcn_readlane (__double2hiint (delta), src),
+                                                     __builtin_amdgcn_readlane (__double2loint (delta), src));
+#pragma unroll
+                  for (int b = 0; b < 2; b++)
+                    {
+                      acc[b].x = fma (d, tw[b][j].x, acc[b].x);
+                      acc[b].y = fma (d, tw[b][j].y, acc[b].y);
+                    }
+                }
+#pragma unroll
+              for (int b = 0; b < 2; b++)
+                {
+                  const double2 r = tw[b][8];
+                  R[c][b] = make_double2 (acc[b].x * r.x - acc[b].y * r.y, acc[b].x * r.y + acc[b].y * r.x);
+                }
+            }
+        }
+    }
+  if (a.have && lane < count)
+    a.have[stream * a.have_stream_stride + lane] = (have_mask >> lane) & 1;
+  if (a.have && lane == 0 && count > 64)
+    a.have[stream * a.have_stream_stride + 64] = have_64;
+}
+
+hipError_t
+launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
+{
+  if (a.n_streams <= 0 || a.count0 <= 0)
+    return hipSuccess;
+  if (a.hop != 8 || a.count0 > 65 || a.per_channel || (a.n_channels != 1 && a.n_channels != 2))
+    return hipErrorInvalidValue;
+  const unsigned grid = unsigned ((a.n_streams + WAVES - 1) / WAVES);
+  if (a.n_channels == 2)
+    hipLaunchKernelGGL (sync_db_sliding_kernel<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
+  else
+    hipLaunchKernelGGL (sync_db_sliding_kernel<1>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
+  return hipGetLastError();
+}
+
+/* ==========================================================================================
  * K5: sync_decode for 64 candidates x 6 sync bits per workgroup
  * ========================================================================================== */
 __global__ void __launch_bounds__ (384)

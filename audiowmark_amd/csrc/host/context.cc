@@ -244,6 +244,21 @@ awm_ctx_create (int device, awm_ctx **ctx_out)
   const size_t off_synth = blob.size();
   auto synth = gen_synth_window();
   blob.insert (blob.end(), synth.begin(), synth.end());
+  // sliding DFT rotations for bins 19..102 (refinement), double precision
+  std::vector<double> slide;
+  for (int k = 19; k <= 102; k++)
+    {
+      for (int j = 0; j < 8; j++)
+        {
+          slide.push_back (std::cos (-2 * M_PI * k * j / 1024));
+          slide.push_back (std::sin (-2 * M_PI * k * j / 1024));
+        }
+      slide.push_back (std::cos (2 * M_PI * k * 8 / 1024));
+      slide.push_back (std::sin (2 * M_PI * k * 8 / 1024));
+    }
+  if (int rc = upload (ctx->tab_slide, slide.data(), slide.size() * sizeof (double), ctx->stream))
+    return rc;
+  ctx->tabs.slide = ctx->tab_slide.as<double2>();
   if (int rc = upload (ctx->tab_mem, blob.data(), blob.size() * sizeof (float), ctx->stream))
     return rc;
   const float *base = ctx->tab_mem.as<float>();
@@ -276,7 +291,7 @@ awm_ctx_destroy (awm_ctx *ctx)
     }
   for (auto& t : ctx->frame_mod_tables)
     t->dev.release();
-  for (DevBuffer *b : { &ctx->tab_mem, &ctx->ws_db, &ctx->ws_have, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_mean, &ctx->ws_misc,
+  for (DevBuffer *b : { &ctx->tab_mem, &ctx->tab_slide, &ctx->ws_db, &ctx->ws_have, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_mean, &ctx->ws_misc,
                         &ctx->ws_refine, &ctx->ws_refine_have, &ctx->ws_soft, &ctx->ws_viterbi, &ctx->ws_viterbi_in,
                         &ctx->ws_viterbi_bits, &ctx->ws_viterbi_err, &ctx->ws_block_max, &ctx->ws_clip, &ctx->ws_idx })
     b->release();

@@ -66,7 +66,7 @@ struct awm_ctx
   hipStream_t    stream = nullptr;
   bool           own_stream = false;
   awmk::DevTables tabs {};
-  awm::DevBuffer tab_mem;
+  awm::DevBuffer tab_mem, tab_slide;
 
   std::vector<std::unique_ptr<awm::KeyTables>>     key_tables;
   std::vector<std::unique_ptr<awm::FrameModTable>> frame_mod_tables;

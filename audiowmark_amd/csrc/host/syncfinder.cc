@@ -340,7 +340,10 @@ SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
               if (lane_count[c])
                 bytes += double (NW) * ((1024.0 + 8.0 * (lane_count[c] - 1)) * 4 * wav.n_channels + 324.0 * lane_count[c]);
             ProfScope ps (m_ctx, PROF_REFINE_DB, bytes);
-            AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+            if (wav.n_channels <= 2 && !getenv ("AWM_REFINE_FFT"))
+              AWM_HIP_CHECK (awmk::launch_sync_db_sliding (st, m_ctx->tabs, da));       // K4s: sliding DFT over the fine offsets
+            else
+              AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));               // K4: one FFT per fine offset
           }
 
           awmk::SyncScanArgs sa {};
