@@ -172,10 +172,33 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
       });
       return 0;
     }
-  if (int rc = fetch_scores (n_scores, out))
-    return rc;
-  select_local_maxima (out);
-  mask_avg_false_positives (out);
+  // fewer than n_best peaks above the threshold: the reference then keeps the n_best largest unmasked maxima.
+  // Fetch ALL unmasked local maxima (threshold -1) from the device and finish the selection here.
+  const unsigned int big_cap = unsigned (std::min<long long> (n_scores, 1 << 22));
+  if (int rc = m_ctx->ws_refine.reserve (size_t (big_cap) * sizeof (awmk::PeakOut))) return rc;
+  auto *d_all = m_ctx->ws_refine.as<awmk::PeakOut>();
+  AWM_HIP_CHECK (awmk::launch_peak_select (st, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>(), n_scores, -1.0, d_count, d_all, big_cap));
+  AWM_HIP_CHECK (hipMemcpyAsync (&count, d_count, sizeof (count), hipMemcpyDeviceToHost, st));
+  AWM_HIP_CHECK (hipStreamSynchronize (st));
+  if (count > big_cap)
+    {
+      // cannot happen (at most every second score is a maximum); keep the sequential formulation as a safety net
+      if (int rc = fetch_scores (n_scores, out))
+        return rc;
+      select_local_maxima (out);
+      mask_avg_false_positives (out);
+      select_threshold_and_n_best (out, threshold);
+      return 0;
+    }
+  std::vector<awmk::PeakOut> peaks (count);
+  if (count)
+    {
+      AWM_HIP_CHECK (hipMemcpyAsync (peaks.data(), d_all, count * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipStreamSynchronize (st));
+    }
+  std::sort (peaks.begin(), peaks.end(), [] (const awmk::PeakOut& a, const awmk::PeakOut& b) { return a.p < b.p; });   // index order, as the reference's list
+  for (const auto& pk : peaks)
+    out.push_back ({ size_t (pk.p >> 2) * Params::frame_size + size_t (pk.p & 3) * Params::sync_search_step, pk.raw, pk.mean });
   select_threshold_and_n_best (out, threshold);
   return 0;
 }

@@ -89,6 +89,8 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n = int(args.minutes * 60 * RATE)
+    if world > 1:
+        n -= n % 1024            # spans of a sharded stream are whole frames (only the last one may be ragged)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     x = torch.rand((n, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1   # test-gen-noise distribution
@@ -142,7 +144,7 @@ def main():
     prof = [(awm.lib.awm_prof_name(i).decode(), ms, l, b) for (i, ms, l, b) in prof]
 
     if rank == 0:
-        audio_seconds = args.minutes * 60 * world
+        audio_seconds = n * world / RATE
         matches = sum(1 for p in (pats or []) if p["bits"] == PAYLOAD)
         total_ms = sum(p[1] for p in prof) or 1.0
         dom = max(prof, key=lambda p: p[1]) if prof else None

@@ -329,3 +329,37 @@ def test_sharded_stream_world1(gpu):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_three_channels_end_to_end(gpu):
+    """Channel counts other than 1 / 2 take the generic kernels (strided fetch, FFT based refinement)."""
+    n = 58 * 44100
+    x = noise(93, n, 3)
+    w = gpu.ctx.add_watermark(None, PAY2, gpu.dev(x))
+    want_w = orc.add(None, x, 3, PAY2).reshape(n, 3)
+    assert rms(w.cpu().numpy(), want_w) < RMS_TOL
+    got = gpu.ctx.get_watermark(None, gpu.dev(want_w))
+    want = orc.get(None, want_w, 3)
+    assert [pkey(p) for p in got] == [pkey(p) for p in want]
+    assert any(p["bits"] == PAY2 for p in got)
+
+
+def test_unmarked_audio_uses_n_best_fallback(gpu):
+    """No watermark -> fewer than n_best peaks above the threshold: the n_best largest maxima are still refined and
+    decoded (sync_select_threshold_and_n_best, reference syncfinder.cc:364-383) and agree with the oracle."""
+    n = 75 * 44100
+    x = noise(95, n, 2)
+    gi, gq, gb = gpu.ctx.sync_search(None, gpu.dev(x))
+    oi, oq, ob = orc.sync_search(None, x, 2)
+    assert gi.tolist() == oi.tolist() and gb.tolist() == ob.tolist() and len(gi) == 8
+    assert np.abs(gq - oq).max() < QUALITY_TOL
+    assert all(p["bits"] != PAY1 for p in gpu.ctx.get_watermark(None, gpu.dev(x)))
+
+
+def test_unsupported_parameters_are_refused(gpu):
+    gpu.awm.set_params(frames_per_bit=3)
+    try:
+        with pytest.raises(gpu.awm.AwmError):
+            gpu.ctx.add_watermark(None, PAY1, gpu.dev(noise(1, 5000, 2)))
+    finally:
+        gpu.awm.set_params()
