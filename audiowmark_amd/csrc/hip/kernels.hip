@@ -799,7 +799,7 @@ template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
 sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 {
   __shared__ float2 s_tw[512];
-  __shared__ __attribute__ ((aligned (16))) float s_scratch[WAVES][NB * SL_TILE];      // FFT exchange tile (>= 576 float2) / dB tile
+  __shared__ __attribute__ ((aligned (16))) float s_scratch[WAVES][NB * SL_TILE];      // FFT exchange tile (>= 576 float2) / dB tile [offset][band]
   static_assert (NB * SL_TILE * sizeof (float) >= XBUF_ELEMS * sizeof (float2), "scratch too small for the FFT tile");
   for (int i = threadIdx.x; i < 512; i += blockDim.x)
     s_tw[i] = t.tw512[i];
@@ -905,10 +905,11 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
       if (bins)
         {
           const int bandA = kA - MIN_BAND, bandB = bandA + 1;           // -1 .. 80 / 0 .. 82
+          // [offset][band] with the odd row length 81: the 42 writing lanes and the transposed flush are conflict free
           if (bandA >= 0 && bandA < NB)
-            tile[bandA * SL_TILE + col] = dbA;
+            tile[col * NB + bandA] = dbA;
           if (bandB < NB)
-            tile[bandB * SL_TILE + col] = dbB;
+            tile[col * NB + bandB] = dbB;
         }
       if (col == SL_TILE - 1 || step == count - 1)
         {
@@ -919,7 +920,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
             {
               const int band = i / SL_TILE, cc = i % SL_TILE;
               if (cc < n_cols)
-                out[band * a.ld + cc] = tile[i];
+                out[band * a.ld + cc] = tile[cc * NB + band];
             }
           wave_sync();
         }

@@ -41,7 +41,7 @@ check_ctx (awm_ctx *ctx)
 }
 
 int
-frames_per_span (long long n_frames1024)
+frames_per_span (awm_ctx *ctx, long long n_frames1024)
 {
   if (const char *env = getenv ("AWM_ADD_SPAN"))
     {
@@ -49,12 +49,31 @@ frames_per_span (long long n_frames1024)
       if (v >= 1)
         return v;
     }
-  // enough waves to fill 256 CUs several times over, long enough spans to amortise the 2 halo frames
-  if (n_frames1024 >= 64 * 1024)
-    return 16;
-  if (n_frames1024 >= 8 * 1024)
-    return 8;
-  return 4;
+  // Every wave streams through L frames plus 2 halo frames.  All waves of one "round" (CUs x resident waves) start
+  // and finish together, so pick the number of rounds k that minimises k * (L + 2) with L = ceil (F / (k * capacity)):
+  // long spans amortise the halo, whole rounds avoid a half-empty tail.
+  static int capacity = 0;
+  if (!capacity)
+    {
+      hipDeviceProp_t prop;
+      int cus = 256;
+      if (hipGetDeviceProperties (&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
+        cus = prop.multiProcessorCount;
+      capacity = cus * 12;                     // add_mix_kernel runs 3 waves per SIMD
+    }
+  long long best_l = 4, best_cost = -1;
+  for (int k = 1; k <= 16; k++)
+    {
+      long long l = (n_frames1024 + (long long) k * capacity - 1) / ((long long) k * capacity);
+      l = std::max<long long> (l, 4);
+      const long long cost = k * (l + 2);
+      if (best_cost < 0 || cost < best_cost)
+        {
+          best_cost = cost;
+          best_l = l;
+        }
+    }
+  return int (std::min<long long> (best_l, 4096));
 }
 
 void
@@ -139,7 +158,7 @@ add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames
   a.first_block = (long long) first_block;
   a.n_blocks = (long long) n_blocks;
   a.limiter_block = LIMITER_BLOCK;
-  a.frames_per_span = frames_per_span ((long long) (n_frames + 1023) / 1024);
+  a.frames_per_span = frames_per_span (ctx, (long long) (n_frames + 1023) / 1024);
   ProfScope ps (ctx, PROF_ADD_MIX, double (n_frames) * n_channels * 8.0);     // read + write every sample once
   AWM_HIP_CHECK (awmk::launch_add_mix (ctx->stream, ctx->tabs, a));
   return 0;

@@ -24,6 +24,57 @@ FRAME = 1024
 LIMITER_BLOCK = 44100
 
 
+class _Comm:
+    """Thin view of torch.distributed that also works when the process group cannot move device tensors itself
+    (gloo with CUDA tensors: used to test the multi-rank numerics on a single-GPU box).  With the nccl (RCCL) backend
+    every call goes straight to torch.distributed and the data stays on the devices (xGMI)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+        self.stage = dist.get_backend() != "nccl"
+
+    def _h(self, t):
+        return t.cpu() if (self.stage and t.is_cuda) else t
+
+    def all_gather(self, outs, t):
+        if not (self.stage and t.is_cuda):
+            return self.dist.all_gather(outs, t)
+        host = [o.cpu() for o in outs]
+        self.dist.all_gather(host, t.cpu())
+        for o, h in zip(outs, host):
+            o.copy_(h)
+
+    def all_reduce_max(self, t):
+        if not (self.stage and t.is_cuda):
+            return self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        h = t.cpu()
+        self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX)
+        t.copy_(h)
+
+    def exchange(self, sends, recvs):
+        """sends: [(tensor, dst)], recvs: [(tensor, src)] -- all posted together, completed before returning."""
+        dist = self.dist
+        host_recv = []
+        ops = []
+        for t, dst in sends:
+            ops.append(dist.P2POp(dist.isend, self._h(t).contiguous(), dst))
+        for t, src in recvs:
+            h = torch_empty_like_host(t) if (self.stage and t.is_cuda) else t
+            host_recv.append((t, h))
+            ops.append(dist.P2POp(dist.irecv, h, src))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for t, h in host_recv:
+            if h is not t:
+                t.copy_(h)
+
+
+def torch_empty_like_host(t):
+    import torch
+    return torch.empty(t.shape, dtype=t.dtype)
+
+
 @dataclass
 class Partition:
     """Contiguous spans of a stream, one per rank; every span but the last must be a whole number of frames."""
@@ -95,7 +146,7 @@ def exchange_edge_frames(dist, local, n_channels):
     tail = view[last_start:]
     edge[1, :tail.shape[0]] = tail
     gathered = [torch.empty_like(edge) for _ in range(world)]
-    dist.all_gather(gathered, edge)
+    _Comm(dist).all_gather(gathered, edge)
     before = gathered[rank - 1][1].contiguous() if rank > 0 else None
     after = gathered[rank + 1][0].contiguous() if rank + 1 < world else None
     return before, after
@@ -113,23 +164,15 @@ def fetch_range(dist, part: Partition, local, n_channels):
     a, b = max(lo, my_s), min(hi, my_e)
     if a < b:
         buf[a - lo:b - lo] = view[a - my_s:b - my_s]
-    ops, keep = [], []
+    sends, recvs = [], []
     for src, dst, g_lo, g_hi in part.transfers():
         if src == rank:
-            t = view[g_lo - my_s:g_hi - my_s].contiguous()
-            keep.append(t)
-            ops.append(dist.P2POp(dist.isend, t, dst))
+            sends.append((view[g_lo - my_s:g_hi - my_s].contiguous(), dst))
         elif dst == rank:
-            t = torch.empty((g_hi - g_lo, n_channels), dtype=local.dtype, device=local.device)
-            keep.append((t, g_lo))
-            ops.append(dist.P2POp(dist.irecv, t, src))
-    if ops:
-        for req in dist.batch_isend_irecv(ops):
-            req.wait()
-    for item in keep:
-        if isinstance(item, tuple):
-            t, g_lo = item
-            buf[g_lo - lo:g_lo - lo + t.shape[0]] = t
+            recvs.append((torch.empty((g_hi - g_lo, n_channels), dtype=local.dtype, device=local.device), src, g_lo))
+    _Comm(dist).exchange(sends, [(t, src) for t, src, _ in recvs])
+    for t, _, g_lo in recvs:
+        buf[g_lo - lo:g_lo - lo + t.shape[0]] = t
     return buf, lo
 
 
@@ -160,7 +203,7 @@ class ShardedStream:
         self.ctx, self.dist, self.n_channels = ctx, dist, n_channels
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         lens = [torch.zeros(1, dtype=torch.int64, device=self._device()) for _ in range(self.world)]
-        dist.all_gather(lens, torch.tensor([n_frames_local], dtype=torch.int64, device=self._device()))
+        _Comm(dist).all_gather(lens, torch.tensor([n_frames_local], dtype=torch.int64, device=self._device()))
         self.part = Partition([int(t.item()) for t in lens])
         self._fm_cache = {}
 
@@ -186,7 +229,7 @@ class ShardedStream:
             self.ctx.add_init_block_max(block_max)
         self.ctx.add_mix(local, out, self._frame_mod(key, payload_hex), water_delta, start // FRAME, before, after, block_max)
         if use_limiter:
-            dist.all_reduce(block_max, op=dist.ReduceOp.MAX)      # seconds that straddle span edges
+            _Comm(dist).all_reduce_max(block_max)                  # seconds that straddle span edges
             self.ctx.add_limit(out, start, block_max)
         return out
 

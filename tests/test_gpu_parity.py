@@ -363,3 +363,65 @@ def test_unsupported_parameters_are_refused(gpu):
             gpu.ctx.add_watermark(None, PAY1, gpu.dev(noise(1, 5000, 2)))
     finally:
         gpu.awm.set_params()
+
+
+def _sharded_worker(rank, world, port, lengths, q):
+    import torch
+    import torch.distributed as dist
+    import audiowmark_amd as awm
+    from audiowmark_amd import sharded
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share the one GPU of the test box
+    try:
+        awm.set_params(chunk_size_min=10.0)
+        total = sum(lengths)
+        whole = noise(97, total, 2)
+        s = sum(lengths[:rank])
+        local = torch.from_numpy(whole[s:s + lengths[rank]].copy()).cuda()
+        ctx = awm.Context(0)
+        pipe = sharded.ShardedStream(ctx, dist, lengths[rank], 2)
+        out = torch.empty_like(local)
+        pipe.add_watermark(None, PAY1, local, out)
+        pats = pipe.get_watermark(None, out)
+        q.put((rank, "ok", out.cpu().numpy(), pats, [c[3] for c in pipe.part.chunk_plan()]))
+    except Exception:
+        import traceback
+        q.put((rank, "fail", traceback.format_exc(), None, None))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_two_ranks_equal_single_process(gpu):
+    """Two processes (gloo transport, one shared GPU) run the sharded add + get on a 21 minute stream cut into two
+    spans: the PCM must equal the single-call result bit for bit and the merged patterns must be identical.
+    Same code path as the multi-GPU bench except for the transport (RCCL there)."""
+    import socket
+    import torch.multiprocessing as mp
+    lengths = [14 * 60 * 44100 // 1024 * 1024, 7 * 60 * 44100 + 333]
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    mpctx = mp.get_context("spawn")
+    q = mpctx.Queue()
+    procs = [mpctx.Process(target=_sharded_worker, args=(r, 2, port, lengths, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in results:
+        assert r[1] == "ok", r[2]
+    gpu.awm.set_params(chunk_size_min=10.0)
+    try:
+        whole = gpu.dev(noise(97, sum(lengths), 2))
+        want = gpu.ctx.add_watermark(None, PAY1, whole)
+        got = np.concatenate([results[0][2], results[1][2]])
+        assert np.array_equal(got, want.cpu().numpy())
+        want_pats = gpu.ctx.get_watermark(None, want)
+        assert [pkey(p) for p in results[0][3]] == [pkey(p) for p in want_pats]
+        assert results[1][3] is None and len(set(results[0][4])) == 2          # both ranks decoded chunks
+        assert sum(p["bits"] == PAY1 for p in want_pats) >= 20
+    finally:
+        gpu.awm.set_params()
