@@ -102,6 +102,8 @@ lib.awm_conv_encode.argtypes = [C.c_int, _vp, C.c_size_t, _vp]
 
 
 lib.awm_decode_chunks_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_size_t, _vp, _vp]
+lib.awm_pcm_decode_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp]
+lib.awm_pcm_encode_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, _vp]
 lib.awm_plan_chunks.argtypes = [C.c_size_t, C.c_size_t, _vp, _vp, _vp]
 lib.awm_merge_patterns.argtypes = [_vp, _vp, _vp, C.c_int, C.c_size_t, _vp]
 lib.awm_prof_name.restype = C.c_char_p
@@ -282,6 +284,24 @@ class Context:
 
     def synchronize(self):
         _check(lib.awm_ctx_synchronize(self._h), "awm_ctx_synchronize")
+
+    # RawConverter::from_raw / to_raw on the device
+    def pcm_decode(self, raw_bytes, bit_depth, encoding=0, big_endian=False):
+        import torch
+        assert raw_bytes.dtype == torch.uint8 and raw_bytes.is_cuda and raw_bytes.is_contiguous()
+        n = raw_bytes.numel() // (bit_depth // 8)
+        out = torch.empty(n, dtype=torch.float32, device=raw_bytes.device)
+        _check(lib.awm_pcm_decode_d(self._h, _dev_ptr(raw_bytes), n, bit_depth, encoding, int(big_endian), _dev_ptr(out)), "awm_pcm_decode_d")
+        return out
+
+    def pcm_encode(self, samples, bit_depth, encoding=0, big_endian=False, direct16=True):
+        import torch
+        assert samples.dtype == torch.float32 and samples.is_cuda and samples.is_contiguous()
+        n = samples.numel()
+        out = torch.empty(n * (bit_depth // 8), dtype=torch.uint8, device=samples.device)
+        _check(lib.awm_pcm_encode_d(self._h, _dev_ptr(samples), n, bit_depth, encoding, int(big_endian), int(direct16), _dev_ptr(out)),
+               "awm_pcm_encode_d")
+        return out
 
     # FFTAnalyzer::fft_range
     def fft_range(self, pcm, start_index, frame_count, hop=1024):

@@ -142,6 +142,14 @@ size_t viterbi_workspace_bytes (long long coded_len, int rate, long long n_block
 } // namespace awmk
 
 namespace awmk {
+/* I/O staging: interleaved PCM bytes <-> float32 on the device with the reference's
+ * conversion rules (rawconverter.cc:155-286, rawconverter.hh:34-50).  width = bytes per value (1..4 integer, 4 / 8 float);
+ * encoding 0 signed / 1 unsigned / 2 float; direct16 = the reference's native little-endian signed 16 bit rule
+ * (truncate at 16 bit) instead of "clip to 32 bit, keep the top bits". */
+struct PcmFormatDev { int width, encoding, big_endian, direct16; };
+hipError_t launch_pcm_decode (hipStream_t st, const unsigned char *bytes, float *out, long long n_values, PcmFormatDev f);
+hipError_t launch_pcm_encode (hipStream_t st, const float *in, unsigned char *bytes, long long n_values, PcmFormatDev f);
+
 /* first / one-past-last non-zero value of an interleaved buffer (SyncFinder::scan_silence,
  * reference syncfinder.cc:155-169); result[0] = first (n_values if all zero), result[1] = last */
 hipError_t launch_nonzero_range (hipStream_t st, const float *data, long long n_values, unsigned long long *result);

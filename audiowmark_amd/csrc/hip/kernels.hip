@@ -1396,4 +1396,178 @@ launch_peak_select (hipStream_t st, const double *raw, const double *mean, long 
   return hipGetLastError();
 }
 
+/* ==========================================================================================
+ * PCM <-> float staging
+ * ========================================================================================== */
+__device__ __forceinline__ float
+pcm_decode_value (const unsigned char *b, const PcmFormatDev& f)
+{
+  if (f.encoding == 2)
+    {
+      unsigned char tmp[8];
+      for (int i = 0; i < f.width; i++)
+        tmp[i] = b[f.big_endian ? f.width - 1 - i : i];
+      if (f.width == 4)
+        {
+          float v;
+          memcpy (&v, tmp, 4);
+          return v;
+        }
+      double d;
+      memcpy (&d, tmp, 8);
+      return float (d);
+    }
+  unsigned int u = 0;
+  for (int i = 0; i < f.width; i++)
+    {
+      const int significance = f.big_endian ? f.width - 1 - i : i;
+      u |= (unsigned int) b[i] << (8 * (4 - f.width + significance));
+    }
+  if (f.encoding == 1)
+    u ^= 0x80000000u;
+  return __fmul_rn (float (int (u)), 1.0f / 2147483648.0f);
+}
+
+__device__ __forceinline__ void
+pcm_encode_value (float v, unsigned char *b, const PcmFormatDev& f)
+{
+  if (f.encoding == 2)
+    {
+      const float c = v >= 1.f ? 1.f : (v <= -1.f ? -1.f : v);
+      unsigned char tmp[8];
+      if (f.width == 4)
+        memcpy (tmp, &c, 4);
+      else
+        {
+          const double d = c;
+          memcpy (tmp, &d, 8);
+        }
+      for (int i = 0; i < f.width; i++)
+        b[f.big_endian ? f.width - 1 - i : i] = tmp[i];
+      return;
+    }
+  unsigned int u;
+  if (f.direct16)
+    {
+      const float s = __fmul_rn (v, 32768.f);
+      const int i = s >= 32767.f ? 32767 : (s <= -32768.f ? -32768 : int (s));
+      u = (unsigned int) i << 16;
+    }
+  else
+    {
+      const float s = __fmul_rn (v, 2147483648.f);
+      const int i = s >= 2147483648.f ? 2147483647 : (s <= -2147483648.f ? int (0x80000000u) : int (s));
+      u = (unsigned int) i;
+    }
+  if (f.encoding == 1)
+    u ^= 0x80000000u;
+  for (int i = 0; i < f.width; i++)
+    {
+      const int significance = f.big_endian ? f.width - 1 - i : i;
+      b[i] = (unsigned char) (u >> (8 * (4 - f.width + significance)));
+    }
+}
+
+__global__ void __launch_bounds__ (256)
+pcm_decode_kernel (const unsigned char *bytes, float *out, long long n_values, PcmFormatDev f)
+{
+  const long long stride = (long long) gridDim.x * blockDim.x;
+  for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride)
+    out[i] = pcm_decode_value (bytes + i * f.width, f);
+}
+
+// little-endian signed 16 bit: 4 values (8 bytes in, 16 bytes out) per thread
+__global__ void __launch_bounds__ (256)
+pcm_decode_s16le_kernel (const short4 *in, float4 *out, long long n_vec)
+{
+  const long long stride = (long long) gridDim.x * blockDim.x;
+  for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride)
+    {
+      const short4 v = in[i];
+      const float k = 1.0f / 32768.0f;
+      out[i] = make_float4 (__fmul_rn (float (v.x), k), __fmul_rn (float (v.y), k), __fmul_rn (float (v.z), k), __fmul_rn (float (v.w), k));
+    }
+}
+
+__global__ void __launch_bounds__ (256)
+pcm_encode_kernel (const float *in, unsigned char *bytes, long long n_values, PcmFormatDev f)
+{
+  const long long stride = (long long) gridDim.x * blockDim.x;
+  for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n_values; i += stride)
+    pcm_encode_value (in[i], bytes + i * f.width, f);
+}
+
+__global__ void __launch_bounds__ (256)
+pcm_encode_s16le_kernel (const float4 *in, short4 *out, long long n_vec, int direct16)
+{
+  const long long stride = (long long) gridDim.x * blockDim.x;
+  for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < n_vec; i += stride)
+    {
+      const float4 v = in[i];
+      const float x[4] = { v.x, v.y, v.z, v.w };
+      short r[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        {
+          if (direct16)
+            {
+              const float s = __fmul_rn (x[j], 32768.f);
+              r[j] = short (s >= 32767.f ? 32767 : (s <= -32768.f ? -32768 : int (s)));
+            }
+          else
+            {
+              const float s = __fmul_rn (x[j], 2147483648.f);
+              const int i32 = s >= 2147483648.f ? 2147483647 : (s <= -2147483648.f ? int (0x80000000u) : int (s));
+              r[j] = short (i32 >> 16);
+            }
+        }
+      out[i] = make_short4 (r[0], r[1], r[2], r[3]);
+    }
+}
+
+static unsigned
+pcm_grid (long long n)
+{
+  long long blocks = (n + 255) / 256;
+  return unsigned (blocks > 256 * 16 ? 256 * 16 : (blocks < 1 ? 1 : blocks));
+}
+
+hipError_t
+launch_pcm_decode (hipStream_t st, const unsigned char *bytes, float *out, long long n_values, PcmFormatDev f)
+{
+  if (n_values <= 0)
+    return hipSuccess;
+  long long done = 0;
+  if (f.encoding == 0 && f.width == 2 && !f.big_endian && (reinterpret_cast<uintptr_t> (bytes) & 7) == 0 && (reinterpret_cast<uintptr_t> (out) & 15) == 0)
+    {
+      const long long n_vec = n_values / 4;
+      if (n_vec)
+        hipLaunchKernelGGL (pcm_decode_s16le_kernel, dim3 (pcm_grid (n_vec)), dim3 (256), 0, st, reinterpret_cast<const short4 *> (bytes),
+                            reinterpret_cast<float4 *> (out), n_vec);
+      done = n_vec * 4;
+    }
+  if (done < n_values)
+    hipLaunchKernelGGL (pcm_decode_kernel, dim3 (pcm_grid (n_values - done)), dim3 (256), 0, st, bytes + done * f.width, out + done, n_values - done, f);
+  return hipGetLastError();
+}
+
+hipError_t
+launch_pcm_encode (hipStream_t st, const float *in, unsigned char *bytes, long long n_values, PcmFormatDev f)
+{
+  if (n_values <= 0)
+    return hipSuccess;
+  long long done = 0;
+  if (f.encoding == 0 && f.width == 2 && !f.big_endian && (reinterpret_cast<uintptr_t> (bytes) & 7) == 0 && (reinterpret_cast<uintptr_t> (in) & 15) == 0)
+    {
+      const long long n_vec = n_values / 4;
+      if (n_vec)
+        hipLaunchKernelGGL (pcm_encode_s16le_kernel, dim3 (pcm_grid (n_vec)), dim3 (256), 0, st, reinterpret_cast<const float4 *> (in),
+                            reinterpret_cast<short4 *> (bytes), n_vec, f.direct16);
+      done = n_vec * 4;
+    }
+  if (done < n_values)
+    hipLaunchKernelGGL (pcm_encode_kernel, dim3 (pcm_grid (n_values - done)), dim3 (256), 0, st, in + done, bytes + done * f.width, n_values - done, f);
+  return hipGetLastError();
+}
+
 } // namespace awmk

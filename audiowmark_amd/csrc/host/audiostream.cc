@@ -187,6 +187,15 @@ public:
     m_codec->decode (bytes.data(), samples.data(), samples.size());
     return Error::Code::NONE;
   }
+  bool raw_access (RawFormat& format) const override { format = m_format; return true; }
+  Error
+  read_raw (unsigned char *dst, size_t max_frames, size_t& got_frames) override
+  {
+    got_frames = fread (dst, size_t (m_format.n_channels) * m_codec->sample_width(), max_frames, m_file);
+    if (ferror (m_file))
+      return Error ("error reading sample data");
+    return Error::Code::NONE;
+  }
 };
 
 class RawOutputStream : public AudioOutputStream
@@ -230,6 +239,15 @@ public:
     std::vector<unsigned char> bytes (samples.size() * m_codec->sample_width());
     m_codec->encode (samples.data(), bytes.data(), samples.size());
     fwrite (bytes.data(), 1, bytes.size(), m_file);
+    if (ferror (m_file))
+      return Error ("write sample data failed");
+    return Error::Code::NONE;
+  }
+  bool raw_access (RawFormat& format, bool& direct16) const override { format = m_format; direct16 = m_codec->direct16(); return true; }
+  Error
+  write_raw (const unsigned char *bytes, size_t n_frames) override
+  {
+    fwrite (bytes, size_t (m_format.n_channels) * m_codec->sample_width(), n_frames, m_file);
     if (ferror (m_file))
       return Error ("write sample data failed");
     return Error::Code::NONE;
@@ -396,6 +414,19 @@ public:
       }
     return Error::Code::NONE;
   }
+  bool raw_access (RawFormat& format) const override { format = m_format; return true; }
+  Error
+  read_raw (unsigned char *dst, size_t max_frames, size_t& got_frames) override
+  {
+    if (m_frames_left != N_FRAMES_UNKNOWN)
+      max_frames = std::min (max_frames, m_frames_left);
+    got_frames = max_frames ? fread (dst, size_t (m_format.n_channels) * m_codec->sample_width(), max_frames, m_file) : 0;
+    if (ferror (m_file))
+      return Error (string_printf ("error reading wav input sample data: %s", strerror (errno)));
+    if (m_frames_left != N_FRAMES_UNKNOWN)
+      m_frames_left -= got_frames;
+    return Error::Code::NONE;
+  }
 };
 
 class WavOutputStream : public AudioOutputStream
@@ -486,6 +517,25 @@ public:
           return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
         m_bytes_written += todo * width;
       }
+    return Error::Code::NONE;
+  }
+  bool
+  raw_access (RawFormat& format, bool& direct16) const override
+  {
+    format = m_codec->format();
+    format.n_channels = m_n_channels;
+    format.sample_rate = m_sample_rate;
+    direct16 = m_codec->direct16();
+    return true;
+  }
+  Error
+  write_raw (const unsigned char *bytes, size_t n_frames) override
+  {
+    const size_t n = n_frames * m_n_channels * (m_bit_depth / 8);
+    fwrite (bytes, 1, n, m_file);
+    if (ferror (m_file))
+      return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
+    m_bytes_written += n;
     return Error::Code::NONE;
   }
   Error

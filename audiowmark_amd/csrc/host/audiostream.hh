@@ -37,6 +37,8 @@ class PcmCodec
 public:
   static std::unique_ptr<PcmCodec> create (const RawFormat& format, Error& err, bool libsndfile_int_rule = false);
   int  sample_width() const { return m_format.bit_depth / 8; }
+  const RawFormat& format() const { return m_format; }
+  bool direct16() const { return !m_libsndfile_int_rule && m_format.endian == RawFormat::LITTLE && m_format.encoding == Encoding::SIGNED && m_format.bit_depth == 16; }
   void decode (const unsigned char *bytes, float *samples, size_t n_samples) const;
   void encode (const float *samples, unsigned char *bytes, size_t n_samples) const;
 };
@@ -59,6 +61,10 @@ public:
   virtual Encoding encoding() const = 0;
   // up to `count` interleaved frames normalised to [-1,1); a short / empty vector means EOF
   virtual Error    read_frames (std::vector<float>& samples, size_t count) = 0;
+  // optional fast path for the GPU pipeline: hand out the undecoded sample bytes (decoded on the device by
+  // awm_pcm_decode_d with the same rules as read_frames).  Default: not available.
+  virtual bool     raw_access (RawFormat& format) const { (void) format; return false; }
+  virtual Error    read_raw (unsigned char *dst, size_t max_frames, size_t& got_frames) { (void) dst; (void) max_frames; got_frames = 0; return Error ("raw access not supported"); }
 };
 
 class AudioOutputStream : public AudioStream
@@ -68,6 +74,10 @@ public:
                                                     Encoding encoding, size_t n_frames, Error& err);
   virtual Error write_frames (const std::vector<float>& frames) = 0;
   virtual Error close() = 0;
+  // optional fast path: accept sample bytes that were encoded on the device (awm_pcm_encode_d); direct16 tells which
+  // of the reference's two 16 bit rules this stream's own write_frames applies
+  virtual bool  raw_access (RawFormat& format, bool& direct16) const { (void) format; (void) direct16; return false; }
+  virtual Error write_raw (const unsigned char *bytes, size_t n_frames) { (void) bytes; (void) n_frames; return Error ("raw access not supported"); }
 };
 
 // global stream format selection, as in the reference's Params (wmcommon.hh:79-83)

@@ -230,6 +230,43 @@ awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, i
   return add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, ctx->ws_misc.as<int8_t>(), water_delta, use_limiter);
 }
 
+static bool
+pcm_format_ok (int bit_depth, int encoding)
+{
+  if (encoding == 2)
+    return bit_depth == 32 || bit_depth == 64;
+  return (encoding == 0 || encoding == 1) && (bit_depth == 8 || bit_depth == 16 || bit_depth == 24 || bit_depth == 32);
+}
+
+int
+awm_pcm_decode_d (awm_ctx *ctx, const void *bytes_d, size_t n_values, int bit_depth, int encoding, int big_endian, float *out_d)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (!pcm_format_ok (bit_depth, encoding))
+    {
+      set_error ("awm_pcm_decode_d: unsupported sample format");
+      return AWM_ERR_ARG;
+    }
+  const awmk::PcmFormatDev f { bit_depth / 8, encoding, big_endian != 0, 0 };
+  AWM_HIP_CHECK (awmk::launch_pcm_decode (ctx->stream, static_cast<const unsigned char *> (bytes_d), out_d, (long long) n_values, f));
+  return 0;
+}
+
+int
+awm_pcm_encode_d (awm_ctx *ctx, const float *in_d, size_t n_values, int bit_depth, int encoding, int big_endian, int direct16, void *bytes_d)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (!pcm_format_ok (bit_depth, encoding))
+    {
+      set_error ("awm_pcm_encode_d: unsupported sample format");
+      return AWM_ERR_ARG;
+    }
+  const bool d16 = direct16 && bit_depth == 16 && encoding == 0 && !big_endian;
+  const awmk::PcmFormatDev f { bit_depth / 8, encoding, big_endian != 0, d16 };
+  AWM_HIP_CHECK (awmk::launch_pcm_encode (ctx->stream, in_d, static_cast<unsigned char *> (bytes_d), (long long) n_values, f));
+  return 0;
+}
+
 int
 awm_sync_fft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, size_t index, size_t frame_count,
                 const char *want_frames, size_t first, size_t last, float *db_out_d, char *have_out_d)

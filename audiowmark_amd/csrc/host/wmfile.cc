@@ -9,40 +9,83 @@ namespace awm {
 
 namespace {
 
-// pinned host staging buffer (PCIe transfers at full rate, reusable)
-struct PinnedBuffer
+// pinned host staging buffer (PCIe transfers at full rate), grows geometrically
+struct PinnedBytes
 {
-  float *ptr = nullptr;
-  size_t values = 0;
-  ~PinnedBuffer() { if (ptr) (void) hipHostFree (ptr); }
+  unsigned char *ptr = nullptr;
+  size_t capacity = 0;
+  ~PinnedBytes() { if (ptr) (void) hipHostFree (ptr); }
   bool
-  reserve (size_t n)
+  reserve (size_t n, size_t keep)
   {
-    if (n <= values)
+    if (n <= capacity)
       return true;
-    float *np = nullptr;
-    size_t cap = std::max<size_t> (n, values * 2);
-    if (hipHostMalloc (reinterpret_cast<void **> (&np), cap * sizeof (float), hipHostMallocDefault) != hipSuccess)
+    unsigned char *np = nullptr;
+    const size_t cap = std::max<size_t> (n, capacity * 2);
+    if (hipHostMalloc (reinterpret_cast<void **> (&np), cap, hipHostMallocDefault) != hipSuccess)
       return false;
     if (ptr)
       {
-        std::copy (ptr, ptr + values, np);
+        std::copy (ptr, ptr + keep, np);
         (void) hipHostFree (ptr);
       }
     ptr = np;
-    values = cap;
+    capacity = cap;
     return true;
   }
 };
 
+bool
+device_codec_supported (const RawFormat& f)
+{
+  if (f.encoding == Encoding::FLOAT)
+    return f.bit_depth == 32 || f.bit_depth == 64;
+  return f.bit_depth == 8 || f.bit_depth == 16 || f.bit_depth == 24 || f.bit_depth == 32;
+}
+
+int encoding_id (Encoding e) { return e == Encoding::SIGNED ? 0 : (e == Encoding::UNSIGNED ? 1 : 2); }
+
+/* Whole stream -> float32 PCM in HBM.  Streams that can hand out their sample bytes are read straight into pinned
+ * memory, cross PCIe in their own format and are converted on the device (awm_pcm_decode_d, same rules as the host
+ * codec); everything else goes through read_frames. */
 Error
-read_all (AudioInputStream *in_stream, PinnedBuffer& buf, size_t& n_values)
+load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_pcm, size_t& n_values)
 {
   const int C = in_stream->n_channels();
   n_values = 0;
-  if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN)
-    if (!buf.reserve (in_stream->n_frames() * C + 1))
-      return Error ("out of (pinned) host memory");
+  PinnedBytes host;
+  RawFormat fmt;
+  if (in_stream->raw_access (fmt) && device_codec_supported (fmt))
+    {
+      const size_t frame_bytes = size_t (C) * (fmt.bit_depth / 8);
+      size_t frames = 0;
+      if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN && !host.reserve ((in_stream->n_frames() + 1) * frame_bytes, 0))
+        return Error ("out of (pinned) host memory");
+      while (true)
+        {
+          const size_t block = size_t (1) << 22;                       // frames per read
+          if (!host.reserve ((frames + block) * frame_bytes, frames * frame_bytes))
+            return Error ("out of (pinned) host memory");
+          size_t got = 0;
+          Error err = in_stream->read_raw (host.ptr + frames * frame_bytes, block, got);
+          if (err)
+            return err;
+          if (!got)
+            break;
+          frames += got;
+        }
+      n_values = frames * C;
+      if (!n_values)
+        return Error::Code::NONE;
+      DevBuffer d_bytes;
+      if (d_bytes.reserve (frames * frame_bytes) || d_pcm.reserve (n_values * sizeof (float)))
+        return Error (awm_last_error());
+      bool ok = hipMemcpyAsync (d_bytes.ptr, host.ptr, frames * frame_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess
+             && awm_pcm_decode_d (ctx, d_bytes.ptr, n_values, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, d_pcm.as<float>()) == 0
+             && hipStreamSynchronize (ctx->stream) == hipSuccess;
+      d_bytes.release();
+      return ok ? Error (Error::Code::NONE) : Error (std::string ("GPU staging failed: ") + awm_last_error());
+    }
   std::vector<float> tile;
   while (true)
     {
@@ -51,10 +94,58 @@ read_all (AudioInputStream *in_stream, PinnedBuffer& buf, size_t& n_values)
         return err;
       if (tile.empty())
         break;
-      if (!buf.reserve (n_values + tile.size()))
+      if (!host.reserve ((n_values + tile.size()) * sizeof (float), n_values * sizeof (float)))
         return Error ("out of (pinned) host memory");
-      std::copy (tile.begin(), tile.end(), buf.ptr + n_values);
+      std::copy (tile.begin(), tile.end(), reinterpret_cast<float *> (host.ptr) + n_values);
       n_values += tile.size();
+    }
+  if (!n_values)
+    return Error::Code::NONE;
+  if (d_pcm.reserve (n_values * sizeof (float)))
+    return Error (awm_last_error());
+  if (hipMemcpyAsync (d_pcm.ptr, host.ptr, n_values * sizeof (float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess
+      || hipStreamSynchronize (ctx->stream) != hipSuccess)
+    return Error ("GPU transfer failed");
+  return Error::Code::NONE;
+}
+
+/* float32 PCM in HBM -> output stream, mirror image of load_stream_to_device */
+Error
+store_device_to_stream (awm_ctx *ctx, AudioOutputStream *out_stream, const float *d_pcm, size_t n_values)
+{
+  if (!n_values)
+    return Error::Code::NONE;
+  const int C = out_stream->n_channels();
+  PinnedBytes host;
+  RawFormat fmt;
+  bool direct16 = false;
+  if (out_stream->raw_access (fmt, direct16) && device_codec_supported (fmt))
+    {
+      const size_t bytes = n_values * (fmt.bit_depth / 8);
+      DevBuffer d_bytes;
+      if (d_bytes.reserve (bytes) || !host.reserve (bytes, 0))
+        return Error ("out of memory for output staging");
+      bool ok = awm_pcm_encode_d (ctx, d_pcm, n_values, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, direct16, d_bytes.ptr) == 0
+             && hipMemcpyAsync (host.ptr, d_bytes.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess
+             && hipStreamSynchronize (ctx->stream) == hipSuccess;
+      d_bytes.release();
+      if (!ok)
+        return Error (std::string ("GPU staging failed: ") + awm_last_error());
+      return out_stream->write_raw (host.ptr, n_values / C);
+    }
+  if (!host.reserve (n_values * sizeof (float), 0))
+    return Error ("out of (pinned) host memory");
+  if (hipMemcpyAsync (host.ptr, d_pcm, n_values * sizeof (float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
+      || hipStreamSynchronize (ctx->stream) != hipSuccess)
+    return Error ("GPU transfer failed");
+  const float *result = reinterpret_cast<const float *> (host.ptr);
+  const size_t tile = size_t (1 << 20) * C;                     // write in tiles through the unchanged stream surface
+  for (size_t pos = 0; pos < n_values; pos += tile)
+    {
+      std::vector<float> part (result + pos, result + std::min (n_values, pos + tile));
+      Error err = out_stream->write_frames (part);
+      if (err)
+        return err;
     }
   return Error::Code::NONE;
 }
@@ -134,27 +225,20 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
   info ("Channels:     %d\n", in_stream->n_channels());
 
   const int C = in_stream->n_channels();
-  PinnedBuffer host;
+  DevBuffer d_in, d_out;
+  auto cleanup = [&] { d_in.release(); d_out.release(); };
   size_t n_values = 0;
-  Error err = read_all (in_stream, host, n_values);
+  Error err = load_stream_to_device (ctx, in_stream, d_in, n_values);
   if (err)
     {
       error ("audiowmark: input stream read failed: %s\n", err.message());
-      return 1;
-    }
-  const size_t n_frames = n_values / C;
-  DevBuffer d_in, d_out;
-  auto cleanup = [&] { d_in.release(); d_out.release(); };
-  if (d_in.reserve (std::max<size_t> (n_values, 1) * sizeof (float)) || d_out.reserve (std::max<size_t> (n_values, 1) * sizeof (float)))
-    {
-      error ("audiowmark: %s\n", awm_last_error());
       cleanup();
       return 1;
     }
-  std::vector<float> result (n_values);
+  const size_t n_frames = n_values / C;
   if (n_values)
     {
-      if (hipMemcpyAsync (d_in.ptr, host.ptr, n_values * sizeof (float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess
+      if (d_out.reserve (n_values * sizeof (float))
           || awm_add_watermark_d (ctx, key.aes_key(), bit_vec_to_str (bitvec).c_str(), d_in.as<float>(), d_out.as<float>(), n_frames, C,
                                   in_stream->sample_rate()) != 0)
         {
@@ -162,22 +246,18 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
           cleanup();
           return 1;
         }
-      // reuse the pinned buffer for the way back; keep the original for --snr
-      std::vector<float> orig;
-      if (Params::snr)
-        orig.assign (host.ptr, host.ptr + n_values);
-      if (hipMemcpyAsync (host.ptr, d_out.ptr, n_values * sizeof (float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
-          || hipStreamSynchronize (ctx->stream) != hipSuccess)
-        {
-          error ("audiowmark: GPU transfer failed\n");
-          cleanup();
-          return 1;
-        }
-      std::copy (host.ptr, host.ptr + n_values, result.begin());
       if (Params::snr)
         {
           // the reference measures the watermark before the limiter (wmadd.cc:553-563); with the limiter
           // active this is the power of (output - original), which includes the limiter's gain change
+          std::vector<float> orig (n_values), result (n_values);
+          if (hipMemcpy (orig.data(), d_in.ptr, n_values * sizeof (float), hipMemcpyDeviceToHost) != hipSuccess
+              || hipMemcpy (result.data(), d_out.ptr, n_values * sizeof (float), hipMemcpyDeviceToHost) != hipSuccess)
+            {
+              error ("audiowmark: GPU transfer failed\n");
+              cleanup();
+              return 1;
+            }
           double delta_power = 0, signal_power = 0;
           for (size_t i = 0; i < n_values; i++)
             {
@@ -187,20 +267,15 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
             }
           info ("SNR:          %f dB\n", 10 * log10 (signal_power / delta_power));
         }
-    }
-  cleanup();
-  // write in tiles through the unchanged stream surface
-  const size_t tile = size_t (1 << 20) * C;
-  for (size_t pos = 0; pos < result.size(); pos += tile)
-    {
-      std::vector<float> part (result.begin() + pos, result.begin() + std::min (result.size(), pos + tile));
-      err = out_stream->write_frames (part);
+      err = store_device_to_stream (ctx, out_stream, d_out.as<float>(), n_values);
       if (err)
         {
           error ("audiowmark output write failed: %s\n", err.message());
+          cleanup();
           return 1;
         }
     }
+  cleanup();
   info ("Data Blocks:  %d\n", count_data_blocks (n_frames, in_stream->sample_rate(), !Params::test_no_limiter));
   if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN && n_frames != in_stream->n_frames())
     {
@@ -286,12 +361,13 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
       return 1;
     }
   const int C = in_stream->n_channels();
-  PinnedBuffer host;
+  DevBuffer d_in;
   size_t n_values = 0;
-  err = read_all (in_stream.get(), host, n_values);
+  err = load_stream_to_device (ctx, in_stream.get(), d_in, n_values);
   if (err)
     {
       error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
+      d_in.release();
       return 1;
     }
   if (Params::test_truncate)
@@ -300,29 +376,22 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
   ResultSet result_set;
   if (n_frames)
     {
-      DevBuffer d_in;
-      if (d_in.reserve (n_values * sizeof (float))
-          || hipMemcpyAsync (d_in.ptr, host.ptr, n_values * sizeof (float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
-        {
-          error ("audiowmark: GPU transfer failed: %s\n", awm_last_error());
-          d_in.release();
-          return 1;
-        }
       DeviceWav wav;
       wav.data = d_in.as<float>();
       wav.n_frames = n_frames;
       wav.n_channels = C;
       wav.sample_rate = Params::mark_sample_rate;
       const int rc = get_watermark_device (ctx, key_list, wav, result_set);
-      d_in.release();
       if (rc)
         {
           error ("audiowmark: GPU detection failed: %s\n", awm_last_error());
+          d_in.release();
           return 1;
         }
     }
   else
     result_set.sort (key_list);
+  d_in.release();
   const size_t time_length = lrint (double (n_values) / (double (Params::mark_sample_rate) * C));
 
   /* report (reference wmget.cc:941-969) */

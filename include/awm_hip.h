@@ -105,6 +105,14 @@ int awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels
 int awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
                const int8_t *frame_mod, double water_delta, int use_limiter);
 
+/* I/O staging: RawConverter::from_raw / to_raw (rawconverter.cc:155-286) on the device, so that files cross PCIe in
+ * their own sample format.  bit_depth 8/16/24/32 (integer) or 32/64 (float); encoding 0 signed, 1 unsigned, 2 float.
+ * direct16 != 0 selects the reference's native little-endian signed-16 rule (truncate at 16 bit, what its stdout / raw
+ * writers do); 0 = clip to 32 bit and keep the top bits (what writing through libsndfile does). */
+int awm_pcm_decode_d (awm_ctx *ctx, const void *bytes_d, size_t n_values, int bit_depth, int encoding, int big_endian, float *out_d);
+int awm_pcm_encode_d (awm_ctx *ctx, const float *in_d, size_t n_values, int bit_depth, int encoding, int big_endian, int direct16,
+                      void *bytes_d);
+
 /* SyncFinder::sync_fft (syncfinder.cc:560-605): dB magnitudes of bins 20..100, channels summed.
  * db_out_d: [frame_count][81] float32, have_out_d: [frame_count] bytes.
  * want_frames (host, may be NULL) and [first,last) (value indices of the non-silent range,

@@ -469,3 +469,58 @@ def test_degenerate_sync_ties(gpu, kind):
     w = gpu.ctx.add_watermark(None, PAY1, gpu.dev(x)).cpu().numpy()
     assert rms(w, orc.add(None, x, 2, PAY1).reshape(x.shape)) < RMS_TOL
     assert all(q["bits"] != PAY1 for q in gpu.ctx.get_watermark(None, gpu.dev(x)))           # and no crash on NaN soft bits
+
+
+def _np_encode(x, bits, encoding, big, direct16):
+    """The reference's RawConverter::to_raw rules (rawconverter.cc:155-215, rawconverter.hh:34-50) in numpy float32."""
+    x = x.astype(np.float32)
+    width = bits // 8
+    if encoding == 2:
+        c = np.clip(x, -1, 1)
+        a = c.astype(">f4" if big else "<f4") if bits == 32 else c.astype(np.float64).astype(">f8" if big else "<f8")
+        return a.view(np.uint8)
+    if direct16:
+        s = (x * np.float32(32768)).astype(np.float32)
+        i = np.where(s >= 32767, 32767, np.where(s <= -32768, -32768, np.trunc(s))).astype(np.int64) << 16
+    else:
+        s = (x * np.float32(2147483648)).astype(np.float32)
+        i = np.where(s >= np.float32(2147483648), 2147483647, np.where(s <= np.float32(-2147483648), -2147483648, np.trunc(s.astype(np.float64)))).astype(np.int64)
+    u = (i & 0xFFFFFFFF).astype(np.uint64)
+    if encoding == 1:
+        u ^= 0x80000000
+    out = np.zeros((len(x), width), np.uint8)
+    for b in range(width):
+        sig = width - 1 - b if big else b
+        out[:, b] = (u >> (8 * (4 - width + sig))) & 0xFF
+    return out.ravel()
+
+
+def _np_decode(raw, bits, encoding, big):
+    width = bits // 8
+    b = raw.reshape(-1, width)
+    if encoding == 2:
+        a = b.copy().view((">f4" if big else "<f4") if bits == 32 else (">f8" if big else "<f8")).ravel()
+        return a.astype(np.float32)
+    u = np.zeros(len(b), np.uint64)
+    for k in range(width):
+        sig = width - 1 - k if big else k
+        u |= b[:, k].astype(np.uint64) << (8 * (4 - width + sig))
+    if encoding == 1:
+        u ^= 0x80000000
+    i = u.astype(np.uint32).view(np.int32)
+    return (i.astype(np.float32) * np.float32(1.0 / 2147483648.0)).astype(np.float32)
+
+
+@pytest.mark.parametrize("bits,encoding,big,direct16", [
+    (16, 0, False, True), (16, 0, False, False), (16, 0, True, True), (24, 0, False, True), (24, 0, True, True),
+    (32, 0, False, True), (8, 1, False, True), (16, 1, False, True), (32, 2, False, True), (64, 2, True, True)])
+def test_pcm_staging_bit_exact(gpu, bits, encoding, big, direct16):
+    """Device-side RawConverter: every sample format byte for byte (encode) / bit for bit (decode)."""
+    rng = np.random.default_rng(bits * 10 + encoding)
+    x = np.concatenate([rng.uniform(-1.2, 1.2, 100003), [0, 1, -1, 0.99999994, -0.5 / 32768, 0.5 / 32768, 32767 / 32768, 1e-9, -1e-9]]).astype(np.float32)
+    got = gpu.ctx.pcm_encode(gpu.dev(x), bits, encoding, big, direct16).cpu().numpy()
+    d16 = direct16 and bits == 16 and encoding == 0 and not big
+    want = _np_encode(x, bits, encoding, big, d16)
+    assert np.array_equal(got, want)
+    back = gpu.ctx.pcm_decode(gpu.dev(want), bits, encoding, big).cpu().numpy()
+    assert np.array_equal(back.view(np.uint32), _np_decode(want, bits, encoding, big).view(np.uint32))
