@@ -45,7 +45,9 @@ hipError_t launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs&
 /* K3: limiter ramp, in place */
 hipError_t launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels, long long first_sample,
                            const float *block_max, long long first_block, long long n_blocks,
-                           int limiter_block, float ceiling);
+                           int limiter_block, float ceiling, float2 *scale_tab = nullptr, size_t scale_tab_entries = 0);
+/* entries launch_limiter needs in scale_tab for this span (one (scale_start, scale_step) pair per limiter block) */
+size_t     limiter_tab_entries (long long n_frames, long long first_sample, int limiter_block);
 hipError_t launch_fill_u32 (hipStream_t st, unsigned int *p, unsigned int v, size_t n);
 
 /* K4: STFT -> dB of the 81 bands, written band-major ("transposed") so that scans over the
@@ -86,6 +88,10 @@ struct SyncTableDev
   // (frame for the approximate search, want-list position for the refinement); wave-uniform -> scalar loads
   const int *packed;
   int        rows_per_bit;
+  // approximate search only: [6][rows16][16] uint32, dwords 0..14 = the 60 band bytes (up 0..29, down 0..29),
+  // dword 15 = frame; rows past rows_per_bit carry frame 0xffff (rows16 = multiple of 4, >= rows_per_bit + 9)
+  const unsigned *packed16;
+  int        rows16_per_bit;
 };
 struct SyncScanArgs
 {
@@ -116,6 +122,9 @@ hipError_t launch_local_mean (hipStream_t st, const double *q, long long q_strid
 struct PeakOut { long long p; double raw, mean; };
 hipError_t launch_peak_select (hipStream_t st, const double *raw_sorted, const double *local_mean, long long n, double threshold,
                                unsigned int *count, PeakOut *out, unsigned int cap);
+
+/* K5d: per-slice top k (by |raw - mean|) of a peak list whose length lives in *count; out is [n_slices][k], p = -1 = empty */
+hipError_t launch_peak_topk (hipStream_t st, const PeakOut *in, const unsigned int *count, unsigned int cap, PeakOut *out, int k, int n_slices);
 
 /* K7: mix_decode (wmget.cc:67-108): db is [n_blocks][C][81][ld] (band-major), out [n_blocks][858] */
 struct SoftBitsArgs

@@ -574,16 +574,104 @@ limiter_kernel_v4 (float4 *data, long long n_vec, long long first_sample, const 
     }
 }
 
+/* K3 in two steps.  The ramp of a limiter block (scale_start, scale_step) only depends on three block maxima, so it
+ * is computed once per block (K3a) instead of once per sample (three IEEE divisions and a 64 bit integer division each);
+ * K3b then streams the samples: every workgroup owns a run of 2048 float4 -- shorter than a limiter block, so it meets
+ * at most two table entries, which it fetches with scalar loads -- and does one multiply-add per frame.  Runs whose
+ * entries are (1, 0) are left untouched: x * 1.0f == x, the pass is the identity there (audio that never reaches the
+ * ceiling costs no memory traffic at all).  The arithmetic per sample is unchanged (reference limiter.cc:99-124). */
+__global__ void
+limiter_table_kernel (float2 *tab, long long tab_first_block, long long n_tab, const float *block_max,
+                      long long first_block, long long n_blocks, int BS, float ceiling)
+{
+  const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n_tab)
+    return;
+  const long long b = tab_first_block + k;
+  auto M = [&] (long long bb) -> float {
+    const long long j = bb - first_block;
+    if (bb < 0 || j < 0 || j >= n_blocks)
+      return ceiling;
+    return fmaxf (block_max[j], ceiling);
+  };
+  const float m_last = M (b - 1), m_cur = M (b), m_next = M (b + 1);
+  const float scale_start = __fdiv_rn (ceiling, fmaxf (m_last, m_cur));
+  const float scale_end   = __fdiv_rn (ceiling, fmaxf (m_cur, m_next));
+  tab[k] = make_float2 (scale_start, __fdiv_rn (__fsub_rn (scale_end, scale_start), float (BS)));
+}
+
+constexpr int LIMITER_RUN = 2048;       // float4 per workgroup (8 per thread)
+
+template<int C> __global__ void __launch_bounds__ (256)
+limiter_apply_kernel (float4 *data, long long n_vec, long long first_sample, const float2 *tab, long long tab_first_block, int BS)
+{
+  constexpr int FPV = 4 / C;            // frames per float4
+  const long long base = (long long) blockIdx.x * LIMITER_RUN;
+  const long long gs0 = first_sample + base * FPV;
+  const long long b0 = gs0 / BS;                          // uniform: once per workgroup
+  const int i0 = int (gs0 - b0 * BS);
+  const float2 *tb = tab + (b0 - tab_first_block);
+  const float2 t0 = tb[0], t1 = tb[1];
+  if (t0.x == 1.f && t0.y == 0.f && t1.x == 1.f && t1.y == 0.f)
+    return;
+  auto scale = [&] (int i) -> float {
+    const bool next = i >= BS;
+    const float2 t = next ? t1 : t0;
+    return __fadd_rn (t.x, __fmul_rn (float (next ? i - BS : i), t.y));
+  };
+#pragma unroll
+  for (int j = 0; j < LIMITER_RUN / 256; j++)
+    {
+      const int r = threadIdx.x + 256 * j;
+      const long long q = base + r;
+      if (q >= n_vec)
+        break;
+      float4 v = data[q];
+      const int i = i0 + r * FPV;
+      if (C == 2)
+        {
+          const float s0 = scale (i), s1 = scale (i + 1);
+          v = make_float4 (__fmul_rn (v.x, s0), __fmul_rn (v.y, s0), __fmul_rn (v.z, s1), __fmul_rn (v.w, s1));
+        }
+      else
+        v = make_float4 (__fmul_rn (v.x, scale (i)), __fmul_rn (v.y, scale (i + 1)), __fmul_rn (v.z, scale (i + 2)), __fmul_rn (v.w, scale (i + 3)));
+      data[q] = v;
+    }
+}
+
+size_t
+limiter_tab_entries (long long n_frames, long long first_sample, int limiter_block)
+{
+  if (n_frames <= 0 || limiter_block <= 0)
+    return 0;
+  return size_t ((first_sample + n_frames - 1) / limiter_block - first_sample / limiter_block + 2);
+}
+
 hipError_t
 launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels, long long first_sample,
-                const float *block_max, long long first_block, long long n_blocks, int limiter_block, float ceiling)
+                const float *block_max, long long first_block, long long n_blocks, int limiter_block, float ceiling,
+                float2 *scale_tab, size_t scale_tab_entries)
 {
   const long long n_values = n_frames * n_channels;
   if (n_values <= 0)
     return hipSuccess;
   const bool vec = (n_channels == 1 || n_channels == 2) && (reinterpret_cast<uintptr_t> (data) & 15) == 0;
   const long long n_vec = vec ? n_values / 4 : 0;
-  if (n_vec)
+  const size_t need = limiter_tab_entries (n_frames, first_sample, limiter_block);
+  if (n_vec && scale_tab && scale_tab_entries >= need && limiter_block >= 4 * LIMITER_RUN)
+    {
+      const long long tab_first = first_sample / limiter_block;
+      hipLaunchKernelGGL (limiter_table_kernel, dim3 (unsigned ((need + 255) / 256)), dim3 (256), 0, st, scale_tab, tab_first, (long long) need,
+                          block_max, first_block, n_blocks, limiter_block, ceiling);
+      const unsigned grid = unsigned ((n_vec + LIMITER_RUN - 1) / LIMITER_RUN);
+      if (n_channels == 2)
+        hipLaunchKernelGGL (limiter_apply_kernel<2>, dim3 (grid), dim3 (256), 0, st, reinterpret_cast<float4 *> (data), n_vec, first_sample,
+                            scale_tab, tab_first, limiter_block);
+      else
+        hipLaunchKernelGGL (limiter_apply_kernel<1>, dim3 (grid), dim3 (256), 0, st, reinterpret_cast<float4 *> (data), n_vec, first_sample,
+                            scale_tab, tab_first, limiter_block);
+    }
+  else if (n_vec)
     {
       long long blocks = (n_vec + 255) / 256;
       if (blocks > 256 * 16)
@@ -1065,14 +1153,277 @@ sync_scan_kernel (SyncScanArgs a)
  * five sibling waves (one per sync bit).  The workgroup therefore streams the 81-band matrix through a 2 x 64 frame
  * ring in LDS exactly once (coalesced 256 B rows), and all 30 600 gathers per candidate are served from LDS
  * instead of the L2 -- 16x less L2 traffic than K5 while keeping every accumulation in the reference's order. */
-constexpr int SCAN_RING = 128;
-
-__global__ void __launch_bounds__ (384)
+/* NT = candidate tiles (of 64) per workgroup.  All tiles share the ring (NT + 1 halves of 64 frames) and the row
+ * table reads; every wave keeps NT independent accumulator pairs, which gives the LDS pipeline NT times more work per
+ * dependent row step (the kernel is latency bound: table -> address -> LDS -> 30 dependent adds). */
+template<int NT> __global__ void __launch_bounds__ (384)
 sync_scan_window_kernel (SyncScanArgs a, int total_frames)
 {
-  __shared__ __attribute__ ((aligned (16))) float s_win[NB * SCAN_RING];
-  __shared__ float s_u[6][64], s_d[6][64];
-  __shared__ int   s_n[6][64];
+  constexpr int RING = 64 * (NT + 1);
+  __shared__ __attribute__ ((aligned (16))) float s_win[NB * RING];
+  /* the epilogue's exchange buffers alias the ring (it is dead after the last barrier of the main loop): with
+   * NT = 1 the workgroup then needs 41.5 KB, so that three of them fit beside each other on a CU */
+  float (*s_u)[64 * NT] = reinterpret_cast<float (*)[64 * NT]> (s_win);
+  float (*s_d)[64 * NT] = reinterpret_cast<float (*)[64 * NT]> (s_win + 6 * 64 * NT);
+  int   *s_n = reinterpret_cast<int *> (s_win + 12 * 64 * NT);
+  const int lane = threadIdx.x;
+  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const long long plane = blockIdx.y;
+  const long long n_tiles = (a.n_lanes + 64 * NT - 1) / (64 * NT);
+  const long long per_xcd = (n_tiles + 7) / 8;
+  const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
+    return;                                               // uniform for the workgroup
+  const long long sf0 = tile * 64 * NT;
+  const float *db = a.db + plane * a.plane_stride;
+  const long long ld = a.band_stride;
+  const int R = a.table.rows_per_bit;
+  const_int_ptr tab = (const_int_ptr) (a.table.packed + (size_t) bit * R * 64);
+
+  auto load_half = [&] (int h) {
+    const long long base = sf0 + 64LL * h;
+    float *dst = s_win + 64 * (h % (NT + 1));
+    const bool in_range = base + 64 <= ld;
+    for (int idx = tid; idx < NB * 16; idx += 384)
+      {
+        const int band = idx >> 4, q = idx & 15;
+        float4 v = make_float4 (0.f, 0.f, 0.f, 0.f);
+        if (in_range)
+          v = *reinterpret_cast<const float4 *> (db + band * ld + base + 4 * q);
+        *reinterpret_cast<float4 *> (dst + band * RING + 4 * q) = v;
+      }
+  };
+
+  float umag[NT], dmag[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+    umag[t] = dmag[t] = 0.f;
+  int n = 0, r = 0;
+  for (int h = 0; h < NT; h++)
+    load_half (h);
+  for (int k = 0; 64 * k < total_frames; k++)
+    {
+      load_half (k + NT);
+      __syncthreads();
+      const int ring0 = 64 * (k % (NT + 1));
+      while (r < R)
+        {
+          const_int_ptr tr = tab + r * 64;
+          const int fr = tr[60];
+          if (fr >= 64 * (k + 1))
+            break;
+          const int x = fr - 64 * k + lane + ring0;          // < 2 * RING
+#pragma unroll
+          for (int t = 0; t < NT; t++)
+            {
+              int phys = x + 64 * t;
+              phys -= phys >= RING ? RING : 0;
+              phys -= phys >= RING ? RING : 0;
+              float uv[30], dv[30];
+#pragma unroll
+              for (int i = 0; i < 30; i++)
+                {
+                  uv[i] = s_win[tr[i] * RING + phys];
+                  dv[i] = s_win[tr[30 + i] * RING + phys];
+                }
+#pragma unroll
+              for (int i = 0; i < 30; i++)
+                {
+                  umag[t] = __fadd_rn (umag[t], uv[i]);
+                  dmag[t] = __fadd_rn (dmag[t], dv[i]);
+                }
+            }
+          n++;
+          r++;
+        }
+      __syncthreads();
+    }
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+    {
+      s_u[bit][64 * t + lane] = umag[t];
+      s_d[bit][64 * t + lane] = dmag[t];
+    }
+  if (lane == 0)
+    s_n[bit] = n;
+  __syncthreads();
+  for (int c = tid; c < 64 * NT; c += 384)
+    {
+      const long long cand = sf0 + c;
+      if (cand >= a.n_lanes)
+        continue;
+      double q = 0;
+      int total = 0;
+      for (int b = 0; b < 6; b++)
+        {
+          const float um = s_u[b][c], dm = s_d[b][c];
+          float raw;
+          if (um == 0 || dm == 0)
+            raw = 0;
+          else if (um < dm)
+            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
+          else
+            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
+          const double rb = (b & 1) ? double (raw) : -double (raw);
+          q += rb * s_n[b];
+          total += s_n[b];
+        }
+      if (total)
+        q /= total;
+      q = q / a.min_delta / 2.9;
+      a.quality[plane * a.q_stride + cand] = q;
+    }
+}
+
+__device__ unsigned long long g_scan_dbg[8];
+template<int NT> __global__ void __launch_bounds__ (384)
+sync_scan_dbg_kernel (SyncScanArgs a, int total_frames)
+{
+  constexpr int RING = 64 * (NT + 1);
+  __shared__ __attribute__ ((aligned (16))) float s_win[NB * RING];
+  /* the epilogue's exchange buffers alias the ring (it is dead after the last barrier of the main loop): with
+   * NT = 1 the workgroup then needs 41.5 KB, so that three of them fit beside each other on a CU */
+  float (*s_u)[64 * NT] = reinterpret_cast<float (*)[64 * NT]> (s_win);
+  float (*s_d)[64 * NT] = reinterpret_cast<float (*)[64 * NT]> (s_win + 6 * 64 * NT);
+  int   *s_n = reinterpret_cast<int *> (s_win + 12 * 64 * NT);
+  const int lane = threadIdx.x;
+  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const long long plane = blockIdx.y;
+  const long long n_tiles = (a.n_lanes + 64 * NT - 1) / (64 * NT);
+  const long long per_xcd = (n_tiles + 7) / 8;
+  const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
+    return;                                               // uniform for the workgroup
+  const long long sf0 = tile * 64 * NT;
+  const float *db = a.db + plane * a.plane_stride;
+  const long long ld = a.band_stride;
+  const int R = a.table.rows_per_bit;
+  const_int_ptr tab = (const_int_ptr) (a.table.packed + (size_t) bit * R * 64);
+
+  auto load_half = [&] (int h) {
+    const long long base = sf0 + 64LL * h;
+    float *dst = s_win + 64 * (h % (NT + 1));
+    const bool in_range = base + 64 <= ld;
+    for (int idx = tid; idx < NB * 16; idx += 384)
+      {
+        const int band = idx >> 4, q = idx & 15;
+        float4 v = make_float4 (0.f, 0.f, 0.f, 0.f);
+        if (in_range)
+          v = *reinterpret_cast<const float4 *> (db + band * ld + base + 4 * q);
+        *reinterpret_cast<float4 *> (dst + band * RING + 4 * q) = v;
+      }
+  };
+
+  float umag[NT], dmag[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+    umag[t] = dmag[t] = 0.f;
+  int n = 0, r = 0;
+  unsigned long long d_load = 0, d_bar1 = 0, d_rows = 0, d_bar2 = 0;
+  for (int h = 0; h < NT; h++)
+    load_half (h);
+  for (int k = 0; 64 * k < total_frames; k++)
+    {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+      load_half (k + NT);
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      const int ring0 = 64 * (k % (NT + 1));
+      while (r < R)
+        {
+          const_int_ptr tr = tab + r * 64;
+          const int fr = tr[60];
+          if (fr >= 64 * (k + 1))
+            break;
+          const int x = fr - 64 * k + lane + ring0;          // < 2 * RING
+#pragma unroll
+          for (int t = 0; t < NT; t++)
+            {
+              int phys = x + 64 * t;
+              phys -= phys >= RING ? RING : 0;
+              phys -= phys >= RING ? RING : 0;
+              float uv[30], dv[30];
+#pragma unroll
+              for (int i = 0; i < 30; i++)
+                {
+                  uv[i] = s_win[tr[i] * RING + phys];
+                  dv[i] = s_win[tr[30 + i] * RING + phys];
+                }
+#pragma unroll
+              for (int i = 0; i < 30; i++)
+                {
+                  umag[t] = __fadd_rn (umag[t], uv[i]);
+                  dmag[t] = __fadd_rn (dmag[t], dv[i]);
+                }
+            }
+          n++;
+          r++;
+        }
+      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+      __syncthreads();
+      const unsigned long long t4 = __builtin_amdgcn_s_memtime();
+      d_load += t1 - t0; d_bar1 += t2 - t1; d_rows += t3 - t2; d_bar2 += t4 - t3;
+    }
+  if (lane == 0)
+    {
+      atomicAdd (&g_scan_dbg[0], d_load); atomicAdd (&g_scan_dbg[1], d_bar1); atomicAdd (&g_scan_dbg[2], d_rows);
+      atomicAdd (&g_scan_dbg[3], d_bar2); atomicAdd (&g_scan_dbg[4], (unsigned long long) n); atomicAdd (&g_scan_dbg[5], 1ull);
+    }
+#pragma unroll
+  for (int t = 0; t < NT; t++)
+    {
+      s_u[bit][64 * t + lane] = umag[t];
+      s_d[bit][64 * t + lane] = dmag[t];
+    }
+  if (lane == 0)
+    s_n[bit] = n;
+  __syncthreads();
+  for (int c = tid; c < 64 * NT; c += 384)
+    {
+      const long long cand = sf0 + c;
+      if (cand >= a.n_lanes)
+        continue;
+      double q = 0;
+      int total = 0;
+      for (int b = 0; b < 6; b++)
+        {
+          const float um = s_u[b][c], dm = s_d[b][c];
+          float raw;
+          if (um == 0 || dm == 0)
+            raw = 0;
+          else if (um < dm)
+            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
+          else
+            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
+          const double rb = (b & 1) ? double (raw) : -double (raw);
+          q += rb * s_n[b];
+          total += s_n[b];
+        }
+      if (total)
+        q /= total;
+      q = q / a.min_delta / 2.9;
+      a.quality[plane * a.q_stride + cand] = q;
+    }
+}
+
+/* K5p: K5w with the two latencies of its step loop taken off the critical path.
+ *  - the table: a row is 16 dwords (60 band bytes + its frame) and four rows arrive with ONE vector load (lane l holds
+ *    dword l of the group), always two groups ahead of their use; v_readlane turns them into the scalars the LDS
+ *    addresses are built from.  K5w paid two dependent scalar-cache round trips per row (130 KB table, 16 KB cache);
+ *  - the ring: the global loads of half k + 2 are issued before the rows of step k are processed and written to LDS
+ *    after them, so that HBM latency overlaps the gathers instead of sitting between two barriers.
+ * Accumulation order is unchanged (reference syncfinder.cc:129-145). */
+__global__ void __launch_bounds__ (384)
+sync_scan_pipe_kernel (SyncScanArgs a, int total_frames)
+{
+  constexpr int RING = 128;
+  __shared__ __attribute__ ((aligned (16))) float s_win[NB * RING];
+  float (*s_u)[64] = reinterpret_cast<float (*)[64]> (s_win);           // epilogue buffers alias the dead ring
+  float (*s_d)[64] = reinterpret_cast<float (*)[64]> (s_win + 6 * 64);
+  int   *s_n = reinterpret_cast<int *> (s_win + 12 * 64);
   const int lane = threadIdx.x;
   const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
   const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -1083,94 +1434,119 @@ sync_scan_window_kernel (SyncScanArgs a, int total_frames)
   if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
     return;                                               // uniform for the workgroup
   const long long sf0 = tile * 64;
-  const long long cand = sf0 + lane;
-  const bool active = cand < a.n_lanes;
   const float *db = a.db + plane * a.plane_stride;
   const long long ld = a.band_stride;
-  const char *have = a.have ? a.have + plane * a.have_plane_stride + (active ? cand : 0) : nullptr;
-  const int R = a.table.rows_per_bit;
+  const unsigned *tab = a.table.packed16 + (size_t) bit * a.table.rows16_per_bit * 16;
 
-  const_int_ptr tab = (const_int_ptr) (a.table.packed + (size_t) bit * R * 64);
-
-  auto load_half = [&] (int h) {
+  float4 stage[4];
+  auto fetch_half = [&] (int h) {
     const long long base = sf0 + 64LL * h;
-    float *dst = s_win + 64 * (h & 1);
     const bool in_range = base + 64 <= ld;
-    for (int idx = tid; idx < NB * 16; idx += 384)
+#pragma unroll
+    for (int j = 0; j < 4; j++)
       {
+        const int idx = tid + 384 * j;
         const int band = idx >> 4, q = idx & 15;
-        float4 v = make_float4 (0.f, 0.f, 0.f, 0.f);
-        if (in_range)
-          v = *reinterpret_cast<const float4 *> (db + band * ld + base + 4 * q);
-        *reinterpret_cast<float4 *> (dst + band * SCAN_RING + 4 * q) = v;
+        stage[j] = make_float4 (0.f, 0.f, 0.f, 0.f);
+        if (in_range && idx < NB * 16)
+          stage[j] = *reinterpret_cast<const float4 *> (db + band * ld + base + 4 * q);
+      }
+  };
+  auto store_half = [&] (int h) {
+    float *dst = s_win + 64 * (h & 1);
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      {
+        const int idx = tid + 384 * j;
+        const int band = idx >> 4, q = idx & 15;
+        if (idx < NB * 16)
+          *reinterpret_cast<float4 *> (dst + band * RING + 4 * q) = stage[j];
       }
   };
 
+  unsigned g_cur = tab[lane], g_nxt = tab[64 + lane];
   float umag = 0.f, dmag = 0.f;
   int n = 0, r = 0;
-  load_half (0);
+  fetch_half (0);
+  store_half (0);
+  fetch_half (1);
   for (int k = 0; 64 * k < total_frames; k++)
     {
-      load_half (k + 1);
+      store_half (k + 1);
       __syncthreads();
-      const int ring0 = 64 * (k & 1);
-      while (r < R)
+      fetch_half (k + 2);
+      while (true)
         {
-          const_int_ptr tr = tab + r * 64;
-          const int fr = tr[60];
+          const int q16 = (r & 3) * 16;
+          const unsigned w15 = __builtin_amdgcn_readlane (g_cur, q16 + 15);
+          const int fr = w15 & 0xffff;
           if (fr >= 64 * (k + 1))
             break;
-          const int phys = (fr - 64 * k + lane + ring0) & (SCAN_RING - 1);
-          const bool present = have ? have[fr] != 0 : true;
+          const int x = (fr + lane) & (RING - 1);            // frame f lives at ring position f % 128
+          unsigned w[15];
+#pragma unroll
+          for (int i = 0; i < 15; i++)
+            w[i] = __builtin_amdgcn_readlane (g_cur, q16 + i);
           float uv[30], dv[30];
 #pragma unroll
           for (int i = 0; i < 30; i++)
             {
-              uv[i] = s_win[tr[i] * SCAN_RING + phys];
-              dv[i] = s_win[tr[30 + i] * SCAN_RING + phys];
+              const unsigned ub = (w[i >> 2] >> (8 * (i & 3))) & 0xff;
+              const unsigned dbnd = (w[(30 + i) >> 2] >> (8 * ((30 + i) & 3))) & 0xff;
+              uv[i] = s_win[ub * RING + x];
+              dv[i] = s_win[dbnd * RING + x];
             }
-          if (present)
-            {
 #pragma unroll
-              for (int i = 0; i < 30; i++)
-                {
-                  umag = __fadd_rn (umag, uv[i]);
-                  dmag = __fadd_rn (dmag, dv[i]);
-                }
-              n++;
+          for (int i = 0; i < 30; i++)
+            {
+              umag = __fadd_rn (umag, uv[i]);
+              dmag = __fadd_rn (dmag, dv[i]);
             }
+          n++;
           r++;
+          if ((r & 3) == 0)
+            {
+              g_cur = g_nxt;
+              g_nxt = tab[(r / 4 + 1) * 64 + lane];
+            }
         }
       __syncthreads();
     }
   s_u[bit][lane] = umag;
   s_d[bit][lane] = dmag;
-  s_n[bit][lane] = n;
+  if (lane == 0)
+    s_n[bit] = n;
   __syncthreads();
-  if (bit == 0 && active)
+  if (bit == 0)
     {
-      double q = 0;
-      int total = 0;
-      for (int b = 0; b < 6; b++)
+      const long long cand = sf0 + lane;
+      if (cand < a.n_lanes)
         {
-          const float um = s_u[b][lane], dm = s_d[b][lane];
-          float raw;
-          if (um == 0 || dm == 0)
-            raw = 0;
-          else if (um < dm)
-            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
-          else
-            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
-          const double rb = (b & 1) ? double (raw) : -double (raw);
-          q += rb * s_n[b][lane];
-          total += s_n[b][lane];
+          double q = 0;
+          int total = 0;
+          for (int b = 0; b < 6; b++)
+            {
+              const float um = s_u[b][lane], dm = s_d[b][lane];
+              float raw;
+              if (um == 0 || dm == 0)
+                raw = 0;
+              else if (um < dm)
+                raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
+              else
+                raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
+              const double rb = (b & 1) ? double (raw) : -double (raw);
+              q += rb * s_n[b];
+              total += s_n[b];
+            }
+          if (total)
+            q /= total;
+          q = q / a.min_delta / 2.9;
+          a.quality[plane * a.q_stride + cand] = q;
         }
-      if (total)
-        q /= total;
-      q = q / a.min_delta / 2.9;
-      a.quality[plane * a.q_stride + cand] = q;
     }
 }
+
+hipError_t launch_sync_scan (hipStream_t st, const SyncScanArgs& a);
 
 hipError_t
 launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames)
@@ -1179,9 +1555,36 @@ launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames
     return hipSuccess;
   if (a.row_stride != 1 || a.n_planes > 65535 || (a.band_stride & 63) || a.lane_count)
     return hipErrorInvalidValue;
-  const long long per_xcd = ((a.n_lanes + 63) / 64 + 7) / 8;
+  if (a.have)
+    return launch_sync_scan (st, a);                      // skipped (silent) frames: the generic kernel handles `have`
+  static const int nt = getenv ("AWM_SCAN_TILES") ? atoi (getenv ("AWM_SCAN_TILES")) : 0;
+  if (getenv ("AWM_SCAN_DEBUG"))
+    {
+      unsigned long long z[8] = {0}, o[8];
+      hipMemcpyToSymbol (HIP_SYMBOL (g_scan_dbg), z, sizeof (z));
+      const long long px = ((a.n_lanes + 63) / 64 + 7) / 8;
+      hipLaunchKernelGGL (sync_scan_dbg_kernel<1>, dim3 ((unsigned) (px * 8), (unsigned) a.n_planes), dim3 (64, 6), 0, st, a, total_frames);
+      hipStreamSynchronize (st);
+      hipMemcpyFromSymbol (o, HIP_SYMBOL (g_scan_dbg), sizeof (o));
+      fprintf (stderr, "scan dbg: waves %llu rows/wave %.1f  cycles per wave: load %.0f bar1 %.0f rows %.0f bar2 %.0f  (per row %.0f)\n", o[5], double (o[4]) / o[5],
+               double (o[0]) / o[5], double (o[1]) / o[5], double (o[2]) / o[5], double (o[3]) / o[5], double (o[2]) / o[4]);
+      return hipGetLastError();
+    }
+  if (nt == 0 && a.table.packed16)
+    {
+      const long long px = ((a.n_lanes + 63) / 64 + 7) / 8;
+      hipLaunchKernelGGL (sync_scan_pipe_kernel, dim3 ((unsigned) (px * 8), (unsigned) a.n_planes), dim3 (64, 6), 0, st, a, total_frames);
+      return hipGetLastError();
+    }
+  const int cands = 64 * (nt == 3 ? 3 : (nt == 1 ? 1 : 2));
+  const long long per_xcd = ((a.n_lanes + cands - 1) / cands + 7) / 8;
   const dim3 grid ((unsigned) (per_xcd * 8), (unsigned) a.n_planes);
-  hipLaunchKernelGGL (sync_scan_window_kernel, grid, dim3 (64, 6), 0, st, a, total_frames);
+  if (nt == 1)
+    hipLaunchKernelGGL (sync_scan_window_kernel<1>, grid, dim3 (64, 6), 0, st, a, total_frames);
+  else if (nt == 3)
+    hipLaunchKernelGGL (sync_scan_window_kernel<3>, grid, dim3 (64, 6), 0, st, a, total_frames);
+  else
+    hipLaunchKernelGGL (sync_scan_window_kernel<2>, grid, dim3 (64, 6), 0, st, a, total_frames);
   return hipGetLastError();
 }
 
@@ -1393,6 +1796,102 @@ launch_peak_select (hipStream_t st, const double *raw, const double *mean, long 
   if (e != hipSuccess || n <= 0)
     return e;
   hipLaunchKernelGGL (peak_select_kernel, dim3 (unsigned ((n + 255) / 256)), dim3 (256), 0, st, raw, mean, n, threshold, count, out, cap);
+  return hipGetLastError();
+}
+
+/* K5d: the K largest |raw - mean| of an (unordered) peak list, per slice of the list.  Workgroup g owns slice g of
+ * gridDim.x and writes its K best entries (order: quality descending, position ascending) to out[g * K ...];
+ * unused slots get p = -1.  The global top K is a subset of the union, which the host merges (a few KB instead
+ * of the whole list: the n_best fallback of syncfinder.cc:364-383 on unmarked or short material). */
+__global__ void __launch_bounds__ (256)
+peak_topk_kernel (const PeakOut *in, const unsigned int *count_ptr, unsigned int cap, PeakOut *out, int K)
+{
+  __shared__ double    s_q[256];
+  __shared__ long long s_p[256];
+  __shared__ long long s_i[256];
+  const unsigned int count = *count_ptr < cap ? *count_ptr : cap;
+  const long long lo = (long long) count * blockIdx.x / gridDim.x;
+  const long long hi = (long long) count * (blockIdx.x + 1) / gridDim.x;
+  double last_q = 0;
+  long long last_p = -1;
+  bool have_last = false;
+  for (int it = 0; it < K; it++)
+    {
+      double best_q = -1;
+      long long best_p = 0, best_i = -1;
+      for (long long i = lo + threadIdx.x; i < hi; i += 256)
+        {
+          const double q = fabs (in[i].raw - in[i].mean);
+          const long long p = in[i].p;
+          if (have_last && !(q < last_q || (q == last_q && p > last_p)))
+            continue;                                   // already taken (or NaN: never selected)
+          if (best_i < 0 || q > best_q || (q == best_q && p < best_p))
+            {
+              best_q = q;
+              best_p = p;
+              best_i = i;
+            }
+        }
+      s_q[threadIdx.x] = best_q;
+      s_p[threadIdx.x] = best_p;
+      s_i[threadIdx.x] = best_i;
+      __syncthreads();
+      for (int step = 128; step > 0; step >>= 1)
+        {
+          if (threadIdx.x < step)
+            {
+              const int o = threadIdx.x + step;
+              const bool take = s_i[o] >= 0 && (s_i[threadIdx.x] < 0 || s_q[o] > s_q[threadIdx.x]
+                                                || (s_q[o] == s_q[threadIdx.x] && s_p[o] < s_p[threadIdx.x]));
+              if (take)
+                {
+                  s_q[threadIdx.x] = s_q[o];
+                  s_p[threadIdx.x] = s_p[o];
+                  s_i[threadIdx.x] = s_i[o];
+                }
+            }
+          __syncthreads();
+        }
+      const long long sel = s_i[0];
+      if (sel >= 0)
+        {
+          last_q = s_q[0];
+          last_p = s_p[0];
+          have_last = true;
+        }
+      if (threadIdx.x == 0)
+        {
+          PeakOut o;
+          if (sel >= 0)
+            o = in[sel];
+          else
+            {
+              o.p = -1;
+              o.raw = o.mean = 0;
+            }
+          out[(long long) blockIdx.x * K + it] = o;
+        }
+      __syncthreads();
+      if (sel < 0)
+        {
+          for (int rest = it + 1 + threadIdx.x; rest < K; rest += 256)
+            {
+              PeakOut o;
+              o.p = -1;
+              o.raw = o.mean = 0;
+              out[(long long) blockIdx.x * K + rest] = o;
+            }
+          break;
+        }
+    }
+}
+
+hipError_t
+launch_peak_topk (hipStream_t st, const PeakOut *in, const unsigned int *count, unsigned int cap, PeakOut *out, int k, int n_slices)
+{
+  if (k <= 0 || n_slices <= 0)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL (peak_topk_kernel, dim3 (n_slices), dim3 (256), 0, st, in, count, cap, out, k);
   return hipGetLastError();
 }
 

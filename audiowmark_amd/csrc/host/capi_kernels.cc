@@ -188,9 +188,12 @@ awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels, si
                  const float *block_max_d, size_t first_block, size_t n_blocks)
 {
   if (int rc = check_ctx (ctx)) return rc;
+  const size_t tab_entries = awmk::limiter_tab_entries ((long long) n_frames, (long long) first_sample, LIMITER_BLOCK);
+  if (int rc = ctx->ws_limit_tab.reserve ((tab_entries + 1) * sizeof (float2))) return rc;
   ProfScope ps (ctx, PROF_LIMITER, double (n_frames) * n_channels * 8.0);
   AWM_HIP_CHECK (awmk::launch_limiter (ctx->stream, out_d, (long long) n_frames, n_channels, (long long) first_sample, block_max_d,
-                                       (long long) first_block, (long long) n_blocks, LIMITER_BLOCK, LIMITER_CEILING));
+                                       (long long) first_block, (long long) n_blocks, LIMITER_BLOCK, LIMITER_CEILING,
+                                       ctx->ws_limit_tab.as<float2>(), tab_entries));
   return 0;
 }
 

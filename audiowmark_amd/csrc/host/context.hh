@@ -35,6 +35,8 @@ struct KeyTables
   {
     SyncTable host;
     DevBuffer packed_approx;       // [6][rows][64] row = frame
+    DevBuffer packed16_approx;     // [6][rows16][16] byte packed rows for K5p (kernels.hh SyncTableDev)
+    int       rows16 = 0;
     DevBuffer packed_refine;       // [6][rows][64] row = position in the want list
     std::vector<int> want_list;    // sorted sync frames (510 or 1020)
     DevBuffer want_list_dev;
@@ -73,7 +75,7 @@ struct awm_ctx
 
   // workspaces
   awm::DevBuffer ws_db, ws_have, ws_q, ws_raw, ws_mean, ws_misc, ws_refine, ws_refine_have, ws_soft,
-                 ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx;
+                 ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx, ws_limit_tab;
 
   // profiling
   bool   prof_enabled = false;

@@ -119,6 +119,8 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   sa.q_stride = q_stride;
   sa.table.packed = kt->sync[clip].packed_approx.as<int>();
   sa.table.rows_per_bit = kt->sync[clip].host.rows_per_bit;
+  sa.table.packed16 = kt->sync[clip].packed16_approx.as<unsigned>();
+  sa.table.rows16_per_bit = kt->sync[clip].rows16;
   {
     // algorithmic HBM bytes of the scan: the dB matrix once, candidates re-read it from cache
     ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0);
@@ -178,6 +180,38 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
   if (int rc = m_ctx->ws_refine.reserve (size_t (big_cap) * sizeof (awmk::PeakOut))) return rc;
   auto *d_all = m_ctx->ws_refine.as<awmk::PeakOut>();
   AWM_HIP_CHECK (awmk::launch_peak_select (st, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>(), n_scores, -1.0, d_count, d_all, big_cap));
+  // Only the n_best largest survive select_threshold_and_n_best here (fewer than n_best are above the threshold), so
+  // reduce the list on the device: n_best + 1 per slice, so that a tie across the cut is visible -- in that case
+  // (degenerate input) the complete list goes through the same std::sort as in the reference instead.
+  const int k = Params::get_n_best + 1;
+  constexpr int n_slices = 64;
+  const bool fewer_than_n_best = int (count) < Params::get_n_best;      // (not: more than `cap` above the threshold)
+  if (fewer_than_n_best && k <= 64 && !getenv ("AWM_NBEST_HOST"))
+    {
+      auto *d_top = reinterpret_cast<awmk::PeakOut *> (m_ctx->ws_misc.as<char>() + 256);      // the threshold list is dead
+      static_assert (sizeof (awmk::PeakOut) * 64 * n_slices <= 16384 * sizeof (awmk::PeakOut), "ws_misc too small");
+      AWM_HIP_CHECK (awmk::launch_peak_topk (st, d_all, d_count, big_cap, d_top, k, n_slices));
+      std::vector<awmk::PeakOut> top (size_t (k) * n_slices);
+      AWM_HIP_CHECK (hipMemcpyAsync (top.data(), d_top, top.size() * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      top.erase (std::remove_if (top.begin(), top.end(), [] (const awmk::PeakOut& pk) { return pk.p < 0; }), top.end());
+      auto absq = [] (const awmk::PeakOut& pk) { return std::fabs (pk.raw - pk.mean); };
+      std::sort (top.begin(), top.end(), [&] (const awmk::PeakOut& a, const awmk::PeakOut& b) {
+        return absq (a) != absq (b) ? absq (a) > absq (b) : a.p < b.p;
+      });
+      const size_t nb = size_t (Params::get_n_best);
+      const bool tie_at_cut = top.size() > nb && absq (top[nb - 1]) == absq (top[nb]);
+      if (!tie_at_cut)
+        {
+          if (top.size() > nb)
+            top.resize (nb);
+          std::sort (top.begin(), top.end(), [] (const awmk::PeakOut& a, const awmk::PeakOut& b) { return a.p < b.p; });
+          for (const auto& pk : top)
+            out.push_back ({ size_t (pk.p >> 2) * Params::frame_size + size_t (pk.p & 3) * Params::sync_search_step, pk.raw, pk.mean });
+          select_threshold_and_n_best (out, threshold);
+          return 0;
+        }
+    }
   AWM_HIP_CHECK (hipMemcpyAsync (&count, d_count, sizeof (count), hipMemcpyDeviceToHost, st));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
   if (count > big_cap)
