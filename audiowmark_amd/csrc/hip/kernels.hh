@@ -72,6 +72,11 @@ struct SyncDbArgs
   long long    have_stream_stride;
   long long    first, last;             // non-silent value range [first, last) (syncfinder.cc:155-169)
   int          tile_frames;             // frames per workgroup tile (<= 72)
+  // K4s only, "gathered" output for the refinement scan (K5g): stream s = plane * rows_per_plane + w writes its
+  // rows to stream slot plane * rows_per_plane + row_perm[w], and band b to row band_pos[w * 81 + b] (255: dropped)
+  const int           *row_perm = nullptr;
+  const unsigned char *band_pos = nullptr;
+  int                  rows_per_plane = 0;
 };
 hipError_t launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a);
 /* K4s: same output as K4 for streams whose frames advance by 8 samples (search_refine): instead of one FFT per fine
@@ -88,10 +93,6 @@ struct SyncTableDev
   // (frame for the approximate search, want-list position for the refinement); wave-uniform -> scalar loads
   const int *packed;
   int        rows_per_bit;
-  // approximate search only: [6][rows16][16] uint32, dwords 0..14 = the 60 band bytes (up 0..29, down 0..29),
-  // dword 15 = frame; rows past rows_per_bit carry frame 0xffff (rows16 = multiple of 4, >= rows_per_bit + 9)
-  const unsigned *packed16;
-  int        rows16_per_bit;
 };
 struct SyncScanArgs
 {
@@ -112,6 +113,25 @@ hipError_t launch_sync_scan (hipStream_t st, const SyncScanArgs& a);
 /* K5w: same result for band-major planes (row_stride == 1, band_stride % 64 == 0): dB matrix streamed through an LDS ring.
  * total_frames = frames a candidate spans (2226 BLOCK / 4452 CLIP). */
 hipError_t launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames);
+
+/* K5g: sync_decode over the gathered layout K4s writes for the refinement: plane (candidate) p holds
+ * [6 bits][rows_per_bit][60 values: up 0..29, down 0..29][ld fine offsets] -- exactly the order the sums consume them,
+ * so the scan is a sequential stream without any table.  have: [plane][6 * rows_per_bit][ld] or nullptr. */
+struct GatheredScanArgs
+{
+  const float *db;
+  const char  *have;
+  long long    plane_stride, have_plane_stride;
+  int          ld;
+  int          rows_per_bit;
+  int          n_lanes;         // fine offsets (<= 128)
+  const int   *lane_count;      // per plane
+  long long    n_planes;
+  double       min_delta;
+  double      *quality;         // [plane][q_stride]
+  long long    q_stride;
+};
+hipError_t launch_sync_scan_gathered (hipStream_t st, const GatheredScanArgs& a);
 
 /* K5b: local mean over the index-sorted scores (syncfinder.cc:234-254); q is [4][q_stride] by shift,
  * sorted position p = 4 * start_frame + shift.  Writes raw[p], mean[p]. */

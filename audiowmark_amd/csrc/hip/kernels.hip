@@ -619,23 +619,34 @@ limiter_apply_kernel (float4 *data, long long n_vec, long long first_sample, con
     const float2 t = next ? t1 : t0;
     return __fadd_rn (t.x, __fmul_rn (float (next ? i - BS : i), t.y));
   };
+  constexpr int U = LIMITER_RUN / 256;
+  float4 v[U];
 #pragma unroll
-  for (int j = 0; j < LIMITER_RUN / 256; j++)
+  for (int j = 0; j < U; j++)                   // all loads first: the stores below must not serialise them
+    {
+      const long long q = base + threadIdx.x + 256 * j;
+      v[j] = q < n_vec ? data[q] : make_float4 (0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+  for (int j = 0; j < U; j++)
     {
       const int r = threadIdx.x + 256 * j;
-      const long long q = base + r;
-      if (q >= n_vec)
-        break;
-      float4 v = data[q];
       const int i = i0 + r * FPV;
       if (C == 2)
         {
           const float s0 = scale (i), s1 = scale (i + 1);
-          v = make_float4 (__fmul_rn (v.x, s0), __fmul_rn (v.y, s0), __fmul_rn (v.z, s1), __fmul_rn (v.w, s1));
+          v[j] = make_float4 (__fmul_rn (v[j].x, s0), __fmul_rn (v[j].y, s0), __fmul_rn (v[j].z, s1), __fmul_rn (v[j].w, s1));
         }
       else
-        v = make_float4 (__fmul_rn (v.x, scale (i)), __fmul_rn (v.y, scale (i + 1)), __fmul_rn (v.z, scale (i + 2)), __fmul_rn (v.w, scale (i + 3)));
-      data[q] = v;
+        v[j] = make_float4 (__fmul_rn (v[j].x, scale (i)), __fmul_rn (v[j].y, scale (i + 1)), __fmul_rn (v[j].z, scale (i + 2)),
+                            __fmul_rn (v[j].w, scale (i + 3)));
+    }
+#pragma unroll
+  for (int j = 0; j < U; j++)
+    {
+      const long long q = base + threadIdx.x + 256 * j;
+      if (q < n_vec)
+        data[q] = v[j];
     }
 }
 
@@ -889,14 +900,24 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
   __shared__ float2 s_tw[512];
   __shared__ __attribute__ ((aligned (16))) float s_scratch[WAVES][NB * SL_TILE];      // FFT exchange tile (>= 576 float2) / dB tile [offset][band]
   static_assert (NB * SL_TILE * sizeof (float) >= XBUF_ELEMS * sizeof (float2), "scratch too small for the FFT tile");
+  __shared__ unsigned char s_pos[WAVES][NB + 3];
   for (int i = threadIdx.x; i < 512; i += blockDim.x)
     s_tw[i] = t.tw512[i];
+  {
+    // gathered output (refinement): which row of its 60 the stream's band b goes to; identity otherwise
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long long s = (long long) blockIdx.x * WAVES + w;
+    for (int b = l; b < NB; b += 64)
+      s_pos[w][b] = (a.band_pos && s < a.n_streams) ? a.band_pos[(s % a.rows_per_plane) * NB + b] : (unsigned char) b;
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long stream = (long long) blockIdx.x * WAVES + wave;
   if (stream >= a.n_streams)
     return;
+  // where this stream's rows go
+  const long long out_slot = a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane + a.row_perm[stream % a.rows_per_plane] : stream;
   const long long base = a.stream_base ? a.stream_base[stream] : a.base0 + stream * a.base_stride;
   const int count = a.stream_count ? a.stream_count[stream] : a.count0;
   if (count <= 0)
@@ -1003,12 +1024,13 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
         {
           wave_sync();
           const int t0 = step - col, n_cols = col + 1;
-          float *out = a.out + stream * a.out_stream_stride + t0;
+          float *out = a.out + out_slot * a.out_stream_stride + t0;
           for (int i = lane; i < NB * SL_TILE; i += 64)
             {
               const int band = i / SL_TILE, cc = i % SL_TILE;
-              if (cc < n_cols)
-                out[band * a.ld + cc] = tile[cc * NB + band];
+              const int row = s_pos[wave][band];
+              if (cc < n_cols && row != 255)
+                out[row * a.ld + cc] = tile[cc * NB + band];
             }
           wave_sync();
         }
@@ -1046,9 +1068,9 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
         }
     }
   if (a.have && lane < count)
-    a.have[stream * a.have_stream_stride + lane] = (have_mask >> lane) & 1;
+    a.have[out_slot * a.have_stream_stride + lane] = (have_mask >> lane) & 1;
   if (a.have && lane == 0 && count > 64)
-    a.have[stream * a.have_stream_stride + 64] = have_64;
+    a.have[out_slot * a.have_stream_stride + 64] = have_64;
 }
 
 hipError_t
@@ -1083,6 +1105,8 @@ sync_scan_kernel (SyncScanArgs a)
   const long long per_xcd = (n_tiles + 7) / 8;
   const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   const bool tile_ok = (blockIdx.x >> 3) < per_xcd && tile < n_tiles;
+  if (!tile_ok)
+    return;                                               // uniform for the workgroup (grid is padded to 8 per XCD round)
   const long long cand = tile * 64 + lane;
   const long long n_valid = a.lane_count ? a.lane_count[plane] : a.n_lanes;
   const bool active = tile_ok && cand < n_valid;
@@ -1149,43 +1173,42 @@ sync_scan_kernel (SyncScanArgs a)
 }
 
 /* K5w: the same computation for the approximate search, where the planes are band-major dB matrices
- * (row_stride == 1): every candidate of a 64-candidate tile walks frames tile .. tile + 2226 (+ 64), and so do its
- * five sibling waves (one per sync bit).  The workgroup therefore streams the 81-band matrix through a 2 x 64 frame
- * ring in LDS exactly once (coalesced 256 B rows), and all 30 600 gathers per candidate are served from LDS
- * instead of the L2 -- 16x less L2 traffic than K5 while keeping every accumulation in the reference's order. */
-/* NT = candidate tiles (of 64) per workgroup.  All tiles share the ring (NT + 1 halves of 64 frames) and the row
- * table reads; every wave keeps NT independent accumulator pairs, which gives the LDS pipeline NT times more work per
- * dependent row step (the kernel is latency bound: table -> address -> LDS -> 30 dependent adds). */
-template<int NT> __global__ void __launch_bounds__ (384)
+ * (row_stride == 1): every candidate of a 64-candidate tile walks frames tile .. tile + 2226 (+ 64), and so do its five
+ * sibling waves (one per sync bit).  A workgroup owns two adjacent tiles (12 waves: tile x sync bit) and streams the
+ * 81-band matrix through a ring of 3 x 64 frames in LDS exactly once (coalesced 256 B rows): tile 1 needs at step k
+ * what tile 0 needs at step k + 1, so one extra slot serves both.  All 30 600 gathers per candidate are served from LDS
+ * instead of the L2, every accumulation stays in the reference's order.  Measured (60 min stereo, MI355X): one tile per
+ * workgroup (6 waves, 41 KB, 18 waves/CU) 3.2 ms, two tiles (62 KB, 24 waves/CU) 2.1 ms -- the kernel is bound by
+ * the number of waves that keep LDS reads in flight, not by LDS bandwidth (38 %) or VALU (33 %). */
+__global__ void __launch_bounds__ (768)
 sync_scan_window_kernel (SyncScanArgs a, int total_frames)
 {
-  constexpr int RING = 64 * (NT + 1);
+  constexpr int RING = 192;
   __shared__ __attribute__ ((aligned (16))) float s_win[NB * RING];
-  /* the epilogue's exchange buffers alias the ring (it is dead after the last barrier of the main loop): with
-   * NT = 1 the workgroup then needs 41.5 KB, so that three of them fit beside each other on a CU */
-  float (*s_u)[64 * NT] = reinterpret_cast<float (*)[64 * NT]> (s_win);
-  float (*s_d)[64 * NT] = reinterpret_cast<float (*)[64 * NT]> (s_win + 6 * 64 * NT);
-  int   *s_n = reinterpret_cast<int *> (s_win + 12 * 64 * NT);
+  float (*s_u)[64] = reinterpret_cast<float (*)[64]> (s_win);           // [12][64], alias the dead ring
+  float (*s_d)[64] = reinterpret_cast<float (*)[64]> (s_win + 12 * 64);
+  int   *s_n = reinterpret_cast<int *> (s_win + 24 * 64);
   const int lane = threadIdx.x;
-  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
+  const int wv = __builtin_amdgcn_readfirstlane (threadIdx.y);
+  const int bit = wv % 6, sub = wv / 6;
   const int tid = threadIdx.y * 64 + threadIdx.x;
   const long long plane = blockIdx.y;
-  const long long n_tiles = (a.n_lanes + 64 * NT - 1) / (64 * NT);
+  const long long n_tiles = (a.n_lanes + 127) / 128;
   const long long per_xcd = (n_tiles + 7) / 8;
   const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
   if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
     return;                                               // uniform for the workgroup
-  const long long sf0 = tile * 64 * NT;
+  const long long sf0 = tile * 128;
   const float *db = a.db + plane * a.plane_stride;
   const long long ld = a.band_stride;
   const int R = a.table.rows_per_bit;
   const_int_ptr tab = (const_int_ptr) (a.table.packed + (size_t) bit * R * 64);
 
-  auto load_half = [&] (int h) {
+  auto load_slot = [&] (int h) {
     const long long base = sf0 + 64LL * h;
-    float *dst = s_win + 64 * (h % (NT + 1));
+    float *dst = s_win + 64 * (h % 3);
     const bool in_range = base + 64 <= ld;
-    for (int idx = tid; idx < NB * 16; idx += 384)
+    for (int idx = tid; idx < NB * 16; idx += 768)
       {
         const int band = idx >> 4, q = idx & 15;
         float4 v = make_float4 (0.f, 0.f, 0.f, 0.f);
@@ -1195,306 +1218,29 @@ sync_scan_window_kernel (SyncScanArgs a, int total_frames)
       }
   };
 
-  float umag[NT], dmag[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++)
-    umag[t] = dmag[t] = 0.f;
-  int n = 0, r = 0;
-  for (int h = 0; h < NT; h++)
-    load_half (h);
-  for (int k = 0; 64 * k < total_frames; k++)
-    {
-      load_half (k + NT);
-      __syncthreads();
-      const int ring0 = 64 * (k % (NT + 1));
-      while (r < R)
-        {
-          const_int_ptr tr = tab + r * 64;
-          const int fr = tr[60];
-          if (fr >= 64 * (k + 1))
-            break;
-          const int x = fr - 64 * k + lane + ring0;          // < 2 * RING
-#pragma unroll
-          for (int t = 0; t < NT; t++)
-            {
-              int phys = x + 64 * t;
-              phys -= phys >= RING ? RING : 0;
-              phys -= phys >= RING ? RING : 0;
-              float uv[30], dv[30];
-#pragma unroll
-              for (int i = 0; i < 30; i++)
-                {
-                  uv[i] = s_win[tr[i] * RING + phys];
-                  dv[i] = s_win[tr[30 + i] * RING + phys];
-                }
-#pragma unroll
-              for (int i = 0; i < 30; i++)
-                {
-                  umag[t] = __fadd_rn (umag[t], uv[i]);
-                  dmag[t] = __fadd_rn (dmag[t], dv[i]);
-                }
-            }
-          n++;
-          r++;
-        }
-      __syncthreads();
-    }
-#pragma unroll
-  for (int t = 0; t < NT; t++)
-    {
-      s_u[bit][64 * t + lane] = umag[t];
-      s_d[bit][64 * t + lane] = dmag[t];
-    }
-  if (lane == 0)
-    s_n[bit] = n;
-  __syncthreads();
-  for (int c = tid; c < 64 * NT; c += 384)
-    {
-      const long long cand = sf0 + c;
-      if (cand >= a.n_lanes)
-        continue;
-      double q = 0;
-      int total = 0;
-      for (int b = 0; b < 6; b++)
-        {
-          const float um = s_u[b][c], dm = s_d[b][c];
-          float raw;
-          if (um == 0 || dm == 0)
-            raw = 0;
-          else if (um < dm)
-            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
-          else
-            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
-          const double rb = (b & 1) ? double (raw) : -double (raw);
-          q += rb * s_n[b];
-          total += s_n[b];
-        }
-      if (total)
-        q /= total;
-      q = q / a.min_delta / 2.9;
-      a.quality[plane * a.q_stride + cand] = q;
-    }
-}
-
-__device__ unsigned long long g_scan_dbg[8];
-template<int NT> __global__ void __launch_bounds__ (384)
-sync_scan_dbg_kernel (SyncScanArgs a, int total_frames)
-{
-  constexpr int RING = 64 * (NT + 1);
-  __shared__ __attribute__ ((aligned (16))) float s_win[NB * RING];
-  /* the epilogue's exchange buffers alias the ring (it is dead after the last barrier of the main loop): with
-   * NT = 1 the workgroup then needs 41.5 KB, so that three of them fit beside each other on a CU */
-  float (*s_u)[64 * NT] = reinterpret_cast<float (*)[64 * NT]> (s_win);
-  float (*s_d)[64 * NT] = reinterpret_cast<float (*)[64 * NT]> (s_win + 6 * 64 * NT);
-  int   *s_n = reinterpret_cast<int *> (s_win + 12 * 64 * NT);
-  const int lane = threadIdx.x;
-  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  const long long plane = blockIdx.y;
-  const long long n_tiles = (a.n_lanes + 64 * NT - 1) / (64 * NT);
-  const long long per_xcd = (n_tiles + 7) / 8;
-  const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
-    return;                                               // uniform for the workgroup
-  const long long sf0 = tile * 64 * NT;
-  const float *db = a.db + plane * a.plane_stride;
-  const long long ld = a.band_stride;
-  const int R = a.table.rows_per_bit;
-  const_int_ptr tab = (const_int_ptr) (a.table.packed + (size_t) bit * R * 64);
-
-  auto load_half = [&] (int h) {
-    const long long base = sf0 + 64LL * h;
-    float *dst = s_win + 64 * (h % (NT + 1));
-    const bool in_range = base + 64 <= ld;
-    for (int idx = tid; idx < NB * 16; idx += 384)
-      {
-        const int band = idx >> 4, q = idx & 15;
-        float4 v = make_float4 (0.f, 0.f, 0.f, 0.f);
-        if (in_range)
-          v = *reinterpret_cast<const float4 *> (db + band * ld + base + 4 * q);
-        *reinterpret_cast<float4 *> (dst + band * RING + 4 * q) = v;
-      }
-  };
-
-  float umag[NT], dmag[NT];
-#pragma unroll
-  for (int t = 0; t < NT; t++)
-    umag[t] = dmag[t] = 0.f;
-  int n = 0, r = 0;
-  unsigned long long d_load = 0, d_bar1 = 0, d_rows = 0, d_bar2 = 0;
-  for (int h = 0; h < NT; h++)
-    load_half (h);
-  for (int k = 0; 64 * k < total_frames; k++)
-    {
-      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-      load_half (k + NT);
-      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
-      __syncthreads();
-      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
-      const int ring0 = 64 * (k % (NT + 1));
-      while (r < R)
-        {
-          const_int_ptr tr = tab + r * 64;
-          const int fr = tr[60];
-          if (fr >= 64 * (k + 1))
-            break;
-          const int x = fr - 64 * k + lane + ring0;          // < 2 * RING
-#pragma unroll
-          for (int t = 0; t < NT; t++)
-            {
-              int phys = x + 64 * t;
-              phys -= phys >= RING ? RING : 0;
-              phys -= phys >= RING ? RING : 0;
-              float uv[30], dv[30];
-#pragma unroll
-              for (int i = 0; i < 30; i++)
-                {
-                  uv[i] = s_win[tr[i] * RING + phys];
-                  dv[i] = s_win[tr[30 + i] * RING + phys];
-                }
-#pragma unroll
-              for (int i = 0; i < 30; i++)
-                {
-                  umag[t] = __fadd_rn (umag[t], uv[i]);
-                  dmag[t] = __fadd_rn (dmag[t], dv[i]);
-                }
-            }
-          n++;
-          r++;
-        }
-      const unsigned long long t3 = __builtin_amdgcn_s_memtime();
-      __syncthreads();
-      const unsigned long long t4 = __builtin_amdgcn_s_memtime();
-      d_load += t1 - t0; d_bar1 += t2 - t1; d_rows += t3 - t2; d_bar2 += t4 - t3;
-    }
-  if (lane == 0)
-    {
-      atomicAdd (&g_scan_dbg[0], d_load); atomicAdd (&g_scan_dbg[1], d_bar1); atomicAdd (&g_scan_dbg[2], d_rows);
-      atomicAdd (&g_scan_dbg[3], d_bar2); atomicAdd (&g_scan_dbg[4], (unsigned long long) n); atomicAdd (&g_scan_dbg[5], 1ull);
-    }
-#pragma unroll
-  for (int t = 0; t < NT; t++)
-    {
-      s_u[bit][64 * t + lane] = umag[t];
-      s_d[bit][64 * t + lane] = dmag[t];
-    }
-  if (lane == 0)
-    s_n[bit] = n;
-  __syncthreads();
-  for (int c = tid; c < 64 * NT; c += 384)
-    {
-      const long long cand = sf0 + c;
-      if (cand >= a.n_lanes)
-        continue;
-      double q = 0;
-      int total = 0;
-      for (int b = 0; b < 6; b++)
-        {
-          const float um = s_u[b][c], dm = s_d[b][c];
-          float raw;
-          if (um == 0 || dm == 0)
-            raw = 0;
-          else if (um < dm)
-            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
-          else
-            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
-          const double rb = (b & 1) ? double (raw) : -double (raw);
-          q += rb * s_n[b];
-          total += s_n[b];
-        }
-      if (total)
-        q /= total;
-      q = q / a.min_delta / 2.9;
-      a.quality[plane * a.q_stride + cand] = q;
-    }
-}
-
-/* K5p: K5w with the two latencies of its step loop taken off the critical path.
- *  - the table: a row is 16 dwords (60 band bytes + its frame) and four rows arrive with ONE vector load (lane l holds
- *    dword l of the group), always two groups ahead of their use; v_readlane turns them into the scalars the LDS
- *    addresses are built from.  K5w paid two dependent scalar-cache round trips per row (130 KB table, 16 KB cache);
- *  - the ring: the global loads of half k + 2 are issued before the rows of step k are processed and written to LDS
- *    after them, so that HBM latency overlaps the gathers instead of sitting between two barriers.
- * Accumulation order is unchanged (reference syncfinder.cc:129-145). */
-__global__ void __launch_bounds__ (384)
-sync_scan_pipe_kernel (SyncScanArgs a, int total_frames)
-{
-  constexpr int RING = 128;
-  __shared__ __attribute__ ((aligned (16))) float s_win[NB * RING];
-  float (*s_u)[64] = reinterpret_cast<float (*)[64]> (s_win);           // epilogue buffers alias the dead ring
-  float (*s_d)[64] = reinterpret_cast<float (*)[64]> (s_win + 6 * 64);
-  int   *s_n = reinterpret_cast<int *> (s_win + 12 * 64);
-  const int lane = threadIdx.x;
-  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  const long long plane = blockIdx.y;
-  const long long n_tiles = (a.n_lanes + 63) / 64;
-  const long long per_xcd = (n_tiles + 7) / 8;
-  const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
-    return;                                               // uniform for the workgroup
-  const long long sf0 = tile * 64;
-  const float *db = a.db + plane * a.plane_stride;
-  const long long ld = a.band_stride;
-  const unsigned *tab = a.table.packed16 + (size_t) bit * a.table.rows16_per_bit * 16;
-
-  float4 stage[4];
-  auto fetch_half = [&] (int h) {
-    const long long base = sf0 + 64LL * h;
-    const bool in_range = base + 64 <= ld;
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      {
-        const int idx = tid + 384 * j;
-        const int band = idx >> 4, q = idx & 15;
-        stage[j] = make_float4 (0.f, 0.f, 0.f, 0.f);
-        if (in_range && idx < NB * 16)
-          stage[j] = *reinterpret_cast<const float4 *> (db + band * ld + base + 4 * q);
-      }
-  };
-  auto store_half = [&] (int h) {
-    float *dst = s_win + 64 * (h & 1);
-#pragma unroll
-    for (int j = 0; j < 4; j++)
-      {
-        const int idx = tid + 384 * j;
-        const int band = idx >> 4, q = idx & 15;
-        if (idx < NB * 16)
-          *reinterpret_cast<float4 *> (dst + band * RING + 4 * q) = stage[j];
-      }
-  };
-
-  unsigned g_cur = tab[lane], g_nxt = tab[64 + lane];
   float umag = 0.f, dmag = 0.f;
   int n = 0, r = 0;
-  fetch_half (0);
-  store_half (0);
-  fetch_half (1);
+  load_slot (0);
+  load_slot (1);
   for (int k = 0; 64 * k < total_frames; k++)
     {
-      store_half (k + 1);
+      load_slot (k + 2);
       __syncthreads();
-      fetch_half (k + 2);
-      while (true)
+      const int ring0 = 64 * ((k + sub) % 3) - 64 * k;      // + fr = ring position of this wave's lane 0 (before the wrap)
+      while (r < R)
         {
-          const int q16 = (r & 3) * 16;
-          const unsigned w15 = __builtin_amdgcn_readlane (g_cur, q16 + 15);
-          const int fr = w15 & 0xffff;
+          const_int_ptr tr = tab + r * 64;
+          const int fr = tr[60];
           if (fr >= 64 * (k + 1))
             break;
-          const int x = (fr + lane) & (RING - 1);            // frame f lives at ring position f % 128
-          unsigned w[15];
-#pragma unroll
-          for (int i = 0; i < 15; i++)
-            w[i] = __builtin_amdgcn_readlane (g_cur, q16 + i);
+          int phys = fr + ring0 + lane;                      // < 128 + 64 + 64
+          phys -= phys >= RING ? RING : 0;
           float uv[30], dv[30];
 #pragma unroll
           for (int i = 0; i < 30; i++)
             {
-              const unsigned ub = (w[i >> 2] >> (8 * (i & 3))) & 0xff;
-              const unsigned dbnd = (w[(30 + i) >> 2] >> (8 * ((30 + i) & 3))) & 0xff;
-              uv[i] = s_win[ub * RING + x];
-              dv[i] = s_win[dbnd * RING + x];
+              uv[i] = s_win[tr[i] * RING + phys];
+              dv[i] = s_win[tr[30 + i] * RING + phys];
             }
 #pragma unroll
           for (int i = 0; i < 30; i++)
@@ -1504,29 +1250,25 @@ sync_scan_pipe_kernel (SyncScanArgs a, int total_frames)
             }
           n++;
           r++;
-          if ((r & 3) == 0)
-            {
-              g_cur = g_nxt;
-              g_nxt = tab[(r / 4 + 1) * 64 + lane];
-            }
         }
       __syncthreads();
     }
-  s_u[bit][lane] = umag;
-  s_d[bit][lane] = dmag;
+  s_u[wv][lane] = umag;
+  s_d[wv][lane] = dmag;
   if (lane == 0)
-    s_n[bit] = n;
+    s_n[wv] = n;
   __syncthreads();
-  if (bit == 0)
+  if (tid < 128)
     {
-      const long long cand = sf0 + lane;
+      const int t = tid >> 6, l = tid & 63;
+      const long long cand = sf0 + tid;
       if (cand < a.n_lanes)
         {
           double q = 0;
           int total = 0;
           for (int b = 0; b < 6; b++)
             {
-              const float um = s_u[b][lane], dm = s_d[b][lane];
+              const float um = s_u[t * 6 + b][l], dm = s_d[t * 6 + b][l];
               float raw;
               if (um == 0 || dm == 0)
                 raw = 0;
@@ -1535,8 +1277,8 @@ sync_scan_pipe_kernel (SyncScanArgs a, int total_frames)
               else
                 raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
               const double rb = (b & 1) ? double (raw) : -double (raw);
-              q += rb * s_n[b];
-              total += s_n[b];
+              q += rb * s_n[t * 6 + b];
+              total += s_n[t * 6 + b];
             }
           if (total)
             q /= total;
@@ -1557,34 +1299,8 @@ launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames
     return hipErrorInvalidValue;
   if (a.have)
     return launch_sync_scan (st, a);                      // skipped (silent) frames: the generic kernel handles `have`
-  static const int nt = getenv ("AWM_SCAN_TILES") ? atoi (getenv ("AWM_SCAN_TILES")) : 0;
-  if (getenv ("AWM_SCAN_DEBUG"))
-    {
-      unsigned long long z[8] = {0}, o[8];
-      hipMemcpyToSymbol (HIP_SYMBOL (g_scan_dbg), z, sizeof (z));
-      const long long px = ((a.n_lanes + 63) / 64 + 7) / 8;
-      hipLaunchKernelGGL (sync_scan_dbg_kernel<1>, dim3 ((unsigned) (px * 8), (unsigned) a.n_planes), dim3 (64, 6), 0, st, a, total_frames);
-      hipStreamSynchronize (st);
-      hipMemcpyFromSymbol (o, HIP_SYMBOL (g_scan_dbg), sizeof (o));
-      fprintf (stderr, "scan dbg: waves %llu rows/wave %.1f  cycles per wave: load %.0f bar1 %.0f rows %.0f bar2 %.0f  (per row %.0f)\n", o[5], double (o[4]) / o[5],
-               double (o[0]) / o[5], double (o[1]) / o[5], double (o[2]) / o[5], double (o[3]) / o[5], double (o[2]) / o[4]);
-      return hipGetLastError();
-    }
-  if (nt == 0 && a.table.packed16)
-    {
-      const long long px = ((a.n_lanes + 63) / 64 + 7) / 8;
-      hipLaunchKernelGGL (sync_scan_pipe_kernel, dim3 ((unsigned) (px * 8), (unsigned) a.n_planes), dim3 (64, 6), 0, st, a, total_frames);
-      return hipGetLastError();
-    }
-  const int cands = 64 * (nt == 3 ? 3 : (nt == 1 ? 1 : 2));
-  const long long per_xcd = ((a.n_lanes + cands - 1) / cands + 7) / 8;
-  const dim3 grid ((unsigned) (per_xcd * 8), (unsigned) a.n_planes);
-  if (nt == 1)
-    hipLaunchKernelGGL (sync_scan_window_kernel<1>, grid, dim3 (64, 6), 0, st, a, total_frames);
-  else if (nt == 3)
-    hipLaunchKernelGGL (sync_scan_window_kernel<3>, grid, dim3 (64, 6), 0, st, a, total_frames);
-  else
-    hipLaunchKernelGGL (sync_scan_window_kernel<2>, grid, dim3 (64, 6), 0, st, a, total_frames);
+  const long long px = ((a.n_lanes + 127) / 128 + 7) / 8;
+  hipLaunchKernelGGL (sync_scan_window_kernel, dim3 ((unsigned) (px * 8), (unsigned) a.n_planes), dim3 (64, 12), 0, st, a, total_frames);
   return hipGetLastError();
 }
 
@@ -1611,6 +1327,105 @@ launch_sync_scan (hipStream_t st, const SyncScanArgs& a)
       done += n;
     }
   return hipSuccess;
+}
+
+/* K5g: the refinement's sync_decode over the gathered layout (kernels.hh GatheredScanArgs).  One workgroup = one
+ * candidate x 64 fine offsets, one wave per sync bit; a wave reads its 85 x 60 rows front to back (every value exactly
+ * once, 256 B coalesced per row).  There are only (candidates x 2) workgroups, so a wave must hide the HBM latency
+ * itself: the 60 loads of the next sync frame are issued before the 60 dependent adds of the current one. */
+template<bool HAVE> __global__ void __launch_bounds__ (384)
+sync_scan_gathered_kernel (GatheredScanArgs a)
+{
+  __shared__ float s_u[6][64], s_d[6][64];
+  __shared__ int   s_n[6][64];
+  const int lane = threadIdx.x;
+  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
+  const long long plane = blockIdx.y;
+  const int cand = blockIdx.x * 64 + lane;
+  const bool active = cand < a.lane_count[plane];
+  const int R = a.rows_per_bit;
+  const float *p = a.db + plane * a.plane_stride + (long long) bit * R * 60 * a.ld + (active ? cand : 0);
+  const char *hv = HAVE ? a.have + plane * a.have_plane_stride + (long long) bit * R * a.ld + (active ? cand : 0) : nullptr;
+  const int ld = a.ld;
+
+  float umag = 0.f, dmag = 0.f;
+  int n = 0;
+  auto issue = [&] (int r, float (&v)[60], bool& present) {
+    const float *q = p + (long long) r * 60 * ld;
+    present = HAVE ? hv[r * ld] != 0 : true;
+#pragma unroll
+    for (int i = 0; i < 60; i++)
+      v[i] = q[i * ld];
+  };
+  auto accumulate = [&] (const float (&v)[60], bool present) {
+    if (present)
+      {
+#pragma unroll
+        for (int i = 0; i < 30; i++)
+          {
+            umag = __fadd_rn (umag, v[i]);
+            dmag = __fadd_rn (dmag, v[30 + i]);
+          }
+        n++;
+      }
+  };
+  float va[60], vb[60];
+  bool pa = false, pb = false;
+  int r = 0;
+  if (R > 0)
+    issue (0, va, pa);
+  for (; r + 1 < R; r += 2)
+    {
+      issue (r + 1, vb, pb);
+      accumulate (va, pa);
+      if (r + 2 < R)
+        issue (r + 2, va, pa);
+      accumulate (vb, pb);
+    }
+  if (r < R)
+    accumulate (va, pa);
+  s_u[bit][lane] = umag;
+  s_d[bit][lane] = dmag;
+  s_n[bit][lane] = n;
+  __syncthreads();
+  if (bit == 0 && active)
+    {
+      double q = 0;
+      int total = 0;
+      for (int b = 0; b < 6; b++)
+        {
+          const float um = s_u[b][lane], dm = s_d[b][lane];
+          float raw;                                      // SyncFinder::bit_quality (reference syncfinder.cc:94-114)
+          if (um == 0 || dm == 0)
+            raw = 0;
+          else if (um < dm)
+            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
+          else
+            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
+          const double rb = (b & 1) ? double (raw) : -double (raw);
+          q += rb * s_n[b][lane];
+          total += s_n[b][lane];
+        }
+      if (total)
+        q /= total;
+      q = q / a.min_delta / 2.9;
+      a.quality[plane * a.q_stride + cand] = q;
+    }
+}
+
+hipError_t
+launch_sync_scan_gathered (hipStream_t st, const GatheredScanArgs& a)
+{
+  if (a.n_lanes <= 0 || a.n_planes <= 0)
+    return hipSuccess;
+  if (!a.lane_count || a.n_planes > 65535)
+    return hipErrorInvalidValue;
+  const dim3 grid (unsigned ((a.n_lanes + 63) / 64), unsigned (a.n_planes));
+  if (a.have)
+    hipLaunchKernelGGL (sync_scan_gathered_kernel<true>, grid, dim3 (64, 6), 0, st, a);
+  else
+    hipLaunchKernelGGL (sync_scan_gathered_kernel<false>, grid, dim3 (64, 6), 0, st, a);
+  return hipGetLastError();
 }
 
 /* K5b: local mean (reference syncfinder.cc:234-254): 41-tap window without the 7 centre taps */

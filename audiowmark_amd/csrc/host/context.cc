@@ -75,30 +75,6 @@ pack_sync_table (const SyncTable& t, const std::vector<int>& want_pos /* empty: 
   return packed;
 }
 
-static std::vector<unsigned>
-pack_sync_table16 (const SyncTable& t, int& rows16)
-{
-  const int R = t.rows_per_bit;
-  rows16 = ((R + 3) / 4 + 3) * 4;
-  std::vector<unsigned> packed (size_t (6) * rows16 * 16, 0);
-  for (int bit = 0; bit < 6; bit++)
-    for (int r = 0; r < rows16; r++)
-      {
-        unsigned *row = &packed[(size_t (bit) * rows16 + r) * 16];
-        row[15] = 0xffff;
-        if (r >= R)
-          continue;
-        const size_t src = size_t (bit) * R + r;
-        for (int i = 0; i < 60; i++)
-          {
-            const unsigned band = i < 30 ? t.up[src * 30 + i] : t.down[src * 30 + i - 30];
-            row[i >> 2] |= band << (8 * (i & 3));
-          }
-        row[15] = t.frame[src];
-      }
-  return packed;
-}
-
 KeyTables *
 awm_ctx::get_key_tables (const Key& key)
 {
@@ -127,9 +103,26 @@ awm_ctx::get_key_tables (const Key& key)
       auto pr = pack_sync_table (s.host, want_pos);
       if (upload (s.packed_approx, pa.data(), pa.size() * sizeof (int), stream)) return nullptr;
       if (upload (s.packed_refine, pr.data(), pr.size() * sizeof (int), stream)) return nullptr;
-      auto p16 = pack_sync_table16 (s.host, s.rows16);
-      if (upload (s.packed16_approx, p16.data(), p16.size() * sizeof (unsigned), stream)) return nullptr;
       if (upload (s.want_list_dev, s.want_list.data(), s.want_list.size() * sizeof (int), stream)) return nullptr;
+      {
+        const int R = s.host.rows_per_bit, NW = int (s.want_list.size());
+        std::vector<int> perm (NW, 0);
+        std::vector<unsigned char> pos (size_t (NW) * Params::n_bands, 255);
+        for (int bit = 0; bit < 6; bit++)
+          for (int r = 0; r < R; r++)
+            {
+              const size_t src = size_t (bit) * R + r;
+              const int w = want_pos[s.host.frame[src]];
+              perm[w] = int (src);
+              for (int i = 0; i < 30; i++)
+                {
+                  pos[size_t (w) * Params::n_bands + s.host.up[src * 30 + i]] = (unsigned char) i;
+                  pos[size_t (w) * Params::n_bands + s.host.down[src * 30 + i]] = (unsigned char) (30 + i);
+                }
+            }
+        if (upload (s.refine_perm, perm.data(), perm.size() * sizeof (int), stream)) return nullptr;
+        if (upload (s.refine_pos, pos.data(), pos.size(), stream)) return nullptr;
+      }
     }
   kt->mix_host = build_mix_table (key);
   if (upload (kt->mix_frame, kt->mix_host.frame.data(), kt->mix_host.frame.size() * sizeof (int16_t), stream)) return nullptr;
@@ -308,9 +301,10 @@ awm_ctx_destroy (awm_ctx *ctx)
       for (auto& s : kt->sync)
         {
           s.packed_approx.release();
-          s.packed16_approx.release();
           s.packed_refine.release();
           s.want_list_dev.release();
+          s.refine_perm.release();
+          s.refine_pos.release();
         }
       kt->mix_frame.release();
       kt->mix_up.release();

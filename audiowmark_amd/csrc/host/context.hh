@@ -35,11 +35,11 @@ struct KeyTables
   {
     SyncTable host;
     DevBuffer packed_approx;       // [6][rows][64] row = frame
-    DevBuffer packed16_approx;     // [6][rows16][16] byte packed rows for K5p (kernels.hh SyncTableDev)
-    int       rows16 = 0;
     DevBuffer packed_refine;       // [6][rows][64] row = position in the want list
     std::vector<int> want_list;    // sorted sync frames (510 or 1020)
     DevBuffer want_list_dev;
+    DevBuffer refine_perm;         // [want rows] int: row w of the want list -> bit * rows_per_bit + j (K4s gathered layout)
+    DevBuffer refine_pos;          // [want rows][81] uint8: band -> 0..29 (up), 30..59 (down), 255 (unused)
   } sync[2];
   MixTable  mix_host;
   DevBuffer mix_frame, mix_up, mix_down;

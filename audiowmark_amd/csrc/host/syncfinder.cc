@@ -119,8 +119,6 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   sa.q_stride = q_stride;
   sa.table.packed = kt->sync[clip].packed_approx.as<int>();
   sa.table.rows_per_bit = kt->sync[clip].host.rows_per_bit;
-  sa.table.packed16 = kt->sync[clip].packed16_approx.as<unsigned>();
-  sa.table.rows16_per_bit = kt->sync[clip].rows16;
   {
     // algorithmic HBM bytes of the scan: the dB matrix once, candidates re-read it from cache
     ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0);
@@ -324,7 +322,10 @@ SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
   if (!n_cand)
     return 0;
 
-  const size_t per_cand = size_t (NW) * Params::n_bands * TP;
+  // K4s + K5g (<= 2 channels): every sync frame stores only the 60 values its sync bit sums, in summation order
+  const bool gathered = wav.n_channels <= 2 && !getenv ("AWM_REFINE_FFT");
+  const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
+  const size_t per_cand = size_t (NW) * row_values * TP;
   size_t batch = std::max<size_t> (1, (size_t (3) << 30) / (per_cand * sizeof (float)));    // <= 3 GiB of dB rows at a time
   batch = std::min (batch, n_cand);
   if (int rc = m_ctx->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
@@ -380,7 +381,13 @@ SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
           da.n_streams = (long long) nb * NW;
           da.hop = Params::sync_search_fine;
           da.out = m_ctx->ws_refine.as<float>();
-          da.out_stream_stride = (long long) Params::n_bands * TP;
+          da.out_stream_stride = (long long) row_values * TP;
+          if (gathered)
+            {
+              da.row_perm = sync.refine_perm.as<int>();
+              da.band_pos = sync.refine_pos.as<unsigned char>();
+              da.rows_per_plane = NW;
+            }
           da.ld = TP;
           da.have = m_ctx->ws_refine_have.as<char>();
           da.have_stream_stride = TP;
@@ -395,34 +402,53 @@ SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
             double bytes = 0;
             for (size_t c = 0; c < nb; c++)
               if (lane_count[c])
-                bytes += double (NW) * ((1024.0 + 8.0 * (lane_count[c] - 1)) * 4 * wav.n_channels + 324.0 * lane_count[c]);
+                bytes += double (NW) * ((1024.0 + 8.0 * (lane_count[c] - 1)) * 4 * wav.n_channels + 4.0 * row_values * lane_count[c]);
             ProfScope ps (m_ctx, PROF_REFINE_DB, bytes);
-            if (wav.n_channels <= 2 && !getenv ("AWM_REFINE_FFT"))
+            if (gathered)
               AWM_HIP_CHECK (awmk::launch_sync_db_sliding (st, m_ctx->tabs, da));       // K4s: sliding DFT over the fine offsets
             else
               AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));               // K4: one FFT per fine offset
           }
 
-          awmk::SyncScanArgs sa {};
-          sa.db = m_ctx->ws_refine.as<float>();
-          sa.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
-          sa.plane_stride = (long long) per_cand;
-          sa.have_plane_stride = (long long) NW * TP;
-          sa.row_stride = (long long) Params::n_bands * TP;
-          sa.band_stride = TP;
-          sa.have_row_stride = TP;
-          sa.n_lanes = max_count;
-          sa.lane_count = d_lanes;
-          sa.n_planes = (long long) nb;
-          sa.min_delta = std::min (Params::water_delta, 0.080);
-          sa.quality = m_ctx->ws_q.as<double>();
-          sa.q_stride = QS;
-          sa.table.packed = sync.packed_refine.as<int>();
-          sa.table.rows_per_bit = sync.host.rows_per_bit;
-          {
-            ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 324.0);
-            AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
-          }
+          if (gathered)
+            {
+              awmk::GatheredScanArgs ga {};
+              ga.db = m_ctx->ws_refine.as<float>();
+              ga.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
+              ga.plane_stride = (long long) per_cand;
+              ga.have_plane_stride = (long long) NW * TP;
+              ga.ld = TP;
+              ga.rows_per_bit = sync.host.rows_per_bit;
+              ga.n_lanes = max_count;
+              ga.lane_count = d_lanes;
+              ga.n_planes = (long long) nb;
+              ga.min_delta = std::min (Params::water_delta, 0.080);
+              ga.quality = m_ctx->ws_q.as<double>();
+              ga.q_stride = QS;
+              ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 4.0 * row_values);
+              AWM_HIP_CHECK (awmk::launch_sync_scan_gathered (st, ga));
+            }
+          else
+            {
+              awmk::SyncScanArgs sa {};
+              sa.db = m_ctx->ws_refine.as<float>();
+              sa.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
+              sa.plane_stride = (long long) per_cand;
+              sa.have_plane_stride = (long long) NW * TP;
+              sa.row_stride = (long long) Params::n_bands * TP;
+              sa.band_stride = TP;
+              sa.have_row_stride = TP;
+              sa.n_lanes = max_count;
+              sa.lane_count = d_lanes;
+              sa.n_planes = (long long) nb;
+              sa.min_delta = std::min (Params::water_delta, 0.080);
+              sa.quality = m_ctx->ws_q.as<double>();
+              sa.q_stride = QS;
+              sa.table.packed = sync.packed_refine.as<int>();
+              sa.table.rows_per_bit = sync.host.rows_per_bit;
+              ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 324.0);
+              AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+            }
           AWM_HIP_CHECK (hipMemcpyAsync (q.data(), m_ctx->ws_q.ptr, q.size() * sizeof (double), hipMemcpyDeviceToHost, st));
         }
       AWM_HIP_CHECK (hipStreamSynchronize (st));
