@@ -162,6 +162,31 @@ struct SoftBitsArgs
 };
 hipError_t launch_soft_bits (hipStream_t st, const SoftBitsArgs& a);
 
+/* K7b: everything between mix_decode and the Viterbi decoder, per decode job (reference wmget.cc:40-65 normalize_soft_bits,
+ * wmcommon.cc:165-185 randomize_bit_order, wmget.cc:554-701 AB interleave / "all" average): the raw soft bits of the
+ * blocks never leave the device.  Job j reads its sources src[src_off .. src_off + n_src) = (block slot, half) and
+ * writes len = 858 (single block) or 1716 normalised soft bits to out + out_off. */
+struct SoftJobDev
+{
+  int       mode;          // 0: one block; 1: interleave (half 0 / 1 of every pair of bits); 2: average of several blocks per half
+  int       n_src, src_off;
+  int       len;           // 858 or 1716
+  int       norm0, norm1;  // mode 2: blocks per half
+  long long out_off;       // floats
+};
+struct SoftPrepArgs
+{
+  const float      *raw;         // [slots][n_bits]
+  int               n_bits;      // 858
+  const int        *inv_order;   // [n_bits]: restored[k] = raw[inv_order[k]]
+  const SoftJobDev *jobs;
+  const int2       *src;         // (slot, half)
+  long long         n_jobs;
+  int               hard;        // Params::hard
+  float            *out;
+};
+hipError_t launch_soft_prep (hipStream_t st, const SoftPrepArgs& a);
+
 /* K8: soft Viterbi (convcode.cc:128-213), one workgroup per coded block */
 /* index 0 / 1 / 2 = A / B / AB coded blocks (rate 6 / 6 / 12); every block has n_steps = payload + 15 trellis steps */
 hipError_t launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_blocks[3], long long n_steps,

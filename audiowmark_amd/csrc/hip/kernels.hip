@@ -1531,6 +1531,83 @@ nonzero_range_kernel (const float *data, long long n_values, unsigned long long 
     }
 }
 
+/* K7b (kernels.hh SoftPrepArgs).  One workgroup per decode job.  The only order-sensitive step is the mean of |v| --
+ * a double accumulated front to back (reference wmget.cc:52-55) -- which one thread does from LDS (<= 1716 adds). */
+__global__ void __launch_bounds__ (256)
+soft_prep_kernel (SoftPrepArgs a)
+{
+  __shared__ float  s_v[1728];
+  __shared__ double s_mean;
+  const SoftJobDev job = a.jobs[blockIdx.x];
+  const int2 *src = a.src + job.src_off;
+  const int nb = a.n_bits;
+  if (job.len > 1728)
+    return;
+  if (job.mode == 0)
+    {
+      const float *raw = a.raw + (long long) src[0].x * nb;
+      for (int k = threadIdx.x; k < nb; k += 256)
+        s_v[k] = raw[a.inv_order[k]];
+    }
+  else if (job.mode == 1)
+    {
+      for (int s = 0; s < job.n_src; s++)
+        {
+          const float *raw = a.raw + (long long) src[s].x * nb;
+          const int half = src[s].y;
+          for (int k = threadIdx.x; k < nb; k += 256)
+            s_v[2 * k + half] = raw[a.inv_order[k]];
+        }
+    }
+  else
+    {
+      const float div0 = float (job.norm0 > 1 ? job.norm0 : 1), div1 = float (job.norm1 > 1 ? job.norm1 : 1);
+      for (int k = threadIdx.x; k < nb; k += 256)
+        {
+          const int i = a.inv_order[k];
+          float acc0 = 0.f, acc1 = 0.f;                   // all_bits starts at zero and the blocks are added in list order
+          for (int s = 0; s < job.n_src; s++)
+            {
+              const float v = a.raw[(long long) src[s].x * nb + i];
+              if (src[s].y)
+                acc1 = __fadd_rn (acc1, v);
+              else
+                acc0 = __fadd_rn (acc0, v);
+            }
+          s_v[2 * k] = __fdiv_rn (acc0, div0);
+          s_v[2 * k + 1] = __fdiv_rn (acc1, div1);
+        }
+    }
+  __syncthreads();
+  float *out = a.out + job.out_off;
+  if (a.hard)
+    {
+      for (int k = threadIdx.x; k < job.len; k += 256)
+        out[k] = s_v[k] > 0 ? 1.f : 0.f;
+      return;
+    }
+  if (threadIdx.x == 0)
+    {
+      double mean = 0;
+      for (int k = 0; k < job.len; k++)
+        mean = __dadd_rn (mean, double (fabsf (s_v[k])));
+      s_mean = __ddiv_rn (mean, double (job.len));
+    }
+  __syncthreads();
+  const double mean = s_mean;
+  for (int k = threadIdx.x; k < job.len; k += 256)
+    out[k] = float (__dmul_rn (0.5, __dadd_rn (__ddiv_rn (double (s_v[k]), mean), 1.0)));
+}
+
+hipError_t
+launch_soft_prep (hipStream_t st, const SoftPrepArgs& a)
+{
+  if (a.n_jobs <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (soft_prep_kernel, dim3 (unsigned (a.n_jobs)), dim3 (256), 0, st, a);
+  return hipGetLastError();
+}
+
 hipError_t
 launch_nonzero_range (hipStream_t st, const float *data, long long n_values, unsigned long long *result)
 {

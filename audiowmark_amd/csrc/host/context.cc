@@ -32,6 +32,35 @@ DevBuffer::reserve (size_t want)
   return 0;
 }
 
+int
+PinnedBuffer::reserve (size_t want)
+{
+  if (want <= bytes)
+    return 0;
+  release();
+  size_t cap = size_t (64) << 10;
+  while (cap < want)
+    cap *= 2;
+  hipError_t e = hipHostMalloc (&ptr, cap, hipHostMallocDefault);
+  if (e != hipSuccess)
+    {
+      ptr = nullptr;
+      set_error ("hipHostMalloc of " + std::to_string (cap) + " bytes failed: " + hip_error_string (e));
+      return AWM_ERR_HIP;
+    }
+  bytes = cap;
+  return 0;
+}
+
+void
+PinnedBuffer::release()
+{
+  if (ptr)
+    (void) hipHostFree (ptr);
+  ptr = nullptr;
+  bytes = 0;
+}
+
 void
 DevBuffer::release()
 {
@@ -129,6 +158,12 @@ awm_ctx::get_key_tables (const Key& key)
   if (upload (kt->mix_up, kt->mix_host.up.data(), kt->mix_host.up.size(), stream)) return nullptr;
   if (upload (kt->mix_down, kt->mix_host.down.data(), kt->mix_host.down.size(), stream)) return nullptr;
   kt->bit_order_a = bit_order (key, code_size (ConvBlockType::a, Params::payload_size));
+  {
+    std::vector<int> inv (kt->bit_order_a.size());
+    for (size_t i = 0; i < inv.size(); i++)
+      inv[kt->bit_order_a[i]] = int (i);            // apply_bit_order (decode): out[order[i]] = in[i]
+    if (upload (kt->bit_order_inv_dev, inv.data(), inv.size() * sizeof (int), stream)) return nullptr;
+  }
   key_tables.push_back (std::move (kt));
   return key_tables.back().get();
 }
@@ -309,13 +344,19 @@ awm_ctx_destroy (awm_ctx *ctx)
       kt->mix_frame.release();
       kt->mix_up.release();
       kt->mix_down.release();
+      kt->bit_order_inv_dev.release();
     }
   for (auto& t : ctx->frame_mod_tables)
     t->dev.release();
   for (DevBuffer *b : { &ctx->tab_mem, &ctx->tab_slide, &ctx->ws_db, &ctx->ws_have, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_mean, &ctx->ws_misc,
                         &ctx->ws_refine, &ctx->ws_refine_have, &ctx->ws_soft, &ctx->ws_viterbi, &ctx->ws_viterbi_in,
-                        &ctx->ws_viterbi_bits, &ctx->ws_viterbi_err, &ctx->ws_block_max, &ctx->ws_clip, &ctx->ws_idx })
+                        &ctx->ws_viterbi_bits, &ctx->ws_viterbi_err, &ctx->ws_block_max, &ctx->ws_clip, &ctx->ws_idx, &ctx->ws_limit_tab, &ctx->ws_jobs })
     b->release();
+  for (PinnedBuffer *b : { &ctx->pin_refine_in[0], &ctx->pin_refine_in[1], &ctx->pin_refine_q[0], &ctx->pin_refine_q[1], &ctx->pin_peaks, &ctx->pin_blocks, &ctx->pin_jobs, &ctx->pin_bits })
+    b->release();
+  for (hipEvent_t& ev : ctx->ev_refine)
+    if (ev)
+      (void) hipEventDestroy (ev);
   if (ctx->own_stream && ctx->stream)
     (void) hipStreamDestroy (ctx->stream);
   delete ctx;

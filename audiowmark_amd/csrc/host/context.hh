@@ -26,6 +26,17 @@ struct DevBuffer
   template<class T> T *as() const { return static_cast<T *> (ptr); }
 };
 
+// grow-only page-locked host buffer: staging area for copies that must not block the host (hipMemcpyAsync from or
+// to pageable memory is staged by the runtime and stalls the calling thread)
+struct PinnedBuffer
+{
+  void  *ptr = nullptr;
+  size_t bytes = 0;
+  int reserve (size_t want);
+  void release();
+  template<class T> T *as() const { return static_cast<T *> (ptr); }
+};
+
 // device copies of the key-derived tables
 struct KeyTables
 {
@@ -44,6 +55,7 @@ struct KeyTables
   MixTable  mix_host;
   DevBuffer mix_frame, mix_up, mix_down;
   std::vector<unsigned> bit_order_a;        // randomize_bit_order permutation for 858 bits
+  DevBuffer bit_order_inv_dev;              // int [858]: restored[k] = raw[inv[k]]
 };
 
 struct FrameModTable
@@ -75,7 +87,11 @@ struct awm_ctx
 
   // workspaces
   awm::DevBuffer ws_db, ws_have, ws_q, ws_raw, ws_mean, ws_misc, ws_refine, ws_refine_have, ws_soft,
-                 ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx, ws_limit_tab;
+                 ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx, ws_limit_tab, ws_jobs;
+
+  // host staging (two slots: the search of chunk i + 1 is issued while chunk i's refinement is still in flight)
+  awm::PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits;
+  hipEvent_t        ev_refine[2] = { nullptr, nullptr };
 
   // profiling
   bool   prof_enabled = false;

@@ -156,14 +156,23 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
     ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_scores) * 16.0);
     AWM_HIP_CHECK (awmk::launch_peak_select (st, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>(), n_scores, threshold, d_count, d_out, cap));
   }
-  unsigned int count = 0;
-  AWM_HIP_CHECK (hipMemcpyAsync (&count, d_count, sizeof (count), hipMemcpyDeviceToHost, st));
+  // one round trip for the counter and the first peaks (usually all of them), through page-locked memory
+  const unsigned int head = 1024;
+  if (int rc = m_ctx->pin_peaks.reserve (256 + cap * sizeof (awmk::PeakOut))) return rc;
+  char *pin = m_ctx->pin_peaks.as<char>();
+  AWM_HIP_CHECK (hipMemcpyAsync (pin, d_count, 256 + head * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
+  unsigned int count = *reinterpret_cast<unsigned int *> (pin);
   if (int (count) >= Params::get_n_best && count <= cap)
     {
-      std::vector<awmk::PeakOut> peaks (count);
-      AWM_HIP_CHECK (hipMemcpyAsync (peaks.data(), d_out, count * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      if (count > head)
+        {
+          AWM_HIP_CHECK (hipMemcpyAsync (pin + 256 + head * sizeof (awmk::PeakOut), d_out + head, (count - head) * sizeof (awmk::PeakOut),
+                                         hipMemcpyDeviceToHost, st));
+          AWM_HIP_CHECK (hipStreamSynchronize (st));
+        }
+      const auto *pk0 = reinterpret_cast<const awmk::PeakOut *> (pin + 256);
+      std::vector<awmk::PeakOut> peaks (pk0, pk0 + count);
       for (const auto& pk : peaks)
         out.push_back ({ size_t (pk.p >> 2) * Params::frame_size + size_t (pk.p & 3) * Params::sync_search_step, pk.raw, pk.mean });
       // same order the reference continues with: descending quality (atomics delivered them unordered)
@@ -311,166 +320,227 @@ SyncFinder::select_truncate_n (std::vector<SearchScore>& scores, size_t n)
 int
 SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& scores)
 {
+  SearchJob job;
+  job.candidates = scores;
+  if (int rc = refine_launch (kt, wav, mode, job))
+    return rc;
+  return refine_finish (job, scores);
+}
+
+namespace {
+constexpr int REFINE_TP = 72;            // padded fine-offset axis (<= 65 used)
+constexpr int REFINE_QS = 128;
+}
+
+int
+SyncFinder::refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, SearchJob& job)
+{
+  const int clip = mode == Mode::CLIP;
+  const auto& sync = kt->sync[clip];
+  const int NW = int (sync.want_list.size());
+  const size_t n_cand = job.candidates.size();
+  job.refined.clear();
+  job.batch_pending = false;
+  if (!n_cand)
+    return 0;
+  const bool gathered = wav.n_channels <= 2 && !getenv ("AWM_REFINE_FFT");
+  const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
+  const size_t per_cand = size_t (NW) * row_values * REFINE_TP;
+  size_t batch = std::max<size_t> (1, (size_t (3) << 30) / (per_cand * sizeof (float)));    // <= 3 GiB of dB rows at a time
+  batch = std::min (batch, n_cand);
+  if (int rc = m_ctx->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
+  if (int rc = m_ctx->ws_refine_have.reserve (batch * NW * REFINE_TP)) return rc;
+  if (int rc = m_ctx->ws_q.reserve (batch * REFINE_QS * sizeof (double))) return rc;
+  if (int rc = m_ctx->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + batch * sizeof (int))) return rc;
+  for (size_t c0 = 0; c0 < n_cand; c0 += batch)
+    {
+      if (job.batch_pending)
+        if (int rc = refine_batch_finish (job))
+          return rc;
+      if (int rc = refine_batch_launch (kt, wav, mode, job, c0, std::min (batch, n_cand - c0), batch))
+        return rc;
+    }
+  return 0;
+}
+
+int
+SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, SearchJob& job, size_t c0, size_t nb, size_t batch)
+{
   const int clip = mode == Mode::CLIP;
   const auto& sync = kt->sync[clip];
   const int NW = int (sync.want_list.size());
   const long long total = total_frames (mode);
-  const int TP = 72;                       // padded fine-offset axis (<= 65 used)
-  const int QS = 128;
+  const int TP = REFINE_TP, QS = REFINE_QS;
   hipStream_t st = m_ctx->stream;
-  const size_t n_cand = scores.size();
-  if (!n_cand)
-    return 0;
-
-  // K4s + K5g (<= 2 channels): every sync frame stores only the 60 values its sync bit sums, in summation order
   const bool gathered = wav.n_channels <= 2 && !getenv ("AWM_REFINE_FFT");
   const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
   const size_t per_cand = size_t (NW) * row_values * TP;
-  size_t batch = std::max<size_t> (1, (size_t (3) << 30) / (per_cand * sizeof (float)));    // <= 3 GiB of dB rows at a time
-  batch = std::min (batch, n_cand);
-  if (int rc = m_ctx->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
-  if (int rc = m_ctx->ws_refine_have.reserve (batch * NW * TP)) return rc;
-  if (int rc = m_ctx->ws_q.reserve (batch * QS * sizeof (double))) return rc;
-  if (int rc = m_ctx->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + batch * sizeof (int))) return rc;
+  (void) batch;
 
-  std::vector<SearchScore> refined;
-  for (size_t c0 = 0; c0 < n_cand; c0 += batch)
+  // stream tables: [nb * NW] long long base, [nb * NW] int count, [nb] int lanes -- one page-locked block, one copy
+  const size_t in_bytes = nb * NW * (sizeof (long long) + sizeof (int)) + nb * sizeof (int);
+  PinnedBuffer& pin_in = m_ctx->pin_refine_in[job.slot];
+  PinnedBuffer& pin_q = m_ctx->pin_refine_q[job.slot];
+  if (int rc = pin_in.reserve (in_bytes)) return rc;
+  if (int rc = pin_q.reserve (nb * QS * sizeof (double))) return rc;
+  auto *stream_base = pin_in.as<long long>();
+  int *stream_count = reinterpret_cast<int *> (stream_base + nb * NW);
+  int *lanes = stream_count + nb * NW;
+  job.lane_count.assign (nb, 0);
+  job.starts.assign (nb, 0);
+  job.c0 = c0;
+  job.nb = nb;
+  int max_count = 0;
+  long long n_items = 0;
+  double db_bytes = 0;
+  for (size_t c = 0; c < nb; c++)
     {
-      const size_t nb = std::min (batch, n_cand - c0);
-      std::vector<long long> stream_base (nb * NW);
-      std::vector<int> stream_count (nb * NW), lane_count (nb), starts (nb);
-      int max_count = 0;
-      for (size_t c = 0; c < nb; c++)
+      const SearchScore& s = job.candidates[c0 + c];
+      const int start = std::max (int (s.index) - Params::sync_search_step, 0);
+      const int end = int (s.index) + Params::sync_search_step;
+      // fine offsets for which sync_fft does not read past the end (syncfinder.cc:566-568)
+      const long long limit = (long long) wav.n_frames - total * Params::frame_size;
+      int count = 0;
+      for (int fine = start; fine <= end; fine += Params::sync_search_fine)
+        if (fine <= limit)
+          count++;
+      job.starts[c] = start;
+      job.lane_count[c] = lanes[c] = count;
+      max_count = std::max (max_count, count);
+      n_items += (long long) count * NW;
+      // per (candidate, sync frame): a (1024 + 8 (T - 1))-sample window read once, T rows of dB values written
+      if (count)
+        db_bytes += double (NW) * ((1024.0 + 8.0 * (count - 1)) * 4 * wav.n_channels + 4.0 * row_values * count);
+      for (int w = 0; w < NW; w++)
         {
-          const SearchScore& s = scores[c0 + c];
-          const int start = std::max (int (s.index) - Params::sync_search_step, 0);
-          const int end = int (s.index) + Params::sync_search_step;
-          // fine offsets for which sync_fft does not read past the end (syncfinder.cc:566-568)
-          const long long limit = (long long) wav.n_frames - total * Params::frame_size;
-          int count = 0;
-          for (int fine = start; fine <= end; fine += Params::sync_search_fine)
-            if (fine <= limit)
-              count++;
-          starts[c] = start;
-          lane_count[c] = count;
-          max_count = std::max (max_count, count);
-          for (int w = 0; w < NW; w++)
-            {
-              stream_base[c * NW + w] = start + (long long) sync.want_list[w] * Params::frame_size;
-              stream_count[c * NW + w] = count;
-            }
-        }
-      auto *d_base = m_ctx->ws_idx.as<long long>();
-      int *d_count = reinterpret_cast<int *> (d_base + batch * NW);
-      int *d_lanes = d_count + batch * NW;
-      AWM_HIP_CHECK (hipMemcpyAsync (d_base, stream_base.data(), stream_base.size() * sizeof (long long), hipMemcpyHostToDevice, st));
-      AWM_HIP_CHECK (hipMemcpyAsync (d_count, stream_count.data(), stream_count.size() * sizeof (int), hipMemcpyHostToDevice, st));
-      AWM_HIP_CHECK (hipMemcpyAsync (d_lanes, lane_count.data(), lane_count.size() * sizeof (int), hipMemcpyHostToDevice, st));
-
-      std::vector<double> q (nb * QS, 0.0);
-      if (max_count > 0)
-        {
-          awmk::SyncDbArgs da {};
-          da.pcm = wav.data;
-          da.n_frames = wav.n_frames;
-          da.n_channels = wav.n_channels;
-          da.per_channel = 0;
-          da.stream_base = d_base;
-          da.stream_count = d_count;
-          da.count0 = max_count;
-          da.n_streams = (long long) nb * NW;
-          da.hop = Params::sync_search_fine;
-          da.out = m_ctx->ws_refine.as<float>();
-          da.out_stream_stride = (long long) row_values * TP;
-          if (gathered)
-            {
-              da.row_perm = sync.refine_perm.as<int>();
-              da.band_pos = sync.refine_pos.as<unsigned char>();
-              da.rows_per_plane = NW;
-            }
-          da.ld = TP;
-          da.have = m_ctx->ws_refine_have.as<char>();
-          da.have_stream_stride = TP;
-          da.first = (long long) m_first;
-          da.last = (long long) m_last;
-          da.tile_frames = TP;
-          long long n_items = 0;
-          for (size_t c = 0; c < nb; c++)
-            n_items += (long long) lane_count[c] * NW;
-          {
-            // per (candidate, sync frame): a (1024 + 8 (T - 1))-sample window read once, T rows of 81 dB values written
-            double bytes = 0;
-            for (size_t c = 0; c < nb; c++)
-              if (lane_count[c])
-                bytes += double (NW) * ((1024.0 + 8.0 * (lane_count[c] - 1)) * 4 * wav.n_channels + 4.0 * row_values * lane_count[c]);
-            ProfScope ps (m_ctx, PROF_REFINE_DB, bytes);
-            if (gathered)
-              AWM_HIP_CHECK (awmk::launch_sync_db_sliding (st, m_ctx->tabs, da));       // K4s: sliding DFT over the fine offsets
-            else
-              AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));               // K4: one FFT per fine offset
-          }
-
-          if (gathered)
-            {
-              awmk::GatheredScanArgs ga {};
-              ga.db = m_ctx->ws_refine.as<float>();
-              ga.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
-              ga.plane_stride = (long long) per_cand;
-              ga.have_plane_stride = (long long) NW * TP;
-              ga.ld = TP;
-              ga.rows_per_bit = sync.host.rows_per_bit;
-              ga.n_lanes = max_count;
-              ga.lane_count = d_lanes;
-              ga.n_planes = (long long) nb;
-              ga.min_delta = std::min (Params::water_delta, 0.080);
-              ga.quality = m_ctx->ws_q.as<double>();
-              ga.q_stride = QS;
-              ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 4.0 * row_values);
-              AWM_HIP_CHECK (awmk::launch_sync_scan_gathered (st, ga));
-            }
-          else
-            {
-              awmk::SyncScanArgs sa {};
-              sa.db = m_ctx->ws_refine.as<float>();
-              sa.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
-              sa.plane_stride = (long long) per_cand;
-              sa.have_plane_stride = (long long) NW * TP;
-              sa.row_stride = (long long) Params::n_bands * TP;
-              sa.band_stride = TP;
-              sa.have_row_stride = TP;
-              sa.n_lanes = max_count;
-              sa.lane_count = d_lanes;
-              sa.n_planes = (long long) nb;
-              sa.min_delta = std::min (Params::water_delta, 0.080);
-              sa.quality = m_ctx->ws_q.as<double>();
-              sa.q_stride = QS;
-              sa.table.packed = sync.packed_refine.as<int>();
-              sa.table.rows_per_bit = sync.host.rows_per_bit;
-              ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 324.0);
-              AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
-            }
-          AWM_HIP_CHECK (hipMemcpyAsync (q.data(), m_ctx->ws_q.ptr, q.size() * sizeof (double), hipMemcpyDeviceToHost, st));
-        }
-      AWM_HIP_CHECK (hipStreamSynchronize (st));
-      for (size_t c = 0; c < nb; c++)
-        {
-          const SearchScore& s = scores[c0 + c];
-          double best_quality = s.raw_quality;
-          size_t best_index = s.index;
-          for (int t = 0; t < lane_count[c]; t++)
-            {
-              const double qt = q[c * QS + t];
-              if (std::fabs (qt - s.local_mean) > std::fabs (best_quality - s.local_mean))
-                {
-                  best_quality = qt;
-                  best_index = starts[c] + t * Params::sync_search_fine;
-                }
-            }
-          refined.push_back ({ best_index, best_quality, s.local_mean });
+          stream_base[c * NW + w] = start + (long long) sync.want_list[w] * Params::frame_size;
+          stream_count[c * NW + w] = count;
         }
     }
-  std::stable_sort (refined.begin(), refined.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
-  scores.swap (refined);
+  auto *d_base = m_ctx->ws_idx.as<long long>();
+  int *d_count = reinterpret_cast<int *> (d_base + nb * NW);
+  int *d_lanes = d_count + nb * NW;
+  AWM_HIP_CHECK (hipMemcpyAsync (d_base, stream_base, in_bytes, hipMemcpyHostToDevice, st));
+
+  double *q = pin_q.as<double>();
+  std::fill (q, q + nb * QS, 0.0);
+  if (max_count > 0)
+    {
+      awmk::SyncDbArgs da {};
+      da.pcm = wav.data;
+      da.n_frames = wav.n_frames;
+      da.n_channels = wav.n_channels;
+      da.per_channel = 0;
+      da.stream_base = d_base;
+      da.stream_count = d_count;
+      da.count0 = max_count;
+      da.n_streams = (long long) nb * NW;
+      da.hop = Params::sync_search_fine;
+      da.out = m_ctx->ws_refine.as<float>();
+      da.out_stream_stride = (long long) row_values * TP;
+      if (gathered)
+        {
+          da.row_perm = sync.refine_perm.as<int>();
+          da.band_pos = sync.refine_pos.as<unsigned char>();
+          da.rows_per_plane = NW;
+        }
+      da.ld = TP;
+      da.have = m_ctx->ws_refine_have.as<char>();
+      da.have_stream_stride = TP;
+      da.first = (long long) m_first;
+      da.last = (long long) m_last;
+      da.tile_frames = TP;
+      {
+        ProfScope ps (m_ctx, PROF_REFINE_DB, db_bytes);
+        if (gathered)
+          AWM_HIP_CHECK (awmk::launch_sync_db_sliding (st, m_ctx->tabs, da));       // K4s: sliding DFT over the fine offsets
+        else
+          AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));               // K4: one FFT per fine offset
+      }
+      if (gathered)
+        {
+          awmk::GatheredScanArgs ga {};
+          ga.db = m_ctx->ws_refine.as<float>();
+          ga.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
+          ga.plane_stride = (long long) per_cand;
+          ga.have_plane_stride = (long long) NW * TP;
+          ga.ld = TP;
+          ga.rows_per_bit = sync.host.rows_per_bit;
+          ga.n_lanes = max_count;
+          ga.lane_count = d_lanes;
+          ga.n_planes = (long long) nb;
+          ga.min_delta = std::min (Params::water_delta, 0.080);
+          ga.quality = m_ctx->ws_q.as<double>();
+          ga.q_stride = QS;
+          ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 4.0 * row_values);
+          AWM_HIP_CHECK (awmk::launch_sync_scan_gathered (st, ga));
+        }
+      else
+        {
+          awmk::SyncScanArgs sa {};
+          sa.db = m_ctx->ws_refine.as<float>();
+          sa.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
+          sa.plane_stride = (long long) per_cand;
+          sa.have_plane_stride = (long long) NW * TP;
+          sa.row_stride = (long long) Params::n_bands * TP;
+          sa.band_stride = TP;
+          sa.have_row_stride = TP;
+          sa.n_lanes = max_count;
+          sa.lane_count = d_lanes;
+          sa.n_planes = (long long) nb;
+          sa.min_delta = std::min (Params::water_delta, 0.080);
+          sa.quality = m_ctx->ws_q.as<double>();
+          sa.q_stride = QS;
+          sa.table.packed = sync.packed_refine.as<int>();
+          sa.table.rows_per_bit = sync.host.rows_per_bit;
+          ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 324.0);
+          AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
+        }
+      AWM_HIP_CHECK (hipMemcpyAsync (q, m_ctx->ws_q.ptr, nb * QS * sizeof (double), hipMemcpyDeviceToHost, st));
+    }
+  hipEvent_t& ev = m_ctx->ev_refine[job.slot];
+  if (!ev)
+    AWM_HIP_CHECK (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
+  AWM_HIP_CHECK (hipEventRecord (ev, st));
+  job.batch_pending = true;
+  return 0;
+}
+
+int
+SyncFinder::refine_batch_finish (SearchJob& job)
+{
+  if (!job.batch_pending)
+    return 0;
+  AWM_HIP_CHECK (hipEventSynchronize (m_ctx->ev_refine[job.slot]));
+  job.batch_pending = false;
+  const double *q = m_ctx->pin_refine_q[job.slot].as<double>();
+  for (size_t c = 0; c < job.nb; c++)
+    {
+      const SearchScore& s = job.candidates[job.c0 + c];
+      double best_quality = s.raw_quality;
+      size_t best_index = s.index;
+      for (int t = 0; t < job.lane_count[c]; t++)
+        {
+          const double qt = q[c * REFINE_QS + t];
+          if (std::fabs (qt - s.local_mean) > std::fabs (best_quality - s.local_mean))
+            {
+              best_quality = qt;
+              best_index = job.starts[c] + t * Params::sync_search_fine;
+            }
+        }
+      job.refined.push_back ({ best_index, best_quality, s.local_mean });
+    }
+  return 0;
+}
+
+int
+SyncFinder::refine_finish (SearchJob& job, std::vector<SearchScore>& scores)
+{
+  if (int rc = refine_batch_finish (job))
+    return rc;
+  std::stable_sort (job.refined.begin(), job.refined.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
+  scores.swap (job.refined);
+  job.refined.clear();
   return 0;
 }
 
@@ -488,7 +558,18 @@ SyncFinder::prepare (const DeviceWav& wav, Mode mode)
 int
 SyncFinder::search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out)
 {
-  out.clear();
+  SearchJob job;
+  if (int rc = search_launch (key, wav, mode, job))
+    return rc;
+  return search_finish (job, out);
+}
+
+int
+SyncFinder::search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job)
+{
+  job.out.clear();
+  job.done = true;
+  job.batch_pending = false;
   KeyTables *kt = m_ctx->get_key_tables (key);
   if (!kt)
     return AWM_ERR_HIP;
@@ -501,22 +582,36 @@ SyncFinder::search (const Key& key, const DeviceWav& wav, Mode mode, std::vector
           const size_t end = (wav.n_frames / Params::frame_size) * Params::frame_size;
           int ab = 0;
           for (size_t idx = expect0; idx + step < end; idx += step)
-            out.push_back ({ idx, 1.0, (ab++ & 1) ? ConvBlockType::b : ConvBlockType::a });
+            job.out.push_back ({ idx, 1.0, (ab++ & 1) ? ConvBlockType::b : ConvBlockType::a });
         }
       return 0;
     }
   if (int rc = prepare (wav, mode))
     return rc;
-  std::vector<SearchScore> scores;
   long long n_scores = 0;
   if (int rc = approx_device (kt, wav, mode, n_scores))
     return rc;
-  if (int rc = select_candidates (n_scores, Params::sync_threshold2 * 0.75, scores))
+  if (int rc = select_candidates (n_scores, Params::sync_threshold2 * 0.75, job.candidates))
     return rc;
   if (mode == Mode::CLIP)
-    select_truncate_n (scores, std::max (Params::get_n_best, 5));
-  if (int rc = search_refine (kt, wav, mode, scores))
+    select_truncate_n (job.candidates, std::max (Params::get_n_best, 5));
+  job.done = false;
+  return refine_launch (kt, wav, mode, job);
+}
+
+int
+SyncFinder::search_finish (SearchJob& job, std::vector<Score>& out)
+{
+  out.clear();
+  if (job.done)
+    {
+      out = job.out;
+      return 0;
+    }
+  std::vector<SearchScore> scores;
+  if (int rc = refine_finish (job, scores))
     return rc;
+  job.done = true;
   select_threshold_and_n_best (scores, Params::sync_threshold2);
   std::sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
   for (const auto& s : scores)

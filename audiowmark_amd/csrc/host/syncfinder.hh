@@ -47,6 +47,24 @@ public:
   int select_candidates (long long n_scores, double threshold, std::vector<SearchScore>& out);
   int search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& scores);
 
+  /* search() in two halves, so that a caller with several chunks can issue the next chunk's search while the
+   * refinement of this one is still running on the device (the host never leaves the GPU idle between chunks):
+   *   search_launch (chunk i + 1, job[(i + 1) & 1]);  search_finish (job[i & 1], scores_i);
+   * At most two jobs (slots 0 and 1) may be in flight. */
+  struct SearchJob
+  {
+    int    slot = 0;
+    bool   done = true;                     // nothing on the device (result already in `out`)
+    std::vector<Score> out;
+    // refinement state
+    std::vector<SearchScore> candidates, refined;
+    std::vector<int> lane_count, starts;
+    size_t c0 = 0, nb = 0;
+    bool   batch_pending = false;
+  };
+  int search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job);
+  int search_finish (SearchJob& job, std::vector<Score>& out);
+
   static void select_local_maxima (std::vector<SearchScore>& scores);
   static void mask_avg_false_positives (std::vector<SearchScore>& scores);
   static void select_threshold_and_n_best (std::vector<SearchScore>& scores, double threshold);
@@ -56,6 +74,10 @@ private:
   size_t   m_first = 0, m_last = 0;     // non-silent value range [first, last)
   int scan_silence (const DeviceWav& wav);
   int fetch_scores (long long n_scores, std::vector<SearchScore>& out);
+  int refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, SearchJob& job);
+  int refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, SearchJob& job, size_t c0, size_t nb, size_t batch);
+  int refine_batch_finish (SearchJob& job);
+  int refine_finish (SearchJob& job, std::vector<SearchScore>& scores);
 };
 
 } // namespace awm

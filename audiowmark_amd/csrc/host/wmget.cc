@@ -245,24 +245,24 @@ normalize_soft_bits (const std::vector<float>& soft_bits)
   return norm;
 }
 
-/* FFTAnalyzer::fft_range (index, 2226 frames) + mix_decode for a batch of block starts */
+/* FFTAnalyzer::fft_range (index, 2226 frames) + mix_decode for a batch of block starts; the soft bits stay on the device:
+ * block i (if ok[i]) is slot[i] of ctx->ws_soft ([slots][858] floats) */
 int
-block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
-                 std::vector<std::vector<float>>& raw_bits, std::vector<char>& ok)
+block_soft_bits_dev (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
+                     std::vector<int>& slot_of, std::vector<char>& ok)
 {
   const size_t count = mark_block_frame_count();
   const int n_bits = mark_data_frame_count() / Params::frames_per_bit;
   const int C = wav.n_channels;
-  raw_bits.assign (index.size(), {});
+  slot_of.assign (index.size(), -1);
   ok.assign (index.size(), 0);
   std::vector<long long> bases;
-  std::vector<size_t> slot;
   for (size_t i = 0; i < index.size(); i++)
     if (wav.n_values() >= (index[i] + count * Params::frame_size) * C)    // fft_range bound, reference wmcommon.cc:128-130
       {
         ok[i] = 1;
+        slot_of[i] = int (bases.size());
         bases.push_back ((long long) index[i]);
-        slot.push_back (i);
       }
   if (bases.empty())
     return 0;
@@ -270,19 +270,21 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
   const long long ld = (count + 63) & ~size_t (63);
   const long long block_stride = (long long) C * Params::n_bands * ld;
   const size_t max_batch = std::max<size_t> (1, (size_t (2) << 30) / (block_stride * sizeof (float)));
+  if (int rc = ctx->ws_soft.reserve (bases.size() * n_bits * sizeof (float))) return rc;
+  if (int rc = ctx->ws_idx.reserve (bases.size() * sizeof (long long))) return rc;
+  if (int rc = ctx->pin_blocks.reserve (bases.size() * sizeof (long long))) return rc;
+  std::copy (bases.begin(), bases.end(), ctx->pin_blocks.as<long long>());
+  AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_idx.ptr, ctx->pin_blocks.ptr, bases.size() * sizeof (long long), hipMemcpyHostToDevice, st));
   for (size_t b0 = 0; b0 < bases.size(); b0 += max_batch)
     {
       const size_t nb = std::min (max_batch, bases.size() - b0);
       if (int rc = ctx->ws_db.reserve (nb * block_stride * sizeof (float))) return rc;
-      if (int rc = ctx->ws_idx.reserve (nb * sizeof (long long))) return rc;
-      if (int rc = ctx->ws_soft.reserve (nb * n_bits * sizeof (float))) return rc;
-      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_idx.ptr, bases.data() + b0, nb * sizeof (long long), hipMemcpyHostToDevice, st));
       awmk::SyncDbArgs da {};
       da.pcm = wav.data;
       da.n_frames = wav.n_frames;
       da.n_channels = C;
       da.per_channel = 1;
-      da.stream_base = ctx->ws_idx.as<long long>();
+      da.stream_base = ctx->ws_idx.as<long long>() + b0;
       da.count0 = int (count);
       da.n_streams = (long long) nb;
       da.hop = Params::frame_size;
@@ -310,17 +312,36 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
       sb.frames_per_bit = Params::frames_per_bit;
       sb.block_frames = int (count);
       sb.n_blocks = (long long) nb;
-      sb.out = ctx->ws_soft.as<float>();
+      sb.out = ctx->ws_soft.as<float>() + b0 * n_bits;
       {
         ProfScope ps (ctx, PROF_SOFT_BITS, double (nb) * count * C * 324.0);
         AWM_HIP_CHECK (awmk::launch_soft_bits (st, sb));
       }
-      std::vector<float> host (nb * n_bits);
-      AWM_HIP_CHECK (hipMemcpyAsync (host.data(), ctx->ws_soft.ptr, host.size() * sizeof (float), hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (hipStreamSynchronize (st));
-      for (size_t i = 0; i < nb; i++)
-        raw_bits[slot[b0 + i]].assign (host.begin() + i * n_bits, host.begin() + (i + 1) * n_bits);
     }
+  return 0;
+}
+
+/* the same with the soft bits copied to the host (awm_block_soft_bits_d) */
+int
+block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
+                 std::vector<std::vector<float>>& raw_bits, std::vector<char>& ok)
+{
+  const int n_bits = mark_data_frame_count() / Params::frames_per_bit;
+  std::vector<int> slot_of;
+  raw_bits.assign (index.size(), {});
+  if (int rc = block_soft_bits_dev (ctx, kt, wav, index, slot_of, ok))
+    return rc;
+  size_t n_slots = 0;
+  for (int sl : slot_of)
+    n_slots = std::max (n_slots, size_t (sl + 1));
+  if (!n_slots)
+    return 0;
+  std::vector<float> host (n_slots * n_bits);
+  AWM_HIP_CHECK (hipMemcpyAsync (host.data(), ctx->ws_soft.ptr, host.size() * sizeof (float), hipMemcpyDeviceToHost, ctx->stream));
+  AWM_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  for (size_t i = 0; i < index.size(); i++)
+    if (slot_of[i] >= 0)
+      raw_bits[i].assign (host.begin() + size_t (slot_of[i]) * n_bits, host.begin() + size_t (slot_of[i] + 1) * n_bits);
   return 0;
 }
 
@@ -432,53 +453,143 @@ viterbi_decode (awm_ctx *ctx, ConvBlockType block_type, const std::vector<std::v
 
 namespace {
 
-struct PatternRawBits
+struct PatternRawBits      // a decoded block: where its raw soft bits live on the device
 {
-  size_t             index;
-  double             quality;
-  std::vector<float> raw_bit_vec;
-  ConvBlockType      block_type;
+  size_t        index;
+  double        quality;
+  int           slot;        // row of ctx->ws_soft
+  ConvBlockType block_type;
 };
 
 struct PendingDecode       // one Viterbi job and what to do with its result
 {
   ConvBlockType      code_type;
-  std::vector<float> soft;
+  int                mode;            // awmk::SoftJobDev::mode
+  std::vector<std::pair<int, int>> src;      // (slot, half)
+  int                norm0, norm1;
   double             time;
   SyncFinder::Score  score;
   ResultSet::Type    type;
   size_t             chunk = 0;       // which chunk's ResultSet receives the pattern
 };
 
-// every pending decode of a stream goes to the GPU in ONE launch (A, B and AB blocks side by side)
+// Every pending decode of a stream goes to the GPU in one pass: K7b builds the normalised decoder inputs from the raw
+// soft bits that are already on the device, K8 decodes A, B and AB blocks side by side; only payload bits come back.
 int
-run_pending (awm_ctx *ctx, const Key& key, std::vector<PendingDecode>& pending, const std::vector<ResultSet *>& result_sets, double speed)
+run_pending (awm_ctx *ctx, KeyTables *kt, const Key& key, std::vector<PendingDecode>& pending, const std::vector<ResultSet *>& result_sets, double speed)
 {
-  std::vector<std::vector<float>> soft[3];
+  if (pending.empty())
+    return 0;
+  hipStream_t st = ctx->stream;
+  const int n_bits = mark_data_frame_count() / Params::frames_per_bit;                 // 858
+  const size_t n_steps = size_t (n_bits) / 6;                                          // trellis steps (payload + 15)
+  const size_t n_out = n_steps - conv_order;
+  const size_t max_batch = 512;                                                        // decodes per launch and code type
   std::vector<size_t> which[3];
   for (size_t i = 0; i < pending.size(); i++)
+    which[int (pending[i].code_type)].push_back (i);
+  std::vector<std::vector<int>> bits (pending.size());
+  std::vector<float> errors (pending.size(), 0.f);
+  size_t done[3] = { 0, 0, 0 };
+  while (done[0] < which[0].size() || done[1] < which[1].size() || done[2] < which[2].size())
     {
-      const int t = int (pending[i].code_type);
-      soft[t].push_back (std::move (pending[i].soft));
-      which[t].push_back (i);
+      size_t nb[3], in_off[3], ws_off[3], bits_off[3], err_off[3];
+      size_t in_total = 0, ws_total = 0, bits_total = 0, err_total = 0, n_jobs = 0, n_src = 0;
+      for (int t = 0; t < 3; t++)
+        {
+          const size_t rate = t == 2 ? 12 : 6;
+          nb[t] = std::min (max_batch, which[t].size() - done[t]);
+          in_off[t] = in_total;    in_total += nb[t] * n_steps * rate;
+          ws_off[t] = ws_total;    ws_total += awmk::viterbi_workspace_bytes (n_steps * rate, rate, nb[t]);
+          bits_off[t] = bits_total; bits_total += nb[t] * n_out;
+          err_off[t] = err_total;  err_total += nb[t];
+          n_jobs += nb[t];
+          for (size_t i = 0; i < nb[t]; i++)
+            n_src += pending[which[t][done[t] + i]].src.size();
+        }
+      // job table + source list: one page-locked block, one copy
+      const size_t jobs_bytes = (n_jobs * sizeof (awmk::SoftJobDev) + 15) & ~size_t (15);
+      const size_t table_bytes = jobs_bytes + n_src * sizeof (int2);
+      if (int rc = ctx->pin_jobs.reserve (table_bytes)) return rc;
+      if (int rc = ctx->ws_jobs.reserve (table_bytes)) return rc;
+      auto *jobs = ctx->pin_jobs.as<awmk::SoftJobDev>();
+      auto *srcs = reinterpret_cast<int2 *> (ctx->pin_jobs.as<char>() + jobs_bytes);
+      size_t j = 0, so = 0;
+      for (int t = 0; t < 3; t++)
+        {
+          const size_t len = n_steps * (t == 2 ? 12 : 6);
+          for (size_t i = 0; i < nb[t]; i++)
+            {
+              const PendingDecode& p = pending[which[t][done[t] + i]];
+              jobs[j].mode = p.mode;
+              jobs[j].n_src = int (p.src.size());
+              jobs[j].src_off = int (so);
+              jobs[j].len = int (len);
+              jobs[j].norm0 = p.norm0;
+              jobs[j].norm1 = p.norm1;
+              jobs[j].out_off = (long long) (in_off[t] + i * len);
+              for (const auto& sp : p.src)
+                srcs[so++] = make_int2 (sp.first, sp.second);
+              j++;
+            }
+        }
+      if (int rc = ctx->ws_viterbi_in.reserve (std::max<size_t> (1, in_total) * sizeof (float))) return rc;
+      if (int rc = ctx->ws_viterbi.reserve (std::max<size_t> (1, ws_total))) return rc;
+      if (int rc = ctx->ws_viterbi_bits.reserve (std::max<size_t> (1, bits_total) * sizeof (int) + err_total * sizeof (float))) return rc;
+      if (int rc = ctx->pin_bits.reserve (bits_total * sizeof (int) + err_total * sizeof (float))) return rc;
+      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_jobs.ptr, ctx->pin_jobs.ptr, table_bytes, hipMemcpyHostToDevice, st));
+      awmk::SoftPrepArgs pa {};
+      pa.raw = ctx->ws_soft.as<float>();
+      pa.n_bits = n_bits;
+      pa.inv_order = kt->bit_order_inv_dev.as<int>();
+      pa.jobs = ctx->ws_jobs.as<awmk::SoftJobDev>();
+      pa.src = reinterpret_cast<const int2 *> (ctx->ws_jobs.as<char>() + jobs_bytes);
+      pa.n_jobs = (long long) n_jobs;
+      pa.hard = Params::hard ? 1 : 0;
+      pa.out = ctx->ws_viterbi_in.as<float>();
+      const float *d_soft[3];
+      unsigned char *d_ws[3];
+      int *d_bits[3];
+      float *d_err[3];
+      long long n_blocks[3];
+      double bytes = 0;
+      float *err_base = reinterpret_cast<float *> (ctx->ws_viterbi_bits.as<int>() + bits_total);     // bits and errors: one block, one copy back
+      for (int t = 0; t < 3; t++)
+        {
+          d_soft[t] = ctx->ws_viterbi_in.as<float>() + in_off[t];
+          d_ws[t] = ctx->ws_viterbi.as<unsigned char>() + ws_off[t];
+          d_bits[t] = ctx->ws_viterbi_bits.as<int>() + bits_off[t];
+          d_err[t] = err_base + err_off[t];
+          n_blocks[t] = (long long) nb[t];
+          bytes += double (nb[t]) * n_steps * (t == 2 ? 12 : 6) * 4.0;
+        }
+      {
+        ProfScope ps (ctx, PROF_VITERBI, 2.0 * bytes + 2.0 * ws_total);
+        AWM_HIP_CHECK (awmk::launch_soft_prep (st, pa));
+        AWM_HIP_CHECK (awmk::launch_viterbi (st, d_soft, n_blocks, (long long) n_steps, d_ws, d_bits, d_err));
+      }
+      AWM_HIP_CHECK (hipMemcpyAsync (ctx->pin_bits.ptr, ctx->ws_viterbi_bits.ptr, bits_total * sizeof (int) + err_total * sizeof (float),
+                                     hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      const int *hbits = ctx->pin_bits.as<int>();
+      const float *herr = reinterpret_cast<const float *> (hbits + bits_total);
+      for (int t = 0; t < 3; t++)
+        {
+          for (size_t i = 0; i < nb[t]; i++)
+            {
+              const size_t pi = which[t][done[t] + i];
+              bits[pi].assign (hbits + bits_off[t] + i * n_out, hbits + bits_off[t] + (i + 1) * n_out);
+              errors[pi] = herr[err_off[t] + i];
+            }
+          done[t] += nb[t];
+        }
     }
-  std::vector<std::vector<int>> bits[3];
-  std::vector<float> errors[3];
-  if (int rc = viterbi_decode_all (ctx, soft, bits, errors))
-    return rc;
   // patterns are added in submission order (A/B block patterns first, then AB, then "all" -- like the reference's job order)
-  std::vector<std::pair<size_t, std::pair<int, size_t>>> order;
-  for (int t = 0; t < 3; t++)
-    for (size_t j = 0; j < which[t].size(); j++)
-      order.push_back ({ which[t][j], { t, j } });
-  std::sort (order.begin(), order.end());
-  for (const auto& o : order)
+  for (size_t i = 0; i < pending.size(); i++)
     {
-      const PendingDecode& p = pending[o.first];
-      const int t = o.second.first;
-      const size_t j = o.second.second;
-      if (!bits[t][j].empty())
-        result_sets[p.chunk]->add_pattern (key, p.time, p.score, bits[t][j], errors[t][j], p.type, speed);
+      const PendingDecode& p = pending[i];
+      if (!bits[i].empty())
+        result_sets[p.chunk]->add_pattern (key, p.time, p.score, bits[i], errors[i], p.type, speed);
     }
   return 0;
 }
@@ -509,15 +620,9 @@ combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const Device
         continue;
       const auto& a_pattern = pattern_raw_vec[best_j];
       const auto& b_pattern = pattern_raw_vec[i];
-      std::vector<float> ab_bits (a_pattern.raw_bit_vec.size() * 2);
-      for (size_t k = 0; k < a_pattern.raw_bit_vec.size(); k++)
-        {
-          ab_bits[2 * k] = a_pattern.raw_bit_vec[k];
-          ab_bits[2 * k + 1] = b_pattern.raw_bit_vec[k];
-        }
       SyncFinder::Score score_ab { b_pattern.index, (a_pattern.quality + b_pattern.quality) / 2, ConvBlockType::ab };
-      pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (ab_bits), double (b_pattern.index) / wav.sample_rate,
-                           score_ab, ResultSet::Type::BLOCK, chunk });
+      pending.push_back ({ ConvBlockType::ab, 1, { { a_pattern.slot, 0 }, { b_pattern.slot, 1 } }, 0, 0,
+                           double (b_pattern.index) / wav.sample_rate, score_ab, ResultSet::Type::BLOCK, chunk });
     }
   /* all: best chain of consecutive, alternating blocks */
   std::vector<size_t> best_all_blocks;
@@ -562,7 +667,8 @@ combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const Device
     }
   if (best_all_blocks.size() > 1)
     {
-      std::vector<float> all_bits (code_size (ConvBlockType::ab, Params::payload_size));
+      // all_bits[2 k + ab] = sum over the chain's blocks of that type (list order) / their number: done by K7b (mode 2)
+      std::vector<std::pair<int, int>> src;
       int norm[2] = { 0, 0 };
       SyncFinder::Score score_all { 0, 0, ConvBlockType::a };
       for (auto bi : best_all_blocks)
@@ -570,17 +676,11 @@ combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const Device
           const auto& pattern = pattern_raw_vec[bi];
           score_all.quality += pattern.quality;
           const int ab = pattern.block_type == ConvBlockType::b ? 1 : 0;
-          for (size_t k = 0; k < pattern.raw_bit_vec.size(); k++)
-            all_bits[2 * k + ab] += pattern.raw_bit_vec[k];
+          src.push_back ({ pattern.slot, ab });
           norm[ab]++;
         }
-      for (size_t k = 0; k < all_bits.size(); k += 2)
-        {
-          all_bits[k]     /= std::max (norm[0], 1);
-          all_bits[k + 1] /= std::max (norm[1], 1);
-        }
       score_all.quality /= norm[0] + norm[1];
-      pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (all_bits), 0.0, score_all, ResultSet::Type::ALL, chunk });
+      pending.push_back ({ ConvBlockType::ab, 2, src, norm[0], norm[1], 0.0, score_all, ResultSet::Type::ALL, chunk });
     }
 }
 
@@ -602,19 +702,41 @@ block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceW
         return AWM_ERR_HIP;
       std::vector<std::vector<SyncFinder::Score>> scores (chunks.size());
       std::vector<size_t> abs_index;
+      auto chunk_wav = [&] (size_t c) {
+        DeviceWav cw = stream;
+        cw.data = stream.data + chunks[c].first_frame * stream.n_channels;
+        cw.n_frames = chunks[c].n_frames;
+        return cw;
+      };
+      // software pipeline over the chunks: chunk c + 1 is searched (kernels queued) before chunk c's refinement is
+      // collected, so the device always has work while the host evaluates results
+      SyncFinder::SearchJob jobs[2];
+      jobs[0].slot = 0;
+      jobs[1].slot = 1;
+      auto collect = [&] (size_t c) -> int {
+        if (int rc = sync_finder.search_finish (jobs[c & 1], scores[c]))
+          return rc;
+        return 0;
+      };
       for (size_t c = 0; c < chunks.size(); c++)
         {
-          DeviceWav cw = stream;
-          cw.data = stream.data + chunks[c].first_frame * stream.n_channels;
-          cw.n_frames = chunks[c].n_frames;
-          if (int rc = sync_finder.search (key, cw, SyncFinder::Mode::BLOCK, scores[c]))
+          if (int rc = sync_finder.search_launch (key, chunk_wav (c), SyncFinder::Mode::BLOCK, jobs[c & 1]))
             return rc;
+          if (c > 0)
+            if (int rc = collect (c - 1))
+              return rc;
+        }
+      if (!chunks.empty())
+        if (int rc = collect (chunks.size() - 1))
+          return rc;
+      for (size_t c = 0; c < chunks.size(); c++)
+        {
           if (ki == 0 && c == 0)
             first_scores = scores[c];
           for (const auto& s : scores[c])
             {
               // fft_range refuses blocks that run past the end OF THE CHUNK (reference wmcommon.cc:128-130)
-              const bool ok = cw.n_frames >= s.index + count * Params::frame_size;
+              const bool ok = chunks[c].n_frames >= s.index + count * Params::frame_size;
               abs_index.push_back (ok ? chunks[c].first_frame + s.index : size_t (-1));
             }
         }
@@ -622,9 +744,9 @@ block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceW
       for (size_t v : abs_index)
         if (v != size_t (-1))
           wanted.push_back (v);
-      std::vector<std::vector<float>> raw;
+      std::vector<int> slot_of;
       std::vector<char> ok;
-      if (int rc = block_soft_bits (ctx, kt, stream, wanted, raw, ok))
+      if (int rc = block_soft_bits_dev (ctx, kt, stream, wanted, slot_of, ok))
         return rc;
 
       std::vector<PendingDecode> pending;
@@ -636,19 +758,18 @@ block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceW
             {
               if (abs_index[flat++] == size_t (-1))
                 continue;
-              const std::vector<float>& bits = raw[got++];
               PatternRawBits rb;
               rb.index = s.index;
               rb.quality = s.quality;
-              rb.raw_bit_vec = apply_bit_order (kt->bit_order_a, bits, /* encode */ false);   // randomize_bit_order, permutation cached per key
+              rb.slot = slot_of[got++];
               rb.block_type = s.block_type;
-              pending.push_back ({ rb.block_type, normalize_soft_bits (rb.raw_bit_vec), double (rb.index) / stream.sample_rate,
+              pending.push_back ({ rb.block_type, 0, { { rb.slot, 0 } }, 0, 0, double (rb.index) / stream.sample_rate,
                                    s, ResultSet::Type::BLOCK, c });
-              pattern_raw_vec.push_back (std::move (rb));
+              pattern_raw_vec.push_back (rb);
             }
           combine_blocks (pattern_raw_vec, stream, c, pending);
         }
-      if (int rc = run_pending (ctx, key, pending, result_sets, speed))
+      if (int rc = run_pending (ctx, kt, key, pending, result_sets, speed))
         return rc;
     }
   if (debug_sync_first_chunk)
@@ -695,37 +816,23 @@ clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav
           index.push_back (s.index);
           index.push_back (s.index + count * Params::frame_size);
         }
-      std::vector<std::vector<float>> raw;
+      std::vector<int> slot_of;
       std::vector<char> ok;
-      if (int rc = block_soft_bits (ctx, kt, wav, index, raw, ok))
+      if (int rc = block_soft_bits_dev (ctx, kt, wav, index, slot_of, ok))
         return rc;
       std::vector<PendingDecode> pending;
       for (size_t i = 0; i < sync_scores.size(); i++)
         {
           if (!ok[2 * i] || !ok[2 * i + 1])
             continue;
-          const auto bits1 = apply_bit_order (kt->bit_order_a, raw[2 * i], false);
-          const auto bits2 = apply_bit_order (kt->bit_order_a, raw[2 * i + 1], false);
-          std::vector<float> ab;
-          ab.reserve (bits1.size() * 2);
-          for (size_t k = 0; k < bits1.size(); k++)
-            {
-              if (sync_scores[i].block_type == ConvBlockType::a)
-                {
-                  ab.push_back (bits1[k]);
-                  ab.push_back (bits2[k]);
-                }
-              else
-                {
-                  ab.push_back (bits2[k]);
-                  ab.push_back (bits1[k]);
-                }
-            }
+          // the block at the sync position carries the half its type says, the following block the other one
+          const int first_half = sync_scores[i].block_type == ConvBlockType::a ? 0 : 1;
           SyncFinder::Score nopad = sync_scores[i];
           nopad.index = time_offset_sec * wav.sample_rate;
-          pending.push_back ({ ConvBlockType::ab, normalize_soft_bits (ab), time_offset_sec, nopad, ResultSet::Type::CLIP, 0 });
+          pending.push_back ({ ConvBlockType::ab, 1, { { slot_of[2 * i], first_half }, { slot_of[2 * i + 1], 1 - first_half } }, 0, 0,
+                               time_offset_sec, nopad, ResultSet::Type::CLIP, 0 });
         }
-      if (int rc = run_pending (ctx, key, pending, { &result_set }, speed))
+      if (int rc = run_pending (ctx, kt, key, pending, { &result_set }, speed))
         return rc;
     }
   return 0;
