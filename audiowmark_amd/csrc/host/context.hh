@@ -16,6 +16,32 @@ namespace awm { void set_error (const std::string& msg); std::string hip_error_s
 
 namespace awm {
 
+// Wait for the stream (or an event) by polling: a blocking hipStreamSynchronize wakes the thread up tens of
+// microseconds late, which is paid at every point where the host has to look at a device result before it can
+// issue the next kernels.  Falls back to the blocking call after a few milliseconds.
+inline hipError_t
+stream_wait (hipStream_t st)
+{
+  for (int i = 0; i < 20000; i++)
+    {
+      const hipError_t e = hipStreamQuery (st);
+      if (e != hipErrorNotReady)
+        return e;
+    }
+  return hipStreamSynchronize (st);
+}
+inline hipError_t
+event_wait (hipEvent_t ev)
+{
+  for (int i = 0; i < 20000; i++)
+    {
+      const hipError_t e = hipEventQuery (ev);
+      if (e != hipErrorNotReady)
+        return e;
+    }
+  return hipEventSynchronize (ev);
+}
+
 // grow-only device buffer
 struct DevBuffer
 {

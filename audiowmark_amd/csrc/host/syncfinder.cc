@@ -21,7 +21,7 @@ SyncFinder::scan_silence (const DeviceWav& wav)
   AWM_HIP_CHECK (awmk::launch_nonzero_range (m_ctx->stream, wav.data, (long long) wav.n_values(), res));
   unsigned long long h[2];
   AWM_HIP_CHECK (hipMemcpyAsync (h, res, sizeof (h), hipMemcpyDeviceToHost, m_ctx->stream));
-  AWM_HIP_CHECK (hipStreamSynchronize (m_ctx->stream));
+  AWM_HIP_CHECK (stream_wait (m_ctx->stream));
   m_first = h[0];
   m_last = h[0] >= wav.n_values() ? wav.n_values() : h[1];
   return 0;
@@ -48,7 +48,7 @@ SyncFinder::fetch_scores (long long n_scores, std::vector<SearchScore>& out)
   std::vector<double> raw (n_scores), mean (n_scores);
   AWM_HIP_CHECK (hipMemcpyAsync (raw.data(), m_ctx->ws_raw.ptr, raw.size() * sizeof (double), hipMemcpyDeviceToHost, st));
   AWM_HIP_CHECK (hipMemcpyAsync (mean.data(), m_ctx->ws_mean.ptr, mean.size() * sizeof (double), hipMemcpyDeviceToHost, st));
-  AWM_HIP_CHECK (hipStreamSynchronize (st));
+  AWM_HIP_CHECK (stream_wait (st));
   out.resize (raw.size());
   for (size_t p = 0; p < raw.size(); p++)
     {
@@ -161,7 +161,7 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
   if (int rc = m_ctx->pin_peaks.reserve (256 + cap * sizeof (awmk::PeakOut))) return rc;
   char *pin = m_ctx->pin_peaks.as<char>();
   AWM_HIP_CHECK (hipMemcpyAsync (pin, d_count, 256 + head * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
-  AWM_HIP_CHECK (hipStreamSynchronize (st));
+  AWM_HIP_CHECK (stream_wait (st));
   unsigned int count = *reinterpret_cast<unsigned int *> (pin);
   if (int (count) >= Params::get_n_best && count <= cap)
     {
@@ -169,7 +169,7 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
         {
           AWM_HIP_CHECK (hipMemcpyAsync (pin + 256 + head * sizeof (awmk::PeakOut), d_out + head, (count - head) * sizeof (awmk::PeakOut),
                                          hipMemcpyDeviceToHost, st));
-          AWM_HIP_CHECK (hipStreamSynchronize (st));
+          AWM_HIP_CHECK (stream_wait (st));
         }
       const auto *pk0 = reinterpret_cast<const awmk::PeakOut *> (pin + 256);
       std::vector<awmk::PeakOut> peaks (pk0, pk0 + count);
@@ -200,7 +200,7 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
       AWM_HIP_CHECK (awmk::launch_peak_topk (st, d_all, d_count, big_cap, d_top, k, n_slices));
       std::vector<awmk::PeakOut> top (size_t (k) * n_slices);
       AWM_HIP_CHECK (hipMemcpyAsync (top.data(), d_top, top.size() * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      AWM_HIP_CHECK (stream_wait (st));
       top.erase (std::remove_if (top.begin(), top.end(), [] (const awmk::PeakOut& pk) { return pk.p < 0; }), top.end());
       auto absq = [] (const awmk::PeakOut& pk) { return std::fabs (pk.raw - pk.mean); };
       std::sort (top.begin(), top.end(), [&] (const awmk::PeakOut& a, const awmk::PeakOut& b) {
@@ -220,7 +220,7 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
         }
     }
   AWM_HIP_CHECK (hipMemcpyAsync (&count, d_count, sizeof (count), hipMemcpyDeviceToHost, st));
-  AWM_HIP_CHECK (hipStreamSynchronize (st));
+  AWM_HIP_CHECK (stream_wait (st));
   if (count > big_cap)
     {
       // cannot happen (at most every second score is a maximum); keep the sequential formulation as a safety net
@@ -235,7 +235,7 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
   if (count)
     {
       AWM_HIP_CHECK (hipMemcpyAsync (peaks.data(), d_all, count * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      AWM_HIP_CHECK (stream_wait (st));
     }
   std::sort (peaks.begin(), peaks.end(), [] (const awmk::PeakOut& a, const awmk::PeakOut& b) { return a.p < b.p; });   // index order, as the reference's list
   for (const auto& pk : peaks)
@@ -511,7 +511,7 @@ SyncFinder::refine_batch_finish (SearchJob& job)
 {
   if (!job.batch_pending)
     return 0;
-  AWM_HIP_CHECK (hipEventSynchronize (m_ctx->ev_refine[job.slot]));
+  AWM_HIP_CHECK (event_wait (m_ctx->ev_refine[job.slot]));
   job.batch_pending = false;
   const double *q = m_ctx->pin_refine_q[job.slot].as<double>();
   for (size_t c = 0; c < job.nb; c++)

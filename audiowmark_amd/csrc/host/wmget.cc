@@ -338,7 +338,7 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
     return 0;
   std::vector<float> host (n_slots * n_bits);
   AWM_HIP_CHECK (hipMemcpyAsync (host.data(), ctx->ws_soft.ptr, host.size() * sizeof (float), hipMemcpyDeviceToHost, ctx->stream));
-  AWM_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  AWM_HIP_CHECK (stream_wait (ctx->stream));
   for (size_t i = 0; i < index.size(); i++)
     if (slot_of[i] >= 0)
       raw_bits[i].assign (host.begin() + size_t (slot_of[i]) * n_bits, host.begin() + size_t (slot_of[i] + 1) * n_bits);
@@ -420,7 +420,7 @@ viterbi_decode_all (awm_ctx *ctx, const std::vector<std::vector<float>> soft[3],
       std::vector<float> herr (err_total);
       AWM_HIP_CHECK (hipMemcpyAsync (hbits.data(), ctx->ws_viterbi_bits.ptr, hbits.size() * sizeof (int), hipMemcpyDeviceToHost, st));
       AWM_HIP_CHECK (hipMemcpyAsync (herr.data(), ctx->ws_viterbi_err.ptr, herr.size() * sizeof (float), hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      AWM_HIP_CHECK (stream_wait (st));
       for (int t = 0; t < 3; t++)
         {
           for (size_t i = 0; i < nb[t]; i++)
@@ -570,7 +570,7 @@ run_pending (awm_ctx *ctx, KeyTables *kt, const Key& key, std::vector<PendingDec
       }
       AWM_HIP_CHECK (hipMemcpyAsync (ctx->pin_bits.ptr, ctx->ws_viterbi_bits.ptr, bits_total * sizeof (int) + err_total * sizeof (float),
                                      hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (hipStreamSynchronize (st));
+      AWM_HIP_CHECK (stream_wait (st));
       const int *hbits = ctx->pin_bits.as<int>();
       const float *herr = reinterpret_cast<const float *> (hbits + bits_total);
       for (int t = 0; t < 3; t++)
