@@ -1220,6 +1220,7 @@ sync_scan_window_kernel (SyncScanArgs a, int total_frames)
 
   float umag = 0.f, dmag = 0.f;
   int n = 0, r = 0;
+  int fr = R > 0 ? tab[60] : 0x7fffffff;                  // frame of row r; the table row carries its successor's ([61])
   load_slot (0);
   load_slot (1);
   for (int k = 0; 64 * k < total_frames; k++)
@@ -1227,12 +1228,9 @@ sync_scan_window_kernel (SyncScanArgs a, int total_frames)
       load_slot (k + 2);
       __syncthreads();
       const int ring0 = 64 * ((k + sub) % 3) - 64 * k;      // + fr = ring position of this wave's lane 0 (before the wrap)
-      while (r < R)
+      while (fr < 64 * (k + 1))
         {
           const_int_ptr tr = tab + r * 64;
-          const int fr = tr[60];
-          if (fr >= 64 * (k + 1))
-            break;
           int phys = fr + ring0 + lane;                      // < 128 + 64 + 64
           phys -= phys >= RING ? RING : 0;
           float uv[30], dv[30];
@@ -1248,6 +1246,7 @@ sync_scan_window_kernel (SyncScanArgs a, int total_frames)
               umag = __fadd_rn (umag, uv[i]);
               dmag = __fadd_rn (dmag, dv[i]);
             }
+          fr = tr[61];
           n++;
           r++;
         }

@@ -100,6 +100,9 @@ pack_sync_table (const SyncTable& t, const std::vector<int>& want_pos /* empty: 
             row[30 + i] = t.down[src * 30 + i];
           }
         row[60] = want_pos.empty() ? t.frame[src] : want_pos[t.frame[src]];
+        // [61]: row index of the NEXT row of this bit (or a sentinel), so that a scan that stops at a frame limit
+        // knows the next frame without another dependent load (K5w)
+        row[61] = r + 1 < R ? (want_pos.empty() ? t.frame[src + 1] : want_pos[t.frame[src + 1]]) : 0x7fffffff;
       }
   return packed;
 }
