@@ -894,6 +894,21 @@ launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
  * ========================================================================================== */
 constexpr int SL_TILE = 16;                                   // fine offsets buffered in LDS between flushes
 
+__device__ __forceinline__ double
+dpp_from_lower_lane (double v)                                // lane i receives lane i - 1's value
+{
+  const int lo = __builtin_amdgcn_update_dpp (0, __double2loint (v), 0x138, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp (0, __double2hiint (v), 0x138, 0xf, 0xf, false);
+  return __hiloint2double (hi, lo);
+}
+__device__ __forceinline__ double
+dpp_from_upper_lane (double v)                                // lane i receives lane i + 1's value
+{
+  const int lo = __builtin_amdgcn_update_dpp (0, __double2loint (v), 0x130, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp (0, __double2hiint (v), 0x130, 0xf, 0xf, false);
+  return __hiloint2double (hi, lo);
+}
+
 template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
 sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 {
@@ -901,6 +916,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
   __shared__ __attribute__ ((aligned (16))) float s_scratch[WAVES][NB * SL_TILE];      // FFT exchange tile (>= 576 float2) / dB tile [offset][band]
   static_assert (NB * SL_TILE * sizeof (float) >= XBUF_ELEMS * sizeof (float2), "scratch too small for the FFT tile");
   __shared__ unsigned char s_pos[WAVES][NB + 3];
+  __shared__ __attribute__ ((aligned (16))) double s_delta[WAVES][SL_TILE * 8 * CV];     // sample differences of 16 steps
   for (int i = threadIdx.x; i < 512; i += blockDim.x)
     s_tw[i] = t.tw512[i];
   {
@@ -967,23 +983,41 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
     for (int j = 0; j < 9; j++)
       tw[b][j] = t.slide[(kA + b - 19) * 9 + j];
 
-  // sample feed: lanes [0, 8 C) hold the 8 C samples entering the window at the next step, lanes [8 C, 16 C) those leaving
-  auto feed = [&] (int step) -> float {
-    // samples for the transition step -> step + 1
-    const long long s0 = base + 8LL * step;
-    float v = 0.f;
-    if (lane < 8 * C)
-      v = a.pcm[(s0 + 1024) * C + lane];
-    else if (lane < 16 * C)
-      v = a.pcm[s0 * C + (lane - 8 * C)];
-    return v;
+  // Sample feed.  The transition step -> step + 1 needs the 8 C samples entering the window and the 8 C leaving it.
+  // Sixteen transitions are fetched at once (both blocks are contiguous: 128 C floats, 2 C per lane), a whole block
+  // of steps before they are needed, turned into double differences and published in LDS, where every lane reads
+  // them back as broadcasts: no global load is ever waited for inside the step loop.
+  constexpr int FPL = 2 * CV;                                     // floats per lane and block
+  float f_in[FPL], f_out[FPL];
+  auto fetch_block = [&] (int q) {
+    const long long s0 = base + 128LL * q;
+#pragma unroll
+    for (int i = 0; i < FPL; i++)
+      {
+        const int e = lane * FPL + i;                             // (transition * 8 + j) * C + c
+        const int trans = SL_TILE * q + e / (8 * C);
+        const bool need = trans + 1 < count;
+        f_in[i] = need ? a.pcm[(s0 + 1024) * C + e] : 0.f;
+        f_out[i] = need ? a.pcm[s0 * C + e] : 0.f;
+      }
   };
-  float next_feed = count > 1 ? feed (0) : 0.f;
+  auto publish_block = [&] () {
+#pragma unroll
+    for (int i = 0; i < FPL; i++)
+      s_delta[wave][lane * FPL + i] = double (f_in[i]) - double (f_out[i]);
+  };
+  fetch_block (0);
   unsigned long long have_mask = 0;      // offsets 0..63
   bool have_64 = false;                  // offset 64 (a candidate has at most 65 fine offsets)
 
   for (int step = 0; step < count; step++)
     {
+      if (step % SL_TILE == 0)
+        {
+          publish_block();                                        // fetched one block of steps ago
+          wave_sync();
+          fetch_block (step / SL_TILE + 1);
+        }
       // ---- output for this fine offset
       const long long idx = base + 8LL * step;
       const long long f_first = idx * C, f_last = (idx + 1024) * C;
@@ -998,14 +1032,15 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 #pragma unroll
           for (int c = 0; c < CV; c++)
             {
-              // neighbours: R[kA - 1] lives in lane - 1 (its kB), R[kB + 1] in lane + 1 (its kA)
-              const double2 up = make_double2 (__shfl_up (R[c][1].x, 1), __shfl_up (R[c][1].y, 1));
-              const double2 dn = make_double2 (__shfl_down (R[c][0].x, 1), __shfl_down (R[c][0].y, 1));
-              const double s = 1.0 / 256;
-              const float xa_re = float ((0.5 * R[c][0].x - 0.25 * (up.x + R[c][1].x)) * s);
-              const float xa_im = float ((0.5 * R[c][0].y - 0.25 * (up.y + R[c][1].y)) * s);
-              const float xb_re = float ((0.5 * R[c][1].x - 0.25 * (R[c][0].x + dn.x)) * s);
-              const float xb_im = float ((0.5 * R[c][1].y - 0.25 * (R[c][0].y + dn.y)) * s);
+              // neighbours: R[kA - 1] lives in lane - 1 (its kB), R[kB + 1] in lane + 1 (its kA): DPP wave shifts
+              const double2 up = make_double2 (dpp_from_lower_lane (R[c][1].x), dpp_from_lower_lane (R[c][1].y));
+              const double2 dn = make_double2 (dpp_from_upper_lane (R[c][0].x), dpp_from_upper_lane (R[c][0].y));
+              // X[k] = (R[k] / 2 - (R[k-1] + R[k+1]) / 4) / 256 = (2 R[k] - (R[k-1] + R[k+1])) / 1024: one rounding in the
+              // subtraction either way, the power of two scalings are exact
+              const float xa_re = float (fma (2.0, R[c][0].x, -(up.x + R[c][1].x))) * 0x1p-10f;
+              const float xa_im = float (fma (2.0, R[c][0].y, -(up.y + R[c][1].y))) * 0x1p-10f;
+              const float xb_re = float (fma (2.0, R[c][1].x, -(R[c][0].x + dn.x))) * 0x1p-10f;
+              const float xb_im = float (fma (2.0, R[c][1].y, -(R[c][0].y + dn.y))) * 0x1p-10f;
               dbA = __fadd_rn (dbA, db_from_complex (make_float2 (xa_re, xa_im)));
               dbB = __fadd_rn (dbB, db_from_complex (make_float2 (xb_re, xb_im)));
             }
@@ -1037,10 +1072,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
       // ---- advance by 8 samples
       if (step + 1 < count)
         {
-          const float v = next_feed;
-          if (step + 2 < count)
-            next_feed = feed (step + 1);
-          const double delta = double (v) - double (__shfl_down (v, 8 * C));    // lanes [0, 8 C): entering - leaving
+          const double *dl = s_delta[wave] + (step % SL_TILE) * 8 * C;
 #pragma unroll
           for (int c = 0; c < CV; c++)
             {
@@ -1048,9 +1080,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 #pragma unroll
               for (int j = 0; j < 8; j++)
                 {
-                  const int src = j * C + c;
-                  const double d = __hiloint2double (__builtin_amdgcn_readlane (__double2hiint (delta), src),
-                                                     __builtin_amdgcn_readlane (__double2loint (delta), src));
+                  const double d = dl[j * C + c];
 #pragma unroll
                   for (int b = 0; b < 2; b++)
                     {
@@ -1066,6 +1096,8 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
                 }
             }
         }
+      if (step % SL_TILE == SL_TILE - 1)
+        wave_sync();                                              // all reads of this block's differences done
     }
   if (a.have && lane < count)
     a.have[out_slot * a.have_stream_stride + lane] = (have_mask >> lane) & 1;
