@@ -72,6 +72,7 @@ struct SyncDbArgs
   long long    have_stream_stride;
   long long    first, last;             // non-silent value range [first, last) (syncfinder.cc:155-169)
   int          tile_frames;             // frames per workgroup tile (<= 72)
+  int          xcd_interleave = 0;      // set by the launcher: 1-D grid, the streams of one tile on the same XCD (see kernels.hip)
   // K4s only, "gathered" output for the refinement scan (K5g): stream s = plane * rows_per_plane + w writes its
   // rows to stream slot plane * rows_per_plane + row_perm[w], and band b to row band_pos[w * 81 + b] (255: dropped)
   const int           *row_perm = nullptr;

@@ -730,7 +730,11 @@ launch_fill_u32 (hipStream_t st, unsigned int *p, unsigned int v, size_t n)
 constexpr int TILE_MAX = 72;
 constexpr int TILE_LD = TILE_MAX + 1;
 
-template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
+/* SPLIT (stereo, one output plane per channel -- the block decoder's fft_range): the interleaved samples are read ONCE and
+ * both channels are transformed by the same wave; the tile holds the two planes side by side (<= 36 frames each). */
+constexpr int SPLIT_COLS = TILE_MAX / 2;
+
+template<int CV, bool SPLIT> __global__ void __launch_bounds__ (64 * WAVES)
 sync_db_kernel (DevTables t, SyncDbArgs a)
 {
   __shared__ float2 s_tw[512];
@@ -743,12 +747,22 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
   load_shared_tables (t, s_tw, s_win, s_twb);
   __syncthreads();
 
-  const long long stream = blockIdx.y;
+  // Which (stream, tile).  The approximate search transforms the SAME samples once per shift (4 streams, 256 samples
+  // apart): with xcd_interleave the grid is 1-D and workgroup id = 8 j + x runs tile 8 (j / n_streams) + x of stream
+  // j % n_streams -- ids are dealt to the XCDs round robin, so the shifts of one tile run back to back on ONE XCD and
+  // all but the first find the samples in its L2 (measured: 4x less HBM traffic, this kernel was HBM bound).
+  long long stream = blockIdx.y, tile_idx = blockIdx.x;
+  if (a.xcd_interleave)
+    {
+      const long long j = blockIdx.x >> 3;
+      stream = j % a.n_streams;
+      tile_idx = (j / a.n_streams) * 8 + (blockIdx.x & 7);
+    }
   const int plane_ch = blockIdx.z;                       // only used in per-channel mode
   const long long base = a.stream_base ? a.stream_base[stream] : a.base0 + stream * a.base_stride;
   const int count = a.stream_count ? a.stream_count[stream] : a.count0;
   const int TF = a.tile_frames;
-  const long long tile0 = (long long) blockIdx.x * TF;
+  const long long tile0 = tile_idx * TF;
   if (tile0 >= count)
     return;
   const int C = a.n_channels;
@@ -762,6 +776,7 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
       const long long f_first = idx * C, f_last = (idx + 1024) * C;
       const bool skip = (f_last < a.first) || (f_first > a.last) || idx < 0 || idx + 1024 > a.n_frames;
       float acc0 = 0.f, acc1 = 0.f;                      // bins 20 + lane, 84 + lane
+      float split0 = 0.f, split1 = 0.f;                  // SPLIT: the same for channel 0 (acc0 / acc1 then hold channel 1)
       if (!skip)
         {
           if (CV == 2)
@@ -771,6 +786,12 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
 #pragma unroll
               for (int c = 0; c < 2; c++)
                 {
+                  if (SPLIT && c == 1)
+                    {
+                      split0 = acc0;
+                      split1 = acc1;
+                      acc0 = acc1 = 0.f;
+                    }
                   float2 z[8];
                   window_pack (in[c], s_win, lane, z);
                   fft512_forward (z, xbuf, s_tw, lane);
@@ -819,19 +840,47 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
                 }
             }
         }
-      s_tile[lane * TILE_LD + ff] = acc0;
-      if (lane < NB - 64)
-        s_tile[(64 + lane) * TILE_LD + ff] = acc1;
+      if (SPLIT)
+        {
+          s_tile[lane * TILE_LD + ff] = split0;
+          s_tile[lane * TILE_LD + SPLIT_COLS + ff] = acc0;
+          if (lane < NB - 64)
+            {
+              s_tile[(64 + lane) * TILE_LD + ff] = split1;
+              s_tile[(64 + lane) * TILE_LD + SPLIT_COLS + ff] = acc1;
+            }
+        }
+      else
+        {
+          s_tile[lane * TILE_LD + ff] = acc0;
+          if (lane < NB - 64)
+            s_tile[(64 + lane) * TILE_LD + ff] = acc1;
+        }
       if (lane == 0)
         s_have[ff] = skip ? 0 : 1;
     }
   __syncthreads();
-  const long long plane = a.per_channel ? plane_ch : 0;
-  float *out = a.out + stream * a.out_stream_stride + plane * NB * a.ld + tile0;
-  for (int i = threadIdx.x; i < NB * n_here; i += blockDim.x)
+  if (SPLIT)
     {
-      const int band = i / n_here, ff = i - band * n_here;
-      out[band * a.ld + ff] = s_tile[band * TILE_LD + ff];
+      for (int p = 0; p < 2; p++)
+        {
+          float *out = a.out + stream * a.out_stream_stride + (long long) p * NB * a.ld + tile0;
+          for (int i = threadIdx.x; i < NB * n_here; i += blockDim.x)
+            {
+              const int band = i / n_here, ff = i - band * n_here;
+              out[band * a.ld + ff] = s_tile[band * TILE_LD + p * SPLIT_COLS + ff];
+            }
+        }
+    }
+  else
+    {
+      const long long plane = a.per_channel ? plane_ch : 0;
+      float *out = a.out + stream * a.out_stream_stride + plane * NB * a.ld + tile0;
+      for (int i = threadIdx.x; i < NB * n_here; i += blockDim.x)
+        {
+          const int band = i / n_here, ff = i - band * n_here;
+          out[band * a.ld + ff] = s_tile[band * TILE_LD + ff];
+        }
     }
   if (a.have && plane_ch == 0)
     for (int i = threadIdx.x; i < n_here; i += blockDim.x)
@@ -870,12 +919,26 @@ launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
         }
       return hipSuccess;
     }
+  if (a.n_channels == 2 && a.per_channel)
+    {
+      SyncDbArgs b = a;
+      b.tile_frames = a.tile_frames < SPLIT_COLS ? a.tile_frames : 32;
+      const unsigned split_tiles = unsigned ((max_count + b.tile_frames - 1) / b.tile_frames);
+      hipLaunchKernelGGL ((sync_db_kernel<2, true>), dim3 (split_tiles, unsigned (a.n_streams), 1), dim3 (64 * WAVES), 0, st, t, b);
+      return hipGetLastError();
+    }
   const unsigned planes = a.per_channel ? unsigned (a.n_channels) : 1u;
-  const dim3 grid (tiles, unsigned (a.n_streams), planes);
+  dim3 grid (tiles, unsigned (a.n_streams), planes);
+  SyncDbArgs b = a;
+  if (!a.stream_base && !a.stream_count && a.n_streams >= 2 && a.n_streams <= 8 && planes == 1)
+    {
+      b.xcd_interleave = 1;
+      grid = dim3 (unsigned (((tiles + 7) / 8) * 8 * a.n_streams), 1, 1);
+    }
   if (a.n_channels == 2 && !a.per_channel)
-    hipLaunchKernelGGL (sync_db_kernel<2>, grid, dim3 (64 * WAVES), 0, st, t, a);
+    hipLaunchKernelGGL ((sync_db_kernel<2, false>), grid, dim3 (64 * WAVES), 0, st, t, b);
   else
-    hipLaunchKernelGGL (sync_db_kernel<1>, grid, dim3 (64 * WAVES), 0, st, t, a);
+    hipLaunchKernelGGL ((sync_db_kernel<1, false>), grid, dim3 (64 * WAVES), 0, st, t, b);
   return hipGetLastError();
 }
 
