@@ -63,11 +63,34 @@ def cpu_baseline(sample_seconds):
                       f"({cores} threads), payload recovered={ok}; FFTW replaced by the oracle's double-precision FFT"}
 
 
+# HIP-event scope (awm_prof_name) -> device kernel whose PMC counters profiles/r01/traffic.json holds
+PROF_TO_KERNEL = {
+    "add_mix_kernel": "add_mix_kernel_w3<2>", "limiter_kernel": "limiter_apply_kernel<2>", "sync_db_kernel(approx)": "sync_db_kernel<2, false>",
+    "sync_scan_kernel(approx)": "sync_scan_window_kernel", "local_mean_kernel": "local_mean_kernel",
+    "sync_db_kernel(refine)": "sync_db_sliding_kernel<2>", "sync_scan_kernel(refine)": "sync_scan_gathered_kernel<false>",
+    "sync_db_kernel(block)": "sync_db_kernel<2, true>", "soft_bits_kernel": "soft_bits_kernel", "viterbi_kernel": "viterbi_kernel",
+}
+
+
+def pmc_traffic(prof_name):
+    """HBM bytes per launch of the kernel behind a profiling scope: FETCH_SIZE (x2, gfx950 calibration) + WRITE_SIZE from the
+    separate rocprofv3 --pmc passes of this very command (tools/pmc_traffic.py -> profiles/r01/traffic.json; counters cannot
+    be read from inside the process).  None if the summary is not there or was taken for another workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "traffic.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        e = t[PROF_TO_KERNEL[prof_name]]
+        return int(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per GPU")
     ap.add_argument("--cpu-sample-seconds", type=float, default=200.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -153,7 +176,7 @@ def main():
             name, ms, launches, nbytes = dom
             achieved = nbytes / (ms * 1e-3) / 1e9        # algorithmic GB/s: sum(bytes)/sum(time) == per-launch bytes / avg duration
             roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name) if args.minutes == 60.0 else None,
                         "launches": launches, "avg_ms": round(ms / launches, 4),
                         "share_of_gpu_time": round(ms / total_ms, 3)}
         res = {
