@@ -53,8 +53,14 @@ viterbi_body (const float *soft, int n_steps, unsigned int *decisions, int *bits
     lane_parity |= (unsigned (__popc ((unsigned (t) << 1) & v_gen<BT> (g)) & 1)) << g;
   __syncthreads();
 
+  // After V_ORDER steps every state is reachable, and for finite input all path metrics are >= 0 from then on: the
+  // reachability tests (metric >= 0, which a NaN also fails -- the reference then skips that predecessor) only matter
+  // in the first V_ORDER steps or for NaN input.  normalize_soft_bits turns ALL bits of a block into NaN or none
+  // (0 / 0 mean), so one look at the first value decides whether the plain compare-select may be used.
+  const bool plain_ok = coded[0] == coded[0];
   for (int step = 0; step < n_steps; step++)
     {
+      const bool plain = plain_ok && step >= V_ORDER;     // uniform
       if (t < rate)
         {
           const float c = coded[step * rate + t];
@@ -98,12 +104,24 @@ viterbi_body (const float *soft, int n_steps, unsigned int *decisions, int *bits
               d0 += (v2f) { ea, ea };
               d1 += (v2f) { eb, eb };
             }
-          const bool r0 = old0[i] >= 0.f, r1 = old1[i] >= 0.f;
-          // strict "<": the low predecessor is visited first by the reference and keeps ties
-          const unsigned c0 = r0 ? (r1 && d0.y < d0.x) : (r1 ? 1u : 0u);
-          const unsigned c1 = r0 ? (r1 && d1.y < d1.x) : (r1 ? 1u : 0u);
-          const float best0 = c0 ? d0.y : (r0 ? d0.x : -1.f);
-          const float best1 = c1 ? d1.y : (r0 ? d1.x : -1.f);
+          unsigned c0, c1;
+          float best0, best1;
+          if (plain)
+            {
+              // strict "<": the low predecessor is visited first by the reference and keeps ties
+              c0 = d0.y < d0.x;
+              c1 = d1.y < d1.x;
+              best0 = c0 ? d0.y : d0.x;
+              best1 = c1 ? d1.y : d1.x;
+            }
+          else
+            {
+              const bool r0 = old0[i] >= 0.f, r1 = old1[i] >= 0.f;
+              c0 = r0 ? (r1 && d0.y < d0.x) : (r1 ? 1u : 0u);
+              c1 = r0 ? (r1 && d1.y < d1.x) : (r1 ? 1u : 0u);
+              best0 = c0 ? d0.y : (r0 ? d0.x : -1.f);
+              best1 = c1 ? d1.y : (r0 ? d1.x : -1.f);
+            }
           word |= (c0 << (2 * i)) | (c1 << (2 * i + 1));
           reinterpret_cast<float2 *> (s_metric)[p] = make_float2 (best0, best1);
         }
