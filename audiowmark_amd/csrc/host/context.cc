@@ -72,6 +72,44 @@ DevBuffer::release()
 
 } // namespace awm
 
+void
+awm::WorkLane::release_lane()
+{
+  for (DevBuffer *b : { &ws_db, &ws_have, &ws_q, &ws_raw, &ws_mean, &ws_misc, &ws_refine, &ws_refine_have, &ws_soft, &ws_viterbi,
+                        &ws_viterbi_in, &ws_viterbi_bits, &ws_viterbi_err, &ws_block_max, &ws_clip, &ws_idx, &ws_limit_tab, &ws_jobs })
+    b->release();
+  for (PinnedBuffer *b : { &pin_refine_in[0], &pin_refine_in[1], &pin_refine_q[0], &pin_refine_q[1], &pin_peaks, &pin_blocks, &pin_jobs, &pin_bits })
+    b->release();
+  for (hipEvent_t& ev : ev_refine)
+    if (ev)
+      {
+        (void) hipEventDestroy (ev);
+        ev = nullptr;
+      }
+  if (ev_sync)
+    (void) hipEventDestroy (ev_sync);
+  ev_sync = nullptr;
+}
+
+awm::WorkLane *
+awm_ctx::lane (int i)
+{
+  if (i <= 0)
+    return this;
+  if (i >= awm::MAX_LANES)
+    return nullptr;
+  auto& l = extra_lanes[i - 1];
+  if (!l)
+    {
+      auto nl = std::make_unique<awm::WorkLane>();
+      if (hipStreamCreateWithFlags (&nl->stream, hipStreamNonBlocking) != hipSuccess)
+        return nullptr;
+      nl->own_stream = true;
+      l = std::move (nl);
+    }
+  return l.get();
+}
+
 using namespace awm;
 
 static int
@@ -351,15 +389,18 @@ awm_ctx_destroy (awm_ctx *ctx)
     }
   for (auto& t : ctx->frame_mod_tables)
     t->dev.release();
-  for (DevBuffer *b : { &ctx->tab_mem, &ctx->tab_slide, &ctx->ws_db, &ctx->ws_have, &ctx->ws_q, &ctx->ws_raw, &ctx->ws_mean, &ctx->ws_misc,
-                        &ctx->ws_refine, &ctx->ws_refine_have, &ctx->ws_soft, &ctx->ws_viterbi, &ctx->ws_viterbi_in,
-                        &ctx->ws_viterbi_bits, &ctx->ws_viterbi_err, &ctx->ws_block_max, &ctx->ws_clip, &ctx->ws_idx, &ctx->ws_limit_tab, &ctx->ws_jobs })
-    b->release();
-  for (PinnedBuffer *b : { &ctx->pin_refine_in[0], &ctx->pin_refine_in[1], &ctx->pin_refine_q[0], &ctx->pin_refine_q[1], &ctx->pin_peaks, &ctx->pin_blocks, &ctx->pin_jobs, &ctx->pin_bits })
-    b->release();
-  for (hipEvent_t& ev : ctx->ev_refine)
-    if (ev)
-      (void) hipEventDestroy (ev);
+  ctx->tab_mem.release();
+  ctx->tab_slide.release();
+  for (auto& l : ctx->extra_lanes)
+    if (l)
+      {
+        if (l->stream)
+          (void) hipStreamSynchronize (l->stream);
+        l->release_lane();
+        if (l->own_stream && l->stream)
+          (void) hipStreamDestroy (l->stream);
+      }
+  ctx->release_lane();
   if (ctx->own_stream && ctx->stream)
     (void) hipStreamDestroy (ctx->stream);
   delete ctx;

@@ -100,24 +100,36 @@ enum ProfId { PROF_ADD_MIX, PROF_LIMITER, PROF_SYNC_DB, PROF_SYNC_SCAN, PROF_LOC
 struct ProfPending { int id; hipEvent_t start, stop; };
 }
 
-struct awm_ctx
+namespace awm {
+// A stream with its own workspaces and staging buffers.  The context itself is lane 0 (its stream is the one the
+// caller sees); `get` runs the chunks of a stream on up to MAX_LANES lanes concurrently, so that the latency bound
+// parts of one chunk (candidate round trip, refinement scan, Viterbi) overlap with the wide kernels of the others.
+struct WorkLane
 {
-  int            device = -1;
   hipStream_t    stream = nullptr;
   bool           own_stream = false;
+  // workspaces
+  DevBuffer ws_db, ws_have, ws_q, ws_raw, ws_mean, ws_misc, ws_refine, ws_refine_have, ws_soft,
+            ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx, ws_limit_tab, ws_jobs;
+  // host staging (two refinement slots: see SyncFinder::SearchJob)
+  PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits;
+  hipEvent_t   ev_refine[2] = { nullptr, nullptr };
+  hipEvent_t   ev_sync = nullptr;        // cross-lane ordering (input ready / lane done)
+  void release_lane();
+};
+constexpr int MAX_LANES = 4;
+}
+
+struct awm_ctx : awm::WorkLane
+{
+  int            device = -1;
   awmk::DevTables tabs {};
   awm::DevBuffer tab_mem, tab_slide;
 
   std::vector<std::unique_ptr<awm::KeyTables>>     key_tables;
   std::vector<std::unique_ptr<awm::FrameModTable>> frame_mod_tables;
-
-  // workspaces
-  awm::DevBuffer ws_db, ws_have, ws_q, ws_raw, ws_mean, ws_misc, ws_refine, ws_refine_have, ws_soft,
-                 ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx, ws_limit_tab, ws_jobs;
-
-  // host staging (two slots: the search of chunk i + 1 is issued while chunk i's refinement is still in flight)
-  awm::PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits;
-  hipEvent_t        ev_refine[2] = { nullptr, nullptr };
+  std::unique_ptr<awm::WorkLane> extra_lanes[awm::MAX_LANES - 1];
+  awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
 
   // profiling
   bool   prof_enabled = false;
@@ -140,14 +152,15 @@ struct ProfScope
   awm_ctx *ctx;
   int      id;
   hipEvent_t start = nullptr;
-  ProfScope (awm_ctx *c, int i, double algorithmic_bytes) : ctx (c), id (i)
+  hipStream_t st;
+  ProfScope (awm_ctx *c, int i, double algorithmic_bytes, hipStream_t stream = nullptr) : ctx (c), id (i), st (stream ? stream : c->stream)
   {
     if (!ctx->prof_enabled)
       return;
     ctx->prof_bytes[id] += algorithmic_bytes;
     ctx->prof_launches[id]++;
     if (hipEventCreate (&start) != hipSuccess) { start = nullptr; return; }
-    (void) hipEventRecord (start, ctx->stream);
+    (void) hipEventRecord (start, st);
   }
   ~ProfScope()
   {
@@ -155,7 +168,7 @@ struct ProfScope
       return;
     hipEvent_t stop = nullptr;
     if (hipEventCreate (&stop) != hipSuccess) { (void) hipEventDestroy (start); return; }
-    (void) hipEventRecord (stop, ctx->stream);
+    (void) hipEventRecord (stop, st);
     ctx->prof_pending.push_back ({ id, start, stop });
   }
 };

@@ -15,13 +15,13 @@ total_frames (SyncFinder::Mode mode)
 int
 SyncFinder::scan_silence (const DeviceWav& wav)
 {
-  if (int rc = m_ctx->ws_misc.reserve (64))
+  if (int rc = m_lane->ws_misc.reserve (64))
     return rc;
-  auto *res = m_ctx->ws_misc.as<unsigned long long>();
-  AWM_HIP_CHECK (awmk::launch_nonzero_range (m_ctx->stream, wav.data, (long long) wav.n_values(), res));
+  auto *res = m_lane->ws_misc.as<unsigned long long>();
+  AWM_HIP_CHECK (awmk::launch_nonzero_range (m_lane->stream, wav.data, (long long) wav.n_values(), res));
   unsigned long long h[2];
-  AWM_HIP_CHECK (hipMemcpyAsync (h, res, sizeof (h), hipMemcpyDeviceToHost, m_ctx->stream));
-  AWM_HIP_CHECK (stream_wait (m_ctx->stream));
+  AWM_HIP_CHECK (hipMemcpyAsync (h, res, sizeof (h), hipMemcpyDeviceToHost, m_lane->stream));
+  AWM_HIP_CHECK (stream_wait (m_lane->stream));
   m_first = h[0];
   m_last = h[0] >= wav.n_values() ? wav.n_values() : h[1];
   return 0;
@@ -44,10 +44,10 @@ SyncFinder::fetch_scores (long long n_scores, std::vector<SearchScore>& out)
   out.clear();
   if (n_scores <= 0)
     return 0;
-  hipStream_t st = m_ctx->stream;
+  hipStream_t st = m_lane->stream;
   std::vector<double> raw (n_scores), mean (n_scores);
-  AWM_HIP_CHECK (hipMemcpyAsync (raw.data(), m_ctx->ws_raw.ptr, raw.size() * sizeof (double), hipMemcpyDeviceToHost, st));
-  AWM_HIP_CHECK (hipMemcpyAsync (mean.data(), m_ctx->ws_mean.ptr, mean.size() * sizeof (double), hipMemcpyDeviceToHost, st));
+  AWM_HIP_CHECK (hipMemcpyAsync (raw.data(), m_lane->ws_raw.ptr, raw.size() * sizeof (double), hipMemcpyDeviceToHost, st));
+  AWM_HIP_CHECK (hipMemcpyAsync (mean.data(), m_lane->ws_mean.ptr, mean.size() * sizeof (double), hipMemcpyDeviceToHost, st));
   AWM_HIP_CHECK (stream_wait (st));
   out.resize (raw.size());
   for (size_t p = 0; p < raw.size(); p++)
@@ -70,16 +70,16 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   const long long S = n_db - total_frames (mode);  // start frames with (start + total) * 81 < db.size()
   if (n_db <= 0 || S <= 0)
     return 0;
-  hipStream_t st = m_ctx->stream;
+  hipStream_t st = m_lane->stream;
   const int n_shifts = Params::frame_size / Params::sync_search_step;
   const long long ld = (n_db + 63) & ~63LL;
   const long long plane = ld * Params::n_bands;
   const long long q_stride = (S + 63) & ~63LL;
-  if (int rc = m_ctx->ws_db.reserve (size_t (n_shifts) * plane * sizeof (float))) return rc;
-  if (int rc = m_ctx->ws_have.reserve (size_t (n_shifts) * ld)) return rc;
-  if (int rc = m_ctx->ws_q.reserve (size_t (n_shifts) * q_stride * sizeof (double))) return rc;
-  if (int rc = m_ctx->ws_raw.reserve (size_t (n_shifts) * S * sizeof (double))) return rc;
-  if (int rc = m_ctx->ws_mean.reserve (size_t (n_shifts) * S * sizeof (double))) return rc;
+  if (int rc = m_lane->ws_db.reserve (size_t (n_shifts) * plane * sizeof (float))) return rc;
+  if (int rc = m_lane->ws_have.reserve (size_t (n_shifts) * ld)) return rc;
+  if (int rc = m_lane->ws_q.reserve (size_t (n_shifts) * q_stride * sizeof (double))) return rc;
+  if (int rc = m_lane->ws_raw.reserve (size_t (n_shifts) * S * sizeof (double))) return rc;
+  if (int rc = m_lane->ws_mean.reserve (size_t (n_shifts) * S * sizeof (double))) return rc;
 
   awmk::SyncDbArgs da {};
   da.pcm = wav.data;
@@ -91,22 +91,22 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   da.count0 = int (n_db);
   da.n_streams = n_shifts;
   da.hop = Params::frame_size;
-  da.out = m_ctx->ws_db.as<float>();
+  da.out = m_lane->ws_db.as<float>();
   da.out_stream_stride = plane;
   da.ld = ld;
-  da.have = m_ctx->ws_have.as<char>();
+  da.have = m_lane->ws_have.as<char>();
   da.have_stream_stride = ld;
   da.first = (long long) m_first;
   da.last = (long long) m_last;
   da.tile_frames = 64;
   {
-    ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_shifts) * n_db * (4096.0 * wav.n_channels + 324.0));
+    ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_shifts) * n_db * (4096.0 * wav.n_channels + 324.0), st);
     AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
   }
 
   awmk::SyncScanArgs sa {};
-  sa.db = m_ctx->ws_db.as<float>();
-  sa.have = clip ? m_ctx->ws_have.as<char>() : nullptr;     // BLOCK mode never skips a frame
+  sa.db = m_lane->ws_db.as<float>();
+  sa.have = clip ? m_lane->ws_have.as<char>() : nullptr;     // BLOCK mode never skips a frame
   sa.plane_stride = plane;
   sa.have_plane_stride = ld;
   sa.row_stride = 1;
@@ -115,21 +115,21 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   sa.n_lanes = S;
   sa.n_planes = n_shifts;
   sa.min_delta = std::min (Params::water_delta, 0.080);
-  sa.quality = m_ctx->ws_q.as<double>();
+  sa.quality = m_lane->ws_q.as<double>();
   sa.q_stride = q_stride;
   sa.table.packed = kt->sync[clip].packed_approx.as<int>();
   sa.table.rows_per_bit = kt->sync[clip].host.rows_per_bit;
   {
     // algorithmic HBM bytes of the scan: the dB matrix once, candidates re-read it from cache
-    ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0);
+    ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0, st);
     if (getenv ("AWM_SCAN_DIRECT"))
       AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
     else
       AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));
   }
   {
-    ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_shifts) * S * 24.0);
-    AWM_HIP_CHECK (awmk::launch_local_mean (st, m_ctx->ws_q.as<double>(), q_stride, S, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>()));
+    ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_shifts) * S * 24.0, st);
+    AWM_HIP_CHECK (awmk::launch_local_mean (st, m_lane->ws_q.as<double>(), q_stride, S, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>()));
   }
 
   n_scores = (long long) n_shifts * S;
@@ -144,23 +144,45 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
 int
 SyncFinder::select_candidates (long long n_scores, double threshold, std::vector<SearchScore>& out)
 {
+  if (int rc = select_launch (n_scores, threshold))
+    return rc;
+  return select_finish (n_scores, threshold, out);
+}
+
+namespace { constexpr unsigned int PEAK_CAP = 16384, PEAK_HEAD = 1024; }
+
+int
+SyncFinder::select_launch (long long n_scores, double threshold)
+{
+  if (n_scores <= 0)
+    return 0;
+  hipStream_t st = m_lane->stream;
+  const unsigned int cap = PEAK_CAP;
+  if (int rc = m_lane->ws_misc.reserve (256 + cap * sizeof (awmk::PeakOut))) return rc;
+  auto *d_count = m_lane->ws_misc.as<unsigned int>();
+  auto *d_out = reinterpret_cast<awmk::PeakOut *> (m_lane->ws_misc.as<char>() + 256);
+  {
+    ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_scores) * 16.0, st);
+    AWM_HIP_CHECK (awmk::launch_peak_select (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, threshold, d_count, d_out, cap));
+  }
+  // one round trip for the counter and the first peaks (usually all of them), through page-locked memory
+  if (int rc = m_lane->pin_peaks.reserve (256 + cap * sizeof (awmk::PeakOut))) return rc;
+  AWM_HIP_CHECK (hipMemcpyAsync (m_lane->pin_peaks.ptr, d_count, 256 + PEAK_HEAD * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
+  return 0;
+}
+
+int
+SyncFinder::select_finish (long long n_scores, double threshold, std::vector<SearchScore>& out)
+{
   out.clear();
   if (n_scores <= 0)
     return 0;
-  hipStream_t st = m_ctx->stream;
-  const unsigned int cap = 16384;
-  if (int rc = m_ctx->ws_misc.reserve (256 + cap * sizeof (awmk::PeakOut))) return rc;
-  auto *d_count = m_ctx->ws_misc.as<unsigned int>();
-  auto *d_out = reinterpret_cast<awmk::PeakOut *> (m_ctx->ws_misc.as<char>() + 256);
-  {
-    ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_scores) * 16.0);
-    AWM_HIP_CHECK (awmk::launch_peak_select (st, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>(), n_scores, threshold, d_count, d_out, cap));
-  }
-  // one round trip for the counter and the first peaks (usually all of them), through page-locked memory
-  const unsigned int head = 1024;
-  if (int rc = m_ctx->pin_peaks.reserve (256 + cap * sizeof (awmk::PeakOut))) return rc;
-  char *pin = m_ctx->pin_peaks.as<char>();
-  AWM_HIP_CHECK (hipMemcpyAsync (pin, d_count, 256 + head * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
+  hipStream_t st = m_lane->stream;
+  const unsigned int cap = PEAK_CAP;
+  auto *d_count = m_lane->ws_misc.as<unsigned int>();
+  auto *d_out = reinterpret_cast<awmk::PeakOut *> (m_lane->ws_misc.as<char>() + 256);
+  const unsigned int head = PEAK_HEAD;
+  char *pin = m_lane->pin_peaks.as<char>();
   AWM_HIP_CHECK (stream_wait (st));
   unsigned int count = *reinterpret_cast<unsigned int *> (pin);
   if (int (count) >= Params::get_n_best && count <= cap)
@@ -184,9 +206,9 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
   // fewer than n_best peaks above the threshold: the reference then keeps the n_best largest unmasked maxima.
   // Fetch ALL unmasked local maxima (threshold -1) from the device and finish the selection here.
   const unsigned int big_cap = unsigned (std::min<long long> (n_scores, 1 << 22));
-  if (int rc = m_ctx->ws_refine.reserve (size_t (big_cap) * sizeof (awmk::PeakOut))) return rc;
-  auto *d_all = m_ctx->ws_refine.as<awmk::PeakOut>();
-  AWM_HIP_CHECK (awmk::launch_peak_select (st, m_ctx->ws_raw.as<double>(), m_ctx->ws_mean.as<double>(), n_scores, -1.0, d_count, d_all, big_cap));
+  if (int rc = m_lane->ws_refine.reserve (size_t (big_cap) * sizeof (awmk::PeakOut))) return rc;
+  auto *d_all = m_lane->ws_refine.as<awmk::PeakOut>();
+  AWM_HIP_CHECK (awmk::launch_peak_select (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, -1.0, d_count, d_all, big_cap));
   // Only the n_best largest survive select_threshold_and_n_best here (fewer than n_best are above the threshold), so
   // reduce the list on the device: n_best + 1 per slice, so that a tie across the cut is visible -- in that case
   // (degenerate input) the complete list goes through the same std::sort as in the reference instead.
@@ -195,7 +217,7 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
   const bool fewer_than_n_best = int (count) < Params::get_n_best;      // (not: more than `cap` above the threshold)
   if (fewer_than_n_best && k <= 64 && !getenv ("AWM_NBEST_HOST"))
     {
-      auto *d_top = reinterpret_cast<awmk::PeakOut *> (m_ctx->ws_misc.as<char>() + 256);      // the threshold list is dead
+      auto *d_top = reinterpret_cast<awmk::PeakOut *> (m_lane->ws_misc.as<char>() + 256);      // the threshold list is dead
       static_assert (sizeof (awmk::PeakOut) * 64 * n_slices <= 16384 * sizeof (awmk::PeakOut), "ws_misc too small");
       AWM_HIP_CHECK (awmk::launch_peak_topk (st, d_all, d_count, big_cap, d_top, k, n_slices));
       std::vector<awmk::PeakOut> top (size_t (k) * n_slices);
@@ -348,10 +370,10 @@ SyncFinder::refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, Searc
   const size_t per_cand = size_t (NW) * row_values * REFINE_TP;
   size_t batch = std::max<size_t> (1, (size_t (3) << 30) / (per_cand * sizeof (float)));    // <= 3 GiB of dB rows at a time
   batch = std::min (batch, n_cand);
-  if (int rc = m_ctx->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
-  if (int rc = m_ctx->ws_refine_have.reserve (batch * NW * REFINE_TP)) return rc;
-  if (int rc = m_ctx->ws_q.reserve (batch * REFINE_QS * sizeof (double))) return rc;
-  if (int rc = m_ctx->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + batch * sizeof (int))) return rc;
+  if (int rc = m_lane->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
+  if (int rc = m_lane->ws_refine_have.reserve (batch * NW * REFINE_TP)) return rc;
+  if (int rc = m_lane->ws_q.reserve (batch * REFINE_QS * sizeof (double))) return rc;
+  if (int rc = m_lane->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + batch * sizeof (int))) return rc;
   for (size_t c0 = 0; c0 < n_cand; c0 += batch)
     {
       if (job.batch_pending)
@@ -371,7 +393,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
   const int NW = int (sync.want_list.size());
   const long long total = total_frames (mode);
   const int TP = REFINE_TP, QS = REFINE_QS;
-  hipStream_t st = m_ctx->stream;
+  hipStream_t st = m_lane->stream;
   const bool gathered = wav.n_channels <= 2 && !getenv ("AWM_REFINE_FFT");
   const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
   const size_t per_cand = size_t (NW) * row_values * TP;
@@ -379,8 +401,8 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
 
   // stream tables: [nb * NW] long long base, [nb * NW] int count, [nb] int lanes -- one page-locked block, one copy
   const size_t in_bytes = nb * NW * (sizeof (long long) + sizeof (int)) + nb * sizeof (int);
-  PinnedBuffer& pin_in = m_ctx->pin_refine_in[job.slot];
-  PinnedBuffer& pin_q = m_ctx->pin_refine_q[job.slot];
+  PinnedBuffer& pin_in = m_lane->pin_refine_in[job.slot];
+  PinnedBuffer& pin_q = m_lane->pin_refine_q[job.slot];
   if (int rc = pin_in.reserve (in_bytes)) return rc;
   if (int rc = pin_q.reserve (nb * QS * sizeof (double))) return rc;
   auto *stream_base = pin_in.as<long long>();
@@ -417,7 +439,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           stream_count[c * NW + w] = count;
         }
     }
-  auto *d_base = m_ctx->ws_idx.as<long long>();
+  auto *d_base = m_lane->ws_idx.as<long long>();
   int *d_count = reinterpret_cast<int *> (d_base + nb * NW);
   int *d_lanes = d_count + nb * NW;
   AWM_HIP_CHECK (hipMemcpyAsync (d_base, stream_base, in_bytes, hipMemcpyHostToDevice, st));
@@ -436,7 +458,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
       da.count0 = max_count;
       da.n_streams = (long long) nb * NW;
       da.hop = Params::sync_search_fine;
-      da.out = m_ctx->ws_refine.as<float>();
+      da.out = m_lane->ws_refine.as<float>();
       da.out_stream_stride = (long long) row_values * TP;
       if (gathered)
         {
@@ -445,13 +467,13 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           da.rows_per_plane = NW;
         }
       da.ld = TP;
-      da.have = m_ctx->ws_refine_have.as<char>();
+      da.have = m_lane->ws_refine_have.as<char>();
       da.have_stream_stride = TP;
       da.first = (long long) m_first;
       da.last = (long long) m_last;
       da.tile_frames = TP;
       {
-        ProfScope ps (m_ctx, PROF_REFINE_DB, db_bytes);
+        ProfScope ps (m_ctx, PROF_REFINE_DB, db_bytes, st);
         if (gathered)
           AWM_HIP_CHECK (awmk::launch_sync_db_sliding (st, m_ctx->tabs, da));       // K4s: sliding DFT over the fine offsets
         else
@@ -460,8 +482,8 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
       if (gathered)
         {
           awmk::GatheredScanArgs ga {};
-          ga.db = m_ctx->ws_refine.as<float>();
-          ga.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
+          ga.db = m_lane->ws_refine.as<float>();
+          ga.have = clip ? m_lane->ws_refine_have.as<char>() : nullptr;
           ga.plane_stride = (long long) per_cand;
           ga.have_plane_stride = (long long) NW * TP;
           ga.ld = TP;
@@ -470,16 +492,16 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           ga.lane_count = d_lanes;
           ga.n_planes = (long long) nb;
           ga.min_delta = std::min (Params::water_delta, 0.080);
-          ga.quality = m_ctx->ws_q.as<double>();
+          ga.quality = m_lane->ws_q.as<double>();
           ga.q_stride = QS;
-          ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 4.0 * row_values);
+          ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 4.0 * row_values, st);
           AWM_HIP_CHECK (awmk::launch_sync_scan_gathered (st, ga));
         }
       else
         {
           awmk::SyncScanArgs sa {};
-          sa.db = m_ctx->ws_refine.as<float>();
-          sa.have = clip ? m_ctx->ws_refine_have.as<char>() : nullptr;
+          sa.db = m_lane->ws_refine.as<float>();
+          sa.have = clip ? m_lane->ws_refine_have.as<char>() : nullptr;
           sa.plane_stride = (long long) per_cand;
           sa.have_plane_stride = (long long) NW * TP;
           sa.row_stride = (long long) Params::n_bands * TP;
@@ -489,16 +511,16 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           sa.lane_count = d_lanes;
           sa.n_planes = (long long) nb;
           sa.min_delta = std::min (Params::water_delta, 0.080);
-          sa.quality = m_ctx->ws_q.as<double>();
+          sa.quality = m_lane->ws_q.as<double>();
           sa.q_stride = QS;
           sa.table.packed = sync.packed_refine.as<int>();
           sa.table.rows_per_bit = sync.host.rows_per_bit;
-          ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 324.0);
+          ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 324.0, st);
           AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
         }
-      AWM_HIP_CHECK (hipMemcpyAsync (q, m_ctx->ws_q.ptr, nb * QS * sizeof (double), hipMemcpyDeviceToHost, st));
+      AWM_HIP_CHECK (hipMemcpyAsync (q, m_lane->ws_q.ptr, nb * QS * sizeof (double), hipMemcpyDeviceToHost, st));
     }
-  hipEvent_t& ev = m_ctx->ev_refine[job.slot];
+  hipEvent_t& ev = m_lane->ev_refine[job.slot];
   if (!ev)
     AWM_HIP_CHECK (hipEventCreateWithFlags (&ev, hipEventDisableTiming));
   AWM_HIP_CHECK (hipEventRecord (ev, st));
@@ -511,9 +533,9 @@ SyncFinder::refine_batch_finish (SearchJob& job)
 {
   if (!job.batch_pending)
     return 0;
-  AWM_HIP_CHECK (event_wait (m_ctx->ev_refine[job.slot]));
+  AWM_HIP_CHECK (event_wait (m_lane->ev_refine[job.slot]));
   job.batch_pending = false;
-  const double *q = m_ctx->pin_refine_q[job.slot].as<double>();
+  const double *q = m_lane->pin_refine_q[job.slot].as<double>();
   for (size_t c = 0; c < job.nb; c++)
     {
       const SearchScore& s = job.candidates[job.c0 + c];
@@ -567,9 +589,18 @@ SyncFinder::search (const Key& key, const DeviceWav& wav, Mode mode, std::vector
 int
 SyncFinder::search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job)
 {
+  if (int rc = approx_launch (key, wav, mode, job))
+    return rc;
+  return select_refine (job);
+}
+
+int
+SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job)
+{
   job.out.clear();
   job.done = true;
   job.batch_pending = false;
+  job.select_pending = false;
   KeyTables *kt = m_ctx->get_key_tables (key);
   if (!kt)
     return AWM_ERR_HIP;
@@ -588,15 +619,30 @@ SyncFinder::search_launch (const Key& key, const DeviceWav& wav, Mode mode, Sear
     }
   if (int rc = prepare (wav, mode))
     return rc;
-  long long n_scores = 0;
-  if (int rc = approx_device (kt, wav, mode, n_scores))
+  job.kt = kt;
+  job.wav = wav;
+  job.mode = mode;
+  job.n_scores = 0;
+  if (int rc = approx_device (kt, wav, mode, job.n_scores))
     return rc;
-  if (int rc = select_candidates (n_scores, Params::sync_threshold2 * 0.75, job.candidates))
+  if (int rc = select_launch (job.n_scores, Params::sync_threshold2 * 0.75))
     return rc;
-  if (mode == Mode::CLIP)
-    select_truncate_n (job.candidates, std::max (Params::get_n_best, 5));
   job.done = false;
-  return refine_launch (kt, wav, mode, job);
+  job.select_pending = true;
+  return 0;
+}
+
+int
+SyncFinder::select_refine (SearchJob& job)
+{
+  if (job.done || !job.select_pending)
+    return 0;
+  job.select_pending = false;
+  if (int rc = select_finish (job.n_scores, Params::sync_threshold2 * 0.75, job.candidates))
+    return rc;
+  if (job.mode == Mode::CLIP)
+    select_truncate_n (job.candidates, std::max (Params::get_n_best, 5));
+  return refine_launch (job.kt, job.wav, job.mode, job);
 }
 
 int

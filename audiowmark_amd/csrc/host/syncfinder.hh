@@ -36,7 +36,7 @@ public:
   };
   static constexpr int local_mean_distance = 20;
 
-  explicit SyncFinder (awm_ctx *ctx) : m_ctx (ctx) {}
+  explicit SyncFinder (awm_ctx *ctx, WorkLane *lane = nullptr) : m_ctx (ctx), m_lane (lane ? lane : ctx) {}
 
   int search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out);
   int prepare (const DeviceWav& wav, Mode mode);     // silence scan (CLIP) / full range (BLOCK)
@@ -45,6 +45,8 @@ public:
   int approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores);
   // local maxima + mask + threshold (+ n_best fallback): the candidate list search_refine works on
   int select_candidates (long long n_scores, double threshold, std::vector<SearchScore>& out);
+  int select_launch (long long n_scores, double threshold);                                 // device part of it, not waited for
+  int select_finish (long long n_scores, double threshold, std::vector<SearchScore>& out);
   int search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& scores);
 
   /* search() in two halves, so that a caller with several chunks can issue the next chunk's search while the
@@ -61,16 +63,27 @@ public:
     std::vector<int> lane_count, starts;
     size_t c0 = 0, nb = 0;
     bool   batch_pending = false;
+    // approximate search still on the device
+    KeyTables *kt = nullptr;
+    DeviceWav  wav;
+    Mode       mode = Mode::BLOCK;
+    long long  n_scores = 0;
+    bool       select_pending = false;
   };
-  int search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job);
+  int search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job);     // = approx_launch + select_refine
   int search_finish (SearchJob& job, std::vector<Score>& out);
+  // finer steps for callers that drive several lanes: approx_launch never waits for the device,
+  // select_refine waits for this lane's candidate list and queues the refinement
+  int approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job);
+  int select_refine (SearchJob& job);
 
   static void select_local_maxima (std::vector<SearchScore>& scores);
   static void mask_avg_false_positives (std::vector<SearchScore>& scores);
   static void select_threshold_and_n_best (std::vector<SearchScore>& scores, double threshold);
   static void select_truncate_n (std::vector<SearchScore>& scores, size_t n);
 private:
-  awm_ctx *m_ctx;
+  awm_ctx  *m_ctx;
+  WorkLane *m_lane;                     // stream, workspaces and staging buffers of this finder
   size_t   m_first = 0, m_last = 0;     // non-silent value range [first, last)
   int scan_silence (const DeviceWav& wav);
   int fetch_scores (long long n_scores, std::vector<SearchScore>& out);

@@ -248,7 +248,7 @@ normalize_soft_bits (const std::vector<float>& soft_bits)
 /* FFTAnalyzer::fft_range (index, 2226 frames) + mix_decode for a batch of block starts; the soft bits stay on the device:
  * block i (if ok[i]) is slot[i] of ctx->ws_soft ([slots][858] floats) */
 int
-block_soft_bits_dev (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
+block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
                      std::vector<int>& slot_of, std::vector<char>& ok)
 {
   const size_t count = mark_block_frame_count();
@@ -266,29 +266,29 @@ block_soft_bits_dev (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const st
       }
   if (bases.empty())
     return 0;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = lane->stream;
   const long long ld = (count + 63) & ~size_t (63);
   const long long block_stride = (long long) C * Params::n_bands * ld;
   const size_t max_batch = std::max<size_t> (1, (size_t (2) << 30) / (block_stride * sizeof (float)));
-  if (int rc = ctx->ws_soft.reserve (bases.size() * n_bits * sizeof (float))) return rc;
-  if (int rc = ctx->ws_idx.reserve (bases.size() * sizeof (long long))) return rc;
-  if (int rc = ctx->pin_blocks.reserve (bases.size() * sizeof (long long))) return rc;
-  std::copy (bases.begin(), bases.end(), ctx->pin_blocks.as<long long>());
-  AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_idx.ptr, ctx->pin_blocks.ptr, bases.size() * sizeof (long long), hipMemcpyHostToDevice, st));
+  if (int rc = lane->ws_soft.reserve (bases.size() * n_bits * sizeof (float))) return rc;
+  if (int rc = lane->ws_idx.reserve (bases.size() * sizeof (long long))) return rc;
+  if (int rc = lane->pin_blocks.reserve (bases.size() * sizeof (long long))) return rc;
+  std::copy (bases.begin(), bases.end(), lane->pin_blocks.as<long long>());
+  AWM_HIP_CHECK (hipMemcpyAsync (lane->ws_idx.ptr, lane->pin_blocks.ptr, bases.size() * sizeof (long long), hipMemcpyHostToDevice, st));
   for (size_t b0 = 0; b0 < bases.size(); b0 += max_batch)
     {
       const size_t nb = std::min (max_batch, bases.size() - b0);
-      if (int rc = ctx->ws_db.reserve (nb * block_stride * sizeof (float))) return rc;
+      if (int rc = lane->ws_db.reserve (nb * block_stride * sizeof (float))) return rc;
       awmk::SyncDbArgs da {};
       da.pcm = wav.data;
       da.n_frames = wav.n_frames;
       da.n_channels = C;
       da.per_channel = 1;
-      da.stream_base = ctx->ws_idx.as<long long>() + b0;
+      da.stream_base = lane->ws_idx.as<long long>() + b0;
       da.count0 = int (count);
       da.n_streams = (long long) nb;
       da.hop = Params::frame_size;
-      da.out = ctx->ws_db.as<float>();
+      da.out = lane->ws_db.as<float>();
       da.out_stream_stride = block_stride;
       da.ld = ld;
       da.have = nullptr;
@@ -296,12 +296,12 @@ block_soft_bits_dev (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const st
       da.last = (long long) wav.n_values();      // mix_decode uses plain run_fft: no silence skipping
       da.tile_frames = 64;
       {
-        ProfScope ps (ctx, PROF_BLOCK_DB, double (nb) * count * C * (4096.0 + 324.0));
+        ProfScope ps (ctx, PROF_BLOCK_DB, double (nb) * count * C * (4096.0 + 324.0), st);
         AWM_HIP_CHECK (awmk::launch_sync_db (st, ctx->tabs, da));
       }
 
       awmk::SoftBitsArgs sb {};
-      sb.db = ctx->ws_db.as<float>();
+      sb.db = lane->ws_db.as<float>();
       sb.block_stride = block_stride;
       sb.ld = ld;
       sb.n_channels = C;
@@ -312,9 +312,9 @@ block_soft_bits_dev (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const st
       sb.frames_per_bit = Params::frames_per_bit;
       sb.block_frames = int (count);
       sb.n_blocks = (long long) nb;
-      sb.out = ctx->ws_soft.as<float>() + b0 * n_bits;
+      sb.out = lane->ws_soft.as<float>() + b0 * n_bits;
       {
-        ProfScope ps (ctx, PROF_SOFT_BITS, double (nb) * count * C * 324.0);
+        ProfScope ps (ctx, PROF_SOFT_BITS, double (nb) * count * C * 324.0, st);
         AWM_HIP_CHECK (awmk::launch_soft_bits (st, sb));
       }
     }
@@ -329,7 +329,7 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
   const int n_bits = mark_data_frame_count() / Params::frames_per_bit;
   std::vector<int> slot_of;
   raw_bits.assign (index.size(), {});
-  if (int rc = block_soft_bits_dev (ctx, kt, wav, index, slot_of, ok))
+  if (int rc = block_soft_bits_dev (ctx, ctx, kt, wav, index, slot_of, ok))
     return rc;
   size_t n_slots = 0;
   for (int sl : slot_of)
@@ -473,125 +473,150 @@ struct PendingDecode       // one Viterbi job and what to do with its result
   size_t             chunk = 0;       // which chunk's ResultSet receives the pattern
 };
 
-// Every pending decode of a stream goes to the GPU in one pass: K7b builds the normalised decoder inputs from the raw
-// soft bits that are already on the device, K8 decodes A, B and AB blocks side by side; only payload bits come back.
-int
-run_pending (awm_ctx *ctx, KeyTables *kt, const Key& key, std::vector<PendingDecode>& pending, const std::vector<ResultSet *>& result_sets, double speed)
+// Every pending decode goes to the GPU in one pass: K7b builds the normalised decoder inputs from the raw soft bits that
+// are already on the device, K8 decodes A, B and AB blocks side by side; only payload bits come back.
+// decode_launch queues all of it on the lane's stream without waiting, decode_finish collects the payloads.
+struct DecodeJob
 {
-  if (pending.empty())
+  std::vector<PendingDecode> pending;
+  std::vector<size_t> which[3];
+  size_t nb[3] = { 0, 0, 0 }, bits_off[3] = { 0, 0, 0 }, err_off[3] = { 0, 0, 0 };
+  size_t bits_total = 0, err_total = 0, n_out = 0;
+  bool   launched = false;
+};
+
+int
+decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job)
+{
+  job.launched = false;
+  for (auto& w : job.which)
+    w.clear();
+  if (job.pending.empty())
     return 0;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = lane->stream;
   const int n_bits = mark_data_frame_count() / Params::frames_per_bit;                 // 858
   const size_t n_steps = size_t (n_bits) / 6;                                          // trellis steps (payload + 15)
-  const size_t n_out = n_steps - conv_order;
-  const size_t max_batch = 512;                                                        // decodes per launch and code type
-  std::vector<size_t> which[3];
-  for (size_t i = 0; i < pending.size(); i++)
-    which[int (pending[i].code_type)].push_back (i);
-  std::vector<std::vector<int>> bits (pending.size());
-  std::vector<float> errors (pending.size(), 0.f);
-  size_t done[3] = { 0, 0, 0 };
-  while (done[0] < which[0].size() || done[1] < which[1].size() || done[2] < which[2].size())
+  job.n_out = n_steps - conv_order;
+  for (size_t i = 0; i < job.pending.size(); i++)
+    job.which[int (job.pending[i].code_type)].push_back (i);
+  size_t in_off[3], ws_off[3];
+  size_t in_total = 0, ws_total = 0, n_jobs = 0, n_src = 0;
+  job.bits_total = job.err_total = 0;
+  for (int t = 0; t < 3; t++)
     {
-      size_t nb[3], in_off[3], ws_off[3], bits_off[3], err_off[3];
-      size_t in_total = 0, ws_total = 0, bits_total = 0, err_total = 0, n_jobs = 0, n_src = 0;
-      for (int t = 0; t < 3; t++)
+      const size_t rate = t == 2 ? 12 : 6;
+      job.nb[t] = job.which[t].size();
+      in_off[t] = in_total;    in_total += job.nb[t] * n_steps * rate;
+      ws_off[t] = ws_total;    ws_total += awmk::viterbi_workspace_bytes (n_steps * rate, rate, job.nb[t]);
+      job.bits_off[t] = job.bits_total; job.bits_total += job.nb[t] * job.n_out;
+      job.err_off[t] = job.err_total;  job.err_total += job.nb[t];
+      n_jobs += job.nb[t];
+      for (size_t i : job.which[t])
+        n_src += job.pending[i].src.size();
+    }
+  // job table + source list: one page-locked block, one copy
+  const size_t jobs_bytes = (n_jobs * sizeof (awmk::SoftJobDev) + 15) & ~size_t (15);
+  const size_t table_bytes = jobs_bytes + n_src * sizeof (int2);
+  if (int rc = lane->pin_jobs.reserve (table_bytes)) return rc;
+  if (int rc = lane->ws_jobs.reserve (table_bytes)) return rc;
+  auto *jobs = lane->pin_jobs.as<awmk::SoftJobDev>();
+  auto *srcs = reinterpret_cast<int2 *> (lane->pin_jobs.as<char>() + jobs_bytes);
+  size_t j = 0, so = 0;
+  for (int t = 0; t < 3; t++)
+    {
+      const size_t len = n_steps * (t == 2 ? 12 : 6);
+      for (size_t i = 0; i < job.nb[t]; i++)
         {
-          const size_t rate = t == 2 ? 12 : 6;
-          nb[t] = std::min (max_batch, which[t].size() - done[t]);
-          in_off[t] = in_total;    in_total += nb[t] * n_steps * rate;
-          ws_off[t] = ws_total;    ws_total += awmk::viterbi_workspace_bytes (n_steps * rate, rate, nb[t]);
-          bits_off[t] = bits_total; bits_total += nb[t] * n_out;
-          err_off[t] = err_total;  err_total += nb[t];
-          n_jobs += nb[t];
-          for (size_t i = 0; i < nb[t]; i++)
-            n_src += pending[which[t][done[t] + i]].src.size();
-        }
-      // job table + source list: one page-locked block, one copy
-      const size_t jobs_bytes = (n_jobs * sizeof (awmk::SoftJobDev) + 15) & ~size_t (15);
-      const size_t table_bytes = jobs_bytes + n_src * sizeof (int2);
-      if (int rc = ctx->pin_jobs.reserve (table_bytes)) return rc;
-      if (int rc = ctx->ws_jobs.reserve (table_bytes)) return rc;
-      auto *jobs = ctx->pin_jobs.as<awmk::SoftJobDev>();
-      auto *srcs = reinterpret_cast<int2 *> (ctx->pin_jobs.as<char>() + jobs_bytes);
-      size_t j = 0, so = 0;
-      for (int t = 0; t < 3; t++)
-        {
-          const size_t len = n_steps * (t == 2 ? 12 : 6);
-          for (size_t i = 0; i < nb[t]; i++)
-            {
-              const PendingDecode& p = pending[which[t][done[t] + i]];
-              jobs[j].mode = p.mode;
-              jobs[j].n_src = int (p.src.size());
-              jobs[j].src_off = int (so);
-              jobs[j].len = int (len);
-              jobs[j].norm0 = p.norm0;
-              jobs[j].norm1 = p.norm1;
-              jobs[j].out_off = (long long) (in_off[t] + i * len);
-              for (const auto& sp : p.src)
-                srcs[so++] = make_int2 (sp.first, sp.second);
-              j++;
-            }
-        }
-      if (int rc = ctx->ws_viterbi_in.reserve (std::max<size_t> (1, in_total) * sizeof (float))) return rc;
-      if (int rc = ctx->ws_viterbi.reserve (std::max<size_t> (1, ws_total))) return rc;
-      if (int rc = ctx->ws_viterbi_bits.reserve (std::max<size_t> (1, bits_total) * sizeof (int) + err_total * sizeof (float))) return rc;
-      if (int rc = ctx->pin_bits.reserve (bits_total * sizeof (int) + err_total * sizeof (float))) return rc;
-      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_jobs.ptr, ctx->pin_jobs.ptr, table_bytes, hipMemcpyHostToDevice, st));
-      awmk::SoftPrepArgs pa {};
-      pa.raw = ctx->ws_soft.as<float>();
-      pa.n_bits = n_bits;
-      pa.inv_order = kt->bit_order_inv_dev.as<int>();
-      pa.jobs = ctx->ws_jobs.as<awmk::SoftJobDev>();
-      pa.src = reinterpret_cast<const int2 *> (ctx->ws_jobs.as<char>() + jobs_bytes);
-      pa.n_jobs = (long long) n_jobs;
-      pa.hard = Params::hard ? 1 : 0;
-      pa.out = ctx->ws_viterbi_in.as<float>();
-      const float *d_soft[3];
-      unsigned char *d_ws[3];
-      int *d_bits[3];
-      float *d_err[3];
-      long long n_blocks[3];
-      double bytes = 0;
-      float *err_base = reinterpret_cast<float *> (ctx->ws_viterbi_bits.as<int>() + bits_total);     // bits and errors: one block, one copy back
-      for (int t = 0; t < 3; t++)
-        {
-          d_soft[t] = ctx->ws_viterbi_in.as<float>() + in_off[t];
-          d_ws[t] = ctx->ws_viterbi.as<unsigned char>() + ws_off[t];
-          d_bits[t] = ctx->ws_viterbi_bits.as<int>() + bits_off[t];
-          d_err[t] = err_base + err_off[t];
-          n_blocks[t] = (long long) nb[t];
-          bytes += double (nb[t]) * n_steps * (t == 2 ? 12 : 6) * 4.0;
-        }
-      {
-        ProfScope ps (ctx, PROF_VITERBI, 2.0 * bytes + 2.0 * ws_total);
-        AWM_HIP_CHECK (awmk::launch_soft_prep (st, pa));
-        AWM_HIP_CHECK (awmk::launch_viterbi (st, d_soft, n_blocks, (long long) n_steps, d_ws, d_bits, d_err));
-      }
-      AWM_HIP_CHECK (hipMemcpyAsync (ctx->pin_bits.ptr, ctx->ws_viterbi_bits.ptr, bits_total * sizeof (int) + err_total * sizeof (float),
-                                     hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (stream_wait (st));
-      const int *hbits = ctx->pin_bits.as<int>();
-      const float *herr = reinterpret_cast<const float *> (hbits + bits_total);
-      for (int t = 0; t < 3; t++)
-        {
-          for (size_t i = 0; i < nb[t]; i++)
-            {
-              const size_t pi = which[t][done[t] + i];
-              bits[pi].assign (hbits + bits_off[t] + i * n_out, hbits + bits_off[t] + (i + 1) * n_out);
-              errors[pi] = herr[err_off[t] + i];
-            }
-          done[t] += nb[t];
+          const PendingDecode& p = job.pending[job.which[t][i]];
+          jobs[j].mode = p.mode;
+          jobs[j].n_src = int (p.src.size());
+          jobs[j].src_off = int (so);
+          jobs[j].len = int (len);
+          jobs[j].norm0 = p.norm0;
+          jobs[j].norm1 = p.norm1;
+          jobs[j].out_off = (long long) (in_off[t] + i * len);
+          for (const auto& sp : p.src)
+            srcs[so++] = make_int2 (sp.first, sp.second);
+          j++;
         }
     }
-  // patterns are added in submission order (A/B block patterns first, then AB, then "all" -- like the reference's job order)
-  for (size_t i = 0; i < pending.size(); i++)
+  if (int rc = lane->ws_viterbi_in.reserve (std::max<size_t> (1, in_total) * sizeof (float))) return rc;
+  if (int rc = lane->ws_viterbi.reserve (std::max<size_t> (1, ws_total))) return rc;
+  if (int rc = lane->ws_viterbi_bits.reserve (std::max<size_t> (1, job.bits_total) * sizeof (int) + job.err_total * sizeof (float))) return rc;
+  if (int rc = lane->pin_bits.reserve (job.bits_total * sizeof (int) + job.err_total * sizeof (float))) return rc;
+  AWM_HIP_CHECK (hipMemcpyAsync (lane->ws_jobs.ptr, lane->pin_jobs.ptr, table_bytes, hipMemcpyHostToDevice, st));
+  awmk::SoftPrepArgs pa {};
+  pa.raw = lane->ws_soft.as<float>();
+  pa.n_bits = n_bits;
+  pa.inv_order = kt->bit_order_inv_dev.as<int>();
+  pa.jobs = lane->ws_jobs.as<awmk::SoftJobDev>();
+  pa.src = reinterpret_cast<const int2 *> (lane->ws_jobs.as<char>() + jobs_bytes);
+  pa.n_jobs = (long long) n_jobs;
+  pa.hard = Params::hard ? 1 : 0;
+  pa.out = lane->ws_viterbi_in.as<float>();
+  const float *d_soft[3];
+  unsigned char *d_ws[3];
+  int *d_bits[3];
+  float *d_err[3];
+  long long n_blocks[3];
+  double bytes = 0;
+  float *err_base = reinterpret_cast<float *> (lane->ws_viterbi_bits.as<int>() + job.bits_total);     // bits and errors: one block, one copy back
+  for (int t = 0; t < 3; t++)
     {
-      const PendingDecode& p = pending[i];
+      d_soft[t] = lane->ws_viterbi_in.as<float>() + in_off[t];
+      d_ws[t] = lane->ws_viterbi.as<unsigned char>() + ws_off[t];
+      d_bits[t] = lane->ws_viterbi_bits.as<int>() + job.bits_off[t];
+      d_err[t] = err_base + job.err_off[t];
+      n_blocks[t] = (long long) job.nb[t];
+      bytes += double (job.nb[t]) * n_steps * (t == 2 ? 12 : 6) * 4.0;
+    }
+  {
+    ProfScope ps (ctx, PROF_VITERBI, 2.0 * bytes + 2.0 * ws_total, st);
+    AWM_HIP_CHECK (awmk::launch_soft_prep (st, pa));
+    AWM_HIP_CHECK (awmk::launch_viterbi (st, d_soft, n_blocks, (long long) n_steps, d_ws, d_bits, d_err));
+  }
+  AWM_HIP_CHECK (hipMemcpyAsync (lane->pin_bits.ptr, lane->ws_viterbi_bits.ptr, job.bits_total * sizeof (int) + job.err_total * sizeof (float),
+                                 hipMemcpyDeviceToHost, st));
+  job.launched = true;
+  return 0;
+}
+
+int
+decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::vector<ResultSet *>& result_sets, double speed)
+{
+  if (!job.launched)
+    return 0;
+  AWM_HIP_CHECK (stream_wait (lane->stream));
+  job.launched = false;
+  const int *hbits = lane->pin_bits.as<int>();
+  const float *herr = reinterpret_cast<const float *> (hbits + job.bits_total);
+  std::vector<std::vector<int>> bits (job.pending.size());
+  std::vector<float> errors (job.pending.size(), 0.f);
+  for (int t = 0; t < 3; t++)
+    for (size_t i = 0; i < job.nb[t]; i++)
+      {
+        const size_t pi = job.which[t][i];
+        bits[pi].assign (hbits + job.bits_off[t] + i * job.n_out, hbits + job.bits_off[t] + (i + 1) * job.n_out);
+        errors[pi] = herr[job.err_off[t] + i];
+      }
+  // patterns are added in submission order (A/B block patterns first, then AB, then "all" -- like the reference's job order)
+  for (size_t i = 0; i < job.pending.size(); i++)
+    {
+      const PendingDecode& p = job.pending[i];
       if (!bits[i].empty())
         result_sets[p.chunk]->add_pattern (key, p.time, p.score, bits[i], errors[i], p.type, speed);
     }
   return 0;
+}
+
+int
+run_pending (awm_ctx *ctx, KeyTables *kt, const Key& key, std::vector<PendingDecode>& pending, const std::vector<ResultSet *>& result_sets, double speed)
+{
+  DecodeJob job;
+  job.pending = std::move (pending);
+  if (int rc = decode_launch (ctx, ctx, kt, job))
+    return rc;
+  return decode_finish (ctx, key, job, result_sets, speed);
 }
 
 /* AB pairing and "all" pattern of BlockDecoder::run (reference wmget.cc:554-701) for the blocks of one chunk */
@@ -691,86 +716,105 @@ int
 block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& stream, const std::vector<ChunkRange>& chunks,
                    const std::vector<ResultSet *>& result_sets, double speed, std::string *debug_sync_first_chunk)
 {
-  SyncFinder sync_finder (ctx);
   const size_t count = mark_block_frame_count();
   std::vector<SyncFinder::Score> first_scores;
+  /* The chunks of a stream are independent until their patterns are merged, so each one runs on its own lane (stream +
+   * workspaces) and up to MAX_LANES of them are in flight: while one chunk waits for its candidate list, runs its
+   * 150-workgroup refinement scan or its one-CU-per-block Viterbi decodes, the wide kernels of the others fill the
+   * machine.  The host issues the stages lane by lane and only ever waits for the lane whose result it needs next.
+   * A single chunk (short files) runs on the context's own stream. */
+  const int n_lanes = getenv ("AWM_ONE_LANE") ? 1 : int (std::min<size_t> (chunks.size(), MAX_LANES));
+  std::vector<WorkLane *> lanes;
+  for (int i = 0; i < std::max (n_lanes, 1); i++)
+    {
+      WorkLane *l = ctx->lane (i);
+      if (!l)
+        {
+          set_error ("cannot create a work lane (stream)");
+          return AWM_ERR_HIP;
+        }
+      lanes.push_back (l);
+    }
+  if (lanes.size() > 1)
+    {
+      // the PCM may still be in flight on the context's stream (e.g. add -> get): the other lanes wait for it
+      if (!ctx->ev_sync)
+        AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
+      AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));
+      for (size_t i = 1; i < lanes.size(); i++)
+        AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ctx->ev_sync, 0));
+    }
+  auto chunk_wav = [&] (size_t c) {
+    DeviceWav cw = stream;
+    cw.data = stream.data + chunks[c].first_frame * stream.n_channels;
+    cw.n_frames = chunks[c].n_frames;
+    return cw;
+  };
   for (size_t ki = 0; ki < key_list.size(); ki++)
     {
       const Key& key = key_list[ki];
       KeyTables *kt = ctx->get_key_tables (key);
       if (!kt)
         return AWM_ERR_HIP;
-      std::vector<std::vector<SyncFinder::Score>> scores (chunks.size());
-      std::vector<size_t> abs_index;
-      auto chunk_wav = [&] (size_t c) {
-        DeviceWav cw = stream;
-        cw.data = stream.data + chunks[c].first_frame * stream.n_channels;
-        cw.n_frames = chunks[c].n_frames;
-        return cw;
-      };
-      // software pipeline over the chunks: chunk c + 1 is searched (kernels queued) before chunk c's refinement is
-      // collected, so the device always has work while the host evaluates results
-      SyncFinder::SearchJob jobs[2];
-      jobs[0].slot = 0;
-      jobs[1].slot = 1;
-      auto collect = [&] (size_t c) -> int {
-        if (int rc = sync_finder.search_finish (jobs[c & 1], scores[c]))
-          return rc;
-        return 0;
-      };
-      for (size_t c = 0; c < chunks.size(); c++)
+      for (size_t g0 = 0; g0 < chunks.size(); g0 += lanes.size())          // groups of chunks, one lane each
         {
-          if (int rc = sync_finder.search_launch (key, chunk_wav (c), SyncFinder::Mode::BLOCK, jobs[c & 1]))
-            return rc;
-          if (c > 0)
-            if (int rc = collect (c - 1))
+          const size_t gn = std::min (lanes.size(), chunks.size() - g0);
+          std::vector<SyncFinder> finders;
+          std::vector<SyncFinder::SearchJob> jobs (gn);
+          std::vector<DecodeJob> decodes (gn);
+          for (size_t i = 0; i < gn; i++)
+            finders.emplace_back (ctx, lanes[i]);
+          for (size_t i = 0; i < gn; i++)
+            if (int rc = finders[i].approx_launch (key, chunk_wav (g0 + i), SyncFinder::Mode::BLOCK, jobs[i]))
+              return rc;
+          for (size_t i = 0; i < gn; i++)
+            if (int rc = finders[i].select_refine (jobs[i]))
+              return rc;
+          for (size_t i = 0; i < gn; i++)
+            {
+              const size_t c = g0 + i;
+              std::vector<SyncFinder::Score> scores;
+              if (int rc = finders[i].search_finish (jobs[i], scores))
+                return rc;
+              if (ki == 0 && c == 0)
+                first_scores = scores;
+              // blocks of this chunk: fft_range refuses blocks that run past the end OF THE CHUNK (reference wmcommon.cc:128-130)
+              std::vector<size_t> wanted;
+              std::vector<const SyncFinder::Score *> wanted_score;
+              for (const auto& sc : scores)
+                if (chunks[c].n_frames >= sc.index + count * Params::frame_size)
+                  {
+                    wanted.push_back (chunks[c].first_frame + sc.index);
+                    wanted_score.push_back (&sc);
+                  }
+              std::vector<int> slot_of;
+              std::vector<char> ok;
+              if (int rc = block_soft_bits_dev (ctx, lanes[i], kt, stream, wanted, slot_of, ok))
+                return rc;
+              std::vector<PatternRawBits> pattern_raw_vec;
+              auto& pending = decodes[i].pending;
+              for (size_t w = 0; w < wanted.size(); w++)
+                {
+                  if (!ok[w])
+                    continue;
+                  const SyncFinder::Score& sc = *wanted_score[w];
+                  PatternRawBits rb;
+                  rb.index = sc.index;
+                  rb.quality = sc.quality;
+                  rb.slot = slot_of[w];
+                  rb.block_type = sc.block_type;
+                  pending.push_back ({ rb.block_type, 0, { { rb.slot, 0 } }, 0, 0, double (rb.index) / stream.sample_rate,
+                                       sc, ResultSet::Type::BLOCK, c });
+                  pattern_raw_vec.push_back (rb);
+                }
+              combine_blocks (pattern_raw_vec, stream, c, pending);
+              if (int rc = decode_launch (ctx, lanes[i], kt, decodes[i]))
+                return rc;
+            }
+          for (size_t i = 0; i < gn; i++)
+            if (int rc = decode_finish (lanes[i], key, decodes[i], result_sets, speed))
               return rc;
         }
-      if (!chunks.empty())
-        if (int rc = collect (chunks.size() - 1))
-          return rc;
-      for (size_t c = 0; c < chunks.size(); c++)
-        {
-          if (ki == 0 && c == 0)
-            first_scores = scores[c];
-          for (const auto& s : scores[c])
-            {
-              // fft_range refuses blocks that run past the end OF THE CHUNK (reference wmcommon.cc:128-130)
-              const bool ok = chunks[c].n_frames >= s.index + count * Params::frame_size;
-              abs_index.push_back (ok ? chunks[c].first_frame + s.index : size_t (-1));
-            }
-        }
-      std::vector<size_t> wanted;
-      for (size_t v : abs_index)
-        if (v != size_t (-1))
-          wanted.push_back (v);
-      std::vector<int> slot_of;
-      std::vector<char> ok;
-      if (int rc = block_soft_bits_dev (ctx, kt, stream, wanted, slot_of, ok))
-        return rc;
-
-      std::vector<PendingDecode> pending;
-      size_t flat = 0, got = 0;
-      for (size_t c = 0; c < chunks.size(); c++)
-        {
-          std::vector<PatternRawBits> pattern_raw_vec;
-          for (const auto& s : scores[c])
-            {
-              if (abs_index[flat++] == size_t (-1))
-                continue;
-              PatternRawBits rb;
-              rb.index = s.index;
-              rb.quality = s.quality;
-              rb.slot = slot_of[got++];
-              rb.block_type = s.block_type;
-              pending.push_back ({ rb.block_type, 0, { { rb.slot, 0 } }, 0, 0, double (rb.index) / stream.sample_rate,
-                                   s, ResultSet::Type::BLOCK, c });
-              pattern_raw_vec.push_back (rb);
-            }
-          combine_blocks (pattern_raw_vec, stream, c, pending);
-        }
-      if (int rc = run_pending (ctx, kt, key, pending, result_sets, speed))
-        return rc;
     }
   if (debug_sync_first_chunk)
     {
@@ -818,7 +862,7 @@ clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav
         }
       std::vector<int> slot_of;
       std::vector<char> ok;
-      if (int rc = block_soft_bits_dev (ctx, kt, wav, index, slot_of, ok))
+      if (int rc = block_soft_bits_dev (ctx, ctx, kt, wav, index, slot_of, ok))
         return rc;
       std::vector<PendingDecode> pending;
       for (size_t i = 0; i < sync_scores.size(); i++)
