@@ -155,16 +155,35 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # per-kernel HIP-event times of the timed region (this rank)
+    # per-kernel HIP-event times of the timed region (this rank).  `get` runs the chunks of the stream on concurrent
+    # lanes, so these durations overlap (their sum exceeds the wall time) and each is stretched by the kernels it
+    # shares the GPU with.
     import ctypes as C
-    prof = []
-    for i in range(awm.lib.awm_prof_count()):
-        ms, launches, nbytes = C.c_double(), C.c_long(), C.c_double()
-        awm.lib.awm_prof_read(ctx._h, i, C.byref(ms), C.byref(launches), C.byref(nbytes))
-        if launches.value:
-            prof.append((i, ms.value, launches.value, nbytes.value))
     awm.lib.awm_prof_name.restype = C.c_char_p
-    prof = [(awm.lib.awm_prof_name(i).decode(), ms, l, b) for (i, ms, l, b) in prof]
+
+    def read_prof():
+        prof = []
+        for i in range(awm.lib.awm_prof_count()):
+            ms, launches, nbytes = C.c_double(), C.c_long(), C.c_double()
+            awm.lib.awm_prof_read(ctx._h, i, C.byref(ms), C.byref(launches), C.byref(nbytes))
+            if launches.value:
+                prof.append((awm.lib.awm_prof_name(i).decode(), ms.value, launches.value, nbytes.value))
+        return prof
+
+    prof = read_prof()
+    # the same kernels one after the other (AWM_ONE_LANE: a single stream), outside the timed region: the duration a
+    # kernel has when it owns the GPU -- the number a roofline is about
+    serial_steps = 3
+    os.environ["AWM_ONE_LANE"] = "1"
+    step()
+    awm.lib.awm_prof_reset(ctx._h)
+    awm.lib.awm_prof_enable(ctx._h, 1)
+    for _ in range(serial_steps):
+        step()
+    sync()
+    awm.lib.awm_prof_enable(ctx._h, 0)
+    serial = {p[0]: p for p in read_prof()}
+    del os.environ["AWM_ONE_LANE"]
 
     if rank == 0:
         audio_seconds = n * world / RATE
@@ -179,6 +198,11 @@ def main():
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name) if args.minutes == 60.0 else None,
                         "launches": launches, "avg_ms": round(ms / launches, 4),
                         "share_of_gpu_time": round(ms / total_ms, 3)}
+            if name in serial:
+                _, sms, sl, sb = serial[name]
+                roofline["alone_avg_ms"] = round(sms / sl, 4)            # not sharing the GPU with the other lanes' kernels
+                roofline["alone_achieved"] = round(sb / (sms * 1e-3) / 1e9, 1)
+                roofline["alone_frac"] = round(sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         res = {
             "metric": "audio seconds watermarked+decoded per wall-second (xRT), 44.1 kHz stereo",
             "value": round(audio_seconds * args.steps / elapsed, 1),
@@ -197,8 +221,11 @@ def main():
                        "patterns": len(pats or []), "payload_matches": matches},
             "roofline": roofline,
             "kernels_ms_per_step": {p[0]: round(p[1] / args.steps, 3) for p in prof},
+            # one stream, kernels back to back (untimed extra pass): true per-kernel cost; their sum is what a step
+            # would take without the concurrent lanes
+            "kernels_ms_per_step_alone": {k: round(v[1] / serial_steps, 3) for k, v in serial.items()},
             # algorithmic GB/s (SURVEY.md 8d bytes / HIP-event time) of every kernel, same definition as roofline.achieved
-            "kernels_algorithmic_GBps": {p[0]: round(p[3] / (p[1] * 1e-3) / 1e9, 1) for p in prof if p[1] > 0},
+            "kernels_algorithmic_GBps": {k: round(v[3] / (v[1] * 1e-3) / 1e9, 1) for k, v in serial.items() if v[1] > 0},
         }
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds)

@@ -427,6 +427,30 @@ def test_sharded_two_ranks_equal_single_process(gpu):
         gpu.awm.set_params()
 
 
+def test_many_chunks_on_lanes(gpu):
+    """A stream cut into more chunks than there are work lanes (3 minute chunks of a 16 minute stream): the chunk groups, the
+    concurrent lanes and the single-lane order must all give the oracle's pattern list."""
+    import os
+    x = noise(123, 16 * 60 * 44100 + 777, 2)
+    gpu.awm.set_params(chunk_size_min=3.0)
+    orc.set_params(chunk_size_min=3.0)
+    try:
+        assert len(gpu.awm.plan_chunks(len(x))) > 4
+        w = gpu.ctx.add_watermark(None, PAY1, gpu.dev(x))
+        got = gpu.ctx.get_watermark(None, w)
+        os.environ["AWM_ONE_LANE"] = "1"
+        try:
+            one = gpu.ctx.get_watermark(None, w)
+        finally:
+            del os.environ["AWM_ONE_LANE"]
+        want = orc.get(None, w.cpu().numpy(), 2)
+        assert [pkey(p) for p in got] == [pkey(p) for p in one] == [pkey(p) for p in want]
+        assert sum(p["bits"] == PAY1 for p in got) >= 10
+    finally:
+        gpu.awm.set_params()
+        orc.set_params()
+
+
 @pytest.mark.parametrize("n", [0, 1, 1000, 1024, 2049, 44100])
 def test_get_on_tiny_inputs(gpu, n):
     """Inputs far too short to carry a block: the reference pads and searches anyway (ClipDecoder); results must agree."""

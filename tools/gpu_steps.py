@@ -1,5 +1,5 @@
 import time, torch, sys
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.join(__import__('os').path.dirname(__import__('os').path.abspath(__file__)), '..'))
 import audiowmark_amd as awm
 dev = torch.device('cuda', 0)
 ctx = awm.Context(0)
