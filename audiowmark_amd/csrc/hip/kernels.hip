@@ -1039,12 +1039,14 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
       }
   }
   // per-lane rotation constants
-  double2 tw[2][9];
+  double2 tw[2][8];                                           // e^{-2 pi i k j / N}, j = 1..7 (j = 0 is 1), then e^{+2 pi i 8 k / N}
+  int k_tab = kA - 19;
+  asm volatile ("" : "+v" (k_tab));                           // keep these 64 registers out of the FFT above (no hoisting)
 #pragma unroll
   for (int b = 0; b < 2; b++)
 #pragma unroll
-    for (int j = 0; j < 9; j++)
-      tw[b][j] = t.slide[(kA + b - 19) * 9 + j];
+    for (int j = 0; j < 8; j++)
+      tw[b][j] = t.slide[(k_tab + b) * 9 + j + 1];
 
   // Sample feed.  The transition step -> step + 1 needs the 8 C samples entering the window and the 8 C leaving it.
   // Sixteen transitions are fetched at once (both blocks are contiguous: 128 C floats, 2 C per lane), a whole block
@@ -1147,14 +1149,19 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 #pragma unroll
                   for (int b = 0; b < 2; b++)
                     {
-                      acc[b].x = fma (d, tw[b][j].x, acc[b].x);
-                      acc[b].y = fma (d, tw[b][j].y, acc[b].y);
+                      if (j == 0)
+                        acc[b].x = acc[b].x + d;
+                      else
+                        {
+                          acc[b].x = fma (d, tw[b][j - 1].x, acc[b].x);
+                          acc[b].y = fma (d, tw[b][j - 1].y, acc[b].y);
+                        }
                     }
                 }
 #pragma unroll
               for (int b = 0; b < 2; b++)
                 {
-                  const double2 r = tw[b][8];
+                  const double2 r = tw[b][7];
                   R[c][b] = make_double2 (acc[b].x * r.x - acc[b].y * r.y, acc[b].x * r.y + acc[b].y * r.x);
                 }
             }
