@@ -64,12 +64,12 @@ class Pattern(C.Structure):
 _HEX = np.frombuffer(b"0123456789abcdef", np.uint8)
 
 
-def patterns_to_dicts(buf, count):
+def patterns_to_dicts(buf, count, first=0):
     """The first `count` entries of a ctypes Pattern array as dicts (Pattern.as_dict for each, vectorised: the payload
     hex strings are built with numpy instead of 128 Python operations per pattern)."""
     if count <= 0:
         return []
-    a = np.frombuffer(buf, dtype=np.dtype(Pattern), count=count)
+    a = np.frombuffer(buf, dtype=np.dtype(Pattern), count=count, offset=first * C.sizeof(Pattern))
     bits = a["bits"].astype(np.uint8)
     nib = (bits[:, 0::4] << 3) | (bits[:, 1::4] << 2) | (bits[:, 2::4] << 1) | bits[:, 3::4]
     text = _HEX[nib]                                   # [count, 32] ASCII
@@ -110,6 +110,7 @@ lib.awm_block_soft_bits_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C
 lib.awm_viterbi_decode.argtypes = [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, _vp]
 lib.awm_add_watermark_d.argtypes = [_vp, _vp, C.c_char_p, _vp, _vp, C.c_size_t, C.c_int, C.c_int]
 lib.awm_get_watermark_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_size_t, _vp]
+lib.awm_get_watermark_batch_d.argtypes = [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
 lib.awm_decode_chunk_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _vp]
 lib.awm_tab_up_down.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
 lib.awm_tab_bit_pos.argtypes = [_vp, _vp]
@@ -441,6 +442,22 @@ class Context:
     def get_watermark(self, key, pcm):
         n, ch = _pcm_shape(pcm)
         return self._patterns(lib.awm_get_watermark_d, "awm_get_watermark_d", self._h, key_bytes(key), _dev_ptr(pcm), n, ch)
+
+    def get_watermark_batch(self, key, clips, n_threads=0, max_out_per_clip=64):
+        """get_watermark of many independent resident clips (same channel count), spread over the context's work lanes;
+        returns one pattern list per clip."""
+        if not clips:
+            return []
+        shapes = [_pcm_shape(c) for c in clips]
+        ch = shapes[0][1]
+        assert all(s[1] == ch for s in shapes)
+        ptrs = (C.c_void_p * len(clips))(*[_dev_ptr(c) for c in clips])
+        frames = (C.c_size_t * len(clips))(*[s[0] for s in shapes])
+        n_out = (C.c_int * len(clips))()
+        buf = self._pattern_buffer(len(clips) * max_out_per_clip)
+        _check(lib.awm_get_watermark_batch_d(self._h, key_bytes(key), len(clips), ptrs, frames, ch, n_threads, max_out_per_clip,
+                                             C.cast(buf, C.c_void_p), n_out), "awm_get_watermark_batch_d")
+        return [patterns_to_dicts(buf, min(n_out[i], max_out_per_clip), i * max_out_per_clip) for i in range(len(clips))]
 
     def decode_chunks(self, key, pcm, chunks, first_is_stream_start, max_out=8192):
         """decode() of several chunks [(first_frame, n_frames), ...] of one resident buffer; returns one pattern list per

@@ -475,6 +475,31 @@ awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, si
 }
 
 int
+awm_get_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], size_t n_clips, const float *const *pcm_d, const size_t *n_frames,
+                           int n_channels, int n_threads, size_t max_out_per_clip, awm_pattern *out, int *n_out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (n_clips && (!pcm_d || !n_frames || !n_out || (max_out_per_clip && !out)))
+    {
+      set_error ("awm_get_watermark_batch_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  std::vector<DeviceWav> clips;
+  for (size_t i = 0; i < n_clips; i++)
+    clips.push_back (make_wav (pcm_d[i], n_frames[i], n_channels));
+  std::vector<ResultSet> sets;
+  if (int rc = get_watermark_batch_device (ctx, { capi_key (key) }, clips, sets, n_threads))
+    return rc;
+  for (size_t i = 0; i < n_clips; i++)
+    {
+      n_out[i] = int (sets[i].patterns.size());
+      for (size_t j = 0; j < sets[i].patterns.size() && j < max_out_per_clip; j++)
+        fill_pattern (sets[i].patterns[j], out[i * max_out_per_clip + j]);
+    }
+  return 0;
+}
+
+int
 awm_decode_chunks_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
                      int n_chunks, const uint64_t *first_frame, const uint64_t *chunk_frames, int first_is_stream_start,
                      size_t max_out, awm_pattern *out, int *chunk_of_pattern)

@@ -148,6 +148,7 @@ pack_sync_table (const SyncTable& t, const std::vector<int>& want_pos /* empty: 
 KeyTables *
 awm_ctx::get_key_tables (const Key& key)
 {
+  std::lock_guard<std::mutex> lock (table_mutex);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& kt : key_tables)
     if (kt->key == kb)
@@ -240,6 +241,7 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
 void
 awm_ctx::prof_collect()
 {
+  std::lock_guard<std::mutex> lock (prof_mutex);
   for (auto& p : prof_pending)
     {
       float ms = 0;

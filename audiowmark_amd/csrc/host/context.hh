@@ -3,13 +3,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <map>
+#include <mutex>
 #include <memory>
 #include <string>
 #include <vector>
 #include "../hip/kernels.hh"
 #include "wmcommon.hh"
 
-namespace awm { void set_error (const std::string& msg); std::string hip_error_string (hipError_t e); }
+namespace awm { void set_error (const std::string& msg); const std::string& last_error(); std::string hip_error_string (hipError_t e); }
 
 #define AWM_HIP_CHECK(expr) \
   do { hipError_t e__ = (expr); if (e__ != hipSuccess) { awm::set_error (std::string (#expr) + ": " + awm::hip_error_string (e__)); return AWM_ERR_HIP; } } while (0)
@@ -19,9 +20,13 @@ namespace awm {
 // Wait for the stream (or an event) by polling: a blocking hipStreamSynchronize wakes the thread up tens of
 // microseconds late, which is paid at every point where the host has to look at a device result before it can
 // issue the next kernels.  Falls back to the blocking call after a few milliseconds.
+// (several host threads polling at once fight over the runtime's locks: batch workers set this and block instead)
+inline bool& wait_blocking() { static thread_local bool b = false; return b; }
 inline hipError_t
 stream_wait (hipStream_t st)
 {
+  if (wait_blocking())
+    return hipStreamSynchronize (st);
   for (int i = 0; i < 20000; i++)
     {
       const hipError_t e = hipStreamQuery (st);
@@ -33,6 +38,8 @@ stream_wait (hipStream_t st)
 inline hipError_t
 event_wait (hipEvent_t ev)
 {
+  if (wait_blocking())
+    return hipEventSynchronize (ev);
   for (int i = 0; i < 20000; i++)
     {
       const hipError_t e = hipEventQuery (ev);
@@ -117,7 +124,8 @@ struct WorkLane
   hipEvent_t   ev_sync = nullptr;        // cross-lane ordering (input ready / lane done)
   void release_lane();
 };
-constexpr int MAX_LANES = 4;
+constexpr int MAX_LANES = 16;       // lanes a context can own (batch of clips: one clip per lane)
+constexpr int CHUNK_LANES = 4;      // lanes the chunks of ONE stream are spread over
 }
 
 struct awm_ctx : awm::WorkLane
@@ -131,6 +139,8 @@ struct awm_ctx : awm::WorkLane
   std::unique_ptr<awm::WorkLane> extra_lanes[awm::MAX_LANES - 1];
   awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
 
+  std::mutex     table_mutex;            // key / frame_mod table caches (lanes may be driven by different host threads)
+  std::mutex     prof_mutex;
   // profiling
   bool   prof_enabled = false;
   std::vector<awm::ProfPending> prof_pending;
@@ -157,8 +167,11 @@ struct ProfScope
   {
     if (!ctx->prof_enabled)
       return;
-    ctx->prof_bytes[id] += algorithmic_bytes;
-    ctx->prof_launches[id]++;
+    {
+      std::lock_guard<std::mutex> lock (ctx->prof_mutex);
+      ctx->prof_bytes[id] += algorithmic_bytes;
+      ctx->prof_launches[id]++;
+    }
     if (hipEventCreate (&start) != hipSuccess) { start = nullptr; return; }
     (void) hipEventRecord (start, st);
   }
@@ -169,6 +182,7 @@ struct ProfScope
     hipEvent_t stop = nullptr;
     if (hipEventCreate (&stop) != hipSuccess) { (void) hipEventDestroy (start); return; }
     (void) hipEventRecord (stop, st);
+    std::lock_guard<std::mutex> lock (ctx->prof_mutex);
     ctx->prof_pending.push_back ({ id, start, stop });
   }
 };

@@ -1,4 +1,6 @@
 #include "wmget.hh"
+#include <atomic>
+#include <thread>
 #include "utils.hh"
 #include <algorithm>
 #include <cmath>
@@ -610,13 +612,14 @@ decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::vector
 }
 
 int
-run_pending (awm_ctx *ctx, KeyTables *kt, const Key& key, std::vector<PendingDecode>& pending, const std::vector<ResultSet *>& result_sets, double speed)
+run_pending (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const Key& key, std::vector<PendingDecode>& pending,
+             const std::vector<ResultSet *>& result_sets, double speed)
 {
   DecodeJob job;
   job.pending = std::move (pending);
-  if (int rc = decode_launch (ctx, ctx, kt, job))
+  if (int rc = decode_launch (ctx, lane, kt, job))
     return rc;
-  return decode_finish (ctx, key, job, result_sets, speed);
+  return decode_finish (lane, key, job, result_sets, speed);
 }
 
 /* AB pairing and "all" pattern of BlockDecoder::run (reference wmget.cc:554-701) for the blocks of one chunk */
@@ -713,8 +716,9 @@ combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const Device
  * is searched and combined on its own exactly like the reference does; only the device work is batched across
  * chunks (soft bits in one pass, one Viterbi launch per code type). */
 int
-block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& stream, const std::vector<ChunkRange>& chunks,
-                   const std::vector<ResultSet *>& result_sets, double speed, std::string *debug_sync_first_chunk)
+block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<Key>& key_list, const DeviceWav& stream,
+                   const std::vector<ChunkRange>& chunks, const std::vector<ResultSet *>& result_sets, double speed,
+                   std::string *debug_sync_first_chunk)
 {
   const size_t count = mark_block_frame_count();
   std::vector<SyncFinder::Score> first_scores;
@@ -723,18 +727,23 @@ block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceW
    * 150-workgroup refinement scan or its one-CU-per-block Viterbi decodes, the wide kernels of the others fill the
    * machine.  The host issues the stages lane by lane and only ever waits for the lane whose result it needs next.
    * A single chunk (short files) runs on the context's own stream. */
-  const int n_lanes = getenv ("AWM_ONE_LANE") ? 1 : int (std::min<size_t> (chunks.size(), MAX_LANES));
+  // `spread` = use the context's lanes 0 .. CHUNK_LANES - 1 (the caller owns the whole context); otherwise everything
+  // stays on `home` (a batch of clips runs one clip per lane, each driven by its own host thread)
+  const int n_lanes = (!spread || getenv ("AWM_ONE_LANE")) ? 1 : int (std::min<size_t> (chunks.size(), CHUNK_LANES));
   std::vector<WorkLane *> lanes;
-  for (int i = 0; i < std::max (n_lanes, 1); i++)
-    {
-      WorkLane *l = ctx->lane (i);
-      if (!l)
-        {
-          set_error ("cannot create a work lane (stream)");
-          return AWM_ERR_HIP;
-        }
-      lanes.push_back (l);
-    }
+  if (!spread)
+    lanes.push_back (home);
+  else
+    for (int i = 0; i < std::max (n_lanes, 1); i++)
+      {
+        WorkLane *l = ctx->lane (i);
+        if (!l)
+          {
+            set_error ("cannot create a work lane (stream)");
+            return AWM_ERR_HIP;
+          }
+        lanes.push_back (l);
+      }
   if (lanes.size() > 1)
     {
       // the PCM may still be in flight on the context's stream (e.g. add -> get): the other lanes wait for it
@@ -841,10 +850,10 @@ block_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceW
 /* ---- ClipDecoder (reference wmget.cc:764-884) ----------------------------------------- */
 
 int
-clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set,
+clip_run_padded (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set,
                  double time_offset_sec, double speed)
 {
-  SyncFinder sync_finder (ctx);
+  SyncFinder sync_finder (ctx, lane);
   const size_t count = mark_block_frame_count();
   for (const Key& key : key_list)
     {
@@ -862,7 +871,7 @@ clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav
         }
       std::vector<int> slot_of;
       std::vector<char> ok;
-      if (int rc = block_soft_bits_dev (ctx, ctx, kt, wav, index, slot_of, ok))
+      if (int rc = block_soft_bits_dev (ctx, lane, kt, wav, index, slot_of, ok))
         return rc;
       std::vector<PendingDecode> pending;
       for (size_t i = 0; i < sync_scores.size(); i++)
@@ -876,7 +885,7 @@ clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav
           pending.push_back ({ ConvBlockType::ab, 1, { { slot_of[2 * i], first_half }, { slot_of[2 * i + 1], 1 - first_half } }, 0, 0,
                                time_offset_sec, nopad, ResultSet::Type::CLIP, 0 });
         }
-      if (int rc = run_pending (ctx, kt, key, pending, { &result_set }, speed))
+      if (int rc = run_pending (ctx, lane, kt, key, pending, { &result_set }, speed))
         return rc;
     }
   return 0;
@@ -885,7 +894,7 @@ clip_run_padded (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav
 enum class ClipPos { START, END };
 
 int
-clip_run_block (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set, ClipPos pos, double speed)
+clip_run_block (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set, ClipPos pos, double speed)
 {
   const size_t C = wav.n_channels;
   const size_t n = (mark_block_frame_count() + 5) * Params::frame_size * C;      // in values
@@ -906,10 +915,10 @@ clip_run_block (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav&
     }
   const double time_offset = double (first_sample) / wav.sample_rate / C;
   const size_t total = pad_start + (last_sample - first_sample) + pad_end;
-  if (int rc = ctx->ws_clip.reserve (total * sizeof (float)))
+  if (int rc = lane->ws_clip.reserve (total * sizeof (float)))
     return rc;
-  float *ext = ctx->ws_clip.as<float>();
-  hipStream_t st = ctx->stream;
+  float *ext = lane->ws_clip.as<float>();
+  hipStream_t st = lane->stream;
   AWM_HIP_CHECK (hipMemsetAsync (ext, 0, pad_start * sizeof (float), st));
   AWM_HIP_CHECK (hipMemcpyAsync (ext + pad_start, wav.data + first_sample, (last_sample - first_sample) * sizeof (float), hipMemcpyDeviceToDevice, st));
   AWM_HIP_CHECK (hipMemsetAsync (ext + pad_start + (last_sample - first_sample), 0, pad_end * sizeof (float), st));
@@ -918,18 +927,18 @@ clip_run_block (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav&
   l_wav.n_frames = total / C;
   l_wav.n_channels = wav.n_channels;
   l_wav.sample_rate = wav.sample_rate;
-  return clip_run_padded (ctx, key_list, l_wav, result_set, time_offset, speed);
+  return clip_run_padded (ctx, lane, key_list, l_wav, result_set, time_offset, speed);
 }
 
 int
-clip_decoder_run (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set, double speed)
+clip_decoder_run (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set, double speed)
 {
   const int wav_frames = wav.n_values() / (Params::frame_size * wav.n_channels);
   if (wav_frames < int (mark_block_frame_count()) * 3.1)       // only short files
     {
-      if (int rc = clip_run_block (ctx, key_list, wav, result_set, ClipPos::START, speed))
+      if (int rc = clip_run_block (ctx, lane, key_list, wav, result_set, ClipPos::START, speed))
         return rc;
-      if (int rc = clip_run_block (ctx, key_list, wav, result_set, ClipPos::END, speed))
+      if (int rc = clip_run_block (ctx, lane, key_list, wav, result_set, ClipPos::END, speed))
         return rc;
     }
   return 0;
@@ -941,10 +950,10 @@ int
 decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav, bool first_chunk)
 {
   std::string debug_sync;
-  if (int rc = block_decoder_run (ctx, key_list, wav, { ChunkRange { 0, wav.n_frames, 0.0 } }, { &result_set }, 1, &debug_sync))
+  if (int rc = block_decoder_run (ctx, ctx, true, key_list, wav, { ChunkRange { 0, wav.n_frames, 0.0 } }, { &result_set }, 1, &debug_sync))
     return rc;
   if (first_chunk)
-    if (int rc = clip_decoder_run (ctx, key_list, wav, result_set, 1))
+    if (int rc = clip_decoder_run (ctx, ctx, key_list, wav, result_set, 1))
       return rc;
   result_set.set_debug_sync (debug_sync);
   return 0;
@@ -986,9 +995,9 @@ plan_chunks (size_t n_frames, int n_channels)
   return chunks;
 }
 
-int
-decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
-               bool first_is_stream_start, std::vector<ResultSet>& chunk_sets)
+static int
+decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<Key>& key_list, const DeviceWav& wav,
+                  const std::vector<ChunkRange>& chunks, bool first_is_stream_start, std::vector<ResultSet>& chunk_sets)
 {
   chunk_sets.clear();
   chunk_sets.resize (chunks.size());
@@ -996,7 +1005,7 @@ decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& 
   for (auto& cs : chunk_sets)
     ptrs.push_back (&cs);
   std::string debug_sync;
-  if (int rc = block_decoder_run (ctx, key_list, wav, chunks, ptrs, 1, &debug_sync))
+  if (int rc = block_decoder_run (ctx, home, spread, key_list, wav, chunks, ptrs, 1, &debug_sync))
     return rc;
   if (!chunks.empty() && first_is_stream_start)
     {
@@ -1004,7 +1013,7 @@ decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& 
       DeviceWav cw = wav;
       cw.data = wav.data + chunks[0].first_frame * wav.n_channels;
       cw.n_frames = chunks[0].n_frames;
-      if (int rc = clip_decoder_run (ctx, key_list, cw, chunk_sets[0], 1))
+      if (int rc = clip_decoder_run (ctx, home, key_list, cw, chunk_sets[0], 1))
         return rc;
       chunk_sets[0].set_debug_sync (debug_sync);
     }
@@ -1012,11 +1021,18 @@ decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& 
 }
 
 int
-get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set)
+decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
+               bool first_is_stream_start, std::vector<ResultSet>& chunk_sets)
+{
+  return decode_chunks_on (ctx, ctx, true, key_list, wav, chunks, first_is_stream_start, chunk_sets);
+}
+
+static int
+get_watermark_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set)
 {
   const auto chunks = plan_chunks (wav.n_frames, wav.n_channels);
   std::vector<ResultSet> chunk_sets;
-  if (int rc = decode_chunks (ctx, key_list, wav, chunks, true, chunk_sets))
+  if (int rc = decode_chunks_on (ctx, home, spread, key_list, wav, chunks, true, chunk_sets))
     return rc;
   for (size_t c = 0; c < chunks.size(); c++)
     {
@@ -1024,6 +1040,88 @@ get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const Devi
       result_set.merge (chunk_sets[c]);
     }
   result_set.sort (key_list);
+  return 0;
+}
+
+int
+get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set)
+{
+  return get_watermark_on (ctx, ctx, true, key_list, wav, result_set);
+}
+
+/* get_watermark for many independent inputs (BASELINE config 5: a batch of short clips).  A clip's `get` is a chain of
+ * small, latency bound steps (two padded CLIP searches, two one-CU Viterbi decodes, ~10 host round trips: 2 ms for a
+ * 30 s clip that keeps the GPU busy for a fraction of that), so the clips are spread over the context's lanes, each
+ * lane driven by its own host thread that pulls the next clip when it is done.  Results are those of
+ * get_watermark_device per clip. */
+int
+get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips,
+                            std::vector<ResultSet>& result_sets, int n_threads)
+{
+  result_sets.clear();
+  result_sets.resize (clips.size());
+  if (clips.empty())
+    return 0;
+  n_threads = std::max (1, std::min<int> ({ n_threads > 0 ? n_threads : MAX_LANES, MAX_LANES, int (clips.size()) }));
+  std::vector<WorkLane *> lanes;
+  for (int i = 0; i < n_threads; i++)
+    {
+      WorkLane *l = ctx->lane (i);
+      if (!l)
+        {
+          set_error ("cannot create a work lane (stream)");
+          return AWM_ERR_HIP;
+        }
+      lanes.push_back (l);
+    }
+  for (const Key& key : key_list)
+    if (!ctx->get_key_tables (key))                 // built once, before the workers start
+      return AWM_ERR_HIP;
+  // the clips may still be in flight on the context's stream
+  if (!ctx->ev_sync)
+    AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
+  AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));
+  for (size_t i = 1; i < lanes.size(); i++)
+    AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ctx->ev_sync, 0));
+  std::atomic<size_t> next { 0 };
+  std::vector<int> rc (lanes.size(), 0);
+  std::vector<std::string> err (lanes.size());
+  auto worker = [&] (size_t li) {
+    const bool was_blocking = wait_blocking();
+    wait_blocking() = lanes.size() > 1;
+    struct Restore { bool v; ~Restore() { wait_blocking() = v; } } restore { was_blocking };
+    if (hipSetDevice (ctx->device) != hipSuccess)
+      {
+        rc[li] = AWM_ERR_HIP;
+        err[li] = "hipSetDevice failed in a batch worker";
+        return;
+      }
+    for (;;)
+      {
+        const size_t i = next.fetch_add (1);
+        if (i >= clips.size())
+          break;
+        if (int r = get_watermark_on (ctx, lanes[li], false, key_list, clips[i], result_sets[i]))
+          {
+            rc[li] = r;
+            err[li] = last_error();
+            next.store (clips.size());             // stop the other workers
+            break;
+          }
+      }
+  };
+  std::vector<std::thread> threads;
+  for (size_t li = 1; li < lanes.size(); li++)
+    threads.emplace_back (worker, li);
+  worker (0);
+  for (auto& t : threads)
+    t.join();
+  for (size_t li = 0; li < lanes.size(); li++)
+    if (rc[li])
+      {
+        set_error (err[li]);
+        return rc[li];
+      }
   return 0;
 }
 

@@ -165,6 +165,14 @@ int awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payloa
  * ClipDecoder, merge + sort.  Returns the pattern count (<= max_out filled). */
 int awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
                          int n_channels, size_t max_out, awm_pattern *out);
+/* get_watermark for a batch of independent inputs (BASELINE config 5: many short clips; the reference would run one
+ * `audiowmark get` process per file, wmget.cc:886-1013 each).  Clip i = n_frames[i] frames at pcm_d[i] (device pointers),
+ * all with n_channels channels.  The clips are spread over the context's work lanes (n_threads host threads, <= 0: all
+ * lanes).  Patterns of clip i go to out[i * max_out_per_clip ...], their number (possibly > max_out_per_clip) to n_out[i];
+ * every clip's result equals awm_get_watermark_d on it.  Returns 0 or an error code. */
+int awm_get_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], size_t n_clips, const float *const *pcm_d,
+                               const size_t *n_frames, int n_channels, int n_threads, size_t max_out_per_clip,
+                               awm_pattern *out, int *n_out);
 /* decode() of one chunk only (wmget.cc:886-939) -- the unit `get` is sharded by */
 int awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
                         int n_channels, int first_chunk, size_t max_out, awm_pattern *out);

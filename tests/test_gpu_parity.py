@@ -451,6 +451,23 @@ def test_many_chunks_on_lanes(gpu):
         orc.set_params()
 
 
+def test_clip_batch_on_lanes(gpu):
+    """BASELINE config 5 in miniature: a batch of independent 30 s clips (different noise, keys as in SURVEY 8d are not
+    needed for parity) decoded concurrently on the context's lanes gives, clip by clip, what the single call and the oracle give."""
+    n = 30 * 44100
+    clips = [noise(900 + i, n + 17 * i, 2) for i in range(6)]
+    marked = [gpu.ctx.add_watermark(None, PAY1 if i % 2 else PAY2, gpu.dev(c)) for i, c in enumerate(clips)]
+    one_by_one = [gpu.ctx.get_watermark(None, m) for m in marked]
+    for threads in (1, 3, 0):
+        batch = gpu.ctx.get_watermark_batch(None, marked, n_threads=threads)
+        assert [[pkey(p) for p in b] for b in batch] == [[pkey(p) for p in o] for o in one_by_one]
+    for i in (0, 5):
+        want = orc.get(None, marked[i].cpu().numpy(), 2)
+        assert [pkey(p) for p in one_by_one[i]] == [pkey(p) for p in want]
+        assert any(p["bits"] == (PAY1 if i % 2 else PAY2) for p in one_by_one[i])
+    assert gpu.ctx.get_watermark_batch(None, []) == []
+
+
 @pytest.mark.parametrize("n", [0, 1, 1000, 1024, 2049, 44100])
 def test_get_on_tiny_inputs(gpu, n):
     """Inputs far too short to carry a block: the reference pads and searches anyway (ClipDecoder); results must agree."""
