@@ -20,6 +20,14 @@ namespace awm {
 // Wait for the stream (or an event) by polling: a blocking hipStreamSynchronize wakes the thread up tens of
 // microseconds late, which is paid at every point where the host has to look at a device result before it can
 // issue the next kernels.  Falls back to the blocking call after a few milliseconds.
+// Between two queries the thread stays off the runtime's locks for about a microsecond, so that another host thread
+// driving another lane can get its calls through.
+inline void
+cpu_relax()
+{
+  for (int k = 0; k < 48; k++)
+    __builtin_ia32_pause();
+}
 // (several host threads polling at once fight over the runtime's locks: batch workers set this and block instead)
 inline bool& wait_blocking() { static thread_local bool b = false; return b; }
 inline hipError_t
@@ -32,6 +40,7 @@ stream_wait (hipStream_t st)
       const hipError_t e = hipStreamQuery (st);
       if (e != hipErrorNotReady)
         return e;
+      cpu_relax();
     }
   return hipStreamSynchronize (st);
 }
@@ -45,6 +54,7 @@ event_wait (hipEvent_t ev)
       const hipError_t e = hipEventQuery (ev);
       if (e != hipErrorNotReady)
         return e;
+      cpu_relax();
     }
   return hipEventSynchronize (ev);
 }

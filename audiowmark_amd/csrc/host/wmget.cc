@@ -931,15 +931,52 @@ clip_run_block (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, 
 }
 
 int
-clip_decoder_run (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set, double speed)
+clip_decoder_run (awm_ctx *ctx, WorkLane *lane, bool spread, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set,
+                  double speed)
 {
   const int wav_frames = wav.n_values() / (Params::frame_size * wav.n_channels);
   if (wav_frames < int (mark_block_frame_count()) * 3.1)       // only short files
     {
-      if (int rc = clip_run_block (ctx, lane, key_list, wav, result_set, ClipPos::START, speed))
-        return rc;
-      if (int rc = clip_run_block (ctx, lane, key_list, wav, result_set, ClipPos::END, speed))
-        return rc;
+      WorkLane *second = (spread && !getenv ("AWM_ONE_LANE")) ? ctx->lane (lane == ctx ? 1 : 0) : nullptr;
+      if (!second)
+        {
+          if (int rc = clip_run_block (ctx, lane, key_list, wav, result_set, ClipPos::START, speed))
+            return rc;
+          return clip_run_block (ctx, lane, key_list, wav, result_set, ClipPos::END, speed);
+        }
+      // The START and the END search are independent chains of small kernels and host round trips (1 ms each for a
+      // 30 s clip): the END one runs on a second lane, driven by a helper thread; its patterns are appended after
+      // START's, the order the reference produces them in.
+      if (!lane->ev_sync)
+        AWM_HIP_CHECK (hipEventCreateWithFlags (&lane->ev_sync, hipEventDisableTiming));
+      AWM_HIP_CHECK (hipEventRecord (lane->ev_sync, lane->stream));
+      AWM_HIP_CHECK (hipStreamWaitEvent (second->stream, lane->ev_sync, 0));       // the PCM may still be in flight on `lane`
+      ResultSet end_set;
+      int end_rc = 0;
+      std::string end_err;
+      const int device = ctx->device;
+      std::thread helper ([&] {
+        if (hipSetDevice (device) != hipSuccess)
+          {
+            end_rc = AWM_ERR_HIP;
+            end_err = "hipSetDevice failed in the clip helper thread";
+            return;
+          }
+        end_rc = clip_run_block (ctx, second, key_list, wav, end_set, ClipPos::END, speed);
+        if (end_rc)
+          end_err = last_error();
+      });
+      const int start_rc = clip_run_block (ctx, lane, key_list, wav, result_set, ClipPos::START, speed);
+      helper.join();
+      if (start_rc)
+        return start_rc;
+      if (end_rc)
+        {
+          set_error (end_err);
+          return end_rc;
+        }
+      for (auto& p : end_set.patterns)
+        result_set.patterns.push_back (std::move (p));
     }
   return 0;
 }
@@ -953,7 +990,7 @@ decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& key_l
   if (int rc = block_decoder_run (ctx, ctx, true, key_list, wav, { ChunkRange { 0, wav.n_frames, 0.0 } }, { &result_set }, 1, &debug_sync))
     return rc;
   if (first_chunk)
-    if (int rc = clip_decoder_run (ctx, ctx, key_list, wav, result_set, 1))
+    if (int rc = clip_decoder_run (ctx, ctx, true, key_list, wav, result_set, 1))
       return rc;
   result_set.set_debug_sync (debug_sync);
   return 0;
@@ -1013,7 +1050,7 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
       DeviceWav cw = wav;
       cw.data = wav.data + chunks[0].first_frame * wav.n_channels;
       cw.n_frames = chunks[0].n_frames;
-      if (int rc = clip_decoder_run (ctx, home, key_list, cw, chunk_sets[0], 1))
+      if (int rc = clip_decoder_run (ctx, home, spread, key_list, cw, chunk_sets[0], 1))
         return rc;
       chunk_sets[0].set_debug_sync (debug_sync);
     }
