@@ -220,6 +220,14 @@ def main():
                                    f"payload {PAYLOAD}, strength 10", "parallelism": f"stream sharded over {world} GPU(s)" if world > 1 else "1 GPU",
                        "patterns": len(pats or []), "payload_matches": matches},
             "roofline": roofline,
+            # the batched STFT north_star puts the 40 % HBM target on: the fused add kernel (STFT + band edit + inverse +
+            # overlap-add), 8192 algorithmic bytes per frame-channel, stand-alone duration
+            "stft_roofline": ({"kernel": "add_mix_kernel", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                               "achieved": round(serial["add_mix_kernel"][3] / (serial["add_mix_kernel"][1] * 1e-3) / 1e9, 1),
+                               "frac": round(serial["add_mix_kernel"][3] / (serial["add_mix_kernel"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                               "avg_ms": round(serial["add_mix_kernel"][1] / serial["add_mix_kernel"][2], 4),
+                               "traffic": pmc_traffic("add_mix_kernel") if args.minutes == 60.0 else None}
+                              if "add_mix_kernel" in serial else None),
             "kernels_ms_per_step": {p[0]: round(p[1] / args.steps, 3) for p in prof},
             # one stream, kernels back to back (untimed extra pass): true per-kernel cost; their sum is what a step
             # would take without the concurrent lanes
