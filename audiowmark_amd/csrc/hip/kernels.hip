@@ -732,11 +732,13 @@ constexpr int TILE_LD = TILE_MAX + 1;
 
 /* SPLIT (stereo, one output plane per channel -- the block decoder's fft_range): the interleaved samples are read ONCE and
  * both channels are transformed by the same wave; the tile holds the two planes side by side (<= 36 frames each). */
-constexpr int SPLIT_COLS = TILE_MAX / 2;
 
-template<int CV, bool SPLIT> __global__ void __launch_bounds__ (64 * WAVES)
+// TLD: row length of the output tile in LDS (frames per tile + 1).  33 keeps a workgroup at 38 KB so that FOUR of them
+// (16 waves) fit on a CU; the full 73 is only needed by the table-driven refinement fallback (72 fine offsets).
+template<int CV, bool SPLIT, int TLD> __global__ void __launch_bounds__ (64 * WAVES)
 sync_db_kernel (DevTables t, SyncDbArgs a)
 {
+  constexpr int TILE_LD = TLD, TILE_MAX = TLD - 1, SPLIT_COLS = TILE_MAX / 2;
   __shared__ float2 s_tw[512];
   __shared__ float  s_win[1024];
   __shared__ float2 s_twb[NB];
@@ -890,7 +892,7 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
 hipError_t
 launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
 {
-  if (a.n_streams <= 0 || a.tile_frames <= 0 || a.tile_frames > TILE_MAX)
+  if (a.n_streams <= 0 || a.tile_frames <= 0 || a.tile_frames > 72)
     return a.n_streams <= 0 ? hipSuccess : hipErrorInvalidValue;
   int max_count = a.count0;
   // with per-stream counts the caller passes the maximum in count0
@@ -919,12 +921,13 @@ launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
         }
       return hipSuccess;
     }
+  const bool small = a.tile_frames <= 32;
   if (a.n_channels == 2 && a.per_channel)
     {
       SyncDbArgs b = a;
-      b.tile_frames = a.tile_frames < SPLIT_COLS ? a.tile_frames : 32;
+      b.tile_frames = 16;                                        // two planes of 16 frames side by side in a 33-column tile
       const unsigned split_tiles = unsigned ((max_count + b.tile_frames - 1) / b.tile_frames);
-      hipLaunchKernelGGL ((sync_db_kernel<2, true>), dim3 (split_tiles, unsigned (a.n_streams), 1), dim3 (64 * WAVES), 0, st, t, b);
+      hipLaunchKernelGGL ((sync_db_kernel<2, true, 33>), dim3 (split_tiles, unsigned (a.n_streams), 1), dim3 (64 * WAVES), 0, st, t, b);
       return hipGetLastError();
     }
   const unsigned planes = a.per_channel ? unsigned (a.n_channels) : 1u;
@@ -936,9 +939,19 @@ launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
       grid = dim3 (unsigned (((tiles + 7) / 8) * 8 * a.n_streams), 1, 1);
     }
   if (a.n_channels == 2 && !a.per_channel)
-    hipLaunchKernelGGL ((sync_db_kernel<2, false>), grid, dim3 (64 * WAVES), 0, st, t, b);
+    {
+      if (small)
+        hipLaunchKernelGGL ((sync_db_kernel<2, false, 33>), grid, dim3 (64 * WAVES), 0, st, t, b);
+      else
+        hipLaunchKernelGGL ((sync_db_kernel<2, false, 73>), grid, dim3 (64 * WAVES), 0, st, t, b);
+    }
   else
-    hipLaunchKernelGGL ((sync_db_kernel<1, false>), grid, dim3 (64 * WAVES), 0, st, t, b);
+    {
+      if (small)
+        hipLaunchKernelGGL ((sync_db_kernel<1, false, 33>), grid, dim3 (64 * WAVES), 0, st, t, b);
+      else
+        hipLaunchKernelGGL ((sync_db_kernel<1, false, 73>), grid, dim3 (64 * WAVES), 0, st, t, b);
+    }
   return hipGetLastError();
 }
 

@@ -300,7 +300,7 @@ awm_sync_fft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channel
   da.have = ctx->ws_have.as<char>();
   da.first = (long long) first;
   da.last = (long long) last;
-  da.tile_frames = 64;
+  da.tile_frames = 32;
   AWM_HIP_CHECK (hipMemsetAsync (ctx->ws_db.ptr, 0, size_t (ld) * Params::n_bands * sizeof (float), st));
   AWM_HIP_CHECK (hipMemsetAsync (ctx->ws_have.ptr, 0, ld, st));
   if (!want_frames)

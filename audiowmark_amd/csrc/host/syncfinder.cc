@@ -98,7 +98,7 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   da.have_stream_stride = ld;
   da.first = (long long) m_first;
   da.last = (long long) m_last;
-  da.tile_frames = 64;
+  da.tile_frames = 32;
   {
     ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_shifts) * n_db * (4096.0 * wav.n_channels + 324.0), st);
     AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));

@@ -296,7 +296,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
       da.have = nullptr;
       da.first = 0;
       da.last = (long long) wav.n_values();      // mix_decode uses plain run_fft: no silence skipping
-      da.tile_frames = 64;
+      da.tile_frames = 32;
       {
         ProfScope ps (ctx, PROF_BLOCK_DB, double (nb) * count * C * (4096.0 + 324.0), st);
         AWM_HIP_CHECK (awmk::launch_sync_db (st, ctx->tabs, da));
