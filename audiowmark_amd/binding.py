@@ -110,6 +110,9 @@ lib.awm_block_soft_bits_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C
 lib.awm_viterbi_decode.argtypes = [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, _vp]
 lib.awm_add_watermark_d.argtypes = [_vp, _vp, C.c_char_p, _vp, _vp, C.c_size_t, C.c_int, C.c_int]
 lib.awm_get_watermark_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_size_t, _vp]
+lib.awm_resample_frames.argtypes = [_vp, C.c_size_t, C.c_int, C.c_int]
+lib.awm_resample_frames.restype = C.c_size_t
+lib.awm_resample_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]
 lib.awm_get_watermark_batch_d.argtypes = [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
 lib.awm_decode_chunk_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _vp]
 lib.awm_tab_up_down.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
@@ -341,6 +344,17 @@ class Context:
             out = torch.empty_like(pcm)
         _check(lib.awm_add_watermark_d(self._h, key_bytes(key), payload_hex.encode(), _dev_ptr(pcm), _dev_ptr(out), n, ch,
                                        sample_rate), "awm_add_watermark_d")
+        return out
+
+    def resample(self, pcm, rate_in, rate_out):
+        """The stream the reference's loader hands to the decoder for a file at rate_in (zita-resampler restated)."""
+        import torch
+        n, ch = _pcm_shape(pcm)
+        m = lib.awm_resample_frames(self._h, n, rate_in, rate_out)
+        if n and not m:
+            raise AwmError("resampling %d -> %d Hz is not supported: %s" % (rate_in, rate_out, lib.awm_last_error().decode()))
+        out = torch.empty((m, ch), dtype=torch.float32, device=pcm.device)
+        _check(lib.awm_resample_d(self._h, _dev_ptr(pcm), n, ch, rate_in, rate_out, _dev_ptr(out), m), "awm_resample_d")
         return out
 
     def add_d(self, pcm, frame_mod, water_delta=0.01, use_limiter=True, out=None):

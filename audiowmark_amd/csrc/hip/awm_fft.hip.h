@@ -58,24 +58,30 @@ radix8 (float2 (&a)[8])
   radix4<INV> (a[0], a[2], a[4], a[6]);   // even samples -> F0[0..3] in a0,a2,a4,a6
   radix4<INV> (a[1], a[3], a[5], a[7]);   // odd samples  -> F1[0..3] in a1,a3,a5,a7
   constexpr float r = 0.70710678118654752440f;
-  float2 f1 = a[3], f2 = a[5], f3 = a[7];
+  const float2 g1 = a[3], g2 = a[5], g3 = a[7];
+  // odd outputs times the eighth roots of unity; the 1/sqrt 2 of the diagonal ones is folded into the final
+  // add / subtract as an explicit FMA (device code is built with -ffp-contract=on: nothing is fused behind our back,
+  // so that the arithmetic the reference defines -- mix, limiter, dB, soft bits -- keeps separately rounded products)
+  float2 t1, f2, t3;
   if (INV)
     {
-      f1 = make_float2 ((f1.x - f1.y) * r, (f1.x + f1.y) * r);      // * (1 + i) / sqrt 2
-      f2 = make_float2 (-f2.y, f2.x);                               // * i
-      f3 = make_float2 ((-f3.x - f3.y) * r, (f3.x - f3.y) * r);     // * (-1 + i) / sqrt 2
+      t1 = make_float2 (g1.x - g1.y, g1.x + g1.y);                  // * (1 + i)
+      f2 = make_float2 (-g2.y, g2.x);                               // * i
+      t3 = make_float2 (-g3.x - g3.y, g3.x - g3.y);                 // * (-1 + i)
     }
   else
     {
-      f1 = make_float2 ((f1.x + f1.y) * r, (f1.y - f1.x) * r);      // * (1 - i) / sqrt 2
-      f2 = make_float2 (f2.y, -f2.x);                               // * -i
-      f3 = make_float2 ((f3.y - f3.x) * r, (-f3.x - f3.y) * r);     // * (-1 - i) / sqrt 2
+      t1 = make_float2 (g1.x + g1.y, g1.y - g1.x);                  // * (1 - i)
+      f2 = make_float2 (g2.y, -g2.x);                               // * -i
+      t3 = make_float2 (g3.y - g3.x, -g3.x - g3.y);                 // * (-1 - i)
     }
   const float2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6], o0 = a[1];
   a[0] = cadd (e0, o0); a[4] = csub (e0, o0);
-  a[1] = cadd (e1, f1); a[5] = csub (e1, f1);
+  a[1] = make_float2 (fmaf (t1.x, r, e1.x), fmaf (t1.y, r, e1.y));
+  a[5] = make_float2 (fmaf (-t1.x, r, e1.x), fmaf (-t1.y, r, e1.y));
   a[2] = cadd (e2, f2); a[6] = csub (e2, f2);
-  a[3] = cadd (e3, f3); a[7] = csub (e3, f3);
+  a[3] = make_float2 (fmaf (t3.x, r, e3.x), fmaf (t3.y, r, e3.y));
+  a[7] = make_float2 (fmaf (-t3.x, r, e3.x), fmaf (-t3.y, r, e3.y));
 }
 
 // Forward complex FFT-512 of one wave.

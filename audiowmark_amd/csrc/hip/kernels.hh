@@ -39,6 +39,7 @@ struct AddMixArgs
   long long    n_blocks;
   int          limiter_block;     // samples per limiter block (44100)
   int          frames_per_span;   // frames each wave streams through
+  int          delta_only = 0;    // 1: write the watermark signal alone (out = d W..., without "+ in"): WatermarkGen::run for the resampled path
 };
 hipError_t launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a);
 
@@ -49,6 +50,27 @@ hipError_t launch_limiter (hipStream_t st, float *data, long long n_frames, int 
 /* entries launch_limiter needs in scale_tab for this span (one (scale_start, scale_step) pair per limiter block) */
 size_t     limiter_tab_entries (long long n_frames, long long first_sample, int limiter_block);
 hipError_t launch_fill_u32 (hipStream_t st, unsigned int *p, unsigned int v, size_t n);
+
+/* K10: fixed-ratio polyphase resampler = zita-resampler's Resampler (restated; the reference uses it with hlen 16 for
+ * every sample rate other than 44100 Hz, resample.cc:128-270).  Output frame m of the stream "hl - 1 null frames, the
+ * input, null frames for ever":  b = floor (m s / np), ph = m s mod np,
+ *   y[m] = (1e-20f + sum_{i < hl} (P[b + i] c1[i] + P[b + 2 hl - 1 - i] c2[i])) - 1e-20f,   c1 = ctab + hl ph, c2 = ctab + hl (np - ph)
+ * in float, products and sums rounded separately in this order. */
+struct ResampleArgs
+{
+  const float *in;
+  long long    n_in;        // frames available (everything else reads as zero)
+  int          n_channels;
+  const float *ctab;        // device, (np + 1) * hl
+  int          hl, np, step; // step = s = fs_in / gcd
+  float       *out;
+  long long    n_out;       // frames to produce
+};
+hipError_t launch_resample (hipStream_t st, const ResampleArgs& a);
+
+/* K11: out = wm + orig (reference wmadd.cc:564-565) and the per-limiter-block maxima of the result (limiter.cc:90-97) */
+hipError_t launch_mix_max (hipStream_t st, const float *orig, const float *wm, float *out, long long n_frames, int n_channels,
+                           unsigned int *block_max, long long n_blocks, int limiter_block);
 
 /* K4: STFT -> dB of the 81 bands, written band-major ("transposed") so that scans over the
  * frame axis are coalesced.  Stream s (0 <= s < n_streams) consists of count(s) frames starting

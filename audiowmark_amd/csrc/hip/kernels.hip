@@ -343,6 +343,15 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
             }
         }
 
+      if (a.delta_only)
+        {
+          // WatermarkGen::run alone: the mix below then adds 0 instead of the input
+#pragma unroll
+          for (int c = 0; c < CV; c++)
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+              in[c][j] = 0.f;
+        }
       const bool own = m >= s && m < e;
       const bool own_prev = m - 1 >= s && m - 1 < e;
       float max0 = 0.f, max1 = 0.f, pmax0 = 0.f, pmax1 = 0.f;
@@ -708,6 +717,100 @@ launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels,
   return hipGetLastError();
 }
 
+/* ==========================================================================================
+ * K10 / K11: other sample rates (kernels.hh ResampleArgs)
+ * ========================================================================================== */
+__global__ void __launch_bounds__ (256)
+resample_kernel (ResampleArgs a)
+{
+  const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= a.n_out)
+    return;
+  const int C = a.n_channels, hl = a.hl;
+  const long long t = m * a.step;
+  const long long b = t / a.np;
+  const int ph = int (t - b * a.np);
+  const float *c1 = a.ctab + (long long) hl * ph;
+  const float *c2 = a.ctab + (long long) hl * (a.np - ph);
+  const long long first = b - (hl - 1);                       // input frame of P[b]
+  for (int c = 0; c < C; c++)
+    {
+      float sum = 1e-20f;
+      for (int i = 0; i < hl; i++)
+        {
+          const long long j1 = first + i, j2 = first + 2 * hl - 1 - i;
+          const float x1 = (j1 >= 0 && j1 < a.n_in) ? a.in[j1 * C + c] : 0.f;
+          const float x2 = (j2 >= 0 && j2 < a.n_in) ? a.in[j2 * C + c] : 0.f;
+          sum = __fadd_rn (sum, __fadd_rn (__fmul_rn (x1, c1[i]), __fmul_rn (x2, c2[i])));
+        }
+      a.out[m * C + c] = __fsub_rn (sum, 1e-20f);
+    }
+}
+
+hipError_t
+launch_resample (hipStream_t st, const ResampleArgs& a)
+{
+  if (a.n_out <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (resample_kernel, dim3 (unsigned ((a.n_out + 255) / 256)), dim3 (256), 0, st, a);
+  return hipGetLastError();
+}
+
+constexpr int MIX_RUN = 2048;            // values per thread group run: 256 threads x 8
+
+__global__ void __launch_bounds__ (256)
+mix_max_kernel (const float *orig, const float *wm, float *out, long long n_values, int C, unsigned int *block_max, long long n_blocks, int BS)
+{
+  __shared__ float s_m0[4], s_m1[4];
+  const long long base = (long long) blockIdx.x * MIX_RUN;
+  const long long f0 = base / C;                             // first frame this workgroup touches
+  const long long b0 = f0 / BS;
+  const long long bound = (b0 + 1) * BS * C;                  // first value of the next limiter block
+  float m0 = 0.f, m1 = 0.f;
+  for (int j = 0; j < MIX_RUN / 256; j++)
+    {
+      const long long v = base + threadIdx.x + 256LL * j;
+      if (v < n_values)
+        {
+          const float r = __fadd_rn (wm[v], orig[v]);
+          out[v] = r;
+          if (v < bound)
+            m0 = fmaxf (m0, fabsf (r));
+          else
+            m1 = fmaxf (m1, fabsf (r));
+        }
+    }
+  m0 = wave_max (m0);
+  m1 = wave_max (m1);
+  if ((threadIdx.x & 63) == 0)
+    {
+      s_m0[threadIdx.x >> 6] = m0;
+      s_m1[threadIdx.x >> 6] = m1;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0 && block_max)
+    {
+      m0 = fmaxf (fmaxf (s_m0[0], s_m0[1]), fmaxf (s_m0[2], s_m0[3]));
+      m1 = fmaxf (fmaxf (s_m1[0], s_m1[1]), fmaxf (s_m1[2], s_m1[3]));
+      if (b0 < n_blocks && m0 > 0.f) atomicMax (block_max + b0, __float_as_uint (m0));
+      if (b0 + 1 < n_blocks && m1 > 0.f) atomicMax (block_max + b0 + 1, __float_as_uint (m1));
+    }
+}
+
+hipError_t
+launch_mix_max (hipStream_t st, const float *orig, const float *wm, float *out, long long n_frames, int n_channels,
+                unsigned int *block_max, long long n_blocks, int limiter_block)
+{
+  const long long n_values = n_frames * n_channels;
+  if (n_values <= 0)
+    return hipSuccess;
+  if ((long long) limiter_block * n_channels < MIX_RUN)
+    return hipErrorInvalidValue;                               // a run may only straddle one block boundary
+  hipLaunchKernelGGL (mix_max_kernel, dim3 (unsigned ((n_values + MIX_RUN - 1) / MIX_RUN)), dim3 (256), 0, st, orig, wm, out, n_values,
+                      n_channels, block_max, n_blocks, limiter_block);
+  return hipGetLastError();
+}
+
 __global__ void
 fill_u32_kernel (unsigned int *p, unsigned int v, size_t n)
 {
@@ -727,8 +830,6 @@ launch_fill_u32 (hipStream_t st, unsigned int *p, unsigned int v, size_t n)
 /* ==========================================================================================
  * K4: STFT -> dB of 81 bands, band-major output tiles
  * ========================================================================================== */
-constexpr int TILE_MAX = 72;
-constexpr int TILE_LD = TILE_MAX + 1;
 
 /* SPLIT (stereo, one output plane per channel -- the block decoder's fft_range): the interleaved samples are read ONCE and
  * both channels are transformed by the same wave; the tile holds the two planes side by side (<= 36 frames each). */

@@ -217,6 +217,117 @@ add_full (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, in
   return 0;
 }
 
+/* frames the streaming resampler delivers for n_in input frames when it is fed "hl - 1 null frames, the input, hl null
+ * frames" (WavChunkLoader at EOF, wavchunkloader.cc:200-216): every m with floor (m s / np) <= n_in - 1 */
+static size_t
+resample_frames (const ResampleTable& t, size_t n_in)
+{
+  return size_t ((static_cast<unsigned __int128> (n_in) * unsigned (t.np) + unsigned (t.step) - 1) / unsigned (t.step));
+}
+
+static int
+resample_device (awm_ctx *ctx, const ResampleTable& t, const float *in_d, size_t n_in, int n_channels, float *out_d, size_t n_out)
+{
+  awmk::ResampleArgs ra {};
+  ra.in = in_d;
+  ra.n_in = (long long) n_in;
+  ra.n_channels = n_channels;
+  ra.ctab = t.ctab.as<float>();
+  ra.hl = t.hl;
+  ra.np = t.np;
+  ra.step = t.step;
+  ra.out = out_d;
+  ra.n_out = (long long) n_out;
+  AWM_HIP_CHECK (awmk::launch_resample (ctx->stream, ra));
+  return 0;
+}
+
+size_t
+awm_resample_frames (awm_ctx *ctx, size_t n_frames, int rate_in, int rate_out)
+{
+  if (check_ctx (ctx))
+    return 0;
+  const ResampleTable *t = ctx->get_resample_table (rate_in, rate_out);
+  return t ? resample_frames (*t, n_frames) : 0;
+}
+
+int
+awm_resample_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_channels, int rate_in, int rate_out,
+                float *out_d, size_t n_out_frames)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  const ResampleTable *t = ctx->get_resample_table (rate_in, rate_out);
+  if (!t)
+    return AWM_ERR_ARG;
+  if ((n_frames && !pcm_in_d) || (n_out_frames && !out_d) || n_channels < 1)
+    {
+      set_error ("awm_resample_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  return resample_device (ctx, *t, pcm_in_d, n_frames, n_channels, out_d, n_out_frames);
+}
+
+/* add_stream_watermark for a stream at another rate (WatermarkResampler, reference wmadd.cc:353-430 + 520-589): the
+ * input is resampled to 44.1 kHz, the watermark SIGNAL is generated there frame by frame, resampled back and added to
+ * the original; limiter blocks are one second at the input rate.  The reference feeds zero frames after the input until
+ * everything is written, so every stage simply sees a zero extended input here. */
+static int
+add_full_rate (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int C, const int8_t *frame_mod_dev,
+               double water_delta, int use_limiter, int rate)
+{
+  const ResampleTable *down = ctx->get_resample_table (rate, Params::mark_sample_rate);
+  const ResampleTable *up = ctx->get_resample_table (Params::mark_sample_rate, rate);
+  if (!down || !up)
+    return AWM_ERR_ARG;
+  if (!n_frames)
+    return 0;
+  // watermark frames (44.1 kHz) the last output sample can reach: window of output n ends at floor (n s / np) + hl (input index)
+  const size_t last44 = size_t ((static_cast<unsigned __int128> (n_frames - 1) * unsigned (up->step)) / unsigned (up->np)) + size_t (up->hl) + 1;
+  const size_t F = last44 / Params::frame_size + 1;              // watermark frames 0 .. F - 1 are needed
+  const size_t n44 = (F + 1) * Params::frame_size;               // frame F's delta completes frame F - 1
+  if (int rc = ctx->ws_rate_a.reserve (n44 * C * sizeof (float))) return rc;
+  if (int rc = ctx->ws_rate_b.reserve (n44 * C * sizeof (float))) return rc;
+  if (int rc = ctx->ws_rate_c.reserve (n_frames * C * sizeof (float))) return rc;
+  float *x44 = ctx->ws_rate_a.as<float>(), *wm44 = ctx->ws_rate_b.as<float>(), *wm = ctx->ws_rate_c.as<float>();
+  if (int rc = resample_device (ctx, *down, pcm_in_d, n_frames, C, x44, n44)) return rc;
+  {
+    awmk::AddMixArgs a {};
+    a.pcm_in = x44;
+    a.out = wm44;
+    a.n_frames = (long long) n44;
+    a.n_channels = C;
+    a.frame_mod = frame_mod_dev;
+    a.neg_delta_up = float (-water_delta * 1);
+    a.neg_delta_down = float (-water_delta * -1);
+    a.limiter_block = LIMITER_BLOCK;
+    a.frames_per_span = frames_per_span (ctx, (long long) (F + 1));
+    a.delta_only = 1;
+    ProfScope ps (ctx, PROF_ADD_MIX, double (n44) * C * 8.0);
+    AWM_HIP_CHECK (awmk::launch_add_mix (ctx->stream, ctx->tabs, a));
+  }
+  // only frames 0 .. F - 1 of wm44 are complete; nothing later is read (n_in = F * 1024 makes the rest zero, unreachable anyway)
+  if (int rc = resample_device (ctx, *up, wm44, F * Params::frame_size, C, wm, n_frames)) return rc;
+  const int lim_block = int (size_t (rate) * size_t (Params::limiter_block_size_ms) / 1000);
+  const size_t n_blocks = n_frames / lim_block + 2;
+  unsigned int *block_max = nullptr;
+  if (use_limiter)
+    {
+      if (int rc = ctx->ws_block_max.reserve (n_blocks * sizeof (float))) return rc;
+      block_max = ctx->ws_block_max.as<unsigned int>();
+      if (int rc = awm_add_init_block_max_d (ctx, ctx->ws_block_max.as<float>(), n_blocks)) return rc;
+    }
+  AWM_HIP_CHECK (awmk::launch_mix_max (ctx->stream, pcm_in_d, wm, out_d, (long long) n_frames, C, block_max, (long long) n_blocks, lim_block));
+  if (use_limiter)
+    {
+      const size_t tab_entries = awmk::limiter_tab_entries ((long long) n_frames, 0, lim_block);
+      if (int rc = ctx->ws_limit_tab.reserve ((tab_entries + 1) * sizeof (float2))) return rc;
+      ProfScope ps (ctx, PROF_LIMITER, double (n_frames) * C * 8.0);
+      AWM_HIP_CHECK (awmk::launch_limiter (ctx->stream, out_d, (long long) n_frames, C, 0, ctx->ws_block_max.as<float>(), 0, (long long) n_blocks,
+                                           lim_block, LIMITER_CEILING, ctx->ws_limit_tab.as<float2>(), tab_entries));
+    }
+  return 0;
+}
+
 int
 awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
            const int8_t *frame_mod, double water_delta, int use_limiter)
@@ -449,15 +560,11 @@ awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_he
                      size_t n_frames, int n_channels, int sample_rate)
 {
   if (int rc = check_ctx (ctx)) return rc;
-  if (sample_rate != Params::mark_sample_rate)
-    {
-      // the reference resamples to 44.1 kHz and back with zita-resampler (wmadd.cc:358-431); not part of this path yet
-      set_error ("awm_add_watermark_d: only 44100 Hz input is supported");
-      return AWM_ERR_ARG;
-    }
   FrameModTable *fm = ctx->get_frame_mod (capi_key (key), payload_hex ? payload_hex : "");
   if (!fm)
     return AWM_ERR_ARG;
+  if (sample_rate != Params::mark_sample_rate)
+    return add_full_rate (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter, sample_rate);
   return add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter);
 }
 

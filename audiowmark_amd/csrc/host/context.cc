@@ -210,6 +210,65 @@ awm_ctx::get_key_tables (const Key& key)
   return key_tables.back().get();
 }
 
+/* zita-resampler 1.x, Resampler::setup (fs_inp, fs_out, nchan, hlen) and Resampler_table::Resampler_table (fr, hl, np),
+ * restated from the library's published algorithm (the library itself is not part of the reference tree): parity unpinned. */
+ResampleTable *
+awm_ctx::get_resample_table (int rate_in, int rate_out)
+{
+  std::lock_guard<std::mutex> lock (table_mutex);
+  for (auto& t : resample_tables)
+    if (t->rate_in == rate_in && t->rate_out == rate_out)
+      return t.get();
+  if (rate_in <= 0 || rate_out <= 0)
+    return nullptr;
+  const int hlen = 16;
+  double frel = 1.0 - 2.6 / hlen;
+  const double r = double (rate_out) / double (rate_in);
+  unsigned a = unsigned (rate_out), b = unsigned (rate_in);
+  while (b)
+    {
+      const unsigned tmp = a % b;
+      a = b;
+      b = tmp;
+    }
+  const unsigned n = unsigned (rate_out) / a, s = unsigned (rate_in) / a;
+  if (!(16 * r >= 1 && n <= 1000))
+    {
+      set_error ("resampling from " + std::to_string (rate_in) + " to " + std::to_string (rate_out) + " Hz needs zita's VResampler (not supported)");
+      return nullptr;
+    }
+  unsigned h = hlen;
+  if (r < 1)
+    {
+      frel *= r;
+      h = unsigned (std::ceil (h / r));
+    }
+  auto sinc = [] (double x) { x = std::fabs (x); if (x < 1e-6) return 1.0; x *= M_PI; return std::sin (x) / x; };
+  auto wind = [] (double x) { x = std::fabs (x); if (x >= 1.0) return 0.0; x *= M_PI; return 0.384 + 0.500 * std::cos (x) + 0.116 * std::cos (2 * x); };
+  std::vector<float> ctab (size_t (h) * (n + 1));
+  float *p = ctab.data();
+  for (unsigned j = 0; j <= n; j++)
+    {
+      double t = double (j) / double (n);
+      for (unsigned i = 0; i < h; i++)
+        {
+          p[h - i - 1] = float (frel * sinc (t * frel) * wind (t / h));
+          t += 1;
+        }
+      p += h;
+    }
+  auto rt = std::make_unique<ResampleTable>();
+  rt->rate_in = rate_in;
+  rt->rate_out = rate_out;
+  rt->hl = int (h);
+  rt->np = int (n);
+  rt->step = int (s);
+  if (upload (rt->ctab, ctab.data(), ctab.size() * sizeof (float), stream))
+    return nullptr;
+  resample_tables.push_back (std::move (rt));
+  return resample_tables.back().get();
+}
+
 FrameModTable *
 awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
 {
@@ -391,6 +450,11 @@ awm_ctx_destroy (awm_ctx *ctx)
     }
   for (auto& t : ctx->frame_mod_tables)
     t->dev.release();
+  for (auto& t : ctx->resample_tables)
+    t->ctab.release();
+  ctx->ws_rate_a.release();
+  ctx->ws_rate_b.release();
+  ctx->ws_rate_c.release();
   ctx->tab_mem.release();
   ctx->tab_slide.release();
   for (auto& l : ctx->extra_lanes)

@@ -101,6 +101,14 @@ struct KeyTables
   DevBuffer bit_order_inv_dev;              // int [858]: restored[k] = raw[inv[k]]
 };
 
+// polyphase table of zita-resampler's fixed-ratio Resampler for one (input rate, output rate) pair (hlen 16)
+struct ResampleTable
+{
+  int       rate_in = 0, rate_out = 0;
+  int       hl = 0, np = 0, step = 0;
+  DevBuffer ctab;                  // (np + 1) * hl floats
+};
+
 struct FrameModTable
 {
   std::vector<unsigned char> key;
@@ -146,6 +154,9 @@ struct awm_ctx : awm::WorkLane
 
   std::vector<std::unique_ptr<awm::KeyTables>>     key_tables;
   std::vector<std::unique_ptr<awm::FrameModTable>> frame_mod_tables;
+  std::vector<std::unique_ptr<awm::ResampleTable>> resample_tables;
+  awm::ResampleTable *get_resample_table (int rate_in, int rate_out);      // nullptr: ratio not supported by the fixed-ratio resampler
+  awm::DevBuffer ws_rate_a, ws_rate_b, ws_rate_c;                          // resampled input / watermark signals of the other-rate add path
   std::unique_ptr<awm::WorkLane> extra_lanes[awm::MAX_LANES - 1];
   awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
 

@@ -206,10 +206,12 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
       error ("audiowmark: zero_frames (HLS segment watermarking) is not supported by the GPU path\n");
       return 1;
     }
-  if (in_stream->sample_rate() != Params::mark_sample_rate)
+  if (in_stream->sample_rate() != Params::mark_sample_rate
+      && (!awm_resample_frames (ctx, 1024, in_stream->sample_rate(), Params::mark_sample_rate)
+          || !awm_resample_frames (ctx, 1024, Params::mark_sample_rate, in_stream->sample_rate())))
     {
-      // the reference resamples to 44100 Hz and back with zita-resampler (wmadd.cc:358-431)
-      error ("audiowmark: only %d Hz input is supported by the GPU path (got %d Hz)\n", Params::mark_sample_rate, in_stream->sample_rate());
+      // the reference falls back to zita's VResampler for such ratios (resample.cc:233-270)
+      error ("audiowmark: resampling from old_rate=%d to new_rate=%d not implemented\n", in_stream->sample_rate(), Params::mark_sample_rate);
       return 1;
     }
   info ("Message:      %s\n", bit_vec_to_str (bitvec).c_str());
@@ -354,12 +356,6 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
       error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
       return 1;
     }
-  if (in_stream->sample_rate() != Params::mark_sample_rate)
-    {
-      // WavChunkLoader resamples to the watermark rate with zita-resampler (wavchunkloader.cc:71-72)
-      error ("audiowmark: only %d Hz input is supported by the GPU path (got %d Hz)\n", Params::mark_sample_rate, in_stream->sample_rate());
-      return 1;
-    }
   const int C = in_stream->n_channels();
   DevBuffer d_in;
   size_t n_values = 0;
@@ -369,6 +365,25 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
       error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
       d_in.release();
       return 1;
+    }
+  if (in_stream->sample_rate() != Params::mark_sample_rate)
+    {
+      // WavChunkLoader resamples the whole stream to the watermark rate before anything else (wavchunkloader.cc:70-71, 200-216)
+      const size_t in_frames = n_values / C;
+      const size_t out_frames = awm_resample_frames (ctx, in_frames, in_stream->sample_rate(), Params::mark_sample_rate);
+      DevBuffer d_res;
+      if ((in_frames && !out_frames) || d_res.reserve (std::max<size_t> (1, out_frames * C * sizeof (float)))
+          || awm_resample_d (ctx, d_in.as<float>(), in_frames, C, in_stream->sample_rate(), Params::mark_sample_rate, d_res.as<float>(), out_frames))
+        {
+          error ("audiowmark: resampling from old_rate=%d to new_rate=%d not implemented\n", in_stream->sample_rate(), Params::mark_sample_rate);
+          d_in.release();
+          d_res.release();
+          return 1;
+        }
+      (void) hipStreamSynchronize (ctx->stream);
+      d_in.release();
+      d_in = d_res;
+      n_values = out_frames * C;
     }
   if (Params::test_truncate)
     n_values = std::min (n_values, size_t (Params::mark_sample_rate) * C * Params::test_truncate);

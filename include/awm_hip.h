@@ -161,6 +161,16 @@ typedef struct
 int awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex,
                          const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
                          int sample_rate);
+/* Streams at another sample rate.  The reference resamples them to 44.1 kHz with zita-resampler's fixed-ratio Resampler
+ * (hlen 16): `get` decodes the resampled stream (WavChunkLoader, wavchunkloader.cc:70-71,200-216), `add` generates the
+ * watermark at 44.1 kHz and resamples the watermark signal back (WatermarkResampler, wmadd.cc:353-430) -- the latter is
+ * what awm_add_watermark_d does for sample_rate != 44100.  awm_resample_d is the former: out_d receives n_out_frames
+ * frames of the stream the reference's loader would hand to the decoder, awm_resample_frames tells how many there are
+ * (0: the ratio would need zita's VResampler, which is not restated).  zita-resampler is not part of the reference
+ * tree; its algorithm is restated from the library's description, bit parity with it is unpinned. */
+size_t awm_resample_frames (awm_ctx *ctx, size_t n_frames, int rate_in, int rate_out);
+int awm_resample_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_channels, int rate_in, int rate_out,
+                    float *out_d, size_t n_out_frames);
 /* get_watermark core (wmget.cc:886-1013) on resident 44.1 kHz PCM: chunk loop, BlockDecoder,
  * ClipDecoder, merge + sort.  Returns the pattern count (<= max_out filled). */
 int awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,

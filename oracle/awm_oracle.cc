@@ -500,10 +500,64 @@ db_from_complex (cfloat v)                                                 /* wm
 }
 
 /* ---- add (wmadd.cc:61-84, 215-250, 297-344, 448-618; limiter.cc:45-124) ---------------- */
+static vector<float> limiter_process (const vector<float>& mixed, size_t n_frames, int C, size_t limiter_block);
+
+/* the watermark signal alone (WatermarkGen::run, wmadd.cc:297-317, for every 1024-sample frame of `in`, zero extended to
+ * total_frames frames): wm[v] for v < (total_frames - 1) * 1024 * C */
+vector<float>
+watermark_signal (const uint8_t key[16], const float *in, size_t n_frames, int C, const vector<int>& payload, size_t total_frames)
+{
+  const size_t N = P::frame_size, block = block_frame_count();
+  vector<vector<uint8_t>> fm[2] = { frame_mod_table (key, payload, 0), frame_mod_table (key, payload, 1) };
+  const auto swin = synth_window();
+  vector<float> wm (total_frames ? (total_frames - 1) * N * C : 0, 0.f);
+  vector<float> synth (3 * N * C, 0.f);                /* WatermarkSynth::synth_samples */
+  vector<float> frame_in (N * C), delta (N);
+  for (size_t m = 0; m < total_frames; m++)
+    {
+      for (size_t i = 0; i < N * C; i++)
+        {
+          const size_t v = m * N * C + i;
+          frame_in[i] = v < n_frames * C ? in[v] : 0.f;
+        }
+      vector<vector<cfloat>> spect;
+      run_fft (frame_in.data(), C, 0, spect);
+      const size_t fnum = (2 * block - P::frames_pad_start + m) % (2 * block);      /* wmadd.cc:293-294, 326-344 */
+      const vector<uint8_t>& mod = fnum >= block ? fm[1][fnum - block] : fm[0][fnum];
+      std::copy (synth.begin() + N * C, synth.end(), synth.begin());
+      std::fill (synth.begin() + 2 * N * C, synth.end(), 0.f);
+      for (int ch = 0; ch < C; ch++)
+        {
+          vector<cfloat> d (513);
+          for (size_t i = 0; i < mod.size(); i++)                           /* apply_frame_mod */
+            {
+              if (!mod[i])
+                continue;
+              const int sign = mod[i] == 1 ? 1 : -1;
+              const float mag = std::abs (spect[ch][i]);
+              if (mag > 1e-7f)
+                {
+                  const float mag_factor = powf (mag, -P::water_delta * sign);
+                  d[i] = spect[ch][i] * (mag_factor - 1);
+                }
+            }
+          fft1024().c2r (d.data(), delta.data());
+          for (int slot = 0; slot < 3; slot++)
+            for (size_t x = 0; x < N; x++)
+              synth[(slot * N + x) * C + ch] += delta[x] * swin[slot * N + x];
+        }
+      if (m == 0)
+        continue;                                      /* first call emits nothing (1 frame latency) */
+      std::copy (synth.begin(), synth.begin() + N * C, wm.begin() + (m - 1) * N * C);
+    }
+  return wm;
+}
+
 vector<float>
 add_watermark (const uint8_t key[16], const float *in, size_t n_frames, int C, const vector<int>& payload)
 {
   const size_t N = P::frame_size, block = block_frame_count();
+
   vector<vector<uint8_t>> fm[2] = { frame_mod_table (key, payload, 0), frame_mod_table (key, payload, 1) };
   const auto swin = synth_window();
   const size_t F = (n_frames + N - 1) / N;
@@ -564,7 +618,14 @@ add_watermark (const uint8_t key[16], const float *in, size_t n_frames, int C, c
       std::copy (mixed.begin(), mixed.begin() + n_frames * C, out.begin());
       return out;
     }
-  /* Limiter (limiter.cc:90-124): 1 s blocks, ceiling 0.99 */
+  return limiter_process (mixed, n_frames, C, limiter_block);
+}
+
+/* Limiter (limiter.cc:90-124): blocks of one second, ceiling 0.99; `mixed` extends (zero filled) at least two blocks past n_frames */
+static vector<float>
+limiter_process (const vector<float>& mixed, size_t n_frames, int C, size_t limiter_block)
+{
+  vector<float> out (n_frames * C);
   const float ceiling = 0.99;
   const size_t n_blocks = n_frames / limiter_block + 2;
   auto block_max = [&] (size_t b) {
@@ -1257,6 +1318,215 @@ fill_patterns (const vector<Pattern>& v, size_t max_out, orc_pattern *out)
 
 extern "C" {
 
+
+/* ---- sample rates other than 44100 Hz ------------------------------------------------------------------------------
+ * The reference resamples with zita-resampler (Resampler, hlen = 16; resample.cc:128-270), which is not part of
+ * /root/reference and not installed here: PARITY UNPINNED for everything below.  The class restates zita-resampler
+ * 1.x's published algorithm (Resampler::setup / process, Resampler_table: a polyphase windowed-sinc FIR with
+ * 2 hl taps, np phases, window 0.384 + 0.5 cos + 0.116 cos 2x); the call sequences are the reference's. */
+struct ZitaTable
+{
+  unsigned hl = 0, np = 0;
+  vector<float> ctab;                 /* (np + 1) * hl */
+  ZitaTable (double fr, unsigned hl_, unsigned np_) : hl (hl_), np (np_), ctab (size_t (hl_) * (np_ + 1))
+  {
+    auto sinc = [] (double x) { x = fabs (x); if (x < 1e-6) return 1.0; x *= M_PI; return sin (x) / x; };
+    auto wind = [] (double x) { x = fabs (x); if (x >= 1.0) return 0.0; x *= M_PI; return 0.384 + 0.500 * cos (x) + 0.116 * cos (2 * x); };
+    float *p = ctab.data();
+    for (unsigned j = 0; j <= np; j++)
+      {
+        double t = double (j) / double (np);
+        for (unsigned i = 0; i < hl; i++)
+          {
+            p[hl - i - 1] = float (fr * sinc (t * fr) * wind (t / hl));
+            t += 1;
+          }
+        p += hl;
+      }
+  }
+};
+
+static unsigned zita_gcd (unsigned a, unsigned b) { while (b) { const unsigned t = a % b; a = b; b = t; } return a; }
+
+class ZitaResampler
+{
+  std::unique_ptr<ZitaTable> table;
+  unsigned nchan_ = 0, inmax = 0, index = 0, nread = 0, nzero = 0, phase = 0, pstep = 0;
+  vector<float> buff;
+public:
+  unsigned     inp_count = 0, out_count = 0;
+  const float *inp_data = nullptr;
+  float       *out_data = nullptr;
+  unsigned nchan() const { return nchan_; }
+  unsigned inpsize() const { return table ? 2 * table->hl : 0; }
+  int
+  setup (unsigned fs_inp, unsigned fs_out, unsigned nchan, unsigned hlen)
+  {
+    double frel = 1.0 - 2.6 / hlen;
+    if (!fs_inp || !fs_out || !nchan)
+      return 1;
+    const double r = double (fs_out) / double (fs_inp);
+    const unsigned g = zita_gcd (fs_out, fs_inp), n = fs_out / g, s = fs_inp / g;
+    if (!(16 * r >= 1 && n <= 1000))
+      return 1;
+    unsigned h = hlen, k = 250;
+    if (r < 1)
+      {
+        frel *= r;
+        h = unsigned (ceil (h / r));
+        k = unsigned (ceil (k / r));
+      }
+    table = std::make_unique<ZitaTable> (frel, h, n);
+    buff.assign (size_t (nchan) * (2 * h - 1 + k), 0.f);
+    nchan_ = nchan;
+    inmax = k;
+    pstep = s;
+    index = 0; nzero = 0; phase = 0;
+    nread = 2 * h;
+    return 0;
+  }
+  void
+  process()
+  {
+    if (!table)
+      return;
+    const unsigned hl = table->hl, np = table->np, dp = pstep;
+    unsigned in = index, nr = nread, ph = phase, nz = nzero;
+    unsigned n = (2 * hl - nr) * nchan_;
+    float *p1 = buff.data() + in * nchan_;
+    float *p2 = p1 + n;
+    while (out_count)
+      {
+        if (nr)
+          {
+            if (inp_count == 0)
+              break;
+            if (inp_data)
+              {
+                for (unsigned c = 0; c < nchan_; c++)
+                  p2[c] = inp_data[c];
+                inp_data += nchan_;
+                nz = 0;
+              }
+            else
+              {
+                for (unsigned c = 0; c < nchan_; c++)
+                  p2[c] = 0;
+                if (nz < 2 * hl)
+                  nz++;
+              }
+            nr--;
+            p2 += nchan_;
+            inp_count--;
+          }
+        else
+          {
+            if (out_data)
+              {
+                if (nz < 2 * hl)
+                  {
+                    const float *c1 = table->ctab.data() + hl * ph;
+                    const float *c2 = table->ctab.data() + hl * (np - ph);
+                    for (unsigned c = 0; c < nchan_; c++)
+                      {
+                        const float *q1 = p1 + c;
+                        const float *q2 = p2 + c;
+                        float sum = 1e-20f;
+                        for (unsigned i = 0; i < hl; i++)
+                          {
+                            q2 -= nchan_;
+                            sum += *q1 * c1[i] + *q2 * c2[i];
+                            q1 += nchan_;
+                          }
+                        *out_data++ = sum - 1e-20f;
+                      }
+                  }
+                else
+                  for (unsigned c = 0; c < nchan_; c++)
+                    *out_data++ = 0;
+              }
+            out_count--;
+            ph += dp;
+            if (ph >= np)
+              {
+                nr = ph / np;
+                ph -= nr * np;
+                in += nr;
+                p1 += nr * nchan_;
+                if (in >= inmax)
+                  {
+                    n = (2 * hl - nr) * nchan_;
+                    memmove (buff.data(), p1, n * sizeof (float));
+                    in = 0;
+                    p1 = buff.data();
+                    p2 = p1 + n;
+                  }
+              }
+          }
+      }
+    index = in; nread = nr; phase = ph; nzero = nz;
+  }
+};
+
+/* BufferedResamplerImpl (resample.cc:128-231) fed with the whole stream: hl - 1 null frames first ("avoid timeshift"),
+ * the input, and -- if `trailing` (WavChunkLoader at EOF, wavchunkloader.cc:212-216) -- hl null frames. */
+static vector<float>
+zita_stream (const float *in, size_t n_frames, int C, int rate_in, int rate_out, bool trailing)
+{
+  ZitaResampler rs;
+  vector<float> out;
+  if (rs.setup (rate_in, rate_out, C, 16) != 0)
+    return out;
+  vector<float> chunk (size_t (P::frame_size) * C);
+  auto feed = [&] (const float *data, size_t frames) {
+    size_t done = 0;
+    while (done < frames)
+      {
+        rs.out_count = P::frame_size;
+        rs.out_data = chunk.data();
+        const unsigned given = unsigned (std::min<size_t> (frames - done, 1u << 30));
+        rs.inp_count = given;
+        rs.inp_data = data ? data + done * C : nullptr;
+        rs.process();
+        const size_t count = P::frame_size - rs.out_count;
+        out.insert (out.end(), chunk.begin(), chunk.begin() + count * C);
+        done += given - rs.inp_count;
+      }
+  };
+  /* priming: inp_count = inpsize / 2 - 1 null frames, output discarded (none is produced) */
+  rs.inp_count = rs.inpsize() / 2 - 1;
+  rs.inp_data = nullptr;
+  rs.out_count = 1000000;
+  rs.out_data = nullptr;
+  rs.process();
+  feed (in, n_frames);
+  if (trailing)
+    feed (nullptr, rs.inpsize() / 2);
+  return out;
+}
+
+/* add_stream_watermark with a WatermarkResampler (wmadd.cc:353-430, 520-589): input resampled to 44.1 kHz, watermark
+ * generated there frame by frame, resampled back and added to the original; limiter blocks of one second at the
+ * input rate.  The reference keeps feeding zero frames until as many frames are written as were read. */
+vector<float>
+add_watermark_rate (const uint8_t key[16], const float *in, size_t n_frames, int C, const vector<int>& payload, int rate)
+{
+  const size_t N = P::frame_size;
+  const size_t extra = 16 * N;                                     /* zero frames after the input: more than anything can reach */
+  vector<float> padded ((n_frames + extra) * C, 0.f);
+  std::copy (in, in + n_frames * C, padded.begin());
+  const vector<float> x44 = zita_stream (padded.data(), n_frames + extra, C, rate, P::mark_sample_rate, false);
+  const size_t frames44 = x44.size() / C / N;                      /* whole frames that became available */
+  const vector<float> wm44 = watermark_signal (key, x44.data(), frames44 * N, C, payload, frames44);
+  const vector<float> wm = zita_stream (wm44.data(), wm44.size() / C, C, P::mark_sample_rate, rate, false);
+  vector<float> mixed ((n_frames + 3 * size_t (rate)) * C, 0.f);
+  for (size_t v = 0; v < n_frames * C; v++)
+    mixed[v] = (v < wm.size() ? wm[v] : 0.f) + in[v];               /* samples[i] += orig_samples[i] */
+  if (P::test_no_limiter)
+    return vector<float> (mixed.begin(), mixed.begin() + n_frames * C);
+  return limiter_process (mixed, n_frames, C, size_t (rate));
+}
+
 void
 orc_set_params (double water_delta, int mix, int frames_per_bit, int test_no_limiter, double sync_threshold2, int n_best, double chunk_size_min)
 {
@@ -1390,12 +1660,17 @@ int
 orc_add (const uint8_t key[16], const float *samples, size_t n_frames, int n_channels, int sample_rate,
          const char *payload_hex, float *out, size_t *out_frames, double *)
 {
-  if (sample_rate != P::mark_sample_rate)
-    return 1;                                          /* resampling (zita) is outside the oracle */
   const auto payload = parse_payload (payload_hex);
   if (payload.empty())
     return 1;
-  const auto r = add_watermark (key, samples, n_frames, n_channels, payload);
+  if (sample_rate != P::mark_sample_rate)
+    {
+      ZitaResampler probe;
+      if (probe.setup (sample_rate, P::mark_sample_rate, n_channels, 16) || probe.setup (P::mark_sample_rate, sample_rate, n_channels, 16))
+        return 1;                                      /* would need zita's VResampler */
+    }
+  const auto r = sample_rate == P::mark_sample_rate ? add_watermark (key, samples, n_frames, n_channels, payload)
+                                                    : add_watermark_rate (key, samples, n_frames, n_channels, payload, sample_rate);
   std::copy (r.begin(), r.end(), out);
   if (out_frames)
     *out_frames = n_frames;
@@ -1470,6 +1745,17 @@ int
 orc_get (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, size_t max_out, orc_pattern *out)
 {
   return fill_patterns (get_watermark (key, samples, n_values, n_channels), max_out, out);
+}
+
+/* WavChunkLoader's view of a file with another sample rate: the 44.1 kHz stream it decodes (parity unpinned, see above).
+ * Returns the number of output frames (0 if zita's fixed-ratio Resampler cannot do the conversion). */
+size_t
+orc_resample (const float *samples, size_t n_frames, int n_channels, int rate_in, int rate_out, size_t max_out_frames, float *out)
+{
+  const auto r = zita_stream (samples, n_frames, n_channels, rate_in, rate_out, true);
+  const size_t frames = r.size() / n_channels;
+  std::copy (r.begin(), r.begin() + std::min (frames, max_out_frames) * n_channels, out);
+  return frames;
 }
 
 } /* extern "C" */

@@ -43,6 +43,10 @@ void   orc_ifft (size_t n, const float *spect, float *out);
 int    orc_add (const uint8_t key[16], const float *samples, size_t n_frames, int n_channels, int sample_rate,
                 const char *payload_hex, float *out, size_t *out_frames, double *snr_db);
 
+/* sample rates other than 44100 Hz (zita-resampler restated, PARITY UNPINNED): orc_add accepts them; this is the
+ * 44.1 kHz stream `get` decodes for such a file */
+size_t orc_resample (const float *samples, size_t n_frames, int n_channels, int rate_in, int rate_out, size_t max_out_frames, float *out);
+
 int    orc_sync_fft (const float *samples, size_t n_values, int n_channels, size_t index, size_t frame_count,
                      const char *want_frames, size_t first, size_t last, float *db_out, char *have_out);
 double orc_sync_decode (const uint8_t key[16], int clip_mode, size_t start_frame,

@@ -174,6 +174,18 @@ def add(key, samples, n_channels, payload_hex, sample_rate=44100):
     return out[:of.value * n_channels]
 
 
+def resample(samples, n_channels, rate_in, rate_out):
+    """The stream WavChunkLoader decodes for a file at rate_in (zita restated -- parity unpinned)."""
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    n_frames = samples.size // n_channels
+    cap = int(n_frames * rate_out / rate_in) + 64
+    out = np.zeros(cap * n_channels, np.float32)
+    lib().orc_resample.restype = C.c_size_t
+    n = lib().orc_resample(_p(samples), C.c_size_t(n_frames), n_channels, rate_in, rate_out, C.c_size_t(cap), _p(out))
+    assert 0 < n <= cap
+    return out[:n * n_channels]
+
+
 def sync_fft(samples, n_channels, index, frame_count, want_frames=None, first=0, last=None):
     samples = np.ascontiguousarray(samples, np.float32).ravel()
     if last is None:

@@ -427,6 +427,50 @@ def test_sharded_two_ranks_equal_single_process(gpu):
         gpu.awm.set_params()
 
 
+# ---- sample rates other than 44100 Hz (zita-resampler restated on both sides: parity with zita itself is unpinned) ----
+@pytest.mark.parametrize("rate_in,rate_out,ch,n", [(48000, 44100, 2, 100000), (44100, 48000, 2, 77777), (96000, 44100, 1, 50001),
+                                                   (22050, 44100, 2, 30000), (48000, 44100, 1, 5), (32000, 44100, 2, 1)])
+def test_resample_matches_restated_zita(gpu, rate_in, rate_out, ch, n):
+    x = noise(700 + n % 89, n, ch)
+    want = orc.resample(x, ch, rate_in, rate_out).reshape(-1, ch)
+    got = gpu.ctx.resample(gpu.dev(x), rate_in, rate_out).cpu().numpy()
+    assert got.shape == want.shape and got.shape[0] == -(-n * rate_out // rate_in)      # ceil (n * rate_out / rate_in)
+    assert np.array_equal(got, want)                                                     # same products, same order
+
+
+def test_resample_unsupported_ratio(gpu):
+    with pytest.raises(gpu.awm.AwmError):
+        gpu.ctx.resample(gpu.dev(noise(1, 1000, 1)), 33333, 44100)                       # zita would fall back to VResampler
+
+
+@pytest.mark.parametrize("rate,ch,limiter", [(48000, 2, True), (96000, 1, True), (32000, 2, False)])
+def test_add_at_other_rates(gpu, rate, ch, limiter):
+    n = 60 * rate + 123
+    x = noise(800 + ch, n, ch)
+    gpu.awm.set_params(test_no_limiter=not limiter)
+    orc.set_params(test_no_limiter=not limiter)
+    try:
+        want = orc.add(None, x, ch, PAY1, sample_rate=rate).reshape(n, ch)
+        got = gpu.ctx.add_watermark(None, PAY1, gpu.dev(x), sample_rate=rate).cpu().numpy()
+    finally:
+        gpu.awm.set_params()
+        orc.set_params()
+    assert rms(got, want) < RMS_TOL and np.abs(got - want).max() < 2e-6
+    assert 0.003 < rms(want, x) < 0.05
+
+
+def test_roundtrip_48k(gpu):
+    """add at 48 kHz, then what `get` does with a 48 kHz file: resample to 44.1 kHz and decode -- against the oracle's same steps."""
+    rate, n = 48000, 115 * 48000
+    x = noise(811, n, 2)
+    w = gpu.ctx.add_watermark(None, PAY2, gpu.dev(x), sample_rate=rate)
+    y = gpu.ctx.resample(w, rate, 44100)
+    got = gpu.ctx.get_watermark(None, y)
+    want = orc.get(None, orc.resample(w.cpu().numpy(), 2, rate, 44100), 2)
+    assert [pkey(p) for p in got] == [pkey(p) for p in want]
+    assert sum(p["bits"] == PAY2 for p in got) >= 3
+
+
 def test_many_chunks_on_lanes(gpu):
     """A stream cut into more chunks than there are work lanes (3 minute chunks of a 16 minute stream): the chunk groups, the
     concurrent lanes and the single-lane order must all give the oracle's pattern list."""
