@@ -69,7 +69,10 @@ def patterns_to_dicts(buf, count, first=0):
     hex strings are built with numpy instead of 128 Python operations per pattern)."""
     if count <= 0:
         return []
-    a = np.frombuffer(buf, dtype=np.dtype(Pattern), count=count, offset=first * C.sizeof(Pattern))
+    if isinstance(buf, np.ndarray):
+        a = buf[first:first + count]
+    else:
+        a = np.frombuffer(buf, dtype=np.dtype(Pattern), count=count, offset=first * C.sizeof(Pattern))
     bits = a["bits"].astype(np.uint8)
     nib = (bits[:, 0::4] << 3) | (bits[:, 1::4] << 2) | (bits[:, 2::4] << 1) | bits[:, 3::4]
     text = _HEX[nib]                                   # [count, 32] ASCII
@@ -194,6 +197,23 @@ def _pattern_from_dict(d):
     for i, b in enumerate(bits):
         p.bits[i] = b
     return p
+
+
+PATTERN_DTYPE = np.dtype(Pattern)
+
+
+def merge_patterns_raw(key, per_chunk_arrays):
+    """ResultSet.merge + sort over per-chunk structured arrays (dtype PATTERN_DTYPE, times already offset); returns dicts.
+    No per-pattern Python work: this runs inside the timed region of the multi-GPU path."""
+    counts = np.array([len(a) for a in per_chunk_arrays], np.int32)
+    total = int(counts.sum())
+    if total == 0:
+        return []
+    arr = np.ascontiguousarray(np.concatenate([a for a in per_chunk_arrays if len(a)]))
+    out = np.zeros(total, PATTERN_DTYPE)
+    n = lib.awm_merge_patterns(key_bytes(key), arr.ctypes.data_as(C.c_void_p), _np(counts), len(per_chunk_arrays), total,
+                               out.ctypes.data_as(C.c_void_p))
+    return patterns_to_dicts(out, min(n, total))
 
 
 def merge_patterns(key, per_chunk):
@@ -488,6 +508,20 @@ class Context:
         for i, d in enumerate(patterns_to_dicts(buf, min(cnt, max_out))):
             out[which[i]].append(d)
         return out
+
+    def decode_chunks_raw(self, key, pcm, chunks, first_is_stream_start, max_out=8192):
+        """decode_chunks without building Python objects: (patterns, which) -- a structured array (PATTERN_DTYPE, times relative
+        to the chunk) and the index into `chunks` each pattern belongs to."""
+        n, ch = _pcm_shape(pcm)
+        first = np.array([c[0] for c in chunks], np.uint64)
+        count = np.array([c[1] for c in chunks], np.uint64)
+        out = np.zeros(max_out, PATTERN_DTYPE)
+        which = np.zeros(max_out, np.int32)
+        cnt = _check(lib.awm_decode_chunks_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, len(chunks), _np(first), _np(count),
+                                             int(first_is_stream_start), max_out, out.ctypes.data_as(C.c_void_p), _np(which)),
+                     "awm_decode_chunks_d")
+        cnt = min(cnt, max_out)
+        return out[:cnt], which[:cnt]
 
     def decode_chunk(self, key, pcm, first_chunk=True):
         n, ch = _pcm_shape(pcm)

@@ -119,11 +119,15 @@ class Partition:
 
     # ---- get: reference chunks ----------------------------------------------------------------
     def chunk_plan(self):
-        """[(first_frame, n_frames, time_offset, owner_rank)] for the whole stream."""
-        out = []
-        for first, count, off in awm.plan_chunks(self.total):
-            out.append((first, count, off, self.owner_of(first + count // 2)))
-        return out
+        """[(first_frame, n_frames, time_offset, owner_rank)] for the whole stream (computed once: it is consulted several
+        times per `get`, inside the timed region)."""
+        plan = getattr(self, "_plan", None)
+        if plan is None:
+            plan = []
+            for first, count, off in awm.plan_chunks(self.total):
+                plan.append((first, count, off, self.owner_of(first + count // 2)))
+            self._plan = plan
+        return plan
 
     def chunk_range(self, rank):
         """(lo, hi, chunks) -- the global sample range rank must hold to decode its chunks; chunks are consecutive."""
@@ -136,6 +140,9 @@ class Partition:
 
     def transfers(self):
         """All point-to-point copies needed before `get`: (src_rank, dst_rank, global_lo, global_hi)."""
+        cached = getattr(self, "_transfers", None)
+        if cached is not None:
+            return cached
         out = []
         for dst in range(len(self.lengths)):
             lo, hi, _ = self.chunk_range(dst)
@@ -146,6 +153,7 @@ class Partition:
                 a, b = max(lo, s), min(hi, e)
                 if a < b:
                     out.append((src, dst, a, b))
+        self._transfers = out
         return out
 
 
@@ -193,22 +201,34 @@ def fetch_range(dist, part: Partition, local, n_channels):
 
 
 def gather_and_merge(dist, part: Partition, key, my_chunk_patterns):
-    """my_chunk_patterns: {global chunk index: [pattern dicts with chunk relative times]} -> merged list on rank 0."""
+    """my_chunk_patterns: {global chunk index: patterns with chunk relative times} -> merged list on rank 0.  The values are
+    structured arrays (binding.PATTERN_DTYPE) on the fast path or lists of pattern dicts (tests)."""
     plan = part.chunk_plan()
     payload = {}
+    raw = True
     for ci, pats in my_chunk_patterns.items():
         off = plan[ci][2]
-        payload[ci] = [dict(p, time=p["time"] + off) for p in pats]          # ResultSet::apply_time_offset
+        if isinstance(pats, np.ndarray):
+            pats = pats.copy()
+            pats["time"] += off                                                # ResultSet::apply_time_offset
+            payload[ci] = pats
+        else:
+            raw = False
+            payload[ci] = [dict(p, time=p["time"] + off) for p in pats]
     world = dist.get_world_size()
     gathered = [None] * world if dist.get_rank() == 0 else None
-    dist.gather_object(payload, gathered, dst=0)
+    dist.gather_object((raw, payload), gathered, dst=0)
     if dist.get_rank() != 0:
         return None
-    per_chunk = [[] for _ in plan]
-    for d in gathered:
+    all_raw = all(g[0] for g in gathered)
+    per_chunk = [np.zeros(0, awm.PATTERN_DTYPE) if all_raw else [] for _ in plan]
+    for is_raw, d in gathered:
         for ci, pats in d.items():
-            per_chunk[ci] = pats
-    return awm.merge_patterns(key, per_chunk)
+            if all_raw or not is_raw:
+                per_chunk[ci] = pats
+            else:
+                per_chunk[ci] = awm.patterns_to_dicts(pats, len(pats))
+    return awm.merge_patterns_raw(key, per_chunk) if all_raw else awm.merge_patterns(key, per_chunk)
 
 
 class ShardedStream:
@@ -271,8 +291,8 @@ class ShardedStream:
         found = {}
         if inside:
             rel = [(c[0] - my_s, c[1]) for _, c in inside]
-            lists = self.ctx.decode_chunks(key, view, rel, first_is_stream_start=(inside[0][1][0] == 0))
-            found.update({ci: pats for (ci, _), pats in zip(inside, lists)})
+            pats, which = self.ctx.decode_chunks_raw(key, view, rel, first_is_stream_start=(inside[0][1][0] == 0))
+            found.update({ci: pats[which == i] for i, (ci, _) in enumerate(inside)})
         finish()
         if cross:
             c_lo = min(c[0] for _, c in cross)
@@ -286,6 +306,6 @@ class ShardedStream:
                 if a < b:
                     buf[a - c_lo:b - c_lo] = t[a - g_lo:b - g_lo]
             rel = [(c[0] - c_lo, c[1]) for _, c in cross]
-            lists = self.ctx.decode_chunks(key, buf, rel, first_is_stream_start=(cross[0][1][0] == 0))
-            found.update({ci: pats for (ci, _), pats in zip(cross, lists)})
+            pats, which = self.ctx.decode_chunks_raw(key, buf, rel, first_is_stream_start=(cross[0][1][0] == 0))
+            found.update({ci: pats[which == i] for i, (ci, _) in enumerate(cross)})
         return gather_and_merge(self.dist, self.part, key, found)

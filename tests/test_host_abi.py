@@ -94,3 +94,12 @@ def test_merge_patterns_dedup_and_sort():
     assert len(out) == 6
     assert [p["bits"] for p in out[:5]] == [good] * 5 and out[5]["bits"] == junk
     assert out[4]["type"] == 2 and [round(p["time"], 1) for p in out[:4]] == [5.8, 57.4, 57.4, 109.1]
+    # the array path (no per-pattern Python objects; used inside the timed region of the multi-GPU path) gives the same list
+    def arr(chunk):
+        a = np.zeros(len(chunk), awm.PATTERN_DTYPE)
+        for i, d in enumerate(chunk):
+            p = awm.binding._pattern_from_dict(d)
+            a[i] = np.frombuffer(bytes(p), awm.PATTERN_DTYPE)[0]
+        return a
+    assert awm.merge_patterns_raw(None, [arr(chunk0), arr(chunk1)]) == out
+    assert awm.merge_patterns_raw(None, [arr([]), arr([])]) == []
