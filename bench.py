@@ -94,6 +94,8 @@ def main():
     ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per GPU")
     ap.add_argument("--cpu-sample-seconds", type=float, default=200.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="debug: take the multi-GPU (ShardedStream / torch.distributed) code path even with one process")
     args = ap.parse_args()
 
     import torch
@@ -107,12 +109,18 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    sharded_path = world > 1 or args.sharded
+    if sharded_path:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     n = int(args.minutes * 60 * RATE)
-    if world > 1:
+    if sharded_path:
         n -= n % 1024            # spans of a sharded stream are whole frames (only the last one may be ragged)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -120,7 +128,7 @@ def main():
     out = torch.empty_like(x)
     ctx = awm.Context(local_rank)
 
-    if world > 1:
+    if sharded_path:
         from audiowmark_amd import sharded
         pipe = sharded.ShardedStream(ctx, dist, n_frames_local=n, n_channels=2)
 
@@ -239,7 +247,14 @@ def main():
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds)
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        # RCCL prints its version banner through C stdio at exit; flush it first so that the JSON is the last line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(res), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
