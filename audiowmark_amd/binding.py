@@ -19,6 +19,11 @@ def library_path():
     return os.path.join(_HERE, "libawm_hip.so")
 
 
+# more hardware queues than the default 4, so that the lanes of `get` do not share one (see bench.py); only effective if the
+# HIP runtime has not been initialised yet by whoever imported us
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
+
 def _load_hip_runtime():
     """libawm_hip.so has no DT_NEEDED on a HIP runtime: bind it to the runtime of this process.  PyTorch
     ships its own libamdhip64.so (no SONAME) next to libtorch_hip.so; a second runtime in the same process

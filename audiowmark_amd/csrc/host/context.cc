@@ -1,4 +1,5 @@
 #include "context.hh"
+#include <cstdlib>
 #include "utils.hh"
 #include <cmath>
 #include <cstring>
@@ -366,6 +367,9 @@ awm_ctx_create (int device, awm_ctx **ctx_out)
   if (!ctx_out)
     return AWM_ERR_ARG;
   *ctx_out = nullptr;
+  // lanes are HIP streams; the runtime maps streams to GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one
+  // queue serialise.  No effect if the runtime is already initialised (e.g. inside a PyTorch process: set it there).
+  setenv ("GPU_MAX_HW_QUEUES", "8", 0);
   int n_dev = 0;
   hipError_t e = hipGetDeviceCount (&n_dev);
   if (e != hipSuccess || n_dev <= 0)

@@ -22,6 +22,12 @@ import os
 import sys
 import time
 
+# `get` runs the chunks of a stream on concurrent HIP streams (lanes).  The runtime multiplexes all streams of the process
+# onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run back to back; with the collective
+# library's own streams in the process two lanes ended up on one queue (multi-GPU step 9.0 ms instead of 7.5 ms).  Must be
+# set before the HIP runtime initialises, i.e. before torch is imported.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -153,8 +159,13 @@ def main():
     sync()
     t0 = time.perf_counter()
     pats = None
-    for _ in range(args.steps):
+    trace = os.environ.get("AWM_BENCH_TRACE")
+    for i in range(args.steps):
+        ts = time.perf_counter()
         pats = step()
+        if trace:
+            torch.cuda.synchronize(dev)
+            print(f"step {i}: {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr)
     sync()
     elapsed = time.perf_counter() - t0
     awm.lib.awm_prof_enable(ctx._h, 0)
