@@ -753,6 +753,18 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
       for (size_t i = 1; i < lanes.size(); i++)
         AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ctx->ev_sync, 0));
     }
+  // an error return must not leave kernels in flight on lanes whose buffers the next call will reuse
+  struct LaneDrain
+  {
+    const std::vector<WorkLane *>& lanes;
+    bool ok = false;
+    ~LaneDrain()
+    {
+      if (!ok)
+        for (WorkLane *l : lanes)
+          (void) hipStreamSynchronize (l->stream);
+    }
+  } drain { lanes };
   auto chunk_wav = [&] (size_t c) {
     DeviceWav cw = stream;
     cw.data = stream.data + chunks[c].first_frame * stream.n_channels;
@@ -825,6 +837,7 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
               return rc;
         }
     }
+  drain.ok = true;
   if (debug_sync_first_chunk)
     {
       debug_sync_first_chunk->clear();
