@@ -1716,12 +1716,69 @@ soft_bits_kernel (SoftBitsArgs a)
   a.out[blk * n_bits + bit] = float (umag - dmag);
 }
 
+/* K7 as one wave per soft bit.  A bit sums 30 mix entries x frames_per_bit x C terms, each of them three scattered dB values of
+ * the block's matrix (table lookup first, then the value: two dependent trips to memory).  With one thread per bit the
+ * 720 loads of a bit were issued almost one after the other (250 us for 31 000 threads on an otherwise idle GPU); here the
+ * lanes of a wave fetch the terms in parallel and stage them in LDS, and lane 0 adds them up in the reference's order
+ * (wmget.cc:67-108: double accumulators, terms in entry order), which keeps the result bit-identical. */
+constexpr int SB_WAVES = 4;           // bits per workgroup
+constexpr int SB_MAX_ITEMS = 256;     // frames_per_bit * C * 30 terms per bit (stereo: 120); more -> one thread per bit kernel
+
+__global__ void __launch_bounds__ (64 * SB_WAVES)
+soft_bits_wave_kernel (SoftBitsArgs a)
+{
+  __shared__ float4 s_item[SB_WAVES][SB_MAX_ITEMS];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long blk = blockIdx.y;
+  const int n_bits = a.n_data_frames / a.frames_per_bit;
+  const int bit = blockIdx.x * SB_WAVES + wave;
+  if (bit >= n_bits)
+    return;
+  const float *db = a.db + blk * a.block_stride;
+  const int C = a.n_channels;
+  const int n_items = a.frames_per_bit * C * 30;
+  for (int i = lane; i < n_items; i += 64)
+    {
+      // item order = summation order: frame of the bit, channel, entry
+      const int fi = i / (C * 30), ch = (i / 30) % C, j = i % 30;
+      const int b = (bit * a.frames_per_bit + fi) * 30 + j;
+      const int frame = a.mix_frame[b];
+      // neighbours reflected at the block edges (reference wmget.cc:87-88)
+      const int next = frame + 1 < a.block_frames ? frame + 1 : frame - 1;
+      const int prev = frame - 1 >= 0 ? frame - 1 : frame + 1;
+      const float *plane = db + (long long) ch * NB * a.ld;
+      const float *pu = plane + (long long) (a.mix_up[b] - MIN_BAND) * a.ld;
+      const float *pd = plane + (long long) (a.mix_down[b] - MIN_BAND) * a.ld;
+      s_item[wave][i] = make_float4 (pu[frame], __fadd_rn (pu[prev], pu[next]), pd[frame], __fadd_rn (pd[prev], pd[next]));
+    }
+  wave_sync();
+  if (lane == 0)
+    {
+      double umag = 0, dmag = 0;
+      for (int i = 0; i < n_items; i++)
+        {
+          const float4 t = s_item[wave][i];
+          umag = __dadd_rn (umag, double (t.x));
+          umag = __dsub_rn (umag, __dmul_rn (double (t.y), 0.5));
+          dmag = __dadd_rn (dmag, double (t.z));
+          dmag = __dsub_rn (dmag, __dmul_rn (double (t.w), 0.5));
+        }
+      a.out[blk * n_bits + bit] = float (__dsub_rn (umag, dmag));
+    }
+}
+
 hipError_t
 launch_soft_bits (hipStream_t st, const SoftBitsArgs& a)
 {
   if (a.n_blocks <= 0)
     return hipSuccess;
   const int n_bits = a.n_data_frames / a.frames_per_bit;
+  if (a.frames_per_bit * a.n_channels * 30 <= SB_MAX_ITEMS)
+    {
+      const dim3 grid (unsigned ((n_bits + SB_WAVES - 1) / SB_WAVES), unsigned (a.n_blocks));
+      hipLaunchKernelGGL (soft_bits_wave_kernel, grid, dim3 (64 * SB_WAVES), 0, st, a);
+      return hipGetLastError();
+    }
   const dim3 grid (unsigned ((n_bits + 127) / 128), unsigned (a.n_blocks));
   hipLaunchKernelGGL (soft_bits_kernel, grid, dim3 (128), 0, st, a);
   return hipGetLastError();
