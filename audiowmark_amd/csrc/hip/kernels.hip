@@ -1883,8 +1883,10 @@ launch_soft_prep (hipStream_t st, const SoftPrepArgs& a)
 hipError_t
 launch_nonzero_range (hipStream_t st, const float *data, long long n_values, unsigned long long *result)
 {
-  const unsigned long long init[2] = { (unsigned long long) n_values, 0 };
-  hipError_t e = hipMemcpyAsync (result, init, sizeof (init), hipMemcpyHostToDevice, st);
+  // result[0] = min index of a non-zero value (all ones if there is none), result[1] = max index + 1 (no host copy: async)
+  hipError_t e = hipMemsetAsync (result, 0xff, sizeof (unsigned long long), st);
+  if (e == hipSuccess)
+    e = hipMemsetAsync (result + 1, 0, sizeof (unsigned long long), st);
   if (e != hipSuccess || n_values <= 0)
     return e;
   hipLaunchKernelGGL (nonzero_range_kernel, dim3 (1024), dim3 (256), 0, st, data, n_values, result);

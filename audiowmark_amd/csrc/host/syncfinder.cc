@@ -15,15 +15,46 @@ total_frames (SyncFinder::Mode mode)
 int
 SyncFinder::scan_silence (const DeviceWav& wav)
 {
-  if (int rc = m_lane->ws_misc.reserve (64))
+  if (int rc = prepare_launch (wav, Mode::CLIP))
     return rc;
+  return prepare_finish();
+}
+
+int
+SyncFinder::prepare_launch (const DeviceWav& wav, Mode mode, size_t scan_lo, size_t scan_hi)
+{
+  m_prepare_pending = false;
+  if (mode != Mode::CLIP)
+    {
+      m_first = 0;
+      m_last = wav.n_values();
+      return 0;
+    }
+  // padding is not transformed and does not count (reference syncfinder.cc:155-169, 491-502)
+  if (int rc = m_lane->ws_misc.reserve (64)) return rc;
+  if (int rc = m_lane->pin_small.reserve (64)) return rc;
   auto *res = m_lane->ws_misc.as<unsigned long long>();
-  AWM_HIP_CHECK (awmk::launch_nonzero_range (m_lane->stream, wav.data, (long long) wav.n_values(), res));
-  unsigned long long h[2];
-  AWM_HIP_CHECK (hipMemcpyAsync (h, res, sizeof (h), hipMemcpyDeviceToHost, m_lane->stream));
+  scan_hi = std::min (scan_hi, wav.n_values());
+  scan_lo = std::min (scan_lo, scan_hi);
+  AWM_HIP_CHECK (awmk::launch_nonzero_range (m_lane->stream, wav.data + scan_lo, (long long) (scan_hi - scan_lo), res));
+  AWM_HIP_CHECK (hipMemcpyAsync (m_lane->pin_small.ptr, res, 2 * sizeof (unsigned long long), hipMemcpyDeviceToHost, m_lane->stream));
+  m_prepare_values = wav.n_values();
+  m_prepare_lo = scan_lo;
+  m_prepare_pending = true;
+  return 0;
+}
+
+int
+SyncFinder::prepare_finish()
+{
+  if (!m_prepare_pending)
+    return 0;
+  m_prepare_pending = false;
   AWM_HIP_CHECK (stream_wait (m_lane->stream));
-  m_first = h[0];
-  m_last = h[0] >= wav.n_values() ? wav.n_values() : h[1];
+  const auto *h = m_lane->pin_small.as<unsigned long long>();
+  const bool none = h[0] == ~0ULL;                       // every value is zero
+  m_first = none ? m_prepare_values : m_prepare_lo + h[0];
+  m_last = none ? m_prepare_values : m_prepare_lo + h[1];
   return 0;
 }
 
@@ -149,10 +180,10 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
   return select_finish (n_scores, threshold, out);
 }
 
-namespace { constexpr unsigned int PEAK_CAP = 16384, PEAK_HEAD = 1024; }
+namespace { constexpr unsigned int PEAK_CAP = 16384, PEAK_HEAD = 1024; constexpr int TOPK_MAX = 64, TOPK_SLICES = 64; }
 
 int
-SyncFinder::select_launch (long long n_scores, double threshold)
+SyncFinder::select_launch (long long n_scores, double threshold, bool speculate_n_best)
 {
   if (n_scores <= 0)
     return 0;
@@ -166,13 +197,26 @@ SyncFinder::select_launch (long long n_scores, double threshold)
     AWM_HIP_CHECK (awmk::launch_peak_select (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, threshold, d_count, d_out, cap));
   }
   // one round trip for the counter and the first peaks (usually all of them), through page-locked memory
-  if (int rc = m_lane->pin_peaks.reserve (256 + cap * sizeof (awmk::PeakOut))) return rc;
+  if (int rc = m_lane->pin_peaks.reserve (256 + cap * sizeof (awmk::PeakOut) + TOPK_MAX * TOPK_SLICES * sizeof (awmk::PeakOut))) return rc;
   AWM_HIP_CHECK (hipMemcpyAsync (m_lane->pin_peaks.ptr, d_count, 256 + PEAK_HEAD * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
+  if (speculate_n_best && Params::get_n_best + 1 <= TOPK_MAX)
+    {
+      // Short material rarely has n_best peaks above the threshold: queue the fallback (all unmasked maxima, reduced to
+      // the n_best + 1 largest per slice) right away, so that select_finish finds both answers after ONE wait.
+      const unsigned int big_cap = unsigned (std::min<long long> (n_scores, 1 << 22));
+      if (int rc = m_lane->ws_refine.reserve (size_t (big_cap) * sizeof (awmk::PeakOut))) return rc;
+      auto *d_all = m_lane->ws_refine.as<awmk::PeakOut>();
+      AWM_HIP_CHECK (awmk::launch_peak_select (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, -1.0, d_count, d_all, big_cap));
+      const int k = Params::get_n_best + 1;
+      AWM_HIP_CHECK (awmk::launch_peak_topk (st, d_all, d_count, big_cap, d_out, k, TOPK_SLICES));      // the threshold list is already on its way
+      AWM_HIP_CHECK (hipMemcpyAsync (m_lane->pin_peaks.as<char>() + 256 + cap * sizeof (awmk::PeakOut), d_out,
+                                     size_t (k) * TOPK_SLICES * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
+    }
   return 0;
 }
 
 int
-SyncFinder::select_finish (long long n_scores, double threshold, std::vector<SearchScore>& out)
+SyncFinder::select_finish (long long n_scores, double threshold, std::vector<SearchScore>& out, bool speculated)
 {
   out.clear();
   if (n_scores <= 0)
@@ -206,23 +250,34 @@ SyncFinder::select_finish (long long n_scores, double threshold, std::vector<Sea
   // fewer than n_best peaks above the threshold: the reference then keeps the n_best largest unmasked maxima.
   // Fetch ALL unmasked local maxima (threshold -1) from the device and finish the selection here.
   const unsigned int big_cap = unsigned (std::min<long long> (n_scores, 1 << 22));
+  speculated = speculated && Params::get_n_best + 1 <= TOPK_MAX;
   if (int rc = m_lane->ws_refine.reserve (size_t (big_cap) * sizeof (awmk::PeakOut))) return rc;
   auto *d_all = m_lane->ws_refine.as<awmk::PeakOut>();
-  AWM_HIP_CHECK (awmk::launch_peak_select (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, -1.0, d_count, d_all, big_cap));
+  if (!speculated)
+    AWM_HIP_CHECK (awmk::launch_peak_select (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, -1.0, d_count, d_all, big_cap));
   // Only the n_best largest survive select_threshold_and_n_best here (fewer than n_best are above the threshold), so
   // reduce the list on the device: n_best + 1 per slice, so that a tie across the cut is visible -- in that case
   // (degenerate input) the complete list goes through the same std::sort as in the reference instead.
   const int k = Params::get_n_best + 1;
-  constexpr int n_slices = 64;
+  constexpr int n_slices = TOPK_SLICES;
   const bool fewer_than_n_best = int (count) < Params::get_n_best;      // (not: more than `cap` above the threshold)
-  if (fewer_than_n_best && k <= 64 && !getenv ("AWM_NBEST_HOST"))
+  if (fewer_than_n_best && k <= TOPK_MAX && !getenv ("AWM_NBEST_HOST"))
     {
-      auto *d_top = reinterpret_cast<awmk::PeakOut *> (m_lane->ws_misc.as<char>() + 256);      // the threshold list is dead
-      static_assert (sizeof (awmk::PeakOut) * 64 * n_slices <= 16384 * sizeof (awmk::PeakOut), "ws_misc too small");
-      AWM_HIP_CHECK (awmk::launch_peak_topk (st, d_all, d_count, big_cap, d_top, k, n_slices));
       std::vector<awmk::PeakOut> top (size_t (k) * n_slices);
-      AWM_HIP_CHECK (hipMemcpyAsync (top.data(), d_top, top.size() * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
-      AWM_HIP_CHECK (stream_wait (st));
+      if (speculated)
+        {
+          // already computed and copied by select_launch
+          const auto *src = reinterpret_cast<const awmk::PeakOut *> (pin + 256 + cap * sizeof (awmk::PeakOut));
+          std::copy (src, src + top.size(), top.begin());
+        }
+      else
+        {
+          auto *d_top = reinterpret_cast<awmk::PeakOut *> (m_lane->ws_misc.as<char>() + 256);      // the threshold list is dead
+          static_assert (sizeof (awmk::PeakOut) * TOPK_MAX * n_slices <= PEAK_CAP * sizeof (awmk::PeakOut), "ws_misc too small");
+          AWM_HIP_CHECK (awmk::launch_peak_topk (st, d_all, d_count, big_cap, d_top, k, n_slices));
+          AWM_HIP_CHECK (hipMemcpyAsync (top.data(), d_top, top.size() * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
+          AWM_HIP_CHECK (stream_wait (st));
+        }
       top.erase (std::remove_if (top.begin(), top.end(), [] (const awmk::PeakOut& pk) { return pk.p < 0; }), top.end());
       auto absq = [] (const awmk::PeakOut& pk) { return std::fabs (pk.raw - pk.mean); };
       std::sort (top.begin(), top.end(), [&] (const awmk::PeakOut& a, const awmk::PeakOut& b) {
@@ -569,11 +624,9 @@ SyncFinder::refine_finish (SearchJob& job, std::vector<SearchScore>& scores)
 int
 SyncFinder::prepare (const DeviceWav& wav, Mode mode)
 {
-  if (mode == Mode::CLIP)
-    return scan_silence (wav);       // padding is not transformed and does not count (reference syncfinder.cc:491-502)
-  m_first = 0;
-  m_last = wav.n_values();
-  return 0;
+  if (int rc = prepare_launch (wav, mode))
+    return rc;
+  return prepare_finish();
 }
 
 /* reference syncfinder.cc:487-558 */
@@ -595,7 +648,7 @@ SyncFinder::search_launch (const Key& key, const DeviceWav& wav, Mode mode, Sear
 }
 
 int
-SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job)
+SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool prepared)
 {
   job.out.clear();
   job.done = true;
@@ -617,15 +670,17 @@ SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, Sear
         }
       return 0;
     }
-  if (int rc = prepare (wav, mode))
-    return rc;
+  if (!prepared)
+    if (int rc = prepare (wav, mode))
+      return rc;
   job.kt = kt;
   job.wav = wav;
   job.mode = mode;
   job.n_scores = 0;
   if (int rc = approx_device (kt, wav, mode, job.n_scores))
     return rc;
-  if (int rc = select_launch (job.n_scores, Params::sync_threshold2 * 0.75))
+  job.speculate_n_best = mode == Mode::CLIP;            // clips hold one or two sync peaks: the n_best fallback is the rule
+  if (int rc = select_launch (job.n_scores, Params::sync_threshold2 * 0.75, job.speculate_n_best))
     return rc;
   job.done = false;
   job.select_pending = true;
@@ -638,7 +693,7 @@ SyncFinder::select_refine (SearchJob& job)
   if (job.done || !job.select_pending)
     return 0;
   job.select_pending = false;
-  if (int rc = select_finish (job.n_scores, Params::sync_threshold2 * 0.75, job.candidates))
+  if (int rc = select_finish (job.n_scores, Params::sync_threshold2 * 0.75, job.candidates, job.speculate_n_best))
     return rc;
   if (job.mode == Mode::CLIP)
     select_truncate_n (job.candidates, std::max (Params::get_n_best, 5));

@@ -40,13 +40,17 @@ public:
 
   int search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out);
   int prepare (const DeviceWav& wav, Mode mode);     // silence scan (CLIP) / full range (BLOCK)
+  // the same without waiting for the device; [scan_lo, scan_hi) = values that can be non-zero at all (a caller that padded
+  // the buffer itself knows where the data is: the silence scan then skips the padding)
+  int prepare_launch (const DeviceWav& wav, Mode mode, size_t scan_lo = 0, size_t scan_hi = size_t (-1));
+  int prepare_finish();                                   // ... and the wait
   int search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& out);
   // kernels of search_approx only: scores stay on the device (ws_raw / ws_mean, index order); n_scores = 4 * start frames
   int approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores);
   // local maxima + mask + threshold (+ n_best fallback): the candidate list search_refine works on
   int select_candidates (long long n_scores, double threshold, std::vector<SearchScore>& out);
-  int select_launch (long long n_scores, double threshold);                                 // device part of it, not waited for
-  int select_finish (long long n_scores, double threshold, std::vector<SearchScore>& out);
+  int select_launch (long long n_scores, double threshold, bool speculate_n_best = false);   // device part of it, not waited for
+  int select_finish (long long n_scores, double threshold, std::vector<SearchScore>& out, bool speculated = false);
   int search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& scores);
 
   /* search() in two halves, so that a caller with several chunks can issue the next chunk's search while the
@@ -69,12 +73,13 @@ public:
     Mode       mode = Mode::BLOCK;
     long long  n_scores = 0;
     bool       select_pending = false;
+    bool       speculate_n_best = false;    // queue the n_best fallback together with the threshold selection (one round trip)
   };
   int search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job);     // = approx_launch + select_refine
   int search_finish (SearchJob& job, std::vector<Score>& out);
   // finer steps for callers that drive several lanes: approx_launch never waits for the device,
   // select_refine waits for this lane's candidate list and queues the refinement
-  int approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job);
+  int approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool prepared = false);
   int select_refine (SearchJob& job);
 
   static void select_local_maxima (std::vector<SearchScore>& scores);
@@ -85,6 +90,8 @@ private:
   awm_ctx  *m_ctx;
   WorkLane *m_lane;                     // stream, workspaces and staging buffers of this finder
   size_t   m_first = 0, m_last = 0;     // non-silent value range [first, last)
+  size_t   m_prepare_values = 0, m_prepare_lo = 0;
+  bool     m_prepare_pending = false;
   int scan_silence (const DeviceWav& wav);
   int fetch_scores (long long n_scores, std::vector<SearchScore>& out);
   int refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, SearchJob& job);

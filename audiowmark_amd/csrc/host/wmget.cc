@@ -1099,6 +1099,141 @@ get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const Devi
   return get_watermark_on (ctx, ctx, true, key_list, wav, result_set);
 }
 
+/* Short clips (less than one block + 2 frames: 51.7 s) go through exactly one thing in `get`: the ClipDecoder's START pass
+ * (the block decoder finds no room for a block, the END pass needs more than one long block; reference wmget.cc:769-884,
+ * 886-939).  For a batch of them that pass is run stage by stage over a group of lanes from ONE host thread: pad + silence
+ * scan for all clips of the group, approximate search for all, candidate selection + refinement for all, soft bits +
+ * Viterbi for all -- the device sees up to MAX_LANES independent chains of small kernels, the host waits once per
+ * stage and lane instead of ten times per clip, and no two host threads fight over the runtime. */
+static bool
+clip_is_short (const DeviceWav& w)
+{
+  return w.n_frames > 0 && w.n_frames < (mark_block_frame_count() + 2) * Params::frame_size;
+}
+
+static int
+clip_batch_staged (awm_ctx *ctx, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips, const std::vector<size_t>& which,
+                   std::vector<ResultSet>& result_sets)
+{
+  const size_t count = mark_block_frame_count();
+  std::vector<WorkLane *> lanes;
+  for (int i = 0; i < int (std::min<size_t> (which.size(), MAX_LANES)); i++)
+    {
+      WorkLane *l = ctx->lane (i);
+      if (!l)
+        {
+          set_error ("cannot create a work lane (stream)");
+          return AWM_ERR_HIP;
+        }
+      lanes.push_back (l);
+    }
+  struct LaneDrain
+  {
+    const std::vector<WorkLane *>& lanes;
+    bool ok = false;
+    ~LaneDrain() { if (!ok) for (WorkLane *l : lanes) (void) hipStreamSynchronize (l->stream); }
+  } drain { lanes };
+  std::vector<ResultSet> chunk_sets (which.size());
+  for (size_t g0 = 0; g0 < which.size(); g0 += lanes.size())
+    {
+      const size_t gn = std::min (lanes.size(), which.size() - g0);
+      std::vector<DeviceWav> padded (gn);
+      // stage 0: padded copy (reference wmget.cc:830-867, START position) on the lane
+      for (size_t i = 0; i < gn; i++)
+        {
+          const DeviceWav& wav = clips[which[g0 + i]];
+          WorkLane *lane = lanes[i];
+          const size_t C = wav.n_channels;
+          const size_t n = (count + 5) * Params::frame_size * C;                     // in values
+          const size_t len = wav.n_values();                                          // < n for a short clip
+          const size_t pad_start = n + (n - len), total = pad_start + len + n;       // data + padding cover one long block
+          if (int rc = lane->ws_clip.reserve (total * sizeof (float)))
+            return rc;
+          float *ext = lane->ws_clip.as<float>();
+          AWM_HIP_CHECK (hipMemsetAsync (ext, 0, pad_start * sizeof (float), lane->stream));
+          AWM_HIP_CHECK (hipMemcpyAsync (ext + pad_start, wav.data, len * sizeof (float), hipMemcpyDeviceToDevice, lane->stream));
+          AWM_HIP_CHECK (hipMemsetAsync (ext + pad_start + len, 0, n * sizeof (float), lane->stream));
+          padded[i].data = ext;
+          padded[i].n_frames = total / C;
+          padded[i].n_channels = wav.n_channels;
+          padded[i].sample_rate = wav.sample_rate;
+        }
+      for (const Key& key : key_list)
+        {
+          KeyTables *kt = ctx->get_key_tables (key);
+          if (!kt)
+            return AWM_ERR_HIP;
+          std::vector<SyncFinder> finders;
+          std::vector<SyncFinder::SearchJob> jobs (gn);
+          std::vector<DecodeJob> decodes (gn);
+          for (size_t i = 0; i < gn; i++)
+            finders.emplace_back (ctx, lanes[i]);
+          for (size_t i = 0; i < gn; i++)
+            {
+              // only the copied clip can hold non-zero values: the silence scan skips the padding
+              const DeviceWav& wav = clips[which[g0 + i]];
+              const size_t n = (count + 5) * Params::frame_size * wav.n_channels, len = wav.n_values();
+              if (int rc = finders[i].prepare_launch (padded[i], SyncFinder::Mode::CLIP, n + (n - len), n + (n - len) + len))
+                return rc;
+            }
+          for (size_t i = 0; i < gn; i++)
+            {
+              if (int rc = finders[i].prepare_finish())
+                return rc;
+              if (int rc = finders[i].approx_launch (key, padded[i], SyncFinder::Mode::CLIP, jobs[i], /* prepared */ true))
+                return rc;
+            }
+          for (size_t i = 0; i < gn; i++)
+            if (int rc = finders[i].select_refine (jobs[i]))
+              return rc;
+          for (size_t i = 0; i < gn; i++)
+            {
+              std::vector<SyncFinder::Score> sync_scores;
+              if (int rc = finders[i].search_finish (jobs[i], sync_scores))
+                return rc;
+              std::vector<size_t> index;
+              for (const auto& sc : sync_scores)
+                {
+                  index.push_back (sc.index);
+                  index.push_back (sc.index + count * Params::frame_size);
+                }
+              std::vector<int> slot_of;
+              std::vector<char> ok;
+              if (int rc = block_soft_bits_dev (ctx, lanes[i], kt, padded[i], index, slot_of, ok))
+                return rc;
+              auto& pending = decodes[i].pending;
+              for (size_t k = 0; k < sync_scores.size(); k++)
+                {
+                  if (!ok[2 * k] || !ok[2 * k + 1])
+                    continue;
+                  const int first_half = sync_scores[k].block_type == ConvBlockType::a ? 0 : 1;
+                  SyncFinder::Score nopad = sync_scores[k];
+                  nopad.index = 0;                                                 // time offset of the START position is 0
+                  pending.push_back ({ ConvBlockType::ab, 1, { { slot_of[2 * k], first_half }, { slot_of[2 * k + 1], 1 - first_half } }, 0, 0,
+                                       0.0, nopad, ResultSet::Type::CLIP, g0 + i });
+                }
+              if (int rc = decode_launch (ctx, lanes[i], kt, decodes[i]))
+                return rc;
+            }
+          std::vector<ResultSet *> ptrs;
+          for (auto& cs : chunk_sets)
+            ptrs.push_back (&cs);
+          for (size_t i = 0; i < gn; i++)
+            if (int rc = decode_finish (lanes[i], key, decodes[i], ptrs, 1))
+              return rc;
+        }
+    }
+  drain.ok = true;
+  for (size_t j = 0; j < which.size(); j++)
+    {
+      ResultSet& rs = result_sets[which[j]];                        // as get_watermark_device: one chunk at offset 0, merge, sort
+      chunk_sets[j].apply_time_offset (0.0);
+      rs.merge (chunk_sets[j]);
+      rs.sort (key_list);
+    }
+  return 0;
+}
+
 /* get_watermark for many independent inputs (BASELINE config 5: a batch of short clips).  A clip's `get` is a chain of
  * small, latency bound steps (two padded CLIP searches, two one-CU Viterbi decodes, ~10 host round trips: 2 ms for a
  * 30 s clip that keeps the GPU busy for a fraction of that), so the clips are spread over the context's lanes, each
@@ -1112,7 +1247,27 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
   result_sets.resize (clips.size());
   if (clips.empty())
     return 0;
-  n_threads = std::max (1, std::min<int> ({ n_threads > 0 ? n_threads : MAX_LANES, MAX_LANES, int (clips.size()) }));
+  // short clips: staged over the lanes from this thread; everything else: one clip per lane and host thread
+  std::vector<size_t> staged, threaded;
+  for (size_t i = 0; i < clips.size(); i++)
+    (clip_is_short (clips[i]) && !getenv ("AWM_BATCH_THREADS") ? staged : threaded).push_back (i);
+  if (!staged.empty())
+    {
+      if (!ctx->ev_sync)
+        AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
+      AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));                   // the clips may still be in flight there
+      for (int i = 1; i < int (std::min<size_t> (staged.size(), MAX_LANES)); i++)
+        {
+          WorkLane *l = ctx->lane (i);
+          if (l)
+            AWM_HIP_CHECK (hipStreamWaitEvent (l->stream, ctx->ev_sync, 0));
+        }
+      if (int rc = clip_batch_staged (ctx, key_list, clips, staged, result_sets))
+        return rc;
+    }
+  if (threaded.empty())
+    return 0;
+  n_threads = std::max (1, std::min<int> ({ n_threads > 0 ? n_threads : MAX_LANES, MAX_LANES, int (threaded.size()) }));
   std::vector<WorkLane *> lanes;
   for (int i = 0; i < n_threads; i++)
     {
@@ -1148,14 +1303,15 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
       }
     for (;;)
       {
-        const size_t i = next.fetch_add (1);
-        if (i >= clips.size())
+        const size_t t = next.fetch_add (1);
+        if (t >= threaded.size())
           break;
+        const size_t i = threaded[t];
         if (int r = get_watermark_on (ctx, lanes[li], false, key_list, clips[i], result_sets[i]))
           {
             rc[li] = r;
             err[li] = last_error();
-            next.store (clips.size());             // stop the other workers
+            next.store (threaded.size());          // stop the other workers
             break;
           }
       }
