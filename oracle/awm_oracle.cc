@@ -10,6 +10,8 @@
  * x86-64 where float expressions are never fused.
  */
 #include "awm_oracle.h"
+#include "zita_restated.h"
+#include "sha1.h"
 #include "aes128.h"
 
 #include <algorithm>
@@ -658,7 +660,7 @@ limiter_process (const vector<float>& mixed, size_t n_frames, int C, size_t limi
 }
 
 /* ---- sync search (syncfinder.cc) --------------------------------------------------------- */
-struct Wav { const float *s; size_t n_values; int C; size_t frames() const { return n_values / C / P::frame_size; } };
+struct Wav { const float *s; size_t n_values; int C; int rate = 44100; size_t frames() const { return n_values / C / P::frame_size; } };
 
 struct SyncCtx { size_t first = 0, last = 0; };
 
@@ -1088,7 +1090,7 @@ struct Decoder
         if (!block_bits (w, s.index, r.bits))
           continue;
         raws.push_back (r);
-        add_decoded (res, s.block_type, r.bits, double (s.index) / P::mark_sample_rate, s, 0);
+        add_decoded (res, s.block_type, r.bits, double (s.index) / w.rate, s, 0);
       }
     for (size_t i = 0; i < raws.size(); i++)                               /* AB pairs */
       if (raws[i].block_type == 1)
@@ -1112,7 +1114,7 @@ struct Decoder
                   ab[2 * k] = raws[best_j].bits[k];
                   ab[2 * k + 1] = raws[i].bits[k];
                 }
-              add_decoded (res, 2, ab, double (raws[i].index) / P::mark_sample_rate,
+              add_decoded (res, 2, ab, double (raws[i].index) / w.rate,
                            { raws[i].index, (raws[best_j].quality + raws[i].quality) / 2, 2 }, 0);
             }
         }
@@ -1192,10 +1194,10 @@ struct Decoder
         first = w.n_values - n;
         last = w.n_values;
       }
-    const double time_offset = double (first) / P::mark_sample_rate / w.C;
+    const double time_offset = double (first) / w.rate / w.C;
     vector<float> ext (pad_start + (last - first) + pad_end, 0.f);
     std::copy (w.s + first, w.s + last, ext.begin() + pad_start);
-    const Wav lw { ext.data(), ext.size(), w.C };
+    const Wav lw { ext.data(), ext.size(), w.C, w.rate };
     const size_t count = block_frame_count();
     for (const auto& s : sync_search (key, lw, true))
       {
@@ -1209,21 +1211,359 @@ struct Decoder
             ab.push_back (s.block_type == 0 ? b2[k] : b1[k]);
           }
         Score nopad = s;
-        nopad.index = time_offset * P::mark_sample_rate;
+        nopad.index = time_offset * w.rate;
         add_decoded (res, 2, ab, time_offset, nopad, 1);
       }
   }
   void
-  decode (const Wav& w, bool first_chunk, vector<Pattern>& res)            /* wmget.cc:886-939 */
+  decode_plain (const Wav& w, bool first_chunk, vector<Pattern>& res, double speed)
   {
+    const size_t before = res.size();
     block_decoder (w, res);
     if (first_chunk && int (w.n_values / (P::frame_size * w.C)) < int (block_frame_count()) * 3.1)
       {
         clip_block (w, res, false);
         clip_block (w, res, true);
       }
+    for (size_t i = before; i < res.size(); i++)
+      res[i].speed = speed;
+  }
+  void decode (const Wav& w, bool first_chunk, vector<Pattern>& res);     /* wmget.cc:886-939, below (needs the speed detection) */
+};
+
+
+/* ---- speed detection (wmspeed.cc) and the VResampler call sequences (resample.cc:29-125) --------------------------
+ * zita-resampler restated (zita_restated.h): PARITY UNPINNED against the real library. */
+template<class R> void
+process_resampler (R& rs, const float *in, size_t in_values, float *out, size_t out_values)      /* resample.cc:29-50 */
+{
+  rs.out_count = unsigned (out_values / rs.nchan());
+  rs.out_data = out;
+  rs.inp_count = rs.inpsize() / 2 - 1;               /* "avoid timeshift": k/2 - 1 null frames before the input */
+  rs.inp_data = nullptr;
+  rs.process();
+  rs.inp_count = unsigned (in_values / rs.nchan());
+  rs.inp_data = in;
+  rs.process();
+  rs.inp_count = rs.inpsize() / 2;                   /* k/2 null frames after it */
+  rs.inp_data = nullptr;
+  rs.process();
+}
+
+vector<float>
+resample_ratio_truncate (const float *in, size_t n_values, int C, int rate, double ratio, double max_in_seconds)   /* resample.cc:96-119 */
+{
+  size_t in_values = n_values;
+  if (max_in_seconds > 0)
+    in_values = std::min<size_t> (in_values, C * lrint (rate * max_in_seconds));
+  vector<float> out (size_t (lrint (in_values / C * ratio)) * C);
+  ZitaVResampler rs;
+  if (rs.setup (ratio, C, 16) != 0)
+    return {};
+  process_resampler (rs, in, in_values, out.data(), out.size());
+  return out;
+}
+
+struct SpeedScanParams { double seconds; double step; int n_steps; int n_center_steps; };
+struct SpeedScore { double speed = 0, quality = 0; };
+
+struct SpeedClip { const float *s; size_t n_values; };
+SpeedClip
+get_speed_clip (double location, const float *s, size_t n_values, int C, int rate, double clip_seconds)   /* wmspeed.cc:33-52 */
+{
+  const size_t n_frames = n_values / C;
+  const double end_sec = double (n_frames) / rate;
+  double start_sec = location * (end_sec - clip_seconds);
+  if (start_sec < 0)
+    start_sec = 0;
+  const size_t start_point = start_sec * rate;
+  const size_t end_point = std::min<size_t> (start_point + clip_seconds * rate, n_frames);
+  return { s + start_point * C, (end_point - start_point) * C };
+}
+
+const FFT& fft512() { static FFT f (512); return f; }
+
+/* SpeedSync (wmspeed.cc:96-395): one centre speed; the magnitude matrix is [column = sync frame][row = time step] */
+struct SpeedSync
+{
+  struct Bit { int bit; const FrameBit *fb; };
+  vector<vector<FrameBit>> table;
+  vector<Bit> bits;                                  /* all 510 sync frames of a block sorted by frame */
+  vector<float> umag, dmag;                          /* [col * rows + row] */
+  int rows = 0;
+  SpeedClip clip;
+  int C, rate;
+  double center;
+  SpeedSync (const uint8_t key[16], SpeedClip c, int C_, int rate_, double center_) :
+    table (sync_bits_table (key, false)), clip (c), C (C_), rate (rate_), center (center_)
+  {
+    for (size_t b = 0; b < table.size(); b++)
+      for (const auto& fb : table[b])
+        bits.push_back ({ int (b), &fb });
+    std::sort (bits.begin(), bits.end(), [] (const Bit& a, const Bit& b) { return a.fb->frame < b.fb->frame; });
+  }
+  void
+  prepare_mags (const SpeedScanParams& sp)                                                       /* wmspeed.cc:204-268 */
+  {
+    /* the clip at half the mark rate, stretched by 1 / center */
+    const vector<float> sub = resample_ratio_truncate (clip.s, clip.n_values, C, rate, center / 2, sp.seconds / center);
+    const size_t sub_frames = sub.size() / C;
+    const int N = P::frame_size / 2, hop = P::sync_search_step / 2;
+    static const vector<float> win = normalized_window (N);
+    rows = 0;
+    for (size_t pos = 0; pos + N < sub_frames; pos += hop)
+      rows++;
+    const int cols = int (bits.size());
+    umag.assign (size_t (rows) * cols, 0.f);
+    dmag.assign (size_t (rows) * cols, 0.f);
+    parallel_for (rows, [&] (size_t row) {
+      const size_t pos = row * hop;
+      float db[P::n_bands] = { 0 };
+      float frame[512];
+      cfloat spect[257];
+      for (int ch = 0; ch < C; ch++)
+        {
+          for (int i = 0; i < N; i++)
+            frame[i] = sub[ch + (pos + i) * C] * win[i];
+          fft512().r2c (frame, spect);
+          for (int i = P::min_band; i <= P::max_band; i++)
+            db[i - P::min_band] += db_from_complex (spect[i]);
+        }
+      for (int col = 0; col < cols; col++)
+        {
+          float u = 0, d = 0;
+          for (int i = 0; i < 30; i++)
+            {
+              u += db[bits[col].fb->up[i]];
+              d += db[bits[col].fb->down[i]];
+            }
+          umag[size_t (col) * rows + row] = u;
+          dmag[size_t (col) * rows + row] = d;
+        }
+    });
+  }
+  /* compare + compare_bits<0..2> (wmspeed.cc:270-395).  Q16 time steps; states are the candidate block starts
+   * -pad_start .. -1 (in steps of sync_search_step at the centre speed) */
+  SpeedScore
+  compare (double relative_speed) const
+  {
+    constexpr int SHIFT = 16;
+    const int steps_per_frame = P::frame_size / P::sync_search_step;
+    const int frames_per_block = int (block_frame_count());
+    const int pad_start = frames_per_block * steps_per_frame + steps_per_frame;
+    const double relative_speed_inv = 1 / relative_speed;
+    struct BitValue { float umag = 0, dmag = 0; int count = 0; };
+    struct State { int offset; BitValue bv[P::sync_bits]; };
+    vector<State> st;
+    for (int offset = -pad_start; offset < 0; offset++)
+      {
+        State cs {};
+        cs.offset = offset * ((1 << SHIFT) / relative_speed);
+        st.push_back (cs);
+      }
+    for (int block = 0; block < 3; block++)
+      {
+        size_t begin = st.size(), end = st.size();
+        for (size_t mi = 0; mi < bits.size(); mi++)
+          {
+            /* the reference keeps this in an int; for the last frames of block 2 at speeds < 0.82 the value passes
+             * INT_MAX (undefined there; with gcc on x86-64 the conversion yields INT_MIN and the wrapped sums select no
+             * state).  Those frames lie more than two block lengths after every state, beyond any matrix the 25 s / 50 s
+             * scans build, so "no state" is also what the exact arithmetic gives: done in 64 bits here. */
+            const int64_t frame_offset = int64_t (((block * frames_per_block + bits[mi].fb->frame) * steps_per_frame * relative_speed_inv + 0.5) * (1 << SHIFT));
+            while (begin > 0 && int64_t (st[begin - 1].offset) + frame_offset >= 0)
+              begin--;
+            while (end > 0 && ((int64_t (st[end - 1].offset) + frame_offset) >> SHIFT) >= rows)
+              end--;
+            for (size_t i = begin; i < end; i++)
+              {
+                const int64_t index = (int64_t (st[i].offset) + frame_offset) >> SHIFT;
+                BitValue& bv = st[i].bv[bits[mi].bit];
+                const float u = umag[mi * rows + index], d = dmag[mi * rows + index];
+                if (block & 1)
+                  {
+                    bv.umag += d;
+                    bv.dmag += u;
+                  }
+                else
+                  {
+                    bv.umag += u;
+                    bv.dmag += d;
+                  }
+                bv.count++;
+              }
+          }
+      }
+    SpeedScore best;
+    for (const auto& cs : st)
+      {
+        double q = 0;
+        int count = 0;
+        for (int bit = 0; bit < P::sync_bits; bit++)
+          {
+            q += bit_quality (cs.bv[bit].umag, cs.bv[bit].dmag, bit) * cs.bv[bit].count;
+            count += cs.bv[bit].count;
+          }
+        if (count)
+          {
+            q /= count;
+            q = fabs (q / std::min (P::water_delta, 0.080) / 2.9);          /* normalize_sync_quality */
+            if (q > best.quality)
+              {
+                best.quality = q;
+                best.speed = relative_speed * center;
+              }
+          }
+      }
+    return best;
   }
 };
+
+/* SpeedSearch::get_jobs + run_search for one key (wmspeed.cc:461-492, 683-719) */
+vector<SpeedScore>
+speed_scan (const uint8_t key[16], const float *s, size_t n_values, int C, int rate, double clip_location,
+            const SpeedScanParams& sp, const vector<double>& speeds)
+{
+  const SpeedClip clip = get_speed_clip (clip_location, s, n_values, C, rate, sp.seconds * 1.3);
+  vector<SpeedScore> scores;
+  for (double speed : speeds)
+    for (int c = -sp.n_center_steps; c <= sp.n_center_steps; c++)
+      {
+        const double c_speed = speed * pow (sp.step, c * (sp.n_steps * 2 + 1));
+        SpeedSync sync (key, clip, C, rate, c_speed);
+        sync.prepare_mags (sp);
+        vector<SpeedScore> part (2 * sp.n_steps + 1);
+        parallel_for (part.size(), [&] (size_t i) {
+          const int p = int (i) - sp.n_steps;
+          part[i] = sync.compare (pow (sp.step, p) * c_speed / c_speed);
+        });
+        scores.insert (scores.end(), part.begin(), part.end());
+      }
+  return scores;
+}
+
+void
+select_n_best_scores (vector<SpeedScore>& scores, size_t n)                                       /* wmspeed.cc:494-531 */
+{
+  std::sort (scores.begin(), scores.end(), [] (const SpeedScore& a, const SpeedScore& b) { return a.speed < b.speed; });
+  auto quality = [&] (int pos) { return pos >= 0 && size_t (pos) < scores.size() ? scores[pos].quality : 0.0; };
+  vector<SpeedScore> lmax;
+  for (int x = 0; size_t (x) < scores.size(); x++)
+    if (quality (x - 1) <= quality (x) && quality (x) >= quality (x + 1))
+      {
+        lmax.push_back (scores[x]);
+        x++;
+      }
+  std::sort (lmax.begin(), lmax.end(), [] (const SpeedScore& a, const SpeedScore& b) { return a.quality > b.quality; });
+  if (lmax.size() > n)
+    lmax.resize (n);
+  scores = lmax;
+}
+
+double
+score_smooth_find_best (vector<SpeedScore> scores, double step, double distance)                 /* wmspeed.cc:397-428 */
+{
+  std::sort (scores.begin(), scores.end(), [] (const SpeedScore& a, const SpeedScore& b) { return a.speed < b.speed; });
+  auto window_cos = [] (double x) { return fabs (x) > 1 ? 0.0 : 0.5 * cos (x * M_PI) + 0.5; };   /* wmcommon.hh:187-193 */
+  double best_speed = 0, best_quality = 0;
+  for (double speed = scores.front().speed; speed < scores.back().speed; speed += 0.000001)
+    {
+      double sum = 0, div = 0;
+      for (const auto& sc : scores)
+        {
+          const double w = window_cos ((sc.speed - speed) / (step * distance));
+          sum += sc.quality * w;
+          div += w;
+        }
+      sum /= div;
+      if (sum > best_quality)
+        {
+          best_speed = speed;
+          best_quality = sum;
+        }
+    }
+  return best_speed;
+}
+
+double
+best_clip_location (const uint8_t key[16], const float *s, size_t n_values, int C, int rate, double seconds, int candidates)   /* wmspeed.cc:533-577 */
+{
+  Rng rng (key, 0, speed_clip);
+  vector<float> x;
+  for (size_t p = 0; p < n_values; p += rng() % 1000)
+    x.push_back (s[p]);
+  uint8_t hash[20];
+  awm_sha1 (x.data(), x.size() * sizeof (float), hash);                  /* Random::seed_from_hash, random.cc:184-190 */
+  uint64_t seed = 0;
+  for (int i = 0; i < 8; i++)
+    seed = (seed << 8) | hash[i];
+  rng.seed (seed, speed_clip);
+  std::uniform_real_distribution<double> dist;
+  double location = 0, best_energy = 0;
+  for (int c = 0; c < candidates; c++)
+    {
+      const double loc = dist (rng);
+      const SpeedClip clip = get_speed_clip (loc, s, n_values, C, rate, seconds);
+      double energy = 0;
+      for (size_t i = 0; i < clip.n_values; i++)
+        energy += clip.s[i] * clip.s[i];
+      if (energy > best_energy)
+        {
+          best_energy = energy;
+          location = loc;
+        }
+    }
+  return location;
+}
+
+/* detect_speed for one key (wmspeed.cc:622-781); returns true if decoding at *speed should be tried */
+bool
+detect_speed (const uint8_t key[16], const float *s, size_t n_values, int C, int rate, bool patient, double *speed, double *quality)
+{
+  if (double (n_values / C) / rate < 0.25)
+    return false;
+  const SpeedScanParams scan1 = patient ? SpeedScanParams { 50, 1.00035, 11, 28 } : SpeedScanParams { 25, 1.0007, 5, 28 };
+  const SpeedScanParams scan2 = patient ? SpeedScanParams { 50, 1.000175, 1, 0 } : SpeedScanParams { 50, 1.00035, 1, 0 };
+  const SpeedScanParams scan3 { 50, 1.00005, 40, 0 };
+  const size_t n_best = patient ? 15 : 5;
+  const double loc = best_clip_location (key, s, n_values, C, rate, scan1.seconds, 5);
+  vector<SpeedScore> scores = speed_scan (key, s, n_values, C, rate, loc, scan1, { 1.0 });
+  select_n_best_scores (scores, n_best);
+  vector<double> speeds;
+  for (const auto& sc : scores)
+    speeds.push_back (sc.speed);
+  scores = speed_scan (key, s, n_values, C, rate, loc, scan2, speeds);
+  select_n_best_scores (scores, 1);
+  scores = speed_scan (key, s, n_values, C, rate, loc, scan3, { scores[0].speed });
+  const double best_speed = score_smooth_find_best (scores, 1 - scan3.step, 20);
+  double best_quality = 0;
+  for (const auto& sc : scores)
+    best_quality = std::max (best_quality, sc.quality);
+  *speed = best_speed;
+  *quality = best_quality;
+  return best_quality > 0.4 && (best_speed < 0.9999 || best_speed > 1.0001);
+}
+
+struct SpeedMode { bool detect = false, patient = false; double try_speed = -1; };
+SpeedMode speed_mode;
+
+void
+Decoder::decode (const Wav& w, bool first_chunk, vector<Pattern>& res)                           /* wmget.cc:886-939 */
+{
+  if (speed_mode.detect || speed_mode.patient || speed_mode.try_speed > 0)
+    {
+      double speed = speed_mode.try_speed, quality = 0;
+      bool have = speed_mode.try_speed > 0;
+      if (speed_mode.detect || speed_mode.patient)
+        have = detect_speed (key, w.s, w.n_values, w.C, P::mark_sample_rate, speed_mode.patient, &speed, &quality);
+      if (have)
+        {
+          const vector<float> stretched = resample_ratio_truncate (w.s, w.n_values, w.C, P::mark_sample_rate, speed, -1);
+          decode_plain ({ stretched.data(), stretched.size(), w.C, int (P::mark_sample_rate * speed) }, first_chunk, res, speed);   /* wmget.cc:916 */
+        }
+    }
+  decode_plain (w, first_chunk, res, 1);
+}
 
 bool
 approx_match (const Pattern& a, const Pattern& b)                          /* wmget.cc:178-190 */
@@ -1320,154 +1660,7 @@ extern "C" {
 
 
 /* ---- sample rates other than 44100 Hz ------------------------------------------------------------------------------
- * The reference resamples with zita-resampler (Resampler, hlen = 16; resample.cc:128-270), which is not part of
- * /root/reference and not installed here: PARITY UNPINNED for everything below.  The class restates zita-resampler
- * 1.x's published algorithm (Resampler::setup / process, Resampler_table: a polyphase windowed-sinc FIR with
- * 2 hl taps, np phases, window 0.384 + 0.5 cos + 0.116 cos 2x); the call sequences are the reference's. */
-struct ZitaTable
-{
-  unsigned hl = 0, np = 0;
-  vector<float> ctab;                 /* (np + 1) * hl */
-  ZitaTable (double fr, unsigned hl_, unsigned np_) : hl (hl_), np (np_), ctab (size_t (hl_) * (np_ + 1))
-  {
-    auto sinc = [] (double x) { x = fabs (x); if (x < 1e-6) return 1.0; x *= M_PI; return sin (x) / x; };
-    auto wind = [] (double x) { x = fabs (x); if (x >= 1.0) return 0.0; x *= M_PI; return 0.384 + 0.500 * cos (x) + 0.116 * cos (2 * x); };
-    float *p = ctab.data();
-    for (unsigned j = 0; j <= np; j++)
-      {
-        double t = double (j) / double (np);
-        for (unsigned i = 0; i < hl; i++)
-          {
-            p[hl - i - 1] = float (fr * sinc (t * fr) * wind (t / hl));
-            t += 1;
-          }
-        p += hl;
-      }
-  }
-};
-
-static unsigned zita_gcd (unsigned a, unsigned b) { while (b) { const unsigned t = a % b; a = b; b = t; } return a; }
-
-class ZitaResampler
-{
-  std::unique_ptr<ZitaTable> table;
-  unsigned nchan_ = 0, inmax = 0, index = 0, nread = 0, nzero = 0, phase = 0, pstep = 0;
-  vector<float> buff;
-public:
-  unsigned     inp_count = 0, out_count = 0;
-  const float *inp_data = nullptr;
-  float       *out_data = nullptr;
-  unsigned nchan() const { return nchan_; }
-  unsigned inpsize() const { return table ? 2 * table->hl : 0; }
-  int
-  setup (unsigned fs_inp, unsigned fs_out, unsigned nchan, unsigned hlen)
-  {
-    double frel = 1.0 - 2.6 / hlen;
-    if (!fs_inp || !fs_out || !nchan)
-      return 1;
-    const double r = double (fs_out) / double (fs_inp);
-    const unsigned g = zita_gcd (fs_out, fs_inp), n = fs_out / g, s = fs_inp / g;
-    if (!(16 * r >= 1 && n <= 1000))
-      return 1;
-    unsigned h = hlen, k = 250;
-    if (r < 1)
-      {
-        frel *= r;
-        h = unsigned (ceil (h / r));
-        k = unsigned (ceil (k / r));
-      }
-    table = std::make_unique<ZitaTable> (frel, h, n);
-    buff.assign (size_t (nchan) * (2 * h - 1 + k), 0.f);
-    nchan_ = nchan;
-    inmax = k;
-    pstep = s;
-    index = 0; nzero = 0; phase = 0;
-    nread = 2 * h;
-    return 0;
-  }
-  void
-  process()
-  {
-    if (!table)
-      return;
-    const unsigned hl = table->hl, np = table->np, dp = pstep;
-    unsigned in = index, nr = nread, ph = phase, nz = nzero;
-    unsigned n = (2 * hl - nr) * nchan_;
-    float *p1 = buff.data() + in * nchan_;
-    float *p2 = p1 + n;
-    while (out_count)
-      {
-        if (nr)
-          {
-            if (inp_count == 0)
-              break;
-            if (inp_data)
-              {
-                for (unsigned c = 0; c < nchan_; c++)
-                  p2[c] = inp_data[c];
-                inp_data += nchan_;
-                nz = 0;
-              }
-            else
-              {
-                for (unsigned c = 0; c < nchan_; c++)
-                  p2[c] = 0;
-                if (nz < 2 * hl)
-                  nz++;
-              }
-            nr--;
-            p2 += nchan_;
-            inp_count--;
-          }
-        else
-          {
-            if (out_data)
-              {
-                if (nz < 2 * hl)
-                  {
-                    const float *c1 = table->ctab.data() + hl * ph;
-                    const float *c2 = table->ctab.data() + hl * (np - ph);
-                    for (unsigned c = 0; c < nchan_; c++)
-                      {
-                        const float *q1 = p1 + c;
-                        const float *q2 = p2 + c;
-                        float sum = 1e-20f;
-                        for (unsigned i = 0; i < hl; i++)
-                          {
-                            q2 -= nchan_;
-                            sum += *q1 * c1[i] + *q2 * c2[i];
-                            q1 += nchan_;
-                          }
-                        *out_data++ = sum - 1e-20f;
-                      }
-                  }
-                else
-                  for (unsigned c = 0; c < nchan_; c++)
-                    *out_data++ = 0;
-              }
-            out_count--;
-            ph += dp;
-            if (ph >= np)
-              {
-                nr = ph / np;
-                ph -= nr * np;
-                in += nr;
-                p1 += nr * nchan_;
-                if (in >= inmax)
-                  {
-                    n = (2 * hl - nr) * nchan_;
-                    memmove (buff.data(), p1, n * sizeof (float));
-                    in = 0;
-                    p1 = buff.data();
-                    p2 = p1 + n;
-                  }
-              }
-          }
-      }
-    index = in; nread = nr; phase = ph; nzero = nz;
-  }
-};
-
+ * zita-resampler restated: see zita_restated.h (PARITY UNPINNED: the library is absent here). */
 /* BufferedResamplerImpl (resample.cc:128-231) fed with the whole stream: hl - 1 null frames first ("avoid timeshift"),
  * the input, and -- if `trailing` (WavChunkLoader at EOF, wavchunkloader.cc:212-216) -- hl null frames. */
 static vector<float>
@@ -1756,6 +1949,93 @@ orc_resample (const float *samples, size_t n_frames, int n_channels, int rate_in
   const size_t frames = r.size() / n_channels;
   std::copy (r.begin(), r.begin() + std::min (frames, max_out_frames) * n_channels, out);
   return frames;
+}
+
+/* ---- speed detection (wmspeed.cc) and VResampler paths; zita-resampler restated: PARITY UNPINNED ------------------ */
+void
+orc_set_speed_params (int detect_speed, int patient, double try_speed)
+{
+  speed_mode.detect = detect_speed != 0;
+  speed_mode.patient = patient != 0;
+  speed_mode.try_speed = try_speed;
+}
+size_t
+orc_resample_ratio (const float *samples, size_t n_frames, int n_channels, int rate, double ratio, double max_in_seconds,
+                    size_t max_out_frames, float *out)
+{
+  const auto r = resample_ratio_truncate (samples, n_frames * n_channels, n_channels, rate, ratio, max_in_seconds);
+  const size_t frames = r.size() / n_channels;
+  std::copy (r.begin(), r.begin() + std::min (frames, max_out_frames) * n_channels, out);
+  return frames;
+}
+double
+orc_speed_clip_location (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate, double seconds, int candidates)
+{
+  return best_clip_location (key, samples, n_values, n_channels, rate, seconds, candidates);
+}
+int
+orc_speed_mags (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate, double clip_location,
+                double center, double seconds, size_t max_rows, float *out)
+{
+  SpeedSync sync (key, get_speed_clip (clip_location, samples, n_values, n_channels, rate, seconds * 1.3), n_channels, rate, center);
+  sync.prepare_mags ({ seconds, 0, 0, 0 });
+  const size_t cols = sync.bits.size();
+  for (size_t r = 0; r < size_t (sync.rows) && r < max_rows; r++)
+    for (size_t c = 0; c < cols; c++)
+      {
+        out[(r * cols + c) * 2] = sync.umag[c * sync.rows + r];
+        out[(r * cols + c) * 2 + 1] = sync.dmag[c * sync.rows + r];
+      }
+  return sync.rows;
+}
+int
+orc_speed_scan (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate, double clip_location,
+                double seconds, double step, int n_steps, int n_center_steps, const double *speeds, int n_speeds,
+                size_t max_out, double *out_speed, double *out_quality)
+{
+  auto scores = speed_scan (key, samples, n_values, n_channels, rate, clip_location, { seconds, step, n_steps, n_center_steps },
+                            vector<double> (speeds, speeds + n_speeds));
+  std::sort (scores.begin(), scores.end(), [] (const SpeedScore& a, const SpeedScore& b) { return a.speed < b.speed; });
+  for (size_t i = 0; i < scores.size() && i < max_out; i++)
+    {
+      out_speed[i] = scores[i].speed;
+      out_quality[i] = scores[i].quality;
+    }
+  return int (scores.size());
+}
+int
+orc_speed_select_n_best (double *speed, double *quality, int count, int n)
+{
+  vector<SpeedScore> scores (count);
+  for (int i = 0; i < count; i++)
+    scores[i] = { speed[i], quality[i] };
+  select_n_best_scores (scores, n);
+  for (size_t i = 0; i < scores.size(); i++)
+    {
+      speed[i] = scores[i].speed;
+      quality[i] = scores[i].quality;
+    }
+  return int (scores.size());
+}
+double
+orc_speed_smooth_best (const double *speed, const double *quality, int count, double step, double distance)
+{
+  vector<SpeedScore> scores (count);
+  for (int i = 0; i < count; i++)
+    scores[i] = { speed[i], quality[i] };
+  return score_smooth_find_best (scores, step, distance);
+}
+int
+orc_detect_speed (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate, int patient,
+                  double *speed_out, double *quality_out)
+{
+  double speed = 0, quality = 0;
+  const bool use = detect_speed (key, samples, n_values, n_channels, rate, patient != 0, &speed, &quality);
+  if (speed_out)
+    *speed_out = speed;
+  if (quality_out)
+    *quality_out = quality;
+  return use;
 }
 
 } /* extern "C" */

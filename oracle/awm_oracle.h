@@ -75,6 +75,24 @@ int    orc_decode_chunk (const uint8_t key[16], const float *samples, size_t n_v
 int    orc_get (const uint8_t key[16], const float *samples, size_t n_values, int n_channels,
                 size_t max_out, orc_pattern *out);
 
+/* ---- speed detection (wmspeed.cc) and the VResampler paths (resample.cc:96-125); zita-resampler restated ---------- */
+void   orc_set_speed_params (int detect_speed, int patient, double try_speed);      /* --detect-speed, --detect-speed-patient, --try-speed */
+size_t orc_resample_ratio (const float *samples, size_t n_frames, int n_channels, int rate, double ratio, double max_in_seconds,
+                           size_t max_out_frames, float *out);                        /* resample_ratio_truncate */
+double orc_speed_clip_location (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate,
+                                double seconds, int candidates);                      /* wmspeed.cc:533-577 */
+int    orc_speed_mags (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate,
+                       double clip_location, double center, double seconds, size_t max_rows, float *out /* [row][510][2] */);
+int    orc_speed_scan (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate,
+                       double clip_location, double seconds, double step, int n_steps, int n_center_steps,
+                       const double *speeds, int n_speeds, size_t max_out, double *out_speed, double *out_quality);
+int    orc_speed_select_n_best (double *speed, double *quality, int count, int n);    /* wmspeed.cc:494-531 */
+double orc_speed_smooth_best (const double *speed, const double *quality, int count, double step, double distance);
+/* detect_speed for one key (wmspeed.cc:622-781): returns 1 if the speed passes the thresholds (quality > 0.4, more than
+ * 1e-4 away from 1); speed / quality are filled in either way */
+int    orc_detect_speed (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate, int patient,
+                         double *speed_out, double *quality_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,27 @@ int    ref_decode_chunk (const uint8_t key[16], const float *samples, size_t n_v
 int    ref_get (const uint8_t key[16], const float *samples, size_t n_values, int n_channels,
                 size_t max_out, ref_pattern *out);
 
+/* ---- speed detection (wmspeed.cc) and VResampler paths (resample.cc:96-125); zita-resampler restated ---------- */
+void   ref_set_speed_params (int detect_speed, int patient, double try_speed);
+/* resample_ratio_truncate (resample.cc:96-119); returns the output length in frames */
+size_t ref_resample_ratio (const float *samples, size_t n_frames, int n_channels, int rate, double ratio, int new_rate,
+                           double max_in_seconds, size_t max_out_frames, float *out);
+/* get_best_clip_location (wmspeed.cc:555-577) */
+double ref_speed_clip_location (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate,
+                                double seconds, int candidates);
+/* SpeedSync::prepare_mags (wmspeed.cc:204-268) for one centre speed; out[row][510][2] = umag, dmag; returns rows */
+int    ref_speed_mags (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate,
+                       double clip_location, double center, double seconds, size_t max_rows, float *out);
+/* one run_search pass (wmspeed.cc:683-719): scores of all centre / relative speeds sorted by speed; returns count */
+int    ref_speed_scan (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate,
+                       double clip_location, double seconds, double step, int n_steps, int n_center_steps,
+                       const double *speeds, int n_speeds, size_t max_out, double *out_speed, double *out_quality);
+int    ref_speed_select_n_best (double *speed, double *quality, int count, int n);               /* wmspeed.cc:494-531 */
+double ref_speed_smooth_best (const double *speed, const double *quality, int count, double step, double distance); /* :397-428 */
+/* detect_speed (wmspeed.cc:622-781) for one key; returns the number of results (0 or 1) */
+int    ref_detect_speed (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate, int patient,
+                         double *speed_out);
+
 #ifdef __cplusplus
 }
 #endif

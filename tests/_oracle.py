@@ -248,3 +248,84 @@ def decode_chunk(key, samples, n_channels, first_chunk=True):
 def get(key, samples, n_channels):
     samples = np.ascontiguousarray(samples, np.float32).ravel()
     return _patterns(lib().orc_get, _key(key), _p(samples), C.c_size_t(samples.size), n_channels)
+
+
+# ---- speed detection (wmspeed.cc) / VResampler paths; restated; zita-resampler parity unpinned ---------------------
+def set_speed_params(detect_speed=False, patient=False, try_speed=-1.0):
+    lib().orc_set_speed_params.argtypes = [C.c_int, C.c_int, C.c_double]
+    lib().orc_set_speed_params(int(detect_speed), int(patient), float(try_speed))
+
+
+def resample_ratio(samples, n_channels, ratio, rate=44100, max_in_seconds=-1.0):
+    s = np.ascontiguousarray(samples, dtype=np.float32)
+    n = s.size // n_channels
+    cap = int(n * ratio) + 16
+    out = np.zeros(cap * n_channels, dtype=np.float32)
+    f = lib().orc_resample_ratio
+    f.restype = C.c_size_t
+    f.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_size_t, C.c_void_p]
+    got = f(_p(s), n, n_channels, rate, ratio, max_in_seconds, cap, _p(out))
+    assert got <= cap
+    return out[:got * n_channels]
+
+
+def speed_clip_location(key, samples, n_channels, seconds, candidates=5, rate=44100):
+    s = np.ascontiguousarray(samples, dtype=np.float32)
+    f = lib().orc_speed_clip_location
+    f.restype = C.c_double
+    f.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int]
+    return f(_key(key), _p(s), s.size, n_channels, rate, seconds, candidates)
+
+
+def speed_mags(key, samples, n_channels, clip_location, center, seconds, rate=44100):
+    s = np.ascontiguousarray(samples, dtype=np.float32)
+    max_rows = int(seconds * 22050 / 128) + 8
+    out = np.zeros((max_rows, 510, 2), dtype=np.float32)
+    f = lib().orc_speed_mags
+    f.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_size_t, C.c_void_p]
+    rows = f(_key(key), _p(s), s.size, n_channels, rate, clip_location, center, seconds, max_rows, _p(out))
+    assert rows <= max_rows
+    return out[:rows]
+
+
+def speed_scan(key, samples, n_channels, clip_location, seconds, step, n_steps, n_center_steps, speeds, rate=44100):
+    s = np.ascontiguousarray(samples, dtype=np.float32)
+    sp = np.ascontiguousarray(speeds, dtype=np.float64)
+    cap = len(sp) * (2 * n_center_steps + 1) * (2 * n_steps + 1)
+    o_s = np.zeros(cap)
+    o_q = np.zeros(cap)
+    f = lib().orc_speed_scan
+    f.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                  C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    n = f(_key(key), _p(s), s.size, n_channels, rate, clip_location, seconds, step, n_steps, n_center_steps,
+          _p(sp), len(sp), cap, _p(o_s), _p(o_q))
+    assert n == cap
+    return o_s, o_q
+
+
+def speed_select_n_best(speed, quality, n):
+    sp = np.array(speed, dtype=np.float64)
+    q = np.array(quality, dtype=np.float64)
+    f = lib().orc_speed_select_n_best
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    k = f(_p(sp), _p(q), len(sp), n)
+    return sp[:k], q[:k]
+
+
+def speed_smooth_best(speed, quality, step, distance):
+    sp = np.ascontiguousarray(speed, dtype=np.float64)
+    q = np.ascontiguousarray(quality, dtype=np.float64)
+    f = lib().orc_speed_smooth_best
+    f.restype = C.c_double
+    f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
+    return f(_p(sp), _p(q), len(sp), step, distance)
+
+
+def detect_speed(key, samples, n_channels, patient=False, rate=44100):
+    s = np.ascontiguousarray(samples, dtype=np.float32)
+    out = C.c_double(0)
+    q = C.c_double(0)
+    f = lib().orc_detect_speed
+    f.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    n = f(_key(key), _p(s), s.size, n_channels, rate, int(patient), C.byref(out), C.byref(q))
+    return (out.value if n else None), out.value, q.value
