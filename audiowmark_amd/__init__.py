@@ -11,11 +11,11 @@ library is missing.
 """
 from .binding import (AwmError, Context, Pattern, lib, library_path, tab_up_down, tab_bit_pos, tab_mix_entries,
                       tab_bit_order, tab_frame_mod, tab_sync_bits, tab_window, tab_synth_window, conv_encode,
-                      set_params, key_bytes, test_key, plan_chunks, merge_patterns, merge_patterns_raw, patterns_to_dicts,
+                      set_params, set_speed_params, key_bytes, test_key, plan_chunks, merge_patterns, merge_patterns_raw, patterns_to_dicts,
                       PATTERN_DTYPE)
 from . import binding
 
 __all__ = ["AwmError", "Context", "Pattern", "lib", "library_path", "tab_up_down", "tab_bit_pos", "tab_mix_entries",
            "tab_bit_order", "tab_frame_mod", "tab_sync_bits", "tab_window", "tab_synth_window", "conv_encode",
-           "set_params", "key_bytes", "test_key", "plan_chunks", "merge_patterns", "merge_patterns_raw", "patterns_to_dicts",
+           "set_params", "set_speed_params", "key_bytes", "test_key", "plan_chunks", "merge_patterns", "merge_patterns_raw", "patterns_to_dicts",
            "PATTERN_DTYPE", "binding"]

@@ -140,6 +140,16 @@ lib.awm_pcm_encode_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int
 lib.awm_plan_chunks.argtypes = [C.c_size_t, C.c_size_t, _vp, _vp, _vp]
 lib.awm_merge_patterns.argtypes = [_vp, _vp, _vp, C.c_int, C.c_size_t, _vp]
 lib.awm_prof_name.restype = C.c_char_p
+lib.awm_set_speed_params.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double]
+lib.awm_set_speed_params.restype = None
+lib.awm_resample_ratio_frames.argtypes = [C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double]
+lib.awm_resample_ratio_frames.restype = C.c_size_t
+lib.awm_resample_ratio_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, _vp, C.c_size_t]
+lib.awm_detect_speed_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, _vp]
+lib.awm_speed_clip_location_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_int, _vp]
+lib.awm_speed_mags_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_size_t, _vp]
+lib.awm_speed_scan_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
+                                 _vp, C.c_int, C.c_size_t, _vp, _vp]
 
 
 def _check(rc, what):
@@ -173,6 +183,11 @@ def set_params(water_delta=0.01, mix=True, frames_per_bit=2, test_no_limiter=Fal
                chunk_size_min=30.0):
     lib.awm_set_params(water_delta, int(mix), frames_per_bit, int(test_no_limiter), sync_threshold2, n_best,
                        chunk_size_min)
+
+
+def set_speed_params(detect_speed=False, patient=False, try_speed=-1.0, test_speed=-1.0):
+    """--detect-speed / --detect-speed-patient / --try-speed / --test-speed of `get` (reference wmcommon.hh:49-52)."""
+    lib.awm_set_speed_params(int(detect_speed), int(patient), float(try_speed), float(test_speed))
 
 
 def plan_chunks(n_frames):
@@ -381,6 +396,52 @@ class Context:
         out = torch.empty((m, ch), dtype=torch.float32, device=pcm.device)
         _check(lib.awm_resample_d(self._h, _dev_ptr(pcm), n, ch, rate_in, rate_out, _dev_ptr(out), m), "awm_resample_d")
         return out
+
+    def resample_ratio(self, pcm, ratio, rate=44100, max_in_seconds=-1.0):
+        """resample_ratio_truncate (reference resample.cc:96-119): zita's VResampler, restated."""
+        import torch
+        n, ch = _pcm_shape(pcm)
+        m = lib.awm_resample_ratio_frames(n, ch, rate, ratio, max_in_seconds)
+        out = torch.empty((m, ch), dtype=torch.float32, device=pcm.device)
+        _check(lib.awm_resample_ratio_d(self._h, _dev_ptr(pcm), n, ch, rate, ratio, max_in_seconds, _dev_ptr(out), m),
+               "awm_resample_ratio_d")
+        return out
+
+    def detect_speed(self, key, pcm, patient=False, rate=44100):
+        """detect_speed for one key (reference wmspeed.cc:622-781): (speed to try or None, best speed, best quality)."""
+        n, ch = _pcm_shape(pcm)
+        speed, quality = C.c_double(0), C.c_double(0)
+        rc = lib.awm_detect_speed_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, rate, int(patient), C.byref(speed), C.byref(quality))
+        if rc < 0:
+            _check(rc, "awm_detect_speed_d")
+        return (speed.value if rc else None), speed.value, quality.value
+
+    def speed_clip_location(self, key, pcm, seconds, candidates=5, rate=44100):
+        n, ch = _pcm_shape(pcm)
+        loc = C.c_double(0)
+        _check(lib.awm_speed_clip_location_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, rate, seconds, candidates, C.byref(loc)),
+               "awm_speed_clip_location_d")
+        return loc.value
+
+    def speed_mags(self, key, pcm, clip_location, center, seconds, rate=44100):
+        n, ch = _pcm_shape(pcm)
+        max_rows = int(seconds * 22050 / 128) + 8
+        out = np.zeros((max_rows, 510, 2), np.float32)
+        rows = lib.awm_speed_mags_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, rate, clip_location, center, seconds, max_rows, _np(out))
+        if rows < 0:
+            _check(rows, "awm_speed_mags_d")
+        return out[:rows]
+
+    def speed_scan(self, key, pcm, clip_location, seconds, step, n_steps, n_center_steps, speeds, rate=44100):
+        n, ch = _pcm_shape(pcm)
+        sp = np.ascontiguousarray(speeds, np.float64)
+        cap = len(sp) * (2 * n_center_steps + 1) * (2 * n_steps + 1)
+        o_s, o_q = np.zeros(cap), np.zeros(cap)
+        cnt = lib.awm_speed_scan_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, rate, clip_location, seconds, step, n_steps,
+                                   n_center_steps, _np(sp), len(sp), cap, _np(o_s), _np(o_q))
+        if cnt < 0:
+            _check(cnt, "awm_speed_scan_d")
+        return o_s[:cnt], o_q[:cnt]
 
     def add_d(self, pcm, frame_mod, water_delta=0.01, use_limiter=True, out=None):
         import torch

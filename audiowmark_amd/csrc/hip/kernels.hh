@@ -231,3 +231,64 @@ hipError_t launch_pcm_encode (hipStream_t st, const float *in, unsigned char *by
  * reference syncfinder.cc:155-169); result[0] = first (n_values if all zero), result[1] = last */
 hipError_t launch_nonzero_range (hipStream_t st, const float *data, long long n_values, unsigned long long *result);
 }
+
+namespace awmk {
+/* ---- speed detection (reference wmspeed.cc; speed.hip) -------------------------------------------------------------- */
+/* one centre speed of a scan pass, or the one ratio of a plain resample_ratio call: zita VResampler geometry */
+struct SpeedCenterDev
+{
+  const float       *ctab;         // (256 + 1) * hl coefficients
+  int                hl;           // taps per side
+  int                shift;        // input window of output m starts at (m * mant) >> shift
+  unsigned long long mant;         // 53 bit mantissa of the phase step 256 / ratio
+  double             frac_scale;   // fraction of that product -> phase 0 .. 256
+  long long          n_in;         // input frames (after truncation)
+  long long          n_out;        // output frames
+  int                rows;         // K12 / K13: STFT rows of the half-rate clip
+};
+/* K11: VResampler (resample.cc:96-125); blockIdx.y = centre, outputs at out + centre * out_stride */
+struct VarResampleArgs
+{
+  const float          *in;
+  int                   n_channels;
+  const SpeedCenterDev *centers;
+  float                *out;
+  long long             out_stride;    // floats
+};
+hipError_t launch_resample_var (hipStream_t st, const VarResampleArgs& a, long long max_n_out, int n_centers);
+
+/* K12: SpeedSync::prepare_mags (wmspeed.cc:204-268) */
+struct SpeedMagsArgs
+{
+  const float          *sub;           // half-rate clips, [centre][sub_stride]
+  long long             sub_stride;
+  int                   n_channels;
+  const SpeedCenterDev *centers;
+  const float          *window512;     // FFTAnalyzer::gen_normalized_window (512)
+  const unsigned int   *cols;          // [510][16] words: 30 up + 30 down band indices (0..80) per sync frame, columns [bit][frame asc]
+  float2               *mags;          // [centre][510][ld] (umag, dmag)
+  long long             mags_center_stride, ld;
+};
+hipError_t launch_speed_mags (hipStream_t st, const DevTables& t, const SpeedMagsArgs& a, int max_rows, int n_centers);
+
+/* K13: SpeedSync::compare (wmspeed.cc:270-395) */
+struct SpeedItemDev { int center; double rel_speed_inv, q16_scale; };
+struct SpeedCompareArgs
+{
+  const float2         *mags;
+  long long             mags_center_stride, ld;
+  const SpeedCenterDev *centers;
+  const SpeedItemDev   *items;
+  const int            *col_frame;     // [510] frame of the column
+  int                   frames_per_block, steps_per_frame, pad_start, rows_per_bit;
+  double                min_delta;
+  unsigned long long   *best;          // [items] bits of the best quality (zero initialised)
+};
+hipError_t launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items);
+
+/* K14 */
+constexpr int ENERGY_PARTS = 256;
+hipError_t launch_gather_values (hipStream_t st, const float *in, const unsigned long long *pos, long long n, float *out);
+hipError_t launch_energy (hipStream_t st, const float *in, const long long *range /* [n][2] value index begin, end */, int n_ranges,
+                          double *out /* [n][ENERGY_PARTS] */);
+}

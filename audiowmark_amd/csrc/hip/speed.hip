@@ -1,0 +1,367 @@
+// speed.hip -- speed detection kernels for gfx950 (reference src/wmspeed.cc, src/resample.cc:96-125)
+//
+//   K11 resample_var_kernel    zita VResampler (arbitrary ratio, 256 phases, interpolated coefficients)
+//   K12 speed_mags_kernel      SpeedSync::prepare_mags: FFT-512 hop 128 on the half-rate clip -> dB -> up / down sums per sync frame
+//   K13 speed_compare_kernel   SpeedSync::compare / compare_bits: Q16 walk of every candidate block start over the magnitude matrix
+//   K14 gather / energy        get_clip_locations sample subset, get_best_clip_location energies
+//
+// Layouts are chosen for the heavy kernel (K13): the magnitude matrix of a centre speed is [column][row] float2
+// (umag, dmag) with the rows (time steps) contiguous, and the columns in the order [sync bit][frame of that bit, ascending],
+// so that a thread (= one candidate block start) sums the frames of one sync bit in the reference's order with plain
+// registers while its neighbours read neighbouring rows (coalesced).
+#include "kernels.hh"
+#include "awm_fft.hip.h"
+
+namespace awmk {
+
+constexpr int SPEED_NB = 81, SPEED_MIN_BAND = 20;
+constexpr int SPEED_COLS = 510;       // sync frames per block
+constexpr int SPEED_TILE = 16;        // rows per workgroup of K12
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K11: output m of the resampler reads the input window that starts at floor (m * step / 256) -- zita accumulates the
+ * phase in double (ph += step with wrap), here it comes from the exact product m * step (128 bit), which differs from
+ * the accumulated value only by the rounding errors zita collects on the way (< 1e-9 phases per million outputs).
+ * The arithmetic per output is zita's: c1[i] = a q1[i] + b q1[i + hl], c2[i] = a q2[i] + b q2[i - hl],
+ * y = (1e-25 + sum_i (x1 c1[i] + x2 c2[i])) - 1e-25 with every product and sum rounded on its own.
+ * ------------------------------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__ (256)
+resample_var_kernel (VarResampleArgs a)
+{
+  const SpeedCenterDev cd = a.centers[blockIdx.y];
+  const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (m >= cd.n_out)
+    return;
+  const int C = a.n_channels, hl = cd.hl, np = 256;
+  const unsigned long long lo = (unsigned long long) m * cd.mant, hi = __umul64hi ((unsigned long long) m, cd.mant);
+  long long b = (long long) ((hi << (64 - cd.shift)) | (lo >> cd.shift));
+  const unsigned long long frac = lo & ((1ull << cd.shift) - 1);
+  double ph = double (frac) * cd.frac_scale;
+  if (ph >= np)                                                // only if the fraction rounds up to a whole step (ratios > 2)
+    {
+      ph = 0;
+      b++;
+    }
+  const unsigned k = unsigned (ph);
+  const float bf = float (ph - k);
+  const float af = __fsub_rn (1.0f, bf);
+  const float *q1 = cd.ctab + (long long) hl * k;
+  const float *q2 = cd.ctab + (long long) hl * (np - k);
+  const long long first = b - (hl - 1);                       // input frame of the first tap
+  const float *in = a.in;
+  float *out = a.out + blockIdx.y * a.out_stride + m * C;
+  for (int c0 = 0; c0 < C; c0 += 2)
+    {
+      const bool two = c0 + 1 < C;
+      float s0 = 1e-25f, s1 = 1e-25f;
+      for (int i = 0; i < hl; i++)
+        {
+          const float c1 = __fadd_rn (__fmul_rn (af, q1[i]), __fmul_rn (bf, q1[i + hl]));
+          const float c2 = __fadd_rn (__fmul_rn (af, q2[i]), __fmul_rn (bf, q2[i - hl]));
+          const long long j1 = first + i, j2 = first + 2 * hl - 1 - i;
+          const bool ok1 = j1 >= 0 && j1 < cd.n_in, ok2 = j2 >= 0 && j2 < cd.n_in;
+          const float x1 = ok1 ? in[j1 * C + c0] : 0.f;
+          const float x2 = ok2 ? in[j2 * C + c0] : 0.f;
+          s0 = __fadd_rn (s0, __fadd_rn (__fmul_rn (x1, c1), __fmul_rn (x2, c2)));
+          if (two)
+            {
+              const float y1 = ok1 ? in[j1 * C + c0 + 1] : 0.f;
+              const float y2 = ok2 ? in[j2 * C + c0 + 1] : 0.f;
+              s1 = __fadd_rn (s1, __fadd_rn (__fmul_rn (y1, c1), __fmul_rn (y2, c2)));
+            }
+        }
+      out[c0] = __fsub_rn (s0, 1e-25f);
+      if (two)
+        out[c0 + 1] = __fsub_rn (s1, 1e-25f);
+    }
+}
+
+hipError_t
+launch_resample_var (hipStream_t st, const VarResampleArgs& a, long long max_n_out, int n_centers)
+{
+  if (max_n_out <= 0 || n_centers <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (resample_var_kernel, dim3 (unsigned ((max_n_out + 255) / 256), unsigned (n_centers)), dim3 (256), 0, st, a);
+  return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K12: one workgroup = 16 consecutive rows (hop 128 at half rate) of one centre speed.
+ *   phase 1: a wave transforms a row: the 512 windowed samples of TWO channels ride in the real and imaginary part of one
+ *            complex FFT-512 (X_a[k] = (Z[k] + conj Z[512-k]) / 2, X_b[k] = (Z[k] - conj Z[512-k]) / 2i), dB of the 81 bands
+ *            summed over the channels in channel order (wmspeed.cc:232-246).  A channel whose frame is digital silence is
+ *            not read out of the shared transform (the other channel's rounding noise would stand where the reference has
+ *            exact zeros = -96 dB): it contributes -96 dB per band directly.
+ *   phase 2: umag / dmag of the 510 sync frames (wmspeed.cc:247-257): thread = (column, row) with the row fastest, so
+ *            that the 16 rows of a column leave as one 128 byte store.
+ * ------------------------------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__ (256)
+speed_mags_kernel (DevTables t, SpeedMagsArgs a)
+{
+  __shared__ float2 s_tw[512];
+  __shared__ float  s_win[512];
+  __shared__ float2 s_x[4][XBUF_ELEMS];
+  __shared__ float  s_db[SPEED_TILE][SPEED_NB];
+  __shared__ unsigned int s_cols[SPEED_COLS * 16];           // 64 bytes per column: 30 up, 30 down band indices, 4 unused
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const SpeedCenterDev cd = a.centers[blockIdx.y];
+  const int row0 = blockIdx.x * SPEED_TILE;
+  if (row0 >= cd.rows)
+    return;
+  for (int i = threadIdx.x; i < 512; i += blockDim.x)
+    {
+      s_tw[i] = t.tw512[i];
+      s_win[i] = a.window512[i];
+    }
+  for (int i = threadIdx.x; i < SPEED_COLS * 16; i += blockDim.x)
+    s_cols[i] = a.cols[i];
+  __syncthreads();
+
+  const int C = a.n_channels;
+  const float *sub = a.sub + blockIdx.y * a.sub_stride;
+  float2 *xbuf = s_x[wave];
+  for (int r = wave; r < SPEED_TILE; r += 4)
+    {
+      const int row = row0 + r;
+      if (row >= cd.rows)
+        break;
+      const long long pos = (long long) row * 128;
+      float acc0 = 0.f, acc1 = 0.f;                            // bands 20 + lane, 84 + lane
+      for (int c0 = 0; c0 < C; c0 += 2)
+        {
+          const bool two = c0 + 1 < C;
+          float2 z[8];
+          bool nz0 = false, nz1 = false;
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            {
+              const int n = lane + 64 * j;
+              const float x0 = sub[(pos + n) * C + c0];
+              const float x1 = two ? sub[(pos + n) * C + c0 + 1] : 0.f;
+              nz0 |= x0 != 0.f;
+              nz1 |= x1 != 0.f;
+              z[j] = make_float2 (__fmul_rn (x0, s_win[n]), __fmul_rn (x1, s_win[n]));
+            }
+          const bool live0 = __any (nz0), live1 = __any (nz1);
+          fft512_forward (z, xbuf, s_tw, lane);
+          xbuf[0 * 64 + lane] = z[0];
+          xbuf[1 * 64 + lane] = z[1];
+          xbuf[6 * 64 + lane] = z[6];
+          xbuf[7 * 64 + lane] = z[7];
+          wave_sync();
+#pragma unroll
+          for (int part = 0; part < 2; part++)
+            {
+              const int k = SPEED_MIN_BAND + 64 * part + lane;
+              if (k <= 100)
+                {
+                  const float2 zk = xbuf[zpos (k)], zm = xbuf[zpos (512 - k)];
+                  const float2 xa = make_float2 (0.5f * (zk.x + zm.x), 0.5f * (zk.y - zm.y));
+                  const float2 xb = make_float2 (0.5f * (zk.y + zm.y), -0.5f * (zk.x - zm.x));
+                  float v = part ? acc1 : acc0;
+                  v = __fadd_rn (v, live0 ? db_from_complex (xa) : -96.f);
+                  if (two)
+                    v = __fadd_rn (v, live1 ? db_from_complex (xb) : -96.f);
+                  if (part)
+                    acc1 = v;
+                  else
+                    acc0 = v;
+                }
+            }
+          wave_sync();
+        }
+      s_db[r][lane] = acc0;
+      if (lane < SPEED_NB - 64)
+        s_db[r][64 + lane] = acc1;
+    }
+  __syncthreads();
+
+  float2 *mags = a.mags + blockIdx.y * a.mags_center_stride;
+  for (int item = threadIdx.x; item < SPEED_COLS * SPEED_TILE; item += blockDim.x)
+    {
+      const int r = item & (SPEED_TILE - 1), col = item >> 4;
+      if (row0 + r >= cd.rows)
+        continue;
+      const unsigned int *cw = s_cols + col * 16;
+      const float *db = s_db[r];
+      float u = 0.f, d = 0.f;
+#pragma unroll
+      for (int i = 0; i < 30; i++)
+        u = __fadd_rn (u, db[(cw[i >> 2] >> (8 * (i & 3))) & 0xff]);
+#pragma unroll
+      for (int i = 30; i < 60; i++)
+        d = __fadd_rn (d, db[(cw[i >> 2] >> (8 * (i & 3))) & 0xff]);
+      mags[(long long) col * a.ld + row0 + r] = make_float2 (u, d);
+    }
+}
+
+hipError_t
+launch_speed_mags (hipStream_t st, const DevTables& t, const SpeedMagsArgs& a, int max_rows, int n_centers)
+{
+  if (max_rows <= 0 || n_centers <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (speed_mags_kernel, dim3 (unsigned ((max_rows + SPEED_TILE - 1) / SPEED_TILE), unsigned (n_centers)), dim3 (256), 0, st, t, a);
+  return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K13: blockIdx.y = one (centre, relative speed) pair, thread = one candidate block start ("state", offset -pad_start .. -1
+ * in steps of sync_search_step, scaled to Q16 by 1 / relative speed; wmspeed.cc:330-344).  A state visits the sync frames of
+ * three consecutive blocks (compare_bits<0..2>, :270-328): row = (offset + frame_offset) >> 16, used when the sum is not
+ * negative and the row exists -- the reference's begin / end iterators are exactly this test because the frame offsets grow
+ * monotonically.  Sums per sync bit are float, in the order block 0, 1, 2 and frame ascending; odd blocks swap up and down.
+ * The best normalised quality over the states (:346-371) is all that survives: a 64 bit atomic max on the bits of the
+ * (non-negative) double.
+ * ------------------------------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__ (256)
+speed_compare_kernel (SpeedCompareArgs a)
+{
+  __shared__ long long s_fo[3 * SPEED_COLS];
+  __shared__ double    s_best[4];
+  const SpeedItemDev it = a.items[blockIdx.y];
+  const SpeedCenterDev cd = a.centers[it.center];
+  for (int e = threadIdx.x; e < 3 * SPEED_COLS; e += blockDim.x)
+    {
+      const int block = e / SPEED_COLS, col = e - block * SPEED_COLS;
+      const int steps = (block * a.frames_per_block + a.col_frame[col]) * a.steps_per_frame;
+      double v = steps * it.rel_speed_inv;
+      v = v + 0.5;
+      v = v * 65536.0;
+      s_fo[e] = (long long) v;
+    }
+  __syncthreads();
+  const int state = blockIdx.x * blockDim.x + threadIdx.x;
+  double q = 0;
+  if (state < a.pad_start)
+    {
+      const double scaled = (state - a.pad_start) * it.q16_scale;
+      const long long offset = (int) scaled;
+      const float2 *mags = a.mags + it.center * a.mags_center_stride;
+      const long long rows = cd.rows;
+      int total = 0;
+      for (int bit = 0; bit < 6; bit++)
+        {
+          float u = 0.f, d = 0.f;
+          int n = 0;
+          for (int block = 0; block < 3; block++)
+            {
+              const long long *fo = s_fo + block * SPEED_COLS + bit * a.rows_per_bit;
+              const float2 *mc = mags + (long long) bit * a.rows_per_bit * a.ld;
+              for (int j = 0; j < a.rows_per_bit; j++)
+                {
+                  const long long sum = offset + fo[j];
+                  const long long idx = sum >> 16;
+                  if (sum >= 0 && idx < rows)
+                    {
+                      const float2 m = mc[j * a.ld + idx];
+                      if (block & 1)
+                        {
+                          u = __fadd_rn (u, m.y);
+                          d = __fadd_rn (d, m.x);
+                        }
+                      else
+                        {
+                          u = __fadd_rn (u, m.x);
+                          d = __fadd_rn (d, m.y);
+                        }
+                      n++;
+                    }
+                }
+            }
+          float raw;                                        // SyncFinder::bit_quality (reference syncfinder.cc:94-114)
+          if (u == 0 || d == 0)
+            raw = 0;
+          else if (u < d)
+            raw = __fsub_rn (1.f, __fdiv_rn (u, d));
+          else
+            raw = __fsub_rn (__fdiv_rn (d, u), 1.f);
+          const double rb = (bit & 1) ? double (raw) : -double (raw);
+          q += rb * n;
+          total += n;
+        }
+      if (total)
+        {
+          q /= total;
+          q = q / a.min_delta / 2.9;                        // normalize_sync_quality
+          q = fabs (q);
+        }
+      else
+        q = 0;
+    }
+  // workgroup maximum
+  for (int o = 32; o > 0; o >>= 1)
+    q = fmax (q, __shfl_xor (q, o));
+  if ((threadIdx.x & 63) == 0)
+    s_best[threadIdx.x >> 6] = q;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    {
+      const double best = fmax (fmax (s_best[0], s_best[1]), fmax (s_best[2], s_best[3]));
+      if (best > 0)
+        atomicMax (a.best + blockIdx.y, (unsigned long long) __double_as_longlong (best));
+    }
+}
+
+hipError_t
+launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items)
+{
+  if (n_items <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (speed_compare_kernel, dim3 (unsigned ((a.pad_start + 255) / 256), unsigned (n_items)), dim3 (256), 0, st, a);
+  return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * K14: get_clip_locations hashes a pseudo random subset of the samples (wmspeed.cc:533-553): the positions come from the
+ * host's AES-CTR generator, the device only gathers.  get_best_clip_location (:555-577) compares the energies of the
+ * candidate clips: float squares summed in double (the reference adds them one by one, here in a tree: the energies
+ * agree to ~1e-15 relative, which only matters for clips of equal energy).
+ * ------------------------------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__ (256)
+gather_values_kernel (const float *in, const unsigned long long *pos, long long n, float *out)
+{
+  const long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n)
+    out[i] = in[pos[i]];
+}
+
+hipError_t
+launch_gather_values (hipStream_t st, const float *in, const unsigned long long *pos, long long n, float *out)
+{
+  if (n <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (gather_values_kernel, dim3 (unsigned ((n + 255) / 256)), dim3 (256), 0, st, in, pos, n, out);
+  return hipGetLastError();
+}
+
+__global__ void __launch_bounds__ (256)
+energy_kernel (const float *in, const long long *range, double *out)
+{
+  __shared__ double s_part[4];
+  const long long begin = range[2 * blockIdx.y], end = range[2 * blockIdx.y + 1];
+  double e = 0;
+  for (long long i = begin + (long long) blockIdx.x * blockDim.x + threadIdx.x; i < end; i += (long long) gridDim.x * blockDim.x)
+    {
+      const float s = in[i];
+      e += double (__fmul_rn (s, s));
+    }
+  for (int o = 32; o > 0; o >>= 1)
+    e += __shfl_xor (e, o);
+  if ((threadIdx.x & 63) == 0)
+    s_part[threadIdx.x >> 6] = e;
+  __syncthreads();
+  if (threadIdx.x == 0)
+    out[blockIdx.y * gridDim.x + blockIdx.x] = (s_part[0] + s_part[1]) + (s_part[2] + s_part[3]);
+}
+
+// out: [n_ranges][ENERGY_PARTS] partial sums (added up by the host in index order: deterministic)
+hipError_t
+launch_energy (hipStream_t st, const float *in, const long long *range, int n_ranges, double *out)
+{
+  if (n_ranges <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (energy_kernel, dim3 (ENERGY_PARTS, unsigned (n_ranges)), dim3 (256), 0, st, in, range, out);
+  return hipGetLastError();
+}
+
+} // namespace awmk

@@ -299,17 +299,29 @@ parse_get_options (ArgParser& ap)
   ap.parse_opt ("--test-truncate", Params::test_truncate);
   if (ap.parse_opt ("--hard")) Params::hard = true;
   if (ap.parse_opt ("--test-no-sync")) Params::test_no_sync = true;
-  for (const char *opt : { "--detect-speed", "--detect-speed-patient" })
-    if (ap.parse_opt (opt))
-      {
-        error ("audiowmark: %s is not supported by the GPU path\n", opt);
-        exit (1);
-      }
-  if (ap.parse_opt ("--try-speed", f) || ap.parse_opt ("--test-speed", f))
+  int speed_options = 0;
+  if (ap.parse_opt ("--detect-speed"))
     {
-      error ("audiowmark: speed options are not supported by the GPU path\n");
+      Params::detect_speed = true;
+      speed_options++;
+    }
+  if (ap.parse_opt ("--detect-speed-patient"))
+    {
+      Params::detect_speed_patient = true;
+      speed_options++;
+    }
+  if (ap.parse_opt ("--try-speed", f))
+    {
+      Params::try_speed = f;
+      speed_options++;
+    }
+  if (speed_options > 1)
+    {
+      error ("audiowmark: can only use one option: --detect-speed or --detect-speed-patient or --try-speed\n");
       exit (1);
     }
+  if (ap.parse_opt ("--test-speed", f))
+    Params::test_speed = f;
   if (ap.parse_opt ("--json", s)) Params::json_output = s;
   if (ap.parse_opt ("--chunk-size", f))
     {
@@ -488,6 +500,16 @@ main (int argc, char **argv)
       ap.parse_opt ("--name", key_name);
       args = parse_positional (ap, "key_file");
       return gen_key (args[0], key_name);
+    }
+  else if (ap.parse_cmd ("test-change-speed"))
+    {
+      parse_shared_options (ap);
+      parse_stream_options (ap, true);
+      args = parse_positional (ap, "input_wav", "output_wav", "speed");
+      awm_ctx *ctx = open_gpu();
+      const int rc = test_change_speed (ctx, args[0], args[1], atof_or_die (args[2]));
+      awm_ctx_destroy (ctx);
+      return rc;
     }
   else if (ap.parse_cmd ("test-gen-noise"))
     {

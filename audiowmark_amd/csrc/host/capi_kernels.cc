@@ -2,6 +2,7 @@
 #include "context.hh"
 #include "syncfinder.hh"
 #include "wmget.hh"
+#include "wmspeed.hh"
 #include "utils.hh"
 #include <algorithm>
 #include <cmath>
@@ -693,6 +694,118 @@ awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, siz
   for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
     fill_pattern (rs.patterns[i], out[i]);
   return int (rs.patterns.size());
+}
+
+/* ---- speed detection (reference wmspeed.cc) ---------------------------------------------------------------------- */
+static DeviceWav
+make_wav_rate (const float *pcm_d, size_t n_frames, int n_channels, int rate)
+{
+  DeviceWav w = make_wav (pcm_d, n_frames, n_channels);
+  w.sample_rate = rate;
+  return w;
+}
+
+void
+awm_set_speed_params (int detect_speed, int detect_speed_patient, double try_speed, double test_speed)
+{
+  Params::detect_speed = detect_speed != 0;
+  Params::detect_speed_patient = detect_speed_patient != 0;
+  Params::try_speed = try_speed;
+  Params::test_speed = test_speed;
+}
+
+size_t
+awm_resample_ratio_frames (size_t n_frames, int n_channels, int rate, double ratio, double max_in_seconds)
+{
+  size_t in_frames = n_frames;
+  if (max_in_seconds > 0)
+    in_frames = std::min<size_t> (in_frames * n_channels, n_channels * lrint (rate * max_in_seconds)) / n_channels;
+  return size_t (lrint (in_frames * ratio));
+}
+
+int
+awm_resample_ratio_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_channels, int rate, double ratio,
+                      double max_in_seconds, float *out_d, size_t n_out_frames)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if ((n_frames && !pcm_in_d) || (n_out_frames && !out_d) || n_channels < 1 || rate < 1)
+    {
+      set_error ("awm_resample_ratio_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  DevBuffer tmp;
+  size_t n_out = 0;
+  int rc = resample_ratio_device (ctx, ctx, make_wav_rate (pcm_in_d, n_frames, n_channels, rate), ratio, max_in_seconds, tmp, &n_out);
+  if (!rc)
+    {
+      const size_t n = std::min (n_out, n_out_frames) * n_channels * sizeof (float);
+      if (n && hipMemcpyAsync (out_d, tmp.ptr, n, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+        rc = AWM_ERR_HIP;
+      if (!rc && hipStreamSynchronize (ctx->stream) != hipSuccess)
+        rc = AWM_ERR_HIP;
+    }
+  tmp.release();
+  return rc;
+}
+
+int
+awm_speed_clip_location_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
+                           double seconds, int candidates, double *location)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  return speed_clip_location (ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), seconds, candidates, location);
+}
+
+int
+awm_speed_mags_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
+                  double clip_location, double center, double seconds, size_t max_rows, float *out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  std::vector<float> m;
+  int rows = 0;
+  if (int rc = speed_mags (ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), clip_location, center, seconds, m, &rows))
+    return rc;
+  std::copy (m.begin(), m.begin() + std::min<size_t> (rows, max_rows) * 510 * 2, out);
+  return rows;
+}
+
+int
+awm_speed_scan_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
+                  double clip_location, double seconds, double step, int n_steps, int n_center_steps,
+                  const double *speeds, int n_speeds, size_t max_out, double *out_speed, double *out_quality)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  std::vector<SpeedScore> scores;
+  if (int rc = speed_scan (ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), clip_location,
+                           { seconds, step, n_steps, n_center_steps }, std::vector<double> (speeds, speeds + n_speeds), scores))
+    return rc;
+  std::sort (scores.begin(), scores.end(), [] (const SpeedScore& a, const SpeedScore& b) { return a.speed < b.speed; });
+  for (size_t i = 0; i < scores.size() && i < max_out; i++)
+    {
+      out_speed[i] = scores[i].speed;
+      out_quality[i] = scores[i].quality;
+    }
+  return int (scores.size());
+}
+
+int
+awm_detect_speed_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
+                    int patient, double *speed_out, double *quality_out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  const bool old_patient = Params::detect_speed_patient;
+  Params::detect_speed_patient = patient != 0;
+  std::vector<DetectSpeedResult> results;
+  double speed = 0, quality = 0;
+  const int rc = detect_speed (ctx, { capi_key (key) }, make_wav_rate (pcm_d, n_frames, n_channels, rate), false, results, &speed, &quality);
+  Params::detect_speed_patient = old_patient;
+  if (rc)
+    return rc;
+  if (speed_out)
+    *speed_out = speed;
+  if (quality_out)
+    *quality_out = quality;
+  return results.empty() ? 0 : 1;
 }
 
 } // extern "C"

@@ -113,14 +113,40 @@ awm_ctx::lane (int i)
 
 using namespace awm;
 
-static int
-upload (DevBuffer& buf, const void *src, size_t bytes, hipStream_t st)
+int
+awm::upload_sync (DevBuffer& buf, const void *src, size_t bytes, hipStream_t st)
 {
   if (int rc = buf.reserve (bytes ? bytes : 1))
     return rc;
   AWM_HIP_CHECK (hipMemcpyAsync (buf.ptr, src, bytes, hipMemcpyHostToDevice, st));
-  AWM_HIP_CHECK (hipStreamSynchronize (st));   // source vectors are temporaries
+  AWM_HIP_CHECK (hipStreamSynchronize (st));
   return 0;
+}
+
+std::vector<float>
+awm::zita_table (double frel, unsigned h, unsigned n)
+{
+  auto sinc = [] (double x) { x = std::fabs (x); if (x < 1e-6) return 1.0; x *= M_PI; return std::sin (x) / x; };
+  auto wind = [] (double x) { x = std::fabs (x); if (x >= 1.0) return 0.0; x *= M_PI; return 0.384 + 0.500 * std::cos (x) + 0.116 * std::cos (2 * x); };
+  std::vector<float> ctab (size_t (h) * (n + 1));
+  float *p = ctab.data();
+  for (unsigned j = 0; j <= n; j++)
+    {
+      double t = double (j) / double (n);
+      for (unsigned i = 0; i < h; i++)
+        {
+          p[h - i - 1] = float (frel * sinc (t * frel) * wind (t / h));
+          t += 1;
+        }
+      p += h;
+    }
+  return ctab;
+}
+
+static int
+upload (DevBuffer& buf, const void *src, size_t bytes, hipStream_t st)
+{
+  return upload_sync (buf, src, bytes, st);
 }
 
 static std::vector<int>
@@ -244,20 +270,7 @@ awm_ctx::get_resample_table (int rate_in, int rate_out)
       frel *= r;
       h = unsigned (std::ceil (h / r));
     }
-  auto sinc = [] (double x) { x = std::fabs (x); if (x < 1e-6) return 1.0; x *= M_PI; return std::sin (x) / x; };
-  auto wind = [] (double x) { x = std::fabs (x); if (x >= 1.0) return 0.0; x *= M_PI; return 0.384 + 0.500 * std::cos (x) + 0.116 * std::cos (2 * x); };
-  std::vector<float> ctab (size_t (h) * (n + 1));
-  float *p = ctab.data();
-  for (unsigned j = 0; j <= n; j++)
-    {
-      double t = double (j) / double (n);
-      for (unsigned i = 0; i < h; i++)
-        {
-          p[h - i - 1] = float (frel * sinc (t * frel) * wind (t / h));
-          t += 1;
-        }
-      p += h;
-    }
+  const std::vector<float> ctab = zita_table (frel, h, n);
   auto rt = std::make_unique<ResampleTable>();
   rt->rate_in = rate_in;
   rt->rate_out = rate_out;
@@ -456,6 +469,7 @@ awm_ctx_destroy (awm_ctx *ctx)
     t->dev.release();
   for (auto& t : ctx->resample_tables)
     t->ctab.release();
+  awm::speed_workspace_free (ctx);
   ctx->ws_rate_a.release();
   ctx->ws_rate_b.release();
   ctx->ws_rate_c.release();

@@ -109,6 +109,15 @@ struct ResampleTable
   DevBuffer ctab;                  // (np + 1) * hl floats
 };
 
+// coefficient table of zita-resampler (Resampler_table): (np + 1) * hl floats
+std::vector<float> zita_table (double frel, unsigned hl, unsigned np);
+// grow `buf` to `bytes` and copy host memory into it on `st`; returns when the copy is done (the source may be a temporary)
+int upload_sync (DevBuffer& buf, const void *src, size_t bytes, hipStream_t st);
+
+struct SpeedWorkspace;            // wmspeed.hh
+} struct awm_ctx; namespace awm {
+void speed_workspace_free (awm_ctx *ctx);
+
 struct FrameModTable
 {
   std::vector<unsigned char> key;
@@ -159,6 +168,9 @@ struct awm_ctx : awm::WorkLane
   awm::DevBuffer ws_rate_a, ws_rate_b, ws_rate_c;                          // resampled input / watermark signals of the other-rate add path
   std::unique_ptr<awm::WorkLane> extra_lanes[awm::MAX_LANES - 1];
   awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
+
+  awm::SpeedWorkspace *speed = nullptr;  // tables and buffers of the speed detection (wmspeed.cc), created on first use
+  std::mutex     speed_mutex;            // one speed search at a time per context
 
   std::mutex     table_mutex;            // key / frame_mod table caches (lanes may be driven by different host threads)
   std::mutex     prof_mutex;

@@ -39,4 +39,7 @@ std::string                 vec_to_hex_str (const std::vector<unsigned char>& ve
 
 double get_time();
 
+// FIPS 180-4 SHA-1 (the reference seeds the speed clip selection from libgcrypt's GCRY_MD_SHA1, random.cc:184-190)
+void sha1 (const void *data, size_t len, unsigned char digest[20]);
+
 } // namespace awm

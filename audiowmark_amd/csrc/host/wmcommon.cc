@@ -16,6 +16,10 @@ size_t      Params::payload_size    = 128;
 double      Params::sync_threshold2 = 0.35;
 int         Params::get_n_best      = 8;
 double      Params::get_chunk_size  = 30;
+bool        Params::detect_speed    = false;
+bool        Params::detect_speed_patient = false;
+double      Params::try_speed       = -1;
+double      Params::test_speed      = -1;
 int         Params::test_cut        = 0;
 bool        Params::test_no_sync    = false;
 bool        Params::test_no_limiter = false;

@@ -46,6 +46,11 @@ struct Params
 
   static double get_chunk_size;     // minutes
 
+  static bool   detect_speed;          // --detect-speed (reference wmcommon.hh:49-52)
+  static bool   detect_speed_patient;  // --detect-speed-patient
+  static double try_speed;             // --try-speed: manual speed correction
+  static double test_speed;            // --test-speed: expected speed, for the detect_speed report line
+
   static int  test_cut;
   static bool test_no_sync;
   static bool test_no_limiter;

@@ -396,6 +396,7 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
       wav.n_frames = n_frames;
       wav.n_channels = C;
       wav.sample_rate = Params::mark_sample_rate;
+      speed_print_results = !orig_bitvec.empty();      // decode (..., orig_bits, ...): the detect_speed report line of `cmp`
       const int rc = get_watermark_device (ctx, key_list, wav, result_set);
       if (rc)
         {
@@ -426,6 +427,53 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
         }
       else if (!match_count)
         return 1;
+    }
+  return 0;
+}
+
+/* `audiowmark test-change-speed in out speed` (reference audiowmark.cc:419-437): resample_ratio (in, 1 / speed, same rate) */
+int
+test_change_speed (awm_ctx *ctx, const std::string& infile, const std::string& outfile, double speed)
+{
+  Error err;
+  auto in_stream = AudioInputStream::create (infile, err);
+  if (err)
+    {
+      error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
+      return 1;
+    }
+  const int C = in_stream->n_channels();
+  DevBuffer d_in, d_out;
+  size_t n_values = 0;
+  err = load_stream_to_device (ctx, in_stream.get(), d_in, n_values);
+  if (err)
+    {
+      error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
+      d_in.release();
+      return 1;
+    }
+  const size_t in_frames = n_values / C;
+  const size_t out_frames = awm_resample_ratio_frames (in_frames, C, in_stream->sample_rate(), 1 / speed, -1);
+  if (d_out.reserve (std::max<size_t> (16, out_frames * C * sizeof (float)))
+      || awm_resample_ratio_d (ctx, d_in.as<float>(), in_frames, C, in_stream->sample_rate(), 1 / speed, -1, d_out.as<float>(), out_frames))
+    {
+      error ("audiowmark: failed to setup vresampler with ratio=%f\n", 1 / speed);
+      d_in.release();
+      d_out.release();
+      return 1;
+    }
+  auto out_stream = AudioOutputStream::create (outfile, C, in_stream->sample_rate(), in_stream->bit_depth() < 16 ? 16 : in_stream->bit_depth(),
+                                               in_stream->bit_depth() < 16 ? Encoding::SIGNED : in_stream->encoding(), out_frames, err);
+  if (!err)
+    err = store_device_to_stream (ctx, out_stream.get(), d_out.as<float>(), out_frames * C);
+  if (!err)
+    err = out_stream->close();
+  d_in.release();
+  d_out.release();
+  if (err)
+    {
+      error ("audiowmark: error saving %s: %s\n", outfile.c_str(), err.message());
+      return 1;
     }
   return 0;
 }

@@ -14,4 +14,6 @@ int add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_str
 int add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits);
 int get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string& infile, const std::string& orig_pattern);
 
+int test_change_speed (awm_ctx *ctx, const std::string& infile, const std::string& outfile, double speed);   // reference audiowmark.cc:419-437
+
 } // namespace awm

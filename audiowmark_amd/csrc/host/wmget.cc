@@ -1,4 +1,5 @@
 #include "wmget.hh"
+#include "wmspeed.hh"
 #include <atomic>
 #include <thread>
 #include "utils.hh"
@@ -996,9 +997,53 @@ clip_decoder_run (awm_ctx *ctx, WorkLane *lane, bool spread, const std::vector<K
 
 } // namespace
 
+/* The speed part of decode() (reference wmget.cc:886-927): "we always (unconditionally) try to decode the watermark on the
+ * original wav data; if detected speed is somewhat different than 1.0, we also try to decode stretched data; we report all
+ * normal and speed results we get".  Runs before the normal decoders of the chunk, like in the reference. */
+static int
+decode_speed (awm_ctx *ctx, WorkLane *home, bool spread, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav,
+              bool first_chunk, bool print_results)
+{
+  if (!(Params::detect_speed || Params::detect_speed_patient || Params::try_speed > 0))
+    return 0;
+  std::vector<DetectSpeedResult> speed_results;
+  if (Params::detect_speed || Params::detect_speed_patient)
+    {
+      if (int rc = detect_speed (ctx, key_list, wav, print_results, speed_results))
+        return rc;
+    }
+  else
+    {
+      for (const Key& key : key_list)
+        speed_results.push_back ({ key, Params::try_speed });
+    }
+  for (const auto& sr : speed_results)
+    {
+      // resample_ratio (wav, speed, mark_sample_rate * speed)
+      size_t n_out = 0;
+      if (int rc = resample_ratio_device (ctx, home, wav, sr.speed, -1, speed_stretch_buffer (ctx), &n_out))
+        return rc;
+      DeviceWav sw;
+      sw.data = speed_stretch_buffer (ctx).as<float>();
+      sw.n_frames = n_out;
+      sw.n_channels = wav.n_channels;
+      sw.sample_rate = int (Params::mark_sample_rate * sr.speed);
+      if (int rc = block_decoder_run (ctx, home, spread, { sr.key }, sw, { ChunkRange { 0, sw.n_frames, 0.0 } }, { &result_set }, sr.speed, nullptr))
+        return rc;
+      if (first_chunk)
+        if (int rc = clip_decoder_run (ctx, home, spread, { sr.key }, sw, result_set, sr.speed))
+          return rc;
+    }
+  return 0;
+}
+
+bool speed_print_results = false;       // decode() passes !orig_bits.empty(): set by the command line front end for `cmp`
+
 int
 decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav, bool first_chunk)
 {
+  if (int rc = decode_speed (ctx, ctx, true, result_set, key_list, wav, first_chunk, speed_print_results))
+    return rc;
   std::string debug_sync;
   if (int rc = block_decoder_run (ctx, ctx, true, key_list, wav, { ChunkRange { 0, wav.n_frames, 0.0 } }, { &result_set }, 1, &debug_sync))
     return rc;
@@ -1054,6 +1099,14 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
   std::vector<ResultSet *> ptrs;
   for (auto& cs : chunk_sets)
     ptrs.push_back (&cs);
+  for (size_t c = 0; c < chunks.size(); c++)
+    {
+      DeviceWav cw = wav;
+      cw.data = wav.data + chunks[c].first_frame * wav.n_channels;
+      cw.n_frames = chunks[c].n_frames;
+      if (int rc = decode_speed (ctx, home, spread, chunk_sets[c], key_list, cw, c == 0 && first_is_stream_start, speed_print_results))
+        return rc;
+    }
   std::string debug_sync;
   if (int rc = block_decoder_run (ctx, home, spread, key_list, wav, chunks, ptrs, 1, &debug_sync))
     return rc;
@@ -1249,6 +1302,14 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
     return 0;
   // short clips: staged over the lanes from this thread; everything else: one clip per lane and host thread
   std::vector<size_t> staged, threaded;
+  if (Params::detect_speed || Params::detect_speed_patient || Params::try_speed > 0)
+    {
+      // the speed search and the stretched copy of a clip live in per-context buffers: one clip after the other
+      for (size_t i = 0; i < clips.size(); i++)
+        if (int rc = get_watermark_on (ctx, ctx, true, key_list, clips[i], result_sets[i]))
+          return rc;
+      return 0;
+    }
   for (size_t i = 0; i < clips.size(); i++)
     (clip_is_short (clips[i]) && !getenv ("AWM_BATCH_THREADS") ? staged : threaded).push_back (i);
   if (!staged.empty())

@@ -40,6 +40,7 @@ private:
 };
 
 // decode() of one chunk (reference wmget.cc:886-939): BlockDecoder + (first chunk) ClipDecoder
+extern bool speed_print_results;   // print the "detect_speed" report line of decode() (reference wmget.cc:902: !orig_bits.empty())
 int decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav, bool first_chunk);
 
 // chunk boundaries of WavChunkLoader for n_frames samples per channel at 44.1 kHz

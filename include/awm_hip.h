@@ -207,6 +207,35 @@ int awm_plan_chunks (size_t n_frames, size_t max_out, uint64_t *first_frame, uin
 int awm_merge_patterns (const uint8_t key[16], const awm_pattern *patterns, const int *chunk_count, int n_chunks,
                         size_t max_out, awm_pattern *out);
 
+/* ---- speed detection (reference wmspeed.cc:622-781) ------------------------------------
+ * `get --detect-speed`: the reference looks for the replay speed (0.8 .. 1.25) of the watermark before decoding, by
+ * correlating the sync pattern with a half-rate STFT of a 25 / 50 s clip over a grid of speeds, and decodes the stream a
+ * second time stretched back to speed 1 (wmget.cc:886-927).  awm_set_speed_params switches that part of decode() on for
+ * awm_get_watermark_d / awm_decode_chunk(s)_d (Params::detect_speed, detect_speed_patient, try_speed, test_speed;
+ * wmcommon.hh:49-52); patterns found on the stretched stream carry the speed in awm_pattern.speed.
+ * The stretch is zita-resampler's VResampler (resample.cc:96-125), restated like the fixed-ratio Resampler: bit parity
+ * with the library is unpinned.  On the device the resampler's phase comes from the exact product instead of zita's
+ * accumulated double (differs by its accumulated rounding only), so stretched PCM agrees to ~1e-7, not bit for bit. */
+void awm_set_speed_params (int detect_speed, int detect_speed_patient, double try_speed, double test_speed);
+/* resample_ratio_truncate (resample.cc:96-119): frames the call produces / the call itself (out_d: n_out_frames frames) */
+size_t awm_resample_ratio_frames (size_t n_frames, int n_channels, int rate, double ratio, double max_in_seconds);
+int awm_resample_ratio_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_channels, int rate, double ratio,
+                          double max_in_seconds, float *out_d, size_t n_out_frames);
+/* detect_speed for one key (wmspeed.cc:622-781) on resident PCM: returns 1 if decoding at *speed_out should be tried
+ * (quality > 0.4 and speed outside 0.9999 .. 1.0001), 0 if not, < 0 on errors; speed / quality are filled in either way */
+int awm_detect_speed_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
+                        int patient, double *speed_out, double *quality_out);
+/* the pieces, for parity tests: get_best_clip_location (wmspeed.cc:555-577); SpeedSync::prepare_mags for one centre speed
+ * (:204-268; out is host memory, [row][510 sync frames sorted by frame][umag, dmag], returns the row count); one
+ * run_search pass (:461-492, 683-719; scores sorted by speed, returns their number) */
+int awm_speed_clip_location_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
+                               double seconds, int candidates, double *location);
+int awm_speed_mags_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
+                      double clip_location, double center, double seconds, size_t max_rows, float *out);
+int awm_speed_scan_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
+                      double clip_location, double seconds, double step, int n_steps, int n_center_steps,
+                      const double *speeds, int n_speeds, size_t max_out, double *out_speed, double *out_quality);
+
 /* global parameters (reference Params, wmcommon.hh:33-89) */
 void awm_set_params (double water_delta, int mix, int frames_per_bit, int test_no_limiter,
                      double sync_threshold2, int n_best, double chunk_size_min);
