@@ -1250,16 +1250,26 @@ process_resampler (R& rs, const float *in, size_t in_values, float *out, size_t 
   rs.process();
 }
 
+bool vresampler_setup_failed = false;
+
 vector<float>
 resample_ratio_truncate (const float *in, size_t n_values, int C, int rate, double ratio, double max_in_seconds)   /* resample.cc:96-119 */
 {
+  if (!(ratio > 0))                                  /* (the reference computes lrint (inf) on its way to the same exit) */
+    {
+      vresampler_setup_failed = true;
+      return {};
+    }
   size_t in_values = n_values;
   if (max_in_seconds > 0)
     in_values = std::min<size_t> (in_values, C * lrint (rate * max_in_seconds));
   vector<float> out (size_t (lrint (in_values / C * ratio)) * C);
   ZitaVResampler rs;
   if (rs.setup (ratio, C, 16) != 0)
-    return {};
+    {
+      vresampler_setup_failed = true;                /* the reference prints "failed to setup vresampler" and exits (resample.cc:110-114) */
+      return {};
+    }
   process_resampler (rs, in, in_values, out.data(), out.size());
   return out;
 }
@@ -2030,7 +2040,10 @@ orc_detect_speed (const uint8_t key[16], const float *samples, size_t n_values, 
                   double *speed_out, double *quality_out)
 {
   double speed = 0, quality = 0;
+  vresampler_setup_failed = false;
   const bool use = detect_speed (key, samples, n_values, n_channels, rate, patient != 0, &speed, &quality);
+  if (vresampler_setup_failed)                       /* e.g. digital silence: every score is 0, the second pass asks for speed 0 */
+    return -1;
   if (speed_out)
     *speed_out = speed;
   if (quality_out)

@@ -89,7 +89,8 @@ int    orc_speed_scan (const uint8_t key[16], const float *samples, size_t n_val
 int    orc_speed_select_n_best (double *speed, double *quality, int count, int n);    /* wmspeed.cc:494-531 */
 double orc_speed_smooth_best (const double *speed, const double *quality, int count, double step, double distance);
 /* detect_speed for one key (wmspeed.cc:622-781): returns 1 if the speed passes the thresholds (quality > 0.4, more than
- * 1e-4 away from 1); speed / quality are filled in either way */
+ * 1e-4 away from 1); speed / quality are filled in either way.  -1: the reference would exit with "failed to setup
+ * vresampler" (every score 0, e.g. digital silence: the second pass is asked to search around speed 0) */
 int    orc_detect_speed (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int rate, int patient,
                          double *speed_out, double *quality_out);
 

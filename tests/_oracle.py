@@ -328,4 +328,6 @@ def detect_speed(key, samples, n_channels, patient=False, rate=44100):
     f = lib().orc_detect_speed
     f.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     n = f(_key(key), _p(s), s.size, n_channels, rate, int(patient), C.byref(out), C.byref(q))
+    if n < 0:
+        raise RuntimeError("failed to setup vresampler (the reference exits here)")
     return (out.value if n else None), out.value, q.value

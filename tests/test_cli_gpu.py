@@ -132,3 +132,31 @@ def test_sample_rate_scenario(tmp_path):
     odd.write_bytes(run([AWM, "test-gen-noise", "-", "10", "33333"]).stdout)
     r = run([AWM, "add", "--format", "wav-pipe", str(odd), "-", PAY], check=False)
     assert r.returncode != 0 and b"not implemented" in r.stderr
+
+
+def test_detect_speed_scenario(work, tmp_path):
+    """reference tests/detect-speed-test.sh: 30 s of noise, watermarked, replayed at another speed, found with --detect-speed"""
+    noise = tmp_path / "n30.wav"
+    marked = tmp_path / "m30.wav"
+    run([AWM, "test-gen-noise", str(noise), "30", "44100"])
+    run([AWM, "add", "--test-key", "1", str(noise), str(marked), PAY])
+    for speed in ("0.9764", "1.0", "1.01"):
+        spd = tmp_path / ("s%s.wav" % speed)
+        run([AWM, "test-change-speed", str(marked), str(spd), speed])
+        for opt in ("--detect-speed", "--detect-speed-patient"):
+            r = run([AWM, "cmp", "--test-key", "1", str(spd), PAY, opt, "--test-speed", speed])
+            out = r.stdout.decode()
+            line = [l for l in out.splitlines() if l.startswith("detect_speed ")]
+            assert len(line) == 1, out
+            found, quality, delta = (float(v) for v in line[0].split()[1:])
+            assert delta < 0.02 and quality > 1, line                       # percent
+            assert "match_count" in out and not out.split("match_count")[1].strip().startswith("0 "), out
+            if speed != "1.0":
+                assert any(l.startswith("speed %.6f" % found) for l in out.splitlines()), out   # ResultSet::print (wmget.cc:397-404)
+    # without speed detection the replayed file is not decodable
+    r = run([AWM, "cmp", "--test-key", "1", str(tmp_path / "s0.9764.wav"), PAY], check=False)
+    assert r.returncode != 0
+    # --try-speed with the known speed finds it as well; only one speed option at a time
+    run([AWM, "cmp", "--test-key", "1", str(tmp_path / "s0.9764.wav"), PAY, "--try-speed", "0.9764"])
+    r = run([AWM, "get", "--test-key", "1", str(spd), "--detect-speed", "--try-speed", "1.01"], check=False)
+    assert r.returncode != 0 and b"can only use one option" in r.stderr

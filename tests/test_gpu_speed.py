@@ -1,0 +1,188 @@
+"""Speed detection (`get --detect-speed`, reference wmspeed.cc) and the variable-ratio resampler behind it, HIP path through
+the C ABI against the oracle and the golden vectors of the compiled reference (tests/golden/speed_v1.json).
+
+Tolerances: the detected speed is a float result of a search over float scores -- it has to agree within 2e-6 (two steps of
+the final smoothing grid, wmspeed.cc:407); scores within 1e-4, magnitudes within 1e-2 dB-sum units (values ~2000); stretched
+PCM within 1e-6; everything that is decoded from the stretched stream (payload bits, sync positions, pattern types) exactly."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import _oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+KEY = bytes(range(16))
+SPEED_TOL = 2e-6
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import audiowmark_amd as awm
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    ctx = awm.Context(0)
+
+    class G:
+        pass
+    g = G()
+    g.torch, g.awm, g.ctx = torch, awm, ctx
+    g.dev = lambda a, ch=2: torch.from_numpy(np.ascontiguousarray(a).reshape(-1, ch)).cuda()
+    yield g
+    awm.set_speed_params()
+    orc.set_speed_params(False, False, -1)
+    ctx.close()
+
+
+@pytest.fixture(scope="module")
+def golden():
+    with open(os.path.join(HERE, "golden", "speed_v1.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def marked(golden):
+    C = golden["channels"]
+    x = orc.gen_noise(KEY, golden["seconds"] * 44100 * C)
+    y = orc.add(KEY, x, C, golden["payload"])
+    assert sha(y) == golden["marked_sha"]
+    return y
+
+
+@pytest.fixture(scope="module")
+def replayed(golden, marked):
+    """the reference's detect-speed-test.sh inputs: the marked noise replayed at 0.9764 / 1.0 / 1.01 (oracle's resampler)"""
+    out = {}
+    for speed, case in golden["cases"].items():
+        z = orc.resample_ratio(marked, golden["channels"], 1 / float(speed))
+        assert sha(z) == case["sha"]
+        out[speed] = z
+    return out
+
+
+@pytest.mark.parametrize("ratio,ch", [(1 / 0.9764, 2), (1 / 1.01, 2), (0.49, 1), (0.8, 3), (1.25, 2), (2.5, 1)])
+def test_resample_ratio_matches_restated_zita(gpu, ratio, ch):
+    x = np.random.default_rng(int(ratio * 1000)).uniform(-1, 1, (200000 + ch, ch)).astype(np.float32)
+    got = gpu.ctx.resample_ratio(gpu.dev(x, ch), ratio).cpu().numpy()
+    want = orc.resample_ratio(x, ch, ratio).reshape(-1, ch)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-6
+    # truncated input (prepare_mags uses it)
+    got = gpu.ctx.resample_ratio(gpu.dev(x, ch), ratio, max_in_seconds=1.5).cpu().numpy()
+    want = orc.resample_ratio(x, ch, ratio, max_in_seconds=1.5).reshape(-1, ch)
+    assert got.shape == want.shape and np.abs(got - want).max() <= 1e-6
+
+
+def test_clip_location_and_magnitudes(gpu, golden, replayed):
+    for speed in ("0.9764", "1.01"):
+        case = golden["cases"][speed]
+        z = replayed[speed]
+        zd = gpu.dev(z)
+        assert gpu.ctx.speed_clip_location(KEY, zd, 25.0) == case["clip_location_25"]
+        mags = gpu.ctx.speed_mags(KEY, zd, case["clip_location_25"], 0.98, 25.0)
+        assert mags.shape[0] == case["mags_rows"]
+        for r, col, u, d in case["mags_samples"]:
+            assert abs(float(mags[r, col, 0]) - u) < 1e-2 and abs(float(mags[r, col, 1]) - d) < 1e-2
+    want = orc.speed_mags(KEY, replayed["1.01"], 2, golden["cases"]["1.01"]["clip_location_25"], 0.98, 25.0)
+    assert np.abs(mags - want).max() < 1e-2
+
+
+def test_scan_pass(gpu, golden, replayed):
+    case = golden["cases"]["0.9764"]
+    s, q = gpu.ctx.speed_scan(KEY, gpu.dev(replayed["0.9764"]), case["clip_location_25"], 25.0, 1.0007, 5, 2, [0.98])
+    assert s.tolist() == case["scan_speed"]
+    assert np.abs(q - np.array(case["scan_quality"])).max() < 1e-4
+    assert abs(s[q.argmax()] - 0.9764) < 1e-3
+
+
+@pytest.mark.parametrize("patient", [False, True])
+def test_detect_speed(gpu, golden, replayed, patient):
+    for speed, case in golden["cases"].items():
+        use, best, quality = gpu.ctx.detect_speed(KEY, gpu.dev(replayed[speed]), patient)
+        want = case["detect_patient" if patient else "detect"]
+        if want is None:
+            assert use is None                           # replay speed 1: nothing to correct (|speed - 1| < 1e-4)
+            assert abs(best - 1) < 1e-4 and quality > 1
+        else:
+            assert abs(use - want) <= SPEED_TOL
+            assert abs(use - float(speed)) / float(speed) < 2e-4
+
+
+def test_decode_with_detect_speed(gpu, golden, replayed):
+    """decode() with --detect-speed (wmget.cc:886-939): the patterns of the stretched stream come first, then the normal ones"""
+    for speed in ("0.9764", "1.01", "1"):
+        want = golden["cases"][speed]["decode_detect_speed"]
+        gpu.awm.set_speed_params(detect_speed=True)
+        try:
+            got = gpu.ctx.decode_chunk(KEY, gpu.dev(replayed[speed]), True)
+            got_all = gpu.ctx.get_watermark(KEY, gpu.dev(replayed[speed]))
+        finally:
+            gpu.awm.set_speed_params()
+        assert [(p["sync_index"], p["type"], p["block_type"], p["bits"]) for p in got] == \
+               [(p["sync_index"], p["type"], p["block_type"], p["bits"]) for p in want]
+        for g, w in zip(got, want):
+            assert abs(g["speed"] - w["speed"]) <= SPEED_TOL and abs(g["time"] - w["time"]) < 1e-3
+            assert abs(g["sync_quality"] - w["sync_quality"]) < 1e-4
+        hits = [p for p in got_all if p["bits"] == golden["payload"]]
+        assert hits and (speed == "1") == all(p["speed"] == 1 for p in hits)
+
+
+def test_try_speed(gpu, golden, replayed):
+    gpu.awm.set_speed_params(try_speed=0.9764)
+    orc.set_speed_params(False, False, 0.9764)
+    try:
+        got = gpu.ctx.decode_chunk(KEY, gpu.dev(replayed["0.9764"]), True)
+        want = orc.decode_chunk(KEY, replayed["0.9764"], 2, True)
+    finally:
+        gpu.awm.set_speed_params()
+        orc.set_speed_params(False, False, -1)
+    assert [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["speed"]) for p in got] == \
+           [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["speed"]) for p in want]
+    assert any(p["bits"] == golden["payload"] and p["speed"] == 0.9764 for p in got)
+
+
+def test_mono_and_long_input_against_oracle(gpu):
+    """mono, 100 s (the block decoder finds whole blocks on the stretched stream; the clip location matters)"""
+    n = 100 * 44100
+    x = orc.gen_noise(KEY, n)
+    y = orc.add(KEY, x, 1, "f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0")
+    z = orc.resample_ratio(y, 1, 1 / 1.07)
+    zd = gpu.dev(z, 1)
+    use, best, quality = gpu.ctx.detect_speed(KEY, zd)
+    o_use, o_best, o_quality = orc.detect_speed(KEY, z, 1)
+    assert abs(use - o_use) <= SPEED_TOL and abs(quality - o_quality) < 1e-4 and abs(use - 1.07) < 3e-4
+    gpu.awm.set_speed_params(detect_speed=True)
+    orc.set_speed_params(True, False, -1)
+    try:
+        got = gpu.ctx.get_watermark(KEY, zd)
+        want = orc.get(KEY, z, 1)
+    finally:
+        gpu.awm.set_speed_params()
+        orc.set_speed_params(False, False, -1)
+    assert [(p["sync_index"], p["type"], p["block_type"], p["bits"]) for p in got] == \
+           [(p["sync_index"], p["type"], p["block_type"], p["bits"]) for p in want]
+    assert all(abs(g["speed"] - w["speed"]) <= SPEED_TOL for g, w in zip(got, want))
+    assert sum(p["bits"] == "f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0" and p["speed"] != 1 for p in got) >= 2
+
+
+def test_short_silent_and_one_silent_channel(gpu):
+    assert gpu.ctx.detect_speed(KEY, gpu.dev(np.zeros((5000, 2), np.float32)))[0] is None        # < 0.25 s
+    # digital silence: every score is 0, the second pass searches around "speed 0": the reference exits with
+    # "failed to setup vresampler with ratio=0.000000" (resample.cc:110-114), the library reports the same error
+    with pytest.raises(gpu.awm.AwmError, match="failed to setup vresampler with ratio=0.000000"):
+        gpu.ctx.detect_speed(KEY, gpu.dev(np.zeros((3 * 44100, 2), np.float32)))
+    # one digitally silent channel: its bands are -96 dB in the reference (exact zeros), not the other channel's rounding noise
+    x = np.random.default_rng(77).uniform(-1, 1, (20 * 44100, 2)).astype(np.float32)
+    x[:, 1] = 0
+    loc = orc.speed_clip_location(KEY, x, 2, 25.0)
+    got = gpu.ctx.speed_mags(KEY, gpu.dev(x), loc, 1.0, 25.0)
+    want = orc.speed_mags(KEY, x.ravel(), 2, loc, 1.0, 25.0)
+    assert got.shape == want.shape and np.abs(got - want).max() < 1e-2
