@@ -237,16 +237,17 @@ namespace awmk {
 /* one centre speed of a scan pass, or the one ratio of a plain resample_ratio call: zita VResampler geometry */
 struct SpeedCenterDev
 {
-  const float       *ctab;         // (256 + 1) * hl coefficients
+  const float       *ctab;         // (256 + 1) rows of `stride` floats, hl coefficients each
   int                hl;           // taps per side
+  int                stride;       // hl | 1 (odd: LDS bank spread)
   int                shift;        // input window of output m starts at (m * mant) >> shift
   unsigned long long mant;         // 53 bit mantissa of the phase step 256 / ratio
   double             frac_scale;   // fraction of that product -> phase 0 .. 256
   long long          n_in;         // input frames (after truncation)
   long long          n_out;        // output frames
-  int                rows;         // K12 / K13: STFT rows of the half-rate clip
+  int                rows;         // K13 / K14: STFT rows of the half-rate clip
 };
-/* K11: VResampler (resample.cc:96-125); blockIdx.y = centre, outputs at out + centre * out_stride */
+/* K12: VResampler (resample.cc:96-125); blockIdx.y = centre, outputs at out + centre * out_stride */
 struct VarResampleArgs
 {
   const float          *in;
@@ -257,7 +258,7 @@ struct VarResampleArgs
 };
 hipError_t launch_resample_var (hipStream_t st, const VarResampleArgs& a, long long max_n_out, int n_centers);
 
-/* K12: SpeedSync::prepare_mags (wmspeed.cc:204-268) */
+/* K13: SpeedSync::prepare_mags (wmspeed.cc:204-268) */
 struct SpeedMagsArgs
 {
   const float          *sub;           // half-rate clips, [centre][sub_stride]
@@ -271,7 +272,7 @@ struct SpeedMagsArgs
 };
 hipError_t launch_speed_mags (hipStream_t st, const DevTables& t, const SpeedMagsArgs& a, int max_rows, int n_centers);
 
-/* K13: SpeedSync::compare (wmspeed.cc:270-395) */
+/* K14: SpeedSync::compare (wmspeed.cc:270-395) */
 struct SpeedItemDev { int center; double rel_speed_inv, q16_scale; };
 struct SpeedCompareArgs
 {
@@ -280,13 +281,14 @@ struct SpeedCompareArgs
   const SpeedCenterDev *centers;
   const SpeedItemDev   *items;
   const int            *col_frame;     // [510] frame of the column
+  const unsigned char  *col_first;     // [6][frames_per_block + 2]: columns of the bit with frame < f
   int                   frames_per_block, steps_per_frame, pad_start, rows_per_bit;
   double                min_delta;
   unsigned long long   *best;          // [items] bits of the best quality (zero initialised)
 };
 hipError_t launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items);
 
-/* K14 */
+/* K15 */
 constexpr int ENERGY_PARTS = 256;
 hipError_t launch_gather_values (hipStream_t st, const float *in, const unsigned long long *pos, long long n, float *out);
 hipError_t launch_energy (hipStream_t st, const float *in, const long long *range /* [n][2] value index begin, end */, int n_ranges,

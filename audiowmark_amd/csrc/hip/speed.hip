@@ -1,11 +1,11 @@
 // speed.hip -- speed detection kernels for gfx950 (reference src/wmspeed.cc, src/resample.cc:96-125)
 //
-//   K11 resample_var_kernel    zita VResampler (arbitrary ratio, 256 phases, interpolated coefficients)
-//   K12 speed_mags_kernel      SpeedSync::prepare_mags: FFT-512 hop 128 on the half-rate clip -> dB -> up / down sums per sync frame
-//   K13 speed_compare_kernel   SpeedSync::compare / compare_bits: Q16 walk of every candidate block start over the magnitude matrix
-//   K14 gather / energy        get_clip_locations sample subset, get_best_clip_location energies
+//   K12 resample_var_kernel    zita VResampler (arbitrary ratio, 256 phases, interpolated coefficients)
+//   K13 speed_mags_kernel      SpeedSync::prepare_mags: FFT-512 hop 128 on the half-rate clip -> dB -> up / down sums per sync frame
+//   K14 speed_compare_kernel   SpeedSync::compare / compare_bits: Q16 walk of every candidate block start over the magnitude matrix
+//   K15 gather / energy        get_clip_locations sample subset, get_best_clip_location energies
 //
-// Layouts are chosen for the heavy kernel (K13): the magnitude matrix of a centre speed is [column][row] float2
+// Layouts are chosen for the heavy kernel (K14): the magnitude matrix of a centre speed is [column][row] float2
 // (umag, dmag) with the rows (time steps) contiguous, and the columns in the order [sync bit][frame of that bit, ascending],
 // so that a thread (= one candidate block start) sums the frames of one sync bit in the reference's order with plain
 // registers while its neighbours read neighbouring rows (coalesced).
@@ -16,23 +16,21 @@ namespace awmk {
 
 constexpr int SPEED_NB = 81, SPEED_MIN_BAND = 20;
 constexpr int SPEED_COLS = 510;       // sync frames per block
-constexpr int SPEED_TILE = 16;        // rows per workgroup of K12
+constexpr int SPEED_TILE = 16;        // rows per workgroup of K13
 
 /* ------------------------------------------------------------------------------------------------------------------
- * K11: output m of the resampler reads the input window that starts at floor (m * step / 256) -- zita accumulates the
+ * K12: output m of the resampler reads the input window that starts at floor (m * step / 256) -- zita accumulates the
  * phase in double (ph += step with wrap), here it comes from the exact product m * step (128 bit), which differs from
  * the accumulated value only by the rounding errors zita collects on the way (< 1e-9 phases per million outputs).
  * The arithmetic per output is zita's: c1[i] = a q1[i] + b q1[i + hl], c2[i] = a q2[i] + b q2[i - hl],
  * y = (1e-25 + sum_i (x1 c1[i] + x2 c2[i])) - 1e-25 with every product and sum rounded on its own.
  * ------------------------------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__ (256)
-resample_var_kernel (VarResampleArgs a)
+// phase and window start of output m
+struct VarPhase { long long first; unsigned k; float af, bf; };
+__device__ __forceinline__ VarPhase
+var_phase (const SpeedCenterDev& cd, long long m)
 {
-  const SpeedCenterDev cd = a.centers[blockIdx.y];
-  const long long m = (long long) blockIdx.x * blockDim.x + threadIdx.x;
-  if (m >= cd.n_out)
-    return;
-  const int C = a.n_channels, hl = cd.hl, np = 256;
+  const int np = 256;
   const unsigned long long lo = (unsigned long long) m * cd.mant, hi = __umul64hi ((unsigned long long) m, cd.mant);
   long long b = (long long) ((hi << (64 - cd.shift)) | (lo >> cd.shift));
   const unsigned long long frac = lo & ((1ull << cd.shift) - 1);
@@ -42,37 +40,102 @@ resample_var_kernel (VarResampleArgs a)
       ph = 0;
       b++;
     }
-  const unsigned k = unsigned (ph);
-  const float bf = float (ph - k);
-  const float af = __fsub_rn (1.0f, bf);
-  const float *q1 = cd.ctab + (long long) hl * k;
-  const float *q2 = cd.ctab + (long long) hl * (np - k);
-  const long long first = b - (hl - 1);                       // input frame of the first tap
-  const float *in = a.in;
-  float *out = a.out + blockIdx.y * a.out_stride + m * C;
-  for (int c0 = 0; c0 < C; c0 += 2)
+  VarPhase v;
+  v.k = unsigned (ph);
+  v.bf = float (ph - v.k);
+  v.af = __fsub_rn (1.0f, v.bf);
+  v.first = b - (cd.hl - 1);                                   // input frame of the first tap
+  return v;
+}
+
+// one output frame, all channels; tab = coefficient rows with `stride` floats each (global or LDS)
+template<int CT> __device__ __forceinline__ void
+var_output (const SpeedCenterDev& cd, const float *tab, int stride, const float *in, int n_channels, long long m, float *out)
+{
+  const int C = CT ? CT : n_channels, hl = cd.hl, np = 256;
+  const VarPhase v = var_phase (cd, m);
+  const float *q1 = tab + stride * v.k, *q1n = q1 + stride;                 // rows k, k + 1         (zita: q1[i], q1[i + hl])
+  const float *q2 = tab + stride * (np - v.k), *q2p = q2 - stride;          // rows np - k, np - k - 1 (q2[i], q2[i - hl])
+  if (CT == 2)
     {
-      const bool two = c0 + 1 < C;
+      const float2 *in2 = reinterpret_cast<const float2 *> (in);
       float s0 = 1e-25f, s1 = 1e-25f;
+      if (__all (v.first >= 0 && v.first + 2 * hl <= cd.n_in))    // the whole wave is away from the ends: no bounds checks
+        {
+          const float2 *p1 = in2 + v.first, *p2 = in2 + v.first + 2 * hl - 1;
+          for (int i = 0; i < hl; i++)
+            {
+              const float c1 = __fadd_rn (__fmul_rn (v.af, q1[i]), __fmul_rn (v.bf, q1n[i]));
+              const float c2 = __fadd_rn (__fmul_rn (v.af, q2[i]), __fmul_rn (v.bf, q2p[i]));
+              const float2 x1 = p1[i], x2 = p2[-i];
+              s0 = __fadd_rn (s0, __fadd_rn (__fmul_rn (x1.x, c1), __fmul_rn (x2.x, c2)));
+              s1 = __fadd_rn (s1, __fadd_rn (__fmul_rn (x1.y, c1), __fmul_rn (x2.y, c2)));
+            }
+          reinterpret_cast<float2 *> (out)[m] = make_float2 (__fsub_rn (s0, 1e-25f), __fsub_rn (s1, 1e-25f));
+          return;
+        }
       for (int i = 0; i < hl; i++)
         {
-          const float c1 = __fadd_rn (__fmul_rn (af, q1[i]), __fmul_rn (bf, q1[i + hl]));
-          const float c2 = __fadd_rn (__fmul_rn (af, q2[i]), __fmul_rn (bf, q2[i - hl]));
-          const long long j1 = first + i, j2 = first + 2 * hl - 1 - i;
-          const bool ok1 = j1 >= 0 && j1 < cd.n_in, ok2 = j2 >= 0 && j2 < cd.n_in;
-          const float x1 = ok1 ? in[j1 * C + c0] : 0.f;
-          const float x2 = ok2 ? in[j2 * C + c0] : 0.f;
-          s0 = __fadd_rn (s0, __fadd_rn (__fmul_rn (x1, c1), __fmul_rn (x2, c2)));
-          if (two)
-            {
-              const float y1 = ok1 ? in[j1 * C + c0 + 1] : 0.f;
-              const float y2 = ok2 ? in[j2 * C + c0 + 1] : 0.f;
-              s1 = __fadd_rn (s1, __fadd_rn (__fmul_rn (y1, c1), __fmul_rn (y2, c2)));
-            }
+          const float c1 = __fadd_rn (__fmul_rn (v.af, q1[i]), __fmul_rn (v.bf, q1n[i]));
+          const float c2 = __fadd_rn (__fmul_rn (v.af, q2[i]), __fmul_rn (v.bf, q2p[i]));
+          const long long j1 = v.first + i, j2 = v.first + 2 * hl - 1 - i;
+          const float2 x1 = (j1 >= 0 && j1 < cd.n_in) ? in2[j1] : make_float2 (0.f, 0.f);
+          const float2 x2 = (j2 >= 0 && j2 < cd.n_in) ? in2[j2] : make_float2 (0.f, 0.f);
+          s0 = __fadd_rn (s0, __fadd_rn (__fmul_rn (x1.x, c1), __fmul_rn (x2.x, c2)));
+          s1 = __fadd_rn (s1, __fadd_rn (__fmul_rn (x1.y, c1), __fmul_rn (x2.y, c2)));
         }
-      out[c0] = __fsub_rn (s0, 1e-25f);
-      if (two)
-        out[c0 + 1] = __fsub_rn (s1, 1e-25f);
+      reinterpret_cast<float2 *> (out)[m] = make_float2 (__fsub_rn (s0, 1e-25f), __fsub_rn (s1, 1e-25f));
+      return;
+    }
+  for (int c = 0; c < C; c++)
+    {
+      float sum = 1e-25f;
+      for (int i = 0; i < hl; i++)
+        {
+          const float c1 = __fadd_rn (__fmul_rn (v.af, q1[i]), __fmul_rn (v.bf, q1n[i]));
+          const float c2 = __fadd_rn (__fmul_rn (v.af, q2[i]), __fmul_rn (v.bf, q2p[i]));
+          const long long j1 = v.first + i, j2 = v.first + 2 * hl - 1 - i;
+          const float x1 = (j1 >= 0 && j1 < cd.n_in) ? in[j1 * C + c] : 0.f;
+          const float x2 = (j2 >= 0 && j2 < cd.n_in) ? in[j2 * C + c] : 0.f;
+          sum = __fadd_rn (sum, __fadd_rn (__fmul_rn (x1, c1), __fmul_rn (x2, c2)));
+        }
+      out[m * C + c] = __fsub_rn (sum, 1e-25f);
+    }
+}
+
+constexpr int RV_TILE = 1024;             // outputs per workgroup
+constexpr int RV_MAX_TAB = 12288;         // floats of LDS for the coefficient table (48 KiB): 257 rows of up to 47 floats
+
+/* Neighbouring outputs have unrelated phases, i.e. every lane reads its own four coefficient rows: from global memory that
+ * is 64 different cache lines per load instruction (the first version of this kernel spent 58 % of the whole speed search
+ * there).  The table (257 rows, row stride odd so that equal columns of different rows fall into different banks) is
+ * therefore staged in LDS once per workgroup of 1024 outputs. */
+template<int CT> __global__ void __launch_bounds__ (256)
+resample_var_kernel (VarResampleArgs a)
+{
+  __shared__ float s_tab[RV_MAX_TAB];
+  const SpeedCenterDev cd = a.centers[blockIdx.y];
+  const long long tile0 = (long long) blockIdx.x * RV_TILE;
+  if (tile0 >= cd.n_out)
+    return;
+  const int stride = cd.stride, n_tab = 257 * stride;
+  const bool in_lds = n_tab <= RV_MAX_TAB;
+  if (in_lds)
+    {
+      for (int i = threadIdx.x; i < n_tab; i += blockDim.x)
+        s_tab[i] = cd.ctab[i];
+      __syncthreads();
+    }
+  float *out = a.out + blockIdx.y * a.out_stride;
+  for (int q = 0; q < RV_TILE / 256; q++)
+    {
+      const long long m = tile0 + q * 256 + threadIdx.x;
+      if (m >= cd.n_out)
+        break;
+      if (in_lds)                                                // two copies of the loop: ds_read vs global_load addressing
+        var_output<CT> (cd, s_tab, stride, a.in, a.n_channels, m, out);
+      else
+        var_output<CT> (cd, cd.ctab, stride, a.in, a.n_channels, m, out);
     }
 }
 
@@ -81,12 +144,17 @@ launch_resample_var (hipStream_t st, const VarResampleArgs& a, long long max_n_o
 {
   if (max_n_out <= 0 || n_centers <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL (resample_var_kernel, dim3 (unsigned ((max_n_out + 255) / 256), unsigned (n_centers)), dim3 (256), 0, st, a);
+  const dim3 grid (unsigned ((max_n_out + RV_TILE - 1) / RV_TILE), unsigned (n_centers));
+  const bool aligned = (reinterpret_cast<uintptr_t> (a.in) & 7) == 0 && (reinterpret_cast<uintptr_t> (a.out) & 7) == 0 && (a.out_stride & 1) == 0;
+  if (a.n_channels == 2 && aligned)
+    hipLaunchKernelGGL (resample_var_kernel<2>, grid, dim3 (256), 0, st, a);
+  else
+    hipLaunchKernelGGL (resample_var_kernel<0>, grid, dim3 (256), 0, st, a);
   return hipGetLastError();
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
- * K12: one workgroup = 16 consecutive rows (hop 128 at half rate) of one centre speed.
+ * K13: one workgroup = 16 consecutive rows (hop 128 at half rate) of one centre speed.
  *   phase 1: a wave transforms a row: the 512 windowed samples of TWO channels ride in the real and imaginary part of one
  *            complex FFT-512 (X_a[k] = (Z[k] + conj Z[512-k]) / 2, X_b[k] = (Z[k] - conj Z[512-k]) / 2i), dB of the 81 bands
  *            summed over the channels in channel order (wmspeed.cc:232-246).  A channel whose frame is digital silence is
@@ -205,7 +273,7 @@ launch_speed_mags (hipStream_t st, const DevTables& t, const SpeedMagsArgs& a, i
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
- * K13: blockIdx.y = one (centre, relative speed) pair, thread = one candidate block start ("state", offset -pad_start .. -1
+ * K14: blockIdx.y = one (centre, relative speed) pair, thread = one candidate block start ("state", offset -pad_start .. -1
  * in steps of sync_search_step, scaled to Q16 by 1 / relative speed; wmspeed.cc:330-344).  A state visits the sync frames of
  * three consecutive blocks (compare_bits<0..2>, :270-328): row = (offset + frame_offset) >> 16, used when the sum is not
  * negative and the row exists -- the reference's begin / end iterators are exactly this test because the frame offsets grow
@@ -232,22 +300,42 @@ speed_compare_kernel (SpeedCompareArgs a)
   __syncthreads();
   const int state = blockIdx.x * blockDim.x + threadIdx.x;
   double q = 0;
-  if (state < a.pad_start)
+  // Offsets grow with the state, frame offsets with the frame: the frames any lane of this wave can use form one interval
+  // of "global" frames (block * frames_per_block + frame).  Bounds with a frame of margin on both sides, the exact test
+  // stays per lane; col_first[bit][f] = number of columns of the bit with frame < f turns them into column ranges.
+  const int wave_state = blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+  const auto offset_of = [&] (int st) {
+    st = st < a.pad_start ? st : a.pad_start - 1;
+    const double scaled = (st - a.pad_start) * it.q16_scale;
+    return (long long) (int) scaled;
+  };
+  const long long rows = cd.rows;
+  const long long o_min = offset_of (wave_state), o_max = offset_of (wave_state + 63), limit = rows << 16;
+  const double steps_per_g = a.steps_per_frame * it.rel_speed_inv;
+  const int g_lo = int (floor ((double (-o_max) / 65536.0 - 0.5) / steps_per_g)) - 1;
+  const int g_hi = int (ceil ((double (limit - o_min) / 65536.0 - 0.5) / steps_per_g)) + 1;
+  if (state < a.pad_start && rows > 0)
     {
       const double scaled = (state - a.pad_start) * it.q16_scale;
       const long long offset = (int) scaled;
       const float2 *mags = a.mags + it.center * a.mags_center_stride;
-      const long long rows = cd.rows;
       int total = 0;
       for (int bit = 0; bit < 6; bit++)
         {
           float u = 0.f, d = 0.f;
           int n = 0;
+          const unsigned char *first = a.col_first + bit * (a.frames_per_block + 2);
           for (int block = 0; block < 3; block++)
             {
+              int f_lo = g_lo - block * a.frames_per_block, f_hi = g_hi - block * a.frames_per_block;
+              f_lo = f_lo < 0 ? 0 : f_lo;
+              f_hi = f_hi > a.frames_per_block - 1 ? a.frames_per_block - 1 : f_hi;
+              if (f_lo > f_hi)
+                continue;
+              const int j_lo = __builtin_amdgcn_readfirstlane (first[f_lo]), j_hi = __builtin_amdgcn_readfirstlane (first[f_hi + 1]);
               const long long *fo = s_fo + block * SPEED_COLS + bit * a.rows_per_bit;
               const float2 *mc = mags + (long long) bit * a.rows_per_bit * a.ld;
-              for (int j = 0; j < a.rows_per_bit; j++)
+              for (int j = j_lo; j < j_hi; j++)
                 {
                   const long long sum = offset + fo[j];
                   const long long idx = sum >> 16;
@@ -312,7 +400,7 @@ launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items)
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
- * K14: get_clip_locations hashes a pseudo random subset of the samples (wmspeed.cc:533-553): the positions come from the
+ * K15: get_clip_locations hashes a pseudo random subset of the samples (wmspeed.cc:533-553): the positions come from the
  * host's AES-CTR generator, the device only gathers.  get_best_clip_location (:555-577) compares the energies of the
  * candidate clips: float squares summed in double (the reference adds them one by one, here in a tree: the energies
  * agree to ~1e-15 relative, which only matters for clips of equal energy).

@@ -2,6 +2,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <sys/time.h>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define AWM_X86_CRYPTO 1
+#endif
 
 namespace awm {
 
@@ -114,6 +118,51 @@ get_time()
   return tv.tv_sec + tv.tv_usec / 1e6;
 }
 
+#ifdef AWM_X86_CRYPTO
+// SHA-1 compression of `blocks` 64 byte blocks on the CPU's SHA unit (four rounds per SHA1RNDS4; the message schedule runs
+// through SHA1MSG1 / SHA1MSG2, the round constant group is the instruction's immediate)
+__attribute__ ((target ("sha,sse4.1,ssse3"))) static void
+sha1_blocks_shani (uint32_t state[5], const unsigned char *data, size_t blocks)
+{
+  const __m128i be = _mm_set_epi64x (0x0001020304050607ll, 0x08090a0b0c0d0e0fll);   // big endian words, word 0 in the top lane
+  __m128i abcd = _mm_shuffle_epi32 (_mm_loadu_si128 (reinterpret_cast<const __m128i *> (state)), 0x1b);
+  __m128i e0 = _mm_set_epi32 (int (state[4]), 0, 0, 0);
+  for (; blocks; blocks--, data += 64)
+    {
+      const __m128i abcd_in = abcd, e_in = e0;
+      __m128i m[4], e1;
+      for (int i = 0; i < 4; i++)
+        m[i] = _mm_shuffle_epi8 (_mm_loadu_si128 (reinterpret_cast<const __m128i *> (data + 16 * i)), be);
+      // 20 groups of four rounds; group g uses W[4g .. 4g + 3] = m[g & 3] (extended in place from group 4 on)
+#define AWM_SHA1_GROUP(g, fn)                                                                   \
+      {                                                                                         \
+        if (g >= 4)                                                                             \
+          {                                                                                     \
+            __m128i w = _mm_sha1msg1_epu32 (m[g & 3], m[(g + 1) & 3]);                           \
+            w = _mm_xor_si128 (w, m[(g + 2) & 3]);                                              \
+            m[g & 3] = _mm_sha1msg2_epu32 (w, m[(g + 3) & 3]);                                   \
+          }                                                                                     \
+        if (g == 0)                                                                             \
+          e1 = _mm_add_epi32 (e0, m[0]);                                                        \
+        else                                                                                    \
+          e1 = _mm_sha1nexte_epu32 (e0, m[g & 3]);                                              \
+        e0 = abcd;                                                                              \
+        abcd = _mm_sha1rnds4_epu32 (abcd, e1, fn);                                              \
+      }
+      AWM_SHA1_GROUP (0, 0) AWM_SHA1_GROUP (1, 0) AWM_SHA1_GROUP (2, 0) AWM_SHA1_GROUP (3, 0) AWM_SHA1_GROUP (4, 0)
+      AWM_SHA1_GROUP (5, 1) AWM_SHA1_GROUP (6, 1) AWM_SHA1_GROUP (7, 1) AWM_SHA1_GROUP (8, 1) AWM_SHA1_GROUP (9, 1)
+      AWM_SHA1_GROUP (10, 2) AWM_SHA1_GROUP (11, 2) AWM_SHA1_GROUP (12, 2) AWM_SHA1_GROUP (13, 2) AWM_SHA1_GROUP (14, 2)
+      AWM_SHA1_GROUP (15, 3) AWM_SHA1_GROUP (16, 3) AWM_SHA1_GROUP (17, 3) AWM_SHA1_GROUP (18, 3) AWM_SHA1_GROUP (19, 3)
+#undef AWM_SHA1_GROUP
+      e0 = _mm_sha1nexte_epu32 (e0, e_in);
+      abcd = _mm_add_epi32 (abcd, abcd_in);
+    }
+  _mm_storeu_si128 (reinterpret_cast<__m128i *> (state), _mm_shuffle_epi32 (abcd, 0x1b));
+  state[4] = uint32_t (_mm_extract_epi32 (e0, 3));
+}
+static const bool have_shani = [] { __builtin_cpu_init(); return bool (__builtin_cpu_supports ("sha")) && bool (__builtin_cpu_supports ("sse4.1")); }();
+#endif
+
 void
 sha1 (const void *data, size_t len, unsigned char digest[20])
 {
@@ -148,6 +197,14 @@ sha1 (const void *data, size_t len, unsigned char digest[20])
     };
   const unsigned char *bytes = static_cast<const unsigned char *> (data);
   size_t rest = len;
+#ifdef AWM_X86_CRYPTO
+  if (have_shani && rest >= 64)
+    {
+      sha1_blocks_shani (state, bytes, rest / 64);
+      bytes += rest / 64 * 64;
+      rest %= 64;
+    }
+#endif
   while (rest >= 64)
     {
       compress (bytes);

@@ -18,6 +18,7 @@ SpeedWorkspace::release()
     {
       t->cols.release();
       t->col_frame.release();
+      t->col_first.release();
     }
   for (DevBuffer *b : { &window512, &sub, &mags, &centers, &items, &best, &gather_pos, &gather_out, &ranges, &energy, &stretched })
     b->release();
@@ -105,7 +106,14 @@ get_var_tables (awm_ctx *ctx, const std::vector<double>& ratios, std::vector<Var
   for (size_t t = 0; t < n_threads; t++)
     threads.emplace_back ([&, t] {
       for (size_t k = t; k < missing.size(); k += n_threads)
-        tabs[k] = zita_table (geo[k].frel, geo[k].hl, 256);
+        {
+          // rows padded to an odd stride (the kernel keeps the table in LDS: equal columns of different rows -> different banks)
+          const std::vector<float> dense = zita_table (geo[k].frel, geo[k].hl, 256);
+          const size_t hl = geo[k].hl, stride = hl | 1;
+          tabs[k].assign (257 * stride, 0.f);
+          for (size_t r = 0; r < 257; r++)
+            std::copy (dense.begin() + r * hl, dense.begin() + (r + 1) * hl, tabs[k].begin() + r * stride);
+        }
     });
   for (auto& th : threads)
     th.join();
@@ -142,6 +150,7 @@ center_dev (const VarResampleTable *vt, double ratio, long long n_in, long long 
   const double f = std::frexp (step, &e);                  // step = f * 2^e, 0.5 <= f < 1
   cd.ctab = vt->ctab.as<float>();
   cd.hl = vt->hl;
+  cd.stride = vt->hl | 1;
   cd.mant = (unsigned long long) std::ldexp (f, 53);       // step = mant * 2^(e - 53)
   cd.shift = 61 - e;                                       // m * step / 256 = (m * mant) >> shift
   cd.frac_scale = std::ldexp (1.0, e - 53);
@@ -176,8 +185,20 @@ get_speed_key_tables (awm_ctx *ctx, const Key& key)
         }
       col_frame[col] = st.frame[col];
     }
+  const int fpb = int (mark_block_frame_count());
+  std::vector<unsigned char> col_first (size_t (6) * (fpb + 2), 0);
+  for (int bit = 0; bit < 6; bit++)
+    for (int f = 0; f < fpb + 2; f++)
+      {
+        int count = 0;
+        for (int r = 0; r < R; r++)
+          count += st.frame[size_t (bit) * R + r] < f;
+        col_first[size_t (bit) * (fpb + 2) + f] = (unsigned char) count;
+      }
   auto t = std::make_unique<SpeedKeyTables>();
   t->key = kb;
+  if (upload_sync (t->col_first, col_first.data(), col_first.size(), ctx->stream))
+    return nullptr;
   if (upload_sync (t->cols, cols.data(), cols.size() * sizeof (unsigned int), ctx->stream))
     return nullptr;
   if (upload_sync (t->col_frame, col_frame.data(), col_frame.size() * sizeof (int), ctx->stream))
@@ -463,6 +484,7 @@ speed_scan (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_loca
   ca.centers = ws->centers.as<awmk::SpeedCenterDev>();
   ca.items = ws->items.as<awmk::SpeedItemDev>();
   ca.col_frame = skt->col_frame.as<int>();
+  ca.col_first = skt->col_first.as<unsigned char>();
   ca.frames_per_block = frames_per_block;
   ca.steps_per_frame = steps_per_frame;
   ca.pad_start = frames_per_block * steps_per_frame + steps_per_frame;      // "a bit of overlap to handle boundaries"

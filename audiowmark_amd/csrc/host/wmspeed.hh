@@ -47,6 +47,7 @@ struct SpeedKeyTables
   std::vector<unsigned char> key;
   DevBuffer cols;           // [510][16] words: 30 up + 30 down band indices
   DevBuffer col_frame;      // [510] int
+  DevBuffer col_first;      // [6][block frames + 2] uint8: columns of the bit with frame < f
 };
 
 struct SpeedWorkspace

@@ -23,6 +23,12 @@ for patient in (False, True):
     for i in range(5):
         t = time.perf_counter(); r = ctx.detect_speed(key, zd, patient); ts.append(time.perf_counter() - t)
     print("detect_speed patient=%d: %s  min %.2f ms  median %.2f ms  (%.0f s stereo)" % (patient, r, min(ts) * 1e3, sorted(ts)[2] * 1e3, seconds))
+r = ctx.resample_ratio(zd, 0.9764); torch.cuda.synchronize()
+t = time.perf_counter(); r = ctx.resample_ratio(zd, 0.9764); torch.cuda.synchronize()
+print("resample_ratio of the whole input: %.2f ms" % ((time.perf_counter() - t) * 1e3))
+t = time.perf_counter(); loc = ctx.speed_clip_location(key, zd, 25.0)
+print("clip location: %.2f ms" % ((time.perf_counter() - t) * 1e3))
+del r
 awm.set_speed_params(detect_speed=True)
 ctx.get_watermark(key, zd)
 ts = []
