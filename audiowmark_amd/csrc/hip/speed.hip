@@ -16,7 +16,7 @@ namespace awmk {
 
 constexpr int SPEED_NB = 81, SPEED_MIN_BAND = 20;
 constexpr int SPEED_COLS = 510;       // sync frames per block
-constexpr int SPEED_TILE = 16;        // rows per workgroup of K13
+constexpr int SPEED_TILE = 64;        // rows per workgroup of K13
 
 /* ------------------------------------------------------------------------------------------------------------------
  * K12: output m of the resampler reads the input window that starts at floor (m * step / 256) -- zita accumulates the
@@ -154,23 +154,27 @@ launch_resample_var (hipStream_t st, const VarResampleArgs& a, long long max_n_o
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
- * K13: one workgroup = 16 consecutive rows (hop 128 at half rate) of one centre speed.
+ * K13: one workgroup = 64 consecutive rows (hop 128 at half rate) of one centre speed.
  *   phase 1: a wave transforms a row: the 512 windowed samples of TWO channels ride in the real and imaginary part of one
  *            complex FFT-512 (X_a[k] = (Z[k] + conj Z[512-k]) / 2, X_b[k] = (Z[k] - conj Z[512-k]) / 2i), dB of the 81 bands
  *            summed over the channels in channel order (wmspeed.cc:232-246).  A channel whose frame is digital silence is
  *            not read out of the shared transform (the other channel's rounding noise would stand where the reference has
  *            exact zeros = -96 dB): it contributes -96 dB per band directly.
- *   phase 2: umag / dmag of the 510 sync frames (wmspeed.cc:247-257): thread = (column, row) with the row fastest, so
- *            that the 16 rows of a column leave as one 128 byte store.
+ *   phase 2: umag / dmag of the 510 sync frames (wmspeed.cc:247-257): a wave takes a column, its lanes are the 64 rows.
+ *            The band list of the column is wave-uniform (scalar loads, scalar byte extraction); the dB tile has a row
+ *            stride of 81 words, so the 64 lanes read 64 different banks, and a column's rows leave as one 512 byte store.
+ *            (First version: thread = (column, row) over 16 rows with the band bytes in LDS: 1.45 ms per pass, bank
+ *            conflicts and per-lane byte extraction; this one: see DESIGN.md.)
  * ------------------------------------------------------------------------------------------------------------------ */
+typedef const unsigned int __attribute__ ((address_space (4))) *const_uint_ptr;
+
 __global__ void __launch_bounds__ (256)
 speed_mags_kernel (DevTables t, SpeedMagsArgs a)
 {
   __shared__ float2 s_tw[512];
   __shared__ float  s_win[512];
   __shared__ float2 s_x[4][XBUF_ELEMS];
-  __shared__ float  s_db[SPEED_TILE][SPEED_NB];
-  __shared__ unsigned int s_cols[SPEED_COLS * 16];           // 64 bytes per column: 30 up, 30 down band indices, 4 unused
+  __shared__ float  s_db[SPEED_TILE * SPEED_NB];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const SpeedCenterDev cd = a.centers[blockIdx.y];
   const int row0 = blockIdx.x * SPEED_TILE;
@@ -181,8 +185,6 @@ speed_mags_kernel (DevTables t, SpeedMagsArgs a)
       s_tw[i] = t.tw512[i];
       s_win[i] = a.window512[i];
     }
-  for (int i = threadIdx.x; i < SPEED_COLS * 16; i += blockDim.x)
-    s_cols[i] = a.cols[i];
   __syncthreads();
 
   const int C = a.n_channels;
@@ -238,20 +240,22 @@ speed_mags_kernel (DevTables t, SpeedMagsArgs a)
             }
           wave_sync();
         }
-      s_db[r][lane] = acc0;
+      s_db[r * SPEED_NB + lane] = acc0;
       if (lane < SPEED_NB - 64)
-        s_db[r][64 + lane] = acc1;
+        s_db[r * SPEED_NB + 64 + lane] = acc1;
     }
   __syncthreads();
 
   float2 *mags = a.mags + blockIdx.y * a.mags_center_stride;
-  for (int item = threadIdx.x; item < SPEED_COLS * SPEED_TILE; item += blockDim.x)
+  const float *db = s_db + lane * SPEED_NB;                    // this lane's row of the tile
+  const bool store = row0 + lane < cd.rows;
+  const_uint_ptr cols = (const_uint_ptr) a.cols;
+  for (int col = __builtin_amdgcn_readfirstlane (wave); col < SPEED_COLS; col += 4)
     {
-      const int r = item & (SPEED_TILE - 1), col = item >> 4;
-      if (row0 + r >= cd.rows)
-        continue;
-      const unsigned int *cw = s_cols + col * 16;
-      const float *db = s_db[r];
+      unsigned int cw[15];
+#pragma unroll
+      for (int i = 0; i < 15; i++)
+        cw[i] = cols[col * 16 + i];
       float u = 0.f, d = 0.f;
 #pragma unroll
       for (int i = 0; i < 30; i++)
@@ -259,7 +263,8 @@ speed_mags_kernel (DevTables t, SpeedMagsArgs a)
 #pragma unroll
       for (int i = 30; i < 60; i++)
         d = __fadd_rn (d, db[(cw[i >> 2] >> (8 * (i & 3))) & 0xff]);
-      mags[(long long) col * a.ld + row0 + r] = make_float2 (u, d);
+      if (store)
+        mags[(long long) col * a.ld + row0 + lane] = make_float2 (u, d);
     }
 }
 

@@ -218,17 +218,53 @@ add_full (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, in
   return 0;
 }
 
-/* frames the streaming resampler delivers for n_in input frames when it is fed "hl - 1 null frames, the input, hl null
- * frames" (WavChunkLoader at EOF, wavchunkloader.cc:200-216): every m with floor (m s / np) <= n_in - 1 */
-static size_t
-resample_frames (const ResampleTable& t, size_t n_in)
+/* ResamplerImpl::create (reference resample.cc:233-270): zita's fixed-ratio Resampler if it takes the two rates, else
+ * its VResampler with ratio new / old.  Both run as closed forms of the streaming classes (K10 / K12). */
+struct RateConverter
 {
-  return size_t ((static_cast<unsigned __int128> (n_in) * unsigned (t.np) + unsigned (t.step) - 1) / unsigned (t.step));
+  const ResampleTable *fixed = nullptr;
+  VarResampleGeometry  var;
+  double               ratio = 0;
+  bool ok() const { return fixed || var.ok; }
+  int  hl() const { return fixed ? fixed->hl : var.hl; }
+  // input frame (of the stream without the leading null frames) where the window of output m starts + hl - 1
+  size_t window_start (size_t m) const
+  {
+    return fixed ? size_t ((static_cast<unsigned __int128> (m) * unsigned (fixed->step)) / unsigned (fixed->np)) : var.window_start (m);
+  }
+  /* frames the streaming resampler delivers for n_in input frames when it is fed "hl - 1 null frames, the input, hl null
+   * frames" (WavChunkLoader at EOF, wavchunkloader.cc:200-216): every m with window_start (m) <= n_in - 1 */
+  size_t stream_frames (size_t n_in) const
+  {
+    if (fixed)
+      return size_t ((static_cast<unsigned __int128> (n_in) * unsigned (fixed->np) + unsigned (fixed->step) - 1) / unsigned (fixed->step));
+    return var.stream_frames (n_in);
+  }
+};
+
+static RateConverter
+rate_converter (awm_ctx *ctx, int rate_in, int rate_out)
+{
+  RateConverter rc;
+  if (rate_in <= 0 || rate_out <= 0)
+    return rc;
+  rc.fixed = ctx->get_resample_table (rate_in, rate_out);
+  if (!rc.fixed)
+    {
+      rc.ratio = double (rate_out) / rate_in;
+      rc.var = var_resample_geometry (rc.ratio);
+      if (!rc.var.ok)
+        set_error (string_printf ("resampling from old_rate=%d to new_rate=%d not implemented", rate_in, rate_out));
+    }
+  return rc;
 }
 
 static int
-resample_device (awm_ctx *ctx, const ResampleTable& t, const float *in_d, size_t n_in, int n_channels, float *out_d, size_t n_out)
+resample_device (awm_ctx *ctx, const RateConverter& conv, const float *in_d, size_t n_in, int n_channels, float *out_d, size_t n_out)
 {
+  if (!conv.fixed)
+    return resample_var_device (ctx, ctx, in_d, n_in, n_channels, conv.ratio, out_d, n_out);
+  const ResampleTable& t = *conv.fixed;
   awmk::ResampleArgs ra {};
   ra.in = in_d;
   ra.n_in = (long long) n_in;
@@ -248,8 +284,8 @@ awm_resample_frames (awm_ctx *ctx, size_t n_frames, int rate_in, int rate_out)
 {
   if (check_ctx (ctx))
     return 0;
-  const ResampleTable *t = ctx->get_resample_table (rate_in, rate_out);
-  return t ? resample_frames (*t, n_frames) : 0;
+  const RateConverter conv = rate_converter (ctx, rate_in, rate_out);
+  return conv.ok() ? conv.stream_frames (n_frames) : 0;
 }
 
 int
@@ -257,15 +293,15 @@ awm_resample_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_chan
                 float *out_d, size_t n_out_frames)
 {
   if (int rc = check_ctx (ctx)) return rc;
-  const ResampleTable *t = ctx->get_resample_table (rate_in, rate_out);
-  if (!t)
+  const RateConverter conv = rate_converter (ctx, rate_in, rate_out);
+  if (!conv.ok())
     return AWM_ERR_ARG;
   if ((n_frames && !pcm_in_d) || (n_out_frames && !out_d) || n_channels < 1)
     {
       set_error ("awm_resample_d: bad argument");
       return AWM_ERR_ARG;
     }
-  return resample_device (ctx, *t, pcm_in_d, n_frames, n_channels, out_d, n_out_frames);
+  return resample_device (ctx, conv, pcm_in_d, n_frames, n_channels, out_d, n_out_frames);
 }
 
 /* add_stream_watermark for a stream at another rate (WatermarkResampler, reference wmadd.cc:353-430 + 520-589): the
@@ -276,21 +312,21 @@ static int
 add_full_rate (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int C, const int8_t *frame_mod_dev,
                double water_delta, int use_limiter, int rate)
 {
-  const ResampleTable *down = ctx->get_resample_table (rate, Params::mark_sample_rate);
-  const ResampleTable *up = ctx->get_resample_table (Params::mark_sample_rate, rate);
-  if (!down || !up)
+  const RateConverter down = rate_converter (ctx, rate, Params::mark_sample_rate);
+  const RateConverter up = rate_converter (ctx, Params::mark_sample_rate, rate);
+  if (!down.ok() || !up.ok())
     return AWM_ERR_ARG;
   if (!n_frames)
     return 0;
   // watermark frames (44.1 kHz) the last output sample can reach: window of output n ends at floor (n s / np) + hl (input index)
-  const size_t last44 = size_t ((static_cast<unsigned __int128> (n_frames - 1) * unsigned (up->step)) / unsigned (up->np)) + size_t (up->hl) + 1;
+  const size_t last44 = up.window_start (n_frames - 1) + size_t (up.hl()) + 1;
   const size_t F = last44 / Params::frame_size + 1;              // watermark frames 0 .. F - 1 are needed
   const size_t n44 = (F + 1) * Params::frame_size;               // frame F's delta completes frame F - 1
   if (int rc = ctx->ws_rate_a.reserve (n44 * C * sizeof (float))) return rc;
   if (int rc = ctx->ws_rate_b.reserve (n44 * C * sizeof (float))) return rc;
   if (int rc = ctx->ws_rate_c.reserve (n_frames * C * sizeof (float))) return rc;
   float *x44 = ctx->ws_rate_a.as<float>(), *wm44 = ctx->ws_rate_b.as<float>(), *wm = ctx->ws_rate_c.as<float>();
-  if (int rc = resample_device (ctx, *down, pcm_in_d, n_frames, C, x44, n44)) return rc;
+  if (int rc = resample_device (ctx, down, pcm_in_d, n_frames, C, x44, n44)) return rc;
   {
     awmk::AddMixArgs a {};
     a.pcm_in = x44;
@@ -307,7 +343,7 @@ add_full_rate (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frame
     AWM_HIP_CHECK (awmk::launch_add_mix (ctx->stream, ctx->tabs, a));
   }
   // only frames 0 .. F - 1 of wm44 are complete; nothing later is read (n_in = F * 1024 makes the rest zero, unreachable anyway)
-  if (int rc = resample_device (ctx, *up, wm44, F * Params::frame_size, C, wm, n_frames)) return rc;
+  if (int rc = resample_device (ctx, up, wm44, F * Params::frame_size, C, wm, n_frames)) return rc;
   const int lim_block = int (size_t (rate) * size_t (Params::limiter_block_size_ms) / 1000);
   const size_t n_blocks = n_frames / lim_block + 2;
   unsigned int *block_max = nullptr;

@@ -318,38 +318,67 @@ speed_stretch_buffer (awm_ctx *ctx)
   return workspace (ctx)->stretched;
 }
 
+VarResampleGeometry
+var_resample_geometry (double ratio)
+{
+  VarResampleGeometry g;
+  const VarGeometry vg = var_geometry (ratio);
+  if (!vg.ok)
+    return g;
+  int e = 0;
+  const double f = std::frexp (vg.step, &e);
+  g.ok = true;
+  g.hl = int (vg.hl);
+  g.mant = (unsigned long long) std::ldexp (f, 53);
+  g.shift = 61 - e;
+  return g;
+}
+
 int
-resample_ratio_device (awm_ctx *ctx, WorkLane *lane, const DeviceWav& wav, double ratio, double max_in_seconds, DevBuffer& out,
-                       size_t *n_out_frames)
+resample_var_device (awm_ctx *ctx, WorkLane *lane, const float *in_d, size_t n_in, int n_channels, double ratio, float *out_d, size_t n_out)
 {
   std::lock_guard<std::mutex> lock (ctx->speed_mutex);
   SpeedWorkspace *ws = workspace (ctx);
-  const int C = wav.n_channels;
-  size_t in_frames = wav.n_frames;
-  if (max_in_seconds > 0)
-    in_frames = std::min<size_t> (in_frames * C, C * lrint (wav.sample_rate * max_in_seconds)) / C;
-  const long long n_out = lrint (in_frames * ratio);
-  *n_out_frames = size_t (n_out);
   std::vector<VarResampleTable *> tables;
   if (int rc = get_var_tables (ctx, { ratio }, tables))
     return rc;
-  if (int rc = out.reserve (std::max<size_t> (size_t (n_out) * C * sizeof (float), 16)))
-    return rc;
-  const awmk::SpeedCenterDev cd = center_dev (tables[0], ratio, (long long) in_frames, n_out);
+  if (!n_out)
+    return 0;
+  const awmk::SpeedCenterDev cd = center_dev (tables[0], ratio, (long long) n_in, (long long) n_out);
   if (int rc = ws->centers.reserve (sizeof (cd)))
     return rc;
   hipStream_t st = lane->stream;
   AWM_HIP_CHECK (hipMemcpyAsync (ws->centers.ptr, &cd, sizeof (cd), hipMemcpyHostToDevice, st));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
   awmk::VarResampleArgs ra {};
-  ra.in = wav.data;
-  ra.n_channels = C;
+  ra.in = in_d;
+  ra.n_channels = n_channels;
   ra.centers = ws->centers.as<awmk::SpeedCenterDev>();
-  ra.out = out.as<float>();
+  ra.out = out_d;
   ra.out_stride = 0;
-  AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, n_out, 1));
+  AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, (long long) n_out, 1));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
   return 0;
+}
+
+int
+resample_ratio_device (awm_ctx *ctx, WorkLane *lane, const DeviceWav& wav, double ratio, double max_in_seconds, DevBuffer& out,
+                       size_t *n_out_frames)
+{
+  const int C = wav.n_channels;
+  size_t in_frames = wav.n_frames;
+  if (max_in_seconds > 0)
+    in_frames = std::min<size_t> (in_frames * C, C * lrint (wav.sample_rate * max_in_seconds)) / C;
+  if (!var_geometry (ratio).ok)
+    {
+      set_error (string_printf ("failed to setup vresampler with ratio=%f", ratio));
+      return AWM_ERR_ARG;
+    }
+  const long long n_out = lrint (in_frames * ratio);
+  *n_out_frames = size_t (n_out);
+  if (int rc = out.reserve (std::max<size_t> (size_t (n_out) * C * sizeof (float), 16)))
+    return rc;
+  return resample_var_device (ctx, lane, wav.data, in_frames, C, ratio, out.as<float>(), size_t (n_out));
 }
 
 int

@@ -60,6 +60,22 @@ struct SpeedWorkspace
   void release();
 };
 
+/* VResampler::setup (ratio, nchan, 16) as the closed form the kernel uses: output m reads the input window that starts at
+ * (m * mant) >> shift (in the stream "hl - 1 null frames, the input, null frames"), 2 hl taps */
+struct VarResampleGeometry
+{
+  bool               ok = false;
+  int                hl = 0;
+  unsigned long long mant = 0;
+  int                shift = 0;
+  size_t window_start (size_t m) const { return size_t ((static_cast<unsigned __int128> (m) * mant) >> shift); }
+  // outputs a streaming resampler delivers for n_in input frames followed by hl null frames: every m with window_start (m) <= n_in - 1
+  size_t stream_frames (size_t n_in) const { return size_t (((static_cast<unsigned __int128> (n_in) << shift) + mant - 1) / mant); }
+};
+VarResampleGeometry var_resample_geometry (double ratio);
+/* n_out output frames of the VResampler stream for n_in input frames (zero extended) */
+int resample_var_device (awm_ctx *ctx, WorkLane *lane, const float *in_d, size_t n_in, int n_channels, double ratio, float *out_d, size_t n_out);
+
 /* resample_ratio_truncate (reference resample.cc:96-119) on the device: `out` receives lrint (frames * ratio) frames
  * (frames = min (wav.n_frames, lrint (rate * max_in_seconds)) if max_in_seconds > 0) */
 int resample_ratio_device (awm_ctx *ctx, WorkLane *lane, const DeviceWav& wav, double ratio, double max_in_seconds,

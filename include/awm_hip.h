@@ -161,12 +161,13 @@ typedef struct
 int awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex,
                          const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
                          int sample_rate);
-/* Streams at another sample rate.  The reference resamples them to 44.1 kHz with zita-resampler's fixed-ratio Resampler
- * (hlen 16): `get` decodes the resampled stream (WavChunkLoader, wavchunkloader.cc:70-71,200-216), `add` generates the
+/* Streams at another sample rate.  The reference resamples them to 44.1 kHz with zita-resampler (hlen 16): the fixed-ratio
+ * Resampler where it takes the two rates, else the VResampler with ratio new / old (ResamplerImpl::create,
+ * resample.cc:233-270).  `get` decodes the resampled stream (WavChunkLoader, wavchunkloader.cc:70-71,200-216), `add` generates the
  * watermark at 44.1 kHz and resamples the watermark signal back (WatermarkResampler, wmadd.cc:353-430) -- the latter is
  * what awm_add_watermark_d does for sample_rate != 44100.  awm_resample_d is the former: out_d receives n_out_frames
  * frames of the stream the reference's loader would hand to the decoder, awm_resample_frames tells how many there are
- * (0: the ratio would need zita's VResampler, which is not restated).  zita-resampler is not part of the reference
+ * (0: neither zita class takes the ratio, i.e. it is below 1 / 16 or above 256).  zita-resampler is not part of the reference
  * tree; its algorithm is restated from the library's description, bit parity with it is unpinned. */
 size_t awm_resample_frames (awm_ctx *ctx, size_t n_frames, int rate_in, int rate_out);
 int awm_resample_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_channels, int rate_in, int rate_out,

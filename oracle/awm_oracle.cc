@@ -1673,13 +1673,11 @@ extern "C" {
  * zita-resampler restated: see zita_restated.h (PARITY UNPINNED: the library is absent here). */
 /* BufferedResamplerImpl (resample.cc:128-231) fed with the whole stream: hl - 1 null frames first ("avoid timeshift"),
  * the input, and -- if `trailing` (WavChunkLoader at EOF, wavchunkloader.cc:212-216) -- hl null frames. */
-static vector<float>
-zita_stream (const float *in, size_t n_frames, int C, int rate_in, int rate_out, bool trailing)
+extern "C++" {
+template<class R> static vector<float>
+zita_stream_run (R& rs, const float *in, size_t n_frames, int C, bool trailing)
 {
-  ZitaResampler rs;
   vector<float> out;
-  if (rs.setup (rate_in, rate_out, C, 16) != 0)
-    return out;
   vector<float> chunk (size_t (P::frame_size) * C);
   auto feed = [&] (const float *data, size_t frames) {
     size_t done = 0;
@@ -1706,6 +1704,20 @@ zita_stream (const float *in, size_t n_frames, int C, int rate_in, int rate_out,
   if (trailing)
     feed (nullptr, rs.inpsize() / 2);
   return out;
+}
+} /* extern "C++" */
+
+/* ResamplerImpl::create (resample.cc:233-270): the fixed-ratio Resampler if it accepts the rates, else VResampler */
+static vector<float>
+zita_stream (const float *in, size_t n_frames, int C, int rate_in, int rate_out, bool trailing)
+{
+  ZitaResampler rs;
+  if (rs.setup (rate_in, rate_out, C, 16) == 0)
+    return zita_stream_run (rs, in, n_frames, C, trailing);
+  ZitaVResampler vrs;
+  if (vrs.setup (double (rate_out) / rate_in, C, 16) == 0)
+    return zita_stream_run (vrs, in, n_frames, C, trailing);
+  return {};
 }
 
 /* add_stream_watermark with a WatermarkResampler (wmadd.cc:353-430, 520-589): input resampled to 44.1 kHz, watermark
@@ -1868,9 +1880,9 @@ orc_add (const uint8_t key[16], const float *samples, size_t n_frames, int n_cha
     return 1;
   if (sample_rate != P::mark_sample_rate)
     {
-      ZitaResampler probe;
-      if (probe.setup (sample_rate, P::mark_sample_rate, n_channels, 16) || probe.setup (P::mark_sample_rate, sample_rate, n_channels, 16))
-        return 1;                                      /* would need zita's VResampler */
+      ZitaVResampler probe;                            /* rates neither Resampler nor VResampler takes (ratio < 1/16 or > 256) */
+      if (probe.setup (double (P::mark_sample_rate) / sample_rate, n_channels, 16) || probe.setup (double (sample_rate) / P::mark_sample_rate, n_channels, 16))
+        return 1;
     }
   const auto r = sample_rate == P::mark_sample_rate ? add_watermark (key, samples, n_frames, n_channels, payload)
                                                     : add_watermark_rate (key, samples, n_frames, n_channels, payload, sample_rate);

@@ -119,7 +119,7 @@ def test_against_reference_binary(work):
 def test_sample_rate_scenario(tmp_path):
     """tests/sample-rate-test.sh of the reference in miniature: 48 kHz and 96 kHz material through `add` and `cmp`
     (resampling to the 44.1 kHz watermark rate and back happens inside; zita-resampler restated, parity unpinned)."""
-    for rate in (48000, 96000):
+    for rate in (48000, 96000, 33333):                 # 33333 Hz: zita's fixed-ratio Resampler refuses, VResampler takes over
         noise = tmp_path / f"noise{rate}.wav"
         noise.write_bytes(run([AWM, "test-gen-noise", "-", "140", str(rate)]).stdout)
         marked = tmp_path / f"marked{rate}.wav"
@@ -127,9 +127,9 @@ def test_sample_rate_scenario(tmp_path):
         assert os.path.getsize(noise) == os.path.getsize(marked)
         out = run([AWM, "cmp", "--input-format", "wav-pipe", str(marked), PAY]).stdout.decode()
         assert "match_count" in out and int(out.split("match_count")[1].split()[0]) >= 2
-    # a ratio the fixed-ratio resampler cannot do is refused with the reference's message
-    odd = tmp_path / "noise33333.wav"
-    odd.write_bytes(run([AWM, "test-gen-noise", "-", "10", "33333"]).stdout)
+    # a ratio neither zita class takes (< 1 / 16) is refused with the reference's message (resample.cc:262)
+    odd = tmp_path / "noise1M.wav"
+    odd.write_bytes(run([AWM, "test-gen-noise", "-", "1", "1000000"]).stdout)
     r = run([AWM, "add", "--format", "wav-pipe", str(odd), "-", PAY], check=False)
     assert r.returncode != 0 and b"not implemented" in r.stderr
 

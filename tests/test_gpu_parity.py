@@ -438,12 +438,23 @@ def test_resample_matches_restated_zita(gpu, rate_in, rate_out, ch, n):
     assert np.array_equal(got, want)                                                     # same products, same order
 
 
+@pytest.mark.parametrize("rate_in,rate_out,ch,n", [(33333, 44100, 2, 100000), (44100, 33333, 1, 70001), (44101, 44100, 2, 50000),
+                                                   (11111, 44100, 1, 20000), (33333, 44100, 2, 3)])
+def test_resample_vresampler_fallback(gpu, rate_in, rate_out, ch, n):
+    """rates zita's fixed-ratio Resampler refuses: ResamplerImpl::create falls back to VResampler (resample.cc:233-270)"""
+    x = noise(900 + n % 97, n, ch)
+    want = orc.resample(x, ch, rate_in, rate_out).reshape(-1, ch)
+    got = gpu.ctx.resample(gpu.dev(x), rate_in, rate_out).cpu().numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1e-6          # phase from the exact product vs zita's accumulated double (DESIGN.md)
+
+
 def test_resample_unsupported_ratio(gpu):
     with pytest.raises(gpu.awm.AwmError):
-        gpu.ctx.resample(gpu.dev(noise(1, 1000, 1)), 33333, 44100)                       # zita would fall back to VResampler
+        gpu.ctx.resample(gpu.dev(noise(1, 1000, 1)), 1000000, 44100)                     # ratio < 1 / 16: neither zita class takes it
 
 
-@pytest.mark.parametrize("rate,ch,limiter", [(48000, 2, True), (96000, 1, True), (32000, 2, False)])
+@pytest.mark.parametrize("rate,ch,limiter", [(48000, 2, True), (96000, 1, True), (32000, 2, False), (33333, 2, True)])
 def test_add_at_other_rates(gpu, rate, ch, limiter):
     n = 60 * rate + 123
     x = noise(800 + ch, n, ch)
