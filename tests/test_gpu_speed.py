@@ -186,3 +186,44 @@ def test_short_silent_and_one_silent_channel(gpu):
     got = gpu.ctx.speed_mags(KEY, gpu.dev(x), loc, 1.0, 25.0)
     want = orc.speed_mags(KEY, x.ravel(), 2, loc, 1.0, 25.0)
     assert got.shape == want.shape and np.abs(got - want).max() < 1e-2
+
+
+def test_config3_full_size_48k_detect_speed(gpu):
+    """BASELINE.json configs[2] at full size (60 min stereo 48 kHz, `get --detect-speed`), through size independent properties:
+    the stream is watermarked at 48 kHz, replayed 2 % fast, read back like the reference's loader does (48 -> 44.1 kHz) and
+    decoded with speed detection: every 30-minute chunk finds the replay speed on its own and the payload is recovered from
+    the stretched stream all along the file, at the original time positions."""
+    t = gpu.torch
+    rate, speed, payload = 48000, 1.02, "0123456789abcdef0011223344556677"
+    n = 60 * 60 * rate
+    g = t.Generator(device="cuda")
+    g.manual_seed(9)
+    x = t.rand((n, 2), generator=g, device="cuda", dtype=t.float32) * 2 - 1
+    w = gpu.ctx.add_watermark(KEY, payload, x, sample_rate=rate)
+    del x
+    fast = gpu.ctx.resample_ratio(w, 1 / speed, rate=rate)                  # test-change-speed
+    assert abs(fast.shape[0] - n / speed) < 1
+    del w
+    y = gpu.ctx.resample(fast, rate, 44100)                                 # WavChunkLoader
+    del fast
+    plain = gpu.ctx.get_watermark(KEY, y)
+    assert not any(p["bits"] == payload for p in plain)                     # undecodable without the speed correction
+    gpu.awm.set_speed_params(detect_speed=True)
+    try:
+        pats = gpu.ctx.get_watermark(KEY, y)
+    finally:
+        gpu.awm.set_speed_params()
+    hits = [p for p in pats if p["bits"] == payload]
+    speeds = sorted({p["speed"] for p in hits})
+    assert hits and all(p["speed"] != 1 for p in hits)
+    assert len(speeds) == len(gpu.awm.plan_chunks(y.shape[0])) == 3         # every chunk detects its own speed
+    assert all(abs(s - speed) / speed < 2e-4 for s in speeds)
+    # block positions: pattern times are seconds of the replayed file (index in the stretched stream / int (44100 * speed),
+    # wmget.cc:543,916): consecutive A / B blocks are 2226 frames of the original apart, i.e. 2226 * 1024 / 44100 / speed seconds
+    block_s = 2226 * 1024 / 44100 / speed
+    starts = np.array(sorted(p["time"] for p in hits if p["type"] == 0 and p["block_type"] < 2))
+    assert len(starts) >= 60
+    gaps = np.diff(starts)
+    steps = np.round(gaps / block_s)
+    assert np.all(steps >= 1) and np.abs(gaps - steps * block_s).max() < 0.1 and (steps == 1).sum() >= 50
+    assert len(plain) > 0 and len(pats) > len(plain)
