@@ -125,11 +125,14 @@ get_var_tables (awm_ctx *ctx, const std::vector<double>& ratios, std::vector<Var
       if (int rc = upload_sync (vt->ctab, tabs[k].data(), tabs[k].size() * sizeof (float), ctx->stream))
         return rc;
       ws->var_tables.push_back (std::move (vt));
-      // the cache only has to carry a pass: the grid of the first pass (always the same centres) plus a few refinements
-      if (ws->var_tables.size() > 512)
+      // Bounded cache.  The grids of the first pass (57 centres each for the normal and the patient search) never change
+      // and are the first entries ever made: they stay; the oldest of the data dependent refinement ratios goes.
+      // (Nothing handed out by this call is dropped: a call either finds all its ratios, or adds the missing ones last.)
+      constexpr size_t keep_first = 128, max_tables = 512;
+      if (ws->var_tables.size() > max_tables)
         {
-          ws->var_tables.front()->ctab.release();
-          ws->var_tables.erase (ws->var_tables.begin());
+          ws->var_tables[keep_first]->ctab.release();
+          ws->var_tables.erase (ws->var_tables.begin() + keep_first);
         }
     }
   for (size_t i = 0; i < ratios.size(); i++)

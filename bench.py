@@ -92,6 +92,47 @@ def pmc_traffic(prof_name):
         return None
 
 
+def detect_speed_config(torch, awm, ctx, key, payload, minutes):
+    """BASELINE.json configs[2] (reported next to the headline number, never part of `value`): `minutes` of stereo 48 kHz,
+    watermarked at 48 kHz (timed), replayed 2 % fast (untimed: that is the attacker's part), then what `get --detect-speed`
+    does with the 48 kHz file (timed): loader resampling to 44.1 kHz, speed search per 30-minute chunk, decode of the stream
+    stretched back to speed 1 and of the original stream.  Everything resident in HBM."""
+    rate, speed = 48000, 1.02
+    n = int(minutes * 60 * rate)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(4711)
+    x = torch.rand((n, 2), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
+
+    def timed(fn, reps=3):
+        best = None
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        return out, best
+
+    w, t_add = timed(lambda: ctx.add_watermark(key, payload, x, sample_rate=rate))
+    del x
+    fast = ctx.resample_ratio(w, 1 / speed, rate=rate)
+    del w
+    awm.set_speed_params(detect_speed=True)
+    try:
+        pats, t_get = timed(lambda: ctx.get_watermark(key, ctx.resample(fast, rate, 44100)))
+    finally:
+        awm.set_speed_params()
+    hits = [p for p in pats if p["bits"] == payload]
+    speeds = sorted({round(p["speed"], 6) for p in hits})
+    seconds = fast.shape[0] / rate
+    return {"workload": "%g min stereo 48 kHz: add at 48 kHz, replay at speed %.2f, get --detect-speed (loader resampling, speed "
+                        "search per chunk, decode of the stretched + the plain stream)" % (minutes, speed),
+            "value": round((n / rate + seconds) / 2 / (t_add + t_get), 1), "unit": "xRT",
+            "add_ms": round(t_add * 1e3, 3), "get_detect_speed_ms": round(t_get * 1e3, 3),
+            "payload_matches": len(hits), "detected_speeds": speeds}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,6 +141,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per GPU")
     ap.add_argument("--cpu-sample-seconds", type=float, default=200.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-detect-speed-config", action="store_true", help="skip the 48 kHz --detect-speed configuration (BASELINE configs[2])")
     ap.add_argument("--sharded", action="store_true",
                     help="debug: take the multi-GPU (ShardedStream / torch.distributed) code path even with one process")
     args = ap.parse_args()
@@ -254,6 +296,11 @@ def main():
             # algorithmic GB/s (SURVEY.md 8d bytes / HIP-event time) of every kernel, same definition as roofline.achieved
             "kernels_algorithmic_GBps": {k: round(v[3] / (v[1] * 1e-3) / 1e9, 1) for k, v in serial.items() if v[1] > 0},
         }
+        if world == 1 and not args.no_detect_speed_config:
+            try:
+                res["detect_speed_config"] = detect_speed_config(torch, awm, ctx, None, PAYLOAD, args.minutes)
+            except Exception as e:                       # reported, never fatal for the headline line
+                res["detect_speed_config"] = {"error": str(e)}
         if not args.no_cpu_baseline and world == 1:
             res["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds)
         else:
