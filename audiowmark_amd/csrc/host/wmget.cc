@@ -1158,6 +1158,8 @@ get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const Devi
  * scan for all clips of the group, approximate search for all, candidate selection + refinement for all, soft bits +
  * Viterbi for all -- the device sees up to MAX_LANES independent chains of small kernels, the host waits once per
  * stage and lane instead of ten times per clip, and no two host threads fight over the runtime. */
+constexpr int STAGED_THREADS = 2;       // host threads of the staged clip batch (AWM_STAGED_THREADS overrides); measured 1: 0.69, 2: 0.64, 4 / 8: 0.61 ms per clip
+
 static bool
 clip_is_short (const DeviceWav& w)
 {
@@ -1166,13 +1168,13 @@ clip_is_short (const DeviceWav& w)
 
 static int
 clip_batch_staged (awm_ctx *ctx, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips, const std::vector<size_t>& which,
-                   std::vector<ResultSet>& result_sets)
+                   std::vector<ResultSet>& result_sets, int lane_first = 0, int lane_count = MAX_LANES)
 {
   const size_t count = mark_block_frame_count();
   std::vector<WorkLane *> lanes;
-  for (int i = 0; i < int (std::min<size_t> (which.size(), MAX_LANES)); i++)
+  for (int i = 0; i < int (std::min<size_t> (which.size(), lane_count)); i++)
     {
-      WorkLane *l = ctx->lane (i);
+      WorkLane *l = ctx->lane (lane_first + i);
       if (!l)
         {
           set_error ("cannot create a work lane (stream)");
@@ -1323,8 +1325,46 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
           if (l)
             AWM_HIP_CHECK (hipStreamWaitEvent (l->stream, ctx->ev_sync, 0));
         }
-      if (int rc = clip_batch_staged (ctx, key_list, clips, staged, result_sets))
-        return rc;
+      // ~45 launches and copies per clip.  A second host thread staging its own share of the clips over its own share of
+      // the lanes helps a little (0.69 -> 0.64 ms per clip), more threads hardly (0.61): the limit is the rate at which one
+      // process gets dispatches and copies through the runtime (~75 000 per second), not the issuing thread
+      const char *env = getenv ("AWM_STAGED_THREADS");
+      const int want = env ? atoi (env) : STAGED_THREADS;
+      const int n_staged_threads = std::max (1, std::min<int> ({ want, MAX_LANES / 2, int ((staged.size() + 3) / 4) }));
+      if (n_staged_threads == 1)
+        {
+          if (int rc = clip_batch_staged (ctx, key_list, clips, staged, result_sets))
+            return rc;
+        }
+      else
+        {
+          for (const Key& key : key_list)
+            if (!ctx->get_key_tables (key))               // built once, before the workers start
+              return AWM_ERR_HIP;
+          const int lanes_per_thread = MAX_LANES / n_staged_threads;
+          for (int i = 0; i < lanes_per_thread * n_staged_threads; i++)
+            if (!ctx->lane (i))
+              {
+                set_error ("cannot create a work lane (stream)");
+                return AWM_ERR_HIP;
+              }
+          std::vector<std::vector<size_t>> share (n_staged_threads);
+          for (size_t i = 0; i < staged.size(); i++)
+            share[i * n_staged_threads / staged.size()].push_back (staged[i]);
+          std::vector<int> rcs (n_staged_threads, 0);
+          std::vector<std::thread> workers;
+          for (int t = 1; t < n_staged_threads; t++)
+            workers.emplace_back ([&, t] {
+              (void) hipSetDevice (ctx->device);
+              rcs[t] = clip_batch_staged (ctx, key_list, clips, share[t], result_sets, t * lanes_per_thread, lanes_per_thread);
+            });
+          rcs[0] = clip_batch_staged (ctx, key_list, clips, share[0], result_sets, 0, lanes_per_thread);
+          for (auto& w : workers)
+            w.join();
+          for (int rc : rcs)
+            if (rc)
+              return rc;
+        }
     }
   if (threaded.empty())
     return 0;
