@@ -21,7 +21,7 @@ def library_path():
 
 # more hardware queues than the default 4, so that the lanes of `get` do not share one (see bench.py); only effective if the
 # HIP runtime has not been initialised yet by whoever imported us
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def _load_hip_runtime():

@@ -382,7 +382,7 @@ awm_ctx_create (int device, awm_ctx **ctx_out)
   *ctx_out = nullptr;
   // lanes are HIP streams; the runtime maps streams to GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one
   // queue serialise.  No effect if the runtime is already initialised (e.g. inside a PyTorch process: set it there).
-  setenv ("GPU_MAX_HW_QUEUES", "8", 0);
+  setenv ("GPU_MAX_HW_QUEUES", "16", 0);   // 16 lanes in the clip batch mode: 0.64 -> 0.535 ms per clip over 8 queues
   int n_dev = 0;
   hipError_t e = hipGetDeviceCount (&n_dev);
   if (e != hipSuccess || n_dev <= 0)

@@ -26,7 +26,7 @@ import time
 # onto GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run back to back; with the collective
 # library's own streams in the process two lanes ended up on one queue (multi-GPU step 9.0 ms instead of 7.5 ms).  Must be
 # set before the HIP runtime initialises, i.e. before torch is imported.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
