@@ -264,6 +264,15 @@ def main():
                 roofline["alone_avg_ms"] = round(sms / sl, 4)            # not sharing the GPU with the other lanes' kernels
                 roofline["alone_achieved"] = round(sb / (sms * 1e-3) / 1e9, 1)
                 roofline["alone_frac"] = round(sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                if name.startswith("sync_scan_kernel(approx)"):
+                    # What limits this kernel is not HBM: every candidate start gathers its 510 sync rows x 60 bands from the
+                    # dB tile in LDS (ds_read_b32, ~75 TB/s for the whole chip per the microarchitecture guide).  Candidates per
+                    # launch from the algorithmic bytes (324 B per frame and shift; a candidate needs a whole block after it).
+                    frame_shifts = sb / 324.0
+                    candidates = max(frame_shifts - 4 * 2226 * sl, 0.0)
+                    lds_tbps = candidates * 510 * 60 * 4 / (sms * 1e-3) / 1e12
+                    roofline["lds_gather"] = {"achieved": round(lds_tbps, 1), "peak": 75.0, "unit": "TB/s", "frac": round(lds_tbps / 75.0, 3),
+                                              "note": "sequential float sums in the reference's order: 60 gathered adds per sync row and candidate"}
         res = {
             "metric": "audio seconds watermarked+decoded per wall-second (xRT), 44.1 kHz stereo",
             "value": round(audio_seconds * args.steps / elapsed, 1),
