@@ -1858,10 +1858,33 @@ nonzero_range_kernel (const float *data, long long n_values, unsigned long long 
         if ((unsigned long long) i < first) first = i;
         if ((unsigned long long) i + 1 > last) last = i + 1;
       }
-  if (first != ~0ULL)
+  // one pair of atomics per workgroup (one per thread used to serialise half a million of them on two addresses:
+  // 0.16 ms for a 30 s clip of noise)
+  for (int o = 32; o > 0; o >>= 1)
     {
-      atomicMin (result, first);
-      atomicMax (result + 1, last);
+      const unsigned long long f = __shfl_xor (first, o), l = __shfl_xor (last, o);
+      first = f < first ? f : first;
+      last = l > last ? l : last;
+    }
+  __shared__ unsigned long long s_first[4], s_last[4];
+  if ((threadIdx.x & 63) == 0)
+    {
+      s_first[threadIdx.x >> 6] = first;
+      s_last[threadIdx.x >> 6] = last;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    {
+      for (int w = 1; w < 4; w++)
+        {
+          first = s_first[w] < first ? s_first[w] : first;
+          last = s_last[w] > last ? s_last[w] : last;
+        }
+      if (first != ~0ULL)
+        {
+          atomicMin (result, first);
+          atomicMax (result + 1, last);
+        }
     }
 }
 

@@ -260,10 +260,7 @@ awm_ctx::get_resample_table (int rate_in, int rate_out)
     }
   const unsigned n = unsigned (rate_out) / a, s = unsigned (rate_in) / a;
   if (!(16 * r >= 1 && n <= 1000))
-    {
-      set_error ("resampling from " + std::to_string (rate_in) + " to " + std::to_string (rate_out) + " Hz needs zita's VResampler (not supported)");
-      return nullptr;
-    }
+    return nullptr;                      // zita's Resampler::setup refuses: ResamplerImpl::create falls back to VResampler (capi_kernels.cc)
   unsigned h = hlen;
   if (r < 1)
     {

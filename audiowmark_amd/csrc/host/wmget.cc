@@ -1202,9 +1202,12 @@ clip_batch_staged (awm_ctx *ctx, const std::vector<Key>& key_list, const std::ve
           const size_t n = (count + 5) * Params::frame_size * C;                     // in values
           const size_t len = wav.n_values();                                          // < n for a short clip
           const size_t pad_start = n + (n - len), total = pad_start + len + n;       // data + padding cover one long block
-          if (int rc = lane->ws_clip.reserve (total * sizeof (float)))
-            return rc;
-          float *ext = lane->ws_clip.as<float>();
+          // the padded clips of a group live side by side in ONE buffer (every slice has 3 n values): the searches run
+          // per clip on the lanes, the block decode of the whole group is one batch (below)
+          if (i == 0)
+            if (int rc = lanes[0]->ws_clip.reserve (lanes.size() * total * sizeof (float)))
+              return rc;
+          float *ext = lanes[0]->ws_clip.as<float>() + i * total;
           AWM_HIP_CHECK (hipMemsetAsync (ext, 0, pad_start * sizeof (float), lane->stream));
           AWM_HIP_CHECK (hipMemcpyAsync (ext + pad_start, wav.data, len * sizeof (float), hipMemcpyDeviceToDevice, lane->stream));
           AWM_HIP_CHECK (hipMemsetAsync (ext + pad_start + len, 0, n * sizeof (float), lane->stream));
@@ -1220,7 +1223,6 @@ clip_batch_staged (awm_ctx *ctx, const std::vector<Key>& key_list, const std::ve
             return AWM_ERR_HIP;
           std::vector<SyncFinder> finders;
           std::vector<SyncFinder::SearchJob> jobs (gn);
-          std::vector<DecodeJob> decodes (gn);
           for (size_t i = 0; i < gn; i++)
             finders.emplace_back (ctx, lanes[i]);
           for (size_t i = 0; i < gn; i++)
@@ -1241,41 +1243,49 @@ clip_batch_staged (awm_ctx *ctx, const std::vector<Key>& key_list, const std::ve
           for (size_t i = 0; i < gn; i++)
             if (int rc = finders[i].select_refine (jobs[i]))
               return rc;
+          // soft bits and Viterbi decodes of ALL clips of the group in one batch on the first lane: one launch per step
+          // instead of one per clip (and 8 x gn decodes in one Viterbi launch instead of gn launches of 8)
+          std::vector<size_t> index;
+          struct Cand { size_t clip; SyncFinder::Score score; };
+          std::vector<Cand> cands;
+          const size_t slice_frames = padded[0].n_frames;
           for (size_t i = 0; i < gn; i++)
             {
               std::vector<SyncFinder::Score> sync_scores;
               if (int rc = finders[i].search_finish (jobs[i], sync_scores))
                 return rc;
-              std::vector<size_t> index;
               for (const auto& sc : sync_scores)
                 {
-                  index.push_back (sc.index);
-                  index.push_back (sc.index + count * Params::frame_size);
-                }
-              std::vector<int> slot_of;
-              std::vector<char> ok;
-              if (int rc = block_soft_bits_dev (ctx, lanes[i], kt, padded[i], index, slot_of, ok))
-                return rc;
-              auto& pending = decodes[i].pending;
-              for (size_t k = 0; k < sync_scores.size(); k++)
-                {
-                  if (!ok[2 * k] || !ok[2 * k + 1])
+                  // both halves of the long block must lie inside the clip's own slice (fft_range bound, reference wmcommon.cc:128-130)
+                  if (sc.index + 2 * count * Params::frame_size > slice_frames)
                     continue;
-                  const int first_half = sync_scores[k].block_type == ConvBlockType::a ? 0 : 1;
-                  SyncFinder::Score nopad = sync_scores[k];
-                  nopad.index = 0;                                                 // time offset of the START position is 0
-                  pending.push_back ({ ConvBlockType::ab, 1, { { slot_of[2 * k], first_half }, { slot_of[2 * k + 1], 1 - first_half } }, 0, 0,
-                                       0.0, nopad, ResultSet::Type::CLIP, g0 + i });
+                  index.push_back (i * slice_frames + sc.index);
+                  index.push_back (i * slice_frames + sc.index + count * Params::frame_size);
+                  cands.push_back ({ i, sc });
                 }
-              if (int rc = decode_launch (ctx, lanes[i], kt, decodes[i]))
-                return rc;
             }
+          DeviceWav group = padded[0];
+          group.n_frames = gn * slice_frames;
+          std::vector<int> slot_of;
+          std::vector<char> ok;
+          if (int rc = block_soft_bits_dev (ctx, lanes[0], kt, group, index, slot_of, ok))
+            return rc;
+          DecodeJob decode;
+          for (size_t k = 0; k < cands.size(); k++)
+            {
+              const int first_half = cands[k].score.block_type == ConvBlockType::a ? 0 : 1;
+              SyncFinder::Score nopad = cands[k].score;
+              nopad.index = 0;                                                     // time offset of the START position is 0
+              decode.pending.push_back ({ ConvBlockType::ab, 1, { { slot_of[2 * k], first_half }, { slot_of[2 * k + 1], 1 - first_half } }, 0, 0,
+                                          0.0, nopad, ResultSet::Type::CLIP, g0 + cands[k].clip });
+            }
+          if (int rc = decode_launch (ctx, lanes[0], kt, decode))
+            return rc;
           std::vector<ResultSet *> ptrs;
           for (auto& cs : chunk_sets)
             ptrs.push_back (&cs);
-          for (size_t i = 0; i < gn; i++)
-            if (int rc = decode_finish (lanes[i], key, decodes[i], ptrs, 1))
-              return rc;
+          if (int rc = decode_finish (lanes[0], key, decode, ptrs, 1))
+            return rc;
         }
     }
   drain.ok = true;
@@ -1352,18 +1362,25 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
           for (size_t i = 0; i < staged.size(); i++)
             share[i * n_staged_threads / staged.size()].push_back (staged[i]);
           std::vector<int> rcs (n_staged_threads, 0);
+          std::vector<std::string> messages (n_staged_threads);          // the error text is per thread
           std::vector<std::thread> workers;
           for (int t = 1; t < n_staged_threads; t++)
             workers.emplace_back ([&, t] {
               (void) hipSetDevice (ctx->device);
               rcs[t] = clip_batch_staged (ctx, key_list, clips, share[t], result_sets, t * lanes_per_thread, lanes_per_thread);
+              if (rcs[t])
+                messages[t] = last_error();
             });
           rcs[0] = clip_batch_staged (ctx, key_list, clips, share[0], result_sets, 0, lanes_per_thread);
           for (auto& w : workers)
             w.join();
-          for (int rc : rcs)
-            if (rc)
-              return rc;
+          for (int t = 0; t < n_staged_threads; t++)
+            if (rcs[t])
+              {
+                if (t)
+                  set_error (messages[t]);
+                return rcs[t];
+              }
         }
     }
   if (threaded.empty())
