@@ -227,3 +227,18 @@ def test_config3_full_size_48k_detect_speed(gpu):
     steps = np.round(gaps / block_s)
     assert np.all(steps >= 1) and np.abs(gaps - steps * block_s).max() < 0.1 and (steps == 1).sum() >= 50
     assert len(plain) > 0 and len(pats) > len(plain)
+
+
+def test_batch_of_clips_with_detect_speed(gpu, golden, replayed):
+    """awm_get_watermark_batch_d with --detect-speed set: the clips are decoded one after the other (the speed search and the
+    stretched copy live in per-context buffers) and every clip's result equals awm_get_watermark_d on it."""
+    clips = [gpu.dev(replayed["0.9764"]), gpu.dev(replayed["1.01"]), gpu.dev(replayed["1"])]
+    gpu.awm.set_speed_params(detect_speed=True)
+    try:
+        batch = gpu.ctx.get_watermark_batch(KEY, clips)
+        single = [gpu.ctx.get_watermark(KEY, c) for c in clips]
+    finally:
+        gpu.awm.set_speed_params()
+    assert batch == single
+    assert [any(p["bits"] == golden["payload"] and p["speed"] != 1 for p in b) for b in batch] == [True, True, False]
+    assert all(any(p["bits"] == golden["payload"] for p in b) for b in batch)
