@@ -242,3 +242,22 @@ def test_batch_of_clips_with_detect_speed(gpu, golden, replayed):
     assert batch == single
     assert [any(p["bits"] == golden["payload"] and p["speed"] != 1 for p in b) for b in batch] == [True, True, False]
     assert all(any(p["bits"] == golden["payload"] for p in b) for b in batch)
+
+
+def test_three_channels_and_short_material(gpu):
+    """odd channel count (the transform of a time step carries channel pairs: the last one rides alone) and material that is
+    shorter than the 25 s / 50 s the passes ask for (fewer rows in the magnitude matrices)"""
+    n, ch = 14 * 44100, 3
+    x = orc.gen_noise(KEY, n * ch)
+    y = orc.add(KEY, x, ch, "0123456789abcdef0011223344556677")
+    z = orc.resample_ratio(y, ch, 1 / 0.93)
+    zd = gpu.dev(z, ch)
+    loc = orc.speed_clip_location(KEY, z, ch, 25.0)
+    assert gpu.ctx.speed_clip_location(KEY, zd, 25.0) == loc
+    want = orc.speed_mags(KEY, z, ch, loc, 0.93, 25.0)
+    got = gpu.ctx.speed_mags(KEY, zd, loc, 0.93, 25.0)
+    assert got.shape == want.shape and got.shape[0] < 4303 and np.abs(got - want).max() < 1e-2
+    use, best, quality = gpu.ctx.detect_speed(KEY, zd)
+    o_use, o_best, o_quality = orc.detect_speed(KEY, z, ch)
+    assert (use is None) == (o_use is None) and abs(best - o_best) <= SPEED_TOL and abs(quality - o_quality) < 1e-4
+    assert abs(best - 0.93) < 1e-3
