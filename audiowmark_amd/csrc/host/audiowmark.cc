@@ -207,10 +207,7 @@ parse_shared_options (ArgParser& ap)
       exit (1);
     }
   if (ap.parse_opt ("--linear"))
-    {
-      error ("audiowmark: --linear is not supported by the GPU path\n");
-      exit (1);
-    }
+    Params::mix = false;
 }
 
 vector<Key>

@@ -31,11 +31,11 @@ check_ctx (awm_ctx *ctx)
       set_error ("hipSetDevice: " + hip_error_string (e));
       return AWM_ERR_HIP;
     }
-  if (Params::frames_per_bit != 2 || !Params::mix || Params::payload_size != 128)
+  if (Params::frames_per_bit != 2 || Params::payload_size != 128)
     {
-      // the kernels are specialised for the default block geometry (2226 frames, mix tables); the reference's
-      // undocumented --frames-per-bit / --linear and the deprecated --short payloads are out of scope
-      set_error ("unsupported watermark parameters (frames_per_bit != 2, linear mode or short payload)");
+      // the kernels are specialised for the default block geometry (2226 frames); the reference's undocumented
+      // --frames-per-bit and the deprecated --short payloads are out of scope
+      set_error ("unsupported watermark parameters (frames_per_bit != 2 or short payload)");
       return AWM_ERR_ARG;
     }
   return 0;

@@ -178,10 +178,11 @@ awm_ctx::get_key_tables (const Key& key)
   std::lock_guard<std::mutex> lock (table_mutex);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& kt : key_tables)
-    if (kt->key == kb)
+    if (kt->key == kb && kt->mix == Params::mix)
       return kt.get();
   auto kt = std::make_unique<KeyTables>();
   kt->key = kb;
+  kt->mix = Params::mix;
   for (int clip = 0; clip < 2; clip++)
     {
       auto& s = kt->sync[clip];
@@ -285,7 +286,7 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
 {
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& t : frame_mod_tables)
-    if (t->key == kb && t->payload == payload_hex)
+    if (t->key == kb && t->payload == payload_hex && t->mix == Params::mix)
       return t.get();
   auto bits = parse_payload (payload_hex);
   if (bits.empty())
@@ -297,6 +298,7 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
   auto t = std::make_unique<FrameModTable>();
   t->key = kb;
   t->payload = payload_hex;
+  t->mix = Params::mix;
   if (upload (t->dev, table.data(), table.size(), stream))
     return nullptr;
   if (frame_mod_tables.size() > 64)     // bounded cache

@@ -84,6 +84,7 @@ struct PinnedBuffer
 struct KeyTables
 {
   std::vector<unsigned char> key;
+  bool mix = true;                 // Params::mix the data tables were built for (--linear: per-frame up / down bands)
   // sync tables, BLOCK and CLIP flavour
   struct Sync
   {
@@ -122,6 +123,7 @@ struct FrameModTable
 {
   std::vector<unsigned char> key;
   std::string payload;
+  bool        mix = true;
   DevBuffer   dev;                 // [2*2226][81] int8
 };
 

@@ -266,8 +266,29 @@ build_sync_table (const Key& key, bool clip_mode)
 MixTable
 build_mix_table (const Key& key)
 {
-  const auto entries = gen_mix_entries (key);
   MixTable t;
+  if (!Params::mix)
+    {
+      // --linear (reference wmget.cc:110-152 linear_decode): data frame f uses its own 30 up / 30 down bands.  Written as the
+      // entry list mix_decode consumes -- frame f's entries in band order -- the two decoders are the same computation:
+      // umag and dmag are separate accumulators, so "all up terms, then all down terms" of a frame and channel is the same
+      // sequence of additions per accumulator as the interleaved order.
+      UpDownGen data_gen (key, Random::Stream::data_up_down);
+      BitPosGen bit_pos_gen (key);
+      for (int f = 0; f < int (mark_data_frame_count()); f++)
+        {
+          UpDownArray up, down;
+          data_gen.get (f, up, down);
+          for (size_t i = 0; i < up.size(); i++)
+            {
+              t.frame.push_back (int16_t (bit_pos_gen.data_frame (f)));
+              t.up.push_back (uint8_t (up[i]));
+              t.down.push_back (uint8_t (down[i]));
+            }
+        }
+      return t;
+    }
+  const auto entries = gen_mix_entries (key);
   for (const auto& e : entries)
     {
       t.frame.push_back (int16_t (e.frame));

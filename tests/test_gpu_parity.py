@@ -620,3 +620,27 @@ def test_pcm_staging_bit_exact(gpu, bits, encoding, big, direct16):
     assert np.array_equal(got, want)
     back = gpu.ctx.pcm_decode(gpu.dev(want), bits, encoding, big).cpu().numpy()
     assert np.array_equal(back.view(np.uint32), _np_decode(want, bits, encoding, big).view(np.uint32))
+
+
+def test_linear_mode(gpu):
+    """--linear (Params::mix = false; reference wmadd.cc:115-126, wmget.cc:110-152): per-frame up / down bands instead of the
+    shuffled mix entries -- same kernels with another table."""
+    x = noise(4242, 130 * 44100, 2)
+    gpu.awm.set_params(mix=False)
+    orc.set_params(mix=False)
+    try:
+        want = orc.add(None, x, 2, PAY2).reshape(-1, 2)
+        w = gpu.ctx.add_watermark(None, PAY2, gpu.dev(x))
+        got = w.cpu().numpy()
+        assert rms(got, want) < RMS_TOL and np.abs(got - want).max() < 2e-6
+        pats = gpu.ctx.get_watermark(None, w)
+        ref = orc.get(None, got, 2)
+        assert [pkey(p) for p in pats] == [pkey(p) for p in ref]
+        assert sum(p["bits"] == PAY2 for p in pats) >= 3
+    finally:
+        gpu.awm.set_params()
+        orc.set_params()
+    # the two modes do not read each other's watermarks, and the tables are cached per mode
+    assert not any(p["bits"] == PAY2 for p in gpu.ctx.get_watermark(None, w))
+    w_mix = gpu.ctx.add_watermark(None, PAY2, gpu.dev(x))
+    assert any(p["bits"] == PAY2 for p in gpu.ctx.get_watermark(None, w_mix))
