@@ -1,6 +1,8 @@
 // C ABI: key-derived tables (pure host; usable without a GPU) -- see include/awm_hip.h
 #include "context.hh"
 #include "utils.hh"
+#include "wmspeed.hh"
+#include "random.hh"
 #include <cstring>
 
 using namespace awm;
@@ -116,6 +118,65 @@ awm_conv_encode (int block_type, const int *bits, size_t n, int *out)
   const auto r = conv_encode (ConvBlockType (block_type), std::vector<int> (bits, bits + n));
   std::copy (r.begin(), r.end(), out);
   return int (r.size());
+}
+
+/* ---- host side pieces of the speed detection (no GPU needed) ---------------------------------------------------- */
+int
+awm_speed_select_n_best (double *speed, double *quality, int count, int n)
+{
+  std::vector<SpeedScore> scores (count);
+  for (int i = 0; i < count; i++)
+    {
+      scores[i].speed = speed[i];
+      scores[i].quality = quality[i];
+    }
+  select_n_best_scores (scores, size_t (n));
+  for (size_t i = 0; i < scores.size(); i++)
+    {
+      speed[i] = scores[i].speed;
+      quality[i] = scores[i].quality;
+    }
+  return int (scores.size());
+}
+
+double
+awm_speed_smooth_best (const double *speed, const double *quality, int count, double step, double distance)
+{
+  std::vector<SpeedScore> scores (count);
+  for (int i = 0; i < count; i++)
+    {
+      scores[i].speed = speed[i];
+      scores[i].quality = quality[i];
+    }
+  return count ? score_smooth_find_best (scores, step, distance) : 0;
+}
+
+size_t
+awm_speed_clip_positions (const uint8_t key[16], size_t n_values, size_t max_out, uint64_t *positions)
+{
+  Random rng (key_from_bytes (key), 0, Random::Stream::speed_clip);
+  size_t count = 0;
+  for (size_t p = 0; p < n_values; p += rng() % 1000)
+    {
+      if (count < max_out)
+        positions[count] = p;
+      count++;
+    }
+  return count;
+}
+
+int
+awm_speed_clip_candidates (const uint8_t key[16], const float *hashed_values, size_t n, int candidates, double *locations)
+{
+  unsigned char hash[20];
+  sha1 (hashed_values, n * sizeof (float), hash);
+  uint64_t seed = 0;
+  for (int i = 0; i < 8; i++)
+    seed = (seed << 8) | hash[i];
+  Random rng (key_from_bytes (key), seed, Random::Stream::speed_clip);
+  for (int c = 0; c < candidates; c++)
+    locations[c] = rng.random_double();
+  return 0;
 }
 
 void

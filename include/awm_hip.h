@@ -237,6 +237,15 @@ int awm_speed_scan_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, s
                       double clip_location, double seconds, double step, int n_steps, int n_center_steps,
                       const double *speeds, int n_speeds, size_t max_out, double *out_speed, double *out_quality);
 
+/* host side pieces of the search (pure host, no GPU): select_n_best_scores (wmspeed.cc:494-531; in place, returns the new
+ * count), score_smooth_find_best (:397-428), and the two halves of get_clip_locations (:533-553): the sample positions that
+ * are hashed, and the candidate locations drawn from the generator re-seeded with the SHA-1 of those samples
+ * (Random::seed_from_hash, random.cc:184-190) */
+int    awm_speed_select_n_best (double *speed, double *quality, int count, int n);
+double awm_speed_smooth_best (const double *speed, const double *quality, int count, double step, double distance);
+size_t awm_speed_clip_positions (const uint8_t key[16], size_t n_values, size_t max_out, uint64_t *positions);
+int    awm_speed_clip_candidates (const uint8_t key[16], const float *hashed_values, size_t n, int candidates, double *locations);
+
 /* global parameters (reference Params, wmcommon.hh:33-89) */
 void awm_set_params (double water_delta, int mix, int frames_per_bit, int test_no_limiter,
                      double sync_threshold2, int n_best, double chunk_size_min);

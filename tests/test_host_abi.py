@@ -103,3 +103,50 @@ def test_merge_patterns_dedup_and_sort():
         return a
     assert awm.merge_patterns_raw(None, [arr(chunk0), arr(chunk1)]) == out
     assert awm.merge_patterns_raw(None, [arr([]), arr([])]) == []
+
+
+def test_speed_host_pieces_match_oracle():
+    """the host side of the speed search (no GPU): peak selection, smoothing, and the clip location generator -- the positions
+    that get hashed and the candidate locations seeded from their SHA-1 (AES / SHA units when the CPU has them) -- against
+    the oracle's restatement"""
+    import ctypes as C
+    import _oracle as orc
+    lib = awm.lib
+    rng = np.random.default_rng(11)
+    speed = np.sort(rng.uniform(0.8, 1.25, 627))
+    quality = rng.uniform(0, 1, 627)
+    quality[100] = quality[101] = 1.5
+    s1, q1 = speed.copy(), quality.copy()
+    lib.awm_speed_select_n_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    n = lib.awm_speed_select_n_best(s1.ctypes.data, q1.ctypes.data, len(s1), 5)
+    so, qo = orc.speed_select_n_best(speed, quality, 5)
+    assert n == 5 and s1[:5].tolist() == so.tolist() and q1[:5].tolist() == qo.tolist()
+    sp = 0.97 + np.arange(81) * 0.00005
+    qq = np.exp(-((sp - 0.9712) / 0.0004) ** 2) + rng.uniform(0, 0.05, 81)
+    lib.awm_speed_smooth_best.restype = C.c_double
+    lib.awm_speed_smooth_best.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_double]
+    assert lib.awm_speed_smooth_best(sp.ctypes.data, qq.ctypes.data, 81, 1 - 1.00005, 20.0) == orc.speed_smooth_best(sp, qq, 1 - 1.00005, 20)
+    # clip location: same samples hashed, same candidates, same winner as the oracle's get_best_clip_location
+    key = bytes(range(16))
+    x = orc.gen_noise(key, 2 * 44100 * 40)
+    x[: 2 * 44100 * 10] *= 0.1                      # a quiet start: the loudest candidate clip is not arbitrary
+    lib.awm_speed_clip_positions.restype = C.c_size_t
+    lib.awm_speed_clip_positions.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_void_p]
+    cap = x.size // 300
+    pos = np.zeros(cap, np.uint64)
+    cnt = lib.awm_speed_clip_positions(key, x.size, cap, pos.ctypes.data)
+    assert 0 < cnt <= cap and pos[0] == 0 and np.all(np.diff(pos[:cnt].astype(np.int64)) < 1000)
+    hashed = np.ascontiguousarray(x[pos[:cnt].astype(np.int64)])
+    loc = np.zeros(5)
+    lib.awm_speed_clip_candidates.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    assert lib.awm_speed_clip_candidates(key, hashed.ctypes.data, cnt, 5, loc.ctypes.data) == 0
+    assert np.all((0 <= loc) & (loc < 1))
+
+    def energy(l, seconds=25.0):
+        frames = x.size // 2
+        start = int(max(l * (frames / 44100 - seconds), 0) * 44100)
+        end = min(int(start + seconds * 44100), frames)
+        c = x[2 * start:2 * end].astype(np.float64)
+        return float((c * c).sum())
+    best = max(loc, key=energy)
+    assert orc.speed_clip_location(key, x, 2, 25.0) == best
