@@ -289,8 +289,8 @@ launch_speed_mags (hipStream_t st, const DevTables& t, const SpeedMagsArgs& a, i
 __global__ void __launch_bounds__ (256)
 speed_compare_kernel (SpeedCompareArgs a)
 {
-  __shared__ long long s_fo[3 * SPEED_COLS];
-  __shared__ double    s_best[4];
+  __shared__ int2   s_fo[3 * SPEED_COLS];            // frame offset in Q16: (whole rows, 16 bit fraction)
+  __shared__ double s_best[4];
   const SpeedItemDev it = a.items[blockIdx.y];
   const SpeedCenterDev cd = a.centers[it.center];
   for (int e = threadIdx.x; e < 3 * SPEED_COLS; e += blockDim.x)
@@ -300,7 +300,8 @@ speed_compare_kernel (SpeedCompareArgs a)
       double v = steps * it.rel_speed_inv;
       v = v + 0.5;
       v = v * 65536.0;
-      s_fo[e] = (long long) v;
+      const long long fo = (long long) v;
+      s_fo[e] = make_int2 (int (fo >> 16), int (fo & 0xffff));
     }
   __syncthreads();
   const int state = blockIdx.x * blockDim.x + threadIdx.x;
@@ -322,7 +323,11 @@ speed_compare_kernel (SpeedCompareArgs a)
   if (state < a.pad_start && rows > 0)
     {
       const double scaled = (state - a.pad_start) * it.q16_scale;
-      const long long offset = (int) scaled;
+      const int offset = (int) scaled;
+      // row = (offset + frame_offset) >> 16 with 32 bit pieces: whole rows + whole rows + carry of the fractions.  The sum
+      // is negative exactly when the row is (arithmetic shift = floor), so one unsigned compare tests both ends.
+      const int off_rows = offset >> 16, off_frac = offset & 0xffff;
+      const unsigned n_rows = unsigned (rows);
       const float2 *mags = a.mags + it.center * a.mags_center_stride;
       int total = 0;
       for (int bit = 0; bit < 6; bit++)
@@ -338,27 +343,23 @@ speed_compare_kernel (SpeedCompareArgs a)
               if (f_lo > f_hi)
                 continue;
               const int j_lo = __builtin_amdgcn_readfirstlane (first[f_lo]), j_hi = __builtin_amdgcn_readfirstlane (first[f_hi + 1]);
-              const long long *fo = s_fo + block * SPEED_COLS + bit * a.rows_per_bit;
+              const int2 *fo = s_fo + block * SPEED_COLS + bit * a.rows_per_bit;
               const float2 *mc = mags + (long long) bit * a.rows_per_bit * a.ld;
+              const unsigned ld = unsigned (a.ld);
+              // branch free: a row outside the matrix reads row 0 and adds zeros (x + 0.0f is x), so that the loads of
+              // several columns can be in flight at once -- the loop is bound by their latency
+#pragma unroll 4
               for (int j = j_lo; j < j_hi; j++)
                 {
-                  const long long sum = offset + fo[j];
-                  const long long idx = sum >> 16;
-                  if (sum >= 0 && idx < rows)
-                    {
-                      const float2 m = mc[j * a.ld + idx];
-                      if (block & 1)
-                        {
-                          u = __fadd_rn (u, m.y);
-                          d = __fadd_rn (d, m.x);
-                        }
-                      else
-                        {
-                          u = __fadd_rn (u, m.x);
-                          d = __fadd_rn (d, m.y);
-                        }
-                      n++;
-                    }
+                  const int2 f = fo[j];
+                  const int idx = off_rows + f.x + ((off_frac + f.y) >> 16);
+                  const bool valid = unsigned (idx) < n_rows;
+                  const float2 m = mc[unsigned (j) * ld + (valid ? unsigned (idx) : 0u)];
+                  const float mu = valid ? ((block & 1) ? m.y : m.x) : 0.f;
+                  const float md = valid ? ((block & 1) ? m.x : m.y) : 0.f;
+                  u = __fadd_rn (u, mu);
+                  d = __fadd_rn (d, md);
+                  n += valid;
                 }
             }
           float raw;                                        // SyncFinder::bit_quality (reference syncfinder.cc:94-114)
