@@ -61,8 +61,44 @@ encrypt_block_aesni (const uint8_t *rk, const uint8_t in[16], uint8_t out[16])
   b = _mm_aesenclast_si128 (b, _mm_loadu_si128 (reinterpret_cast<const __m128i *> (rk + 160)));
   _mm_storeu_si128 (reinterpret_cast<__m128i *> (out), b);
 }
+// eight independent blocks at a time: AESENC has a latency of several cycles but issues every cycle
+__attribute__ ((target ("aes,sse2"))) static void
+encrypt_blocks_aesni (const uint8_t *rk, const uint8_t *in, uint8_t *out, size_t n_blocks)
+{
+  __m128i k[11];
+  for (int r = 0; r < 11; r++)
+    k[r] = _mm_loadu_si128 (reinterpret_cast<const __m128i *> (rk + 16 * r));
+  size_t i = 0;
+  for (; i + 8 <= n_blocks; i += 8)
+    {
+      __m128i b[8];
+      for (int j = 0; j < 8; j++)
+        b[j] = _mm_xor_si128 (_mm_loadu_si128 (reinterpret_cast<const __m128i *> (in + 16 * (i + j))), k[0]);
+      for (int r = 1; r < 10; r++)
+        for (int j = 0; j < 8; j++)
+          b[j] = _mm_aesenc_si128 (b[j], k[r]);
+      for (int j = 0; j < 8; j++)
+        _mm_storeu_si128 (reinterpret_cast<__m128i *> (out + 16 * (i + j)), _mm_aesenclast_si128 (b[j], k[10]));
+    }
+  for (; i < n_blocks; i++)
+    encrypt_block_aesni (rk, in + 16 * i, out + 16 * i);
+}
 static const bool have_aesni = [] { __builtin_cpu_init(); return bool (__builtin_cpu_supports ("aes")); }();
 #endif
+
+void
+Aes128::encrypt_blocks (const uint8_t *in, uint8_t *out, size_t n_blocks) const
+{
+#ifdef AWM_X86_CRYPTO
+  if (have_aesni)
+    {
+      encrypt_blocks_aesni (m_rk, in, out, n_blocks);
+      return;
+    }
+#endif
+  for (size_t i = 0; i < n_blocks; i++)
+    encrypt_block (in + 16 * i, out + 16 * i);
+}
 
 void
 Aes128::encrypt_block (const uint8_t in[16], uint8_t out[16]) const

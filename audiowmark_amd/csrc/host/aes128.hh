@@ -17,6 +17,7 @@ class Aes128
 public:
   void set_key (const uint8_t key[16]);
   void encrypt_block (const uint8_t in[16], uint8_t out[16]) const;
+  void encrypt_blocks (const uint8_t *in, uint8_t *out, size_t n_blocks) const;   // independent blocks (CTR keystream)
 };
 
 } // namespace awm

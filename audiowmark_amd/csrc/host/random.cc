@@ -1,4 +1,5 @@
 #include "random.hh"
+#include <cstring>
 #include "utils.hh"
 #include <cinttypes>
 #include <cstdio>
@@ -162,21 +163,26 @@ Random::seed (uint64_t seed, Stream stream)
 void
 Random::refill()
 {
-  // CTR mode over an all-zero plaintext == raw keystream; 128-bit big-endian counter increment
-  for (size_t blk = 0; blk < WORDS / 2; blk++)
+  // CTR mode over an all-zero plaintext == raw keystream; 128-bit big-endian counter increment.  The counter blocks of
+  // a refill are independent: encrypted as one batch.
+  constexpr size_t BLOCKS = WORDS / 2;
+  uint8_t counters[16 * BLOCKS], ks[16 * BLOCKS];
+  for (size_t blk = 0; blk < BLOCKS; blk++)
     {
-      uint8_t ks[16];
-      m_aes.encrypt_block (m_counter, ks);
+      std::memcpy (counters + 16 * blk, m_counter, 16);
       for (int k = 15; k >= 0; k--)
         if (++m_counter[k])
           break;
-      for (int w = 0; w < 2; w++)
-        {
-          uint64_t v = 0;
-          for (int b = 0; b < 8; b++)
-            v = (v << 8) | ks[8 * w + b];
-          m_words[2 * blk + w] = v;
-        }
+    }
+  m_aes.encrypt_blocks (counters, ks, BLOCKS);
+  for (size_t w = 0; w < WORDS; w++)
+    {
+      uint64_t v;
+      std::memcpy (&v, ks + 8 * w, 8);
+#if __BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__
+      v = __builtin_bswap64 (v);                      // the stream is defined in big endian words
+#endif
+      m_words[w] = v;
     }
   m_pos = 0;
 }
