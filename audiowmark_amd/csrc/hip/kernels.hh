@@ -255,6 +255,8 @@ struct VarResampleArgs
   const SpeedCenterDev *centers;
   float                *out;
   long long             out_stride;    // floats
+  int                   max_stride;    // largest table row stride among the centres (sizes the LDS copy)
+  int                   lds_floats;    // set by the launcher
 };
 hipError_t launch_resample_var (hipStream_t st, const VarResampleArgs& a, long long max_n_out, int n_centers);
 

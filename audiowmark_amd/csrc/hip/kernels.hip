@@ -741,6 +741,7 @@ resample_output (const ResampleArgs& a, const float *tab, int stride, long long 
       if (__all (first >= 0 && first + 2 * hl <= a.n_in))      // the whole wave is away from the ends: no bounds checks
         {
           const float2 *p1 = in2 + first, *p2 = in2 + first + 2 * hl - 1;
+#pragma unroll 4
           for (int i = 0; i < hl; i++)
             {
               const float2 x1 = p1[i], x2 = p2[-i];
@@ -779,12 +780,12 @@ resample_output (const ResampleArgs& a, const float *tab, int stride, long long 
  * down and up again).  The table ((np + 1) x hl, 10 - 30 KiB for the usual rates) is staged in LDS once per 1024 outputs,
  * with an odd row stride so that equal columns of different rows fall into different banks. */
 template<int CT> __global__ void __launch_bounds__ (256)
-resample_kernel (ResampleArgs a)
+resample_kernel (ResampleArgs a, int lds_floats)
 {
-  __shared__ float s_tab[RS_MAX_TAB];
+  extern __shared__ float s_tab[];                           // lds_floats (launcher): the table, or nothing if it is too large
   const long long tile0 = (long long) blockIdx.x * RS_TILE;
   const int stride = a.hl | 1, rows = a.np + 1;
-  const bool in_lds = rows * stride <= RS_MAX_TAB;
+  const bool in_lds = lds_floats > 0;
   if (in_lds)
     {
       for (int r = threadIdx.x / 32; r < rows; r += 8)         // 32 threads per row (hl <= 64 in practice; loop covers more)
@@ -811,10 +812,14 @@ launch_resample (hipStream_t st, const ResampleArgs& a)
     return hipSuccess;
   const dim3 grid (unsigned ((a.n_out + RS_TILE - 1) / RS_TILE));
   const bool aligned = (reinterpret_cast<uintptr_t> (a.in) & 7) == 0 && (reinterpret_cast<uintptr_t> (a.out) & 7) == 0;
+  // dynamic LDS of exactly the table size: 10 - 30 KiB for the usual rates leaves room for up to 8 waves per SIMD
+  const int want = (a.np + 1) * (a.hl | 1);
+  const int lds_floats = want <= RS_MAX_TAB ? want : 0;
+  const size_t lds_bytes = size_t (lds_floats) * sizeof (float);
   if (a.n_channels == 2 && aligned)
-    hipLaunchKernelGGL (resample_kernel<2>, grid, dim3 (256), 0, st, a);
+    hipLaunchKernelGGL (resample_kernel<2>, grid, dim3 (256), lds_bytes, st, a, lds_floats);
   else
-    hipLaunchKernelGGL (resample_kernel<0>, grid, dim3 (256), 0, st, a);
+    hipLaunchKernelGGL (resample_kernel<0>, grid, dim3 (256), lds_bytes, st, a, lds_floats);
   return hipGetLastError();
 }
 

@@ -63,6 +63,7 @@ var_output (const SpeedCenterDev& cd, const float *tab, int stride, const float 
       if (__all (v.first >= 0 && v.first + 2 * hl <= cd.n_in))    // the whole wave is away from the ends: no bounds checks
         {
           const float2 *p1 = in2 + v.first, *p2 = in2 + v.first + 2 * hl - 1;
+#pragma unroll 4
           for (int i = 0; i < hl; i++)
             {
               const float c1 = __fadd_rn (__fmul_rn (v.af, q1[i]), __fmul_rn (v.bf, q1n[i]));
@@ -113,13 +114,13 @@ constexpr int RV_MAX_TAB = 12288;         // floats of LDS for the coefficient t
 template<int CT> __global__ void __launch_bounds__ (256)
 resample_var_kernel (VarResampleArgs a)
 {
-  __shared__ float s_tab[RV_MAX_TAB];
+  extern __shared__ float s_tab[];                           // lds_floats: sized for the largest table of the launch (occupancy)
   const SpeedCenterDev cd = a.centers[blockIdx.y];
   const long long tile0 = (long long) blockIdx.x * RV_TILE;
   if (tile0 >= cd.n_out)
     return;
   const int stride = cd.stride, n_tab = 257 * stride;
-  const bool in_lds = n_tab <= RV_MAX_TAB;
+  const bool in_lds = n_tab <= a.lds_floats;
   if (in_lds)
     {
       for (int i = threadIdx.x; i < n_tab; i += blockDim.x)
@@ -140,16 +141,22 @@ resample_var_kernel (VarResampleArgs a)
 }
 
 hipError_t
-launch_resample_var (hipStream_t st, const VarResampleArgs& a, long long max_n_out, int n_centers)
+launch_resample_var (hipStream_t st, const VarResampleArgs& args, long long max_n_out, int n_centers)
 {
   if (max_n_out <= 0 || n_centers <= 0)
     return hipSuccess;
+  VarResampleArgs a = args;
+  // LDS for the largest table of the launch (a.max_stride): a small table (ratios near 1: 17 KiB) leaves room for 8 waves
+  // per SIMD, which is what hides the load latency of the tap loop; tables beyond 48 KiB stay in global memory
+  const int want = 257 * a.max_stride;
+  a.lds_floats = want <= RV_MAX_TAB ? want : 0;
   const dim3 grid (unsigned ((max_n_out + RV_TILE - 1) / RV_TILE), unsigned (n_centers));
+  const size_t lds_bytes = size_t (a.lds_floats) * sizeof (float);
   const bool aligned = (reinterpret_cast<uintptr_t> (a.in) & 7) == 0 && (reinterpret_cast<uintptr_t> (a.out) & 7) == 0 && (a.out_stride & 1) == 0;
   if (a.n_channels == 2 && aligned)
-    hipLaunchKernelGGL (resample_var_kernel<2>, grid, dim3 (256), 0, st, a);
+    hipLaunchKernelGGL (resample_var_kernel<2>, grid, dim3 (256), lds_bytes, st, a);
   else
-    hipLaunchKernelGGL (resample_var_kernel<0>, grid, dim3 (256), 0, st, a);
+    hipLaunchKernelGGL (resample_var_kernel<0>, grid, dim3 (256), lds_bytes, st, a);
   return hipGetLastError();
 }
 

@@ -294,6 +294,8 @@ prepare_mags (awm_ctx *ctx, const Key& key, const DeviceWav& clip, double second
   ra.centers = ws->centers.as<awmk::SpeedCenterDev>();
   ra.out = ws->sub.as<float>();
   ra.out_stride = sub_stride;
+  for (const auto& cd : cds)
+    ra.max_stride = std::max (ra.max_stride, cd.stride);
   AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, max_out, int (centers.size())));
   awmk::SpeedMagsArgs ma {};
   ma.sub = ws->sub.as<float>();
@@ -359,6 +361,7 @@ resample_var_device (awm_ctx *ctx, WorkLane *lane, const float *in_d, size_t n_i
   ra.centers = ws->centers.as<awmk::SpeedCenterDev>();
   ra.out = out_d;
   ra.out_stride = 0;
+  ra.max_stride = cd.stride;
   AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, (long long) n_out, 1));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
   return 0;
