@@ -1182,6 +1182,16 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
   const int count = a.stream_count ? a.stream_count[stream] : a.count0;
   if (count <= 0)
     return;
+  // every fine offset of this row inside the leading / trailing silence (syncfinder.cc:583-585; CLIP: the padding of a
+  // padded clip): nothing to transform, the row is marked absent
+  if (a.have && ((base + 8LL * (count - 1) + 1024) * CV < a.first || base * CV > a.last))
+    {
+      if (lane < count)
+        a.have[out_slot * a.have_stream_stride + lane] = 0;
+      if (lane == 0 && count > 64)
+        a.have[out_slot * a.have_stream_stride + 64] = 0;
+      return;
+    }
   float2 *xbuf = reinterpret_cast<float2 *> (s_scratch[wave]);
   float *tile = s_scratch[wave];
   const int C = CV;
@@ -1406,6 +1416,8 @@ sync_scan_kernel (SyncScanArgs a)
       const_int_ptr tr = tab + r * 64;
       const long long row = tr[60];
       const bool present = have ? have[row * a.have_row_stride] != 0 : true;
+      if (have && !__any (present))
+        continue;                                         // CLIP: most rows of a padded clip lie in the silent padding
       const float *p = db + row * a.row_stride;
       float uv[30], dv[30];
 #pragma unroll
@@ -1635,6 +1647,8 @@ sync_scan_gathered_kernel (GatheredScanArgs a)
   auto issue = [&] (int r, float (&v)[60], bool& present) {
     const float *q = p + (long long) r * 60 * ld;
     present = HAVE ? hv[r * ld] != 0 : true;
+    if (HAVE && !__any (present))
+      return;                                             // nothing of this row is used by any candidate of the wave
 #pragma unroll
     for (int i = 0; i < 60; i++)
       v[i] = q[i * ld];
