@@ -281,7 +281,8 @@ struct SpeedCompareArgs
   const float2         *mags;
   long long             mags_center_stride, ld;
   const SpeedCenterDev *centers;
-  const SpeedItemDev   *items;
+  const SpeedItemDev   *items;         // [n_centers][items_per_center]
+  int                   n_centers, items_per_center;
   const int            *col_frame;     // [510] frame of the column
   const unsigned char  *col_first;     // [6][frames_per_block + 2]: columns of the bit with frame < f
   int                   frames_per_block, steps_per_frame, pad_start, rows_per_bit;

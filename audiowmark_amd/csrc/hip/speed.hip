@@ -285,63 +285,96 @@ launch_speed_mags (hipStream_t st, const DevTables& t, const SpeedMagsArgs& a, i
 }
 
 /* ------------------------------------------------------------------------------------------------------------------
- * K14: blockIdx.y = one (centre, relative speed) pair, thread = one candidate block start ("state", offset -pad_start .. -1
- * in steps of sync_search_step, scaled to Q16 by 1 / relative speed; wmspeed.cc:330-344).  A state visits the sync frames of
- * three consecutive blocks (compare_bits<0..2>, :270-328): row = (offset + frame_offset) >> 16, used when the sum is not
- * negative and the row exists -- the reference's begin / end iterators are exactly this test because the frame offsets grow
+ * K14: per (centre, relative speed) pair and candidate block start ("state", offset -pad_start .. -1 in steps of
+ * sync_search_step, scaled to Q16 by 1 / relative speed; wmspeed.cc:330-344): the state visits the sync frames of three
+ * consecutive blocks (compare_bits<0..2>, :270-328): row = (offset + frame_offset) >> 16, used when the sum is not negative
+ * and the row exists -- the reference's begin / end iterators are exactly this test because the frame offsets grow
  * monotonically.  Sums per sync bit are float, in the order block 0, 1, 2 and frame ascending; odd blocks swap up and down.
  * The best normalised quality over the states (:346-371) is all that survives: a 64 bit atomic max on the bits of the
  * (non-negative) double.
+ *
+ * Thread = one state for NS relative speeds of ONE centre at a time (registers: NS x (u, d, n) per sync bit).  The relative
+ * speeds of a centre differ by < 1 %, i.e. a state's rows for them lie within a few dozen rows of each other: the NS
+ * gathers of a column hit the same cache lines, so the matrix is read from HBM once per NS speeds.  (One workgroup per
+ * (speed, state range) read 11.7 GB for 1 GB of matrices in the first pass and ran at HBM speed: 1.56 ms.)
  * ------------------------------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__ (256)
+template<int NS> __global__ void __launch_bounds__ (256)
 speed_compare_kernel (SpeedCompareArgs a)
 {
-  __shared__ int2   s_fo[3 * SPEED_COLS];            // frame offset in Q16: (whole rows, 16 bit fraction)
-  __shared__ double s_best[4];
-  const SpeedItemDev it = a.items[blockIdx.y];
-  const SpeedCenterDev cd = a.centers[it.center];
-  for (int e = threadIdx.x; e < 3 * SPEED_COLS; e += blockDim.x)
-    {
-      const int block = e / SPEED_COLS, col = e - block * SPEED_COLS;
-      const int steps = (block * a.frames_per_block + a.col_frame[col]) * a.steps_per_frame;
-      double v = steps * it.rel_speed_inv;
-      v = v + 0.5;
-      v = v * 65536.0;
-      const long long fo = (long long) v;
-      s_fo[e] = make_int2 (int (fo >> 16), int (fo & 0xffff));
-    }
-  __syncthreads();
+  constexpr int BIT_COLS = 3 * 85;                             // columns of one sync bit in the three blocks
+  __shared__ int2   s_fo[NS][BIT_COLS];                        // frame offsets in Q16 (whole rows, fraction) of the current bit
+  __shared__ double s_best[NS][4];
+  const int center = blockIdx.y;
+  const SpeedCenterDev cd = a.centers[center];
+  const int s0 = blockIdx.z * NS;
+  const int ns = a.items_per_center - s0 < NS ? a.items_per_center - s0 : NS;       // speeds this workgroup has
+  const SpeedItemDev *items = a.items + center * a.items_per_center + s0;
   const int state = blockIdx.x * blockDim.x + threadIdx.x;
-  double q = 0;
-  // Offsets grow with the state, frame offsets with the frame: the frames any lane of this wave can use form one interval
-  // of "global" frames (block * frames_per_block + frame).  Bounds with a frame of margin on both sides, the exact test
-  // stays per lane; col_first[bit][f] = number of columns of the bit with frame < f turns them into column ranges.
   const int wave_state = blockIdx.x * blockDim.x + (threadIdx.x & ~63);
-  const auto offset_of = [&] (int st) {
-    st = st < a.pad_start ? st : a.pad_start - 1;
-    const double scaled = (st - a.pad_start) * it.q16_scale;
-    return (long long) (int) scaled;
-  };
   const long long rows = cd.rows;
-  const long long o_min = offset_of (wave_state), o_max = offset_of (wave_state + 63), limit = rows << 16;
-  const double steps_per_g = a.steps_per_frame * it.rel_speed_inv;
-  const int g_lo = int (floor ((double (-o_max) / 65536.0 - 0.5) / steps_per_g)) - 1;
-  const int g_hi = int (ceil ((double (limit - o_min) / 65536.0 - 0.5) / steps_per_g)) + 1;
-  if (state < a.pad_start && rows > 0)
+  const unsigned n_rows = unsigned (rows);
+  const bool active = state < a.pad_start && rows > 0;
+
+  // per speed: this state's offset, and the interval of "global" frames (block * frames_per_block + frame) any lane of the
+  // wave can use (offsets grow with the state, frame offsets with the frame; a frame of margin, the exact test is per lane)
+  int off_rows[NS], off_frac[NS];
+  int g_lo = 0x7fffffff, g_hi = -0x7fffffff;
+#pragma unroll
+  for (int k = 0; k < NS; k++)
     {
-      const double scaled = (state - a.pad_start) * it.q16_scale;
-      const int offset = (int) scaled;
-      // row = (offset + frame_offset) >> 16 with 32 bit pieces: whole rows + whole rows + carry of the fractions.  The sum
-      // is negative exactly when the row is (arithmetic shift = floor), so one unsigned compare tests both ends.
-      const int off_rows = offset >> 16, off_frac = offset & 0xffff;
-      const unsigned n_rows = unsigned (rows);
-      const float2 *mags = a.mags + it.center * a.mags_center_stride;
-      int total = 0;
-      for (int bit = 0; bit < 6; bit++)
+      const SpeedItemDev it = items[k < ns ? k : 0];
+      const auto offset_of = [&] (int st) {
+        st = st < a.pad_start ? st : a.pad_start - 1;
+        const double scaled = (st - a.pad_start) * it.q16_scale;
+        return (int) scaled;
+      };
+      const int offset = offset_of (state);
+      off_rows[k] = offset >> 16;
+      off_frac[k] = offset & 0xffff;
+      const long long o_min = offset_of (wave_state), o_max = offset_of (wave_state + 63), limit = rows << 16;
+      const double steps_per_g = a.steps_per_frame * it.rel_speed_inv;
+      const int lo = int (floor ((double (-o_max) / 65536.0 - 0.5) / steps_per_g)) - 1;
+      const int hi = int (ceil ((double (limit - o_min) / 65536.0 - 0.5) / steps_per_g)) + 1;
+      g_lo = lo < g_lo ? lo : g_lo;
+      g_hi = hi > g_hi ? hi : g_hi;
+    }
+  const float2 *mags = a.mags + center * a.mags_center_stride;
+  const unsigned ld = unsigned (a.ld);
+  double q[NS];
+  int total[NS];
+#pragma unroll
+  for (int k = 0; k < NS; k++)
+    {
+      q[k] = 0;
+      total[k] = 0;
+    }
+  for (int bit = 0; bit < 6; bit++)
+    {
+      __syncthreads();                                         // the previous bit's offsets are still being read
+      for (int e = threadIdx.x; e < NS * BIT_COLS; e += blockDim.x)
         {
-          float u = 0.f, d = 0.f;
-          int n = 0;
+          const int k = e / BIT_COLS, c = e - k * BIT_COLS;
+          const int block = c / 85, j = c - block * 85;
+          const int steps = (block * a.frames_per_block + a.col_frame[bit * a.rows_per_bit + j]) * a.steps_per_frame;
+          double v = steps * items[k < ns ? k : 0].rel_speed_inv;
+          v = v + 0.5;
+          v = v * 65536.0;
+          const long long fo = (long long) v;
+          s_fo[k][c] = make_int2 (int (fo >> 16), int (fo & 0xffff));
+        }
+      __syncthreads();
+      float u[NS], d[NS];
+      int n[NS];
+#pragma unroll
+      for (int k = 0; k < NS; k++)
+        {
+          u[k] = d[k] = 0.f;
+          n[k] = 0;
+        }
+      if (active)
+        {
           const unsigned char *first = a.col_first + bit * (a.frames_per_block + 2);
+          const float2 *mc = mags + (long long) bit * a.rows_per_bit * a.ld;
           for (int block = 0; block < 3; block++)
             {
               int f_lo = g_lo - block * a.frames_per_block, f_hi = g_hi - block * a.frames_per_block;
@@ -350,65 +383,83 @@ speed_compare_kernel (SpeedCompareArgs a)
               if (f_lo > f_hi)
                 continue;
               const int j_lo = __builtin_amdgcn_readfirstlane (first[f_lo]), j_hi = __builtin_amdgcn_readfirstlane (first[f_hi + 1]);
-              const int2 *fo = s_fo + block * SPEED_COLS + bit * a.rows_per_bit;
-              const float2 *mc = mags + (long long) bit * a.rows_per_bit * a.ld;
-              const unsigned ld = unsigned (a.ld);
-              // branch free: a row outside the matrix reads row 0 and adds zeros (x + 0.0f is x), so that the loads of
-              // several columns can be in flight at once -- the loop is bound by their latency
-#pragma unroll 4
+              const bool swap = block & 1;
+              // branch free: a row outside the matrix reads row 0 and adds zeros (x + 0.0f is x)
               for (int j = j_lo; j < j_hi; j++)
                 {
-                  const int2 f = fo[j];
-                  const int idx = off_rows + f.x + ((off_frac + f.y) >> 16);
-                  const bool valid = unsigned (idx) < n_rows;
-                  const float2 m = mc[unsigned (j) * ld + (valid ? unsigned (idx) : 0u)];
-                  const float mu = valid ? ((block & 1) ? m.y : m.x) : 0.f;
-                  const float md = valid ? ((block & 1) ? m.x : m.y) : 0.f;
-                  u = __fadd_rn (u, mu);
-                  d = __fadd_rn (d, md);
-                  n += valid;
+                  const float2 *col = mc + unsigned (j) * ld;
+#pragma unroll
+                  for (int k = 0; k < NS; k++)
+                    {
+                      const int2 f = s_fo[k][block * 85 + j];
+                      const int idx = off_rows[k] + f.x + ((off_frac[k] + f.y) >> 16);
+                      const bool valid = unsigned (idx) < n_rows;
+                      const float2 m = col[valid ? unsigned (idx) : 0u];
+                      const float mu = valid ? (swap ? m.y : m.x) : 0.f;
+                      const float md = valid ? (swap ? m.x : m.y) : 0.f;
+                      u[k] = __fadd_rn (u[k], mu);
+                      d[k] = __fadd_rn (d[k], md);
+                      n[k] += valid;
+                    }
                 }
             }
-          float raw;                                        // SyncFinder::bit_quality (reference syncfinder.cc:94-114)
-          if (u == 0 || d == 0)
-            raw = 0;
-          else if (u < d)
-            raw = __fsub_rn (1.f, __fdiv_rn (u, d));
-          else
-            raw = __fsub_rn (__fdiv_rn (d, u), 1.f);
-          const double rb = (bit & 1) ? double (raw) : -double (raw);
-          q += rb * n;
-          total += n;
         }
-      if (total)
+#pragma unroll
+      for (int k = 0; k < NS; k++)
         {
-          q /= total;
-          q = q / a.min_delta / 2.9;                        // normalize_sync_quality
-          q = fabs (q);
+          float raw;                                        // SyncFinder::bit_quality (reference syncfinder.cc:94-114)
+          if (u[k] == 0 || d[k] == 0)
+            raw = 0;
+          else if (u[k] < d[k])
+            raw = __fsub_rn (1.f, __fdiv_rn (u[k], d[k]));
+          else
+            raw = __fsub_rn (__fdiv_rn (d[k], u[k]), 1.f);
+          const double rb = (bit & 1) ? double (raw) : -double (raw);
+          q[k] += rb * n[k];
+          total[k] += n[k];
         }
-      else
-        q = 0;
     }
-  // workgroup maximum
-  for (int o = 32; o > 0; o >>= 1)
-    q = fmax (q, __shfl_xor (q, o));
-  if ((threadIdx.x & 63) == 0)
-    s_best[threadIdx.x >> 6] = q;
-  __syncthreads();
-  if (threadIdx.x == 0)
+#pragma unroll
+  for (int k = 0; k < NS; k++)
     {
-      const double best = fmax (fmax (s_best[0], s_best[1]), fmax (s_best[2], s_best[3]));
+      double v = 0;
+      if (total[k])
+        {
+          v = q[k] / total[k];
+          v = v / a.min_delta / 2.9;                        // normalize_sync_quality
+          v = fabs (v);
+        }
+      for (int o = 32; o > 0; o >>= 1)
+        v = fmax (v, __shfl_xor (v, o));
+      if ((threadIdx.x & 63) == 0)
+        s_best[k][threadIdx.x >> 6] = v;
+    }
+  __syncthreads();
+  if (threadIdx.x < ns)
+    {
+      const int k = threadIdx.x;
+      const double best = fmax (fmax (s_best[k][0], s_best[k][1]), fmax (s_best[k][2], s_best[k][3]));
       if (best > 0)
-        atomicMax (a.best + blockIdx.y, (unsigned long long) __double_as_longlong (best));
+        atomicMax (a.best + center * a.items_per_center + s0 + k, (unsigned long long) __double_as_longlong (best));
     }
 }
 
 hipError_t
 launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items)
 {
-  if (n_items <= 0)
+  if (n_items <= 0 || a.n_centers <= 0 || a.items_per_center <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL (speed_compare_kernel, dim3 (unsigned ((a.pad_start + 255) / 256), unsigned (n_items)), dim3 (256), 0, st, a);
+  if (a.rows_per_bit != 85 || n_items != a.n_centers * a.items_per_center)
+    return hipErrorInvalidValue;
+  const unsigned ranges = unsigned ((a.pad_start + 255) / 256);
+  const int per = a.items_per_center;
+  // six speeds per thread where that still leaves enough workgroups to fill the chip (the first pass: 57 centres x 11 or 23
+  // speeds); the small refinement passes get one speed per thread and more workgroups instead
+  const unsigned groups6 = unsigned ((per + 5) / 6);
+  if ((long long) ranges * a.n_centers * groups6 >= 1024)
+    hipLaunchKernelGGL (speed_compare_kernel<6>, dim3 (ranges, unsigned (a.n_centers), groups6), dim3 (256), 0, st, a);
+  else
+    hipLaunchKernelGGL (speed_compare_kernel<1>, dim3 (ranges, unsigned (a.n_centers), unsigned (per)), dim3 (256), 0, st, a);
   return hipGetLastError();
 }
 

@@ -518,6 +518,8 @@ speed_scan (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_loca
   ca.ld = ld;
   ca.centers = ws->centers.as<awmk::SpeedCenterDev>();
   ca.items = ws->items.as<awmk::SpeedItemDev>();
+  ca.n_centers = int (centers.size());
+  ca.items_per_center = 2 * sp.n_steps + 1;
   ca.col_frame = skt->col_frame.as<int>();
   ca.col_first = skt->col_first.as<unsigned char>();
   ca.frames_per_block = frames_per_block;
