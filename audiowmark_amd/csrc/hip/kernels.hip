@@ -1161,6 +1161,8 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
   static_assert (NB * SL_TILE * sizeof (float) >= XBUF_ELEMS * sizeof (float2), "scratch too small for the FFT tile");
   __shared__ unsigned char s_pos[WAVES][NB + 3];
   __shared__ __attribute__ ((aligned (16))) double s_delta[WAVES][SL_TILE * 8 * CV];     // sample differences of 16 steps
+  __shared__ int s_nzd[WAVES][SL_TILE * CV];            // per transition and channel: non-zero samples entering minus leaving
+  __shared__ int s_x0[WAVES][SL_TILE * CV];             // per step and channel: the first sample of the window is non-zero
   for (int i = threadIdx.x; i < 512; i += blockDim.x)
     s_tw[i] = t.tw512[i];
   {
@@ -1200,12 +1202,28 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 
   // ---- first offset: plain (unwindowed) DFT bins from the wave FFT
   double2 R[CV][2];
+  // Non-zero samples of the current window per channel.  A window of digital silence has an exactly zero spectrum in the
+  // reference (-96 dB per band, wmcommon.hh:204-224); the recurrence below would arrive there with the rounding residue of
+  // what it slid over (1e-15 of the previous content = -300 dB), so the bins are reset when the count reaches zero.
+  // The same holds when the only non-zero sample sits at window position 0, whose Hann weight is exactly 0.
+  int nz[CV];
   {
     float in[2][16];
     if (CV == 2)
       fetch_stereo (a.pcm, base, 1024, lane, in[0], in[1]);
     else
       fetch_channel (a.pcm, base, 1024, 1, 0, lane, in[0]);
+#pragma unroll
+    for (int c = 0; c < CV; c++)
+      {
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 16; j++)
+          cnt += in[c][j] != 0.f;
+        for (int o = 32; o > 0; o >>= 1)
+          cnt += __shfl_xor (cnt, o);
+        nz[c] = cnt;
+      }
 #pragma unroll
     for (int c = 0; c < CV; c++)
       {
@@ -1254,13 +1272,26 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
         const int trans = SL_TILE * q + e / (8 * C);
         const bool need = trans + 1 < count;
         f_in[i] = need ? a.pcm[(s0 + 1024) * C + e] : 0.f;
-        f_out[i] = need ? a.pcm[s0 * C + e] : 0.f;
+        f_out[i] = trans < count ? a.pcm[s0 * C + e] : 0.f;       // the first 8 samples of the window of step `trans`
       }
   };
   auto publish_block = [&] () {
 #pragma unroll
     for (int i = 0; i < FPL; i++)
       s_delta[wave][lane * FPL + i] = double (f_in[i]) - double (f_out[i]);
+    // a lane holds FPL = 2 C consecutive values (transition * 8 + j) * C + c: two j of every channel; 4 lanes = one transition
+#pragma unroll
+    for (int c = 0; c < CV; c++)
+      {
+        int dn = (f_in[c] != 0.f) - (f_out[c] != 0.f) + (f_in[CV + c] != 0.f) - (f_out[CV + c] != 0.f);
+        dn += __shfl_xor (dn, 1);
+        dn += __shfl_xor (dn, 2);
+        if ((lane & 3) == 0)
+          {
+            s_nzd[wave][(lane >> 2) * CV + c] = dn;
+            s_x0[wave][(lane >> 2) * CV + c] = f_out[c] != 0.f;   // window position 0 of that step: weight 0 in the Hann window
+          }
+      }
   };
   fetch_block (0);
   unsigned long long have_mask = 0;      // offsets 0..63
@@ -1288,6 +1319,13 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 #pragma unroll
           for (int c = 0; c < CV; c++)
             {
+              // every sample that carries weight is zero (position 0 has none): exactly zero frame in the reference
+              if (nz[c] - s_x0[wave][(step % SL_TILE) * CV + c] == 0)
+                {
+                  dbA = __fadd_rn (dbA, -96.f);
+                  dbB = __fadd_rn (dbB, -96.f);
+                  continue;
+                }
               // neighbours: R[kA - 1] lives in lane - 1 (its kB), R[kB + 1] in lane + 1 (its kA): DPP wave shifts
               const double2 up = make_double2 (dpp_from_lower_lane (R[c][1].x), dpp_from_lower_lane (R[c][1].y));
               const double2 dn = make_double2 (dpp_from_upper_lane (R[c][0].x), dpp_from_upper_lane (R[c][0].y));
@@ -1355,6 +1393,9 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
                   const double2 r = tw[b][7];
                   R[c][b] = make_double2 (acc[b].x * r.x - acc[b].y * r.y, acc[b].x * r.y + acc[b].y * r.x);
                 }
+              nz[c] += s_nzd[wave][(step % SL_TILE) * CV + c];
+              if (nz[c] == 0)
+                R[c][0] = R[c][1] = make_double2 (0.0, 0.0);
             }
         }
       if (step % SL_TILE == SL_TILE - 1)

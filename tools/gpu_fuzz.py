@@ -1,0 +1,68 @@
+"""Randomised cross-check on a GPU box: short clips with random lengths, channel counts, digital silence at the edges and in
+the middle, watermarked or not -- `get` through the HIP path against the oracle (pattern lists must be identical), and the
+variable-ratio resampler against the restated zita class on random ratios / lengths."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import torch
+import audiowmark_amd as awm
+import _oracle as orc
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+rng = np.random.default_rng(seed)
+ctx = awm.Context()
+PAY = "0123456789abcdef0011223344556677"
+
+
+def key(p):
+    return (round(p["time"], 9), p["sync_index"], p["type"], p["block_type"], p["bits"])
+
+
+bad = 0
+t0 = time.time()
+for case in range(n_cases):
+    ch = int(rng.choice([1, 2, 2, 2, 3]))
+    seconds = float(rng.uniform(8, 70))
+    n = int(seconds * 44100)
+    x = rng.uniform(-1, 1, (n, ch)).astype(np.float32) * float(rng.choice([1.0, 0.3, 0.05]))
+    marked = rng.random() < 0.8
+    if marked:
+        x = orc.add(None, x, ch, PAY).reshape(-1, ch)
+    lead = int(rng.choice([0, 0, 1, 1000, 44100, 5 * 44100]))
+    trail = int(rng.choice([0, 0, 1, 777, 3 * 44100]))
+    x = np.concatenate([np.zeros((lead, ch), np.float32), x, np.zeros((trail, ch), np.float32)])
+    if rng.random() < 0.3:                                 # a hole of digital silence inside
+        a = int(rng.integers(0, len(x) - 44100))
+        x[a:a + int(rng.integers(1, 44100))] = 0
+    if rng.random() < 0.2:
+        x[:, ch - 1] = 0                                   # one silent channel
+    xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    got = ctx.get_watermark(None, xd)
+    want = orc.get(None, x, ch)
+    dq = max([abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(got, want)] + [0.0])
+    ok = [key(p) for p in got] == [key(p) for p in want] and dq < 1e-4
+    hits = sum(p["bits"] == PAY for p in got)
+    print("case %2d: %d ch %5.1f s lead %6d trail %6d marked %d -> %2d patterns, %d with the payload, max |dq| %.2g, %s"
+          % (case, ch, len(x) / 44100, lead, trail, marked, len(got), hits, dq, "identical" if ok else "DIFFERENT"), flush=True)
+    if not ok:
+        bad += 1
+        for g, w in zip(got, want):
+            if key(g) != key(w) or abs(g["sync_quality"] - w["sync_quality"]) >= 1e-4:
+                print("    gpu", key(g), g["sync_quality"], "\n    orc", key(w), w["sync_quality"])
+                break
+for case in range(n_cases):
+    ch = int(rng.choice([1, 2, 3]))
+    n = int(rng.integers(1, 300000))
+    ratio = float(rng.choice([rng.uniform(0.8, 1.25), rng.uniform(0.4, 0.63), rng.uniform(1 / 16 + 1e-3, 3.0)]))
+    x = rng.uniform(-1, 1, (n, ch)).astype(np.float32)
+    got = ctx.resample_ratio(torch.from_numpy(x).cuda(), ratio).cpu().numpy()
+    want = orc.resample_ratio(x, ch, ratio).reshape(-1, ch)
+    d = float(np.abs(got - want).max()) if got.shape == want.shape and got.size else (0.0 if got.shape == want.shape else 1.0)
+    ok = got.shape == want.shape and d <= 1e-6
+    print("resample case %2d: %d ch %6d frames ratio %.6f -> %6d frames, max |diff| %.2g %s"
+          % (case, ch, n, ratio, got.shape[0], d, "ok" if ok else "DIFFERENT"), flush=True)
+    bad += not ok
+print("%d cases different, %.1f s" % (bad, time.time() - t0))
+sys.exit(1 if bad else 0)
