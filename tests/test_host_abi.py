@@ -45,6 +45,23 @@ def test_host_tables_match_oracle(key):
             assert ((fm[ab] != 0).sum(axis=1) == 60).all()            # 30 up + 30 down bands in every frame
 
 
+def test_linear_mode_tables_match_oracle():
+    """--linear (Params::mix = false): per-frame band lists instead of the shuffled mix entries (reference wmadd.cc:115-126)"""
+    key = KEYS[-1]
+    awm.set_params(mix=False)
+    orc.set_params(mix=False)
+    try:
+        fm = awm.tab_frame_mod(key, PAY)
+        for ab in (0, 1):
+            want = orc.frame_mod(key, PAY, ab)
+            assert np.array_equal(fm[ab], want[:, 20:101])
+            assert ((fm[ab] != 0).sum(axis=1) == 60).all()
+    finally:
+        awm.set_params()
+        orc.set_params()
+    assert not np.array_equal(awm.tab_frame_mod(key, PAY)[0], fm[0])          # the default (mix) tables are different ones
+
+
 def test_windows_and_conv_encode_match_oracle():
     assert np.array_equal(awm.tab_window(1024), orc.window(1024))
     assert np.array_equal(awm.tab_synth_window(), orc.synth_window())
