@@ -182,4 +182,81 @@ db_from_complex (float2 v)
   return -96.f;
 }
 
+// ---- double precision forward transform (same flow as fft512_forward; used once per row by the sliding DFT of the refinement,
+// whose recurrence carries the rounding of its first transform through all 65 fine offsets) ---------------------------------
+__device__ __forceinline__ double2 caddd (double2 a, double2 b) { return make_double2 (a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 csubd (double2 a, double2 b) { return make_double2 (a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 cmuld (double2 a, double2 b) { return make_double2 (a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+
+__device__ __forceinline__ void
+radix4_fwd_d (double2& x0, double2& x1, double2& x2, double2& x3)
+{
+  const double2 t0 = caddd (x0, x2), t1 = csubd (x0, x2), t2 = caddd (x1, x3), t3 = csubd (x1, x3);
+  const double2 t3r = make_double2 (t3.y, -t3.x);             // t3 * (-i)
+  x0 = caddd (t0, t2);
+  x2 = csubd (t0, t2);
+  x1 = caddd (t1, t3r);
+  x3 = csubd (t1, t3r);
+}
+
+__device__ __forceinline__ void
+radix8_fwd_d (double2 (&a)[8])
+{
+  radix4_fwd_d (a[0], a[2], a[4], a[6]);
+  radix4_fwd_d (a[1], a[3], a[5], a[7]);
+  constexpr double r = 0.70710678118654752440;
+  const double2 g1 = a[3], g2 = a[5], g3 = a[7];
+  const double2 t1 = make_double2 (g1.x + g1.y, g1.y - g1.x);   // * (1 - i)
+  const double2 f2 = make_double2 (g2.y, -g2.x);                // * -i
+  const double2 t3 = make_double2 (g3.y - g3.x, -g3.x - g3.y);  // * (-1 - i)
+  const double2 e0 = a[0], e1 = a[2], e2 = a[4], e3 = a[6], o0 = a[1];
+  a[0] = caddd (e0, o0); a[4] = csubd (e0, o0);
+  a[1] = make_double2 (fma (t1.x, r, e1.x), fma (t1.y, r, e1.y));
+  a[5] = make_double2 (fma (-t1.x, r, e1.x), fma (-t1.y, r, e1.y));
+  a[2] = caddd (e2, f2); a[6] = csubd (e2, f2);
+  a[3] = make_double2 (fma (t3.x, r, e3.x), fma (t3.y, r, e3.y));
+  a[7] = make_double2 (fma (-t3.x, r, e3.x), fma (-t3.y, r, e3.y));
+}
+
+// in / out layout as fft512_forward; xbuf: XBUF_ELEMS double2 (9216 B) private to the wave; tw512: e^{-2 pi i k / 512} in double
+__device__ __forceinline__ void
+fft512_forward_d (double2 (&z)[8], double2 *xbuf, const double2 *tw512, int lane)
+{
+  radix8_fwd_d (z);
+#pragma unroll
+  for (int kb = 1; kb < 8; kb++)
+    z[kb] = cmuld (z[kb], tw512[lane * kb]);
+#pragma unroll
+  for (int kb = 0; kb < 8; kb++)
+    xbuf[kb * XROW + lane] = z[kb];
+  wave_sync();
+  const int lo = lane & 7, hi = lane >> 3;
+#pragma unroll
+  for (int nd = 0; nd < 8; nd++)
+    z[nd] = xbuf[hi * XROW + nd * 8 + lo];
+  wave_sync();
+  radix8_fwd_d (z);
+#pragma unroll
+  for (int kd = 1; kd < 8; kd++)
+    z[kd] = cmuld (z[kd], tw512[8 * lo * kd]);
+#pragma unroll
+  for (int kd = 0; kd < 8; kd++)
+    xbuf[hi * XROW + 9 * kd + lo] = z[kd];
+  wave_sync();
+#pragma unroll
+  for (int nc = 0; nc < 8; nc++)
+    z[nc] = xbuf[hi * XROW + 9 * lo + nc];
+  wave_sync();
+  radix8_fwd_d (z);
+}
+
+__device__ __forceinline__ double2
+real_split_d (double2 zk, double2 zm, double2 w)
+{
+  const double2 a = make_double2 (zk.x + zm.x, zk.y - zm.y);   // Z[k] + conj Z[512-k]
+  const double2 b = make_double2 (zk.x - zm.x, zk.y + zm.y);   // Z[k] - conj Z[512-k]
+  const double2 t = cmuld (w, b);
+  return make_double2 (0.5 * (a.x + t.y), 0.5 * (a.y - t.x));
+}
+
 } // namespace awmk

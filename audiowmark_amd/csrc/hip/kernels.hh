@@ -15,6 +15,7 @@ struct DevTables
   const float  *window;   // normalised von Hann analysis window, 1024 (reference wmcommon.cc:68-89)
   const float  *synth;    // synthesis window, 3072 (reference wmadd.cc:177-206)
   const double2 *slide;   // [84 bins 19..102][9]: e^{-2 pi i k j / 1024}, j = 0..7, and e^{+2 pi i 8 k / 1024} at j = 8
+  const double2 *tw512d;  // e^{-2 pi i k / 512} in double (first transform of a refinement row)
 };
 
 /* K1: FFTAnalyzer::run_fft / fft_range */

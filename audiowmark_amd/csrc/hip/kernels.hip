@@ -1153,18 +1153,15 @@ dpp_from_upper_lane (double v)                                // lane i receives
   return __hiloint2double (hi, lo);
 }
 
-template<int CV> __global__ void __launch_bounds__ (64 * WAVES)
+template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
 sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 {
-  __shared__ float2 s_tw[512];
-  __shared__ __attribute__ ((aligned (16))) float s_scratch[WAVES][NB * SL_TILE];      // FFT exchange tile (>= 576 float2) / dB tile [offset][band]
-  static_assert (NB * SL_TILE * sizeof (float) >= XBUF_ELEMS * sizeof (float2), "scratch too small for the FFT tile");
+  constexpr int SCRATCH_FLOATS = XBUF_ELEMS * 4 > NB * SL_TILE ? XBUF_ELEMS * 4 : NB * SL_TILE;
+  __shared__ __attribute__ ((aligned (16))) float s_scratch[WAVES][SCRATCH_FLOATS];    // FFT exchange tile (576 double2) / dB tile [offset][band]
   __shared__ unsigned char s_pos[WAVES][NB + 3];
   __shared__ __attribute__ ((aligned (16))) double s_delta[WAVES][SL_TILE * 8 * CV];     // sample differences of 16 steps
   __shared__ int s_nzd[WAVES][SL_TILE * CV];            // per transition and channel: non-zero samples entering minus leaving
   __shared__ int s_x0[WAVES][SL_TILE * CV];             // per step and channel: the first sample of the window is non-zero
-  for (int i = threadIdx.x; i < 512; i += blockDim.x)
-    s_tw[i] = t.tw512[i];
   {
     // gathered output (refinement): which row of its 60 the stream's band b goes to; identity otherwise
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -1194,7 +1191,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
         a.have[out_slot * a.have_stream_stride + 64] = 0;
       return;
     }
-  float2 *xbuf = reinterpret_cast<float2 *> (s_scratch[wave]);
+  double2 *xbuf = reinterpret_cast<double2 *> (s_scratch[wave]);
   float *tile = s_scratch[wave];
   const int C = CV;
   const bool bins = lane < 42;                                // lane holds bins kA = 19 + 2 lane, kB = kA + 1
@@ -1208,30 +1205,27 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
   // The same holds when the only non-zero sample sits at window position 0, whose Hann weight is exactly 0.
   int nz[CV];
   {
-    float in[2][16];
-    if (CV == 2)
-      fetch_stereo (a.pcm, base, 1024, lane, in[0], in[1]);
-    else
-      fetch_channel (a.pcm, base, 1024, 1, 0, lane, in[0]);
 #pragma unroll
     for (int c = 0; c < CV; c++)
       {
+        // one channel at a time (16 samples per lane live instead of 32: the double transform below needs the registers)
+        float in[16];
+        fetch_channel (a.pcm, base, 1024, CV, c, lane, in);
         int cnt = 0;
 #pragma unroll
         for (int j = 0; j < 16; j++)
-          cnt += in[c][j] != 0.f;
+          cnt += in[j] != 0.f;
         for (int o = 32; o > 0; o >>= 1)
           cnt += __shfl_xor (cnt, o);
         nz[c] = cnt;
-      }
-#pragma unroll
-    for (int c = 0; c < CV; c++)
-      {
-        float2 z[8];
+        // in double: the recurrence carries the rounding of this transform through all fine offsets, and the Hann window is
+        // applied in the frequency domain afterwards -- a float transform (1e-7 of the unwindowed content) shows where the
+        // windowed content is tiny, e.g. for windows that slide into a gap of digital silence
+        double2 z[8];
 #pragma unroll
         for (int j = 0; j < 8; j++)
-          z[j] = make_float2 (in[c][2 * j], in[c][2 * j + 1]);
-        fft512_forward (z, xbuf, s_tw, lane);
+          z[j] = make_double2 (double (in[2 * j]), double (in[2 * j + 1]));
+        fft512_forward_d (z, xbuf, t.tw512d, lane);
         xbuf[0 * 64 + lane] = z[0];
         xbuf[1 * 64 + lane] = z[1];
         xbuf[6 * 64 + lane] = z[6];
@@ -1241,8 +1235,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
         for (int b = 0; b < 2; b++)
           {
             const int k = kA + b;
-            const float2 r = real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], t.tw1024[k]);
-            R[c][b] = make_double2 (double (r.x), double (r.y));
+            R[c][b] = real_split_d (xbuf[zpos (k)], xbuf[zpos (512 - k)], t.slide[(k - 19) * 9 + 1]);
           }
         wave_sync();
       }

@@ -428,9 +428,16 @@ awm_ctx_create (int device, awm_ctx **ctx_out)
       slide.push_back (std::cos (2 * M_PI * k * 8 / 1024));
       slide.push_back (std::sin (2 * M_PI * k * 8 / 1024));
     }
+  const size_t off_tw512d = slide.size();
+  for (int k = 0; k < 512; k++)
+    {
+      slide.push_back (std::cos (-2 * M_PI * k / 512));
+      slide.push_back (std::sin (-2 * M_PI * k / 512));
+    }
   if (int rc = upload (ctx->tab_slide, slide.data(), slide.size() * sizeof (double), ctx->stream))
     return rc;
   ctx->tabs.slide = ctx->tab_slide.as<double2>();
+  ctx->tabs.tw512d = reinterpret_cast<const double2 *> (ctx->tab_slide.as<double>() + off_tw512d);
   if (int rc = upload (ctx->tab_mem, blob.data(), blob.size() * sizeof (float), ctx->stream))
     return rc;
   const float *base = ctx->tab_mem.as<float>();

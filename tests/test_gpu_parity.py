@@ -647,12 +647,11 @@ def test_linear_mode(gpu):
 
 
 def test_digital_silence_inside_the_stream(gpu):
-    """Gaps of digital silence inside the material.  A window of zeros has an exactly zero spectrum in the reference (-96 dB
-    per band), and so has a window whose only non-zero sample sits at position 0 (Hann weight 0): the sliding DFT of the
-    refinement resets its bins / forces -96 dB there (found by tools/gpu_fuzz.py).  Sync positions, block types and decoded
-    bits must be identical.  Qualities: windows that slide INTO a gap keep the float rounding of their first transform
-    (1e-7 of the content they started on) while the windowed content fades to nothing at the window's edge, so single
-    qualities may be off by a few 1e-4 on such material (known deviations) -- bounded here at 1e-3."""
+    """Gaps of digital silence inside the material (found by the randomised cross-check tools/gpu_fuzz.py).  A window of zeros
+    has an exactly zero spectrum in the reference (-96 dB per band), and so has a window whose only non-zero sample sits at
+    position 0 (Hann weight 0): the sliding DFT of the refinement resets its bins / forces -96 dB there.  Windows that slide
+    INTO a gap keep loud samples only at their low-weight edge: the first transform of a row is done in double, else its
+    rounding (1e-7 of the unwindowed content) shows there (2.4e-4 in a sync quality on this material with a float transform)."""
     rng = np.random.default_rng(77)
     for ch, marked in ((2, False), (1, True), (2, True)):
         x = noise(500 + ch, 66 * 44100, ch)
@@ -667,15 +666,14 @@ def test_digital_silence_inside_the_stream(gpu):
         got = gpu.ctx.get_watermark(None, gpu.dev(x))
         want = orc.get(None, x, ch)
         assert [pkey(p) for p in got] == [pkey(p) for p in want]
-        dq = [abs(g["sync_quality"] - w["sync_quality"]) for g, w in zip(got, want)] + [0]
-        assert max(dq) < 1e-3 and sorted(dq)[len(dq) // 2] < QUALITY_TOL
+        assert max([abs(g["sync_quality"] - w["sync_quality"]) for g, w in zip(got, want)] + [0]) < QUALITY_TOL
 
 
 def test_one_clean_gap_is_exact(gpu):
-    """one gap that windows only LEAVE on the fine grid of the refinement (and full windows of silence): exact again"""
+    """one long gap: full windows of silence, windows entering and leaving it"""
     x = noise(503, 66 * 44100, 2)
     x[20 * 44100:24 * 44100] = 0
     got = gpu.ctx.get_watermark(None, gpu.dev(x))
     want = orc.get(None, x, 2)
     assert [pkey(p) for p in got] == [pkey(p) for p in want]
-    assert max([abs(g["sync_quality"] - w["sync_quality"]) for g, w in zip(got, want)] + [0]) < 1e-4
+    assert max([abs(g["sync_quality"] - w["sync_quality"]) for g, w in zip(got, want)] + [0]) < QUALITY_TOL
