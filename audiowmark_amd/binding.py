@@ -299,6 +299,13 @@ def tab_synth_window():
     return out
 
 
+def gen_noise(key, n_values):
+    """`audiowmark test-gen-noise` samples (reference audiowmark.cc:399-417): interleaved float32 in [-1, 1)."""
+    out = np.zeros(n_values, np.float32)
+    lib.awm_test_gen_noise(key_bytes(key), C.c_size_t(n_values), _np(out))
+    return out
+
+
 def conv_encode(block_type, bits):
     bits = np.ascontiguousarray(bits, np.int32)
     out = np.zeros((len(bits) + 15) * 12, np.int32)
@@ -534,9 +541,14 @@ class Context:
         return buf
 
     def _patterns(self, fn, what, *args, max_out=4096):
-        buf = self._pattern_buffer(max_out)
-        cnt = _check(fn(*args, max_out, C.cast(buf, C.c_void_p)), what)
-        return patterns_to_dicts(buf, min(cnt, max_out))
+        # the C ABI returns the number of patterns FOUND; when that exceeds the buffer the call is repeated with a buffer
+        # that holds them all (never a silently truncated list)
+        while True:
+            buf = self._pattern_buffer(max_out)
+            cnt = _check(fn(*args, max_out, C.cast(buf, C.c_void_p)), what)
+            if cnt <= max_out:
+                return patterns_to_dicts(buf, cnt)
+            max_out = cnt
 
     # get_watermark on resident PCM (chunk loop, BlockDecoder, ClipDecoder, merge, sort)
     def get_watermark(self, key, pcm):
@@ -554,10 +566,14 @@ class Context:
         ptrs = (C.c_void_p * len(clips))(*[_dev_ptr(c) for c in clips])
         frames = (C.c_size_t * len(clips))(*[s[0] for s in shapes])
         n_out = (C.c_int * len(clips))()
-        buf = self._pattern_buffer(len(clips) * max_out_per_clip)
-        _check(lib.awm_get_watermark_batch_d(self._h, key_bytes(key), len(clips), ptrs, frames, ch, n_threads, max_out_per_clip,
-                                             C.cast(buf, C.c_void_p), n_out), "awm_get_watermark_batch_d")
-        return [patterns_to_dicts(buf, min(n_out[i], max_out_per_clip), i * max_out_per_clip) for i in range(len(clips))]
+        while True:
+            buf = self._pattern_buffer(len(clips) * max_out_per_clip)
+            _check(lib.awm_get_watermark_batch_d(self._h, key_bytes(key), len(clips), ptrs, frames, ch, n_threads, max_out_per_clip,
+                                                 C.cast(buf, C.c_void_p), n_out), "awm_get_watermark_batch_d")
+            most = max(n_out)
+            if most <= max_out_per_clip:
+                return [patterns_to_dicts(buf, n_out[i], i * max_out_per_clip) for i in range(len(clips))]
+            max_out_per_clip = most           # a clip found more patterns than a slot holds: repeat with slots that fit
 
     def decode_chunks(self, key, pcm, chunks, first_is_stream_start, max_out=8192):
         """decode() of several chunks [(first_frame, n_frames), ...] of one resident buffer; returns one pattern list per
@@ -565,13 +581,17 @@ class Context:
         n, ch = _pcm_shape(pcm)
         first = np.array([c[0] for c in chunks], np.uint64)
         count = np.array([c[1] for c in chunks], np.uint64)
-        buf = self._pattern_buffer(max_out)
-        which = np.zeros(max_out, np.int32)
-        cnt = _check(lib.awm_decode_chunks_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, len(chunks), _np(first), _np(count),
-                                             int(first_is_stream_start), max_out, C.cast(buf, C.c_void_p), _np(which)),
-                     "awm_decode_chunks_d")
+        while True:
+            buf = self._pattern_buffer(max_out)
+            which = np.zeros(max_out, np.int32)
+            cnt = _check(lib.awm_decode_chunks_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, len(chunks), _np(first), _np(count),
+                                                 int(first_is_stream_start), max_out, C.cast(buf, C.c_void_p), _np(which)),
+                         "awm_decode_chunks_d")
+            if cnt <= max_out:
+                break
+            max_out = cnt
         out = [[] for _ in chunks]
-        for i, d in enumerate(patterns_to_dicts(buf, min(cnt, max_out))):
+        for i, d in enumerate(patterns_to_dicts(buf, cnt)):
             out[which[i]].append(d)
         return out
 
@@ -581,13 +601,15 @@ class Context:
         n, ch = _pcm_shape(pcm)
         first = np.array([c[0] for c in chunks], np.uint64)
         count = np.array([c[1] for c in chunks], np.uint64)
-        out = np.zeros(max_out, PATTERN_DTYPE)
-        which = np.zeros(max_out, np.int32)
-        cnt = _check(lib.awm_decode_chunks_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, len(chunks), _np(first), _np(count),
-                                             int(first_is_stream_start), max_out, out.ctypes.data_as(C.c_void_p), _np(which)),
-                     "awm_decode_chunks_d")
-        cnt = min(cnt, max_out)
-        return out[:cnt], which[:cnt]
+        while True:
+            out = np.zeros(max_out, PATTERN_DTYPE)
+            which = np.zeros(max_out, np.int32)
+            cnt = _check(lib.awm_decode_chunks_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, len(chunks), _np(first), _np(count),
+                                                 int(first_is_stream_start), max_out, out.ctypes.data_as(C.c_void_p), _np(which)),
+                         "awm_decode_chunks_d")
+            if cnt <= max_out:
+                return out[:cnt], which[:cnt]
+            max_out = cnt
 
     def decode_chunk(self, key, pcm, first_chunk=True):
         n, ch = _pcm_shape(pcm)

@@ -117,7 +117,12 @@ struct SyncTableDev
   // (frame for the approximate search, want-list position for the refinement); wave-uniform -> scalar loads
   const int *packed;
   int        rows_per_bit;
+  // K5w only (approximate search): [12 chains = sync bit x (up, down)][rows][8] words = the chain's 30 bands of the row as bytes,
+  // then the frame of the chain's NEXT row as u16 (0xffff: none): one 32-byte scalar load per sync frame
+  const unsigned *chains = nullptr;
 };
+/* host side of SyncTableDev::chains from a [6][rows][64] packed table */
+void pack_scan_chains (const int *packed, int rows_per_bit, unsigned *out /* [12 * rows_per_bit * 8] */);
 struct SyncScanArgs
 {
   const float *db;
@@ -134,8 +139,8 @@ struct SyncScanArgs
   SyncTableDev table;
 };
 hipError_t launch_sync_scan (hipStream_t st, const SyncScanArgs& a);
-/* K5w: same result for band-major planes (row_stride == 1, band_stride % 64 == 0): dB matrix streamed through an LDS ring.
- * total_frames = frames a candidate spans (2226 BLOCK / 4452 CLIP). */
+/* K5w (scan.hip): same result for band-major planes (row_stride == 1, band_stride % 64 == 0, table.chains set): the dB
+ * matrix streams through an LDS ring, four candidates per lane.  total_frames = frames a candidate spans (2226 BLOCK / 4452 CLIP). */
 hipError_t launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames);
 
 /* K5g: sync_decode over the gathered layout K4s writes for the refinement: plane (candidate) p holds

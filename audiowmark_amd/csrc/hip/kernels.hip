@@ -1501,137 +1501,6 @@ sync_scan_kernel (SyncScanArgs a)
     }
 }
 
-/* K5w: the same computation for the approximate search, where the planes are band-major dB matrices
- * (row_stride == 1): every candidate of a 64-candidate tile walks frames tile .. tile + 2226 (+ 64), and so do its five
- * sibling waves (one per sync bit).  A workgroup owns two adjacent tiles (12 waves: tile x sync bit) and streams the
- * 81-band matrix through a ring of 3 x 64 frames in LDS exactly once (coalesced 256 B rows): tile 1 needs at step k
- * what tile 0 needs at step k + 1, so one extra slot serves both.  All 30 600 gathers per candidate are served from LDS
- * instead of the L2, every accumulation stays in the reference's order.  Measured (60 min stereo, MI355X): one tile per
- * workgroup (6 waves, 41 KB, 18 waves/CU) 3.2 ms, two tiles (62 KB, 24 waves/CU) 2.1 ms -- the kernel is bound by
- * the number of waves that keep LDS reads in flight, not by LDS bandwidth (38 %) or VALU (33 %). */
-__global__ void __launch_bounds__ (768)
-sync_scan_window_kernel (SyncScanArgs a, int total_frames)
-{
-  constexpr int RING = 192;
-  __shared__ __attribute__ ((aligned (16))) float s_win[NB * RING];
-  float (*s_u)[64] = reinterpret_cast<float (*)[64]> (s_win);           // [12][64], alias the dead ring
-  float (*s_d)[64] = reinterpret_cast<float (*)[64]> (s_win + 12 * 64);
-  int   *s_n = reinterpret_cast<int *> (s_win + 24 * 64);
-  const int lane = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane (threadIdx.y);
-  const int bit = wv % 6, sub = wv / 6;
-  const int tid = threadIdx.y * 64 + threadIdx.x;
-  const long long plane = blockIdx.y;
-  const long long n_tiles = (a.n_lanes + 127) / 128;
-  const long long per_xcd = (n_tiles + 7) / 8;
-  const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
-  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
-    return;                                               // uniform for the workgroup
-  const long long sf0 = tile * 128;
-  const float *db = a.db + plane * a.plane_stride;
-  const long long ld = a.band_stride;
-  const int R = a.table.rows_per_bit;
-  const_int_ptr tab = (const_int_ptr) (a.table.packed + (size_t) bit * R * 64);
-
-  auto load_slot = [&] (int h) {
-    const long long base = sf0 + 64LL * h;
-    float *dst = s_win + 64 * (h % 3);
-    const bool in_range = base + 64 <= ld;
-    for (int idx = tid; idx < NB * 16; idx += 768)
-      {
-        const int band = idx >> 4, q = idx & 15;
-        float4 v = make_float4 (0.f, 0.f, 0.f, 0.f);
-        if (in_range)
-          v = *reinterpret_cast<const float4 *> (db + band * ld + base + 4 * q);
-        *reinterpret_cast<float4 *> (dst + band * RING + 4 * q) = v;
-      }
-  };
-
-  float umag = 0.f, dmag = 0.f;
-  int n = 0, r = 0;
-  int fr = R > 0 ? tab[60] : 0x7fffffff;                  // frame of row r; the table row carries its successor's ([61])
-  load_slot (0);
-  load_slot (1);
-  for (int k = 0; 64 * k < total_frames; k++)
-    {
-      load_slot (k + 2);
-      __syncthreads();
-      const int ring0 = 64 * ((k + sub) % 3) - 64 * k;      // + fr = ring position of this wave's lane 0 (before the wrap)
-      while (fr < 64 * (k + 1))
-        {
-          const_int_ptr tr = tab + r * 64;
-          int phys = fr + ring0 + lane;                      // < 128 + 64 + 64
-          phys -= phys >= RING ? RING : 0;
-          float uv[30], dv[30];
-#pragma unroll
-          for (int i = 0; i < 30; i++)
-            {
-              uv[i] = s_win[tr[i] * RING + phys];
-              dv[i] = s_win[tr[30 + i] * RING + phys];
-            }
-#pragma unroll
-          for (int i = 0; i < 30; i++)
-            {
-              umag = __fadd_rn (umag, uv[i]);
-              dmag = __fadd_rn (dmag, dv[i]);
-            }
-          fr = tr[61];
-          n++;
-          r++;
-        }
-      __syncthreads();
-    }
-  s_u[wv][lane] = umag;
-  s_d[wv][lane] = dmag;
-  if (lane == 0)
-    s_n[wv] = n;
-  __syncthreads();
-  if (tid < 128)
-    {
-      const int t = tid >> 6, l = tid & 63;
-      const long long cand = sf0 + tid;
-      if (cand < a.n_lanes)
-        {
-          double q = 0;
-          int total = 0;
-          for (int b = 0; b < 6; b++)
-            {
-              const float um = s_u[t * 6 + b][l], dm = s_d[t * 6 + b][l];
-              float raw;
-              if (um == 0 || dm == 0)
-                raw = 0;
-              else if (um < dm)
-                raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
-              else
-                raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
-              const double rb = (b & 1) ? double (raw) : -double (raw);
-              q += rb * s_n[t * 6 + b];
-              total += s_n[t * 6 + b];
-            }
-          if (total)
-            q /= total;
-          q = q / a.min_delta / 2.9;
-          a.quality[plane * a.q_stride + cand] = q;
-        }
-    }
-}
-
-hipError_t launch_sync_scan (hipStream_t st, const SyncScanArgs& a);
-
-hipError_t
-launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames)
-{
-  if (a.n_lanes <= 0 || a.n_planes <= 0)
-    return hipSuccess;
-  if (a.row_stride != 1 || a.n_planes > 65535 || (a.band_stride & 63) || a.lane_count)
-    return hipErrorInvalidValue;
-  if (a.have)
-    return launch_sync_scan (st, a);                      // skipped (silent) frames: the generic kernel handles `have`
-  const long long px = ((a.n_lanes + 127) / 128 + 7) / 8;
-  hipLaunchKernelGGL (sync_scan_window_kernel, dim3 ((unsigned) (px * 8), (unsigned) a.n_planes), dim3 (64, 12), 0, st, a, total_frames);
-  return hipGetLastError();
-}
-
 hipError_t
 launch_sync_scan (hipStream_t st, const SyncScanArgs& a)
 {

@@ -1,0 +1,312 @@
+// scan.hip -- K5w: SyncFinder::sync_decode for every start frame of the approximate search
+// (reference syncfinder.cc:116-153 evaluated by search_approx, syncfinder.cc:171-256).
+//
+// Work: a candidate start frame c sums, for each of the 6 sync bits, the dB values of 30 "up" and 30 "down" bands of the
+// 85 (BLOCK) sync frames of that bit: umag += db[c + frame][up[i]], dmag += db[c + frame][down[i]] -- 12 chains of 2550
+// float additions per candidate whose ORDER is part of the result (sync qualities decide which positions are refined).
+// The only freedom is across candidates and across chains.
+//
+// Gathers.  The planes are band-major (db[band][frame], one plane per 256-sample shift), so the candidates c, c+1, ... of
+// one (sync frame, band) term are adjacent floats.  A lane owns FOUR adjacent candidates and fetches a term for all of them
+// with ONE ds_read_b128 from a ring of the matrix in LDS (256 B/clk/CU instead of the 128 B/clk of 4-byte gathers,
+// MI355X_MICROARCH.md, LDS table).  A 16-byte read must be 16-byte aligned, but the quad a lane needs starts at
+// frame + 4 lane, i.e. at any alignment j = frame mod 4: the lane reads the aligned quad that starts j floats earlier
+// (candidates 4 lane - j .. 4 lane - j + 3) and takes the elements that belong to its upper candidates from the lane
+// above through the DPP operand of the addition itself (v_add_f32_dpp wave_shl:1, no extra instruction).  Lane 63 has no
+// lane above: a wave delivers 252 of its 256 candidates, tiles advance by 252.
+//
+// Workgroup = one tile of 252 candidates: 12 CHAIN waves (sync bit x up / down; 4 accumulators per lane, 30 gathers + 120
+// additions per sync frame) and one LOADER wave.  There is no workgroup barrier in the steady state:
+//   * Ring: 7 chunks of 64 frames, chunk-major: s_win[slot][band (84, 81 used)][64 frames] = 150.5 KB.  One LDS-DMA
+//     instruction (global_load_lds_dwordx4: every lane names its own 16 source bytes, the destination is wave base +
+//     16 lane) moves 4 bands x 64 frames = 1 KiB of a chunk, 21 of them a whole chunk, without passing through registers.
+//   * The loader keeps two chunks in flight, publishes `loaded` when a chunk has landed, and issues the next one as soon as
+//     every chain has moved past the frames it replaces.  A chain checks before a sync frame that its 256 + 3 frames are
+//     resident and publishes the frame of its next row afterwards.  The six bits' sync frames are unevenly spread over the
+//     block; with a barrier per ring step the workgroup waited for the slowest bit a third of its time (round 1 kernel).
+//   * The row descriptor of the NEXT sync frame (30 band bytes + next frame: one 32-byte scalar load) is requested before
+//     the gathers of the current one.
+//
+// Measured on MI355X (tools/scan_bench, 55 500 frames x 4 shifts = 213 k candidates, bit-identical qualities):
+//   generic K5 (4-byte gathers from L2)               1.63 ms
+//   round 1 K5w (ring + barriers, ds_read_b32)        0.62 ms
+//   quads + DPP, still one barrier pair per ring step 0.61 ms   (the gathers were never the limit)
+//   this kernel                                       0.37 ms   = 70 TB/s of gathered terms; the shader clock is ~1.6 GHz
+//                                                                 under this load, where 256 B/clk/CU is 105 TB/s
+#include "kernels.hh"
+
+namespace awmk {
+
+namespace {
+
+constexpr int NB = 81;
+typedef const int __attribute__ ((address_space (4))) *const_int_ptr;
+typedef const unsigned __attribute__ ((address_space (4))) *const_uint_ptr;
+typedef int int4v __attribute__ ((ext_vector_type (4)));
+
+constexpr int QUAD_TILE = 252;          // candidates a wave delivers (see above)
+
+/* acc + (value the lane above holds): the compiler folds the DPP move into v_add_f32_dpp; rounding == __fadd_rn */
+__device__ __forceinline__ float
+add_from_upper_lane (float acc, float v)
+{
+  const int up = __builtin_amdgcn_update_dpp (0, __float_as_int (v), 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+  return __fadd_rn (acc, __int_as_float (up));
+}
+
+/* terms of one sync frame: J = (frame mod 4) selects which elements of the aligned quad are the lane's own */
+template<int J, int N> __device__ __forceinline__ void
+add_terms (float (&acc)[4], const float4 (&v)[N])
+{
+#pragma unroll
+  for (int i = 0; i < N; i++)
+    {
+      const float e[4] = { v[i].x, v[i].y, v[i].z, v[i].w };
+#pragma unroll
+      for (int c = 0; c < 4; c++)
+        {
+          if (c + J < 4)
+            acc[c] = __fadd_rn (acc[c], e[c + J]);
+          else
+            acc[c] = add_from_upper_lane (acc[c], e[c + J - 4]);
+        }
+    }
+}
+
+constexpr int NCHAIN = 12;
+constexpr int CH = 64;                  // frames per chunk
+constexpr int SLOTS = 7;
+constexpr int RINGF = SLOTS * CH;
+constexpr int BANDS_PAD = 84;           // 21 DMA pieces of 4 bands
+constexpr int SLOT_FLOATS = BANDS_PAD * CH;
+constexpr int PIECES = BANDS_PAD / 4;
+constexpr int INFLIGHT = 2;             // chunks the loader has in flight
+static_assert (RINGF >= 256 + CH + 3, "the slowest chain's 256 + 3 frames fit beside the chunk being replaced");
+static_assert (PIECES * INFLIGHT < 64, "vmcnt counts 63 outstanding operations");
+
+}  // namespace
+
+__global__ void __launch_bounds__ (832)
+sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
+{
+  __shared__ __attribute__ ((aligned (16))) float s_win[SLOTS * SLOT_FLOATS];
+  __shared__ __attribute__ ((aligned (16))) int s_progress[16];   // per chain: frame of its next sync frame (first frame it still needs); [12..15] = "done"
+  __shared__ int s_loaded;                                 // frames [.., s_loaded) have landed in the ring
+  const int lane = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane (threadIdx.y);
+  const int tid = threadIdx.y * 64 + threadIdx.x;
+  const long long plane = blockIdx.y;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8, every XCD gets one contiguous range of tiles so that the
+  // overlap of neighbouring tiles' frame ranges (90 %) is served by that XCD's L2
+  const long long n_tiles = (a.n_lanes + QUAD_TILE - 1) / QUAD_TILE;
+  const long long per_xcd = (n_tiles + 7) / 8;
+  const long long tile = (long long) (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+  if ((blockIdx.x >> 3) >= per_xcd || tile >= n_tiles)
+    return;                                               // uniform for the workgroup
+  const long long sf0 = tile * QUAD_TILE;                 // multiple of 4
+  const float *db = a.db + plane * a.plane_stride;
+  const long long ld = a.band_stride;                     // multiple of 64
+  const int R = a.table.rows_per_bit;
+
+  if (tid < 16)
+    s_progress[tid] = tid < NCHAIN ? 0 : 0x7fffffff;
+  if (tid == 16)
+    s_loaded = 0;
+  __syncthreads();
+
+  float acc[4] = { 0.f, 0.f, 0.f, 0.f };
+  if (wv == NCHAIN)
+    {
+      /* ---- loader ---- */
+      const int n_chunks = (total_frames + 256 + CH - 1) / CH;            // every chain's last sync frame + 256 lies below
+      const int lb = lane >> 4, lq = lane & 15;                           // lane -> (band within the piece, 4 frames)
+      auto issue = [&] (int c) {
+        const long long f0 = sf0 + (long long) c * CH;
+        // frames past the matrix are only seen by candidates that are dropped: read something that exists instead
+        const long long f = f0 + 4 * lq + 4 <= ld ? f0 + 4 * lq : 0;
+        float *dst = s_win + (c % SLOTS) * SLOT_FLOATS;
+#pragma unroll
+        for (int u = 0; u < PIECES; u++)
+          {
+            const int band = min (4 * u + lb, NB - 1);                    // the pad bands re-read band 80
+            __builtin_amdgcn_global_load_lds (db + band * ld + f, dst + u * 4 * CH, 16, 0, 0);
+          }
+      };
+      // The loader's own LDS accesses are written in assembly: hipcc orders every LDS access it knows of behind ALL
+      // outstanding LDS-DMA of the wave (s_waitcnt vmcnt(0)), which would leave no chunk in flight.
+      const unsigned progress_addr = (unsigned) (uintptr_t) (__attribute__ ((address_space (3))) int *) s_progress;
+      const unsigned loaded_addr = (unsigned) (uintptr_t) (__attribute__ ((address_space (3))) int *) &s_loaded;
+      int published = 0;
+      auto publish = [&] (int c) {
+        if ((c + 1) * CH <= published)
+          return;
+        published = (c + 1) * CH;
+        asm volatile ("ds_write_b32 %0, %1" :: "v" (loaded_addr), "v" (published) : "memory");
+      };
+      auto wait_room = [&] (int c) {
+        // the slot of chunk c still holds chunk c - SLOTS: wait until no chain needs its frames (a chain at frame f reads from f - 3 on)
+        const int need = (c + 1 - SLOTS) * CH + 3;
+        for (;;)
+          {
+            int4v p0, p1, p2;
+            asm volatile ("ds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\tds_read_b128 %2, %3 offset:32\n\ts_waitcnt lgkmcnt(0)"
+                          : "=&v" (p0), "=&v" (p1), "=&v" (p2) : "v" (progress_addr) : "memory");
+            const int m = min (min (min (p0.x, p0.y), min (p0.z, p0.w)), min (min (min (p1.x, p1.y), min (p1.z, p1.w)), min (min (p2.x, p2.y), min (p2.z, p2.w))));
+            if (__builtin_amdgcn_readfirstlane (m) >= need)
+              break;
+            // a chain that is about to need the chunks in flight must not wait for THIS wave: publish them before sleeping
+            asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+            publish (c - 1);
+            __builtin_amdgcn_s_sleep (1);
+          }
+      };
+      for (int c = 0; c < n_chunks; c++)
+        {
+          if (c >= INFLIGHT)
+            {
+              asm volatile ("s_waitcnt vmcnt(%0)" :: "n" (PIECES * (INFLIGHT - 1)) : "memory");   // vmcnt counts the pieces in issue order:
+              publish (c - INFLIGHT);                                                             // all but the youngest chunk(s) have landed
+            }
+          if (c >= SLOTS)
+            wait_room (c);
+          issue (c);
+        }
+      asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+      publish (n_chunks - 1);
+    }
+  else
+    {
+      /* ---- one chain ---- */
+      const_uint_ptr tab = (const_uint_ptr) (a.table.chains + (size_t) wv * R * 8);
+      int loaded = 0;
+      unsigned rowdesc[2][8];                              // 30 band bytes + u16 frame of the next row
+      auto load_row = [&] (unsigned (&w)[8], int r) {
+        const_uint_ptr tr = tab + r * 8;
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+          w[i] = tr[i];                                    // no arithmetic here: the scalar load stays in flight until the row starts
+      };
+      auto row = [&] (const unsigned (&w)[8], int fr) {
+        while (loaded < fr + 256)
+          {
+            loaded = __hip_atomic_load (&s_loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (loaded < fr + 256)
+              __builtin_amdgcn_s_sleep (1);
+          }
+        asm volatile ("" ::: "memory");
+        const int j = fr & 3;
+        int phys = (fr - j) % RINGF + 4 * lane;
+        phys -= phys >= RINGF ? RINGF : 0;
+        const char *base = reinterpret_cast<const char *> (s_win + (phys >> 6) * SLOT_FLOATS + (phys & 63));
+#pragma unroll
+        for (int h = 0; h < 3; h++)
+          {
+            float4 v[10];
+#pragma unroll
+            for (int i = 0; i < 10; i++)
+              {
+                const int t = 10 * h + i;
+                const unsigned band = (w[t >> 2] >> (8 * (t & 3))) & 0xff;
+                v[i] = *reinterpret_cast<const float4 *> (base + (band << 8));        // a band of a chunk = 64 floats
+              }
+            switch (j)
+              {
+              case 0:  add_terms<0> (acc, v); break;
+              case 1:  add_terms<1> (acc, v); break;
+              case 2:  add_terms<2> (acc, v); break;
+              default: add_terms<3> (acc, v); break;
+              }
+          }
+      };
+      auto done_with = [&] (int next_frame) {
+        // the gathers of this row have returned (their values were consumed): its frames may be replaced
+        asm volatile ("" ::: "memory");
+        if (lane == 0)
+          __hip_atomic_store (&s_progress[wv], next_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      };
+      auto next_frame = [] (const unsigned (&w)[8]) { const int f = int (w[7] >> 16); return f == 0xffff ? 0x7fffffff : f; };
+      int fr = R > 0 ? ((const_int_ptr) a.table.packed)[(size_t) (wv >> 1) * R * 64 + 60] : 0x7fffffff;
+      if (R > 0)
+        load_row (rowdesc[0], 0);
+      for (int r = 0; r < R; r += 2)
+        {
+          if (r + 1 < R)
+            load_row (rowdesc[1], r + 1);
+          row (rowdesc[0], fr);
+          fr = next_frame (rowdesc[0]);
+          done_with (fr);
+          if (r + 1 < R)
+            {
+              if (r + 2 < R)
+                load_row (rowdesc[0], r + 2);
+              row (rowdesc[1], fr);
+              fr = next_frame (rowdesc[1]);
+              done_with (fr);
+            }
+        }
+      done_with (0x7fffffff);
+    }
+  __syncthreads();                                         // ring is dead: chain sums -> s_sum[chain][candidate of the tile]
+
+  float (*s_sum)[256] = reinterpret_cast<float (*)[256]> (s_win);
+  if (wv < NCHAIN)
+    *reinterpret_cast<float4 *> (&s_sum[wv][4 * lane]) = make_float4 (acc[0], acc[1], acc[2], acc[3]);
+  __syncthreads();
+  if (tid < QUAD_TILE && sf0 + tid < a.n_lanes)
+    {
+      double q = 0;
+      for (int b = 0; b < 6; b++)
+        {
+          const float um = s_sum[2 * b][tid], dm = s_sum[2 * b + 1][tid];
+          // SyncFinder::bit_quality (reference syncfinder.cc:94-114): float division and subtraction
+          float raw;
+          if (um == 0 || dm == 0)
+            raw = 0;
+          else if (um < dm)
+            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
+          else
+            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
+          const double rb = (b & 1) ? double (raw) : -double (raw);
+          q += rb * R;                                    // frame_bit_count == rows of the bit: no frame is skipped here
+        }
+      if (R)
+        q /= 6 * R;
+      q = q / a.min_delta / 2.9;
+      a.quality[plane * a.q_stride + sf0 + tid] = q;
+    }
+}
+
+void
+pack_scan_chains (const int *packed, int rows_per_bit, unsigned *out)
+{
+  const int R = rows_per_bit;
+  for (int chain = 0; chain < 12; chain++)
+    for (int r = 0; r < R; r++)
+      {
+        const int *row = packed + ((size_t) (chain >> 1) * R + r) * 64;
+        unsigned char bytes[32];
+        for (int i = 0; i < 30; i++)
+          bytes[i] = (unsigned char) row[30 * (chain & 1) + i];
+        const unsigned next = r + 1 < R ? unsigned (row[61]) : 0xffffu;
+        bytes[30] = next & 0xff;
+        bytes[31] = next >> 8;
+        for (int i = 0; i < 8; i++)
+          out[((size_t) chain * R + r) * 8 + i] = bytes[4 * i] | bytes[4 * i + 1] << 8 | bytes[4 * i + 2] << 16 | unsigned (bytes[4 * i + 3]) << 24;
+      }
+}
+
+hipError_t
+launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames)
+{
+  if (a.n_lanes <= 0 || a.n_planes <= 0)
+    return hipSuccess;
+  if (a.row_stride != 1 || a.n_planes > 65535 || (a.band_stride & 63) || a.lane_count)
+    return hipErrorInvalidValue;
+  if (a.have || !a.table.chains || total_frames >= 0xffff)
+    return launch_sync_scan (st, a);                      // skipped (silent) frames: the generic kernel handles `have`
+  const long long px = ((a.n_lanes + QUAD_TILE - 1) / QUAD_TILE + 7) / 8;
+  hipLaunchKernelGGL (sync_scan_stream_kernel, dim3 ((unsigned) (px * 8), (unsigned) a.n_planes), dim3 (64, NCHAIN + 1), 0, st, a, total_frames);
+  return hipGetLastError();
+}
+
+}  // namespace awmk

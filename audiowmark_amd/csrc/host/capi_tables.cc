@@ -34,6 +34,16 @@ awm_tab_up_down (const uint8_t key[16], int stream, int frame, int up[30], int d
 }
 
 int
+awm_test_gen_noise (const uint8_t key[16], size_t n_values, float *out)
+{
+  // reference audiowmark.cc:399-417 (test-gen-noise): uniform [-1, 1) from the data_up_down stream, seed 0
+  Random rng (key_from_bytes (key), 0, Random::Stream::data_up_down);
+  for (size_t i = 0; i < n_values; i++)
+    out[i] = float (rng.random_double() * 2 - 1);
+  return 0;
+}
+
+int
 awm_tab_bit_pos (const uint8_t key[16], int pos[AWM_BLOCK_FRAMES])
 {
   BitPosGen gen (key_from_bytes (key));

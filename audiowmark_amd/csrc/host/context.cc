@@ -202,6 +202,9 @@ awm_ctx::get_key_tables (const Key& key)
       auto pr = pack_sync_table (s.host, want_pos);
       if (upload (s.packed_approx, pa.data(), pa.size() * sizeof (int), stream)) return nullptr;
       if (upload (s.packed_refine, pr.data(), pr.size() * sizeof (int), stream)) return nullptr;
+      std::vector<unsigned> pc (size_t (12) * s.host.rows_per_bit * 8);
+      awmk::pack_scan_chains (pa.data(), s.host.rows_per_bit, pc.data());
+      if (upload (s.chains_approx, pc.data(), pc.size() * sizeof (unsigned), stream)) return nullptr;
       if (upload (s.want_list_dev, s.want_list.data(), s.want_list.size() * sizeof (int), stream)) return nullptr;
       {
         const int R = s.host.rows_per_bit, NW = int (s.want_list.size());
@@ -462,6 +465,7 @@ awm_ctx_destroy (awm_ctx *ctx)
         {
           s.packed_approx.release();
           s.packed_refine.release();
+          s.chains_approx.release();
           s.want_list_dev.release();
           s.refine_perm.release();
           s.refine_pos.release();

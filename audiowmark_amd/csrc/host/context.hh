@@ -91,6 +91,7 @@ struct KeyTables
     SyncTable host;
     DevBuffer packed_approx;       // [6][rows][64] row = frame
     DevBuffer packed_refine;       // [6][rows][64] row = position in the want list
+    DevBuffer chains_approx;       // [12][rows][8] words: byte-packed per-chain rows of packed_approx for K5w (scan.hip)
     std::vector<int> want_list;    // sorted sync frames (510 or 1020)
     DevBuffer want_list_dev;
     DevBuffer refine_perm;         // [want rows] int: row w of the want list -> bit * rows_per_bit + j (K4s gathered layout)

@@ -150,13 +150,11 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   sa.q_stride = q_stride;
   sa.table.packed = kt->sync[clip].packed_approx.as<int>();
   sa.table.rows_per_bit = kt->sync[clip].host.rows_per_bit;
+  sa.table.chains = kt->sync[clip].chains_approx.as<unsigned>();
   {
     // algorithmic HBM bytes of the scan: the dB matrix once, candidates re-read it from cache
     ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0, st);
-    if (getenv ("AWM_SCAN_DIRECT"))
-      AWM_HIP_CHECK (awmk::launch_sync_scan (st, sa));
-    else
-      AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));
+    AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));
   }
   {
     ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_shifts) * S * 24.0, st);

@@ -74,6 +74,9 @@ int awm_tab_sync_bits (const uint8_t key[16], int clip_mode, int *out /* [6*rows
 int awm_tab_window (size_t n, float *out);                    /* FFTAnalyzer::gen_normalized_window wmcommon.cc:68-89 */
 int awm_tab_synth_window (float *out /* [3072] */);           /* WatermarkSynth::generate_window wmadd.cc:177-206 */
 int awm_conv_encode (int block_type, const int *bits, size_t n, int *out); /* conv_encode convcode.cc:100-125 */
+/* `audiowmark test-gen-noise` (audiowmark.cc:399-417): n_values floats = rng.random_double() * 2 - 1 of
+ * Random (key, 0, Stream::data_up_down) -- the reference's own synthetic input (interleaved stereo white noise) */
+int awm_test_gen_noise (const uint8_t key[16], size_t n_values, float *out);
 
 /* ---- kernel level (device pointers) --------------------------------------------------- */
 

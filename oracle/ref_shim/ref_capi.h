@@ -46,6 +46,9 @@ void   ref_ifft (size_t n, const float *spect /* [(n/2+1)*2] */, float *out /* [
 int    ref_add (const uint8_t key[16], const float *samples, size_t n_frames, int n_channels, int sample_rate,
                 const char *payload_hex, float *out, size_t *out_frames, double *snr_db);
 
+/* RawConverter (rawconverter.cc:73-286): encoding 0 signed / 1 unsigned / 2 float; to_raw: floats -> bytes, else bytes -> floats */
+int    ref_raw_convert (int bit_depth, int encoding, int big_endian, int to_raw, const void *in, void *out, size_t n_values);
+
 /* syncfinder.cc private pieces */
 int    ref_sync_fft (const float *samples, size_t n_values, int n_channels, size_t index, size_t frame_count,
                      const char *want_frames /* may be NULL */, size_t first, size_t last,
@@ -82,6 +85,9 @@ int    ref_decode_chunk (const uint8_t key[16], const float *samples, size_t n_v
  * 44.1 kHz data; patterns merged + sorted like the reference; returns count */
 int    ref_get (const uint8_t key[16], const float *samples, size_t n_values, int n_channels,
                 size_t max_out, ref_pattern *out);
+/* the same for a file of another sample rate: the reference's WavChunkLoader resamples to 44.1 kHz (restated zita) */
+int    ref_get_rate (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int sample_rate,
+                     size_t max_out, ref_pattern *out);
 
 /* ---- speed detection (wmspeed.cc) and VResampler paths (resample.cc:96-125); zita-resampler restated ---------- */
 void   ref_set_speed_params (int detect_speed, int patient, double try_speed);

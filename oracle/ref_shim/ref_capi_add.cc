@@ -223,4 +223,22 @@ ref_add (const uint8_t key[16], const float *samples, size_t n_frames, int n_cha
   return rc;
 }
 
+
+/* RawConverter::create + from_raw / to_raw (rawconverter.cc:73-286) for one raw format; returns 0, -1 if the format is refused */
+int
+ref_raw_convert (int bit_depth, int encoding, int big_endian, int to_raw, const void *in, void *out, size_t n_values)
+{
+  RawFormat fmt (2, 44100, bit_depth);
+  fmt.set_encoding (encoding == 0 ? Encoding::SIGNED : encoding == 1 ? Encoding::UNSIGNED : Encoding::FLOAT);
+  fmt.set_endian (big_endian ? RawFormat::BIG : RawFormat::LITTLE);
+  Error err;
+  std::unique_ptr<RawConverter> conv (RawConverter::create (fmt, err));
+  if (err || !conv)
+    return -1;
+  if (to_raw)
+    conv->to_raw ((const float *) in, (unsigned char *) out, n_values);
+  else
+    conv->from_raw ((const unsigned char *) in, (float *) out, n_values);
+  return 0;
+}
 } /* extern "C" */

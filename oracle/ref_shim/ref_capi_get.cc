@@ -156,6 +156,11 @@ ref_decode_chunk (const uint8_t key[16], const float *samples, size_t n_values, 
 int
 ref_get (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, size_t max_out, ref_pattern *out)
 {
+  return ref_get_rate (key, samples, n_values, n_channels, 44100, max_out, out);
+}
+int
+ref_get_rate (const uint8_t key[16], const float *samples, size_t n_values, int n_channels, int sample_rate, size_t max_out, ref_pattern *out)
+{
   /* write the data as headerless float32 and read it back through the reference's own
    * RawInputStream + WavChunkLoader, then run the body of get_watermark (wmget.cc:971-1013) */
   char name[64];
@@ -167,7 +172,7 @@ ref_get (const uint8_t key[16], const float *samples, size_t n_values, int n_cha
   const Format old_format = Params::input_format;
   Params::input_format = Format::RAW;
   Params::raw_input_format.set_channels (n_channels);
-  Params::raw_input_format.set_sample_rate (44100);
+  Params::raw_input_format.set_sample_rate (sample_rate);      /* != 44100: WavChunkLoader resamples (wavchunkloader.cc:70-72) */
   Params::raw_input_format.set_bit_depth (32);
   Params::raw_input_format.set_encoding (Encoding::FLOAT);
   Params::raw_input_format.set_endian (RawFormat::LITTLE);

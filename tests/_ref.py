@@ -224,9 +224,9 @@ def decode_chunk(key, samples, n_channels, first_chunk=True):
     return _patterns(lib().ref_decode_chunk, _key(key), _p(samples), C.c_size_t(samples.size), n_channels, int(first_chunk))
 
 
-def get(key, samples, n_channels):
+def get(key, samples, n_channels, sample_rate=44100):
     samples = np.ascontiguousarray(samples, np.float32).ravel()
-    return _patterns(lib().ref_get, _key(key), _p(samples), C.c_size_t(samples.size), n_channels)
+    return _patterns(lib().ref_get_rate, _key(key), _p(samples), C.c_size_t(samples.size), n_channels, sample_rate)
 
 
 # ---- speed detection (wmspeed.cc) / VResampler paths; zita-resampler is the oracle's restatement ---------------------
@@ -307,3 +307,18 @@ def detect_speed(key, samples, n_channels, patient=False, rate=44100):
     f.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p]
     n = f(_key(key), _p(s), s.size, n_channels, rate, int(patient), C.byref(out))
     return out.value if n else None
+
+
+def raw_convert(values_or_bytes, bit_depth, encoding, big_endian, to_raw):
+    """the reference's RawConverter (rawconverter.cc): floats -> bytes (to_raw) or bytes -> floats"""
+    if to_raw:
+        src = np.ascontiguousarray(values_or_bytes, np.float32)
+        n = src.size
+        out = np.zeros(n * (bit_depth // 8), np.uint8)
+    else:
+        src = np.ascontiguousarray(values_or_bytes, np.uint8)
+        n = src.size // (bit_depth // 8)
+        out = np.zeros(n, np.float32)
+    rc = lib().ref_raw_convert(bit_depth, encoding, int(big_endian), int(to_raw), _p(src), _p(out), C.c_size_t(n))
+    assert rc == 0
+    return out

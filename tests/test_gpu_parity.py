@@ -622,6 +622,33 @@ def test_pcm_staging_bit_exact(gpu, bits, encoding, big, direct16):
     assert np.array_equal(back.view(np.uint32), _np_decode(want, bits, encoding, big).view(np.uint32))
 
 
+RAW_FORMATS = [  # the 18 formats of the reference's tests/raw-format-test.sh:36-69: (name, bits, encoding, big endian)
+    ("s8", 8, 0, False), ("u8", 8, 1, False),
+    ("s16le", 16, 0, False), ("s24le", 24, 0, False), ("s32le", 32, 0, False),
+    ("u16le", 16, 1, False), ("u24le", 24, 1, False), ("u32le", 32, 1, False), ("f32le", 32, 2, False), ("f64le", 64, 2, False),
+    ("s16be", 16, 0, True), ("s24be", 24, 0, True), ("s32be", 32, 0, True),
+    ("u16be", 16, 1, True), ("u24be", 24, 1, True), ("u32be", 32, 1, True), ("f32be", 32, 2, True), ("f64be", 64, 2, True)]
+
+
+@pytest.mark.parametrize("name,bits,encoding,big", RAW_FORMATS, ids=[f[0] for f in RAW_FORMATS])
+def test_pcm_staging_equals_reference_rawconverter(gpu, name, bits, encoding, big):
+    """Device-side conversion == the reference's RawConverter (rawconverter.cc:155-286, compiled unmodified in oracle/_ref):
+    to_raw byte for byte, from_raw bit for bit, for every format of tests/raw-format-test.sh."""
+    import _ref
+    if not _ref.available():
+        pytest.skip("oracle/_ref (compiled reference) not built")
+    rng = np.random.default_rng(len(name) * 1000 + bits + encoding)
+    x = np.concatenate([rng.uniform(-1.2, 1.2, 200003), rng.uniform(-3e-5, 3e-5, 5000),
+                        [0, 1, -1, 0.99999994, -0.99999994, -0.5 / 32768, 0.5 / 32768, 32767 / 32768, -32768.5 / 32768, 1e-9, -1e-9,
+                         1 - 2.0 ** -24, 2.0 ** -31, -2.0 ** -31]]).astype(np.float32)
+    want = _ref.raw_convert(x, bits, encoding, big, True)
+    got = gpu.ctx.pcm_encode(gpu.dev(x), bits, encoding, big, True).cpu().numpy()
+    assert np.array_equal(got, want)
+    raw = rng.integers(0, 256, want.size, dtype=np.uint8) if encoding != 2 else want      # any byte pattern for the integer formats
+    back = gpu.ctx.pcm_decode(gpu.dev(raw), bits, encoding, big).cpu().numpy()
+    assert np.array_equal(back.view(np.uint32), _ref.raw_convert(raw, bits, encoding, big, False).view(np.uint32))
+
+
 def test_linear_mode(gpu):
     """--linear (Params::mix = false; reference wmadd.cc:115-126, wmget.cc:110-152): per-frame up / down bands instead of the
     shuffled mix entries -- same kernels with another table."""
