@@ -132,6 +132,22 @@ lib.awm_tab_sync_bits.argtypes = [_vp, C.c_int, _vp]
 lib.awm_tab_window.argtypes = [C.c_size_t, _vp]
 lib.awm_tab_synth_window.argtypes = [_vp]
 lib.awm_conv_encode.argtypes = [C.c_int, _vp, C.c_size_t, _vp]
+lib.awm_test_gen_noise.argtypes = [_vp, C.c_size_t, _vp]
+
+
+class RawFormat(C.Structure):
+    """awm_raw_format: headerless PCM as with --format raw --raw-rate / --raw-channels / --raw-bits / --raw-encoding / --raw-endian"""
+    _fields_ = [("n_channels", C.c_int), ("sample_rate", C.c_int), ("bit_depth", C.c_int), ("encoding", C.c_int), ("big_endian", C.c_int)]
+
+
+lib.awm_add_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(RawFormat), C.POINTER(RawFormat)]
+lib.awm_get_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.POINTER(RawFormat), C.c_size_t, _vp]
+lib.awm_add_stream_create.argtypes = [_vp, _vp, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(_vp)]
+lib.awm_add_stream_destroy.argtypes = [_vp]
+lib.awm_add_stream_destroy.restype = None
+lib.awm_add_stream_input.argtypes = [_vp]
+lib.awm_add_stream_input.restype = C.c_void_p
+lib.awm_add_stream_push.argtypes = [_vp, C.c_size_t, C.c_int, _vp, _vp]
 
 
 lib.awm_decode_chunks_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, _vp, _vp, C.c_int, C.c_size_t, _vp, _vp]
@@ -313,6 +329,23 @@ def conv_encode(block_type, bits):
     return out[:n]
 
 
+def _hip_memcpy_dtod(ctx, dst, src, nbytes):
+    """device-to-device copy on the context's stream (through torch: the library exports no raw copy)"""
+    if nbytes <= 0:
+        return
+    _as_tensor(dst, nbytes).copy_(_as_tensor(src, nbytes))       # views over raw device pointers; torch's current stream == ctx stream
+
+
+def _as_tensor(ptr, nbytes):
+    import torch
+
+    class _Iface:
+        pass
+    o = _Iface()
+    o.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(o, device="cuda")
+
+
 # ---- device side ---------------------------------------------------------------------------
 def _dev_ptr(t):
     import torch
@@ -391,6 +424,50 @@ class Context:
             out = torch.empty_like(pcm)
         _check(lib.awm_add_watermark_d(self._h, key_bytes(key), payload_hex.encode(), _dev_ptr(pcm), _dev_ptr(out), n, ch,
                                        sample_rate), "awm_add_watermark_d")
+        return out
+
+    # ---- file level: the reference's add_watermark / get_watermark (wmcommon.hh:226-228) ----
+    def add_watermark_file(self, key, payload_hex, in_path, out_path, raw_in=None, raw_out=None):
+        """infile -> outfile; raw_* = RawFormat for headerless PCM, None for WAV"""
+        _check(lib.awm_add_watermark_file(self._h, key_bytes(key), payload_hex.encode(), os.fsencode(in_path), os.fsencode(out_path),
+                                          C.byref(raw_in) if raw_in is not None else None,
+                                          C.byref(raw_out) if raw_out is not None else None), "awm_add_watermark_file")
+
+    def get_watermark_file(self, key, in_path, raw_in=None):
+        return self._patterns(lib.awm_get_watermark_file, "awm_get_watermark_file", self._h, key_bytes(key), os.fsencode(in_path),
+                              C.byref(raw_in) if raw_in is not None else None)
+
+    def add_watermark_tiles(self, key, payload_hex, pcm, tile_frames1024=128):
+        """awm_add_stream: `add` as a tile loop over resident PCM (the bounded-memory form the file path uses); returns the
+        concatenated output -- bit-identical to add_watermark on the whole stream."""
+        import torch
+        n, ch = _pcm_shape(pcm)
+        h = C.c_void_p()
+        _check(lib.awm_add_stream_create(self._h, key_bytes(key), payload_hex.encode(), ch, tile_frames1024, C.byref(h)), "awm_add_stream_create")
+        out = torch.empty_like(pcm)
+        tile = tile_frames1024 * 1024
+        done_p = (C.c_void_p * 3)()
+        done_n = (C.c_size_t * 3)()
+        pos = written = 0
+        esz = pcm.element_size() * ch
+        try:
+            while True:
+                got = min(tile, n - pos)
+                last = pos + got >= n
+                slot = lib.awm_add_stream_input(h)
+                if got:
+                    _hip_memcpy_dtod(self, slot, pcm.data_ptr() + pos * esz, got * esz)
+                k = _check(lib.awm_add_stream_push(h, got, int(last), done_p, done_n), "awm_add_stream_push")
+                for i in range(k):
+                    _hip_memcpy_dtod(self, out.data_ptr() + written * esz, done_p[i], done_n[i] * esz)
+                    written += done_n[i]
+                pos += got
+                if last:
+                    break
+            self.synchronize()
+        finally:
+            lib.awm_add_stream_destroy(h)
+        assert written == n
         return out
 
     def resample(self, pcm, rate_in, rate_out):

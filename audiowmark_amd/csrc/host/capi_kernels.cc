@@ -4,10 +4,12 @@
 #include "wmget.hh"
 #include "wmspeed.hh"
 #include "utils.hh"
+#include "wmfile.hh"
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 
 using namespace awm;
 namespace awm { Key capi_key (const uint8_t key[16]); }
@@ -44,12 +46,6 @@ check_ctx (awm_ctx *ctx)
 int
 frames_per_span (awm_ctx *ctx, long long n_frames1024)
 {
-  if (const char *env = getenv ("AWM_ADD_SPAN"))
-    {
-      const int v = atoi (env);
-      if (v >= 1)
-        return v;
-    }
   // Every wave streams through L frames plus 2 halo frames.  All waves of one "round" (CUs x resident waves) start
   // and finish together, so pick the number of rounds k that minimises k * (L + 2) with L = ceil (F / (k * capacity)):
   // long spans amortise the halo, whole rounds avoid a half-empty tail.
@@ -365,6 +361,171 @@ add_full_rate (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frame
   return 0;
 }
 
+/* ---- add as a tile loop (reference add_stream_watermark, wmadd.cc:520-589: the stream is processed frame by frame with
+ * WatermarkSynth holding one frame back (wmadd.cc:220-222) and the Limiter holding up to two blocks back (limiter.cc:51-64)).
+ * Here a TILE of frames is in flight instead of a frame; what is carried from tile to tile is the same state:
+ *   - tile t can be mixed once the first frame of tile t + 1 is there (the 3-frame overlap-add needs the next frame's spectrum)
+ *     and needs the last frame of tile t - 1,
+ *   - tile t can be limited once tile t + 1 is mixed (the ramp of a block needs the maximum of the following block).
+ * Three input and three mix slots rotate; block maxima are kept for the whole stream (4 bytes per second). ------------------- */
+struct awm_add_stream
+{
+  awm_ctx  *ctx = nullptr;
+  int       C = 0;
+  size_t    tile = 0;                 // samples per channel in a full tile (multiple of 1024)
+  bool      limiter = true;
+  bool      finished = false;
+  long long t = 0;                    // tiles pushed so far
+  size_t    len[3] = { 0, 0, 0 };     // samples per channel in the input slots
+  DevBuffer table, in[3], mix[3], block_max;
+  size_t    n_blocks = 0;             // block maxima allocated (and initialised)
+};
+
+static int
+add_stream_grow_blocks (awm_add_stream *s, size_t need)
+{
+  if (need <= s->n_blocks)
+    return 0;
+  awm_ctx *ctx = s->ctx;
+  size_t cap = std::max<size_t> (4096, s->n_blocks * 2);
+  while (cap < need)
+    cap *= 2;
+  DevBuffer bigger;
+  if (int rc = bigger.reserve (cap * sizeof (float))) return rc;
+  if (s->n_blocks)
+    AWM_HIP_CHECK (hipMemcpyAsync (bigger.ptr, s->block_max.ptr, s->n_blocks * sizeof (float), hipMemcpyDeviceToDevice, ctx->stream));
+  if (int rc = awm_add_init_block_max_d (ctx, bigger.as<float>() + s->n_blocks, cap - s->n_blocks)) return rc;
+  AWM_HIP_CHECK (hipStreamSynchronize (ctx->stream));      // the old array may still be read by a queued kernel
+  s->block_max.release();
+  s->block_max = bigger;
+  s->n_blocks = cap;
+  return 0;
+}
+
+int
+awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, int n_channels, size_t tile_frames1024,
+                       awm_add_stream **out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (!out || n_channels < 1 || tile_frames1024 < 128)
+    {
+      set_error ("awm_add_stream_create: bad argument (a tile is at least 128 frames: the limiter looks one second ahead)");
+      return AWM_ERR_ARG;
+    }
+  FrameModTable *fm = ctx->get_frame_mod (capi_key (key), payload_hex ? payload_hex : "");
+  if (!fm)
+    return AWM_ERR_ARG;
+  auto s = std::make_unique<awm_add_stream>();
+  s->ctx = ctx;
+  s->C = n_channels;
+  s->tile = tile_frames1024 * Params::frame_size;
+  s->limiter = !Params::test_no_limiter;
+  const size_t table_bytes = 2 * mark_block_frame_count() * Params::n_bands;
+  auto fail = [&] (int rc) { awm_add_stream_destroy (s.release()); return rc; };
+  if (int rc = s->table.reserve (table_bytes)) return fail (rc);
+  // own copy of the table: the context's cache may evict its entry while the stream lives
+  if (hipMemcpyAsync (s->table.ptr, fm->dev.ptr, table_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess
+      || hipStreamSynchronize (ctx->stream) != hipSuccess)
+    return fail (AWM_ERR_HIP);
+  for (int i = 0; i < 3; i++)
+    {
+      if (int rc = s->in[i].reserve (s->tile * s->C * sizeof (float))) return fail (rc);
+      if (int rc = s->mix[i].reserve (s->tile * s->C * sizeof (float))) return fail (rc);
+    }
+  *out = s.release();
+  return 0;
+}
+
+void
+awm_add_stream_destroy (awm_add_stream *s)
+{
+  if (!s)
+    return;
+  (void) hipSetDevice (s->ctx->device);
+  (void) hipStreamSynchronize (s->ctx->stream);
+  s->table.release();
+  s->block_max.release();
+  for (int i = 0; i < 3; i++)
+    {
+      s->in[i].release();
+      s->mix[i].release();
+    }
+  delete s;
+}
+
+float *
+awm_add_stream_input (awm_add_stream *s)
+{
+  return s && !s->finished ? s->in[s->t % 3].as<float>() : nullptr;
+}
+
+int
+awm_add_stream_push (awm_add_stream *s, size_t n_frames, int last, const float *out_d[3], size_t out_frames[3])
+{
+  if (!s || !out_d || !out_frames)
+    {
+      set_error ("awm_add_stream_push: bad argument");
+      return AWM_ERR_ARG;
+    }
+  awm_ctx *ctx = s->ctx;
+  if (int rc = check_ctx (ctx)) return rc;
+  if (s->finished || n_frames > s->tile || (!last && n_frames != s->tile))
+    {
+      set_error ("awm_add_stream_push: every tile but the last one must be full, nothing may follow the last one");
+      return AWM_ERR_ARG;
+    }
+  const int C = s->C;
+  const size_t N = Params::frame_size;
+  const long long t = s->t;
+  int n_out = 0;
+  for (int i = 0; i < 3; i++)
+    {
+      out_d[i] = nullptr;
+      out_frames[i] = 0;
+    }
+  auto slot = [&] (long long k) { return int (k % 3); };
+  auto mix_tile = [&] (long long k, bool has_next) -> int {
+    const size_t n = s->len[slot (k)];
+    if (!n)
+      return 0;
+    const float *before = k > 0 ? s->in[slot (k - 1)].as<float>() + (s->tile - N) * C : nullptr;
+    const float *after = has_next ? s->in[slot (k + 1)].as<float>() : nullptr;
+    return add_mix_impl (ctx, s->in[slot (k)].as<float>(), s->mix[slot (k)].as<float>(), n, C, s->table.as<int8_t>(), Params::water_delta,
+                         size_t (k) * (s->tile / N), before, after, s->limiter ? s->block_max.as<float>() : nullptr, 0, s->n_blocks);
+  };
+  auto limit_tile = [&] (long long k) -> int {
+    const size_t n = s->len[slot (k)];
+    if (!n)
+      return 0;
+    if (s->limiter)
+      if (int rc = awm_add_limit_d (ctx, s->mix[slot (k)].as<float>(), n, C, size_t (k) * s->tile, s->block_max.as<float>(), 0, s->n_blocks))
+        return rc;
+    out_d[n_out] = s->mix[slot (k)].as<float>();
+    out_frames[n_out++] = n;
+    return 0;
+  };
+
+  s->len[slot (t)] = n_frames;
+  if (n_frames && n_frames < N)       // a next tile shorter than a frame: the halo the previous tile reads is zero extended
+    AWM_HIP_CHECK (hipMemsetAsync (s->in[slot (t)].as<float>() + n_frames * C, 0, (N - n_frames) * C * sizeof (float), ctx->stream));
+  if (s->limiter)
+    if (int rc = add_stream_grow_blocks (s, (size_t (t) * s->tile + n_frames) / LIMITER_BLOCK + 2)) return rc;
+  if (t >= 1)
+    if (int rc = mix_tile (t - 1, n_frames > 0)) return rc;
+  if (t >= 2)
+    if (int rc = limit_tile (t - 2)) return rc;
+  if (last)
+    {
+      if (int rc = mix_tile (t, false)) return rc;
+      if (t >= 1)
+        if (int rc = limit_tile (t - 1)) return rc;
+      if (int rc = limit_tile (t)) return rc;
+      s->finished = true;
+    }
+  s->t++;
+  return n_out;
+}
+
 int
 awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
            const int8_t *frame_mod, double water_delta, int use_limiter)
@@ -678,6 +839,94 @@ awm_decode_chunks_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, si
         }
     }
   return int (n);
+}
+
+/* ---- file level: the reference's add_watermark / get_watermark (wmcommon.hh:226-228) ------------------------------------ */
+namespace {
+// --input-format raw / --output-format raw with the --raw-* options for the duration of one call (the reference keeps
+// these in the process-global Params, wmcommon.hh:79-83)
+struct FormatScope
+{
+  Format old_in = Params::input_format, old_out = Params::output_format;
+  RawFormat old_raw_in = StreamParams::raw_input_format, old_raw_out = StreamParams::raw_output_format;
+  static bool
+  apply (const awm_raw_format *f, Format& format, RawFormat& raw)
+  {
+    if (!f)
+      {
+        format = Format::AUTO;
+        return true;
+      }
+    if (f->n_channels < 1 || f->sample_rate < 1 || !pcm_format_ok (f->bit_depth, f->encoding))
+      return false;
+    format = Format::RAW;
+    raw.n_channels = f->n_channels;
+    raw.sample_rate = f->sample_rate;
+    raw.bit_depth = f->bit_depth;
+    raw.encoding = f->encoding == 0 ? Encoding::SIGNED : f->encoding == 1 ? Encoding::UNSIGNED : Encoding::FLOAT;
+    raw.endian = f->big_endian ? RawFormat::BIG : RawFormat::LITTLE;
+    return true;
+  }
+  ~FormatScope()
+  {
+    Params::input_format = old_in;
+    Params::output_format = old_out;
+    StreamParams::raw_input_format = old_raw_in;
+    StreamParams::raw_output_format = old_raw_out;
+  }
+};
+}
+
+int
+awm_add_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const char *in_path, const char *out_path,
+                        const awm_raw_format *raw_in, const awm_raw_format *raw_out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (!payload_hex || !in_path || !out_path)
+    {
+      set_error ("awm_add_watermark_file: bad argument");
+      return AWM_ERR_ARG;
+    }
+  FormatScope scope;
+  if (!FormatScope::apply (raw_in, Params::input_format, StreamParams::raw_input_format)
+      || !FormatScope::apply (raw_out, Params::output_format, StreamParams::raw_output_format))
+    {
+      set_error ("awm_add_watermark_file: unsupported raw format");
+      return AWM_ERR_ARG;
+    }
+  return add_watermark (ctx, capi_key (key), in_path, out_path, payload_hex) ? AWM_ERR_ARG : 0;
+}
+
+int
+awm_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *in_path, const awm_raw_format *raw_in,
+                        size_t max_out, awm_pattern *out)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (!in_path || (max_out && !out))
+    {
+      set_error ("awm_get_watermark_file: bad argument");
+      return AWM_ERR_ARG;
+    }
+  FormatScope scope;
+  if (!FormatScope::apply (raw_in, Params::input_format, StreamParams::raw_input_format))
+    {
+      set_error ("awm_get_watermark_file: unsupported raw format");
+      return AWM_ERR_ARG;
+    }
+  Error err;
+  auto in_stream = AudioInputStream::create (in_path, err);
+  if (err)
+    {
+      set_error (std::string ("error loading ") + in_path + ": " + err.message());
+      return AWM_ERR_ARG;
+    }
+  ResultSet rs;
+  size_t n_values = 0;
+  if (get_watermark_stream (ctx, { capi_key (key) }, in_stream.get(), false, rs, n_values, in_path))
+    return AWM_ERR_HIP;
+  for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
+    fill_pattern (rs.patterns[i], out[i]);
+  return int (rs.patterns.size());
 }
 
 int

@@ -1,4 +1,5 @@
 #include "context.hh"
+#include <algorithm>
 #include <cstdlib>
 #include "utils.hh"
 #include <cmath>
@@ -172,6 +173,24 @@ pack_sync_table (const SyncTable& t, const std::vector<int>& want_pos /* empty: 
   return packed;
 }
 
+static void
+release_key_tables (KeyTables& kt)
+{
+  for (auto& s : kt.sync)
+    {
+      s.packed_approx.release();
+      s.packed_refine.release();
+      s.chains_approx.release();
+      s.want_list_dev.release();
+      s.refine_perm.release();
+      s.refine_pos.release();
+    }
+  kt.mix_frame.release();
+  kt.mix_up.release();
+  kt.mix_down.release();
+  kt.bit_order_inv_dev.release();
+}
+
 KeyTables *
 awm_ctx::get_key_tables (const Key& key)
 {
@@ -179,8 +198,22 @@ awm_ctx::get_key_tables (const Key& key)
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& kt : key_tables)
     if (kt->key == kb && kt->mix == Params::mix)
-      return kt.get();
+      {
+        kt->last_use = ++table_clock;
+        return kt.get();
+      }
+  if (key_tables.size() >= MAX_CACHED_TABLES)
+    {
+      // bounded: a `get` over many keys must not keep every key's tables in HBM.  The victim is the least recently used
+      // of MAX_CACHED_TABLES entries (far more than the lanes that can be decoding at once); drain the device before freeing it.
+      auto victim = std::min_element (key_tables.begin(), key_tables.end(),
+                                      [] (const auto& a, const auto& b) { return a->last_use < b->last_use; });
+      (void) hipDeviceSynchronize();
+      release_key_tables (**victim);
+      key_tables.erase (victim);
+    }
   auto kt = std::make_unique<KeyTables>();
+  kt->last_use = ++table_clock;
   kt->key = kb;
   kt->mix = Params::mix;
   for (int clip = 0; clip < 2; clip++)
@@ -287,10 +320,14 @@ awm_ctx::get_resample_table (int rate_in, int rate_out)
 FrameModTable *
 awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
 {
+  std::lock_guard<std::mutex> lock (table_mutex);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& t : frame_mod_tables)
     if (t->key == kb && t->payload == payload_hex && t->mix == Params::mix)
-      return t.get();
+      {
+        t->last_use = ++table_clock;
+        return t.get();
+      }
   auto bits = parse_payload (payload_hex);
   if (bits.empty())
     {
@@ -302,12 +339,17 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
   t->key = kb;
   t->payload = payload_hex;
   t->mix = Params::mix;
+  t->last_use = ++table_clock;
   if (upload (t->dev, table.data(), table.size(), stream))
     return nullptr;
-  if (frame_mod_tables.size() > 64)     // bounded cache
+  if (frame_mod_tables.size() >= MAX_CACHED_TABLES)
     {
-      frame_mod_tables.front()->dev.release();
-      frame_mod_tables.erase (frame_mod_tables.begin());
+      // least recently used entry; a kernel that was given this table may still be queued on some lane: drain the device first
+      auto victim = std::min_element (frame_mod_tables.begin(), frame_mod_tables.end(),
+                                      [] (const auto& a, const auto& b) { return a->last_use < b->last_use; });
+      (void) hipDeviceSynchronize();
+      (*victim)->dev.release();
+      frame_mod_tables.erase (victim);
     }
   frame_mod_tables.push_back (std::move (t));
   return frame_mod_tables.back().get();
@@ -460,21 +502,7 @@ awm_ctx_destroy (awm_ctx *ctx)
   (void) hipSetDevice (ctx->device);
   (void) hipStreamSynchronize (ctx->stream);
   for (auto& kt : ctx->key_tables)
-    {
-      for (auto& s : kt->sync)
-        {
-          s.packed_approx.release();
-          s.packed_refine.release();
-          s.chains_approx.release();
-          s.want_list_dev.release();
-          s.refine_perm.release();
-          s.refine_pos.release();
-        }
-      kt->mix_frame.release();
-      kt->mix_up.release();
-      kt->mix_down.release();
-      kt->bit_order_inv_dev.release();
-    }
+    release_key_tables (*kt);
   for (auto& t : ctx->frame_mod_tables)
     t->dev.release();
   for (auto& t : ctx->resample_tables)

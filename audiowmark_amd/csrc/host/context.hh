@@ -84,6 +84,7 @@ struct PinnedBuffer
 struct KeyTables
 {
   std::vector<unsigned char> key;
+  unsigned long last_use = 0;
   bool mix = true;                 // Params::mix the data tables were built for (--linear: per-frame up / down bands)
   // sync tables, BLOCK and CLIP flavour
   struct Sync
@@ -125,6 +126,7 @@ struct FrameModTable
   std::vector<unsigned char> key;
   std::string payload;
   bool        mix = true;
+  unsigned long last_use = 0;
   DevBuffer   dev;                 // [2*2226][81] int8
 };
 
@@ -176,6 +178,8 @@ struct awm_ctx : awm::WorkLane
   std::mutex     speed_mutex;            // one speed search at a time per context
 
   std::mutex     table_mutex;            // key / frame_mod table caches (lanes may be driven by different host threads)
+  unsigned long  table_clock = 0;        // LRU stamps of both caches
+  static constexpr size_t MAX_CACHED_TABLES = 64;
   std::mutex     prof_mutex;
   // profiling
   bool   prof_enabled = false;

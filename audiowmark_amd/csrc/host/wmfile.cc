@@ -4,36 +4,19 @@
 #include "utils.hh"
 #include <algorithm>
 #include <cmath>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 
 namespace awm {
 
 namespace {
 
-// pinned host staging buffer (PCIe transfers at full rate), grows geometrically
-struct PinnedBytes
-{
-  unsigned char *ptr = nullptr;
-  size_t capacity = 0;
-  ~PinnedBytes() { if (ptr) (void) hipHostFree (ptr); }
-  bool
-  reserve (size_t n, size_t keep)
-  {
-    if (n <= capacity)
-      return true;
-    unsigned char *np = nullptr;
-    const size_t cap = std::max<size_t> (n, capacity * 2);
-    if (hipHostMalloc (reinterpret_cast<void **> (&np), cap, hipHostMallocDefault) != hipSuccess)
-      return false;
-    if (ptr)
-      {
-        std::copy (ptr, ptr + keep, np);
-        (void) hipHostFree (ptr);
-      }
-    ptr = np;
-    capacity = cap;
-    return true;
-  }
-};
+/* File <-> HBM staging with BOUNDED host memory: the stream crosses PCIe chunk by chunk through two page-locked
+ * buffers (the read of chunk k + 1 overlaps the copy of chunk k), in its own sample format where the stream can hand
+ * out its bytes (raw / WAV): conversion is RawConverter's arithmetic on the device (awm_pcm_decode_d / awm_pcm_encode_d). */
+constexpr size_t STAGE_FRAMES = size_t (1) << 22;       // frames per staging chunk (16 MiB of 16 bit stereo)
 
 bool
 device_codec_supported (const RawFormat& f)
@@ -45,109 +28,300 @@ device_codec_supported (const RawFormat& f)
 
 int encoding_id (Encoding e) { return e == Encoding::SIGNED ? 0 : (e == Encoding::UNSIGNED ? 1 : 2); }
 
-/* Whole stream -> float32 PCM in HBM.  Streams that can hand out their sample bytes are read straight into pinned
- * memory, cross PCIe in their own format and are converted on the device (awm_pcm_decode_d, same rules as the host
- * codec); everything else goes through read_frames. */
+/* up to max_frames frames from the stream into `dst` (sample bytes if `raw`, else float32), looping over short reads */
+Error
+read_chunk (AudioInputStream *in, bool raw, size_t unit_bytes, unsigned char *dst, size_t max_frames, size_t& got)
+{
+  got = 0;
+  if (raw)
+    while (got < max_frames)
+      {
+        size_t n = 0;
+        Error err = in->read_raw (dst + got * unit_bytes, max_frames - got, n);
+        if (err)
+          return err;
+        if (!n)
+          break;
+        got += n;
+      }
+  else
+    {
+      std::vector<float> part;
+      while (got < max_frames)
+        {
+          Error err = in->read_frames (part, std::min<size_t> (max_frames - got, 1 << 20));
+          if (err)
+            return err;
+          if (part.empty())
+            break;
+          std::copy (part.begin(), part.end(), reinterpret_cast<float *> (dst) + got * (unit_bytes / sizeof (float)));
+          got += part.size() / (unit_bytes / sizeof (float));
+        }
+    }
+  return Error::Code::NONE;
+}
+
+struct Staging
+{
+  hipStream_t copy = nullptr;
+  hipEvent_t  ev_copied[2] = { nullptr, nullptr }, ev_used[2] = { nullptr, nullptr };
+  PinnedBuffer host[2];
+  DevBuffer    dev[2];
+  bool ok = false;
+  Staging (size_t bytes, bool need_dev)
+  {
+    ok = hipStreamCreateWithFlags (&copy, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < 2 && ok; i++)
+      ok = hipEventCreateWithFlags (&ev_copied[i], hipEventDisableTiming) == hipSuccess
+        && hipEventCreateWithFlags (&ev_used[i], hipEventDisableTiming) == hipSuccess
+        && host[i].reserve (bytes) == 0 && (!need_dev || dev[i].reserve (bytes) == 0);
+  }
+  ~Staging()
+  {
+    if (copy)
+      {
+        (void) hipStreamSynchronize (copy);
+        (void) hipStreamDestroy (copy);
+      }
+    for (int i = 0; i < 2; i++)
+      {
+        if (ev_copied[i]) (void) hipEventDestroy (ev_copied[i]);
+        if (ev_used[i]) (void) hipEventDestroy (ev_used[i]);
+        host[i].release();
+        dev[i].release();
+      }
+  }
+};
+
+/* Whole stream -> float32 PCM in HBM (288 GB hold days of audio; what is bounded is the HOST side: two staging chunks). */
 Error
 load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_pcm, size_t& n_values)
 {
   const int C = in_stream->n_channels();
   n_values = 0;
-  PinnedBytes host;
   RawFormat fmt;
-  if (in_stream->raw_access (fmt) && device_codec_supported (fmt))
+  const bool raw = in_stream->raw_access (fmt) && device_codec_supported (fmt);
+  const size_t unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
+  Staging st (STAGE_FRAMES * unit, raw);
+  if (!st.ok)
+    return Error ("out of memory for input staging");
+  size_t cap_frames = in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN ? in_stream->n_frames() + 1 : STAGE_FRAMES * 4;
+  if (d_pcm.reserve (cap_frames * C * sizeof (float)))
+    return Error (awm_last_error());
+  size_t frames = 0;
+  for (size_t k = 0; ; k++)
     {
-      const size_t frame_bytes = size_t (C) * (fmt.bit_depth / 8);
-      size_t frames = 0;
-      if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN && !host.reserve ((in_stream->n_frames() + 1) * frame_bytes, 0))
-        return Error ("out of (pinned) host memory");
-      while (true)
-        {
-          const size_t block = size_t (1) << 22;                       // frames per read
-          if (!host.reserve ((frames + block) * frame_bytes, frames * frame_bytes))
-            return Error ("out of (pinned) host memory");
-          size_t got = 0;
-          Error err = in_stream->read_raw (host.ptr + frames * frame_bytes, block, got);
-          if (err)
-            return err;
-          if (!got)
-            break;
-          frames += got;
-        }
-      n_values = frames * C;
-      if (!n_values)
-        return Error::Code::NONE;
-      DevBuffer d_bytes;
-      if (d_bytes.reserve (frames * frame_bytes) || d_pcm.reserve (n_values * sizeof (float)))
-        return Error (awm_last_error());
-      bool ok = hipMemcpyAsync (d_bytes.ptr, host.ptr, frames * frame_bytes, hipMemcpyHostToDevice, ctx->stream) == hipSuccess
-             && awm_pcm_decode_d (ctx, d_bytes.ptr, n_values, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, d_pcm.as<float>()) == 0
-             && hipStreamSynchronize (ctx->stream) == hipSuccess;
-      d_bytes.release();
-      return ok ? Error (Error::Code::NONE) : Error (std::string ("GPU staging failed: ") + awm_last_error());
-    }
-  std::vector<float> tile;
-  while (true)
-    {
-      Error err = in_stream->read_frames (tile, 1 << 20);       // the stream surface accepts any count
+      const int b = int (k & 1);
+      if (k >= 2 && hipEventSynchronize (st.ev_copied[b]) != hipSuccess)      // the copy out of this host buffer is done
+        return Error ("GPU transfer failed");
+      size_t got = 0;
+      Error err = read_chunk (in_stream, raw, unit, st.host[b].as<unsigned char>(), STAGE_FRAMES, got);
       if (err)
         return err;
-      if (tile.empty())
+      if (!got)
         break;
-      if (!host.reserve ((n_values + tile.size()) * sizeof (float), n_values * sizeof (float)))
-        return Error ("out of (pinned) host memory");
-      std::copy (tile.begin(), tile.end(), reinterpret_cast<float *> (host.ptr) + n_values);
-      n_values += tile.size();
+      if (frames + got > cap_frames)
+        {
+          // stream of unknown (or understated) length: move to a buffer twice the size
+          DevBuffer bigger;
+          cap_frames = std::max (cap_frames * 2, frames + got);
+          if (hipStreamSynchronize (st.copy) != hipSuccess || hipStreamSynchronize (ctx->stream) != hipSuccess
+              || bigger.reserve (cap_frames * C * sizeof (float))
+              || hipMemcpy (bigger.ptr, d_pcm.ptr, frames * C * sizeof (float), hipMemcpyDeviceToDevice) != hipSuccess)
+            return Error ("out of device memory while loading the stream");
+          d_pcm.release();
+          d_pcm = bigger;
+        }
+      float *dst = d_pcm.as<float>() + frames * C;
+      bool ok;
+      if (raw)
+        {
+          ok = (k < 2 || hipStreamWaitEvent (st.copy, st.ev_used[b], 0) == hipSuccess)          // the decode of chunk k - 2 has read dev[b]
+            && hipMemcpyAsync (st.dev[b].ptr, st.host[b].ptr, got * unit, hipMemcpyHostToDevice, st.copy) == hipSuccess
+            && hipEventRecord (st.ev_copied[b], st.copy) == hipSuccess
+            && hipStreamWaitEvent (ctx->stream, st.ev_copied[b], 0) == hipSuccess
+            && awm_pcm_decode_d (ctx, st.dev[b].ptr, got * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, dst) == 0
+            && hipEventRecord (st.ev_used[b], ctx->stream) == hipSuccess;
+        }
+      else
+        ok = hipMemcpyAsync (dst, st.host[b].ptr, got * unit, hipMemcpyHostToDevice, st.copy) == hipSuccess
+          && hipEventRecord (st.ev_copied[b], st.copy) == hipSuccess;
+      if (!ok)
+        return Error (std::string ("GPU staging failed: ") + awm_last_error());
+      frames += got;
     }
-  if (!n_values)
-    return Error::Code::NONE;
-  if (d_pcm.reserve (n_values * sizeof (float)))
-    return Error (awm_last_error());
-  if (hipMemcpyAsync (d_pcm.ptr, host.ptr, n_values * sizeof (float), hipMemcpyHostToDevice, ctx->stream) != hipSuccess
-      || hipStreamSynchronize (ctx->stream) != hipSuccess)
+  if (hipStreamSynchronize (st.copy) != hipSuccess || hipStreamSynchronize (ctx->stream) != hipSuccess)
     return Error ("GPU transfer failed");
+  n_values = frames * C;
   return Error::Code::NONE;
 }
 
-/* float32 PCM in HBM -> output stream, mirror image of load_stream_to_device */
+/* Completed output chunks are written by a second host thread, so that file writes overlap file reads and GPU work. */
+class ChunkWriter
+{
+  struct Job { const unsigned char *bytes; size_t frames; hipEvent_t ready; int slot; bool raw; };
+  AudioOutputStream *m_out;
+  int                m_channels;
+  std::thread        m_thread;
+  std::mutex         m_mutex;
+  std::condition_variable m_cond;
+  std::deque<Job>    m_jobs;
+  std::vector<char>  m_busy;          // per slot: handed to the writer and not yet written
+  bool               m_quit = false;
+  Error              m_error = Error::Code::NONE;
+  void
+  run()
+  {
+    for (;;)
+      {
+        Job job;
+        {
+          std::unique_lock<std::mutex> lock (m_mutex);
+          m_cond.wait (lock, [&] { return m_quit || !m_jobs.empty(); });
+          if (m_jobs.empty())
+            return;
+          job = m_jobs.front();
+          m_jobs.pop_front();
+        }
+        Error err = Error::Code::NONE;
+        if (hipEventSynchronize (job.ready) != hipSuccess)
+          err = Error ("GPU transfer failed");
+        else if (job.raw)
+          err = m_out->write_raw (job.bytes, job.frames);
+        else
+          {
+            const float *f = reinterpret_cast<const float *> (job.bytes);
+            err = m_out->write_frames (std::vector<float> (f, f + job.frames * m_channels));
+          }
+        std::lock_guard<std::mutex> lock (m_mutex);
+        if (err && !m_error)
+          m_error = err;
+        m_busy[job.slot] = 0;
+        m_cond.notify_all();
+      }
+  }
+public:
+  ChunkWriter (AudioOutputStream *out, int n_slots) : m_out (out), m_channels (out->n_channels()), m_busy (n_slots, 0)
+  {
+    m_thread = std::thread ([this] { run(); });
+  }
+  ~ChunkWriter() { finish(); }
+  void
+  wait_slot (int slot)                // until the bytes of this slot have been written (the buffer may be reused)
+  {
+    std::unique_lock<std::mutex> lock (m_mutex);
+    m_cond.wait (lock, [&] { return !m_busy[slot]; });
+  }
+  void
+  submit (const unsigned char *bytes, size_t frames, hipEvent_t ready, int slot, bool raw)
+  {
+    std::lock_guard<std::mutex> lock (m_mutex);
+    m_busy[slot] = 1;
+    m_jobs.push_back ({ bytes, frames, ready, slot, raw });
+    m_cond.notify_all();
+  }
+  Error
+  finish()
+  {
+    {
+      std::lock_guard<std::mutex> lock (m_mutex);
+      m_quit = true;
+      m_cond.notify_all();
+    }
+    if (m_thread.joinable())
+      m_thread.join();
+    return m_error;
+  }
+};
+
+/* float32 PCM in HBM -> output stream: encode, copy and write chunk by chunk (mirror image of load_stream_to_device).
+ * `OutputStage` is also what the tile loop of `add` uses for its finished tiles. */
+struct OutputStage
+{
+  awm_ctx *ctx;
+  AudioOutputStream *out;
+  int C;
+  RawFormat fmt;
+  bool direct16 = false, raw = false;
+  size_t unit = 0, chunk_frames;
+  static constexpr int SLOTS = 3;
+  hipStream_t copy = nullptr;
+  hipEvent_t  ev_encoded[SLOTS] = {}, ev_copied[SLOTS] = {};
+  PinnedBuffer host[SLOTS];
+  DevBuffer    dev[SLOTS];
+  std::unique_ptr<ChunkWriter> writer;
+  size_t k = 0;
+  bool ok = false;
+  OutputStage (awm_ctx *c, AudioOutputStream *o, size_t frames_per_chunk) : ctx (c), out (o), C (o->n_channels()), chunk_frames (frames_per_chunk)
+  {
+    raw = out->raw_access (fmt, direct16) && device_codec_supported (fmt);
+    unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
+    ok = hipStreamCreateWithFlags (&copy, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < SLOTS && ok; i++)
+      ok = hipEventCreateWithFlags (&ev_encoded[i], hipEventDisableTiming) == hipSuccess
+        && hipEventCreateWithFlags (&ev_copied[i], hipEventDisableTiming) == hipSuccess
+        && host[i].reserve (chunk_frames * unit) == 0 && (!raw || dev[i].reserve (chunk_frames * unit) == 0);
+    if (ok)
+      writer = std::make_unique<ChunkWriter> (out, SLOTS);
+  }
+  ~OutputStage()
+  {
+    writer.reset();
+    if (copy)
+      {
+        (void) hipStreamSynchronize (copy);
+        (void) hipStreamDestroy (copy);
+      }
+    for (int i = 0; i < SLOTS; i++)
+      {
+        if (ev_encoded[i]) (void) hipEventDestroy (ev_encoded[i]);
+        if (ev_copied[i]) (void) hipEventDestroy (ev_copied[i]);
+        host[i].release();
+        dev[i].release();
+      }
+  }
+  /* n_frames <= chunk_frames of finished float32 samples at d_pcm (produced on ctx->stream) */
+  bool
+  put (const float *d_pcm, size_t n_frames)
+  {
+    if (!n_frames)
+      return true;
+    const int b = int (k++ % SLOTS);
+    writer->wait_slot (b);                       // host[b] written out; its copy and encode are long done
+    bool good;
+    if (raw)
+      good = awm_pcm_encode_d (ctx, d_pcm, n_frames * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, direct16, dev[b].ptr) == 0
+          && hipEventRecord (ev_encoded[b], ctx->stream) == hipSuccess
+          && hipStreamWaitEvent (copy, ev_encoded[b], 0) == hipSuccess
+          && hipMemcpyAsync (host[b].ptr, dev[b].ptr, n_frames * unit, hipMemcpyDeviceToHost, copy) == hipSuccess;
+    else
+      good = hipEventRecord (ev_encoded[b], ctx->stream) == hipSuccess
+          && hipStreamWaitEvent (copy, ev_encoded[b], 0) == hipSuccess
+          && hipMemcpyAsync (host[b].ptr, d_pcm, n_frames * unit, hipMemcpyDeviceToHost, copy) == hipSuccess;
+    good = good && hipEventRecord (ev_copied[b], copy) == hipSuccess
+        // the producer may overwrite d_pcm / dev[b] only after the copy: later work on the compute stream waits for it
+        && hipStreamWaitEvent (ctx->stream, ev_copied[b], 0) == hipSuccess;
+    if (good)
+      writer->submit (host[b].as<unsigned char>(), n_frames, ev_copied[b], b, raw);
+    return good;
+  }
+  Error finish() { return writer->finish(); }
+};
+
 Error
 store_device_to_stream (awm_ctx *ctx, AudioOutputStream *out_stream, const float *d_pcm, size_t n_values)
 {
   if (!n_values)
     return Error::Code::NONE;
   const int C = out_stream->n_channels();
-  PinnedBytes host;
-  RawFormat fmt;
-  bool direct16 = false;
-  if (out_stream->raw_access (fmt, direct16) && device_codec_supported (fmt))
-    {
-      const size_t bytes = n_values * (fmt.bit_depth / 8);
-      DevBuffer d_bytes;
-      if (d_bytes.reserve (bytes) || !host.reserve (bytes, 0))
-        return Error ("out of memory for output staging");
-      bool ok = awm_pcm_encode_d (ctx, d_pcm, n_values, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, direct16, d_bytes.ptr) == 0
-             && hipMemcpyAsync (host.ptr, d_bytes.ptr, bytes, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess
-             && hipStreamSynchronize (ctx->stream) == hipSuccess;
-      d_bytes.release();
-      if (!ok)
-        return Error (std::string ("GPU staging failed: ") + awm_last_error());
-      return out_stream->write_raw (host.ptr, n_values / C);
-    }
-  if (!host.reserve (n_values * sizeof (float), 0))
-    return Error ("out of (pinned) host memory");
-  if (hipMemcpyAsync (host.ptr, d_pcm, n_values * sizeof (float), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess
-      || hipStreamSynchronize (ctx->stream) != hipSuccess)
-    return Error ("GPU transfer failed");
-  const float *result = reinterpret_cast<const float *> (host.ptr);
-  const size_t tile = size_t (1 << 20) * C;                     // write in tiles through the unchanged stream surface
-  for (size_t pos = 0; pos < n_values; pos += tile)
-    {
-      std::vector<float> part (result + pos, result + std::min (n_values, pos + tile));
-      Error err = out_stream->write_frames (part);
-      if (err)
-        return err;
-    }
-  return Error::Code::NONE;
+  const size_t n_frames = n_values / C;
+  OutputStage stage (ctx, out_stream, STAGE_FRAMES);
+  if (!stage.ok)
+    return Error ("out of memory for output staging");
+  for (size_t pos = 0; pos < n_frames; pos += STAGE_FRAMES)
+    if (!stage.put (d_pcm + pos * C, std::min (STAGE_FRAMES, n_frames - pos)))
+      return Error (std::string ("GPU staging failed: ") + awm_last_error());
+  return stage.finish();
 }
 
 /* "Data Blocks" counter of WatermarkGen (reference wmadd.cc:311-313, 346-351): depends only on how many frames the
@@ -180,6 +354,191 @@ count_data_blocks (size_t n_frames, int sample_rate, bool limiter)
       total_out += std::min (out, total_in - total_out);
     }
   return std::max (int (data_blocks) - 1, 0);
+}
+
+} // namespace
+
+namespace {
+
+/* SNR report of `add --snr` (reference wmadd.cc:553-563 measures the watermark before the limiter; with the limiter active
+ * this is the power of (output - original), which includes the limiter's gain change): accumulated tile by tile in order */
+struct SnrMeter
+{
+  double delta_power = 0, signal_power = 0;
+  std::vector<float> orig, result;
+  bool
+  add (const float *d_orig, const float *d_result, size_t n_values, hipStream_t st)
+  {
+    orig.resize (n_values);
+    result.resize (n_values);
+    if (hipStreamSynchronize (st) != hipSuccess
+        || hipMemcpy (orig.data(), d_orig, n_values * sizeof (float), hipMemcpyDeviceToHost) != hipSuccess
+        || hipMemcpy (result.data(), d_result, n_values * sizeof (float), hipMemcpyDeviceToHost) != hipSuccess)
+      return false;
+    for (size_t i = 0; i < n_values; i++)
+      {
+        const double o = orig[i], d = double (result[i]) - o;
+        delta_power += d * d;
+        signal_power += o * o;
+      }
+    return true;
+  }
+  void report() const { info ("SNR:          %f dB\n", 10 * log10 (signal_power / delta_power)); }
+};
+
+/* `add` at the watermark rate as a tile loop (awm_add_stream, include/awm_hip.h): bounded memory on BOTH sides -- two
+ * staging chunks of input and three of output on the host, three input and three mix tiles in HBM, whatever the length of
+ * the stream (also for pipes of unknown length).  Per tile: file read -> H2D (copy stream) -> sample decode -> fused STFT /
+ * band edit / inverse / overlap-add / mix of the PREVIOUS tile -> limiter + sample encode of the tile before that -> D2H
+ * (copy stream) -> file write (writer thread); the stages of neighbouring tiles overlap. */
+int
+add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutputStream *out_stream, const std::string& payload_hex,
+           size_t& n_frames)
+{
+  constexpr size_t TILE_FRAMES1024 = 4096;                 // 95 s of audio, 32 MiB of float32 stereo
+  const size_t tile = TILE_FRAMES1024 * Params::frame_size;
+  const int C = in_stream->n_channels();
+  n_frames = 0;
+  awm_add_stream *add = nullptr;
+  if (awm_add_stream_create (ctx, key.aes_key(), payload_hex.c_str(), C, TILE_FRAMES1024, &add))
+    {
+      error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+      return 1;
+    }
+  struct Guard { awm_add_stream *s; ~Guard() { awm_add_stream_destroy (s); } } guard { add };
+  RawFormat fmt;
+  const bool raw = in_stream->raw_access (fmt) && device_codec_supported (fmt);
+  const size_t unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
+  Staging st (tile * unit, raw);
+  OutputStage stage (ctx, out_stream, tile);
+  if (!st.ok || !stage.ok)
+    {
+      error ("audiowmark: out of memory for the staging buffers\n");
+      return 1;
+    }
+  SnrMeter snr;
+  std::vector<const float *> snr_in;                       // --snr: the input slots of the tiles in flight (device pointers)
+  bool eof = false;
+  for (size_t k = 0; !eof; k++)
+    {
+      const int b = int (k & 1);
+      if (k >= 2 && hipEventSynchronize (st.ev_copied[b]) != hipSuccess)
+        {
+          error ("audiowmark: GPU transfer failed\n");
+          return 1;
+        }
+      size_t got = 0;
+      Error err = read_chunk (in_stream, raw, unit, st.host[b].as<unsigned char>(), tile, got);
+      if (err)
+        {
+          error ("audiowmark: input stream read failed: %s\n", err.message());
+          return 1;
+        }
+      eof = got < tile;
+      float *slot = awm_add_stream_input (add);
+      bool ok = true;
+      if (got && raw)
+        ok = (k < 2 || hipStreamWaitEvent (st.copy, st.ev_used[b], 0) == hipSuccess)
+          && hipMemcpyAsync (st.dev[b].ptr, st.host[b].ptr, got * unit, hipMemcpyHostToDevice, st.copy) == hipSuccess
+          && hipEventRecord (st.ev_copied[b], st.copy) == hipSuccess
+          && hipStreamWaitEvent (ctx->stream, st.ev_copied[b], 0) == hipSuccess
+          && awm_pcm_decode_d (ctx, st.dev[b].ptr, got * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, slot) == 0
+          && hipEventRecord (st.ev_used[b], ctx->stream) == hipSuccess;
+      else if (got)
+        // the slot was last read by kernels queued on the compute stream: the copy must not overtake them
+        ok = hipEventRecord (st.ev_used[b], ctx->stream) == hipSuccess
+          && hipStreamWaitEvent (st.copy, st.ev_used[b], 0) == hipSuccess
+          && hipMemcpyAsync (slot, st.host[b].ptr, got * unit, hipMemcpyHostToDevice, st.copy) == hipSuccess
+          && hipEventRecord (st.ev_copied[b], st.copy) == hipSuccess
+          && hipStreamWaitEvent (ctx->stream, st.ev_copied[b], 0) == hipSuccess;
+      const float *done[3];
+      size_t done_frames[3];
+      int n_done = ok ? awm_add_stream_push (add, got, eof, done, done_frames) : -1;
+      if (n_done < 0)
+        {
+          error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+          return 1;
+        }
+      if (Params::snr)
+        snr_in.push_back (slot);
+      for (int i = 0; i < n_done; i++)
+        {
+          if (Params::snr)
+            {
+              // finished tiles come out in stream order: the oldest input slot still listed belongs to this one
+              if (!snr.add (snr_in.front(), done[i], done_frames[i] * C, ctx->stream))
+                {
+                  error ("audiowmark: GPU transfer failed\n");
+                  return 1;
+                }
+              snr_in.erase (snr_in.begin());
+            }
+          if (!stage.put (done[i], done_frames[i]))
+            {
+              error ("audiowmark: GPU staging failed: %s\n", awm_last_error());
+              return 1;
+            }
+        }
+      n_frames += got;
+    }
+  if (hipStreamSynchronize (ctx->stream) != hipSuccess)
+    {
+      error ("audiowmark: GPU watermarking failed\n");
+      return 1;
+    }
+  Error err = stage.finish();
+  if (err)
+    {
+      error ("audiowmark output write failed: %s\n", err.message());
+      return 1;
+    }
+  if (Params::snr && n_frames)
+    snr.report();
+  return 0;
+}
+
+/* `add` at another sample rate: the WatermarkResampler path works on the whole stream in HBM (awm_add_watermark_d); the
+ * host side is still bounded (chunked staging both ways) */
+int
+add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutputStream *out_stream, const std::string& payload_hex,
+           size_t& n_frames)
+{
+  const int C = in_stream->n_channels();
+  DevBuffer d_in, d_out;
+  struct Guard { DevBuffer& a; DevBuffer& b; ~Guard() { a.release(); b.release(); } } guard { d_in, d_out };
+  size_t n_values = 0;
+  Error err = load_stream_to_device (ctx, in_stream, d_in, n_values);
+  if (err)
+    {
+      error ("audiowmark: input stream read failed: %s\n", err.message());
+      return 1;
+    }
+  n_frames = n_values / C;
+  if (!n_values)
+    return 0;
+  if (d_out.reserve (n_values * sizeof (float))
+      || awm_add_watermark_d (ctx, key.aes_key(), payload_hex.c_str(), d_in.as<float>(), d_out.as<float>(), n_frames, C, in_stream->sample_rate()) != 0)
+    {
+      error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+      return 1;
+    }
+  if (Params::snr)
+    {
+      SnrMeter snr;
+      if (!snr.add (d_in.as<float>(), d_out.as<float>(), n_values, ctx->stream))
+        {
+          error ("audiowmark: GPU transfer failed\n");
+          return 1;
+        }
+      snr.report();
+    }
+  err = store_device_to_stream (ctx, out_stream, d_out.as<float>(), n_values);
+  if (err)
+    {
+      error ("audiowmark output write failed: %s\n", err.message());
+      return 1;
+    }
+  return 0;
 }
 
 } // namespace
@@ -227,57 +586,13 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
   info ("Channels:     %d\n", in_stream->n_channels());
 
   const int C = in_stream->n_channels();
-  DevBuffer d_in, d_out;
-  auto cleanup = [&] { d_in.release(); d_out.release(); };
-  size_t n_values = 0;
-  Error err = load_stream_to_device (ctx, in_stream, d_in, n_values);
-  if (err)
-    {
-      error ("audiowmark: input stream read failed: %s\n", err.message());
-      cleanup();
-      return 1;
-    }
-  const size_t n_frames = n_values / C;
-  if (n_values)
-    {
-      if (d_out.reserve (n_values * sizeof (float))
-          || awm_add_watermark_d (ctx, key.aes_key(), bit_vec_to_str (bitvec).c_str(), d_in.as<float>(), d_out.as<float>(), n_frames, C,
-                                  in_stream->sample_rate()) != 0)
-        {
-          error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
-          cleanup();
-          return 1;
-        }
-      if (Params::snr)
-        {
-          // the reference measures the watermark before the limiter (wmadd.cc:553-563); with the limiter
-          // active this is the power of (output - original), which includes the limiter's gain change
-          std::vector<float> orig (n_values), result (n_values);
-          if (hipMemcpy (orig.data(), d_in.ptr, n_values * sizeof (float), hipMemcpyDeviceToHost) != hipSuccess
-              || hipMemcpy (result.data(), d_out.ptr, n_values * sizeof (float), hipMemcpyDeviceToHost) != hipSuccess)
-            {
-              error ("audiowmark: GPU transfer failed\n");
-              cleanup();
-              return 1;
-            }
-          double delta_power = 0, signal_power = 0;
-          for (size_t i = 0; i < n_values; i++)
-            {
-              const double o = orig[i], d = double (result[i]) - o;
-              delta_power += d * d;
-              signal_power += o * o;
-            }
-          info ("SNR:          %f dB\n", 10 * log10 (signal_power / delta_power));
-        }
-      err = store_device_to_stream (ctx, out_stream, d_out.as<float>(), n_values);
-      if (err)
-        {
-          error ("audiowmark output write failed: %s\n", err.message());
-          cleanup();
-          return 1;
-        }
-    }
-  cleanup();
+  size_t n_frames = 0;
+  int rc = in_stream->sample_rate() == Params::mark_sample_rate
+         ? add_tiles (ctx, key, in_stream, out_stream, bit_vec_to_str (bitvec), n_frames)
+         : add_whole (ctx, key, in_stream, out_stream, bit_vec_to_str (bitvec), n_frames);
+  if (rc)
+    return rc;
+  (void) C;
   info ("Data Blocks:  %d\n", count_data_blocks (n_frames, in_stream->sample_rate(), !Params::test_no_limiter));
   if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN && n_frames != in_stream->n_frames())
     {
@@ -289,7 +604,7 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
         }
       warning ("audiowmark: warning: %s\n", msg.c_str());
     }
-  err = out_stream->close();
+  Error err = out_stream->close();
   if (err)
     {
       error ("audiowmark: closing output stream failed: %s\n", err.message());
@@ -339,30 +654,18 @@ add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const st
   return add_stream_watermark (ctx, key, in_stream.get(), out_stream.get(), bits, 0);
 }
 
+/* body of get_watermark (reference wmget.cc:971-1013): stream -> HBM (bounded host memory), loader resampling, chunk loop */
 int
-get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string& infile, const std::string& orig_pattern)
+get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInputStream *in_stream, bool print_speed, ResultSet& result_set,
+                      size_t& n_values_out, const std::string& what)
 {
-  std::vector<int> orig_bitvec;
-  if (!orig_pattern.empty())
-    {
-      orig_bitvec = parse_payload (orig_pattern);
-      if (orig_bitvec.empty())
-        return 1;
-    }
-  Error err;
-  auto in_stream = AudioInputStream::create (infile, err);
-  if (err)
-    {
-      error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
-      return 1;
-    }
   const int C = in_stream->n_channels();
   DevBuffer d_in;
   size_t n_values = 0;
-  err = load_stream_to_device (ctx, in_stream.get(), d_in, n_values);
+  Error err = load_stream_to_device (ctx, in_stream, d_in, n_values);
   if (err)
     {
-      error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
+      error ("audiowmark: error loading %s: %s\n", what.c_str(), err.message());
       d_in.release();
       return 1;
     }
@@ -388,7 +691,7 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
   if (Params::test_truncate)
     n_values = std::min (n_values, size_t (Params::mark_sample_rate) * C * Params::test_truncate);
   const size_t n_frames = n_values / C;
-  ResultSet result_set;
+  n_values_out = n_values;
   if (n_frames)
     {
       DeviceWav wav;
@@ -396,7 +699,7 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
       wav.n_frames = n_frames;
       wav.n_channels = C;
       wav.sample_rate = Params::mark_sample_rate;
-      speed_print_results = !orig_bitvec.empty();      // decode (..., orig_bits, ...): the detect_speed report line of `cmp`
+      speed_print_results = print_speed;                // decode (..., orig_bits, ...): the detect_speed report line of `cmp`
       const int rc = get_watermark_device (ctx, key_list, wav, result_set);
       if (rc)
         {
@@ -408,6 +711,31 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
   else
     result_set.sort (key_list);
   d_in.release();
+  return 0;
+}
+
+int
+get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string& infile, const std::string& orig_pattern)
+{
+  std::vector<int> orig_bitvec;
+  if (!orig_pattern.empty())
+    {
+      orig_bitvec = parse_payload (orig_pattern);
+      if (orig_bitvec.empty())
+        return 1;
+    }
+  Error err;
+  auto in_stream = AudioInputStream::create (infile, err);
+  if (err)
+    {
+      error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
+      return 1;
+    }
+  const int C = in_stream->n_channels();
+  ResultSet result_set;
+  size_t n_values = 0;
+  if (int rc = get_watermark_stream (ctx, key_list, in_stream.get(), !orig_bitvec.empty(), result_set, n_values, infile))
+    return rc;
   const size_t time_length = lrint (double (n_values) / (double (Params::mark_sample_rate) * C));
 
   /* report (reference wmget.cc:941-969) */

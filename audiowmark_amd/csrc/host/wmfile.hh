@@ -13,6 +13,9 @@ int add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_str
                           const std::string& bits, size_t zero_frames);
 int add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits);
 int get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string& infile, const std::string& orig_pattern);
+class ResultSet;
+int get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInputStream *in_stream, bool print_speed, ResultSet& result_set,
+                          size_t& n_values_out, const std::string& what);
 
 int test_change_speed (awm_ctx *ctx, const std::string& infile, const std::string& outfile, double speed);   // reference audiowmark.cc:419-437
 

@@ -108,6 +108,22 @@ int awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels
 int awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
                const int8_t *frame_mod, double water_delta, int use_limiter);
 
+/* add as a tile loop with bounded memory -- the reference's streaming add_stream_watermark (wmadd.cc:520-589) keeps one
+ * frame (WatermarkSynth, wmadd.cc:173,220-222) and up to two limiter blocks (limiter.cc:51-64) of state; here the unit in
+ * flight is a tile of `tile_frames1024` frames (>= 128) and the same state is carried from tile to tile inside the object.
+ *   create:  payload / key tables are resolved once (Params as at this call).
+ *   input:   device pointer where the NEXT tile's interleaved float32 samples are to be written (tile_frames1024 * 1024 * C).
+ *   push:    `n_frames` samples per channel were written there; every tile but the last must be full; last = 1 ends the
+ *            stream (n_frames may be 0).  Work is enqueued on the context's stream.  Returns how many tiles became final
+ *            (0..3, in stream order): out_d[i] / out_frames[i] point into the object and stay valid until the next push.
+ * The concatenated output is bit-identical to awm_add_watermark_d on the whole stream (tests: spans + halo == whole). */
+typedef struct awm_add_stream awm_add_stream;
+int    awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, int n_channels, size_t tile_frames1024,
+                              awm_add_stream **out);
+void   awm_add_stream_destroy (awm_add_stream *s);
+float *awm_add_stream_input (awm_add_stream *s);
+int    awm_add_stream_push (awm_add_stream *s, size_t n_frames, int last, const float *out_d[3], size_t out_frames[3]);
+
 /* I/O staging: RawConverter::from_raw / to_raw (rawconverter.cc:155-286) on the device, so that files cross PCIe in
  * their own sample format.  bit_depth 8/16/24/32 (integer) or 32/64 (float); encoding 0 signed, 1 unsigned, 2 float.
  * direct16 != 0 selects the reference's native little-endian signed-16 rule (truncate at 16 bit, what its stdout / raw
@@ -199,6 +215,18 @@ int awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d,
 int awm_decode_chunks_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
                          int n_chunks, const uint64_t *first_frame, const uint64_t *chunk_frames, int first_is_stream_start,
                          size_t max_out, awm_pattern *out, int *chunk_of_pattern);
+
+/* File level = the reference's own entry points add_watermark (key, infile, outfile, bits) and get_watermark (key_list,
+ * infile, orig_pattern) (wmcommon.hh:226-228, wmadd.cc:620-657, wmget.cc:971-1013) with a GPU context.  The file is streamed
+ * through page-locked staging buffers in its own sample format (bounded host memory: tile loop for `add` at 44.1 kHz, chunked
+ * staging otherwise) and converted on the device.  raw_* = NULL: WAV (RIFF / RF64) by header, like --input-format auto;
+ * else headerless PCM as with --format raw --raw-rate/--raw-channels/--raw-bits/--raw-encoding/--raw-endian.
+ * awm_get_watermark_file returns the number of patterns found (at most max_out are written), < 0 on error. */
+typedef struct { int n_channels, sample_rate, bit_depth, encoding /* 0 signed, 1 unsigned, 2 float */, big_endian; } awm_raw_format;
+int awm_add_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const char *in_path, const char *out_path,
+                            const awm_raw_format *raw_in, const awm_raw_format *raw_out);
+int awm_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *in_path, const awm_raw_format *raw_in,
+                            size_t max_out, awm_pattern *out);
 
 /* chunk plan of WavChunkLoader (wavchunkloader.cc:54-163) for a stream of n_frames samples per channel:
  * chunk i covers [first_frame[i], first_frame[i] + chunk_frames[i]) and reports times offset by

@@ -1,0 +1,122 @@
+"""Bounded-memory paths: `add` as a tile loop (awm_add_stream), file level add / get with chunked staging
+(awm_add_watermark_file / awm_get_watermark_file = the reference's add_watermark / get_watermark, wmcommon.hh:226-228).
+
+Bar: the tile loop's output is BIT-IDENTICAL to the whole-buffer path (same kernels on spans with the carried halo frame and
+limiter maxima; the reference's streaming add keeps the same state, wmadd.cc:173,220-222, limiter.cc:51-64), for every length
+class: shorter than a frame, shorter than a tile, exact tiles, one sample more."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+PAY = "0123456789abcdef0011223344556677"
+TILE = 128                      # frames of 1024 samples: the smallest tile the API takes
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+    import audiowmark_amd as awm
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    ctx = awm.Context(0)
+
+    class G:
+        pass
+    g = G()
+    g.torch, g.awm, g.ctx = torch, awm, ctx
+    yield g
+    awm.set_params()
+    ctx.close()
+
+
+def noise(g, n, ch, seed):
+    gen = g.torch.Generator(device="cuda")
+    gen.manual_seed(seed)
+    return g.torch.rand((n, ch), generator=gen, device="cuda", dtype=g.torch.float32) * 2 - 1
+
+
+@pytest.mark.parametrize("n,ch", [(1, 2), (700, 1), (1024, 2), (TILE * 1024 - 1, 2), (TILE * 1024, 2), (TILE * 1024 + 1, 2),
+                                  (2 * TILE * 1024, 1), (2 * TILE * 1024 + 300, 2), (5 * TILE * 1024 + 44100 * 3 + 17, 2),
+                                  (3 * TILE * 1024 + 1023, 3)])
+def test_add_tiles_equal_whole(gpu, n, ch):
+    x = noise(gpu, n, ch, n % 1000 + ch)
+    whole = gpu.ctx.add_watermark(None, PAY, x)
+    tiles = gpu.ctx.add_watermark_tiles(None, PAY, x, TILE)
+    assert gpu.torch.equal(whole, tiles)
+
+
+def test_add_tiles_without_limiter_and_with_key(gpu):
+    x = noise(gpu, 3 * TILE * 1024 + 5000, 2, 99) * 0.5
+    key = gpu.awm.test_key(3)
+    gpu.awm.set_params(test_no_limiter=True)
+    try:
+        whole = gpu.ctx.add_watermark(key, PAY, x)
+        tiles = gpu.ctx.add_watermark_tiles(key, PAY, x, TILE)
+    finally:
+        gpu.awm.set_params()
+    assert gpu.torch.equal(whole, tiles)
+
+
+def test_add_tiles_rejects_bad_use(gpu):
+    import ctypes as C
+    lib = gpu.awm.lib
+    h = C.c_void_p()
+    assert lib.awm_add_stream_create(gpu.ctx._h, bytes(16), PAY.encode(), 2, 16, C.byref(h)) < 0          # tile below one limiter look-ahead
+    assert lib.awm_add_stream_create(gpu.ctx._h, bytes(16), b"xyz", 2, TILE, C.byref(h)) < 0               # payload does not parse
+    assert lib.awm_add_stream_create(gpu.ctx._h, bytes(16), PAY.encode(), 2, TILE, C.byref(h)) == 0
+    p = (C.c_void_p * 3)()
+    k = (C.c_size_t * 3)()
+    assert lib.awm_add_stream_push(h, 1000, 0, p, k) < 0                                                   # a middle tile must be full
+    assert lib.awm_add_stream_push(h, 1000, 1, p, k) == 1 and k[0] == 1000
+    assert lib.awm_add_stream_push(h, 0, 1, p, k) < 0                                                      # nothing after the last tile
+    lib.awm_add_stream_destroy(h)
+
+
+@pytest.mark.parametrize("seconds,fmt", [(200.5, "s16"), (96.0, "s24be"), (30.0, "f32")])
+def test_file_add_equals_whole_buffer_path_and_get_finds_it(gpu, tmp_path, seconds, fmt):
+    """raw PCM file -> file through the tile loop (95 s tiles: 200 s = 3 tiles) == decode, whole-buffer add, encode"""
+    t, awm = gpu.torch, gpu.awm
+    bits, enc, big = {"s16": (16, 0, False), "s24be": (24, 0, True), "f32": (32, 2, False)}[fmt]
+    n = int(seconds * 44100)
+    x = noise(gpu, n, 2, 7) * 0.9
+    raw_in = gpu.ctx.pcm_encode(x.reshape(-1), bits, enc, big, True).cpu().numpy()
+    src, dst = tmp_path / "in.raw", tmp_path / "out.raw"
+    raw_in.tofile(src)
+    rf = awm.binding.RawFormat(2, 44100, bits, enc, int(big))
+    gpu.ctx.add_watermark_file(None, PAY, src, dst, rf, rf)
+    got = np.fromfile(dst, np.uint8)
+    x_file = gpu.ctx.pcm_decode(t.from_numpy(raw_in).cuda(), bits, enc, big).reshape(n, 2)
+    want = gpu.ctx.pcm_encode(gpu.ctx.add_watermark(None, PAY, x_file).reshape(-1), bits, enc, big, True).cpu().numpy()
+    assert got.size == want.size and np.array_equal(got, want)
+    # get from the file == get from the resident samples
+    from_file = gpu.ctx.get_watermark_file(None, dst, rf)
+    resident = gpu.ctx.get_watermark(None, gpu.ctx.pcm_decode(t.from_numpy(got).cuda(), bits, enc, big).reshape(n, 2))
+    key = lambda p: (round(p["time"], 6), p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
+    assert [key(p) for p in from_file] == [key(p) for p in resident]
+    assert any(p["bits"] == PAY for p in from_file)
+
+
+def test_file_wav_in_wav_out(gpu, tmp_path):
+    """WAV header handling on both sides of the streamed path (RIFF, 16 bit), incl. a length that is not a multiple of a frame"""
+    import struct
+    t = gpu.torch
+    n = 44100 * 100 + 333
+    x = noise(gpu, n, 2, 11) * 0.8
+    pcm = gpu.ctx.pcm_encode(x.reshape(-1), 16, 0, False, True).cpu().numpy()
+    hdr = b"RIFF" + struct.pack("<I", 36 + pcm.size) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16) \
+        + b"data" + struct.pack("<I", pcm.size)
+    src, dst = tmp_path / "in.wav", tmp_path / "out.wav"
+    with open(src, "wb") as f:
+        f.write(hdr)
+        f.write(pcm.tobytes())
+    gpu.ctx.add_watermark_file(None, PAY, src, dst)
+    out = np.fromfile(dst, np.uint8)
+    assert out.size == 44 + pcm.size and bytes(out[:4]) == b"RIFF" and struct.unpack("<I", bytes(out[40:44]))[0] == pcm.size
+    x_file = gpu.ctx.pcm_decode(t.from_numpy(pcm).cuda(), 16, 0, False).reshape(n, 2)
+    # a NAMED WAV file goes through libsndfile in the reference: samples are clipped at 32 bit and the top 16 bits kept
+    # (sfoutputstream.cc:148-155), not the truncate-at-16-bit rule of the stdout / raw path
+    want = gpu.ctx.pcm_encode(gpu.ctx.add_watermark(None, PAY, x_file).reshape(-1), 16, 0, False, False).cpu().numpy()
+    assert np.array_equal(out[44:], want)
+    assert any(p["bits"] == PAY for p in gpu.ctx.get_watermark_file(None, dst))
