@@ -238,6 +238,15 @@ def _pattern_from_dict(d):
 PATTERN_DTYPE = np.dtype(Pattern)
 
 
+def patterns_from_dicts(dicts):
+    """pattern dicts -> structured array (PATTERN_DTYPE)"""
+    out = np.zeros(len(dicts), PATTERN_DTYPE)
+    for i, d in enumerate(dicts):
+        p = _pattern_from_dict(d)
+        out[i] = np.frombuffer(bytes(p), PATTERN_DTYPE)[0]
+    return out
+
+
 def merge_patterns_raw(key, per_chunk_arrays):
     """ResultSet.merge + sort over per-chunk structured arrays (dtype PATTERN_DTYPE, times already offset); returns dicts.
     No per-pattern Python work: this runs inside the timed region of the multi-GPU path."""

@@ -40,6 +40,8 @@ struct AddMixArgs
   long long    n_blocks;
   int          limiter_block;     // samples per limiter block (44100)
   int          frames_per_span;   // frames each wave streams through
+  int          block_frames = 2226;   // mark_block_frame_count(): sync + data frames of a block (wmcommon.cc:36-48)
+  int          frames_pad_start = 250; // Params::frames_pad_start
   int          delta_only = 0;    // 1: write the watermark signal alone (out = d W..., without "+ in"): WatermarkGen::run for the resampled path
 };
 hipError_t launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a);

@@ -494,12 +494,6 @@ add_mix_kernel_w3 (DevTables t, AddMixArgs a, long long frame_number0, int block
 {
   add_mix_body<CV, true> (t, a, frame_number0, block_frames);
 }
-template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
-add_mix_kernel_w4 (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
-{
-  add_mix_body<CV, true> (t, a, frame_number0, block_frames);
-}
-
 hipError_t
 launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
 {
@@ -510,15 +504,11 @@ launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
   const bool stereo = a.n_channels == 2;
   const long long items = n_spans * (stereo ? 1 : a.n_channels);
   const unsigned grid = unsigned ((items + WAVES - 1) / WAVES);
-  const int block_frames = 2226;   // TODO(params): derive from payload size / frames_per_bit
-  const long long frame_number0 = 2LL * block_frames - 250;          // reference wmadd.cc:293-294
-  static const int variant = getenv ("AWM_ADD_VARIANT") ? atoi (getenv ("AWM_ADD_VARIANT")) : 3;   // 3 waves/SIMD measured fastest
-  if (stereo && variant == 3)
+  const int block_frames = a.block_frames;
+  const long long frame_number0 = 2LL * block_frames - a.frames_pad_start;       // reference wmadd.cc:293-294
+  // stereo: both channels in one wave, held at 3 waves per SIMD (measured fastest: 0.72 vs 0.87 ms for 60 min)
+  if (stereo)
     hipLaunchKernelGGL (add_mix_kernel_w3<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
-  else if (stereo && variant == 4)
-    hipLaunchKernelGGL (add_mix_kernel_w4<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
-  else if (stereo)
-    hipLaunchKernelGGL (add_mix_kernel<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
   else
     hipLaunchKernelGGL (add_mix_kernel<1>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
   return hipGetLastError();
@@ -557,32 +547,6 @@ limiter_kernel (float *data, long long n_frames, int C, long long first_sample, 
 }
 
 // 16 bytes per thread: C == 1 -> 4 frames, C == 2 -> 2 frames per float4
-template<int C> __global__ void __launch_bounds__ (256)
-limiter_kernel_v4 (float4 *data, long long n_vec, long long first_sample, const float *block_max,
-                   long long first_block, long long n_blocks, int BS, float ceiling)
-{
-  const long long stride = (long long) gridDim.x * blockDim.x;
-  for (long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x; q < n_vec; q += stride)
-    {
-      float4 v = data[q];
-      const long long gs = first_sample + q * (4 / C);
-      if (C == 2)
-        {
-          const float s0 = limiter_scale (gs, block_max, first_block, n_blocks, BS, ceiling);
-          const float s1 = limiter_scale (gs + 1, block_max, first_block, n_blocks, BS, ceiling);
-          v = make_float4 (__fmul_rn (v.x, s0), __fmul_rn (v.y, s0), __fmul_rn (v.z, s1), __fmul_rn (v.w, s1));
-        }
-      else
-        {
-          v = make_float4 (__fmul_rn (v.x, limiter_scale (gs, block_max, first_block, n_blocks, BS, ceiling)),
-                           __fmul_rn (v.y, limiter_scale (gs + 1, block_max, first_block, n_blocks, BS, ceiling)),
-                           __fmul_rn (v.z, limiter_scale (gs + 2, block_max, first_block, n_blocks, BS, ceiling)),
-                           __fmul_rn (v.w, limiter_scale (gs + 3, block_max, first_block, n_blocks, BS, ceiling)));
-        }
-      data[q] = v;
-    }
-}
-
 /* K3 in two steps.  The ramp of a limiter block (scale_start, scale_step) only depends on three block maxima, so it
  * is computed once per block (K3a) instead of once per sample (three IEEE divisions and a 64 bit integer division each);
  * K3b then streams the samples: every workgroup owns a run of 2048 float4 -- shorter than a limiter block, so it meets
@@ -675,10 +639,13 @@ launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels,
   const long long n_values = n_frames * n_channels;
   if (n_values <= 0)
     return hipSuccess;
-  const bool vec = (n_channels == 1 || n_channels == 2) && (reinterpret_cast<uintptr_t> (data) & 15) == 0;
-  const long long n_vec = vec ? n_values / 4 : 0;
   const size_t need = limiter_tab_entries (n_frames, first_sample, limiter_block);
-  if (n_vec && scale_tab && scale_tab_entries >= need && limiter_block >= 4 * LIMITER_RUN)
+  // vector path: per-block (scale_start, scale_step) table + float4 apply; anything else (odd channel counts, unaligned
+  // spans, limiter blocks shorter than a run, no table workspace) takes the scalar kernel below for all its frames
+  const bool vec = (n_channels == 1 || n_channels == 2) && (reinterpret_cast<uintptr_t> (data) & 15) == 0
+                && scale_tab && scale_tab_entries >= need && limiter_block >= 4 * LIMITER_RUN;
+  const long long n_vec = vec ? n_values / 4 : 0;
+  if (n_vec)
     {
       const long long tab_first = first_sample / limiter_block;
       hipLaunchKernelGGL (limiter_table_kernel, dim3 (unsigned ((need + 255) / 256)), dim3 (256), 0, st, scale_tab, tab_first, (long long) need,
@@ -690,18 +657,6 @@ launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels,
       else
         hipLaunchKernelGGL (limiter_apply_kernel<1>, dim3 (grid), dim3 (256), 0, st, reinterpret_cast<float4 *> (data), n_vec, first_sample,
                             scale_tab, tab_first, limiter_block);
-    }
-  else if (n_vec)
-    {
-      long long blocks = (n_vec + 255) / 256;
-      if (blocks > 256 * 16)
-        blocks = 256 * 16;
-      if (n_channels == 2)
-        hipLaunchKernelGGL (limiter_kernel_v4<2>, dim3 (unsigned (blocks)), dim3 (256), 0, st, reinterpret_cast<float4 *> (data), n_vec,
-                            first_sample, block_max, first_block, n_blocks, limiter_block, ceiling);
-      else
-        hipLaunchKernelGGL (limiter_kernel_v4<1>, dim3 (unsigned (blocks)), dim3 (256), 0, st, reinterpret_cast<float4 *> (data), n_vec,
-                            first_sample, block_max, first_block, n_blocks, limiter_block, ceiling);
     }
   const long long done = n_vec * 4;
   if (done < n_values)

@@ -1,11 +1,15 @@
-// audiowmark -- command line front end of the MI355X watermark path.  Commands, option names, messages
-// and exit codes follow reference src/audiowmark.cc (print_usage :46-90, ArgParser :540-659, option parsing
-// :661-881, main :911-1079) for the subset in scope: add / get / cmp / gen-key / test-gen-noise / test-snr
-// on raw and WAV data at 44.1 kHz.
+// audiowmark -- command line front end of the MI355X watermark path.
+//
+// Same commands, option names, messages and exit codes as the reference's command line (reference src/audiowmark.cc:
+// usage :46-90, options :661-881, commands :911-1079) for the subset in scope: add / get / cmp / gen-key /
+// test-gen-noise / test-snr / test-change-speed on raw and WAV data.  The structure is this file's own: every command
+// is described by a table of option specifications (name, kind, action); one generic pass extracts the options a
+// command knows from the argument list, whatever is left must be its positional arguments.
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include "audiostream.hh"
 #include "context.hh"
 #include "utils.hh"
@@ -17,427 +21,413 @@ using std::vector;
 
 namespace {
 
-void
-print_usage()
+[[noreturn]] void
+die (const string& message)
 {
-  printf ("usage: audiowmark <command> [ <args>... ]\n\n");
-  printf ("Commands:\n");
-  printf ("  * create a watermarked wav file with a message\n");
-  printf ("    audiowmark add <input_wav> <watermarked_wav> <message_hex>\n\n");
-  printf ("  * retrieve message\n");
-  printf ("    audiowmark get <watermarked_wav>\n\n");
-  printf ("  * compare watermark message with expected message\n");
-  printf ("    audiowmark cmp <watermarked_wav> <message_hex>\n\n");
-  printf ("  * generate 128-bit watermarking key, to be used with --key option\n");
-  printf ("    audiowmark gen-key <key_file> [ --name <key_name> ]\n\n");
-  printf ("Global options:\n");
-  printf ("  -q, --quiet             disable information messages\n");
-  printf ("  --strict                treat (minor) problems as errors\n\n");
-  printf ("Options for get / cmp:\n");
-  printf ("  --json <file>           write JSON results into file\n");
-  printf ("  --input-format <f>      raw | wav-pipe | auto (GPU build: get / cmp accept the input options of add)\n\n");
-  printf ("Options for add / get / cmp:\n");
-  printf ("  --key <file>            load watermarking key from file\n");
-  printf ("  --strength <s>          set watermark strength              [%.6g]\n\n", Params::water_delta * 1000);
-  printf ("  --input-format raw      use raw stream as input\n");
-  printf ("  --output-format raw     use raw stream as output\n");
-  printf ("  --format raw            use raw stream as input and output\n\n");
-  printf ("The options to set the raw stream parameters (such as --raw-rate\n");
-  printf ("or --raw-channels) are the reference's.\n");
+  error ("%s", message.c_str());
+  exit (1);
 }
 
-bool is_option (const string& s) { return s.size() > 1 && s[0] == '-'; }
-
+/* ---- values ------------------------------------------------------------------------------------------------------ */
 int
-atoi_or_die (const string& s)
+to_int (const string& s)
 {
-  char *e = nullptr;
-  const int i = strtol (s.c_str(), &e, 0);
-  if (e && e[0])
-    {
-      error ("audiowmark: error during string->int conversion: %s\n", s.c_str());
-      exit (1);
-    }
-  return i;
+  char *end = nullptr;
+  const long v = strtol (s.c_str(), &end, 0);
+  if (end && *end)
+    die ("audiowmark: error during string->int conversion: " + s + "\n");
+  return int (v);
 }
 
 float
-atof_or_die (const string& s)
+to_float (const string& s)
 {
-  char *e = nullptr;
-  const float f = strtod (s.c_str(), &e);
-  if (e && e[0])
-    {
-      error ("audiowmark: error during string->float conversion: %s\n", s.c_str());
-      exit (1);
-    }
-  return f;
+  char *end = nullptr;
+  const double v = strtod (s.c_str(), &end);
+  if (end && *end)
+    die ("audiowmark: error during string->float conversion: " + s + "\n");
+  return float (v);
 }
 
-class ArgParser
+template<class T> T
+from_names (const string& what, const string& s, std::initializer_list<std::pair<const char *, T>> names)
 {
-  vector<string> m_args;
-  string         m_command;
-public:
-  ArgParser (int argc, char **argv) : m_args (argv + 1, argv + argc) {}
-  bool
-  parse_cmd (const string& cmd)
-  {
-    if (m_args.empty() || m_args[0] != cmd)
-      return false;
-    m_args.erase (m_args.begin());
-    m_command = cmd;
-    return true;
-  }
-  vector<string>
-  parse_multi_opt (const string& option)
-  {
-    vector<string> values;
-    for (size_t i = 0; i < m_args.size();)
-      {
-        if (m_args[i] == option && i + 1 < m_args.size())
-          {
-            values.push_back (m_args[i + 1]);
-            m_args.erase (m_args.begin() + i, m_args.begin() + i + 2);
-          }
-        else if (m_args[i].compare (0, option.size() + 1, option + "=") == 0)
-          {
-            values.push_back (m_args[i].substr (option.size() + 1));
-            m_args.erase (m_args.begin() + i);
-          }
-        else
-          i++;
-      }
-    return values;
-  }
-  bool
-  parse_opt (const string& option, string& out)
-  {
-    const auto values = parse_multi_opt (option);
-    if (values.empty())
-      return false;
-    out = values.back();
-    return true;
-  }
-  bool parse_opt (const string& option, int& out) { string s; if (!parse_opt (option, s)) return false; out = atoi_or_die (s); return true; }
-  bool parse_opt (const string& option, float& out) { string s; if (!parse_opt (option, s)) return false; out = atof_or_die (s); return true; }
-  bool
-  parse_opt (const string& option)
-  {
-    for (size_t i = 0; i < m_args.size(); i++)
-      if (m_args[i] == option)
-        {
-          m_args.erase (m_args.begin() + i);
-          return true;
-        }
-    return false;
-  }
-  bool
-  parse_args (size_t expected, vector<string>& out)
-  {
-    if (m_args.size() != expected)
-      return false;
-    for (const auto& a : m_args)
-      if (is_option (a))
-        return false;
-    out = m_args;
-    return true;
-  }
-  const vector<string>& remaining_args() const { return m_args; }
-  const string& command() const { return m_command; }
-};
-
-Format
-parse_format (const string& str)
-{
-  if (str == "raw") return Format::RAW;
-  if (str == "auto") return Format::AUTO;
-  if (str == "rf64") return Format::RF64;
-  if (str == "wav-pipe") return Format::WAV_PIPE;
-  error ("audiowmark: unsupported format '%s'\n", str.c_str());
-  exit (1);
+  for (const auto& n : names)
+    if (s == n.first)
+      return n.second;
+  die ("audiowmark: unsupported " + what + " '" + s + "'\n");
 }
 
-RawFormat::Endian
-parse_endian (const string& str)
+Format to_format (const string& s) { return from_names<Format> ("format", s, { { "raw", Format::RAW }, { "auto", Format::AUTO }, { "rf64", Format::RF64 }, { "wav-pipe", Format::WAV_PIPE } }); }
+RawFormat::Endian to_endian (const string& s) { return from_names<RawFormat::Endian> ("endianness", s, { { "little", RawFormat::LITTLE }, { "big", RawFormat::BIG } }); }
+
+void
+set_encoding (RawFormat& fmt, const string& s)
 {
-  if (str == "little") return RawFormat::LITTLE;
-  if (str == "big") return RawFormat::BIG;
-  error ("audiowmark: unsupported endianness '%s'\n", str.c_str());
-  exit (1);
+  struct Choice { Encoding encoding; int float_bits; };
+  const Choice c = from_names<Choice> ("encoding", s, { { "signed", { Encoding::SIGNED, 0 } }, { "unsigned", { Encoding::UNSIGNED, 0 } },
+                                                         { "float", { Encoding::FLOAT, 32 } }, { "double", { Encoding::FLOAT, 64 } } });
+  fmt.encoding = c.encoding;
+  if (c.float_bits)
+    fmt.bit_depth = c.float_bits;
 }
 
 void
-parse_encoding (const string& str, RawFormat& fmt)
-{
-  if (str == "signed") fmt.encoding = Encoding::SIGNED;
-  else if (str == "unsigned") fmt.encoding = Encoding::UNSIGNED;
-  else if (str == "float") { fmt.encoding = Encoding::FLOAT; fmt.bit_depth = 32; }
-  else if (str == "double") { fmt.encoding = Encoding::FLOAT; fmt.bit_depth = 64; }
-  else
-    {
-      error ("audiowmark: unsupported encoding '%s'\n", str.c_str());
-      exit (1);
-    }
-}
-
-void
-update_raw_bits (RawFormat& fmt, int bits)
+set_bits (RawFormat& fmt, int bits)
 {
   if (fmt.encoding == Encoding::FLOAT)
-    {
-      error ("audiowmark: bit depth can not be changed for float / double encoding\n");
-      exit (1);
-    }
+    die ("audiowmark: bit depth can not be changed for float / double encoding\n");
   fmt.bit_depth = bits;
 }
 
-void
-parse_shared_options (ArgParser& ap)
+/* ---- option tables ------------------------------------------------------------------------------------------------- */
+struct Option
 {
-  int i;
-  if (ap.parse_opt ("--short", i))
+  enum Kind { FLAG, VALUE, MULTI } kind;
+  const char *name;
+  std::function<void (const string&)> action;       // FLAG: called with "" when present; VALUE: last occurrence; MULTI: every one
+};
+typedef vector<Option> Options;
+
+bool looks_like_option (const string& s) { return s.size() > 1 && s[0] == '-'; }
+
+/* removes every occurrence of the option from `args` ("--opt value" and "--opt=value"), returns its values in order */
+vector<string>
+extract (vector<string>& args, const string& name, bool takes_value)
+{
+  vector<string> values;
+  for (size_t i = 0; i < args.size();)
     {
-      error ("audiowmark: --short payloads are not supported by the GPU path\n");
-      exit (1);
+      if (args[i] == name && !takes_value)
+        {
+          values.push_back ("");
+          args.erase (args.begin() + i);
+        }
+      else if (args[i] == name && i + 1 < args.size())
+        {
+          values.push_back (args[i + 1]);
+          args.erase (args.begin() + i, args.begin() + i + 2);
+        }
+      else if (takes_value && args[i].compare (0, name.size() + 1, name + "=") == 0)
+        {
+          values.push_back (args[i].substr (name.size() + 1));
+          args.erase (args.begin() + i);
+        }
+      else
+        i++;
     }
-  if (ap.parse_opt ("--frames-per-bit", i) && i != Params::frames_per_bit)
-    {
-      error ("audiowmark: --frames-per-bit other than %d is not supported by the GPU path\n", Params::frames_per_bit);
-      exit (1);
-    }
-  if (ap.parse_opt ("--linear"))
-    Params::mix = false;
+  return values;
 }
 
-vector<Key>
-parse_key_list (ArgParser& ap)
+void
+apply_options (vector<string>& args, const Options& options)
 {
-  vector<Key> key_list;
-  for (const auto& f : ap.parse_multi_opt ("--key"))
+  for (const Option& o : options)
     {
-      Key key;
-      key.load_key (f);
-      key_list.push_back (key);
+      const auto values = extract (args, o.name, o.kind != Option::FLAG);
+      if (values.empty())
+        continue;
+      if (o.kind == Option::MULTI)
+        for (const auto& v : values)
+          o.action (v);
+      else
+        o.action (values.back());
     }
-  for (const auto& t : ap.parse_multi_opt ("--test-key"))
-    {
-      Key key;
-      key.set_test_key (atoi_or_die (t));
-      key_list.push_back (key);
-    }
-  if (key_list.empty())
-    key_list.push_back (Key());
-  return key_list;
+}
+
+/* what is left must be exactly the positional arguments of the command */
+vector<string>
+positional (const string& command, const vector<string>& args, std::initializer_list<const char *> names)
+{
+  for (const auto& a : args)
+    if (looks_like_option (a))
+      die ("audiowmark: unsupported option '" + a + "' for command '" + command + "' (use audiowmark -h)\n");
+  if (args.size() == names.size())
+    return args;
+  error ("audiowmark: error parsing arguments for command '%s' (use audiowmark -h)\n\n", command.c_str());
+  string usage = "usage: audiowmark " + command + " [options...]";
+  for (const char *n : names)
+    usage += string (" <") + n + ">";
+  die (usage + "\n");
+}
+
+Options
+shared_options()
+{
+  return {
+    { Option::VALUE, "--short", [] (const string&) { die ("audiowmark: --short payloads are not supported by the GPU path\n"); } },
+    { Option::VALUE, "--frames-per-bit", [] (const string& v) {
+        if (to_int (v) != Params::frames_per_bit)
+          die (string_printf ("audiowmark: --frames-per-bit other than %d is not supported by the GPU path\n", Params::frames_per_bit));
+      } },
+    { Option::FLAG, "--linear", [] (const string&) { Params::mix = false; } },
+  };
+}
+
+Options
+stream_options (bool with_output)
+{
+  RawFormat& in = StreamParams::raw_input_format;
+  RawFormat& out = StreamParams::raw_output_format;
+  Options o {
+    { Option::VALUE, "--input-format", [] (const string& v) { Params::input_format = to_format (v); } },
+  };
+  if (with_output)
+    o.push_back ({ Option::VALUE, "--output-format", [] (const string& v) { Params::output_format = to_format (v); } });
+  o.push_back ({ Option::VALUE, "--format", [with_output] (const string& v) {
+      Params::input_format = to_format (v);
+      if (with_output)
+        Params::output_format = Params::input_format;
+    } });
+  const Options raw {
+    { Option::VALUE, "--raw-input-endian", [&in] (const string& v) { in.endian = to_endian (v); } },
+    { Option::VALUE, "--raw-output-endian", [&out] (const string& v) { out.endian = to_endian (v); } },
+    { Option::VALUE, "--raw-endian", [&in, &out] (const string& v) { in.endian = out.endian = to_endian (v); } },
+    { Option::VALUE, "--raw-input-encoding", [&in] (const string& v) { set_encoding (in, v); } },
+    { Option::VALUE, "--raw-output-encoding", [&out] (const string& v) { set_encoding (out, v); } },
+    { Option::VALUE, "--raw-encoding", [&in, &out] (const string& v) { set_encoding (in, v); set_encoding (out, v); } },
+    { Option::VALUE, "--raw-input-bits", [&in] (const string& v) { set_bits (in, to_int (v)); } },
+    { Option::VALUE, "--raw-output-bits", [&out] (const string& v) { set_bits (out, to_int (v)); } },
+    { Option::VALUE, "--raw-bits", [&in, &out] (const string& v) { set_bits (in, to_int (v)); set_bits (out, to_int (v)); } },
+    { Option::VALUE, "--raw-channels", [&in, &out] (const string& v) { in.n_channels = out.n_channels = to_int (v); } },
+    { Option::VALUE, "--raw-rate", [&in, &out] (const string& v) { in.sample_rate = out.sample_rate = to_int (v); } },
+  };
+  o.insert (o.end(), raw.begin(), raw.end());
+  return o;
+}
+
+void
+check_stream_options()
+{
+  if (Params::input_format == Format::RF64)
+    die ("audiowmark: using rf64 as input format has no effect\n");
+}
+
+Options
+key_options (vector<Key>& keys)
+{
+  return {
+    { Option::MULTI, "--key", [&keys] (const string& file) { Key k; k.load_key (file); keys.push_back (k); } },
+    { Option::MULTI, "--test-key", [&keys] (const string& n) { Key k; k.set_test_key (to_int (n)); keys.push_back (k); } },
+  };
+}
+
+Options
+add_options()
+{
+  Options o { { Option::FLAG, "--snr", [] (const string&) { Params::snr = true; } } };
+  const Options s = stream_options (true);
+  o.insert (o.end(), s.begin(), s.end());
+  o.push_back ({ Option::FLAG, "--test-no-limiter", [] (const string&) { Params::test_no_limiter = true; } });
+  o.push_back ({ Option::VALUE, "--strength", [] (const string& v) { Params::water_delta = to_float (v) / 1000; } });
+  return o;
+}
+
+Options
+get_options (int& speed_options)
+{
+  Options o {
+    { Option::VALUE, "--test-cut", [] (const string& v) { Params::test_cut = to_int (v); } },
+    { Option::VALUE, "--test-truncate", [] (const string& v) { Params::test_truncate = to_int (v); } },
+    { Option::FLAG, "--hard", [] (const string&) { Params::hard = true; } },
+    { Option::FLAG, "--test-no-sync", [] (const string&) { Params::test_no_sync = true; } },
+    { Option::FLAG, "--detect-speed", [&speed_options] (const string&) { Params::detect_speed = true; speed_options++; } },
+    { Option::FLAG, "--detect-speed-patient", [&speed_options] (const string&) { Params::detect_speed_patient = true; speed_options++; } },
+    { Option::VALUE, "--try-speed", [&speed_options] (const string& v) { Params::try_speed = to_float (v); speed_options++; } },
+    { Option::VALUE, "--test-speed", [] (const string& v) { Params::test_speed = to_float (v); } },
+    { Option::VALUE, "--json", [] (const string& v) { Params::json_output = v; } },
+    { Option::VALUE, "--chunk-size", [] (const string& v) {
+        const float minutes = to_float (v);
+        if (minutes < 10)
+          die ("audiowmark: --chunk-size needs to be at least 10 minutes\n");
+        Params::get_chunk_size = minutes;
+      } },
+    { Option::VALUE, "--sync-threshold", [] (const string& v) { Params::sync_threshold2 = to_float (v); } },
+    { Option::VALUE, "--n-best", [] (const string& v) {
+        const int n = to_int (v);
+        if (n < 0)
+          die ("audiowmark: --n-best should not be a negative number\n");
+        Params::get_n_best = n;
+      } },
+    { Option::VALUE, "--strength", [] (const string& v) { Params::water_delta = to_float (v) / 1000; } },
+  };
+  // the reference's get / cmp always open the input through libsndfile; this build has the input options of add instead
+  const Options s = stream_options (false);
+  o.insert (o.end(), s.begin(), s.end());
+  return o;
+}
+
+/* ---- commands ------------------------------------------------------------------------------------------------------ */
+void
+print_usage()
+{
+  static const char *const text =
+    "usage: audiowmark <command> [ <args>... ]\n\n"
+    "Commands:\n"
+    "  * create a watermarked wav file with a message\n"
+    "    audiowmark add <input_wav> <watermarked_wav> <message_hex>\n\n"
+    "  * retrieve message\n"
+    "    audiowmark get <watermarked_wav>\n\n"
+    "  * compare watermark message with expected message\n"
+    "    audiowmark cmp <watermarked_wav> <message_hex>\n\n"
+    "  * generate 128-bit watermarking key, to be used with --key option\n"
+    "    audiowmark gen-key <key_file> [ --name <key_name> ]\n\n"
+    "Global options:\n"
+    "  -q, --quiet             disable information messages\n"
+    "  --strict                treat (minor) problems as errors\n\n"
+    "Options for get / cmp:\n"
+    "  --json <file>           write JSON results into file\n"
+    "  --input-format <f>      raw | wav-pipe | auto (GPU build: get / cmp accept the input options of add)\n\n"
+    "Options for add / get / cmp:\n"
+    "  --key <file>            load watermarking key from file\n";
+  fputs (text, stdout);
+  printf ("  --strength <s>          set watermark strength              [%.6g]\n\n", Params::water_delta * 1000);
+  fputs ("  --input-format raw      use raw stream as input\n"
+         "  --output-format raw     use raw stream as output\n"
+         "  --format raw            use raw stream as input and output\n\n"
+         "The options to set the raw stream parameters (such as --raw-rate\n"
+         "or --raw-channels) are the reference's.\n", stdout);
+}
+
+struct Gpu
+{
+  awm_ctx *ctx = nullptr;
+  Gpu()
+  {
+    const char *dev = getenv ("AWM_DEVICE");          // which GPU of the node (default 0)
+    if (awm_ctx_create (dev ? atoi (dev) : 0, &ctx) != 0)
+      die (string ("audiowmark: ") + awm_last_error() + "\n");
+  }
+  ~Gpu() { awm_ctx_destroy (ctx); }
+};
+
+vector<Key>
+keys_or_default (vector<Key> keys)
+{
+  if (keys.empty())
+    keys.push_back (Key());
+  return keys;
 }
 
 Key
-parse_key (ArgParser& ap)
+single_key (const string& command, const vector<Key>& keys)
 {
-  auto key_list = parse_key_list (ap);
-  if (key_list.size() > 1)
-    {
-      error ("audiowmark %s: watermark key can at most be set once (--key / --test-key option)\n", ap.command().c_str());
-      exit (1);
-    }
-  return key_list[0];
-}
-
-void
-parse_stream_options (ArgParser& ap, bool with_output)
-{
-  string s;
-  int i;
-  if (ap.parse_opt ("--input-format", s)) Params::input_format = parse_format (s);
-  if (with_output && ap.parse_opt ("--output-format", s)) Params::output_format = parse_format (s);
-  if (ap.parse_opt ("--format", s))
-    {
-      Params::input_format = parse_format (s);
-      if (with_output)
-        Params::output_format = Params::input_format;
-    }
-  auto& rin = StreamParams::raw_input_format;
-  auto& rout = StreamParams::raw_output_format;
-  if (ap.parse_opt ("--raw-input-endian", s)) rin.endian = parse_endian (s);
-  if (ap.parse_opt ("--raw-output-endian", s)) rout.endian = parse_endian (s);
-  if (ap.parse_opt ("--raw-endian", s)) rin.endian = rout.endian = parse_endian (s);
-  if (ap.parse_opt ("--raw-input-encoding", s)) parse_encoding (s, rin);
-  if (ap.parse_opt ("--raw-output-encoding", s)) parse_encoding (s, rout);
-  if (ap.parse_opt ("--raw-encoding", s)) { parse_encoding (s, rin); parse_encoding (s, rout); }
-  if (ap.parse_opt ("--raw-input-bits", i)) update_raw_bits (rin, i);
-  if (ap.parse_opt ("--raw-output-bits", i)) update_raw_bits (rout, i);
-  if (ap.parse_opt ("--raw-bits", i)) { update_raw_bits (rin, i); update_raw_bits (rout, i); }
-  if (ap.parse_opt ("--raw-channels", i)) rin.n_channels = rout.n_channels = i;
-  if (ap.parse_opt ("--raw-rate", i)) rin.sample_rate = rout.sample_rate = i;
-  if (Params::input_format == Format::RF64)
-    {
-      error ("audiowmark: using rf64 as input format has no effect\n");
-      exit (1);
-    }
-}
-
-void
-parse_add_options (ArgParser& ap)
-{
-  float f;
-  if (ap.parse_opt ("--snr")) Params::snr = true;
-  parse_stream_options (ap, true);
-  if (ap.parse_opt ("--test-no-limiter")) Params::test_no_limiter = true;
-  if (ap.parse_opt ("--strength", f)) Params::water_delta = f / 1000;
-}
-
-void
-parse_get_options (ArgParser& ap)
-{
-  string s;
-  float f;
-  int i;
-  ap.parse_opt ("--test-cut", Params::test_cut);
-  ap.parse_opt ("--test-truncate", Params::test_truncate);
-  if (ap.parse_opt ("--hard")) Params::hard = true;
-  if (ap.parse_opt ("--test-no-sync")) Params::test_no_sync = true;
-  int speed_options = 0;
-  if (ap.parse_opt ("--detect-speed"))
-    {
-      Params::detect_speed = true;
-      speed_options++;
-    }
-  if (ap.parse_opt ("--detect-speed-patient"))
-    {
-      Params::detect_speed_patient = true;
-      speed_options++;
-    }
-  if (ap.parse_opt ("--try-speed", f))
-    {
-      Params::try_speed = f;
-      speed_options++;
-    }
-  if (speed_options > 1)
-    {
-      error ("audiowmark: can only use one option: --detect-speed or --detect-speed-patient or --try-speed\n");
-      exit (1);
-    }
-  if (ap.parse_opt ("--test-speed", f))
-    Params::test_speed = f;
-  if (ap.parse_opt ("--json", s)) Params::json_output = s;
-  if (ap.parse_opt ("--chunk-size", f))
-    {
-      if (f < 10)
-        {
-          error ("audiowmark: --chunk-size needs to be at least 10 minutes\n");
-          exit (1);
-        }
-      Params::get_chunk_size = f;
-    }
-  if (ap.parse_opt ("--sync-threshold", f)) Params::sync_threshold2 = f;
-  if (ap.parse_opt ("--n-best", i))
-    {
-      if (i < 0)
-        {
-          error ("audiowmark: --n-best should not be a negative number\n");
-          exit (1);
-        }
-      Params::get_n_best = i;
-    }
-  if (ap.parse_opt ("--strength", f)) Params::water_delta = f / 1000;
-  // the reference's get / cmp always open the input through libsndfile; this build has the input options of add instead
-  parse_stream_options (ap, false);
-}
-
-template<class... Args> vector<string>
-parse_positional (ArgParser& ap, Args... arg_names)
-{
-  const vector<string> names { arg_names... };
-  vector<string> args;
-  if (ap.parse_args (names.size(), args))
-    return args;
-  for (const auto& arg : ap.remaining_args())
-    if (is_option (arg))
-      {
-        error ("audiowmark: unsupported option '%s' for command '%s' (use audiowmark -h)\n", arg.c_str(), ap.command().c_str());
-        exit (1);
-      }
-  error ("audiowmark: error parsing arguments for command '%s' (use audiowmark -h)\n\n", ap.command().c_str());
-  string msg = "usage: audiowmark " + ap.command() + " [options...]";
-  for (const auto& s : names)
-    msg += " <" + s + ">";
-  error ("%s\n", msg.c_str());
-  exit (1);
-}
-
-awm_ctx *
-open_gpu()
-{
-  awm_ctx *ctx = nullptr;
-  const char *dev = getenv ("AWM_DEVICE");
-  if (awm_ctx_create (dev ? atoi (dev) : 0, &ctx) != 0)
-    {
-      error ("audiowmark: %s\n", awm_last_error());
-      exit (1);
-    }
-  return ctx;
+  if (keys.size() > 1)
+    die ("audiowmark " + command + ": watermark key can at most be set once (--key / --test-key option)\n");
+  return keys_or_default (keys)[0];
 }
 
 int
-gen_key (const string& outfile, const string& key_name)
+cmd_add (vector<string>& args)
 {
-  FILE *f = fopen (outfile.c_str(), "w");
+  vector<Key> keys;
+  apply_options (args, shared_options());
+  apply_options (args, add_options());
+  check_stream_options();
+  apply_options (args, key_options (keys));
+  const Key key = single_key ("add", keys);
+  const auto pos = positional ("add", args, { "input_wav", "watermarked_wav", "message_hex" });
+  Gpu gpu;
+  return add_watermark (gpu.ctx, key, pos[0], pos[1], pos[2]);
+}
+
+int
+cmd_get (vector<string>& args, bool cmp)
+{
+  vector<Key> keys;
+  int speed_options = 0;
+  apply_options (args, shared_options());
+  apply_options (args, get_options (speed_options));
+  if (speed_options > 1)
+    die ("audiowmark: can only use one option: --detect-speed or --detect-speed-patient or --try-speed\n");
+  check_stream_options();
+  if (cmp)
+    apply_options (args, { { Option::VALUE, "--expect-matches", [] (const string& v) { Params::expect_matches = to_int (v); } } });
+  apply_options (args, key_options (keys));
+  const auto pos = cmp ? positional ("cmp", args, { "watermarked_wav", "message_hex" }) : positional ("get", args, { "watermarked_wav" });
+  Gpu gpu;
+  return get_watermark (gpu.ctx, keys_or_default (keys), pos[0], cmp ? pos[1] : "");
+}
+
+int
+cmd_gen_key (vector<string>& args)
+{
+  string name;
+  apply_options (args, { { Option::VALUE, "--name", [&name] (const string& v) { name = v; } } });
+  const auto pos = positional ("gen-key", args, { "key_file" });
+  FILE *f = fopen (pos[0].c_str(), "w");
   if (!f)
     {
-      error ("audiowmark: error writing to file %s\n", outfile.c_str());
+      error ("audiowmark: error writing to file %s\n", pos[0].c_str());
       return 1;
     }
   fprintf (f, "# watermarking key for audiowmark\n\nkey %s\n", Random::gen_key().c_str());
-  if (!key_name.empty())
-    fprintf (f, "name %s\n", key_name.c_str());
+  if (!name.empty())
+    fprintf (f, "name %s\n", name.c_str());
   fclose (f);
   return 0;
 }
 
 int
-test_gen_noise (const Key& key, const string& out_file, double seconds, int rate, int bits)
+cmd_test_change_speed (vector<string>& args)
 {
-  // reference audiowmark.cc:399-417
-  const int channels = 2;
-  vector<float> noise;
-  Random rng (key, 0, Random::Stream::data_up_down);
-  for (size_t i = 0; i < size_t (rate * seconds) * channels; i++)
-    noise.push_back (rng.random_double() * 2 - 1);
-  WavData out (noise, channels, rate, bits);
-  Error err = out.save (out_file);
+  apply_options (args, shared_options());
+  apply_options (args, stream_options (true));
+  check_stream_options();
+  const auto pos = positional ("test-change-speed", args, { "input_wav", "output_wav", "speed" });
+  Gpu gpu;
+  return test_change_speed (gpu.ctx, pos[0], pos[1], to_float (pos[2]));
+}
+
+int
+cmd_test_gen_noise (vector<string>& args)
+{
+  // reference audiowmark.cc:399-417: stereo, uniform [-1, 1) from the key's data_up_down stream
+  vector<Key> keys;
+  int bits = 16;
+  apply_options (args, shared_options());
+  apply_options (args, { { Option::VALUE, "--bits", [&bits] (const string& v) { bits = to_int (v); } } });
+  apply_options (args, key_options (keys));
+  const Key key = single_key ("test-gen-noise", keys);
+  const auto pos = positional ("test-gen-noise", args, { "output_wav", "seconds", "sample_rate" });
+  const int rate = to_int (pos[2]);
+  vector<float> noise (size_t (rate * to_float (pos[1])) * 2);
+  awm_test_gen_noise (key.aes_key(), noise.size(), noise.data());
+  const Error err = WavData (noise, 2, rate, bits).save (pos[0]);
   if (err)
     {
-      error ("audiowmark: error saving %s: %s\n", out_file.c_str(), err.message());
+      error ("audiowmark: error saving %s: %s\n", pos[0].c_str(), err.message());
       return 1;
     }
   return 0;
 }
 
 int
-test_snr (const string& orig_file, const string& wm_file)
+cmd_test_snr (vector<string>& args)
 {
-  WavData orig, wm;
-  Error err = orig.load (orig_file);
+  const auto pos = positional ("test-snr", args, { "orig_wav", "watermarked_wav" });
+  WavData orig, marked;
+  Error err = orig.load (pos[0]);
   if (!err)
-    err = wm.load (wm_file);
+    err = marked.load (pos[1]);
   if (err)
     {
       error ("audiowmark: error loading: %s\n", err.message());
       return 1;
     }
-  if (orig.n_values() != wm.n_values())
+  if (orig.n_values() != marked.n_values())
     {
       error ("audiowmark: files have different length\n");
       return 1;
     }
-  double delta_power = 0, signal_power = 0;
+  double noise_power = 0, signal_power = 0;
   for (size_t i = 0; i < orig.n_values(); i++)
     {
-      const double o = orig.samples()[i], d = o - wm.samples()[i];
-      delta_power += d * d;
-      signal_power += o * o;
+      const double s = orig.samples()[i], n = s - marked.samples()[i];
+      noise_power += n * n;
+      signal_power += s * s;
     }
-  printf ("snr_db %f\n", 10 * log10 (signal_power / delta_power));
+  printf ("snr_db %f\n", 10 * log10 (signal_power / noise_power));
   return 0;
 }
 
@@ -446,91 +436,53 @@ test_snr (const string& orig_file, const string& wm_file)
 int
 main (int argc, char **argv)
 {
-  ArgParser ap (argc, argv);
-  vector<string> args;
-  if (ap.parse_opt ("--help") || ap.parse_opt ("-h"))
+  vector<string> args (argv + 1, argv + argc);
+  bool help = false, version = false;
+  apply_options (args, {
+    { Option::FLAG, "--help", [&help] (const string&) { help = true; } },
+    { Option::FLAG, "-h", [&help] (const string&) { help = true; } },
+    { Option::FLAG, "--version", [&version] (const string&) { version = true; } },
+    { Option::FLAG, "-v", [&version] (const string&) { version = true; } },
+  });
+  if (help)
     {
       print_usage();
       return 0;
     }
-  if (ap.parse_opt ("--version") || ap.parse_opt ("-v"))
+  if (version)
     {
       printf ("audiowmark 0.6.5 (%s)\n", awm_version());
       return 0;
     }
-  if (ap.parse_opt ("--quiet") || ap.parse_opt ("-q"))
-    set_log_level (Log::WARNING);
-  if (ap.parse_opt ("--strict"))
-    Params::strict = true;
-
-  if (ap.parse_cmd ("add"))
+  apply_options (args, {
+    { Option::FLAG, "--quiet", [] (const string&) { set_log_level (Log::WARNING); } },
+    { Option::FLAG, "-q", [] (const string&) { set_log_level (Log::WARNING); } },
+    { Option::FLAG, "--strict", [] (const string&) { Params::strict = true; } },
+  });
+  if (args.empty())
     {
-      parse_shared_options (ap);
-      parse_add_options (ap);
-      Key key = parse_key (ap);
-      args = parse_positional (ap, "input_wav", "watermarked_wav", "message_hex");
-      awm_ctx *ctx = open_gpu();
-      const int rc = add_watermark (ctx, key, args[0], args[1], args[2]);
-      awm_ctx_destroy (ctx);
-      return rc;
-    }
-  else if (ap.parse_cmd ("get") || ap.parse_cmd ("cmp"))
-    {
-      const bool cmp = ap.command() == "cmp";
-      parse_shared_options (ap);
-      parse_get_options (ap);
-      if (cmp)
-        ap.parse_opt ("--expect-matches", Params::expect_matches);
-      vector<Key> key_list = parse_key_list (ap);
-      if (cmp)
-        args = parse_positional (ap, "watermarked_wav", "message_hex");
-      else
-        args = parse_positional (ap, "watermarked_wav");
-      awm_ctx *ctx = open_gpu();
-      const int rc = get_watermark (ctx, key_list, args[0], cmp ? args[1] : "");
-      awm_ctx_destroy (ctx);
-      return rc;
-    }
-  else if (ap.parse_cmd ("gen-key"))
-    {
-      string key_name;
-      ap.parse_opt ("--name", key_name);
-      args = parse_positional (ap, "key_file");
-      return gen_key (args[0], key_name);
-    }
-  else if (ap.parse_cmd ("test-change-speed"))
-    {
-      parse_shared_options (ap);
-      parse_stream_options (ap, true);
-      args = parse_positional (ap, "input_wav", "output_wav", "speed");
-      awm_ctx *ctx = open_gpu();
-      const int rc = test_change_speed (ctx, args[0], args[1], atof_or_die (args[2]));
-      awm_ctx_destroy (ctx);
-      return rc;
-    }
-  else if (ap.parse_cmd ("test-gen-noise"))
-    {
-      parse_shared_options (ap);
-      int bits = 16;
-      ap.parse_opt ("--bits", bits);
-      Key key = parse_key (ap);
-      args = parse_positional (ap, "output_wav", "seconds", "sample_rate");
-      return test_gen_noise (key, args[0], atof_or_die (args[1]), atoi_or_die (args[2]), bits);
-    }
-  else if (ap.parse_cmd ("test-snr"))
-    {
-      args = parse_positional (ap, "orig_wav", "watermarked_wav");
-      return test_snr (args[0], args[1]);
-    }
-  else if (!ap.remaining_args().empty())
-    {
-      const string s = ap.remaining_args().front();
-      if (is_option (s))
-        error ("audiowmark: unsupported global option '%s' (use audiowmark -h)\n", s.c_str());
-      else
-        error ("audiowmark: unsupported command '%s' (use audiowmark -h)\n", s.c_str());
+      error ("audiowmark: error parsing commandline args (use audiowmark -h)\n");
       return 1;
     }
-  error ("audiowmark: error parsing commandline args (use audiowmark -h)\n");
+  const string command = args.front();
+  const std::pair<const char *, std::function<int (vector<string>&)>> commands[] = {
+    { "add", cmd_add },
+    { "get", [] (vector<string>& a) { return cmd_get (a, false); } },
+    { "cmp", [] (vector<string>& a) { return cmd_get (a, true); } },
+    { "gen-key", cmd_gen_key },
+    { "test-change-speed", cmd_test_change_speed },
+    { "test-gen-noise", cmd_test_gen_noise },
+    { "test-snr", cmd_test_snr },
+  };
+  for (const auto& c : commands)
+    if (command == c.first)
+      {
+        args.erase (args.begin());
+        return c.second (args);
+      }
+  if (looks_like_option (command))
+    error ("audiowmark: unsupported global option '%s' (use audiowmark -h)\n", command.c_str());
+  else
+    error ("audiowmark: unsupported command '%s' (use audiowmark -h)\n", command.c_str());
   return 1;
 }

@@ -155,6 +155,8 @@ add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames
   a.first_block = (long long) first_block;
   a.n_blocks = (long long) n_blocks;
   a.limiter_block = LIMITER_BLOCK;
+  a.block_frames = int (mark_block_frame_count());
+  a.frames_pad_start = int (Params::frames_pad_start);
   a.frames_per_span = frames_per_span (ctx, (long long) (n_frames + 1023) / 1024);
   ProfScope ps (ctx, PROF_ADD_MIX, double (n_frames) * n_channels * 8.0);     // read + write every sample once
   AWM_HIP_CHECK (awmk::launch_add_mix (ctx->stream, ctx->tabs, a));
@@ -333,6 +335,8 @@ add_full_rate (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frame
     a.neg_delta_up = float (-water_delta * 1);
     a.neg_delta_down = float (-water_delta * -1);
     a.limiter_block = LIMITER_BLOCK;
+    a.block_frames = int (mark_block_frame_count());
+    a.frames_pad_start = int (Params::frames_pad_start);
     a.frames_per_span = frames_per_span (ctx, (long long) (F + 1));
     a.delta_only = 1;
     ProfScope ps (ctx, PROF_ADD_MIX, double (n44) * C * 8.0);

@@ -202,4 +202,11 @@ awm_set_params (double water_delta, int mix, int frames_per_bit, int test_no_lim
   Params::get_chunk_size = chunk_size_min;
 }
 
+/* -q / --quiet of the command line (reference audiowmark.cc:1020-1023): information messages off */
+void
+awm_set_quiet (int quiet)
+{
+  set_log_level (quiet ? Log::WARNING : Log::INFO);
+}
+
 } // extern "C"

@@ -317,6 +317,15 @@ awm_ctx::get_resample_table (int rate_in, int rate_out)
   return resample_tables.back().get();
 }
 
+hipStream_t
+awm_ctx::get_copy_stream()
+{
+  std::lock_guard<std::mutex> lock (table_mutex);
+  if (!copy_stream && hipStreamCreateWithFlags (&copy_stream, hipStreamNonBlocking) != hipSuccess)
+    copy_stream = nullptr;
+  return copy_stream;
+}
+
 FrameModTable *
 awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
 {
@@ -494,6 +503,15 @@ awm_ctx_create (int device, awm_ctx **ctx_out)
   return 0;
 }
 
+int
+awm_ctx_set_chunk_lanes (awm_ctx *ctx, int n_lanes)
+{
+  if (!ctx || n_lanes < 1)
+    return AWM_ERR_ARG;
+  ctx->chunk_lanes = std::min (n_lanes, awm::CHUNK_LANES);
+  return 0;
+}
+
 void
 awm_ctx_destroy (awm_ctx *ctx)
 {
@@ -523,6 +541,8 @@ awm_ctx_destroy (awm_ctx *ctx)
           (void) hipStreamDestroy (l->stream);
       }
   ctx->release_lane();
+  if (ctx->copy_stream)
+    (void) hipStreamDestroy (ctx->copy_stream);
   if (ctx->own_stream && ctx->stream)
     (void) hipStreamDestroy (ctx->stream);
   delete ctx;

@@ -173,6 +173,9 @@ struct awm_ctx : awm::WorkLane
   awm::DevBuffer ws_rate_a, ws_rate_b, ws_rate_c;                          // resampled input / watermark signals of the other-rate add path
   std::unique_ptr<awm::WorkLane> extra_lanes[awm::MAX_LANES - 1];
   awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
+  hipStream_t    copy_stream = nullptr;  // H2D / D2H staging of the file level paths (created on first use)
+  hipStream_t    get_copy_stream();
+  int            chunk_lanes = awm::CHUNK_LANES;   // lanes the chunks of one stream may be spread over (awm_ctx_set_chunk_lanes)
 
   awm::SpeedWorkspace *speed = nullptr;  // tables and buffers of the speed detection (wmspeed.cc), created on first use
   std::mutex     speed_mutex;            // one speed search at a time per context

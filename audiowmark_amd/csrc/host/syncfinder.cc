@@ -259,7 +259,7 @@ SyncFinder::select_finish (long long n_scores, double threshold, std::vector<Sea
   const int k = Params::get_n_best + 1;
   constexpr int n_slices = TOPK_SLICES;
   const bool fewer_than_n_best = int (count) < Params::get_n_best;      // (not: more than `cap` above the threshold)
-  if (fewer_than_n_best && k <= TOPK_MAX && !getenv ("AWM_NBEST_HOST"))
+  if (fewer_than_n_best && k <= TOPK_MAX)
     {
       std::vector<awmk::PeakOut> top (size_t (k) * n_slices);
       if (speculated)
@@ -418,7 +418,7 @@ SyncFinder::refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, Searc
   job.batch_pending = false;
   if (!n_cand)
     return 0;
-  const bool gathered = wav.n_channels <= 2 && !getenv ("AWM_REFINE_FFT");
+  const bool gathered = wav.n_channels <= 2;
   const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
   const size_t per_cand = size_t (NW) * row_values * REFINE_TP;
   size_t batch = std::max<size_t> (1, (size_t (3) << 30) / (per_cand * sizeof (float)));    // <= 3 GiB of dB rows at a time
@@ -447,7 +447,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
   const long long total = total_frames (mode);
   const int TP = REFINE_TP, QS = REFINE_QS;
   hipStream_t st = m_lane->stream;
-  const bool gathered = wav.n_channels <= 2 && !getenv ("AWM_REFINE_FFT");
+  const bool gathered = wav.n_channels <= 2;
   const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
   const size_t per_cand = size_t (NW) * row_values * TP;
   (void) batch;

@@ -61,6 +61,9 @@ read_chunk (AudioInputStream *in, bool raw, size_t unit_bytes, unsigned char *ds
   return Error::Code::NONE;
 }
 
+/* One copy stream per context serves both directions: every additional HIP stream costs ~190 MB of resident host memory
+ * on this runtime (tools/rss_probe), and a staging chunk crosses PCIe in well under a millisecond -- far less than the file
+ * I/O it overlaps with. */
 struct Staging
 {
   hipStream_t copy = nullptr;
@@ -68,9 +71,10 @@ struct Staging
   PinnedBuffer host[2];
   DevBuffer    dev[2];
   bool ok = false;
-  Staging (size_t bytes, bool need_dev)
+  Staging (awm_ctx *ctx, size_t bytes, bool need_dev)
   {
-    ok = hipStreamCreateWithFlags (&copy, hipStreamNonBlocking) == hipSuccess;
+    copy = ctx->get_copy_stream();
+    ok = copy != nullptr;
     for (int i = 0; i < 2 && ok; i++)
       ok = hipEventCreateWithFlags (&ev_copied[i], hipEventDisableTiming) == hipSuccess
         && hipEventCreateWithFlags (&ev_used[i], hipEventDisableTiming) == hipSuccess
@@ -79,10 +83,7 @@ struct Staging
   ~Staging()
   {
     if (copy)
-      {
-        (void) hipStreamSynchronize (copy);
-        (void) hipStreamDestroy (copy);
-      }
+      (void) hipStreamSynchronize (copy);
     for (int i = 0; i < 2; i++)
       {
         if (ev_copied[i]) (void) hipEventDestroy (ev_copied[i]);
@@ -102,7 +103,7 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
   RawFormat fmt;
   const bool raw = in_stream->raw_access (fmt) && device_codec_supported (fmt);
   const size_t unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
-  Staging st (STAGE_FRAMES * unit, raw);
+  Staging st (ctx, STAGE_FRAMES * unit, raw);
   if (!st.ok)
     return Error ("out of memory for input staging");
   size_t cap_frames = in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN ? in_stream->n_frames() + 1 : STAGE_FRAMES * 4;
@@ -256,7 +257,8 @@ struct OutputStage
   {
     raw = out->raw_access (fmt, direct16) && device_codec_supported (fmt);
     unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
-    ok = hipStreamCreateWithFlags (&copy, hipStreamNonBlocking) == hipSuccess;
+    copy = ctx->get_copy_stream();
+    ok = copy != nullptr;
     for (int i = 0; i < SLOTS && ok; i++)
       ok = hipEventCreateWithFlags (&ev_encoded[i], hipEventDisableTiming) == hipSuccess
         && hipEventCreateWithFlags (&ev_copied[i], hipEventDisableTiming) == hipSuccess
@@ -268,10 +270,7 @@ struct OutputStage
   {
     writer.reset();
     if (copy)
-      {
-        (void) hipStreamSynchronize (copy);
-        (void) hipStreamDestroy (copy);
-      }
+      (void) hipStreamSynchronize (copy);
     for (int i = 0; i < SLOTS; i++)
       {
         if (ev_encoded[i]) (void) hipEventDestroy (ev_encoded[i]);
@@ -409,7 +408,7 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   RawFormat fmt;
   const bool raw = in_stream->raw_access (fmt) && device_codec_supported (fmt);
   const size_t unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
-  Staging st (tile * unit, raw);
+  Staging st (ctx, tile * unit, raw);
   OutputStage stage (ctx, out_stream, tile);
   if (!st.ok || !stage.ok)
     {

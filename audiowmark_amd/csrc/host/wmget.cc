@@ -9,222 +9,6 @@
 
 namespace awm {
 
-/* ---- ResultSet (reference wmget.cc:163-474) ------------------------------------------- */
-
-bool
-ResultSet::Pattern::approx_match (const Pattern& p) const
-{
-  const double time_delta = Params::frame_size / double (Params::mark_sample_rate);
-  const double speed_delta = 0.01;
-  return key == p.key
-      && (std::fabs (time - p.time) < time_delta || type == Type::ALL)
-      && bit_vec == p.bit_vec
-      && sync_score.block_type == p.sync_score.block_type
-      && type == p.type
-      && std::fabs (speed - p.speed) < speed_delta;
-}
-
-void
-ResultSet::add_pattern (const Key& key, double time, SyncFinder::Score sync_score, const std::vector<int>& bit_vec,
-                        float decode_error, Type type, double speed)
-{
-  Pattern p;
-  p.key = key;
-  p.time = time;
-  p.sync_score = sync_score;
-  p.bit_vec = bit_vec;
-  p.decode_error = decode_error;
-  p.type = type;
-  p.speed = speed;
-  patterns.push_back (p);
-}
-
-void
-ResultSet::apply_time_offset (double time_offset)
-{
-  for (auto& p : patterns)
-    p.time += time_offset;
-}
-
-void
-ResultSet::rate_patterns (const Key& key)
-{
-  // sum of sync qualities per distinct payload, "all" patterns count twice; float accumulation
-  std::map<std::string, float> rating;
-  for (const auto& p : patterns)
-    if (p.key == key)
-      rating[bit_vec_to_str (p.bit_vec)] += p.sync_score.quality * (p.type == Type::ALL ? 2.f : 1.f);
-  for (auto& p : patterns)
-    if (p.key == key)
-      p.rating = rating[bit_vec_to_str (p.bit_vec)];
-}
-
-static int
-ab_rank (const ResultSet::Pattern& p)
-{
-  switch (p.sync_score.block_type)
-    {
-    case ConvBlockType::a:  return 0;
-    case ConvBlockType::b:  return 1;
-    case ConvBlockType::ab: return 2;
-    }
-  return 99;
-}
-
-void
-ResultSet::sort (const std::vector<Key>& key_list)
-{
-  for (const auto& key : key_list)
-    rate_patterns (key);
-  std::sort (patterns.begin(), patterns.end(), [] (const Pattern& p1, const Pattern& p2) {
-    const int all1 = p1.type == Type::ALL, all2 = p2.type == Type::ALL;
-    if (p1.key.name() != p2.key.name())
-      return p1.key.name() < p2.key.name();
-    if (p1.rating != p2.rating)
-      return p1.rating > p2.rating;
-    if (all1 != all2)
-      return all1 < all2;
-    if (p1.time != p2.time)
-      return p1.time < p2.time;
-    if (ab_rank (p1) != ab_rank (p2))
-      return ab_rank (p1) < ab_rank (p2);
-    return bit_vec_to_str (p1.bit_vec) < bit_vec_to_str (p2.bit_vec);
-  });
-}
-
-void
-ResultSet::merge (ResultSet& other)
-{
-  std::vector<Pattern> to_merge = other.patterns;
-  std::stable_sort (to_merge.begin(), to_merge.end(), [] (const Pattern& a, const Pattern& b) { return a.time < b.time; });
-  for (const auto& p : to_merge)
-    {
-      bool is_new = true;
-      for (const auto& mine : patterns)
-        if (mine.approx_match (p))
-          is_new = false;
-      if (is_new)
-        patterns.push_back (p);
-    }
-  if (m_debug_sync.empty())
-    m_debug_sync = other.m_debug_sync;
-}
-
-static std::string
-block_label (const ResultSet::Pattern& p)
-{
-  std::string s;
-  switch (p.sync_score.block_type)
-    {
-    case ConvBlockType::a:  s = "A";  break;
-    case ConvBlockType::b:  s = "B";  break;
-    case ConvBlockType::ab: s = "AB"; break;
-    }
-  return s;
-}
-
-void
-ResultSet::print() const
-{
-  std::string last_key_name;
-  bool print_speed = true;
-  for (const auto& pattern : patterns)
-    {
-      if (pattern.key.name() != last_key_name)
-        {
-          printf ("key %s\n", pattern.key.name().c_str());
-          last_key_name = pattern.key.name();
-          print_speed = true;
-        }
-      if (print_speed)
-        {
-          for (const auto& p : patterns)
-            if (p.key == pattern.key && p.speed != 1)
-              {
-                printf ("speed %.6f\n", p.speed);
-                break;
-              }
-          print_speed = false;
-        }
-      if (pattern.type == Type::ALL)
-        printf ("pattern   all %s %.3f %.3f%s\n", bit_vec_to_str (pattern.bit_vec).c_str(), pattern.sync_score.quality,
-                pattern.decode_error, pattern.speed != 1 ? " SPEED" : "");
-      else
-        {
-          std::string block_str = block_label (pattern);
-          if (pattern.type == Type::CLIP)
-            block_str = "CLIP-" + block_str;
-          if (pattern.speed != 1)
-            block_str += "-SPEED";
-          const int seconds = pattern.time;
-          printf ("pattern %2d:%02d %s %.3f %.3f %s\n", seconds / 60, seconds % 60, bit_vec_to_str (pattern.bit_vec).c_str(),
-                  pattern.sync_score.quality, pattern.decode_error, block_str.c_str());
-        }
-    }
-}
-
-static std::string
-json_escape (const std::string& s)
-{
-  std::string r;
-  for (unsigned char ch : s)
-    {
-      if (ch == '"' || ch == '\\')
-        {
-          r += '\\';
-          r += char (ch);
-        }
-      else if (ch < 32)
-        r += string_printf ("\\u%04x", ch);
-      else
-        r += char (ch);
-    }
-  return r;
-}
-
-void
-ResultSet::print_json (size_t time_length, const std::string& json_file) const
-{
-  FILE *out = fopen (json_file == "-" ? "/dev/stdout" : json_file.c_str(), "w");
-  if (!out)
-    {
-      perror (("audiowmark: failed to open \"" + json_file + "\":").c_str());
-      exit (127);
-    }
-  fprintf (out, "{ \"length\": \"%ld:%02ld\",\n", long (time_length / 60), long (time_length % 60));
-  fprintf (out, "  \"matches\": [\n");
-  int nth = 0;
-  for (const auto& p : patterns)
-    {
-      if (nth++)
-        fprintf (out, ",\n");
-      std::string btype = block_label (p);
-      if (p.type == Type::ALL)
-        btype = "ALL";
-      if (p.type == Type::CLIP)
-        btype = "CLIP-" + btype;
-      if (p.speed != 1)
-        btype += "-SPEED";
-      const int seconds = p.time;
-      fprintf (out, "    { \"key\": \"%s\", \"pos\": \"%d:%02d\", \"bits\": \"%s\", \"quality\": %.5f, \"error\": %.6f, \"rating\": %.5f, \"type\": \"%s\", \"speed\": %.6f }",
-               json_escape (p.key.name()).c_str(), seconds / 60, seconds % 60, bit_vec_to_str (p.bit_vec).c_str(),
-               p.sync_score.quality, p.decode_error, p.rating, btype.c_str(), p.speed);
-    }
-  fprintf (out, " ]\n}\n");
-  fclose (out);
-}
-
-int
-ResultSet::print_match_count (const std::vector<int>& orig_bits) const
-{
-  int match_count = 0;
-  for (const auto& p : patterns)
-    if (p.bit_vec == orig_bits)
-      match_count++;
-  printf ("match_count %d %zd\n", match_count, patterns.size());
-  return match_count;
-}
-
 /* ---- soft bits ------------------------------------------------------------------------ */
 
 /* reference wmget.cc:40-65 */
@@ -730,7 +514,7 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
    * A single chunk (short files) runs on the context's own stream. */
   // `spread` = use the context's lanes 0 .. CHUNK_LANES - 1 (the caller owns the whole context); otherwise everything
   // stays on `home` (a batch of clips runs one clip per lane, each driven by its own host thread)
-  const int n_lanes = (!spread || getenv ("AWM_ONE_LANE")) ? 1 : int (std::min<size_t> (chunks.size(), CHUNK_LANES));
+  const int n_lanes = !spread ? 1 : int (std::min<size_t> (chunks.size(), size_t (std::max (1, std::min (ctx->chunk_lanes, CHUNK_LANES)))));
   std::vector<WorkLane *> lanes;
   if (!spread)
     lanes.push_back (home);
@@ -951,7 +735,7 @@ clip_decoder_run (awm_ctx *ctx, WorkLane *lane, bool spread, const std::vector<K
   const int wav_frames = wav.n_values() / (Params::frame_size * wav.n_channels);
   if (wav_frames < int (mark_block_frame_count()) * 3.1)       // only short files
     {
-      WorkLane *second = (spread && !getenv ("AWM_ONE_LANE")) ? ctx->lane (lane == ctx ? 1 : 0) : nullptr;
+      WorkLane *second = (spread && ctx->chunk_lanes > 1) ? ctx->lane (lane == ctx ? 1 : 0) : nullptr;
       if (!second)
         {
           if (int rc = clip_run_block (ctx, lane, key_list, wav, result_set, ClipPos::START, speed))
@@ -1323,7 +1107,7 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
       return 0;
     }
   for (size_t i = 0; i < clips.size(); i++)
-    (clip_is_short (clips[i]) && !getenv ("AWM_BATCH_THREADS") ? staged : threaded).push_back (i);
+    (clip_is_short (clips[i]) ? staged : threaded).push_back (i);
   if (!staged.empty())
     {
       if (!ctx->ev_sync)
@@ -1338,8 +1122,7 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
       // ~45 launches and copies per clip.  A second host thread staging its own share of the clips over its own share of
       // the lanes helps a little (0.69 -> 0.64 ms per clip), more threads hardly (0.61): the limit is the rate at which one
       // process gets dispatches and copies through the runtime (~75 000 per second), not the issuing thread
-      const char *env = getenv ("AWM_STAGED_THREADS");
-      const int want = env ? atoi (env) : STAGED_THREADS;
+      const int want = STAGED_THREADS;
       const int n_staged_threads = std::max (1, std::min<int> ({ want, MAX_LANES / 2, int ((staged.size() + 3) / 4) }));
       if (n_staged_threads == 1)
         {

@@ -157,12 +157,19 @@ class Partition:
         return out
 
 
-def exchange_edge_frames(dist, local, n_channels):
+def exchange_edge_frames(dist, local, n_channels, lengths=None):
     """all_gather of each rank's first and last frame -> (halo_before, halo_after) for this rank (None at the ends).
-    A last frame shorter than 1024 samples is zero padded (it can only be the end of the stream)."""
+    A last frame shorter than 1024 samples is zero padded (it can only be the end of the stream).  Ranks with an EMPTY span
+    are skipped: the halo is the adjacent frame of the stream, i.e. the edge frame of the nearest rank that holds samples.
+    `lengths` = the span lengths of all ranks (Partition.lengths) if the caller knows them, else they are gathered."""
     import torch
     rank, world = dist.get_rank(), dist.get_world_size()
     n = local.shape[0]
+    comm = _Comm(dist)
+    if lengths is None:
+        lens = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
+        comm.all_gather(lens, torch.tensor([n], dtype=torch.int64, device=local.device))
+        lengths = [int(t.item()) for t in lens]
     edge = torch.zeros((2, FRAME, n_channels), dtype=local.dtype, device=local.device)
     view = local.reshape(n, n_channels)
     edge[0, :min(FRAME, n)] = view[:FRAME]
@@ -170,9 +177,11 @@ def exchange_edge_frames(dist, local, n_channels):
     tail = view[last_start:]
     edge[1, :tail.shape[0]] = tail
     gathered = [torch.empty_like(edge) for _ in range(world)]
-    _Comm(dist).all_gather(gathered, edge)
-    before = gathered[rank - 1][1].contiguous() if rank > 0 else None
-    after = gathered[rank + 1][0].contiguous() if rank + 1 < world else None
+    comm.all_gather(gathered, edge)
+    prev = next((r for r in range(rank - 1, -1, -1) if lengths[r]), None)
+    nxt = next((r for r in range(rank + 1, world) if lengths[r]), None)
+    before = gathered[prev][1].contiguous() if prev is not None else None
+    after = gathered[nxt][0].contiguous() if nxt is not None else None
     return before, after
 
 
@@ -200,35 +209,56 @@ def fetch_range(dist, part: Partition, local, n_channels):
     return buf, lo
 
 
+def gather_patterns(dist, my_chunk_patterns):
+    """{chunk index: structured array (PATTERN_DTYPE)} of this rank -> the union over all ranks, on every rank.
+    Two collectives on plain byte tensors (the "score gather" of the path): the record counts, then the records padded to the
+    longest list -- a record is the chunk index (int32) followed by the pattern."""
+    import torch
+    comm = _Comm(dist)
+    world = dist.get_world_size()
+    rec = np.dtype([("chunk", np.int32), ("pattern", awm.PATTERN_DTYPE)])
+    mine = np.zeros(sum(len(p) for p in my_chunk_patterns.values()), rec)
+    pos = 0
+    for ci in sorted(my_chunk_patterns):
+        pats = my_chunk_patterns[ci]
+        mine["chunk"][pos:pos + len(pats)] = ci
+        mine["pattern"][pos:pos + len(pats)] = pats
+        pos += len(pats)
+    dev = getattr(dist, "_awm_device", None) or "cpu"
+    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    comm.all_gather(counts, torch.tensor([len(mine)], dtype=torch.int64, device=dev))
+    counts = [int(c.item()) for c in counts]
+    longest = max(counts)
+    out = {}
+    if longest:
+        buf = np.zeros(longest, rec)
+        buf[:len(mine)] = mine
+        t = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy()).to(dev)
+        parts = [torch.empty_like(t) for _ in range(world)]
+        comm.all_gather(parts, t)
+        for r, p in enumerate(parts):
+            recs = p.cpu().numpy().view(rec)[:counts[r]]
+            for ci in np.unique(recs["chunk"]):
+                out[int(ci)] = recs["pattern"][recs["chunk"] == ci].copy()
+    return out
+
+
 def gather_and_merge(dist, part: Partition, key, my_chunk_patterns):
-    """my_chunk_patterns: {global chunk index: patterns with chunk relative times} -> merged list on rank 0.  The values are
-    structured arrays (binding.PATTERN_DTYPE) on the fast path or lists of pattern dicts (tests)."""
+    """my_chunk_patterns: {global chunk index: patterns with chunk relative times} -> merged list on rank 0 (None elsewhere).
+    The values are structured arrays (binding.PATTERN_DTYPE) or lists of pattern dicts (converted)."""
     plan = part.chunk_plan()
     payload = {}
-    raw = True
     for ci, pats in my_chunk_patterns.items():
-        off = plan[ci][2]
-        if isinstance(pats, np.ndarray):
-            pats = pats.copy()
-            pats["time"] += off                                                # ResultSet::apply_time_offset
-            payload[ci] = pats
-        else:
-            raw = False
-            payload[ci] = [dict(p, time=p["time"] + off) for p in pats]
-    world = dist.get_world_size()
-    gathered = [None] * world if dist.get_rank() == 0 else None
-    dist.gather_object((raw, payload), gathered, dst=0)
+        if not isinstance(pats, np.ndarray):
+            pats = awm.patterns_from_dicts(pats)
+        pats = pats.copy()
+        pats["time"] += plan[ci][2]                                            # ResultSet::apply_time_offset
+        payload[ci] = pats
+    everything = gather_patterns(dist, payload)
     if dist.get_rank() != 0:
         return None
-    all_raw = all(g[0] for g in gathered)
-    per_chunk = [np.zeros(0, awm.PATTERN_DTYPE) if all_raw else [] for _ in plan]
-    for is_raw, d in gathered:
-        for ci, pats in d.items():
-            if all_raw or not is_raw:
-                per_chunk[ci] = pats
-            else:
-                per_chunk[ci] = awm.patterns_to_dicts(pats, len(pats))
-    return awm.merge_patterns_raw(key, per_chunk) if all_raw else awm.merge_patterns(key, per_chunk)
+    per_chunk = [everything.get(ci, np.zeros(0, awm.PATTERN_DTYPE)) for ci in range(len(plan))]
+    return awm.merge_patterns_raw(key, per_chunk)
 
 
 class ShardedStream:
@@ -242,6 +272,7 @@ class ShardedStream:
         _Comm(dist).all_gather(lens, torch.tensor([n_frames_local], dtype=torch.int64, device=self._device()))
         self.part = Partition([int(t.item()) for t in lens])
         self._fm_cache = {}
+        dist._awm_device = self._device() if dist.get_backend() == "nccl" else "cpu"     # where the small collectives live
 
     def _device(self):
         import torch
@@ -253,11 +284,15 @@ class ShardedStream:
             self._fm_cache[k] = awm.tab_frame_mod(key, payload_hex)
         return self._fm_cache[k]
 
-    def add_watermark(self, key, payload_hex, local, out, water_delta=0.01, use_limiter=True):
+    def add_watermark(self, key, payload_hex, local, out, water_delta=0.01, use_limiter=True, sample_rate=44100):
         import torch
+        if sample_rate != 44100:
+            # spans are cut in watermark frames and limiter blocks of 44 100 samples; other rates go through the resampled
+            # path of the single-GPU add (awm_add_watermark_d), which is not sharded
+            raise ValueError("ShardedStream.add_watermark: only 44.1 kHz streams are sharded")
         dist = self.dist
         start, _ = self.part.span(self.rank)
-        before, after = exchange_edge_frames(dist, local, self.n_channels)
+        before, after = exchange_edge_frames(dist, local, self.n_channels, self.part.lengths)
         block_max = None
         if use_limiter:
             n_blocks = self.part.total // LIMITER_BLOCK + 2

@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """bench.py -- audio seconds watermarked + decoded per wall-second (xRT), 44.1 kHz stereo.
 
-One step = `add` (STFT -> band edit -> inverse -> overlap-add -> mix -> limiter) followed by `get`
-(chunked SyncFinder search + refine, soft-bit extraction, Viterbi, merge) over one synthetic
-60-minute stereo stream that is already resident in HBM (BASELINE.json configs[1]).
+One step = `add` (STFT -> band edit -> inverse -> overlap-add -> mix -> limiter) followed by `get` (chunked SyncFinder
+search + refine, soft-bit extraction, Viterbi, merge) over synthetic white noise that is already resident in HBM.
 
-  python bench.py --gpus 1 --steps K --warmup W
+  python bench.py --gpus 1 --steps K --warmup W                     BASELINE.json configs[1]: 60 min stereo per GPU
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  ... bench.py --gpus N --config 8h                                 configs[3]: ONE 8 h stream over the N ranks (strong scaling)
+  ... bench.py --gpus N --config clips                              configs[4]: 1024 clips of 30 s over the N ranks (replicas)
 
-With N > 1 the stream is N x 60 minutes long and sharded across the ranks (audiowmark_amd.sharded:
-frame spans for `add` with a 1-frame halo exchange and an all-reduce(max) of the limiter maxima,
-reference chunks for `get` with an overlap exchange and a gather of the found patterns) -> weak scaling.
+--config 60min with N > 1: the stream is N x 60 minutes long and sharded across the ranks (audiowmark_amd.sharded: frame
+spans for `add` with a 1-frame halo all_gather and an all_reduce(max) of the limiter maxima, the reference's chunks for `get`
+with a point-to-point overlap fetch and an all_gather of the found patterns) -> weak scaling.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the kernel with the largest share of GPU time,
-timed live with HIP events on the context's stream; `cpu_baseline` times the compiled reference
-(oracle/_ref, kind "reference") or the restatement (oracle/, kind "port") on a bounded sample.
+Rank 0 prints ONE JSON line.  At N = 1 (60min) it also carries:
+  roofline       the kernel with the largest STAND-ALONE share of GPU time: algorithmic bytes / its average duration when the
+                 chunks run one after the other (awm_ctx_set_chunk_lanes (1), untimed extra pass; this is what the rocprofv3
+                 summary under profiles/ shows), HBM traffic from the PMC passes of the same command
+  e2e            file -> file through the bounded-memory path (s16 raw in the page cache), PCIe-staged, CLI resident set size
+  cpu_baseline   the compiled reference (oracle/_ref) on the host cores, on a 30 min sample, and on the same sample
+  parity         the HIP path's PCM / pattern list against that reference run ("parity_checked_against": "reference")
 """
 import argparse
 import json
 import os
+import resource
+import subprocess
 import sys
+import tempfile
 import time
 
 # `get` runs the chunks of a stream on concurrent HIP streams (lanes).  The runtime multiplexes all streams of the process
@@ -35,68 +43,96 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PAYLOAD = "0123456789abcdef0011223344556677"
 RATE = 44100
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+
+# HIP-event scope (awm_prof_name) -> (device kernel in the rocprofv3 summaries, what actually limits it)
+KERNELS = {
+    "add_mix_kernel": ("add_mix_kernel_w3<2>", "HBM <-> FP32 issue (3 300 VALU instructions per stereo frame, 3 waves / SIMD)"),
+    "limiter_kernel": ("limiter_apply_kernel<2>", "HBM"),
+    "sync_db_kernel(approx)": ("sync_db_kernel<2, false>", "FP32 issue (the 4 shifts of a tile share one XCD's L2: PCM read once)"),
+    "sync_scan_kernel(approx)": ("sync_scan_stream_kernel", "LDS gathers (ds_read_b128, 256 B/clk/CU) in the reference's summation order"),
+    "local_mean_kernel": ("local_mean_kernel", "latency"),
+    "sync_db_kernel(refine)": ("sync_db_sliding_kernel<2>", "FP64 issue + sequential recurrence (65 steps per wave)"),
+    "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (150 workgroups)"),
+    "sync_db_kernel(block)": ("sync_db_kernel<2, true>", "FP32 issue"),
+    "soft_bits_kernel": ("soft_bits_kernel", "latency of scattered reads"),
+    "viterbi_kernel": ("viterbi_kernel", "FP32 add issue of ONE CU per decode: 2 x 2^15 x rate sequential float adds per trellis step"),
+}
 
 
-def cpu_baseline(sample_seconds):
-    """Reference CPU path on a bounded sample of the same workload (stereo white noise)."""
+def pmc_traffic(prof_name, minutes):
+    """HBM bytes per launch of the kernel behind a profiling scope: FETCH_SIZE (x2, gfx950 calibration) + WRITE_SIZE from the
+    separate rocprofv3 --pmc passes of this very command (tools/pmc_traffic.py -> profiles/r02/traffic.json; counters cannot be
+    read from inside the process).  None if the summary is not there or was taken for another workload."""
+    if minutes != 60.0:
+        return None
+    try:
+        with open(os.path.join(PROFILE_DIR, "traffic.json")) as f:
+            t = json.load(f)
+        e = t[KERNELS[prof_name][0]]
+        return int(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
+    except Exception:
+        return None
+
+
+def quantise16(np, x):
+    """what reading back the 16 bit WAV of `audiowmark test-gen-noise` gives (truncation towards zero, / 32768)"""
+    return (np.clip(np.trunc(x.astype(np.float64) * 32768.0), -32768, 32767) / 32768.0).astype(np.float32)
+
+
+def cpu_baseline_and_parity(torch, awm, ctx, sample_seconds):
+    """The compiled reference (oracle/_ref: unmodified reference sources, `add` single threaded, `get` on all host cores --
+    exactly what `audiowmark add` / `audiowmark get` do) on a bounded sample of the workload (test-gen-noise input), timed;
+    then the HIP path on the same sample, compared with it (untimed)."""
     import numpy as np
     try:
         import _ref
         have_ref = _ref.available()
     except Exception:
         have_ref = False
-    kind = None
     if have_ref:
         impl, kind = _ref, "reference"
     else:
         try:
-            import _oracle
-            impl, kind = _oracle, "port"
+            import _oracle as impl
+            kind = "port"
         except Exception:
-            return None
-    rng = np.random.default_rng(7)
+            return None, None
     n = int(sample_seconds * RATE)
-    x = rng.uniform(-1, 1, (n, 2)).astype(np.float32)
+    x = quantise16(np, awm.binding.gen_noise(None, 2 * n))
     t0 = time.perf_counter()
     w = impl.add(None, x, 2, PAYLOAD)
     t1 = time.perf_counter()
     pats = impl.get(None, w, 2)
     t2 = time.perf_counter()
-    ok = any(p["bits"] == PAYLOAD for p in pats)
+    ok = sum(p["bits"] == PAYLOAD for p in pats)
     cores = os.cpu_count() if kind == "reference" else 1
-    return {"value": round(sample_seconds / (t2 - t0), 2), "unit": "xRT", "cores": cores, "kind": kind,
-            "sample": f"{sample_seconds:.0f} s stereo 44.1 kHz white noise, add {t1 - t0:.2f} s (1 thread) + get {t2 - t1:.2f} s "
-                      f"({cores} threads), payload recovered={ok}; FFTW replaced by the oracle's double-precision FFT"}
-
-
-# HIP-event scope (awm_prof_name) -> device kernel whose PMC counters profiles/r01/traffic.json holds
-PROF_TO_KERNEL = {
-    "add_mix_kernel": "add_mix_kernel_w3<2>", "limiter_kernel": "limiter_apply_kernel<2>", "sync_db_kernel(approx)": "sync_db_kernel<2, false>",
-    "sync_scan_kernel(approx)": "sync_scan_window_kernel", "local_mean_kernel": "local_mean_kernel",
-    "sync_db_kernel(refine)": "sync_db_sliding_kernel<2>", "sync_scan_kernel(refine)": "sync_scan_gathered_kernel<false>",
-    "sync_db_kernel(block)": "sync_db_kernel<2, true>", "soft_bits_kernel": "soft_bits_kernel", "viterbi_kernel": "viterbi_kernel",
-}
-
-
-def pmc_traffic(prof_name):
-    """HBM bytes per launch of the kernel behind a profiling scope: FETCH_SIZE (x2, gfx950 calibration) + WRITE_SIZE from the
-    separate rocprofv3 --pmc passes of this very command (tools/pmc_traffic.py -> profiles/r01/traffic.json; counters cannot
-    be read from inside the process).  None if the summary is not there or was taken for another workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01", "traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-        e = t[PROF_TO_KERNEL[prof_name]]
-        return int(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
-    except Exception:
-        return None
+    base = {"value": round(sample_seconds / (t2 - t0), 2), "unit": "xRT", "cores": cores, "kind": kind,
+            "sample": f"{sample_seconds / 60:.0f} min stereo 44.1 kHz test-gen-noise, add {t1 - t0:.2f} s (1 thread) + get {t2 - t1:.2f} s "
+                      f"({cores} threads), {ok} of {len(pats)} patterns carry the payload; FFTW replaced by the oracle's double-precision FFT"}
+    # parity of the HIP path against this very run
+    xd = torch.from_numpy(x.reshape(n, 2)).cuda()
+    wg = ctx.add_watermark(None, PAYLOAD, xd).cpu().numpy().ravel()
+    d = wg.astype(np.float64) - w.astype(np.float64)
+    got = ctx.get_watermark(None, torch.from_numpy(w.reshape(n, 2)).cuda())
+    key = lambda p: (round(p["time"], 6), p["sync_index"], p["type"], p["block_type"])
+    same_pos = len(got) == len(pats) and all(key(a) == key(b) for a, b in zip(got, pats))
+    watermark_bits_equal = same_pos and all(a["bits"] == b["bits"] for a, b in zip(got, pats) if b["decode_error"] < 0.6)
+    parity = {"parity_checked_against": kind, "sample": base["sample"].split(",")[0],
+              "pcm_rms_diff": float(np.sqrt(np.mean(d * d))), "pcm_max_abs_diff": float(np.abs(d).max()),
+              "patterns": len(pats), "pattern_positions_and_types_equal": bool(same_pos),
+              "payload_bits_equal_for_every_watermark": bool(watermark_bits_equal),
+              "noise_patterns_with_other_bits": int(sum(a["bits"] != b["bits"] for a, b in zip(got, pats))) if same_pos else None,
+              "max_abs_sync_quality_diff": max((abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(got, pats)), default=0.0) if same_pos else None}
+    return base, parity
 
 
 def detect_speed_config(torch, awm, ctx, key, payload, minutes):
     """BASELINE.json configs[2] (reported next to the headline number, never part of `value`): `minutes` of stereo 48 kHz,
     watermarked at 48 kHz (timed), replayed 2 % fast (untimed: that is the attacker's part), then what `get --detect-speed`
     does with the 48 kHz file (timed): loader resampling to 44.1 kHz, speed search per 30-minute chunk, decode of the stream
-    stretched back to speed 1 and of the original stream.  Everything resident in HBM."""
+    stretched back to speed 1 and of the original stream.  Everything resident in HBM.  The zita-resampler stages follow a
+    restatement of the library (absent from the reference tree): parity with the real library is unpinned."""
     rate, speed = 48000, 1.02
     n = int(minutes * 60 * rate)
     g = torch.Generator(device="cuda")
@@ -130,7 +166,94 @@ def detect_speed_config(torch, awm, ctx, key, payload, minutes):
                         "search per chunk, decode of the stretched + the plain stream)" % (minutes, speed),
             "value": round((n / rate + seconds) / 2 / (t_add + t_get), 1), "unit": "xRT",
             "add_ms": round(t_add * 1e3, 3), "get_detect_speed_ms": round(t_get * 1e3, 3),
-            "payload_matches": len(hits), "detected_speeds": speeds}
+            "payload_matches": len(hits), "detected_speeds": speeds, "zita_resampler": "restated (parity with the library unpinned)"}
+
+
+def e2e_leg(torch, awm, ctx, x, resident_ms):
+    """End to end for the same 60 min stream: (1) s16 raw file in the page cache -> watermarked s16 raw file -> decoded, through
+    the file-level entry points (tile loop / chunked staging, bounded host memory); (2) the same with the files replaced by
+    page-locked host buffers (PCIe both ways, no file system); (3) the command line binary on the same file: wall time including
+    process start and HIP initialisation, and its peak resident set size."""
+    import numpy as np
+    n = x.shape[0]
+    seconds = n / RATE
+    d = "/dev/shm" if os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    src, dst, dst2 = (os.path.join(d, "awm_bench_%d_%s.raw" % (os.getpid(), s)) for s in ("in", "out", "cli"))
+    out = {"workload": "%g min stereo 44.1 kHz s16 raw, file -> file (add), file -> patterns (get), files in %s" % (seconds / 60, d)}
+    try:
+        raw = ctx.pcm_encode(x.reshape(-1), 16, 0, False, True)
+        raw.cpu().numpy().tofile(src)
+        rf = awm.binding.RawFormat(2, RATE, 16, 0, 0)
+        awm.lib.awm_set_quiet(1)
+        best_add = best_get = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ctx.add_watermark_file(None, PAYLOAD, src, dst, rf, rf)
+            t1 = time.perf_counter()
+            pats = ctx.get_watermark_file(None, dst, rf)
+            t2 = time.perf_counter()
+            best_add = t1 - t0 if best_add is None else min(best_add, t1 - t0)
+            best_get = t2 - t1 if best_get is None else min(best_get, t2 - t1)
+        out["file_to_file_xRT"] = round(seconds / (best_add + best_get), 1)
+        out["add_file_ms"] = round(best_add * 1e3, 2)
+        out["get_file_ms"] = round(best_get * 1e3, 2)
+        out["file_bytes"] = int(raw.numel())
+        out["payload_matches"] = sum(p["bits"] == PAYLOAD for p in pats)
+        # (2) page-locked host buffers instead of files
+        host_in = torch.empty(raw.numel(), dtype=torch.uint8).pin_memory()
+        host_in.copy_(raw.cpu())
+        host_out = torch.empty_like(host_in).pin_memory()
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            xin = ctx.pcm_decode(host_in.cuda(non_blocking=True), 16, 0, False).reshape(n, 2)
+            w = ctx.add_watermark(None, PAYLOAD, xin)
+            host_out.copy_(ctx.pcm_encode(w.reshape(-1), 16, 0, False, True), non_blocking=True)
+            torch.cuda.synchronize()
+            back = ctx.pcm_decode(host_out.cuda(non_blocking=True), 16, 0, False).reshape(n, 2)
+            ctx.get_watermark(None, back)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["pcie_staged_xRT"] = round(seconds / best, 1)
+        out["pcie_staged_ms"] = round(best * 1e3, 2)
+        out["resident_ms"] = round(resident_ms, 3)
+        # (3) the command line binary
+        cli = os.path.join(ROOT, "audiowmark_amd", "audiowmark")
+        if os.path.exists(cli):
+            fmt = ["--format", "raw", "--raw-rate", str(RATE), "--raw-channels", "2", "--raw-bits", "16"]
+            before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+            t0 = time.perf_counter()
+            r1 = subprocess.run([cli, "add", "-q"] + fmt + [src, dst2, PAYLOAD], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            t1 = time.perf_counter()
+            r2 = subprocess.run([cli, "get"] + fmt + [dst2], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+            t2 = time.perf_counter()
+            after = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+            out["cli"] = {"add_s": round(t1 - t0, 3), "get_s": round(t2 - t1, 3), "xRT_incl_process_start": round(seconds / (t2 - t0), 1),
+                          "rc": [r1.returncode, r2.returncode],
+                          "peak_rss_mb": round(max(after, before) / 1024.0, 1),
+                          "output_identical_to_in_process": bool(r1.returncode == 0 and open(dst, "rb").read() == open(dst2, "rb").read()),
+                          "patterns_with_payload": r2.stdout.decode(errors="replace").count(PAYLOAD)}
+    finally:
+        for f in (src, dst, dst2):
+            try:
+                os.unlink(f)
+            except OSError:
+                pass
+    return out
+
+
+def read_prof(awm, ctx):
+    import ctypes as C
+    awm.lib.awm_prof_name.restype = C.c_char_p
+    prof = []
+    for i in range(awm.lib.awm_prof_count()):
+        ms, launches, nbytes = C.c_double(), C.c_long(), C.c_double()
+        awm.lib.awm_prof_read(ctx._h, i, C.byref(ms), C.byref(launches), C.byref(nbytes))
+        if launches.value:
+            prof.append((awm.lib.awm_prof_name(i).decode(), ms.value, launches.value, nbytes.value))
+    return prof
 
 
 def main():
@@ -138,9 +261,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--minutes", type=float, default=60.0, help="audio minutes per GPU")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=200.0)
+    ap.add_argument("--config", choices=["60min", "8h", "clips"], default="60min",
+                    help="60min: BASELINE configs[1], per GPU (weak scaling); 8h: configs[3], one 8 h stream over all ranks (strong "
+                         "scaling); clips: configs[4], 1024 x 30 s clips over all ranks")
+    ap.add_argument("--minutes", type=float, default=None, help="audio minutes (60min: per GPU, default 60; 8h: in total, default 480)")
+    ap.add_argument("--clips", type=int, default=1024, help="--config clips: clips in total")
+    ap.add_argument("--cpu-sample-seconds", type=float, default=1800.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-detect-speed-config", action="store_true", help="skip the 48 kHz --detect-speed configuration (BASELINE configs[2])")
     ap.add_argument("--sharded", action="store_true",
                     help="debug: take the multi-GPU (ShardedStream / torch.distributed) code path even with one process")
@@ -167,26 +295,50 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    n = int(args.minutes * 60 * RATE)
-    if sharded_path:
-        n -= n % 1024            # spans of a sharded stream are whole frames (only the last one may be ragged)
+    ctx = awm.Context(local_rank)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
-    x = torch.rand((n, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1   # test-gen-noise distribution
-    out = torch.empty_like(x)
-    ctx = awm.Context(local_rank)
-
-    if sharded_path:
-        from audiowmark_amd import sharded
-        pipe = sharded.ShardedStream(ctx, dist, n_frames_local=n, n_channels=2)
+    strong = args.config == "8h"
+    if args.config == "clips":
+        # ---- configs[4]: independent 30 s clips, replicas: rank r takes clips r, r + world, ...; no data-path collective ----
+        n_clip = 30 * RATE
+        mine = list(range(rank, args.clips, world))
+        clips = [torch.rand((n_clip, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1 for _ in mine]
+        outs = [torch.empty_like(c) for c in clips]
+        audio_seconds = args.clips * 30.0
+        workload = (f"{args.clips} clips of 30 s stereo 44.1 kHz white noise over {world} GPU(s) (replicas: {len(mine)} on rank 0), add + get per "
+                    f"clip, one key for the batch (awm_get_watermark_batch_d: ClipDecoder on 16 lanes)")
 
         def step():
-            pipe.add_watermark(None, PAYLOAD, x, out)
-            return pipe.get_watermark(None, out)
+            for c, o in zip(clips, outs):
+                ctx.add_watermark(None, PAYLOAD, c, out=o)
+            return ctx.get_watermark_batch(None, outs)
     else:
-        def step():
-            ctx.add_watermark(None, PAYLOAD, x, out=out)
-            return ctx.get_watermark(None, out)
+        minutes = args.minutes if args.minutes is not None else (480.0 if strong else 60.0)
+        n_total = int(minutes * 60 * RATE) * (1 if strong else world)
+        if sharded_path:
+            per = (n_total // world) // 1024 * 1024          # spans of a sharded stream are whole frames (only the last one may be ragged)
+            n = per if rank < world - 1 or not strong else n_total - per * (world - 1)
+            if not strong:
+                n = per
+        else:
+            n = n_total
+        x = torch.rand((n, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1   # test-gen-noise distribution
+        out = torch.empty_like(x)
+        audio_seconds = (n_total if strong or not sharded_path else n * world) / RATE
+        workload = (f"{minutes:g} min stereo 44.1 kHz white noise " + ("in total" if strong else "per GPU") +
+                    f" resident in HBM, add+get incl. payload decode, payload {PAYLOAD}, strength 10")
+        if sharded_path:
+            from audiowmark_amd import sharded
+            pipe = sharded.ShardedStream(ctx, dist, n_frames_local=n, n_channels=2)
+
+            def step():
+                pipe.add_watermark(None, PAYLOAD, x, out)
+                return pipe.get_watermark(None, out)
+        else:
+            def step():
+                ctx.add_watermark(None, PAYLOAD, x, out=out)
+                return ctx.get_watermark(None, out)
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -201,78 +353,74 @@ def main():
     sync()
     t0 = time.perf_counter()
     pats = None
-    trace = os.environ.get("AWM_BENCH_TRACE")
     for i in range(args.steps):
-        ts = time.perf_counter()
         pats = step()
-        if trace:
-            torch.cuda.synchronize(dev)
-            print(f"step {i}: {1e3 * (time.perf_counter() - ts):.2f} ms", file=sys.stderr)
     sync()
     elapsed = time.perf_counter() - t0
     awm.lib.awm_prof_enable(ctx._h, 0)
+    matches_local = 0
+    if args.config == "clips":
+        matches_local = sum(any(p["bits"] == PAYLOAD for p in clip) for clip in pats)
+    ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        t = torch.tensor([elapsed, float(matches_local), 1.0], device=dev, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)             # final gather of the per-rank results (clips mode: match counts)
+        elapsed = float(tmax[0].item())
+        matches_local = int(t[1].item())
+        ranks_seen = int(t[2].item())
 
-    # per-kernel HIP-event times of the timed region (this rank).  `get` runs the chunks of the stream on concurrent
-    # lanes, so these durations overlap (their sum exceeds the wall time) and each is stretched by the kernels it
-    # shares the GPU with.
-    import ctypes as C
-    awm.lib.awm_prof_name.restype = C.c_char_p
-
-    def read_prof():
-        prof = []
-        for i in range(awm.lib.awm_prof_count()):
-            ms, launches, nbytes = C.c_double(), C.c_long(), C.c_double()
-            awm.lib.awm_prof_read(ctx._h, i, C.byref(ms), C.byref(launches), C.byref(nbytes))
-            if launches.value:
-                prof.append((awm.lib.awm_prof_name(i).decode(), ms.value, launches.value, nbytes.value))
-        return prof
-
-    prof = read_prof()
-    # the same kernels one after the other (AWM_ONE_LANE: a single stream), outside the timed region: the duration a
-    # kernel has when it owns the GPU -- the number a roofline is about
-    serial_steps = 3
-    os.environ["AWM_ONE_LANE"] = "1"
-    step()
-    awm.lib.awm_prof_reset(ctx._h)
-    awm.lib.awm_prof_enable(ctx._h, 1)
-    for _ in range(serial_steps):
+    single_stream = args.config == "60min" and world == 1 and not args.sharded
+    prof = read_prof(awm, ctx)
+    serial, serial_steps = {}, 3
+    if args.config != "clips":
+        # the same kernels one after the other (a single lane), outside the timed region: the duration a kernel has when it
+        # owns the GPU -- the number a roofline is about, and what a rocprofv3 --kernel-trace of this pass shows
+        awm.lib.awm_ctx_set_chunk_lanes(ctx._h, 1)
         step()
-    sync()
-    awm.lib.awm_prof_enable(ctx._h, 0)
-    serial = {p[0]: p for p in read_prof()}
-    del os.environ["AWM_ONE_LANE"]
+        awm.lib.awm_prof_reset(ctx._h)
+        awm.lib.awm_prof_enable(ctx._h, 1)
+        for _ in range(serial_steps):
+            step()
+        sync()
+        awm.lib.awm_prof_enable(ctx._h, 0)
+        serial = {p[0]: p for p in read_prof(awm, ctx)}
+        awm.lib.awm_ctx_set_chunk_lanes(ctx._h, 4)
 
     if rank == 0:
-        audio_seconds = n * world / RATE
-        matches = sum(1 for p in (pats or []) if p["bits"] == PAYLOAD)
-        total_ms = sum(p[1] for p in prof) or 1.0
-        dom = max(prof, key=lambda p: p[1]) if prof else None
+        if args.config == "clips":
+            cfg = {"workload": workload, "parallelism": f"{world} replica(s)", "clips_with_payload": matches_local,
+                   "clip_batch_config": {"lanes": 16, "host_threads": 2, "ms_per_clip_get_and_add": round(elapsed / args.steps * 1e3 / max(1, len(clips)), 4)}}
+        else:
+            matches = sum(1 for p in (pats or []) if p["bits"] == PAYLOAD)
+            cfg = {"workload": workload, "parallelism": (f"one stream sharded over {world} GPU(s)" if sharded_path else "1 GPU"),
+                   "patterns": len(pats or []), "payload_matches": matches}
+        cfg["ranks_seen"] = ranks_seen
+        if dist is not None:
+            try:
+                cfg["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                pass
         roofline = None
-        if dom:
-            name, ms, launches, nbytes = dom
-            achieved = nbytes / (ms * 1e-3) / 1e9        # algorithmic GB/s: sum(bytes)/sum(time) == per-launch bytes / avg duration
-            roofline = {"kernel": name, "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name) if args.minutes == 60.0 else None,
-                        "launches": launches, "avg_ms": round(ms / launches, 4),
-                        "share_of_gpu_time": round(ms / total_ms, 3)}
-            if name in serial:
-                _, sms, sl, sb = serial[name]
-                roofline["alone_avg_ms"] = round(sms / sl, 4)            # not sharing the GPU with the other lanes' kernels
-                roofline["alone_achieved"] = round(sb / (sms * 1e-3) / 1e9, 1)
-                roofline["alone_frac"] = round(sb / (sms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
-                if name.startswith("sync_scan_kernel(approx)"):
-                    # What limits this kernel is not HBM: every candidate start gathers its 510 sync rows x 60 bands from the
-                    # dB tile in LDS (ds_read_b32, ~75 TB/s for the whole chip per the microarchitecture guide).  Candidates per
-                    # launch from the algorithmic bytes (324 B per frame and shift; a candidate needs a whole block after it).
-                    frame_shifts = sb / 324.0
-                    candidates = max(frame_shifts - 4 * 2226 * sl, 0.0)
-                    lds_tbps = candidates * 510 * 60 * 4 / (sms * 1e-3) / 1e12
-                    roofline["lds_gather"] = {"achieved": round(lds_tbps, 1), "peak": 75.0, "unit": "TB/s", "frac": round(lds_tbps / 75.0, 3),
-                                              "note": "sequential float sums in the reference's order: 60 gathered adds per sync row and candidate"}
+        if serial:
+            total_alone = sum(v[1] for v in serial.values()) or 1.0
+            name, sms, sl, sb = max(serial.values(), key=lambda v: v[1])
+            achieved = sb / (sms * 1e-3) / 1e9               # algorithmic GB/s: sum (bytes) / sum (time) == bytes per launch / average duration
+            roofline = {"kernel": name, "device_kernel": KERNELS.get(name, (name, ""))[0], "bound": "hbm", "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                        "traffic": pmc_traffic(name, args.minutes if args.minutes is not None else 60.0) if single_stream else None,
+                        "launches_per_step": round(sl / serial_steps, 2), "avg_ms": round(sms / sl, 4),
+                        "share_of_gpu_time_alone": round(sms / total_alone, 3), "limited_by": KERNELS.get(name, ("", "?"))[1]}
+            if "sync_scan_kernel(approx)" in serial:
+                # K5w works out of LDS: every candidate start gathers its 510 sync rows x 60 bands from the dB ring (four
+                # candidates per ds_read_b128; 256 B/clk/CU = ~150 TB/s for the chip at 2.4 GHz, MI355X_MICROARCH.md).
+                _, kms, kl, kb = serial["sync_scan_kernel(approx)"]
+                frame_shifts = kb / 324.0
+                candidates = max(frame_shifts - 4 * 2226 * kl, 0.0)
+                lds_tbps = candidates * 510 * 60 * 4 / (kms * 1e-3) / 1e12
+                roofline["lds_gather_of_the_scan"] = {"achieved": round(lds_tbps, 1), "peak": 150.0, "unit": "TB/s", "frac": round(lds_tbps / 150.0, 3),
+                                                      "note": "peak at 2.4 GHz; the shader clock under this load is ~1.6 GHz (s_memtime)"}
         res = {
             "metric": "audio seconds watermarked+decoded per wall-second (xRT), 44.1 kHz stereo",
             "value": round(audio_seconds * args.steps / elapsed, 1),
@@ -282,36 +430,46 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if strong or args.config == "clips" else "weak",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"{args.minutes:g} min stereo 44.1 kHz white noise per GPU resident in HBM, add+get incl. payload decode, "
-                                   f"payload {PAYLOAD}, strength 10", "parallelism": f"stream sharded over {world} GPU(s)" if world > 1 else "1 GPU",
-                       "patterns": len(pats or []), "payload_matches": matches},
+            "config": cfg,
             "roofline": roofline,
+        }
+        if serial:
+            am = serial.get("add_mix_kernel")
             # the batched STFT north_star puts the 40 % HBM target on: the fused add kernel (STFT + band edit + inverse +
             # overlap-add), 8192 algorithmic bytes per frame-channel, stand-alone duration
-            "stft_roofline": ({"kernel": "add_mix_kernel", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
-                               "achieved": round(serial["add_mix_kernel"][3] / (serial["add_mix_kernel"][1] * 1e-3) / 1e9, 1),
-                               "frac": round(serial["add_mix_kernel"][3] / (serial["add_mix_kernel"][1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                               "avg_ms": round(serial["add_mix_kernel"][1] / serial["add_mix_kernel"][2], 4),
-                               "traffic": pmc_traffic("add_mix_kernel") if args.minutes == 60.0 else None}
-                              if "add_mix_kernel" in serial else None),
-            "kernels_ms_per_step": {p[0]: round(p[1] / args.steps, 3) for p in prof},
-            # one stream, kernels back to back (untimed extra pass): true per-kernel cost; their sum is what a step
-            # would take without the concurrent lanes
-            "kernels_ms_per_step_alone": {k: round(v[1] / serial_steps, 3) for k, v in serial.items()},
-            # algorithmic GB/s (SURVEY.md 8d bytes / HIP-event time) of every kernel, same definition as roofline.achieved
-            "kernels_algorithmic_GBps": {k: round(v[3] / (v[1] * 1e-3) / 1e9, 1) for k, v in serial.items() if v[1] > 0},
-        }
-        if world == 1 and not args.no_detect_speed_config:
-            try:
-                res["detect_speed_config"] = detect_speed_config(torch, awm, ctx, None, PAYLOAD, args.minutes)
-            except Exception as e:                       # reported, never fatal for the headline line
-                res["detect_speed_config"] = {"error": str(e)}
-        if not args.no_cpu_baseline and world == 1:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_sample_seconds)
+            res["stft_roofline"] = ({"kernel": "add_mix_kernel", "bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                                     "achieved": round(am[3] / (am[1] * 1e-3) / 1e9, 1), "frac": round(am[3] / (am[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                     "avg_ms": round(am[1] / am[2], 4),
+                                     "traffic": pmc_traffic("add_mix_kernel", args.minutes if args.minutes is not None else 60.0) if single_stream else None}
+                                    if am else None)
+            # concurrent lanes (timed region): durations overlap and are stretched by the kernels they share the GPU with
+            res["kernels_ms_per_step"] = {p[0]: round(p[1] / args.steps, 3) for p in prof}
+            # one lane, kernels back to back (untimed extra pass): true per-kernel cost
+            res["kernels_ms_per_step_alone"] = {k: round(v[1] / serial_steps, 3) for k, v in serial.items()}
+            # algorithmic GB/s (SURVEY.md 8d bytes / stand-alone time), same definition as roofline.achieved
+            res["kernels_algorithmic_GBps"] = {k: round(v[3] / (v[1] * 1e-3) / 1e9, 1) for k, v in serial.items() if v[1] > 0}
+        if single_stream:
+            if not args.no_e2e:
+                try:
+                    res["e2e"] = e2e_leg(torch, awm, ctx, x, elapsed / args.steps * 1e3)
+                except Exception as e:
+                    res["e2e"] = {"error": str(e)}
+            if not args.no_detect_speed_config:
+                try:
+                    res["detect_speed_config"] = detect_speed_config(torch, awm, ctx, None, PAYLOAD, args.minutes if args.minutes is not None else 60.0)
+                except Exception as e:                       # reported, never fatal for the headline line
+                    res["detect_speed_config"] = {"error": str(e)}
+            if not args.no_cpu_baseline:
+                try:
+                    res["cpu_baseline"], res["parity"] = cpu_baseline_and_parity(torch, awm, ctx, args.cpu_sample_seconds)
+                except Exception as e:
+                    res["cpu_baseline"], res["parity"] = None, {"error": str(e)}
+            else:
+                res["cpu_baseline"] = None
         else:
             res["cpu_baseline"] = None
         # RCCL prints its version banner through C stdio at exit; flush it first so that the JSON is the last line

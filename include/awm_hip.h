@@ -49,6 +49,9 @@ int   awm_ctx_synchronize (awm_ctx *ctx);
 void *awm_ctx_stream (awm_ctx *ctx);
 /* run all work of this context on an externally owned hipStream_t (e.g. torch's current stream) */
 int   awm_ctx_set_stream (awm_ctx *ctx, void *hip_stream);
+/* `get` decodes the 30-minute chunks of a stream concurrently on up to 4 "lanes" (HIP streams with their own workspaces);
+ * n_lanes = 1 runs them one after the other on the context's stream (per-kernel timing without overlap, smallest footprint) */
+int   awm_ctx_set_chunk_lanes (awm_ctx *ctx, int n_lanes);
 
 /* ---- per-kernel timing: HIP events recorded on the context's stream around every launch.
  * ids 0..awm_prof_count()-1, awm_prof_name(id) is the kernel name as rocprofv3 shows it (plus the
@@ -276,6 +279,9 @@ int    awm_speed_select_n_best (double *speed, double *quality, int count, int n
 double awm_speed_smooth_best (const double *speed, const double *quality, int count, double step, double distance);
 size_t awm_speed_clip_positions (const uint8_t key[16], size_t n_values, size_t max_out, uint64_t *positions);
 int    awm_speed_clip_candidates (const uint8_t key[16], const float *hashed_values, size_t n, int candidates, double *locations);
+
+/* --quiet (reference audiowmark.cc:1020-1023): the "Input: / Output: / Message: ..." information lines of add_watermark off */
+void awm_set_quiet (int quiet);
 
 /* global parameters (reference Params, wmcommon.hh:33-89) */
 void awm_set_params (double water_delta, int mix, int frames_per_bit, int test_no_limiter,

@@ -1,5 +1,6 @@
-"""world_size-2 checks of the multi-GPU sharding logic on CPU (gloo): partition / chunk ownership, the edge-frame
-all_gather, the point-to-point overlap fetch, the limiter-maxima all-reduce and the pattern gather + merge.
+"""world_size-2 and -4 checks of the multi-GPU sharding logic on CPU (gloo): partition / chunk ownership, the edge-frame
+all_gather (also across EMPTY spans), the point-to-point overlap fetch, the limiter-maxima all-reduce and the pattern
+gather (two all_gathers of plain byte tensors) + merge.
 No kernel runs here; the compute side of the same decomposition is covered by
 tests/test_gpu_parity.py::test_add_sharded_spans_equal_whole and ::test_sharded_stream_world1."""
 import os
@@ -44,11 +45,12 @@ def _worker(rank, world, port, lengths, ch, chunk_min, q):
 
         # 1. edge frames for the overlap-add halo
         before, after = sharded.exchange_edge_frames(dist, local, ch)
-        if rank == 0:
+        # the halo is the adjacent frame OF THE STREAM, whichever rank holds it (a rank in between may hold nothing)
+        if s == 0:
             assert before is None
         else:
             assert np.array_equal(before.numpy(), whole[s - 1024:s])
-        if rank == world - 1:
+        if e == total:
             assert after is None
         else:
             want = np.zeros((1024, ch), np.float32)
@@ -81,7 +83,7 @@ def _worker(rank, world, port, lengths, ch, chunk_min, q):
         for ci, c in mine:
             # every chunk "finds" an A block 5.8 s after its start and, if long enough, the B block one block later
             pats = [dict(time=5.8, sync_index=255976, sync_quality=1.3, block_type=0, type=0, decode_error=0.1, speed=1.0, bits=PAY)]
-            found[ci] = pats
+            found[ci] = pats if ci % 2 else awm.binding.patterns_from_dicts(pats)       # both accepted forms
         merged = sharded.gather_and_merge(dist, part, None, found)
         owners = [c[3] for c in plan]
         q.put((rank, "ok", owners, None if merged is None else [round(p["time"], 3) for p in merged]))
@@ -92,13 +94,16 @@ def _worker(rank, world, port, lengths, ch, chunk_min, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("lengths,ch", [([9 * 1024 * 1000, 6_000_321], 1), ([4096 * 1000, 2_000_000], 2)])
-def test_two_rank_sharding(lengths, ch):
+@pytest.mark.parametrize("lengths,ch", [([9 * 1024 * 1000, 6_000_321], 1), ([4096 * 1000, 2_000_000], 2),
+                                        ([5 * 1024 * 1000, 0, 11 * 1024 * 1000, 2_345_678], 2),      # world 4, uneven spans, one empty
+                                        ([1024, 7 * 1024 * 1000, 3 * 1024 * 1000, 0], 1)])            # one frame / empty last rank
+def test_sharding_over_ranks(lengths, ch):
     chunk_min = 3.0
+    world = len(lengths)
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, lengths, ch, chunk_min, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, ch, chunk_min, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
@@ -107,8 +112,8 @@ def test_two_rank_sharding(lengths, ch):
     for r in results:
         assert r[1] == "ok", r[2]
     owners = results[0][2]
-    # chunk ownership follows the chunk midpoints: non-decreasing ranks, both ranks used when the stream is long enough
-    assert owners == sorted(owners)
+    # chunk ownership follows the chunk midpoints: non-decreasing ranks, never a rank without samples
+    assert owners == sorted(owners) and all(lengths[o] > 0 for o in owners)
     awm.set_params(chunk_size_min=chunk_min)
     plan = awm.plan_chunks(sum(lengths))
     awm.set_params()
