@@ -1,27 +1,34 @@
-// viterbi.hip -- K8: soft-decision Viterbi decoder for the K=15 convolutional code on gfx950.
+// viterbi.hip -- K8: soft-decision Viterbi decoder for the K = 15 convolutional code on gfx950.
 // Replaces conv_decode_soft (reference src/convcode.cc:128-213).
 //
-// One 1024-thread workgroup decodes one coded block.  The 2^15 path metrics live in LDS
-// (128 KiB of the CU's 160 KiB); per trellis step every thread updates 16 butterflies
-//   { old[p], old[p + 2^14] } -> { new[2p], new[2p + 1] }
-// reading the old metrics with unit stride across lanes and writing the new ones as float2 with
-// unit stride (no bank conflicts), so the metrics never leave the CU.  Survivor decisions
-// (1 bit per state and step, 4 KiB per step) go to an HBM workspace and are walked back by one
-// lane at the end.
+// What the reference fixes: the path metric of a transition is accumulated term by term in float,
+//   delta = old; for p in 0..rate-1: delta += (cbit[p] - sbit[p])^2
+// for both predecessors of a state; the predecessor with the top state bit set (visited later) wins only on a strict "<";
+// unreachable states carry -1.  So a decode costs 2 x 2^15 x rate sequential float additions per trellis step (143 steps:
+// 56 M for an A or B block, 112 M for an AB block) whatever the implementation -- on ONE compute unit that is 0.4 / 0.8 ms
+// (the round-1 kernel, one workgroup per decode), and a chunk has only ~50 decodes for 256 compute units.
 //
-// Bit-exactness with the reference: the path metric of a transition is accumulated term by term
-//   delta = old; for p in 0..rate-1: delta += (cbit[p] - sbit[p])^2      (float, no FMA)
-// for BOTH predecessors, and the second predecessor (the one with the top state bit set, which the
-// reference visits later) wins only on a strict "<"; unreachable states carry -1 exactly like the
-// reference's StateEntry::delta.
+// This version spreads every decode over the whole chip.  The shift-register trellis closes over short stretches: the 2^K
+// states that share their low 15 - K bits at step T determine exactly the 2^K CONSECUTIVE states (those low bits shifted up)
+// at step T + K, through a private K-step butterfly network.  So a lane loads such a group (32 metrics, stride 1024, for
+// K = 5), runs 5 trellis steps entirely in registers -- no LDS, no barrier -- and stores 32 consecutive metrics and one
+// decision word per step.  A ROUND (5 steps of all blocks of the batch) is one launch of 1024 lanes per block; the kernel
+// boundary is the exchange.  143 steps = 28 rounds of 5 + 1 round of 3.  The expected code bit of a successor state splits
+// into a lane part (parity of the group bits, per step) and a part that is a compile time constant after unrolling.
+//
+// Survivors: lane L's five decision words of a round describe the whole 5-step history of the 32 states it produced, so the
+// trace back needs ONE 32-byte load per round (29 dependent loads instead of 143).
+//
+// Bit-exactness: sums and ties exactly as above; decoded bits and the error value are bit-identical to the oracle.
 #include "kernels.hh"
 
 namespace awmk {
 
+namespace {
+
 constexpr int V_ORDER = 15;
 constexpr int V_STATES = 1 << V_ORDER;       // 32768
-constexpr int V_THREADS = 1024;
-constexpr int V_PER_THREAD = V_STATES / 2 / V_THREADS;   // 16 butterflies
+constexpr int V_WG = 256;
 
 // generator polynomials (reference convcode.cc:42-46), A and B interleaved
 __device__ constexpr unsigned V_GEN_AB[12] = { 066561, 075211, 071545, 054435, 063635, 052475, 063543, 075307, 052547, 045627, 067657, 051757 };
@@ -32,73 +39,64 @@ __device__ constexpr unsigned v_parity (unsigned v) { v ^= v >> 16; v ^= v >> 8;
 
 typedef float v2f __attribute__ ((ext_vector_type (2)));
 
-// The successor state owned by (thread t, butterfly i, bit b) is ns = b | t << 1 | i << 11, so its expected code bit
-// for generator g splits into a lane dependent part parity ((t << 1) & G) and a part that is a compile time constant
-// after unrolling: parity ((i << 11 | b) & G).  Per trellis step a lane therefore needs just two candidate costs per
-// generator (own parity / flipped parity); which one a given (i, b) takes is decided by the compiler.
-template<int BT> __device__ __forceinline__ void
-viterbi_body (const float *soft, int n_steps, unsigned int *decisions, int *bits_out, float *error_out, long long blk,
-              float *s_metric, float *s_e0, float *s_e1)
+/* workspace of one block: [metrics A][metrics B][decision words of all rounds] */
+constexpr size_t V_METRIC_BYTES = V_STATES * sizeof (float);
+
+struct RoundPlan           // host side description of one launch
+{
+  int k;                   // trellis steps of the round (5 or 3)
+  int step0;               // first step
+  size_t dec_offset;       // words, from the start of the block's decision area
+};
+
+/* words per lane and round in the decision area (a power of two, so that a lane's words are one aligned load) */
+constexpr int dec_words (int k) { return k <= 4 ? 4 : 8; }
+
+/* K trellis steps of the 2^K states { L + j 2^(15-K) } -> the 2^K states { L 2^K + loc } */
+template<int BT, int K, bool PLAIN> __device__ __forceinline__ void
+viterbi_round (const float *coded, int step0, const float *m_in, float *m_out, unsigned int *dec, int L)
 {
   constexpr int rate = BT == 2 ? 12 : 6;
-  const int t = threadIdx.x;
-  const float *coded = soft + blk * (long long) n_steps * rate;
-  unsigned int *dec = decisions + blk * (long long) n_steps * V_THREADS;
-
-  for (int i = t; i < V_STATES; i += V_THREADS)
-    s_metric[i] = i == 0 ? 0.f : -1.f;
-  unsigned int lane_parity = 0;                     // bit g: parity ((t << 1) & G_g)
+  constexpr int NS = 1 << K;                               // states per lane
+  constexpr int GROUPS = V_STATES >> K;                    // lanes per block, stride of a lane's states on input
+  float m[NS];
 #pragma unroll
-  for (int g = 0; g < rate; g++)
-    lane_parity |= (unsigned (__popc ((unsigned (t) << 1) & v_gen<BT> (g)) & 1)) << g;
-  __syncthreads();
-
-  // After V_ORDER steps every state is reachable, and for finite input all path metrics are >= 0 from then on: the
-  // reachability tests (metric >= 0, which a NaN also fails -- the reference then skips that predecessor) only matter
-  // in the first V_ORDER steps or for NaN input.  normalize_soft_bits turns ALL bits of a block into NaN or none
-  // (0 / 0 mean), so one look at the first value decides whether the plain compare-select may be used.
-  const bool plain_ok = coded[0] == coded[0];
-  for (int step = 0; step < n_steps; step++)
+  for (int j = 0; j < NS; j++)
+    m[j] = m_in[L + j * GROUPS];
+  unsigned int words[K];
+#pragma unroll
+  for (int i = 1; i <= K; i++)
     {
-      const bool plain = plain_ok && step >= V_ORDER;     // uniform
-      if (t < rate)
-        {
-          const float c = coded[step * rate + t];
-          const float d1 = __fsub_rn (c, 1.0f);
-          s_e0[t] = __fmul_rn (c, c);          // (cbit - 0)^2
-          s_e1[t] = __fmul_rn (d1, d1);        // (cbit - 1)^2
-        }
-      float old0[V_PER_THREAD], old1[V_PER_THREAD];
-#pragma unroll
-      for (int i = 0; i < V_PER_THREAD; i++)
-        {
-          old0[i] = s_metric[t + V_THREADS * i];
-          old1[i] = s_metric[t + V_THREADS * i + V_STATES / 2];
-        }
-      __syncthreads();                         // all reads done (and s_e0/s_e1 visible)
-      float cost_same[rate], cost_flip[rate];  // branch cost if the constant part of the parity is 0 / 1
+      // squared distances of this step's code bits to 0 and 1 (wave uniform), and which of them a lane's states take:
+      // expected bit = parity ((L << i) & G)  ^  compile time part
+      float cost_same[rate], cost_flip[rate];
 #pragma unroll
       for (int g = 0; g < rate; g++)
         {
-          const float e0 = s_e0[g], e1 = s_e1[g];
-          const bool lp = (lane_parity >> g) & 1;
+          const float c = coded[(step0 + i - 1) * rate + g];
+          const float d1 = __fsub_rn (c, 1.0f);
+          const float e0 = __fmul_rn (c, c), e1 = __fmul_rn (d1, d1);        // (cbit - 0)^2, (cbit - 1)^2
+          const bool lp = __popc ((unsigned (L) << i) & v_gen<BT> (g)) & 1;
           cost_same[g] = lp ? e1 : e0;
           cost_flip[g] = lp ? e0 : e1;
         }
+      float n[NS];
       unsigned int word = 0;
 #pragma unroll
-      for (int i = 0; i < V_PER_THREAD; i++)
+      for (int jp = 0; jp < NS / 2; jp++)
         {
-          const unsigned p = t + V_THREADS * i;
+          const float old0 = m[jp], old1 = m[jp + NS / 2];                  // predecessors without / with the top state bit
           // running sums for predecessors {low, high}: .x / .y; one pair per successor bit; term by term like the reference
-          v2f d0 = { old0[i], old1[i] }, d1 = d0;
+          v2f d0 = { old0, old1 }, d1 = d0;
 #pragma unroll
           for (int g = 0; g < rate; g++)
             {
-              constexpr unsigned G = 0;   // placeholder to keep the loop body uniform
-              (void) G;
-              const bool c0 = v_parity ((unsigned (i) << 11) & v_gen<BT> (g));
-              const bool c1 = v_parity (((unsigned (i) << 11) | 1u) & v_gen<BT> (g));
+              // successor loc = 2 jp + b is the state  (L << i) | (loc >> i) << (15 - K + i) | (loc & (2^i - 1))
+              constexpr int hi_shift = V_ORDER - K;
+              const unsigned s0 = (unsigned ((2 * jp) >> i) << (hi_shift + i)) | unsigned ((2 * jp) & ((1 << i) - 1));
+              const unsigned s1 = (unsigned ((2 * jp + 1) >> i) << (hi_shift + i)) | unsigned ((2 * jp + 1) & ((1 << i) - 1));
+              const bool c0 = v_parity (s0 & v_gen<BT> (g));
+              const bool c1 = v_parity (s1 & v_gen<BT> (g));
               const float ea = c0 ? cost_flip[g] : cost_same[g];
               const float eb = c1 ? cost_flip[g] : cost_same[g];
               d0 += (v2f) { ea, ea };
@@ -106,7 +104,7 @@ viterbi_body (const float *soft, int n_steps, unsigned int *decisions, int *bits
             }
           unsigned c0, c1;
           float best0, best1;
-          if (plain)
+          if (PLAIN)
             {
               // strict "<": the low predecessor is visited first by the reference and keeps ties
               c0 = d0.y < d0.x;
@@ -116,67 +114,175 @@ viterbi_body (const float *soft, int n_steps, unsigned int *decisions, int *bits
             }
           else
             {
-              const bool r0 = old0[i] >= 0.f, r1 = old1[i] >= 0.f;
+              // states that cannot be reached from state 0 at step 0 carry -1 (also what a NaN metric turns into a skip)
+              const bool r0 = old0 >= 0.f, r1 = old1 >= 0.f;
               c0 = r0 ? (r1 && d0.y < d0.x) : (r1 ? 1u : 0u);
               c1 = r0 ? (r1 && d1.y < d1.x) : (r1 ? 1u : 0u);
               best0 = c0 ? d0.y : (r0 ? d0.x : -1.f);
               best1 = c1 ? d1.y : (r0 ? d1.x : -1.f);
             }
-          word |= (c0 << (2 * i)) | (c1 << (2 * i + 1));
-          reinterpret_cast<float2 *> (s_metric)[p] = make_float2 (best0, best1);
+          word |= (c0 << (2 * jp)) | (c1 << (2 * jp + 1));
+          n[2 * jp] = best0;
+          n[2 * jp + 1] = best1;
         }
-      dec[(long long) step * V_THREADS + t] = word;
-      __syncthreads();
+      words[i - 1] = word;
+#pragma unroll
+      for (int j = 0; j < NS; j++)
+        m[j] = n[j];
     }
-
-  __threadfence();
-  __syncthreads();
-  if (t == 0)
-    {
-      error_out[blk] = s_metric[0] / float (n_steps * rate);
-      unsigned state = 0;
-      int *bits = bits_out + blk * (long long) (n_steps - V_ORDER);
-      for (int step = n_steps - 1; step >= 0; step--)
-        {
-          if (step < n_steps - V_ORDER)
-            bits[step] = state & 1;
-          const unsigned p = state >> 1;                       // butterfly index
-          const unsigned int word = __builtin_nontemporal_load (&dec[(long long) step * V_THREADS + (p & (V_THREADS - 1))]);
-          const unsigned choose1 = (word >> (2 * (p >> 10) + (state & 1))) & 1;
-          state = p | (choose1 << (V_ORDER - 1));
-        }
-    }
+  float4 *out4 = reinterpret_cast<float4 *> (m_out + (size_t) L * NS);
+#pragma unroll
+  for (int j = 0; j < NS / 4; j++)
+    out4[j] = make_float4 (m[4 * j], m[4 * j + 1], m[4 * j + 2], m[4 * j + 3]);
+  constexpr int DW = dec_words (K);
+  uint4 *dec4 = reinterpret_cast<uint4 *> (dec + (size_t) L * DW);
+  dec4[0] = make_uint4 (words[0], words[1], words[2], K > 3 ? words[K > 3 ? 3 : 0] : 0u);
+  if (DW == 8)
+    dec4[1] = make_uint4 (words[K > 4 ? 4 : 0], 0u, 0u, 0u);
 }
 
 // one launch for all three code types: blocks [0, n0) decode A blocks, [n0, n0 + n1) B blocks, the rest AB blocks
 struct ViterbiBatch
 {
-  const float  *soft[3];
-  unsigned int *decisions[3];
-  int          *bits[3];
-  float        *error[3];
-  int           n[3];
-  int           n_steps;
+  const float   *soft[3];
+  unsigned char *ws[3];        // per type: blocks x block_ws_bytes
+  int           *bits[3];
+  float         *error[3];
+  int            n[3];
+  int            n_steps;
+  size_t         block_ws_bytes;
 };
 
-__global__ void __launch_bounds__ (V_THREADS)
-viterbi_kernel (ViterbiBatch b)
+template<int K, bool PLAIN> __global__ void __launch_bounds__ (V_WG)
+viterbi_round_kernel (ViterbiBatch b, int step0, int parity_in, size_t dec_offset)
 {
-  extern __shared__ __attribute__ ((aligned (16))) float s_metric[];   // V_STATES floats
-  __shared__ float s_e0[12], s_e1[12];
-  int blk = blockIdx.x;
-  if (blk < b.n[0])
-    viterbi_body<0> (b.soft[0], b.n_steps, b.decisions[0], b.bits[0], b.error[0], blk, s_metric, s_e0, s_e1);
-  else if (blk < b.n[0] + b.n[1])
-    viterbi_body<1> (b.soft[1], b.n_steps, b.decisions[1], b.bits[1], b.error[1], blk - b.n[0], s_metric, s_e0, s_e1);
+  int blk = blockIdx.y, t = 0;
+  if (blk >= b.n[0]) { blk -= b.n[0]; t = 1; }
+  if (t == 1 && blk >= b.n[1]) { blk -= b.n[1]; t = 2; }
+  const int rate = t == 2 ? 12 : 6;
+  const int L = blockIdx.x * V_WG + threadIdx.x;
+  unsigned char *ws = b.ws[t] + (size_t) blk * b.block_ws_bytes;
+  const float *m_in = reinterpret_cast<const float *> (ws + (parity_in ? V_METRIC_BYTES : 0));
+  float *m_out = reinterpret_cast<float *> (ws + (parity_in ? 0 : V_METRIC_BYTES));
+  unsigned int *dec = reinterpret_cast<unsigned int *> (ws + 2 * V_METRIC_BYTES) + dec_offset;
+  const float *coded = b.soft[t] + (size_t) blk * b.n_steps * rate;
+  // normalize_soft_bits turns ALL bits of a block into NaN or none (0 / 0 mean): such a block takes the checked path, where a
+  // NaN sum fails every comparison exactly like in the reference
+  const bool finite = coded[0] == coded[0];
+  if (t == 0)
+    {
+      if (PLAIN && finite) viterbi_round<0, K, true> (coded, step0, m_in, m_out, dec, L);
+      else                 viterbi_round<0, K, false> (coded, step0, m_in, m_out, dec, L);
+    }
+  else if (t == 1)
+    {
+      if (PLAIN && finite) viterbi_round<1, K, true> (coded, step0, m_in, m_out, dec, L);
+      else                 viterbi_round<1, K, false> (coded, step0, m_in, m_out, dec, L);
+    }
   else
-    viterbi_body<2> (b.soft[2], b.n_steps, b.decisions[2], b.bits[2], b.error[2], blk - b.n[0] - b.n[1], s_metric, s_e0, s_e1);
+    {
+      if (PLAIN && finite) viterbi_round<2, K, true> (coded, step0, m_in, m_out, dec, L);
+      else                 viterbi_round<2, K, false> (coded, step0, m_in, m_out, dec, L);
+    }
 }
+
+__global__ void __launch_bounds__ (256)
+viterbi_init_kernel (ViterbiBatch b)
+{
+  int blk = blockIdx.y, t = 0;
+  if (blk >= b.n[0]) { blk -= b.n[0]; t = 1; }
+  if (t == 1 && blk >= b.n[1]) { blk -= b.n[1]; t = 2; }
+  float *m = reinterpret_cast<float *> (b.ws[t] + (size_t) blk * b.block_ws_bytes);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  m[i] = i == 0 ? 0.f : -1.f;                              // start state 0, everything else unreachable (convcode.cc:144-146)
+}
+
+constexpr int MAX_ROUNDS = 64;
+struct TracePlan
+{
+  int n_rounds;
+  unsigned char k[MAX_ROUNDS];
+  int step0[MAX_ROUNDS];
+  unsigned int dec_offset[MAX_ROUNDS];                     // words
+  int final_parity;                                        // which metric buffer holds the last step's metrics
+};
+
+/* one lane per block walks the survivors back, round by round (one aligned load of the lane's decision words per round) */
+__global__ void __launch_bounds__ (64)
+viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
+{
+  const int total = b.n[0] + b.n[1] + b.n[2];
+  int blk = blockIdx.x * 64 + threadIdx.x, t = 0;
+  if (blk >= total)
+    return;
+  if (blk >= b.n[0]) { blk -= b.n[0]; t = 1; }
+  if (t == 1 && blk >= b.n[1]) { blk -= b.n[1]; t = 2; }
+  const int rate = t == 2 ? 12 : 6;
+  const unsigned char *ws = b.ws[t] + (size_t) blk * b.block_ws_bytes;
+  const float *metric = reinterpret_cast<const float *> (ws + (plan.final_parity ? V_METRIC_BYTES : 0));
+  const unsigned int *dec = reinterpret_cast<const unsigned int *> (ws + 2 * V_METRIC_BYTES);
+  b.error[t][blk] = metric[0] / float (b.n_steps * rate);  // convcode.cc:197-199: state 0 at the end
+  int *bits = b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER);
+  unsigned state = 0;
+  for (int r = plan.n_rounds - 1; r >= 0; r--)
+    {
+      const int K = plan.k[r];
+      const unsigned L = state >> K;
+      unsigned loc = state & ((1u << K) - 1);
+      const int DW = dec_words (K);
+      unsigned int w[5] = { 0, 0, 0, 0, 0 };
+      const uint4 *p = reinterpret_cast<const uint4 *> (dec + plan.dec_offset[r] + (size_t) L * DW);
+      const uint4 a = p[0];
+      w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
+      if (DW == 8)
+        w[4] = p[1].x;
+      for (int i = K; i >= 1; i--)
+        {
+          const int step = plan.step0[r] + i - 1;
+          if (step < b.n_steps - V_ORDER)
+            bits[step] = loc & 1;                          // the input bit of this step is the state's low bit
+          const unsigned choose_high = (w[i - 1] >> loc) & 1;
+          loc = (loc >> 1) | (choose_high << (K - 1));
+        }
+      state = L + (loc << (V_ORDER - K));                  // state before the round
+    }
+}
+
+std::vector<RoundPlan>
+plan_rounds (int n_steps)
+{
+  // n_steps = 5 a + 3 b with the smallest b
+  std::vector<RoundPlan> rounds;
+  int threes = 0;
+  while (threes < 5 && (n_steps - 3 * threes < 0 || (n_steps - 3 * threes) % 5))
+    threes++;
+  if (threes == 5 || n_steps - 3 * threes < 0)
+    return rounds;
+  int step = 0;
+  size_t off = 0;
+  auto add = [&] (int k) {
+    rounds.push_back ({ k, step, off });
+    step += k;
+    off += size_t (V_STATES >> k) * dec_words (k);
+  };
+  for (int i = 0; i < (n_steps - 3 * threes) / 5; i++)
+    add (5);
+  for (int i = 0; i < threes; i++)
+    add (3);
+  return rounds;
+}
+
+}  // namespace
 
 size_t
 viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks)
 {
-  return size_t (coded_len / rate) * V_THREADS * sizeof (unsigned int) * size_t (n_blocks);
+  const auto rounds = plan_rounds (int (coded_len / rate));
+  size_t words = 0;
+  for (const auto& r : rounds)
+    words += size_t (V_STATES >> r.k) * dec_words (r.k);
+  const size_t per_block = (2 * V_METRIC_BYTES + words * sizeof (unsigned int) + 255) & ~size_t (255);
+  return per_block * size_t (n_blocks);
 }
 
 hipError_t
@@ -186,21 +292,45 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
   const long long total = n_blocks[0] + n_blocks[1] + n_blocks[2];
   if (total <= 0)
     return hipSuccess;
+  const auto rounds = plan_rounds (int (n_steps));
+  if (rounds.empty() || rounds.size() > MAX_ROUNDS || total > 65535)
+    return hipErrorInvalidValue;
   ViterbiBatch b;
   for (int i = 0; i < 3; i++)
     {
       b.soft[i] = soft[i];
-      b.decisions[i] = reinterpret_cast<unsigned int *> (decisions_ws[i]);
+      b.ws[i] = decisions_ws[i];
       b.bits[i] = bits_out[i];
       b.error[i] = error_out[i];
       b.n[i] = int (n_blocks[i]);
     }
   b.n_steps = int (n_steps);
-  const size_t lds = V_STATES * sizeof (float);
-  hipError_t e = hipFuncSetAttribute (reinterpret_cast<const void *> (viterbi_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, int (lds));
-  if (e != hipSuccess)
-    return e;
-  hipLaunchKernelGGL (viterbi_kernel, dim3 ((unsigned) total), dim3 (V_THREADS), lds, st, b);
+  b.block_ws_bytes = viterbi_workspace_bytes (n_steps * 6, 6, 1);          // the layout does not depend on the rate
+  hipLaunchKernelGGL (viterbi_init_kernel, dim3 (V_STATES / 256, (unsigned) total), dim3 (256), 0, st, b);
+  TracePlan tp {};
+  tp.n_rounds = int (rounds.size());
+  int parity = 0;
+  for (size_t r = 0; r < rounds.size(); r++)
+    {
+      const RoundPlan& rp = rounds[r];
+      tp.k[r] = (unsigned char) rp.k;
+      tp.step0[r] = rp.step0;
+      tp.dec_offset[r] = (unsigned int) rp.dec_offset;
+      // after V_ORDER steps every state is reachable and, for finite input, all metrics are >= 0: plain compare-select
+      const bool plain = rp.step0 >= V_ORDER;
+      const dim3 grid ((V_STATES >> rp.k) / V_WG, (unsigned) total);
+      if (rp.k == 5 && plain)
+        hipLaunchKernelGGL ((viterbi_round_kernel<5, true>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
+      else if (rp.k == 5)
+        hipLaunchKernelGGL ((viterbi_round_kernel<5, false>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
+      else if (plain)
+        hipLaunchKernelGGL ((viterbi_round_kernel<3, true>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
+      else
+        hipLaunchKernelGGL ((viterbi_round_kernel<3, false>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
+      parity ^= 1;
+    }
+  tp.final_parity = parity;
+  hipLaunchKernelGGL (viterbi_trace_kernel, dim3 ((unsigned) ((total + 63) / 64)), dim3 (64), 0, st, b, tp);
   return hipGetLastError();
 }
 

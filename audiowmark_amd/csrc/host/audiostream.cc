@@ -1,4 +1,7 @@
 #include "audiostream.hh"
+#include <sys/stat.h>
+#include <unistd.h>
+#include <thread>
 #include "wmcommon.hh"
 #include <algorithm>
 #include <cerrno>
@@ -140,6 +143,72 @@ PcmCodec::encode (const float *samples, unsigned char *bytes, size_t n) const
 
 namespace {
 
+/* Bulk file I/O for the GPU staging path: a chunk of tens of megabytes read from (written to) a REGULAR file is split over a
+ * few threads using pread / pwrite -- a single thread copies out of the page cache at ~8 GB/s, which is what bounded the file
+ * level add + get of an hour of audio (0.23 s).  Pipes and small requests take the plain stdio path. */
+constexpr size_t BULK_IO_MIN = size_t (4) << 20;
+constexpr int    BULK_IO_THREADS = 4;
+
+bool
+is_regular (FILE *f)
+{
+  struct stat st;
+  return f && fstat (fileno (f), &st) == 0 && S_ISREG (st.st_mode);
+}
+
+/* returns bytes transferred (short only at EOF / on error, `failed` tells which) */
+size_t
+bulk_io (FILE *f, unsigned char *buf, size_t bytes, bool writing, bool& failed)
+{
+  failed = false;
+  if (writing)
+    fflush (f);
+  const off_t pos = ftello (f);
+  if (pos < 0)
+    {
+      failed = true;
+      return 0;
+    }
+  const int fd = fileno (f);
+  const size_t part = (bytes / BULK_IO_THREADS + 4095) & ~size_t (4095);
+  size_t done[BULK_IO_THREADS] = {};
+  bool bad[BULK_IO_THREADS] = {};
+  auto work = [&] (int t) {
+    const size_t lo = std::min (bytes, part * t), hi = std::min (bytes, part * (t + 1));
+    size_t n = 0;
+    while (lo + n < hi)
+      {
+        const ssize_t r = writing ? pwrite (fd, buf + lo + n, hi - lo - n, pos + off_t (lo + n)) : pread (fd, buf + lo + n, hi - lo - n, pos + off_t (lo + n));
+        if (r < 0 && errno == EINTR)
+          continue;
+        if (r <= 0)
+          {
+            bad[t] = r < 0;
+            break;
+          }
+        n += size_t (r);
+      }
+    done[t] = n;
+  };
+  std::thread threads[BULK_IO_THREADS - 1];
+  for (int t = 1; t < BULK_IO_THREADS; t++)
+    threads[t - 1] = std::thread (work, t);
+  work (0);
+  for (auto& th : threads)
+    th.join();
+  size_t total = 0;
+  for (int t = 0; t < BULK_IO_THREADS; t++)
+    {
+      failed = failed || bad[t];
+      const size_t want = std::min (bytes, part * (t + 1)) - std::min (bytes, part * t);
+      total += done[t];
+      if (done[t] < want)
+        break;                                             // EOF inside this part: later parts lie beyond it
+    }
+  fseeko (f, pos + off_t (total), SEEK_SET);
+  return total;
+}
+
 class RawInputStream : public AudioInputStream
 {
   RawFormat m_format;
@@ -191,7 +260,14 @@ public:
   Error
   read_raw (unsigned char *dst, size_t max_frames, size_t& got_frames) override
   {
-    got_frames = fread (dst, size_t (m_format.n_channels) * m_codec->sample_width(), max_frames, m_file);
+    const size_t frame_bytes = size_t (m_format.n_channels) * m_codec->sample_width();
+    if (max_frames * frame_bytes >= BULK_IO_MIN && is_regular (m_file))
+      {
+        bool failed;
+        got_frames = bulk_io (m_file, dst, max_frames * frame_bytes, false, failed) / frame_bytes;
+        return failed ? Error ("error reading sample data") : Error (Error::Code::NONE);
+      }
+    got_frames = fread (dst, frame_bytes, max_frames, m_file);
     if (ferror (m_file))
       return Error ("error reading sample data");
     return Error::Code::NONE;
@@ -247,7 +323,14 @@ public:
   Error
   write_raw (const unsigned char *bytes, size_t n_frames) override
   {
-    fwrite (bytes, size_t (m_format.n_channels) * m_codec->sample_width(), n_frames, m_file);
+    const size_t n = n_frames * m_format.n_channels * m_codec->sample_width();
+    if (n >= BULK_IO_MIN && is_regular (m_file))
+      {
+        bool failed;
+        const size_t done = bulk_io (m_file, const_cast<unsigned char *> (bytes), n, true, failed);
+        return failed || done != n ? Error ("write sample data failed") : Error (Error::Code::NONE);
+      }
+    fwrite (bytes, 1, n, m_file);
     if (ferror (m_file))
       return Error ("write sample data failed");
     return Error::Code::NONE;
@@ -344,6 +427,14 @@ public:
             format.bit_depth = u16le (&buffer[14]);
             if (format.bit_depth == 8)
               format.encoding = Encoding::UNSIGNED;        // 8 bit wav is always unsigned
+            // a header that would divide by zero later (libsndfile rejects such files in the reference)
+            if (format.n_channels < 1 || format.sample_rate < 1)
+              return Error (string_printf ("wav input has an invalid fmt chunk (%d channels, %d Hz)", format.n_channels, format.sample_rate));
+            if (format.bit_depth % 8 == 0 && u16le (&buffer[12]) != format.n_channels * format.bit_depth / 8)
+              return Error (string_printf ("wav input has an inconsistent fmt chunk (block align %d for %d channels of %d bits)",
+                                           u16le (&buffer[12]), format.n_channels, format.bit_depth));
+            if ((chunk_size & 1) && fgetc (m_file) == EOF)                 // chunks are word aligned
+              return read_error ("wav input is incomplete (error reading fmt chunk)");
             have_fmt = true;
           }
         else if (id == "ds64" && chunk_size >= 24 && chunk_size <= 4096)
@@ -352,6 +443,8 @@ public:
             if (!fread (buffer.data(), buffer.size(), 1, m_file))
               return read_error ("wav input is incomplete (error reading ds64 chunk)");
             ds64_data_size = u64le (&buffer[8]);
+            if ((chunk_size & 1) && fgetc (m_file) == EOF)
+              return read_error ("wav input is incomplete (error reading ds64 chunk)");
           }
         else if (id == "data")
           {
@@ -420,7 +513,16 @@ public:
   {
     if (m_frames_left != N_FRAMES_UNKNOWN)
       max_frames = std::min (max_frames, m_frames_left);
-    got_frames = max_frames ? fread (dst, size_t (m_format.n_channels) * m_codec->sample_width(), max_frames, m_file) : 0;
+    const size_t frame_bytes = size_t (m_format.n_channels) * m_codec->sample_width();
+    if (max_frames * frame_bytes >= BULK_IO_MIN && is_regular (m_file))
+      {
+        bool failed;
+        got_frames = bulk_io (m_file, dst, max_frames * frame_bytes, false, failed) / frame_bytes;
+        if (failed)
+          return Error (string_printf ("error reading wav input sample data: %s", strerror (errno)));
+      }
+    else
+      got_frames = max_frames ? fread (dst, frame_bytes, max_frames, m_file) : 0;
     if (ferror (m_file))
       return Error (string_printf ("error reading wav input sample data: %s", strerror (errno)));
     if (m_frames_left != N_FRAMES_UNKNOWN)
@@ -433,13 +535,15 @@ class WavOutputStream : public AudioOutputStream
 {
   int    m_bit_depth = 0, m_sample_rate = 0, m_n_channels = 0;
   FILE  *m_file = nullptr;
-  bool   m_close = false, m_fix_header = false;
+  bool   m_close = false, m_fix_header = false, m_rf64 = false;
   size_t m_close_padding = 0, m_bytes_written = 0;
+  static constexpr uint64_t RF64_HEADER_BYTES = 12 + 36 + 24 + 8;      // "RF64" size "WAVE", ds64, fmt, data chunk header
   std::unique_ptr<PcmCodec> m_codec;
 public:
   ~WavOutputStream() { close(); }
   Error
-  open (const std::string& filename, int n_channels, int sample_rate, int bit_depth, Encoding encoding, size_t n_frames, bool wav_pipe)
+  open (const std::string& filename, int n_channels, int sample_rate, int bit_depth, Encoding encoding, size_t n_frames, bool wav_pipe,
+        bool rf64 = false)
   {
     if (encoding == Encoding::FLOAT)
       {
@@ -470,15 +574,37 @@ public:
         m_fix_header = n_frames == AudioInputStream::N_FRAMES_UNKNOWN;    // sizes are patched in close()
       }
     const bool unknown = wav_pipe || n_frames == AudioInputStream::N_FRAMES_UNKNOWN;
-    const size_t data_size = unknown ? 0 : n_frames * n_channels * ((bit_depth + 7) / 8);
+    const uint64_t data_size = unknown ? 0 : uint64_t (n_frames) * n_channels * ((bit_depth + 7) / 8);
     m_close_padding = data_size & 1;
+    m_rf64 = rf64 && !to_stdout && !wav_pipe;
+    if (!m_rf64 && !unknown && 36 + data_size + m_close_padding > 0xFFFFFFFFull)
+      return Error (string_printf ("wav output of %llu bytes does not fit a RIFF header (use --output-format rf64)", (unsigned long long) data_size));
     std::vector<unsigned char> h;
     auto str = [&] (const char *s) { h.insert (h.end(), s, s + 4); };
     auto u32 = [&] (uint32_t u) { for (int i = 0; i < 4; i++) h.push_back ((unsigned char) (u >> (8 * i))); };
+    auto u64 = [&] (uint64_t u) { for (int i = 0; i < 8; i++) h.push_back ((unsigned char) (u >> (8 * i))); };
     auto u16 = [&] (uint16_t u) { h.push_back ((unsigned char) u); h.push_back ((unsigned char) (u >> 8)); };
-    str ("RIFF");
-    u32 (unknown ? 0xFFFFFFFFu : uint32_t (36 + data_size + m_close_padding));
-    str ("WAVE");
+    if (m_rf64)
+      {
+        // EBU Tech 3306: 32 bit sizes read 0xFFFFFFFF, the 64 bit ones live in the ds64 chunk that follows "WAVE"
+        // (what libsndfile writes for SF_FORMAT_RF64, reference sfoutputstream.cc:73)
+        m_fix_header = unknown;
+        str ("RF64");
+        u32 (0xFFFFFFFFu);
+        str ("WAVE");
+        str ("ds64");
+        u32 (28);
+        u64 (unknown ? 0 : RF64_HEADER_BYTES - 8 + data_size + m_close_padding);    // riff size
+        u64 (data_size);
+        u64 (unknown ? 0 : n_frames);                                               // sample count
+        u32 (0);                                                                    // no chunk size table
+      }
+    else
+      {
+        str ("RIFF");
+        u32 (unknown ? 0xFFFFFFFFu : uint32_t (36 + data_size + m_close_padding));
+        str ("WAVE");
+      }
     str ("fmt ");
     u32 (16);
     u16 (encoding == Encoding::FLOAT ? 3 : 1);
@@ -488,7 +614,7 @@ public:
     u16 (n_channels * bit_depth / 8);
     u16 (bit_depth);
     str ("data");
-    u32 (unknown ? 0xFFFFFFFFu : uint32_t (data_size));
+    u32 (unknown || m_rf64 ? 0xFFFFFFFFu : uint32_t (data_size));
     fwrite (h.data(), 1, h.size(), m_file);
     if (ferror (m_file))
       return Error ("write wav header failed");
@@ -532,7 +658,14 @@ public:
   write_raw (const unsigned char *bytes, size_t n_frames) override
   {
     const size_t n = n_frames * m_n_channels * (m_bit_depth / 8);
-    fwrite (bytes, 1, n, m_file);
+    if (n >= BULK_IO_MIN && is_regular (m_file))
+      {
+        bool failed;
+        if (bulk_io (m_file, const_cast<unsigned char *> (bytes), n, true, failed) != n || failed)
+          return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
+      }
+    else
+      fwrite (bytes, 1, n, m_file);
     if (ferror (m_file))
       return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
     m_bytes_written += n;
@@ -549,16 +682,29 @@ public:
       }
     for (size_t i = 0; i < m_close_padding; i++)
       fputc (0, m_file);
-    if (m_fix_header && m_bytes_written + 36 < 0xFFFFFFFFu)
+    Error size_error = Error::Code::NONE;
+    if (m_fix_header)
       {
-        unsigned char b[4];
-        auto put = [&] (long pos, uint32_t v) {
-          for (int i = 0; i < 4; i++) b[i] = (unsigned char) (v >> (8 * i));
+        unsigned char b[8];
+        auto put = [&] (long pos, uint64_t v, int n) {
+          for (int i = 0; i < n; i++) b[i] = (unsigned char) (v >> (8 * i));
           fseek (m_file, pos, SEEK_SET);
-          fwrite (b, 1, 4, m_file);
+          fwrite (b, 1, n, m_file);
         };
-        put (4, uint32_t (36 + m_bytes_written + m_close_padding));
-        put (40, uint32_t (m_bytes_written));
+        if (m_rf64)
+          {
+            put (20, RF64_HEADER_BYTES - 8 + m_bytes_written + m_close_padding, 8);
+            put (28, m_bytes_written, 8);
+            put (36, m_bytes_written / (size_t (m_n_channels) * (m_bit_depth / 8)), 8);
+          }
+        else if (36 + m_bytes_written + m_close_padding <= 0xFFFFFFFFull)
+          {
+            put (4, 36 + m_bytes_written + m_close_padding, 4);
+            put (40, m_bytes_written, 4);
+          }
+        else
+          size_error = Error (string_printf ("wav output of %llu bytes does not fit a RIFF header (use --output-format rf64)",
+                                             (unsigned long long) m_bytes_written));
       }
     fflush (m_file);
     const bool failed = ferror (m_file);
@@ -567,7 +713,7 @@ public:
     m_file = nullptr;
     if (failed)
       return Error ("error during flush");
-    return Error::Code::NONE;
+    return size_error;
   }
 };
 
@@ -609,7 +755,8 @@ AudioOutputStream::create (const std::string& filename, int n_channels, int samp
       return s;
     }
   auto s = std::make_unique<WavOutputStream>();
-  err = s->open (filename, n_channels, sample_rate, bit_depth, encoding, n_frames, Params::output_format == Format::WAV_PIPE);
+  err = s->open (filename, n_channels, sample_rate, bit_depth, encoding, n_frames, Params::output_format == Format::WAV_PIPE,
+                 Params::output_format == Format::RF64);
   if (err)
     return nullptr;
   return s;

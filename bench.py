@@ -56,7 +56,7 @@ KERNELS = {
     "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (150 workgroups)"),
     "sync_db_kernel(block)": ("sync_db_kernel<2, true>", "FP32 issue"),
     "soft_bits_kernel": ("soft_bits_kernel", "latency of scattered reads"),
-    "viterbi_kernel": ("viterbi_kernel", "FP32 add issue of ONE CU per decode: 2 x 2^15 x rate sequential float adds per trellis step"),
+    "viterbi_kernel": ("viterbi_round_kernel<5, true>", "FP32 add issue: 2 x 2^15 x rate sequential float adds per trellis step and decode, 5 steps per launch in registers"),
 }
 
 

@@ -160,3 +160,87 @@ def test_detect_speed_scenario(work, tmp_path):
     run([AWM, "cmp", "--test-key", "1", str(tmp_path / "s0.9764.wav"), PAY, "--try-speed", "0.9764"])
     r = run([AWM, "get", "--test-key", "1", str(spd), "--detect-speed", "--try-speed", "1.01"], check=False)
     assert r.returncode != 0 and b"can only use one option" in r.stderr
+
+
+def test_key_scenarios_and_two_keys_in_one_get(tmp_path):
+    """tests/key-test.sh:13-37 of the reference: key files, wrong key, no key, double watermark with two keys -- and both keys
+    in ONE `get` (syncfinder.cc:171-256 searches all keys over the same dB matrices), compared with the reference binary"""
+    raw = ["--raw-rate", "44100", "--raw-channels", "2", "--raw-bits", "16"]
+    msg2 = "0123456789abcdef0123456789abcdef"
+    noise = wav_samples_from_stdout(run([AWM, "test-gen-noise", "-", "30", "44100"]).stdout)
+    k1, k2 = tmp_path / "key-test-1.key", tmp_path / "key-test-2.key"
+    run([AWM, "gen-key", str(k1)])
+    run([AWM, "gen-key", str(k2), "--name", "second"])
+    assert k1.read_text().startswith("# watermarking key for audiowmark") and "name second" in k2.read_text()
+    add = lambda keyopt, pcm, msg: run([AWM, "add", "-q", "--format", "raw"] + raw + keyopt + ["-", "-", msg], stdin=pcm).stdout
+    cmp_ = lambda keyopt, pcm, msg, n: run([AWM, "cmp", "--input-format", "raw"] + raw + keyopt + ["-", msg, "--expect-matches", str(n)], stdin=pcm)
+    out1 = add(["--key", str(k1)], noise, PAY)
+    out2 = add(["--key", str(k2)], noise, msg2)
+    cmp_(["--key", str(k1)], out1, PAY, 1)
+    cmp_(["--key", str(k2)], out1, PAY, 0)                                   # shouldn't be able to detect without the correct key
+    cmp_([], out1, PAY, 0)
+    cmp_(["--key", str(k2)], out2, msg2, 1)
+    cmp_(["--key", str(k1)], out2, msg2, 0)
+    # double watermark with two different keys
+    both = add(["--test-key", "42"], add([], noise, PAY), msg2)
+    cmp_([], both, PAY, 1)
+    cmp_(["--test-key", "42"], both, msg2, 1)
+    # both keys in one run: a "key" line per named key, each with its own patterns
+    r = run([AWM, "get", "--input-format", "raw"] + raw + ["--test-key", "42", "--test-key", "7", "-"], stdin=both)
+    text = r.stdout.decode()
+    assert "key test-key-42" in text and msg2 in text.split("key test-key-42")[1].split("key test-key-7")[0]
+    assert "key test-key-7" in text and PAY not in text                      # the default key was not asked for
+    if os.path.exists(_ref.BIN):
+        theirs = run([_ref.BIN, "get", "--x-in-raw", "--test-key", "42", "--test-key", "7", "-"], stdin=both, check=False)
+        if theirs.returncode == 0:
+            assert text.splitlines() == theirs.stdout.decode().splitlines()
+
+
+def wav_samples_from_stdout(data):
+    pos = data.index(b"data") + 8
+    return data[pos:]
+
+
+def test_hard_decision_option(work):
+    """--hard (wmget.cc:46-50): soft bits are replaced by 0 / 1 before the Viterbi decoder; same lines as the reference binary"""
+    d, _, marked = work
+    ours = run([AWM, "cmp", "--hard", "--input-format", "wav-pipe", str(marked), PAY, "--expect-matches", "5"]).stdout.decode().splitlines()
+    assert any(l.startswith("pattern") and PAY in l for l in ours)
+    if os.path.exists(_ref.BIN):
+        theirs = run([_ref.BIN, "cmp", "--hard", "--x-in-wav-pipe", str(marked), PAY]).stdout.decode().splitlines()
+        keep = lambda ls: [l for l in ls if not l.startswith(("key", "expect_matches"))]
+        assert keep(ours) == keep(theirs)
+
+
+def test_rf64_output_and_riff_size_limit(work, tmp_path):
+    """--output-format rf64 writes the ds64 chunk with 64 bit sizes (what libsndfile's SF_FORMAT_RF64 produces in the
+    reference); a plain RIFF header that cannot hold the size is refused instead of being written with wrapped sizes"""
+    import struct
+    d, noise, _ = work
+    out = tmp_path / "out.rf64"
+    run([AWM, "add", "-q", "--output-format", "rf64", str(noise), str(out), PAY])
+    data = out.read_bytes()
+    pcm = os.path.getsize(noise) - 44
+    assert data[:4] == b"RF64" and data[4:8] == b"\xff\xff\xff\xff" and data[8:16] == b"WAVEds64"
+    riff_size, data_size, frames = struct.unpack("<QQQ", data[20:44])
+    assert data_size == pcm and frames == pcm // 4 and riff_size == len(data) - 8
+    assert data[72:76] == b"data" and data[76:80] == b"\xff\xff\xff\xff" and len(data) == 80 + pcm
+    r = run([AWM, "cmp", str(out), PAY, "--expect-matches", "5"])            # and it reads its own RF64 back
+    assert b"match_count 5" in r.stdout
+    # a header that announces 5 GiB of samples: the RIFF output header cannot hold that
+    big = tmp_path / "big.wav"
+    n = 5 << 30
+    big.write_bytes(b"RF64" + b"\xff" * 4 + b"WAVEds64" + struct.pack("<IQQQI", 28, n + 72, n, n // 4, 0) + b"fmt "
+                    + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16) + b"data" + b"\xff" * 4 + b"\0" * 4096)
+    r = run([AWM, "add", "-q", str(big), str(tmp_path / "o.wav"), PAY], check=False)
+    assert r.returncode == 1 and b"does not fit a RIFF header" in r.stderr
+
+
+def test_malformed_wav_headers_are_rejected(tmp_path):
+    import struct
+    for ch, rate, align, what in [(0, 44100, 4, b"invalid fmt chunk"), (2, 0, 4, b"invalid fmt chunk"), (2, 44100, 3, b"inconsistent fmt chunk")]:
+        f = tmp_path / "bad.wav"
+        f.write_bytes(b"RIFF" + struct.pack("<I", 436) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, ch, rate, rate * align, align, 16)
+                      + b"data" + struct.pack("<I", 400) + b"\0" * 400)
+        r = run([AWM, "test-snr", str(f), str(f)], check=False)
+        assert r.returncode == 1 and what in r.stderr
