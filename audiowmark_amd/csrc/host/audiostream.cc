@@ -143,9 +143,10 @@ PcmCodec::encode (const float *samples, unsigned char *bytes, size_t n) const
 
 namespace {
 
-/* Bulk file I/O for the GPU staging path: a chunk of tens of megabytes read from (written to) a REGULAR file is split over a
- * few threads using pread / pwrite -- a single thread copies out of the page cache at ~8 GB/s, which is what bounded the file
- * level add + get of an hour of audio (0.23 s).  Pipes and small requests take the plain stdio path. */
+/* Bulk file input for the GPU staging path: a chunk of tens of megabytes read from a REGULAR file is split over a few threads
+ * using pread -- a single thread copies out of the page cache at ~8 GB/s, which bounded the file level `get` of an hour of
+ * audio (87 -> 64 ms).  Pipes and small requests take the plain stdio path; writes stay on the writer thread's fwrite
+ * (splitting them too made `add` slower: 139 -> 183 ms, the page allocations of a growing file do not parallelise). */
 constexpr size_t BULK_IO_MIN = size_t (4) << 20;
 constexpr int    BULK_IO_THREADS = 4;
 
@@ -324,12 +325,6 @@ public:
   write_raw (const unsigned char *bytes, size_t n_frames) override
   {
     const size_t n = n_frames * m_format.n_channels * m_codec->sample_width();
-    if (n >= BULK_IO_MIN && is_regular (m_file))
-      {
-        bool failed;
-        const size_t done = bulk_io (m_file, const_cast<unsigned char *> (bytes), n, true, failed);
-        return failed || done != n ? Error ("write sample data failed") : Error (Error::Code::NONE);
-      }
     fwrite (bytes, 1, n, m_file);
     if (ferror (m_file))
       return Error ("write sample data failed");
@@ -658,14 +653,7 @@ public:
   write_raw (const unsigned char *bytes, size_t n_frames) override
   {
     const size_t n = n_frames * m_n_channels * (m_bit_depth / 8);
-    if (n >= BULK_IO_MIN && is_regular (m_file))
-      {
-        bool failed;
-        if (bulk_io (m_file, const_cast<unsigned char *> (bytes), n, true, failed) != n || failed)
-          return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
-      }
-    else
-      fwrite (bytes, 1, n, m_file);
+    fwrite (bytes, 1, n, m_file);
     if (ferror (m_file))
       return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
     m_bytes_written += n;

@@ -24,7 +24,6 @@ Rank 0 prints ONE JSON line.  At N = 1 (60min) it also carries:
 import argparse
 import json
 import os
-import resource
 import subprocess
 import sys
 import tempfile
@@ -223,18 +222,20 @@ def e2e_leg(torch, awm, ctx, x, resident_ms):
         cli = os.path.join(ROOT, "audiowmark_amd", "audiowmark")
         if os.path.exists(cli):
             fmt = ["--format", "raw", "--raw-rate", str(RATE), "--raw-channels", "2", "--raw-bits", "16"]
-            before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
-            t0 = time.perf_counter()
-            r1 = subprocess.run([cli, "add", "-q"] + fmt + [src, dst2, PAYLOAD], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            t1 = time.perf_counter()
-            r2 = subprocess.run([cli, "get"] + fmt + [dst2], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-            t2 = time.perf_counter()
-            after = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
-            out["cli"] = {"add_s": round(t1 - t0, 3), "get_s": round(t2 - t1, 3), "xRT_incl_process_start": round(seconds / (t2 - t0), 1),
-                          "rc": [r1.returncode, r2.returncode],
-                          "peak_rss_mb": round(max(after, before) / 1024.0, 1),
-                          "output_identical_to_in_process": bool(r1.returncode == 0 and open(dst, "rb").read() == open(dst2, "rb").read()),
-                          "patterns_with_payload": r2.stdout.decode(errors="replace").count(PAYLOAD)}
+            def child(cmd):
+                """run to completion; (seconds, peak resident set size of THIS child in MB, exit status, stdout)"""
+                t0 = time.perf_counter()
+                p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                text = p.stdout.read()
+                _, status, ru = os.wait4(p.pid, 0)
+                p.returncode = os.waitstatus_to_exitcode(status)
+                return time.perf_counter() - t0, ru.ru_maxrss / 1024.0, p.returncode, text
+            ta, rss_a, rc_a, _ = child([cli, "add", "-q"] + fmt + [src, dst2, PAYLOAD])
+            tg, rss_g, rc_g, text = child([cli, "get"] + fmt + [dst2])
+            out["cli"] = {"add_s": round(ta, 3), "get_s": round(tg, 3), "xRT_incl_process_start": round(seconds / (ta + tg), 1),
+                          "rc": [rc_a, rc_g], "peak_rss_mb": {"add": round(rss_a, 1), "get": round(rss_g, 1)},
+                          "output_identical_to_in_process": bool(rc_a == 0 and open(dst, "rb").read() == open(dst2, "rb").read()),
+                          "patterns_with_payload": text.decode(errors="replace").count(PAYLOAD)}
     finally:
         for f in (src, dst, dst2):
             try:
@@ -270,6 +271,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-detect-speed-config", action="store_true", help="skip the 48 kHz --detect-speed configuration (BASELINE configs[2])")
+    ap.add_argument("--lanes", type=int, default=4, help="lanes `get` spreads the chunks of a stream over (1: kernels back to back, for profiling)")
     ap.add_argument("--sharded", action="store_true",
                     help="debug: take the multi-GPU (ShardedStream / torch.distributed) code path even with one process")
     args = ap.parse_args()
@@ -296,6 +298,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     ctx = awm.Context(local_rank)
+    awm.lib.awm_ctx_set_chunk_lanes(ctx._h, args.lanes)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     strong = args.config == "8h"
@@ -386,7 +389,7 @@ def main():
         sync()
         awm.lib.awm_prof_enable(ctx._h, 0)
         serial = {p[0]: p for p in read_prof(awm, ctx)}
-        awm.lib.awm_ctx_set_chunk_lanes(ctx._h, 4)
+        awm.lib.awm_ctx_set_chunk_lanes(ctx._h, args.lanes)
 
     if rank == 0:
         if args.config == "clips":

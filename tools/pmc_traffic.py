@@ -12,7 +12,7 @@ for path in sys.argv[1:]:
             name = row["Kernel_Name"]
             if "awmk::" not in name:
                 continue
-            short = name.split("awmk::")[1].split("(")[0]
+            short = name.replace("(anonymous namespace)::", "").split("awmk::")[1].split("(")[0]
             acc[short][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {}
 for k, ctrs in sorted(acc.items()):
