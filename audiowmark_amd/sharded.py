@@ -209,10 +209,14 @@ def fetch_range(dist, part: Partition, local, n_channels):
     return buf, lo
 
 
+GATHER_CAPACITY = 512          # records per rank in the one-shot gather (an hour of audio yields ~110 patterns)
+
+
 def gather_patterns(dist, my_chunk_patterns):
     """{chunk index: structured array (PATTERN_DTYPE)} of this rank -> the union over all ranks, on every rank.
-    Two collectives on plain byte tensors (the "score gather" of the path): the record counts, then the records padded to the
-    longest list -- a record is the chunk index (int32) followed by the pattern."""
+    ONE collective on plain byte tensors (the "score gather" of the path): every rank contributes a fixed-size block = its record
+    count followed by GATHER_CAPACITY records (chunk index int32 + pattern); only if some rank found more than that, a second
+    all_gather sized for the longest list follows."""
     import torch
     comm = _Comm(dist)
     world = dist.get_world_size()
@@ -225,21 +229,27 @@ def gather_patterns(dist, my_chunk_patterns):
         mine["pattern"][pos:pos + len(pats)] = pats
         pos += len(pats)
     dev = getattr(dist, "_awm_device", None) or "cpu"
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    comm.all_gather(counts, torch.tensor([len(mine)], dtype=torch.int64, device=dev))
-    counts = [int(c.item()) for c in counts]
-    longest = max(counts)
-    out = {}
-    if longest:
-        buf = np.zeros(longest, rec)
-        buf[:len(mine)] = mine
-        t = torch.from_numpy(buf.view(np.uint8).reshape(-1).copy()).to(dev)
+
+    def gather(capacity):
+        block = np.zeros(16 + capacity * rec.itemsize, np.uint8)
+        block[:8] = np.frombuffer(np.int64(len(mine)).tobytes(), np.uint8)
+        k = min(len(mine), capacity)
+        block[16:16 + k * rec.itemsize] = mine[:k].view(np.uint8).reshape(-1)
+        t = torch.from_numpy(block).to(dev)
         parts = [torch.empty_like(t) for _ in range(world)]
         comm.all_gather(parts, t)
-        for r, p in enumerate(parts):
-            recs = p.cpu().numpy().view(rec)[:counts[r]]
-            for ci in np.unique(recs["chunk"]):
-                out[int(ci)] = recs["pattern"][recs["chunk"] == ci].copy()
+        blocks = [p.cpu().numpy() for p in parts]
+        counts = [int(np.frombuffer(b[:8].tobytes(), np.int64)[0]) for b in blocks]
+        return blocks, counts
+
+    blocks, counts = gather(GATHER_CAPACITY)
+    if max(counts) > GATHER_CAPACITY:
+        blocks, counts = gather(max(counts))
+    out = {}
+    for b, n in zip(blocks, counts):
+        recs = np.frombuffer(b[16:16 + n * rec.itemsize].tobytes(), rec)
+        for ci in np.unique(recs["chunk"]):
+            out[int(ci)] = recs["pattern"][recs["chunk"] == ci].copy()
     return out
 
 

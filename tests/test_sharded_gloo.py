@@ -31,11 +31,13 @@ def _stream(total, ch):
     return (np.arange(total * ch, dtype=np.float64) % 65521).astype(np.float32).reshape(total, ch) / 65521.0
 
 
-def _worker(rank, world, port, lengths, ch, chunk_min, q):
+def _worker(rank, world, port, lengths, ch, chunk_min, q, capacity=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if capacity is not None:
+            sharded.GATHER_CAPACITY = capacity      # force the second, exactly sized gather round
         awm.set_params(chunk_size_min=chunk_min)
         part = sharded.Partition(lengths)
         total = part.total
@@ -103,7 +105,8 @@ def test_sharding_over_ranks(lengths, ch):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, ch, chunk_min, q)) for r in range(world)]
+    capacity = 0 if ch == 1 and world == 2 else None
+    procs = [ctx.Process(target=_worker, args=(r, world, port, lengths, ch, chunk_min, q, capacity)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=300) for _ in procs]
