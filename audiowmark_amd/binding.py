@@ -580,12 +580,15 @@ class Context:
     # SyncFinder::search
     def sync_search(self, key, pcm, clip_mode=False, max_out=4096):
         n, ch = _pcm_shape(pcm)
-        idx = np.zeros(max_out, np.uint64)
-        q = np.zeros(max_out, np.float64)
-        bt = np.zeros(max_out, np.int32)
-        cnt = _check(lib.awm_sync_search_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, int(clip_mode), max_out, _np(idx),
-                                           _np(q), _np(bt)), "awm_sync_search_d")
-        return idx[:cnt], q[:cnt], bt[:cnt]
+        while True:
+            idx = np.zeros(max_out, np.uint64)
+            q = np.zeros(max_out, np.float64)
+            bt = np.zeros(max_out, np.int32)
+            cnt = _check(lib.awm_sync_search_d(self._h, key_bytes(key), _dev_ptr(pcm), n, ch, int(clip_mode), max_out, _np(idx),
+                                               _np(q), _np(bt)), "awm_sync_search_d")
+            if cnt <= max_out:
+                return idx[:cnt], q[:cnt], bt[:cnt]
+            max_out = cnt                                    # more scores than the buffer holds: repeat, never truncate
 
     def search_approx(self, key, pcm, clip_mode=False):
         n, ch = _pcm_shape(pcm)

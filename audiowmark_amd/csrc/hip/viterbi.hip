@@ -10,14 +10,16 @@
 //
 // This version spreads every decode over the whole chip.  The shift-register trellis closes over short stretches: the 2^K
 // states that share their low 15 - K bits at step T determine exactly the 2^K CONSECUTIVE states (those low bits shifted up)
-// at step T + K, through a private K-step butterfly network.  So a lane loads such a group (32 metrics, stride 1024, for
-// K = 5), runs 5 trellis steps entirely in registers -- no LDS, no barrier -- and stores 32 consecutive metrics and one
-// decision word per step.  A ROUND (5 steps of all blocks of the batch) is one launch of 1024 lanes per block; the kernel
-// boundary is the exchange.  143 steps = 28 rounds of 5 + 1 round of 3.  The expected code bit of a successor state splits
+// at step T + K, through a private K-step butterfly network.  So a lane loads such a group (16 metrics, stride 2048, for
+// K = 4), runs 4 trellis steps entirely in registers -- no LDS, no barrier -- and stores 16 consecutive metrics and one
+// decision word per step.  A ROUND (4 steps of all blocks of the batch) is one launch of 2048 lanes per block; the kernel
+// boundary is the exchange.  143 steps = 35 rounds of 4 + 1 round of 3.  The expected code bit of a successor state splits
 // into a lane part (parity of the group bits, per step) and a part that is a compile time constant after unrolling.
+// (K = 5: 29 rounds of 10.6 us for eight AB decodes alone on the GPU, 3 600 straight-line instructions per lane; K = 4: 36
+// rounds of about half that with twice the lanes -- 1.33 -> 1.25 ms per step of the 60 min bench.)
 //
-// Survivors: lane L's five decision words of a round describe the whole 5-step history of the 32 states it produced, so the
-// trace back needs ONE 32-byte load per round (29 dependent loads instead of 143).
+// Survivors: lane L's decision words of a round describe the whole K-step history of the 2^K states it produced, so the
+// trace back needs ONE 16-byte load per round (36 dependent loads instead of 143).
 //
 // Bit-exactness: sums and ties exactly as above; decoded bits and the error value are bit-identical to the oracle.
 #include "kernels.hh"
@@ -248,15 +250,17 @@ viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
     }
 }
 
+constexpr int V_K = 4;            // trellis steps per full round (see the header)
+
 std::vector<RoundPlan>
 plan_rounds (int n_steps)
 {
-  // n_steps = 5 a + 3 b with the smallest b
+  // n_steps = V_K a + 3 b with the smallest b
   std::vector<RoundPlan> rounds;
   int threes = 0;
-  while (threes < 5 && (n_steps - 3 * threes < 0 || (n_steps - 3 * threes) % 5))
+  while (threes < V_K && (n_steps - 3 * threes < 0 || (n_steps - 3 * threes) % V_K))
     threes++;
-  if (threes == 5 || n_steps - 3 * threes < 0)
+  if (threes == V_K || n_steps - 3 * threes < 0)
     return rounds;
   int step = 0;
   size_t off = 0;
@@ -265,8 +269,8 @@ plan_rounds (int n_steps)
     step += k;
     off += size_t (V_STATES >> k) * dec_words (k);
   };
-  for (int i = 0; i < (n_steps - 3 * threes) / 5; i++)
-    add (5);
+  for (int i = 0; i < (n_steps - 3 * threes) / V_K; i++)
+    add (V_K);
   for (int i = 0; i < threes; i++)
     add (3);
   return rounds;
@@ -319,10 +323,10 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
       // after V_ORDER steps every state is reachable and, for finite input, all metrics are >= 0: plain compare-select
       const bool plain = rp.step0 >= V_ORDER;
       const dim3 grid ((V_STATES >> rp.k) / V_WG, (unsigned) total);
-      if (rp.k == 5 && plain)
-        hipLaunchKernelGGL ((viterbi_round_kernel<5, true>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
-      else if (rp.k == 5)
-        hipLaunchKernelGGL ((viterbi_round_kernel<5, false>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
+      if (rp.k == V_K && plain)
+        hipLaunchKernelGGL ((viterbi_round_kernel<V_K, true>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
+      else if (rp.k == V_K)
+        hipLaunchKernelGGL ((viterbi_round_kernel<V_K, false>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
       else if (plain)
         hipLaunchKernelGGL ((viterbi_round_kernel<3, true>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
       else
