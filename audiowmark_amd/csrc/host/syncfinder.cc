@@ -92,7 +92,7 @@ SyncFinder::fetch_scores (long long n_scores, std::vector<SearchScore>& out)
 }
 
 int
-SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores)
+SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores, bool db_ready)
 {
   n_scores = 0;
   const int clip = mode == Mode::CLIP;
@@ -130,10 +130,11 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   da.first = (long long) m_first;
   da.last = (long long) m_last;
   da.tile_frames = 32;
-  {
-    ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_shifts) * n_db * (4096.0 * wav.n_channels + 324.0), st);
-    AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
-  }
+  if (!db_ready)                                     // (else: another key of the same `get` left these matrices in the workspace)
+    {
+      ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_shifts) * n_db * (4096.0 * wav.n_channels + 324.0), st);
+      AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+    }
 
   awmk::SyncScanArgs sa {};
   sa.db = m_lane->ws_db.as<float>();
@@ -646,7 +647,7 @@ SyncFinder::search_launch (const Key& key, const DeviceWav& wav, Mode mode, Sear
 }
 
 int
-SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool prepared)
+SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool prepared, bool db_ready)
 {
   job.out.clear();
   job.done = true;
@@ -675,7 +676,7 @@ SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, Sear
   job.wav = wav;
   job.mode = mode;
   job.n_scores = 0;
-  if (int rc = approx_device (kt, wav, mode, job.n_scores))
+  if (int rc = approx_device (kt, wav, mode, job.n_scores, db_ready))
     return rc;
   job.speculate_n_best = mode == Mode::CLIP;            // clips hold one or two sync peaks: the n_best fallback is the rule
   if (int rc = select_launch (job.n_scores, Params::sync_threshold2 * 0.75, job.speculate_n_best))

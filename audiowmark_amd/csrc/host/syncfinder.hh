@@ -46,7 +46,7 @@ public:
   int prepare_finish();                                   // ... and the wait
   int search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& out);
   // kernels of search_approx only: scores stay on the device (ws_raw / ws_mean, index order); n_scores = 4 * start frames
-  int approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores);
+  int approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores, bool db_ready = false);
   // local maxima + mask + threshold (+ n_best fallback): the candidate list search_refine works on
   int select_candidates (long long n_scores, double threshold, std::vector<SearchScore>& out);
   int select_launch (long long n_scores, double threshold, bool speculate_n_best = false);   // device part of it, not waited for
@@ -79,7 +79,8 @@ public:
   int search_finish (SearchJob& job, std::vector<Score>& out);
   // finer steps for callers that drive several lanes: approx_launch never waits for the device,
   // select_refine waits for this lane's candidate list and queues the refinement
-  int approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool prepared = false);
+  // db_ready: the lane workspace still holds the dB matrices of THIS wav from the previous key of the same get (they do not depend on the key)
+  int approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool prepared = false, bool db_ready = false);
   int select_refine (SearchJob& job);
 
   static void select_local_maxima (std::vector<SearchScore>& scores);

@@ -65,7 +65,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
   for (size_t b0 = 0; b0 < bases.size(); b0 += max_batch)
     {
       const size_t nb = std::min (max_batch, bases.size() - b0);
-      if (int rc = lane->ws_db.reserve (nb * block_stride * sizeof (float))) return rc;
+      if (int rc = lane->ws_block_db.reserve (nb * block_stride * sizeof (float))) return rc;
       awmk::SyncDbArgs da {};
       da.pcm = wav.data;
       da.n_frames = wav.n_frames;
@@ -75,7 +75,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
       da.count0 = int (count);
       da.n_streams = (long long) nb;
       da.hop = Params::frame_size;
-      da.out = lane->ws_db.as<float>();
+      da.out = lane->ws_block_db.as<float>();
       da.out_stream_stride = block_stride;
       da.ld = ld;
       da.have = nullptr;
@@ -88,7 +88,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
       }
 
       awmk::SoftBitsArgs sb {};
-      sb.db = lane->ws_db.as<float>();
+      sb.db = lane->ws_block_db.as<float>();
       sb.block_stride = block_stride;
       sb.ld = ld;
       sb.n_channels = C;
@@ -556,14 +556,16 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
     cw.n_frames = chunks[c].n_frames;
     return cw;
   };
-  for (size_t ki = 0; ki < key_list.size(); ki++)
+  for (size_t g0 = 0; g0 < chunks.size(); g0 += lanes.size())              // groups of chunks, one lane each
     {
-      const Key& key = key_list[ki];
-      KeyTables *kt = ctx->get_key_tables (key);
-      if (!kt)
-        return AWM_ERR_HIP;
-      for (size_t g0 = 0; g0 < chunks.size(); g0 += lanes.size())          // groups of chunks, one lane each
+      // every key of the list on this group before the lanes move on: the approximate dB matrices of a chunk are computed
+      // once and shared by the keys (reference syncfinder.cc:171-256)
+      for (size_t ki = 0; ki < key_list.size(); ki++)
         {
+          const Key& key = key_list[ki];
+          KeyTables *kt = ctx->get_key_tables (key);
+          if (!kt)
+            return AWM_ERR_HIP;
           const size_t gn = std::min (lanes.size(), chunks.size() - g0);
           std::vector<SyncFinder> finders;
           std::vector<SyncFinder::SearchJob> jobs (gn);
@@ -571,7 +573,8 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
           for (size_t i = 0; i < gn; i++)
             finders.emplace_back (ctx, lanes[i]);
           for (size_t i = 0; i < gn; i++)
-            if (int rc = finders[i].approx_launch (key, chunk_wav (g0 + i), SyncFinder::Mode::BLOCK, jobs[i]))
+            // (the dB matrices of this chunk are still in the lane's workspace from the previous key: nothing else writes there)
+            if (int rc = finders[i].approx_launch (key, chunk_wav (g0 + i), SyncFinder::Mode::BLOCK, jobs[i], /* prepared */ false, /* db_ready */ ki > 0))
               return rc;
           for (size_t i = 0; i < gn; i++)
             if (int rc = finders[i].select_refine (jobs[i]))
