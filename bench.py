@@ -55,7 +55,7 @@ KERNELS = {
     "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (150 workgroups)"),
     "sync_db_kernel(block)": ("sync_db_kernel<2, true>", "FP32 issue"),
     "soft_bits_kernel": ("soft_bits_kernel", "latency of scattered reads"),
-    "viterbi_kernel": ("viterbi_round_kernel<5, true>", "FP32 add issue: 2 x 2^15 x rate sequential float adds per trellis step and decode, 5 steps per launch in registers"),
+    "viterbi_kernel": ("viterbi_round_kernel<4, true>", "FP32 add issue: 2 x 2^15 x rate sequential float adds per trellis step and decode, 4 steps per launch in registers"),
 }
 
 
@@ -222,16 +222,25 @@ def e2e_leg(torch, awm, ctx, x, resident_ms):
         cli = os.path.join(ROOT, "audiowmark_amd", "audiowmark")
         if os.path.exists(cli):
             fmt = ["--format", "raw", "--raw-rate", str(RATE), "--raw-channels", "2", "--raw-bits", "16"]
-            def child(cmd):
-                """run to completion; (seconds, peak resident set size of THIS child in MB, exit status, stdout)"""
-                t0 = time.perf_counter()
-                p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-                text = p.stdout.read()
-                _, status, ru = os.wait4(p.pid, 0)
-                p.returncode = os.waitstatus_to_exitcode(status)
-                return time.perf_counter() - t0, ru.ru_maxrss / 1024.0, p.returncode, text
-            ta, rss_a, rc_a, _ = child([cli, "add", "-q"] + fmt + [src, dst2, PAYLOAD])
-            tg, rss_g, rc_g, text = child([cli, "get"] + fmt + [dst2])
+            # measured from a FRESH small interpreter: a child forked from this process (torch: several GB resident) would
+            # report the parent's resident set as its own peak (ru_maxrss covers the moment between fork and exec)
+            helper = ("import os, sys, time, json\n"
+                      "def child(cmd):\n"
+                      "    t0 = time.perf_counter(); r, w = os.pipe(); pid = os.fork()\n"
+                      "    if pid == 0:\n"
+                      "        os.dup2(w, 1); os.dup2(os.open(os.devnull, os.O_WRONLY), 2); os.close(r); os.execv(cmd[0], cmd)\n"
+                      "    os.close(w); text = b''\n"
+                      "    while True:\n"
+                      "        b = os.read(r, 1 << 16)\n"
+                      "        if not b: break\n"
+                      "        text += b\n"
+                      "    _, status, ru = os.wait4(pid, 0)\n"
+                      "    return time.perf_counter() - t0, ru.ru_maxrss / 1024.0, os.waitstatus_to_exitcode(status), text.decode(errors='replace')\n"
+                      "cmds = json.loads(sys.argv[1]); print(json.dumps([child(c) for c in cmds]))\n")
+            r = subprocess.run([sys.executable, "-c", helper, json.dumps([[cli, "add", "-q"] + fmt + [src, dst2, PAYLOAD], [cli, "get"] + fmt + [dst2]])],
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+            (ta, rss_a, rc_a, _), (tg, rss_g, rc_g, text) = json.loads(r.stdout.decode())
+            text = text.encode()
             out["cli"] = {"add_s": round(ta, 3), "get_s": round(tg, 3), "xRT_incl_process_start": round(seconds / (ta + tg), 1),
                           "rc": [rc_a, rc_g], "peak_rss_mb": {"add": round(rss_a, 1), "get": round(rss_g, 1)},
                           "output_identical_to_in_process": bool(rc_a == 0 and open(dst, "rb").read() == open(dst2, "rb").read()),
@@ -352,7 +361,9 @@ def main():
     for _ in range(args.warmup):
         step()
     awm.lib.awm_prof_reset(ctx._h)
-    awm.lib.awm_prof_enable(ctx._h, 1)
+    # per-kernel HIP events: two events per launch -- noise for the 60 min kernels, a sizeable cost for the ~40 small launches
+    # of a 30 s clip, so the clips mode is timed without them
+    awm.lib.awm_prof_enable(ctx._h, 0 if args.config == "clips" else 1)
     sync()
     t0 = time.perf_counter()
     pats = None
