@@ -157,13 +157,11 @@ is_regular (FILE *f)
   return f && fstat (fileno (f), &st) == 0 && S_ISREG (st.st_mode);
 }
 
-/* returns bytes transferred (short only at EOF / on error, `failed` tells which) */
+/* returns bytes read (short only at EOF / on error, `failed` tells which) */
 size_t
-bulk_io (FILE *f, unsigned char *buf, size_t bytes, bool writing, bool& failed)
+bulk_read (FILE *f, unsigned char *buf, size_t bytes, bool& failed)
 {
   failed = false;
-  if (writing)
-    fflush (f);
   const off_t pos = ftello (f);
   if (pos < 0)
     {
@@ -179,7 +177,7 @@ bulk_io (FILE *f, unsigned char *buf, size_t bytes, bool writing, bool& failed)
     size_t n = 0;
     while (lo + n < hi)
       {
-        const ssize_t r = writing ? pwrite (fd, buf + lo + n, hi - lo - n, pos + off_t (lo + n)) : pread (fd, buf + lo + n, hi - lo - n, pos + off_t (lo + n));
+        const ssize_t r = pread (fd, buf + lo + n, hi - lo - n, pos + off_t (lo + n));
         if (r < 0 && errno == EINTR)
           continue;
         if (r <= 0)
@@ -265,7 +263,7 @@ public:
     if (max_frames * frame_bytes >= BULK_IO_MIN && is_regular (m_file))
       {
         bool failed;
-        got_frames = bulk_io (m_file, dst, max_frames * frame_bytes, false, failed) / frame_bytes;
+        got_frames = bulk_read (m_file, dst, max_frames * frame_bytes, failed) / frame_bytes;
         return failed ? Error ("error reading sample data") : Error (Error::Code::NONE);
       }
     got_frames = fread (dst, frame_bytes, max_frames, m_file);
@@ -512,7 +510,7 @@ public:
     if (max_frames * frame_bytes >= BULK_IO_MIN && is_regular (m_file))
       {
         bool failed;
-        got_frames = bulk_io (m_file, dst, max_frames * frame_bytes, false, failed) / frame_bytes;
+        got_frames = bulk_read (m_file, dst, max_frames * frame_bytes, failed) / frame_bytes;
         if (failed)
           return Error (string_printf ("error reading wav input sample data: %s", strerror (errno)));
       }

@@ -11,6 +11,7 @@ import _oracle as orc
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+max_seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 70.0       # > 110: whole blocks, the BLOCK search (K5w) sees the gaps too
 rng = np.random.default_rng(seed)
 ctx = awm.Context()
 PAY = "0123456789abcdef0011223344556677"
@@ -24,7 +25,7 @@ bad = 0
 t0 = time.time()
 for case in range(n_cases):
     ch = int(rng.choice([1, 2, 2, 2, 3]))
-    seconds = float(rng.uniform(8, 70))
+    seconds = float(rng.uniform(8, max_seconds))
     n = int(seconds * 44100)
     x = rng.uniform(-1, 1, (n, ch)).astype(np.float32) * float(rng.choice([1.0, 0.3, 0.05]))
     marked = rng.random() < 0.8
@@ -33,7 +34,7 @@ for case in range(n_cases):
     lead = int(rng.choice([0, 0, 1, 1000, 44100, 5 * 44100]))
     trail = int(rng.choice([0, 0, 1, 777, 3 * 44100]))
     x = np.concatenate([np.zeros((lead, ch), np.float32), x, np.zeros((trail, ch), np.float32)])
-    if rng.random() < 0.3:                                 # a hole of digital silence inside
+    for _ in range(int(rng.integers(1, 4)) if rng.random() < 0.3 else 0):          # holes of digital silence inside
         a = int(rng.integers(0, len(x) - 44100))
         x[a:a + int(rng.integers(1, 44100))] = 0
     if rng.random() < 0.2:
