@@ -119,7 +119,15 @@ awm::upload_sync (DevBuffer& buf, const void *src, size_t bytes, hipStream_t st)
 {
   if (int rc = buf.reserve (bytes ? bytes : 1))
     return rc;
-  AWM_HIP_CHECK (hipMemcpyAsync (buf.ptr, src, bytes, hipMemcpyHostToDevice, st));
+  // through a page-locked staging buffer of our own: the runtime's path for PAGEABLE sources costs ~190 MB of resident host
+  // memory at its first use (tools/rss_probe)
+  static std::mutex staging_mutex;
+  static PinnedBuffer staging;
+  std::lock_guard<std::mutex> lock (staging_mutex);
+  if (int rc = staging.reserve (bytes ? bytes : 1))
+    return rc;
+  std::memcpy (staging.ptr, src, bytes);
+  AWM_HIP_CHECK (hipMemcpyAsync (buf.ptr, staging.ptr, bytes, hipMemcpyHostToDevice, st));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
   return 0;
 }
@@ -427,8 +435,22 @@ awm_prof_read (awm_ctx *ctx, int id, double *ms, long *launches, double *algorit
 const char *awm_last_error (void) { return awm::last_error().c_str(); }
 const char *awm_version (void) { return "audiowmark_amd 0.1 (gfx950)"; }
 
+static int ctx_create (int device, bool own_stream, hipStream_t given, awm_ctx **ctx_out);
+
 int
 awm_ctx_create (int device, awm_ctx **ctx_out)
+{
+  return ctx_create (device, true, nullptr, ctx_out);
+}
+
+int
+awm_ctx_create_on_stream (int device, void *hip_stream, awm_ctx **ctx_out)
+{
+  return ctx_create (device, false, (hipStream_t) hip_stream, ctx_out);
+}
+
+static int
+ctx_create (int device, bool own_stream, hipStream_t given, awm_ctx **ctx_out)
 {
   if (!ctx_out)
     return AWM_ERR_ARG;
@@ -451,8 +473,11 @@ awm_ctx_create (int device, awm_ctx **ctx_out)
   AWM_HIP_CHECK (hipSetDevice (device));
   auto ctx = std::make_unique<awm_ctx>();
   ctx->device = device;
-  AWM_HIP_CHECK (hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking));
-  ctx->own_stream = true;
+  if (own_stream)
+    AWM_HIP_CHECK (hipStreamCreateWithFlags (&ctx->stream, hipStreamNonBlocking));
+  else
+    ctx->stream = given;
+  ctx->own_stream = own_stream;
 
   // constant tables, evaluated in double and rounded once
   std::vector<float> blob;

@@ -42,6 +42,9 @@ const char *awm_version (void);
 
 /* ---- context: one per GPU / per rank ------------------------------------------------ */
 int   awm_ctx_create (int device, awm_ctx **ctx_out);
+/* the same on a stream of the caller (NULL: the device's default stream); the context then creates no stream of its own
+ * (every HIP stream costs ~190 MB of resident host memory on this runtime: the command line uses this) */
+int   awm_ctx_create_on_stream (int device, void *hip_stream, awm_ctx **ctx_out);
 void  awm_ctx_destroy (awm_ctx *ctx);
 int   awm_ctx_device (const awm_ctx *ctx);
 int   awm_ctx_synchronize (awm_ctx *ctx);

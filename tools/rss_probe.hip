@@ -1,58 +1,45 @@
 // tools/rss_probe.hip -- where does the resident set size of a process using libawm_hip.so come from?
+// build: hipcc -O2 --offload-arch=gfx950 -o tools/rss_probe tools/rss_probe.hip -Laudiowmark_amd -lawm_hip -Wl,-rpath,'$ORIGIN/../audiowmark_amd'
 #include "../include/awm_hip.h"
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
+#include <vector>
 static long rss_mb() { FILE *f = fopen ("/proc/self/status", "r"); char line[256]; long kb = 0; while (fgets (line, sizeof line, f)) if (!strncmp (line, "VmRSS:", 6)) sscanf (line + 6, "%ld", &kb); fclose (f); return kb / 1024; }
+#define STEP(name) printf ("%-44s %5ld MB\n", name, rss_mb())
 __global__ void tiny (float *p) { p[threadIdx.x] = 1.f; }
-int main()
+int main (int argc, char **argv)
 {
   setvbuf (stdout, nullptr, _IONBF, 0);
-  printf ("start                         %5ld MB\n", rss_mb());
-  hipSetDevice (0);
-  printf ("hipSetDevice                  %5ld MB\n", rss_mb());
-  float *p; hipMalloc (&p, 1 << 20);
-  printf ("hipMalloc 1 MiB               %5ld MB\n", rss_mb());
-  tiny<<<1, 64>>> (p); hipDeviceSynchronize();
-  printf ("first kernel                  %5ld MB\n", rss_mb());
-  float *big; hipMalloc (&big, size_t (1) << 30);
-  printf ("hipMalloc 1 GiB               %5ld MB\n", rss_mb());
-  hipMemset (big, 0, size_t (1) << 30); hipDeviceSynchronize();
-  printf ("hipMemset 1 GiB               %5ld MB\n", rss_mb());
-  void *pin; hipHostMalloc (&pin, 64 << 20, hipHostMallocDefault);
-  printf ("hipHostMalloc 64 MiB          %5ld MB\n", rss_mb());
-  memset (pin, 1, 64 << 20);
-  printf ("  touched                     %5ld MB\n", rss_mb());
-  hipStream_t st; hipStreamCreateWithFlags (&st, hipStreamNonBlocking);
-  printf ("hipStreamCreate               %5ld MB\n", rss_mb());
-  tiny<<<1, 64, 0, st>>> (p); hipStreamSynchronize (st);
-  printf ("kernel on that stream         %5ld MB\n", rss_mb());
+  STEP ("start");
+  (void) hipSetDevice (0);                                   STEP ("hipSetDevice");
+  float *p; (void) hipMalloc (&p, 1 << 20);                  STEP ("hipMalloc 1 MiB");
+  tiny<<<1, 64>>> (p); (void) hipDeviceSynchronize();        STEP ("first kernel (default stream)");
+  float *big; (void) hipMalloc (&big, size_t (1) << 30);
+  (void) hipMemsetAsync (big, 0, size_t (1) << 30, 0); (void) hipDeviceSynchronize();   STEP ("hipMalloc + hipMemsetAsync 1 GiB");
+  (void) hipMemcpyAsync (big + (1 << 20), big, 1 << 20, hipMemcpyDeviceToDevice, 0); (void) hipDeviceSynchronize();   STEP ("hipMemcpyAsync D2D");
+  void *pin; (void) hipHostMalloc (&pin, 64 << 20, hipHostMallocDefault); memset (pin, 1, 64 << 20);      STEP ("hipHostMalloc 64 MiB (touched)");
+  (void) hipMemcpyAsync (big, pin, 64 << 20, hipMemcpyHostToDevice, 0); (void) hipDeviceSynchronize();    STEP ("H2D from pinned, default stream");
+  (void) hipMemcpyAsync (pin, big, 64 << 20, hipMemcpyDeviceToHost, 0); (void) hipDeviceSynchronize();    STEP ("D2H to pinned, default stream");
+  hipEvent_t ev; (void) hipEventCreateWithFlags (&ev, hipEventDisableTiming); (void) hipEventRecord (ev, 0); (void) hipEventSynchronize (ev);  STEP ("event record + synchronize");
+  std::thread ([&] { (void) hipEventSynchronize (ev); }).join();                                          STEP ("hipEventSynchronize on a second host thread");
+  hipStream_t st; (void) hipStreamCreateWithFlags (&st, hipStreamNonBlocking);                            STEP ("hipStreamCreate (non-blocking)");
+  (void) hipMemcpyAsync (big, pin, 64 << 20, hipMemcpyHostToDevice, st); (void) hipStreamSynchronize (st);  STEP ("H2D from pinned on that stream");
+  (void) hipStreamWaitEvent (0, ev, 0); tiny<<<1, 64>>> (p); (void) hipDeviceSynchronize();               STEP ("stream wait event + kernel");
   static float hostbuf[1 << 16];
-  hipMemcpy (p, hostbuf, sizeof hostbuf, hipMemcpyHostToDevice);
-  printf ("hipMemcpy pageable 256 KiB    %5ld MB\n", rss_mb());
-  hipMemcpyAsync (p, hostbuf, sizeof hostbuf, hipMemcpyHostToDevice, st); hipStreamSynchronize (st);
-  printf ("hipMemcpyAsync pageable       %5ld MB\n", rss_mb());
-  hipMemcpy (hostbuf, p, sizeof hostbuf, hipMemcpyDeviceToHost);
-  printf ("hipMemcpy D2H pageable        %5ld MB\n", rss_mb());
-  hipEvent_t ev; hipEventCreate (&ev); hipEventRecord (ev, st); hipEventSynchronize (ev);
-  printf ("event                         %5ld MB\n", rss_mb());
+  (void) hipMemcpy (p, hostbuf, sizeof hostbuf, hipMemcpyHostToDevice);                                   STEP ("hipMemcpy from PAGEABLE memory");
   awm_ctx *ctx = nullptr;
-  awm_ctx_create (0, &ctx);
-  printf ("awm_ctx_create                %5ld MB\n", rss_mb());
-  awm_add_stream *s = nullptr;
-  unsigned char key[16] = {};
-  awm_add_stream_create (ctx, key, "0123456789abcdef0011223344556677", 2, 4096, &s);
-  printf ("awm_add_stream_create         %5ld MB\n", rss_mb());
-  const float *out[3]; size_t nout[3];
-  awm_add_stream_push (s, 4096 * 1024, 0, out, nout);
-  awm_add_stream_push (s, 4096 * 1024, 1, out, nout);
-  awm_ctx_synchronize (ctx);
-  printf ("two tiles pushed              %5ld MB\n", rss_mb());
-  float *pcm; hipMalloc (&pcm, size_t (60) * 44100 * 2 * 4 * 5);
-  hipMemset (pcm, 0, size_t (60) * 44100 * 2 * 4 * 5);
-  awm_pattern pat[64];
-  awm_get_watermark_d (ctx, key, pcm, size_t (60) * 44100 * 5, 2, 64, pat);
-  printf ("get on 5 min                  %5ld MB\n", rss_mb());
+  (void) awm_ctx_create_on_stream (0, nullptr, &ctx);                                                     STEP ("awm_ctx_create_on_stream (default stream)");
+  if (argc > 2)
+    {
+      unsigned char key[16] = {};
+      awm_raw_format rf = { 2, 44100, 16, 0, 0 };
+      awm_set_quiet (1);
+      (void) awm_add_watermark_file (ctx, key, "0123456789abcdef0011223344556677", argv[1], argv[2], &rf, &rf);   STEP ("awm_add_watermark_file");
+      awm_pattern pat[256];
+      (void) awm_get_watermark_file (ctx, key, argv[2], &rf, 256, pat);                                    STEP ("awm_get_watermark_file");
+    }
   return 0;
 }
