@@ -103,6 +103,15 @@ struct SyncDbArgs
   const int           *row_perm = nullptr;
   const unsigned char *band_pos = nullptr;
   int                  rows_per_plane = 0;
+  // Slices (the batched clip search: many padded clips side by side in one buffer).  With streams_per_slice > 0 stream s is
+  // stream s % streams_per_slice of slice s / streams_per_slice: base = base0 + (s % sps) * base_stride + (s / sps) * slice_stride.
+  // stream_range, if set, replaces first / last by the range of the stream's slice: slice = range_index[s / range_div] if
+  // range_index is set, else s / range_div; entries are absolute value indices [first, last), first < 0 = nothing but silence.
+  int                  streams_per_slice = 0;
+  long long            slice_stride = 0;
+  const long long     *stream_range = nullptr;
+  const int           *range_index = nullptr;
+  int                  range_div = 1;
 };
 hipError_t launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a);
 /* K4s: same output as K4 for streams whose frames advance by 8 samples (search_refine): instead of one FFT per fine
@@ -166,16 +175,24 @@ hipError_t launch_sync_scan_gathered (hipStream_t st, const GatheredScanArgs& a)
 
 /* K5b: local mean over the index-sorted scores (syncfinder.cc:234-254); q is [4][q_stride] by shift,
  * sorted position p = 4 * start_frame + shift.  Writes raw[p], mean[p]. */
+/* n_slices > 1: slice y reads q + y * 4 * q_stride and writes raw_sorted / local_mean + y * 4 * n_start_frames */
 hipError_t launch_local_mean (hipStream_t st, const double *q, long long q_stride, long long n_start_frames,
-                              double *raw_sorted, double *local_mean);
+                              double *raw_sorted, double *local_mean, int n_slices = 1);
 
 /* K5c: local maxima + false-positive mask + threshold on the device (syncfinder.cc:258-332, 364-383) */
 struct PeakOut { long long p; double raw, mean; };
 hipError_t launch_peak_select (hipStream_t st, const double *raw_sorted, const double *local_mean, long long n, double threshold,
                                unsigned int *count, PeakOut *out, unsigned int cap);
+/* the same for n_slices independent score lists of n scores each: slice y uses raw / mean + y * n, the counter count[y * count_stride]
+ * (NOT cleared here) and the list out + y * cap */
+hipError_t launch_peak_select_slices (hipStream_t st, const double *raw_sorted, const double *local_mean, long long n, double threshold,
+                                      unsigned int *count, int count_stride, PeakOut *out, unsigned int cap, int n_slices);
 
 /* K5d: per-slice top k (by |raw - mean|) of a peak list whose length lives in *count; out is [n_slices][k], p = -1 = empty */
 hipError_t launch_peak_topk (hipStream_t st, const PeakOut *in, const unsigned int *count, unsigned int cap, PeakOut *out, int k, int n_slices);
+/* the same for n_lists lists: list y = in + y * cap with its length in count[y * count_stride], result out + y * n_slices * k */
+hipError_t launch_peak_topk_lists (hipStream_t st, const PeakOut *in, const unsigned int *count, int count_stride, unsigned int cap,
+                                   PeakOut *out, int k, int n_slices, int n_lists);
 
 /* K7: mix_decode (wmget.cc:67-108): db is [n_blocks][C][81][ld] (band-major), out [n_blocks][858] */
 struct SoftBitsArgs
@@ -238,6 +255,12 @@ hipError_t launch_pcm_encode (hipStream_t st, const float *in, unsigned char *by
 /* first / one-past-last non-zero value of an interleaved buffer (SyncFinder::scan_silence,
  * reference syncfinder.cc:155-169); result[0] = first (n_values if all zero), result[1] = last */
 hipError_t launch_nonzero_range (hipStream_t st, const float *data, long long n_values, unsigned long long *result);
+
+/* The padded copies of a group of clips (ClipDecoder, reference wmget.cc:830-867, START position) side by side in one buffer:
+ * slice i = [pad_start_i zeros][clip i][pad zeros], slice_values each, and the non-silent range of every slice
+ * (range[2 i] = first non-zero value, absolute index in dst, -1 if there is none; range[2 i + 1] = last + 1). */
+struct ClipSrc { const float *data; long long n_values; long long pad_start; };
+hipError_t launch_clip_pad (hipStream_t st, const ClipSrc *src /* device */, int n_clips, float *dst, long long slice_values, long long *range);
 }
 
 namespace awmk {

@@ -853,6 +853,34 @@ launch_fill_u32 (hipStream_t st, unsigned int *p, unsigned int v, size_t n)
  * K4: STFT -> dB of 81 bands, band-major output tiles
  * ========================================================================================== */
 
+/* first sample of a stream (kernels.hh SyncDbArgs: explicit list, or regular streams, optionally repeated per slice) */
+__device__ __forceinline__ long long
+sync_stream_base (const SyncDbArgs& a, long long stream)
+{
+  if (a.stream_base)
+    return a.stream_base[stream];
+  if (a.streams_per_slice > 0)
+    return a.base0 + (stream % a.streams_per_slice) * a.base_stride + (stream / a.streams_per_slice) * a.slice_stride;
+  return a.base0 + stream * a.base_stride;
+}
+
+/* non-silent value range that the skip rules of sync_fft use for this stream (syncfinder.cc:155-169, 578-590) */
+__device__ __forceinline__ void
+sync_stream_range (const SyncDbArgs& a, long long stream, long long& first, long long& last)
+{
+  first = a.first;
+  last = a.last;
+  if (a.stream_range)
+    {
+      const long long g = stream / a.range_div;
+      const long long slice = a.range_index ? a.range_index[g] : g;
+      first = a.stream_range[2 * slice];
+      last = a.stream_range[2 * slice + 1];
+      if (first < 0)
+        first = last = 0x7fffffffffffffffLL;       // nothing but silence: every frame ends before `first`
+    }
+}
+
 /* SPLIT (stereo, one output plane per channel -- the block decoder's fft_range): the interleaved samples are read ONCE and
  * both channels are transformed by the same wave; the tile holds the two planes side by side (<= 36 frames each). */
 
@@ -884,8 +912,10 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
       tile_idx = (j / a.n_streams) * 8 + (blockIdx.x & 7);
     }
   const int plane_ch = blockIdx.z;                       // only used in per-channel mode
-  const long long base = a.stream_base ? a.stream_base[stream] : a.base0 + stream * a.base_stride;
+  const long long base = sync_stream_base (a, stream);
   const int count = a.stream_count ? a.stream_count[stream] : a.count0;
+  long long sil_first, sil_last;
+  sync_stream_range (a, stream, sil_first, sil_last);
   const int TF = a.tile_frames;
   const long long tile0 = tile_idx * TF;
   if (tile0 >= count)
@@ -899,7 +929,7 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
       const long long idx = base + (tile0 + ff) * a.hop;
       // skip rules of sync_fft (reference syncfinder.cc:578-590)
       const long long f_first = idx * C, f_last = (idx + 1024) * C;
-      const bool skip = (f_last < a.first) || (f_first > a.last) || idx < 0 || idx + 1024 > a.n_frames;
+      const bool skip = (f_last < sil_first) || (f_first > sil_last) || idx < 0 || idx + 1024 > a.n_frames;
       float acc0 = 0.f, acc1 = 0.f;                      // bins 20 + lane, 84 + lane
       float split0 = 0.f, split1 = 0.f;                  // SPLIT: the same for channel 0 (acc0 / acc1 then hold channel 1)
       if (!skip)
@@ -1132,13 +1162,15 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
     return;
   // where this stream's rows go
   const long long out_slot = a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane + a.row_perm[stream % a.rows_per_plane] : stream;
-  const long long base = a.stream_base ? a.stream_base[stream] : a.base0 + stream * a.base_stride;
+  const long long base = sync_stream_base (a, stream);
   const int count = a.stream_count ? a.stream_count[stream] : a.count0;
   if (count <= 0)
     return;
+  long long sil_first, sil_last;
+  sync_stream_range (a, stream, sil_first, sil_last);
   // every fine offset of this row inside the leading / trailing silence (syncfinder.cc:583-585; CLIP: the padding of a
   // padded clip): nothing to transform, the row is marked absent
-  if (a.have && ((base + 8LL * (count - 1) + 1024) * CV < a.first || base * CV > a.last))
+  if (a.have && ((base + 8LL * (count - 1) + 1024) * CV < sil_first || base * CV > sil_last))
     {
       if (lane < count)
         a.have[out_slot * a.have_stream_stride + lane] = 0;
@@ -1256,7 +1288,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
       // ---- output for this fine offset
       const long long idx = base + 8LL * step;
       const long long f_first = idx * C, f_last = (idx + 1024) * C;
-      const bool skip = (f_last < a.first) || (f_first > a.last);
+      const bool skip = (f_last < sil_first) || (f_first > sil_last);
       float dbA = 0.f, dbB = 0.f;
       if (!skip)
         {
@@ -1590,6 +1622,9 @@ local_mean_kernel (const double *q, long long q_stride, long long S, double *raw
   const long long n_scores = 4 * S;
   if (p >= n_scores)
     return;
+  q += (long long) blockIdx.y * 4 * q_stride;            // slices (batched clip search): independent score lists
+  raw_sorted += (long long) blockIdx.y * n_scores;
+  local_mean += (long long) blockIdx.y * n_scores;
   double avg = 0;
   int n = 0;
   for (int j = -20; j <= 20; j++)
@@ -1610,12 +1645,14 @@ local_mean_kernel (const double *q, long long q_stride, long long S, double *raw
 }
 
 hipError_t
-launch_local_mean (hipStream_t st, const double *q, long long q_stride, long long n_start_frames, double *raw_sorted, double *local_mean)
+launch_local_mean (hipStream_t st, const double *q, long long q_stride, long long n_start_frames, double *raw_sorted, double *local_mean,
+                   int n_slices)
 {
   const long long n = 4 * n_start_frames;
-  if (n <= 0)
+  if (n <= 0 || n_slices <= 0)
     return hipSuccess;
-  hipLaunchKernelGGL (local_mean_kernel, dim3 (unsigned ((n + 255) / 256)), dim3 (256), 0, st, q, q_stride, n_start_frames, raw_sorted, local_mean);
+  hipLaunchKernelGGL (local_mean_kernel, dim3 (unsigned ((n + 255) / 256), unsigned (n_slices)), dim3 (256), 0, st, q, q_stride, n_start_frames,
+                      raw_sorted, local_mean);
   return hipGetLastError();
 }
 
@@ -1855,6 +1892,77 @@ launch_nonzero_range (hipStream_t st, const float *data, long long n_values, uns
   return hipGetLastError();
 }
 
+/* kernels.hh launch_clip_pad: grid (parts, clips) */
+__global__ void __launch_bounds__ (256)
+clip_pad_kernel (const ClipSrc *src, float *dst, long long slice_values, unsigned long long *range)
+{
+  const ClipSrc c = src[blockIdx.y];
+  float *out = dst + (long long) blockIdx.y * slice_values;
+  const long long slice0 = (long long) blockIdx.y * slice_values;
+  const long long stride = (long long) gridDim.x * blockDim.x;
+  unsigned long long first = ~0ULL, last = 0;
+  for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < slice_values; i += stride)
+    {
+      const long long k = i - c.pad_start;
+      const float v = (k >= 0 && k < c.n_values) ? c.data[k] : 0.f;
+      out[i] = v;
+      if (v != 0.f)
+        {
+          const unsigned long long at = (unsigned long long) (slice0 + i);
+          first = at < first ? at : first;
+          last = at + 1 > last ? at + 1 : last;
+        }
+    }
+  for (int o = 32; o > 0; o >>= 1)
+    {
+      const unsigned long long f = __shfl_xor (first, o), l = __shfl_xor (last, o);
+      first = f < first ? f : first;
+      last = l > last ? l : last;
+    }
+  __shared__ unsigned long long s_first[4], s_last[4];
+  if ((threadIdx.x & 63) == 0)
+    {
+      s_first[threadIdx.x >> 6] = first;
+      s_last[threadIdx.x >> 6] = last;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    {
+      for (int w = 1; w < 4; w++)
+        {
+          first = s_first[w] < first ? s_first[w] : first;
+          last = s_last[w] > last ? s_last[w] : last;
+        }
+      if (first != ~0ULL)
+        {
+          atomicMin (range + 2 * blockIdx.y, first);          // all ones (= -1 as the signed value the consumers read) if nothing is found
+          atomicMax (range + 2 * blockIdx.y + 1, last);
+        }
+    }
+}
+
+__global__ void
+clip_range_init_kernel (unsigned long long *range, int n_clips)
+{
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_clips)
+    {
+      range[2 * i] = ~0ULL;
+      range[2 * i + 1] = 0;
+    }
+}
+
+hipError_t
+launch_clip_pad (hipStream_t st, const ClipSrc *src, int n_clips, float *dst, long long slice_values, long long *range)
+{
+  if (n_clips <= 0 || slice_values <= 0)
+    return hipSuccess;
+  auto *r = reinterpret_cast<unsigned long long *> (range);
+  hipLaunchKernelGGL (clip_range_init_kernel, dim3 (unsigned ((n_clips + 255) / 256)), dim3 (256), 0, st, r, n_clips);
+  hipLaunchKernelGGL (clip_pad_kernel, dim3 (128, unsigned (n_clips)), dim3 (256), 0, st, src, dst, slice_values, r);
+  return hipGetLastError();
+}
+
 /* K5c: sync_select_local_maxima + sync_mask_avg_false_positives + the threshold part of
  * sync_select_threshold_and_n_best (reference syncfinder.cc:258-332, 364-383) evaluated per score.
  *
@@ -1889,9 +1997,13 @@ psel_is_max (const double *raw, const double *mean, long long n, long long i)
 }
 
 __global__ void __launch_bounds__ (256)
-peak_select_kernel (const double *raw, const double *mean, long long n, double threshold, unsigned int *count,
+peak_select_kernel (const double *raw, const double *mean, long long n, double threshold, unsigned int *count, int count_stride,
                     PeakOut *out, unsigned int cap)
 {
+  raw += (long long) blockIdx.y * n;                     // slices: independent score lists with their own counter and output list
+  mean += (long long) blockIdx.y * n;
+  count += (long long) blockIdx.y * count_stride;
+  out += (long long) blockIdx.y * cap;
   const long long p = (long long) blockIdx.x * blockDim.x + threadIdx.x;
   if (p >= n || !psel_is_max (raw, mean, n, p))
     return;
@@ -1923,7 +2035,18 @@ launch_peak_select (hipStream_t st, const double *raw, const double *mean, long 
   hipError_t e = hipMemsetAsync (count, 0, sizeof (unsigned int), st);
   if (e != hipSuccess || n <= 0)
     return e;
-  hipLaunchKernelGGL (peak_select_kernel, dim3 (unsigned ((n + 255) / 256)), dim3 (256), 0, st, raw, mean, n, threshold, count, out, cap);
+  hipLaunchKernelGGL (peak_select_kernel, dim3 (unsigned ((n + 255) / 256)), dim3 (256), 0, st, raw, mean, n, threshold, count, 0, out, cap);
+  return hipGetLastError();
+}
+
+hipError_t
+launch_peak_select_slices (hipStream_t st, const double *raw, const double *mean, long long n, double threshold,
+                           unsigned int *count, int count_stride, PeakOut *out, unsigned int cap, int n_slices)
+{
+  if (n <= 0 || n_slices <= 0)
+    return hipSuccess;
+  hipLaunchKernelGGL (peak_select_kernel, dim3 (unsigned ((n + 255) / 256), unsigned (n_slices)), dim3 (256), 0, st, raw, mean, n, threshold,
+                      count, count_stride, out, cap);
   return hipGetLastError();
 }
 
@@ -1932,11 +2055,14 @@ launch_peak_select (hipStream_t st, const double *raw, const double *mean, long 
  * unused slots get p = -1.  The global top K is a subset of the union, which the host merges (a few KB instead
  * of the whole list: the n_best fallback of syncfinder.cc:364-383 on unmarked or short material). */
 __global__ void __launch_bounds__ (256)
-peak_topk_kernel (const PeakOut *in, const unsigned int *count_ptr, unsigned int cap, PeakOut *out, int K)
+peak_topk_kernel (const PeakOut *in, const unsigned int *count_ptr, int count_stride, unsigned int cap, PeakOut *out, int K)
 {
   __shared__ double    s_q[256];
   __shared__ long long s_p[256];
   __shared__ long long s_i[256];
+  in += (long long) blockIdx.y * cap;                    // lists (batched clip search)
+  count_ptr += (long long) blockIdx.y * count_stride;
+  out += (long long) blockIdx.y * gridDim.x * K;
   const unsigned int count = *count_ptr < cap ? *count_ptr : cap;
   const long long lo = (long long) count * blockIdx.x / gridDim.x;
   const long long hi = (long long) count * (blockIdx.x + 1) / gridDim.x;
@@ -2019,7 +2145,17 @@ launch_peak_topk (hipStream_t st, const PeakOut *in, const unsigned int *count, 
 {
   if (k <= 0 || n_slices <= 0)
     return hipErrorInvalidValue;
-  hipLaunchKernelGGL (peak_topk_kernel, dim3 (n_slices), dim3 (256), 0, st, in, count, cap, out, k);
+  hipLaunchKernelGGL (peak_topk_kernel, dim3 (n_slices), dim3 (256), 0, st, in, count, 0, cap, out, k);
+  return hipGetLastError();
+}
+
+hipError_t
+launch_peak_topk_lists (hipStream_t st, const PeakOut *in, const unsigned int *count, int count_stride, unsigned int cap, PeakOut *out,
+                        int k, int n_slices, int n_lists)
+{
+  if (k <= 0 || n_slices <= 0 || n_lists <= 0)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL (peak_topk_kernel, dim3 (n_slices, n_lists), dim3 (256), 0, st, in, count, count_stride, cap, out, k);
   return hipGetLastError();
 }
 

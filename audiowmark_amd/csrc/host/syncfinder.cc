@@ -179,7 +179,51 @@ SyncFinder::select_candidates (long long n_scores, double threshold, std::vector
   return select_finish (n_scores, threshold, out);
 }
 
-namespace { constexpr unsigned int PEAK_CAP = 16384, PEAK_HEAD = 1024; constexpr int TOPK_MAX = 64, TOPK_SLICES = 64; }
+namespace {
+constexpr unsigned int PEAK_CAP = 16384, PEAK_HEAD = 1024;
+constexpr int TOPK_MAX = 64, TOPK_SLICES = 64;
+
+SyncFinder::SearchScore
+score_of_peak (const awmk::PeakOut& pk)
+{
+  return { size_t (pk.p >> 2) * Params::frame_size + size_t (pk.p & 3) * Params::sync_search_step, pk.raw, pk.mean };
+}
+
+/* the peaks above the threshold (device order) -> the order the reference continues with: descending quality */
+void
+scores_from_threshold_list (const awmk::PeakOut *peaks, unsigned int count, std::vector<SyncFinder::SearchScore>& out)
+{
+  using SearchScore = SyncFinder::SearchScore;
+  for (unsigned int i = 0; i < count; i++)
+    out.push_back (score_of_peak (peaks[i]));
+  std::sort (out.begin(), out.end(), [] (const SearchScore& a, const SearchScore& b) {
+    return a.abs_quality() != b.abs_quality() ? a.abs_quality() > b.abs_quality() : a.index < b.index;
+  });
+}
+
+/* Fewer than n_best peaks above the threshold: select_threshold_and_n_best keeps the n_best largest unmasked maxima.  `top` is
+ * the union of the per-slice n_best + 1 largest (K5d).  false: a tie across the cut -- the complete list has to go through the
+ * reference's std::sort instead. */
+bool
+scores_from_topk (std::vector<awmk::PeakOut> top, double threshold, std::vector<SyncFinder::SearchScore>& out)
+{
+  top.erase (std::remove_if (top.begin(), top.end(), [] (const awmk::PeakOut& pk) { return pk.p < 0; }), top.end());
+  auto absq = [] (const awmk::PeakOut& pk) { return std::fabs (pk.raw - pk.mean); };
+  std::sort (top.begin(), top.end(), [&] (const awmk::PeakOut& a, const awmk::PeakOut& b) {
+    return absq (a) != absq (b) ? absq (a) > absq (b) : a.p < b.p;
+  });
+  const size_t nb = size_t (Params::get_n_best);
+  if (top.size() > nb && absq (top[nb - 1]) == absq (top[nb]))
+    return false;
+  if (top.size() > nb)
+    top.resize (nb);
+  std::sort (top.begin(), top.end(), [] (const awmk::PeakOut& a, const awmk::PeakOut& b) { return a.p < b.p; });
+  for (const auto& pk : top)
+    out.push_back (score_of_peak (pk));
+  SyncFinder::select_threshold_and_n_best (out, threshold);
+  return true;
+}
+}
 
 int
 SyncFinder::select_launch (long long n_scores, double threshold, bool speculate_n_best)
@@ -236,14 +280,7 @@ SyncFinder::select_finish (long long n_scores, double threshold, std::vector<Sea
                                          hipMemcpyDeviceToHost, st));
           AWM_HIP_CHECK (stream_wait (st));
         }
-      const auto *pk0 = reinterpret_cast<const awmk::PeakOut *> (pin + 256);
-      std::vector<awmk::PeakOut> peaks (pk0, pk0 + count);
-      for (const auto& pk : peaks)
-        out.push_back ({ size_t (pk.p >> 2) * Params::frame_size + size_t (pk.p & 3) * Params::sync_search_step, pk.raw, pk.mean });
-      // same order the reference continues with: descending quality (atomics delivered them unordered)
-      std::sort (out.begin(), out.end(), [] (const SearchScore& a, const SearchScore& b) {
-        return a.abs_quality() != b.abs_quality() ? a.abs_quality() > b.abs_quality() : a.index < b.index;
-      });
+      scores_from_threshold_list (reinterpret_cast<const awmk::PeakOut *> (pin + 256), count, out);   // (atomics delivered them unordered)
       return 0;
     }
   // fewer than n_best peaks above the threshold: the reference then keeps the n_best largest unmasked maxima.
@@ -277,23 +314,8 @@ SyncFinder::select_finish (long long n_scores, double threshold, std::vector<Sea
           AWM_HIP_CHECK (hipMemcpyAsync (top.data(), d_top, top.size() * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
           AWM_HIP_CHECK (stream_wait (st));
         }
-      top.erase (std::remove_if (top.begin(), top.end(), [] (const awmk::PeakOut& pk) { return pk.p < 0; }), top.end());
-      auto absq = [] (const awmk::PeakOut& pk) { return std::fabs (pk.raw - pk.mean); };
-      std::sort (top.begin(), top.end(), [&] (const awmk::PeakOut& a, const awmk::PeakOut& b) {
-        return absq (a) != absq (b) ? absq (a) > absq (b) : a.p < b.p;
-      });
-      const size_t nb = size_t (Params::get_n_best);
-      const bool tie_at_cut = top.size() > nb && absq (top[nb - 1]) == absq (top[nb]);
-      if (!tie_at_cut)
-        {
-          if (top.size() > nb)
-            top.resize (nb);
-          std::sort (top.begin(), top.end(), [] (const awmk::PeakOut& a, const awmk::PeakOut& b) { return a.p < b.p; });
-          for (const auto& pk : top)
-            out.push_back ({ size_t (pk.p >> 2) * Params::frame_size + size_t (pk.p & 3) * Params::sync_search_step, pk.raw, pk.mean });
-          select_threshold_and_n_best (out, threshold);
-          return 0;
-        }
+      if (scores_from_topk (std::move (top), threshold, out))
+        return 0;
     }
   AWM_HIP_CHECK (hipMemcpyAsync (&count, d_count, sizeof (count), hipMemcpyDeviceToHost, st));
   AWM_HIP_CHECK (stream_wait (st));
@@ -315,7 +337,7 @@ SyncFinder::select_finish (long long n_scores, double threshold, std::vector<Sea
     }
   std::sort (peaks.begin(), peaks.end(), [] (const awmk::PeakOut& a, const awmk::PeakOut& b) { return a.p < b.p; });   // index order, as the reference's list
   for (const auto& pk : peaks)
-    out.push_back ({ size_t (pk.p >> 2) * Params::frame_size + size_t (pk.p & 3) * Params::sync_search_step, pk.raw, pk.mean });
+    out.push_back (score_of_peak (pk));
   select_threshold_and_n_best (out, threshold);
   return 0;
 }
@@ -422,12 +444,13 @@ SyncFinder::refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, Searc
   const bool gathered = wav.n_channels <= 2;
   const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
   const size_t per_cand = size_t (NW) * row_values * REFINE_TP;
-  size_t batch = std::max<size_t> (1, (size_t (3) << 30) / (per_cand * sizeof (float)));    // <= 3 GiB of dB rows at a time
+  // <= 3 GiB of dB rows at a time (a group of clips: 12 GiB, every further batch is one more wait for the whole group)
+  size_t batch = std::max<size_t> (1, (size_t (job.slice_frames ? 12 : 3) << 30) / (per_cand * sizeof (float)));
   batch = std::min (batch, n_cand);
   if (int rc = m_lane->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
   if (int rc = m_lane->ws_refine_have.reserve (batch * NW * REFINE_TP)) return rc;
   if (int rc = m_lane->ws_q.reserve (batch * REFINE_QS * sizeof (double))) return rc;
-  if (int rc = m_lane->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + batch * sizeof (int))) return rc;
+  if (int rc = m_lane->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + 2 * batch * sizeof (int))) return rc;
   for (size_t c0 = 0; c0 < n_cand; c0 += batch)
     {
       if (job.batch_pending)
@@ -453,8 +476,10 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
   const size_t per_cand = size_t (NW) * row_values * TP;
   (void) batch;
 
-  // stream tables: [nb * NW] long long base, [nb * NW] int count, [nb] int lanes -- one page-locked block, one copy
-  const size_t in_bytes = nb * NW * (sizeof (long long) + sizeof (int)) + nb * sizeof (int);
+  // stream tables: [nb * NW] long long base, [nb * NW] int count, [nb] int lanes, [nb] int slice -- one page-locked block, one copy
+  const size_t in_bytes = nb * NW * (sizeof (long long) + sizeof (int)) + 2 * nb * sizeof (int);
+  const bool slices = job.slice_frames > 0;
+  const long long span_frames = slices ? (long long) job.slice_frames : (long long) wav.n_frames;
   PinnedBuffer& pin_in = m_lane->pin_refine_in[job.slot];
   PinnedBuffer& pin_q = m_lane->pin_refine_q[job.slot];
   if (int rc = pin_in.reserve (in_bytes)) return rc;
@@ -462,6 +487,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
   auto *stream_base = pin_in.as<long long>();
   int *stream_count = reinterpret_cast<int *> (stream_base + nb * NW);
   int *lanes = stream_count + nb * NW;
+  int *slice_of = lanes + nb;
   job.lane_count.assign (nb, 0);
   job.starts.assign (nb, 0);
   job.c0 = c0;
@@ -475,7 +501,9 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
       const int start = std::max (int (s.index) - Params::sync_search_step, 0);
       const int end = int (s.index) + Params::sync_search_step;
       // fine offsets for which sync_fft does not read past the end (syncfinder.cc:566-568)
-      const long long limit = (long long) wav.n_frames - total * Params::frame_size;
+      const long long limit = span_frames - total * Params::frame_size;
+      const long long slice0 = slices ? (long long) job.cand_slice[c0 + c] * span_frames : 0;
+      slice_of[c] = slices ? job.cand_slice[c0 + c] : 0;
       int count = 0;
       for (int fine = start; fine <= end; fine += Params::sync_search_fine)
         if (fine <= limit)
@@ -489,13 +517,14 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
         db_bytes += double (NW) * ((1024.0 + 8.0 * (count - 1)) * 4 * wav.n_channels + 4.0 * row_values * count);
       for (int w = 0; w < NW; w++)
         {
-          stream_base[c * NW + w] = start + (long long) sync.want_list[w] * Params::frame_size;
+          stream_base[c * NW + w] = slice0 + start + (long long) sync.want_list[w] * Params::frame_size;
           stream_count[c * NW + w] = count;
         }
     }
   auto *d_base = m_lane->ws_idx.as<long long>();
   int *d_count = reinterpret_cast<int *> (d_base + nb * NW);
   int *d_lanes = d_count + nb * NW;
+  int *d_slice_of = d_lanes + nb;
   AWM_HIP_CHECK (hipMemcpyAsync (d_base, stream_base, in_bytes, hipMemcpyHostToDevice, st));
 
   double *q = pin_q.as<double>();
@@ -525,6 +554,12 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
       da.have_stream_stride = TP;
       da.first = (long long) m_first;
       da.last = (long long) m_last;
+      if (slices)
+        {
+          da.stream_range = job.slice_range;
+          da.range_index = d_slice_of;
+          da.range_div = NW;
+        }
       da.tile_frames = TP;
       {
         ProfScope ps (m_ctx, PROF_REFINE_DB, db_bytes, st);
@@ -718,6 +753,202 @@ SyncFinder::search_finish (SearchJob& job, std::vector<Score>& out)
     {
       const double q = s.raw_quality - s.local_mean;
       out.push_back ({ s.index, std::fabs (q), q > 0 ? ConvBlockType::a : ConvBlockType::b });
+    }
+  return 0;
+}
+
+/* ---- CLIP search for a group of padded clips (syncfinder.hh GroupJob) -------------------------------------------------------- */
+
+namespace {
+constexpr unsigned int GROUP_HEAD = 32;      // peaks above the threshold fetched per slice (a clip holds one or two sync peaks per block)
+constexpr int GROUP_TOPK_SLICES = 4;
+size_t align256 (size_t n) { return (n + 255) & ~size_t (255); }
+struct GroupLayout
+{
+  size_t off_th, off_top, bytes;
+  GroupLayout (int n_slices, int k)
+  {
+    off_th = align256 (size_t (n_slices) * 2 * sizeof (unsigned int));
+    off_top = off_th + size_t (n_slices) * GROUP_HEAD * sizeof (awmk::PeakOut);
+    bytes = off_top + size_t (n_slices) * GROUP_TOPK_SLICES * k * sizeof (awmk::PeakOut);
+  }
+};
+}
+
+int
+SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_slices, const long long *d_range, GroupJob& gj)
+{
+  gj.n_slices = n_slices;
+  gj.kt = kt;
+  gj.group = group;
+  gj.slice_frames = n_slices > 0 ? group.n_frames / n_slices : 0;
+  gj.n_scores = 0;
+  gj.fallback.assign (std::max (n_slices, 0), 0);
+  gj.refine = SearchJob();
+  gj.refine.slice_frames = gj.slice_frames;
+  gj.refine.slice_range = d_range;
+  const Mode mode = Mode::CLIP;
+  const long long frame_count = gj.slice_frames / Params::frame_size;
+  const long long n_db = frame_count - 1;          // as approx_device, per slice
+  const long long S = n_db - total_frames (mode);
+  const int k = Params::get_n_best + 1;
+  if (n_slices <= 0 || n_db <= 0 || S <= 0)
+    return 0;
+  if (gj.slice_frames % Params::frame_size || k > TOPK_MAX)
+    {
+      gj.fallback.assign (n_slices, 1);            // (slices are whole frames by construction; an n_best beyond the top-k kernel)
+      return 0;
+    }
+  hipStream_t st = m_lane->stream;
+  const int n_shifts = Params::frame_size / Params::sync_search_step;
+  const long long ld = (n_db + 63) & ~63LL;
+  const long long plane = ld * Params::n_bands;
+  const long long q_stride = (S + 63) & ~63LL;
+  const long long n_planes = (long long) n_slices * n_shifts;
+  const long long n_scores = (long long) n_shifts * S;
+  if (int rc = m_lane->ws_db.reserve (size_t (n_planes) * plane * sizeof (float))) return rc;
+  if (int rc = m_lane->ws_have.reserve (size_t (n_planes) * ld)) return rc;
+  if (int rc = m_lane->ws_q.reserve (size_t (n_planes) * q_stride * sizeof (double))) return rc;
+  if (int rc = m_lane->ws_raw.reserve (size_t (n_slices) * n_scores * sizeof (double))) return rc;
+  if (int rc = m_lane->ws_mean.reserve (size_t (n_slices) * n_scores * sizeof (double))) return rc;
+
+  awmk::SyncDbArgs da {};
+  da.pcm = group.data;
+  da.n_frames = group.n_frames;
+  da.n_channels = group.n_channels;
+  da.base0 = 0;
+  da.base_stride = Params::sync_search_step;
+  da.streams_per_slice = n_shifts;
+  da.slice_stride = (long long) gj.slice_frames;
+  da.stream_range = d_range;
+  da.range_div = n_shifts;
+  da.count0 = int (n_db);
+  da.n_streams = n_planes;
+  da.hop = Params::frame_size;
+  da.out = m_lane->ws_db.as<float>();
+  da.out_stream_stride = plane;
+  da.ld = ld;
+  da.have = m_lane->ws_have.as<char>();
+  da.have_stream_stride = ld;
+  da.tile_frames = 32;
+  {
+    ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_planes) * n_db * (4096.0 * group.n_channels + 324.0), st);
+    AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+  }
+  awmk::SyncScanArgs sa {};
+  sa.db = m_lane->ws_db.as<float>();
+  sa.have = m_lane->ws_have.as<char>();
+  sa.plane_stride = plane;
+  sa.have_plane_stride = ld;
+  sa.row_stride = 1;
+  sa.band_stride = ld;
+  sa.have_row_stride = 1;
+  sa.n_lanes = S;
+  sa.n_planes = n_planes;
+  sa.min_delta = std::min (Params::water_delta, 0.080);
+  sa.quality = m_lane->ws_q.as<double>();
+  sa.q_stride = q_stride;
+  sa.table.packed = kt->sync[1].packed_approx.as<int>();
+  sa.table.rows_per_bit = kt->sync[1].host.rows_per_bit;
+  sa.table.chains = kt->sync[1].chains_approx.as<unsigned>();
+  {
+    ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_planes) * n_db * 324.0 + double (n_planes) * S * 8.0, st);
+    AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));
+  }
+  {
+    ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_slices) * n_scores * 56.0, st);
+    AWM_HIP_CHECK (awmk::launch_local_mean (st, m_lane->ws_q.as<double>(), q_stride, S, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(),
+                                            n_slices));
+    // selection (select_launch with the n_best fallback queued right away), every slice with its own counters and lists:
+    // ws_misc = [slices][2] counters | [slices][GROUP_HEAD] above the threshold | [slices][4][k] largest unmasked maxima
+    const GroupLayout lay (n_slices, k);
+    if (int rc = m_lane->ws_misc.reserve (lay.bytes)) return rc;
+    if (int rc = m_lane->pin_peaks.reserve (lay.bytes)) return rc;
+    if (int rc = m_lane->ws_refine.reserve (size_t (n_slices) * n_scores * sizeof (awmk::PeakOut))) return rc;
+    char *base = m_lane->ws_misc.as<char>();
+    auto *d_count = reinterpret_cast<unsigned int *> (base);
+    auto *d_th = reinterpret_cast<awmk::PeakOut *> (base + lay.off_th);
+    auto *d_top = reinterpret_cast<awmk::PeakOut *> (base + lay.off_top);
+    auto *d_all = m_lane->ws_refine.as<awmk::PeakOut>();
+    const double threshold = Params::sync_threshold2 * 0.75;
+    AWM_HIP_CHECK (hipMemsetAsync (d_count, 0, size_t (n_slices) * 2 * sizeof (unsigned int), st));
+    AWM_HIP_CHECK (awmk::launch_peak_select_slices (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, threshold,
+                                                    d_count, 2, d_th, GROUP_HEAD, n_slices));
+    AWM_HIP_CHECK (awmk::launch_peak_select_slices (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, -1.0,
+                                                    d_count + 1, 2, d_all, unsigned (n_scores), n_slices));
+    AWM_HIP_CHECK (awmk::launch_peak_topk_lists (st, d_all, d_count + 1, 2, unsigned (n_scores), d_top, k, GROUP_TOPK_SLICES, n_slices));
+    AWM_HIP_CHECK (hipMemcpyAsync (m_lane->pin_peaks.ptr, base, lay.bytes, hipMemcpyDeviceToHost, st));
+  }
+  gj.n_scores = n_scores;
+  return 0;
+}
+
+int
+SyncFinder::group_select_refine (GroupJob& gj)
+{
+  if (gj.n_scores <= 0)
+    return 0;
+  const int k = Params::get_n_best + 1;
+  const GroupLayout lay (gj.n_slices, k);
+  AWM_HIP_CHECK (stream_wait (m_lane->stream));
+  const char *pin = m_lane->pin_peaks.as<char>();
+  const auto *count = reinterpret_cast<const unsigned int *> (pin);
+  const auto *th = reinterpret_cast<const awmk::PeakOut *> (pin + lay.off_th);
+  const auto *top = reinterpret_cast<const awmk::PeakOut *> (pin + lay.off_top);
+  const double threshold = Params::sync_threshold2 * 0.75;
+  SearchJob& job = gj.refine;
+  for (int i = 0; i < gj.n_slices; i++)
+    {
+      if (gj.fallback[i])
+        continue;
+      std::vector<SearchScore> cands;                      // select_finish for this slice
+      const unsigned int c_th = count[2 * i];
+      if (int (c_th) >= Params::get_n_best && c_th <= GROUP_HEAD)
+        scores_from_threshold_list (th + size_t (i) * GROUP_HEAD, c_th, cands);
+      else if (int (c_th) < Params::get_n_best)
+        {
+          const awmk::PeakOut *t0 = top + size_t (i) * GROUP_TOPK_SLICES * k;
+          if (!scores_from_topk (std::vector<awmk::PeakOut> (t0, t0 + size_t (GROUP_TOPK_SLICES) * k), threshold, cands))
+            gj.fallback[i] = 1;
+        }
+      else
+        gj.fallback[i] = 1;
+      if (gj.fallback[i])
+        continue;
+      select_truncate_n (cands, std::max (Params::get_n_best, 5));     // select_refine, Mode::CLIP
+      for (const auto& c : cands)
+        {
+          job.candidates.push_back (c);
+          job.cand_slice.push_back (i);
+        }
+    }
+  return refine_launch (gj.kt, gj.group, Mode::CLIP, job);
+}
+
+int
+SyncFinder::group_finish (GroupJob& gj, std::vector<std::vector<Score>>& out)
+{
+  out.assign (std::max (gj.n_slices, 0), {});
+  if (gj.n_scores <= 0)
+    return 0;
+  SearchJob& job = gj.refine;
+  if (int rc = refine_batch_finish (job))
+    return rc;
+  // job.refined is in candidate order; per slice: refine_finish + search_finish
+  std::vector<std::vector<SearchScore>> per_slice (gj.n_slices);
+  for (size_t c = 0; c < job.refined.size(); c++)
+    per_slice[job.cand_slice[c]].push_back (job.refined[c]);
+  for (int i = 0; i < gj.n_slices; i++)
+    {
+      auto& scores = per_slice[i];
+      std::stable_sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
+      select_threshold_and_n_best (scores, Params::sync_threshold2);
+      std::sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
+      for (const auto& s : scores)
+        {
+          const double q = s.raw_quality - s.local_mean;
+          out[i].push_back ({ s.index, std::fabs (q), q > 0 ? ConvBlockType::a : ConvBlockType::b });
+        }
     }
   return 0;
 }

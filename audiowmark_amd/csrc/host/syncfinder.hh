@@ -74,6 +74,10 @@ public:
     long long  n_scores = 0;
     bool       select_pending = false;
     bool       speculate_n_best = false;    // queue the n_best fallback together with the threshold selection (one round trip)
+    // batched clip search: `wav` is a row of equal slices, candidate c lives in slice cand_slice[c] (its index is relative to it)
+    std::vector<int> cand_slice;
+    size_t           slice_frames = 0;      // 0: no slices
+    const long long *slice_range = nullptr; // device, [slices][2]: non-silent value range of every slice (kernels.hh launch_clip_pad)
   };
   int search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job);     // = approx_launch + select_refine
   int search_finish (SearchJob& job, std::vector<Score>& out);
@@ -82,6 +86,26 @@ public:
   // db_ready: the lane workspace still holds the dB matrices of THIS wav from the previous key of the same get (they do not depend on the key)
   int approx_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool prepared = false, bool db_ready = false);
   int select_refine (SearchJob& job);
+
+
+  /* The CLIP search for a GROUP of padded clips that lie side by side in one buffer (equal slices, kernels.hh launch_clip_pad), stage by
+   * stage with ONE launch per kernel and ONE wait per stage for the whole group -- a 30 s clip alone keeps the GPU busy for a
+   * fraction of the time its ~20 launches and 3 round trips take.  Results per slice are those of search (key, slice, Mode::CLIP).
+   * A slice whose selection needs the rare sequential path (more peaks above the threshold than the head list holds, a tie at the
+   * n_best cut) is reported in `fallback` and must go through search() on its own. */
+  struct GroupJob
+  {
+    int        n_slices = 0;
+    size_t     slice_frames = 0;
+    long long  n_scores = 0;               // per slice
+    KeyTables *kt = nullptr;
+    DeviceWav  group;
+    SearchJob  refine;
+    std::vector<char> fallback;
+  };
+  int group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_slices, const long long *d_range, GroupJob& gj);
+  int group_select_refine (GroupJob& gj);
+  int group_finish (GroupJob& gj, std::vector<std::vector<Score>>& out);
 
   static void select_local_maxima (std::vector<SearchScore>& scores);
   static void mask_avg_false_positives (std::vector<SearchScore>& scores);

@@ -941,11 +941,13 @@ get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const Devi
 
 /* Short clips (less than one block + 2 frames: 51.7 s) go through exactly one thing in `get`: the ClipDecoder's START pass
  * (the block decoder finds no room for a block, the END pass needs more than one long block; reference wmget.cc:769-884,
- * 886-939).  For a batch of them that pass is run stage by stage over a group of lanes from ONE host thread: pad + silence
- * scan for all clips of the group, approximate search for all, candidate selection + refinement for all, soft bits +
- * Viterbi for all -- the device sees up to MAX_LANES independent chains of small kernels, the host waits once per
- * stage and lane instead of ten times per clip, and no two host threads fight over the runtime. */
-constexpr int STAGED_THREADS = 2;       // host threads of the staged clip batch (AWM_STAGED_THREADS overrides); measured 1: 0.69, 2: 0.64, 4 / 8: 0.61 ms per clip
+ * 886-939).  Alone, such a clip is ~45 small launches and copies and 3 host round trips around a few hundred microseconds of GPU
+ * work.  A batch of them is therefore processed in GROUPS: the padded copies of a group lie side by side in one buffer (equal
+ * slices), and every stage -- pad + silence scan, dB matrices, approximate scan, local mean, peak selection, refinement, block dB +
+ * soft bits, Viterbi -- is ONE launch for the whole group (SyncFinder::group_*), with one wait per stage.  Two host threads work on
+ * their own lanes, so that the waits of one overlap the kernels of the other. */
+constexpr int CLIP_GROUP = 64;          // clips per group
+constexpr int STAGED_THREADS = 2;
 
 static bool
 clip_is_short (const DeviceWav& w)
@@ -954,94 +956,81 @@ clip_is_short (const DeviceWav& w)
 }
 
 static int
-clip_batch_staged (awm_ctx *ctx, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips, const std::vector<size_t>& which,
-                   std::vector<ResultSet>& result_sets, int lane_first = 0, int lane_count = MAX_LANES)
+clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips, const std::vector<size_t>& which,
+                   std::vector<ResultSet>& result_sets)
 {
   const size_t count = mark_block_frame_count();
-  std::vector<WorkLane *> lanes;
-  for (int i = 0; i < int (std::min<size_t> (which.size(), lane_count)); i++)
-    {
-      WorkLane *l = ctx->lane (lane_first + i);
-      if (!l)
-        {
-          set_error ("cannot create a work lane (stream)");
-          return AWM_ERR_HIP;
-        }
-      lanes.push_back (l);
-    }
+  hipStream_t st = lane->stream;
   struct LaneDrain
   {
-    const std::vector<WorkLane *>& lanes;
+    hipStream_t st;
     bool ok = false;
-    ~LaneDrain() { if (!ok) for (WorkLane *l : lanes) (void) hipStreamSynchronize (l->stream); }
-  } drain { lanes };
+    ~LaneDrain() { if (!ok) (void) hipStreamSynchronize (st); }
+  } drain { st };
   std::vector<ResultSet> chunk_sets (which.size());
-  for (size_t g0 = 0; g0 < which.size(); g0 += lanes.size())
+  for (size_t g0 = 0; g0 < which.size(); )
     {
-      const size_t gn = std::min (lanes.size(), which.size() - g0);
-      std::vector<DeviceWav> padded (gn);
-      // stage 0: padded copy (reference wmget.cc:830-867, START position) on the lane
+      // a group: up to CLIP_GROUP clips with the same number of channels (the slices of a group are equal)
+      const int C = clips[which[g0]].n_channels;
+      size_t gn = 0;
+      while (g0 + gn < which.size() && gn < size_t (CLIP_GROUP) && clips[which[g0 + gn]].n_channels == C)
+        gn++;
+      const size_t n = (count + 5) * Params::frame_size * C;                       // in values
+      const size_t slice_values = 3 * n;                                            // pad_start + len + n with pad_start = n + (n - len)
+      const size_t slice_frames = slice_values / C;
+      // stage 0: padded copies (reference wmget.cc:830-867, START position: data + padding cover one long block) and the
+      // non-silent range of every slice
+      if (int rc = lane->ws_clip.reserve (gn * slice_values * sizeof (float))) return rc;
+      const size_t desc_bytes = gn * sizeof (awmk::ClipSrc);
+      if (int rc = lane->pin_group.reserve (desc_bytes)) return rc;
+      if (int rc = lane->ws_group.reserve (desc_bytes + gn * 2 * sizeof (long long))) return rc;
+      AWM_HIP_CHECK (stream_wait (st));                                             // (the previous group's descriptors are consumed)
+      auto *desc = lane->pin_group.as<awmk::ClipSrc>();
       for (size_t i = 0; i < gn; i++)
         {
           const DeviceWav& wav = clips[which[g0 + i]];
-          WorkLane *lane = lanes[i];
-          const size_t C = wav.n_channels;
-          const size_t n = (count + 5) * Params::frame_size * C;                     // in values
-          const size_t len = wav.n_values();                                          // < n for a short clip
-          const size_t pad_start = n + (n - len), total = pad_start + len + n;       // data + padding cover one long block
-          // the padded clips of a group live side by side in ONE buffer (every slice has 3 n values): the searches run
-          // per clip on the lanes, the block decode of the whole group is one batch (below)
-          if (i == 0)
-            if (int rc = lanes[0]->ws_clip.reserve (lanes.size() * total * sizeof (float)))
-              return rc;
-          float *ext = lanes[0]->ws_clip.as<float>() + i * total;
-          AWM_HIP_CHECK (hipMemsetAsync (ext, 0, pad_start * sizeof (float), lane->stream));
-          AWM_HIP_CHECK (hipMemcpyAsync (ext + pad_start, wav.data, len * sizeof (float), hipMemcpyDeviceToDevice, lane->stream));
-          AWM_HIP_CHECK (hipMemsetAsync (ext + pad_start + len, 0, n * sizeof (float), lane->stream));
-          padded[i].data = ext;
-          padded[i].n_frames = total / C;
-          padded[i].n_channels = wav.n_channels;
-          padded[i].sample_rate = wav.sample_rate;
+          desc[i] = { wav.data, (long long) wav.n_values(), (long long) (n + (n - wav.n_values())) };
         }
+      auto *d_desc = lane->ws_group.as<awmk::ClipSrc>();
+      auto *d_range = reinterpret_cast<long long *> (lane->ws_group.as<char>() + desc_bytes);
+      AWM_HIP_CHECK (hipMemcpyAsync (d_desc, desc, desc_bytes, hipMemcpyHostToDevice, st));
+      AWM_HIP_CHECK (awmk::launch_clip_pad (st, d_desc, int (gn), lane->ws_clip.as<float>(), (long long) slice_values, d_range));
+      DeviceWav group;
+      group.data = lane->ws_clip.as<float>();
+      group.n_frames = gn * slice_frames;
+      group.n_channels = C;
+      group.sample_rate = clips[which[g0]].sample_rate;
+      std::vector<ResultSet *> ptrs;
+      for (auto& cs : chunk_sets)
+        ptrs.push_back (&cs);
       for (const Key& key : key_list)
         {
           KeyTables *kt = ctx->get_key_tables (key);
           if (!kt)
             return AWM_ERR_HIP;
-          std::vector<SyncFinder> finders;
-          std::vector<SyncFinder::SearchJob> jobs (gn);
-          for (size_t i = 0; i < gn; i++)
-            finders.emplace_back (ctx, lanes[i]);
-          for (size_t i = 0; i < gn; i++)
-            {
-              // only the copied clip can hold non-zero values: the silence scan skips the padding
-              const DeviceWav& wav = clips[which[g0 + i]];
-              const size_t n = (count + 5) * Params::frame_size * wav.n_channels, len = wav.n_values();
-              if (int rc = finders[i].prepare_launch (padded[i], SyncFinder::Mode::CLIP, n + (n - len), n + (n - len) + len))
-                return rc;
-            }
-          for (size_t i = 0; i < gn; i++)
-            {
-              if (int rc = finders[i].prepare_finish())
-                return rc;
-              if (int rc = finders[i].approx_launch (key, padded[i], SyncFinder::Mode::CLIP, jobs[i], /* prepared */ true))
-                return rc;
-            }
-          for (size_t i = 0; i < gn; i++)
-            if (int rc = finders[i].select_refine (jobs[i]))
-              return rc;
-          // soft bits and Viterbi decodes of ALL clips of the group in one batch on the first lane: one launch per step
-          // instead of one per clip (and 8 x gn decodes in one Viterbi launch instead of gn launches of 8)
+          SyncFinder finder (ctx, lane);
+          SyncFinder::GroupJob gj;
+          std::vector<std::vector<SyncFinder::Score>> scores;
+          if (int rc = finder.group_approx_launch (kt, group, int (gn), d_range, gj)) return rc;
+          if (int rc = finder.group_select_refine (gj)) return rc;
+          if (int rc = finder.group_finish (gj, scores)) return rc;
+          // soft bits and Viterbi decodes of ALL clips of the group in one batch
           std::vector<size_t> index;
           struct Cand { size_t clip; SyncFinder::Score score; };
           std::vector<Cand> cands;
-          const size_t slice_frames = padded[0].n_frames;
           for (size_t i = 0; i < gn; i++)
             {
-              std::vector<SyncFinder::Score> sync_scores;
-              if (int rc = finders[i].search_finish (jobs[i], sync_scores))
-                return rc;
-              for (const auto& sc : sync_scores)
+              if (gj.fallback[i])
+                {
+                  // the rare sequential selection: this clip's slice on its own (same result set, same order of keys)
+                  DeviceWav slice = group;
+                  slice.data = group.data + i * slice_values;
+                  slice.n_frames = slice_frames;
+                  if (int rc = clip_run_padded (ctx, lane, { key }, slice, chunk_sets[g0 + i], 0.0, 1))
+                    return rc;
+                  continue;
+                }
+              for (const auto& sc : scores[i])
                 {
                   // both halves of the long block must lie inside the clip's own slice (fft_range bound, reference wmcommon.cc:128-130)
                   if (sc.index + 2 * count * Params::frame_size > slice_frames)
@@ -1051,29 +1040,27 @@ clip_batch_staged (awm_ctx *ctx, const std::vector<Key>& key_list, const std::ve
                   cands.push_back ({ i, sc });
                 }
             }
-          DeviceWav group = padded[0];
-          group.n_frames = gn * slice_frames;
           std::vector<int> slot_of;
           std::vector<char> ok;
-          if (int rc = block_soft_bits_dev (ctx, lanes[0], kt, group, index, slot_of, ok))
+          if (int rc = block_soft_bits_dev (ctx, lane, kt, group, index, slot_of, ok))
             return rc;
           DecodeJob decode;
           for (size_t k = 0; k < cands.size(); k++)
             {
+              if (!ok[2 * k] || !ok[2 * k + 1])
+                continue;
               const int first_half = cands[k].score.block_type == ConvBlockType::a ? 0 : 1;
               SyncFinder::Score nopad = cands[k].score;
               nopad.index = 0;                                                     // time offset of the START position is 0
               decode.pending.push_back ({ ConvBlockType::ab, 1, { { slot_of[2 * k], first_half }, { slot_of[2 * k + 1], 1 - first_half } }, 0, 0,
                                           0.0, nopad, ResultSet::Type::CLIP, g0 + cands[k].clip });
             }
-          if (int rc = decode_launch (ctx, lanes[0], kt, decode))
+          if (int rc = decode_launch (ctx, lane, kt, decode))
             return rc;
-          std::vector<ResultSet *> ptrs;
-          for (auto& cs : chunk_sets)
-            ptrs.push_back (&cs);
-          if (int rc = decode_finish (lanes[0], key, decode, ptrs, 1))
+          if (int rc = decode_finish (lane, key, decode, ptrs, 1))
             return rc;
         }
+      g0 += gn;
     }
   drain.ok = true;
   for (size_t j = 0; j < which.size(); j++)
@@ -1116,58 +1103,47 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
       if (!ctx->ev_sync)
         AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
       AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));                   // the clips may still be in flight there
-      for (int i = 1; i < int (std::min<size_t> (staged.size(), MAX_LANES)); i++)
+      const int n_staged_threads = std::max (1, std::min<int> (STAGED_THREADS, int ((staged.size() + CLIP_GROUP - 1) / CLIP_GROUP)));
+      for (const Key& key : key_list)
+        if (!ctx->get_key_tables (key))                 // built once, before the workers start
+          return AWM_ERR_HIP;
+      std::vector<WorkLane *> staged_lanes;
+      for (int t = 0; t < n_staged_threads; t++)
         {
-          WorkLane *l = ctx->lane (i);
-          if (l)
-            AWM_HIP_CHECK (hipStreamWaitEvent (l->stream, ctx->ev_sync, 0));
-        }
-      // ~45 launches and copies per clip.  A second host thread staging its own share of the clips over its own share of
-      // the lanes helps a little (0.69 -> 0.64 ms per clip), more threads hardly (0.61): the limit is the rate at which one
-      // process gets dispatches and copies through the runtime (~75 000 per second), not the issuing thread
-      const int want = STAGED_THREADS;
-      const int n_staged_threads = std::max (1, std::min<int> ({ want, MAX_LANES / 2, int ((staged.size() + 3) / 4) }));
-      if (n_staged_threads == 1)
-        {
-          if (int rc = clip_batch_staged (ctx, key_list, clips, staged, result_sets))
-            return rc;
-        }
-      else
-        {
-          for (const Key& key : key_list)
-            if (!ctx->get_key_tables (key))               // built once, before the workers start
+          WorkLane *l = ctx->lane (t);
+          if (!l)
+            {
+              set_error ("cannot create a work lane (stream)");
               return AWM_ERR_HIP;
-          const int lanes_per_thread = MAX_LANES / n_staged_threads;
-          for (int i = 0; i < lanes_per_thread * n_staged_threads; i++)
-            if (!ctx->lane (i))
-              {
-                set_error ("cannot create a work lane (stream)");
-                return AWM_ERR_HIP;
-              }
-          std::vector<std::vector<size_t>> share (n_staged_threads);
-          for (size_t i = 0; i < staged.size(); i++)
-            share[i * n_staged_threads / staged.size()].push_back (staged[i]);
-          std::vector<int> rcs (n_staged_threads, 0);
-          std::vector<std::string> messages (n_staged_threads);          // the error text is per thread
-          std::vector<std::thread> workers;
-          for (int t = 1; t < n_staged_threads; t++)
-            workers.emplace_back ([&, t] {
-              (void) hipSetDevice (ctx->device);
-              rcs[t] = clip_batch_staged (ctx, key_list, clips, share[t], result_sets, t * lanes_per_thread, lanes_per_thread);
-              if (rcs[t])
-                messages[t] = last_error();
-            });
-          rcs[0] = clip_batch_staged (ctx, key_list, clips, share[0], result_sets, 0, lanes_per_thread);
-          for (auto& w : workers)
-            w.join();
-          for (int t = 0; t < n_staged_threads; t++)
-            if (rcs[t])
-              {
-                if (t)
-                  set_error (messages[t]);
-                return rcs[t];
-              }
+            }
+          if (t)
+            AWM_HIP_CHECK (hipStreamWaitEvent (l->stream, ctx->ev_sync, 0));
+          staged_lanes.push_back (l);
         }
+      // whole groups per thread, dealt round robin
+      std::vector<std::vector<size_t>> share (n_staged_threads);
+      for (size_t i = 0; i < staged.size(); i++)
+        share[(i / CLIP_GROUP) % n_staged_threads].push_back (staged[i]);
+      std::vector<int> rcs (n_staged_threads, 0);
+      std::vector<std::string> messages (n_staged_threads);          // the error text is per thread
+      std::vector<std::thread> workers;
+      for (int t = 1; t < n_staged_threads; t++)
+        workers.emplace_back ([&, t] {
+          (void) hipSetDevice (ctx->device);
+          rcs[t] = clip_batch_staged (ctx, staged_lanes[t], key_list, clips, share[t], result_sets);
+          if (rcs[t])
+            messages[t] = last_error();
+        });
+      rcs[0] = clip_batch_staged (ctx, staged_lanes[0], key_list, clips, share[0], result_sets);
+      for (auto& w : workers)
+        w.join();
+      for (int t = 0; t < n_staged_threads; t++)
+        if (rcs[t])
+          {
+            if (t)
+              set_error (messages[t]);
+            return rcs[t];
+          }
     }
   if (threaded.empty())
     return 0;
