@@ -112,6 +112,9 @@ struct SyncDbArgs
   const long long     *stream_range = nullptr;
   const int           *range_index = nullptr;
   int                  range_div = 1;
+  // 1: a frame in the silence outside the range is not skipped but gets the dB values of a transformed frame of zeros (exactly
+  // what the transform would deliver: -96 per band and channel) -- the block decoder's fft_range knows no skipping
+  int                  silent_frames_are_zero = 0;
 };
 hipError_t launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a);
 /* K4s: same output as K4 for streams whose frames advance by 8 samples (search_refine): instead of one FFT per fine
@@ -138,6 +141,8 @@ struct SyncScanArgs
 {
   const float *db;
   const char  *have;            // nullptr: every frame present
+  int          have_is_run = 0; // 1: the present frames of every plane form one run and absent frames hold +0 in db (what K4's silence rule
+                                // produces): lets launch_sync_scan_window use the streaming kernel in CLIP mode too
   long long    plane_stride;    // between blockIdx.y planes (shifts / candidates)
   long long    have_plane_stride;
   long long    row_stride, band_stride, have_row_stride;

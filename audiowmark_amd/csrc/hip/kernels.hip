@@ -929,7 +929,8 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
       const long long idx = base + (tile0 + ff) * a.hop;
       // skip rules of sync_fft (reference syncfinder.cc:578-590)
       const long long f_first = idx * C, f_last = (idx + 1024) * C;
-      const bool skip = (f_last < sil_first) || (f_first > sil_last) || idx < 0 || idx + 1024 > a.n_frames;
+      const bool outside = idx < 0 || idx + 1024 > a.n_frames;
+      const bool skip = (f_last < sil_first) || (f_first > sil_last) || outside;
       float acc0 = 0.f, acc1 = 0.f;                      // bins 20 + lane, 84 + lane
       float split0 = 0.f, split1 = 0.f;                  // SPLIT: the same for channel 0 (acc0 / acc1 then hold channel 1)
       if (!skip)
@@ -993,6 +994,23 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
                     }
                   wave_sync();
                 }
+            }
+        }
+      else if (a.silent_frames_are_zero && !outside)
+        {
+          // every sample of the frame is zero: the spectrum is exactly zero, every band -96 dB (db_from_complex)
+          const float zero_db = db_from_complex (make_float2 (0.f, 0.f));
+          const int n_ch = CV == 2 ? 2 : (a.per_channel ? 1 : C);
+          for (int c = 0; c < n_ch; c++)
+            {
+              if (SPLIT && c == 1)
+                {
+                  split0 = acc0;
+                  split1 = acc1;
+                  acc0 = acc1 = 0.f;
+                }
+              acc0 = __fadd_rn (acc0, zero_db);
+              acc1 = __fadd_rn (acc1, zero_db);
             }
         }
       if (SPLIT)
@@ -1892,26 +1910,35 @@ launch_nonzero_range (hipStream_t st, const float *data, long long n_values, uns
   return hipGetLastError();
 }
 
-/* kernels.hh launch_clip_pad: grid (parts, clips) */
+/* kernels.hh launch_clip_pad: grid (parts, clips); slice_values % 4 == 0, 16-byte stores */
 __global__ void __launch_bounds__ (256)
 clip_pad_kernel (const ClipSrc *src, float *dst, long long slice_values, unsigned long long *range)
 {
   const ClipSrc c = src[blockIdx.y];
-  float *out = dst + (long long) blockIdx.y * slice_values;
+  float4 *out = reinterpret_cast<float4 *> (dst + (long long) blockIdx.y * slice_values);
   const long long slice0 = (long long) blockIdx.y * slice_values;
   const long long stride = (long long) gridDim.x * blockDim.x;
   unsigned long long first = ~0ULL, last = 0;
-  for (long long i = (long long) blockIdx.x * blockDim.x + threadIdx.x; i < slice_values; i += stride)
+  for (long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x; q < slice_values / 4; q += stride)
     {
-      const long long k = i - c.pad_start;
-      const float v = (k >= 0 && k < c.n_values) ? c.data[k] : 0.f;
-      out[i] = v;
-      if (v != 0.f)
+      const long long k = 4 * q - c.pad_start;              // source index of the quad's first value
+      float v[4] = { 0.f, 0.f, 0.f, 0.f };
+      if (k > -4 && k < c.n_values)
         {
-          const unsigned long long at = (unsigned long long) (slice0 + i);
-          first = at < first ? at : first;
-          last = at + 1 > last ? at + 1 : last;
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (k + j >= 0 && k + j < c.n_values)
+              v[j] = c.data[k + j];
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+            if (v[j] != 0.f)
+              {
+                const unsigned long long at = (unsigned long long) (slice0 + 4 * q + j);
+                first = at < first ? at : first;
+                last = at + 1 > last ? at + 1 : last;
+              }
         }
+      out[q] = make_float4 (v[0], v[1], v[2], v[3]);
     }
   for (int o = 32; o > 0; o >>= 1)
     {
@@ -1957,6 +1984,8 @@ launch_clip_pad (hipStream_t st, const ClipSrc *src, int n_clips, float *dst, lo
 {
   if (n_clips <= 0 || slice_values <= 0)
     return hipSuccess;
+  if (slice_values % 4 || (reinterpret_cast<uintptr_t> (dst) & 15))
+    return hipErrorInvalidValue;
   auto *r = reinterpret_cast<unsigned long long *> (range);
   hipLaunchKernelGGL (clip_range_init_kernel, dim3 (unsigned ((n_clips + 255) / 256)), dim3 (256), 0, st, r, n_clips);
   hipLaunchKernelGGL (clip_pad_kernel, dim3 (128, unsigned (n_clips)), dim3 (256), 0, st, src, dst, slice_values, r);

@@ -86,12 +86,18 @@ static_assert (PIECES * INFLIGHT < 64, "vmcnt counts 63 outstanding operations")
 
 }  // namespace
 
-__global__ void __launch_bounds__ (832)
+/* HAVE (CLIP mode): the frames of the plane that were transformed form ONE run [F0, F1) (the rest is the leading / trailing
+ * silence of a padded clip, syncfinder.cc:155-169, 578-590; their matrix entries are +0).  A sync frame none of the tile's
+ * candidates has inside the run is skipped by its chain, chunks no live sync frame can touch are not loaded; inside a live
+ * sync frame the candidates outside the run add +0, which leaves their sums as they are.  The frame counts that weight the
+ * bits (frame_bit_count, syncfinder.cc:147-152) are counted per candidate at the end. */
+template<bool HAVE> __global__ void __launch_bounds__ (832)
 sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
 {
   __shared__ __attribute__ ((aligned (16))) float s_win[SLOTS * SLOT_FLOATS];
   __shared__ __attribute__ ((aligned (16))) int s_progress[16];   // per chain: frame of its next sync frame (first frame it still needs); [12..15] = "done"
   __shared__ int s_loaded;                                 // frames [.., s_loaded) have landed in the ring
+  __shared__ int s_run[2];                                 // HAVE: [F0, F1)
   const int lane = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane (threadIdx.y);
   const int tid = threadIdx.y * 64 + threadIdx.x;
@@ -112,7 +118,42 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
     s_progress[tid] = tid < NCHAIN ? 0 : 0x7fffffff;
   if (tid == 16)
     s_loaded = 0;
+  if (tid == 17)
+    {
+      s_run[0] = 0x7fffffff;
+      s_run[1] = 0;
+    }
   __syncthreads();
+  int run0 = 0, run1 = 0x7fffffff;                         // the run, relative to the tile's first frame
+  if (HAVE)
+    {
+      const char *have = a.have + plane * a.have_plane_stride;
+      const int n_have = int (a.n_lanes) + total_frames;   // frames any candidate of the plane can touch
+      int lo = 0x7fffffff, hi = 0;
+      for (int f = tid; f < n_have; f += 832)
+        if (have[f])
+          {
+            lo = min (lo, f);
+            hi = max (hi, f + 1);
+          }
+      for (int o = 32; o > 0; o >>= 1)
+        {
+          lo = min (lo, __shfl_xor (lo, o));
+          hi = max (hi, __shfl_xor (hi, o));
+        }
+      if (lane == 0 && hi > 0)
+        {
+          atomicMin (&s_run[0], lo);
+          atomicMax (&s_run[1], hi);
+        }
+      __syncthreads();
+      run0 = __builtin_amdgcn_readfirstlane (s_run[0]) - int (sf0);
+      run1 = __builtin_amdgcn_readfirstlane (s_run[1]) - int (sf0);
+      if (__builtin_amdgcn_readfirstlane (s_run[1]) == 0)
+        run0 = run1 = 0;                                    // nothing transformed at all: no sync frame is live
+    }
+  // a sync frame at (tile relative) frame fr is live if one of the tile's 256 candidates has it inside the run
+  auto live = [&] (int fr) { return !HAVE || (fr + 255 >= run0 && fr < run1); };
 
   float acc[4] = { 0.f, 0.f, 0.f, 0.f };
   if (wv == NCHAIN)
@@ -160,19 +201,28 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
             __builtin_amdgcn_s_sleep (1);
           }
       };
-      for (int c = 0; c < n_chunks; c++)
+      // HAVE: live sync frames read the frames [run0 - 258, run1 + 255] of the tile at most: only these chunks are loaded
+      int c_lo = 0, c_hi = n_chunks;
+      if (HAVE)
         {
-          if (c >= INFLIGHT)
+          c_lo = min (n_chunks, max (0, (run0 - 258) >> 6));
+          c_hi = run1 > run0 ? min (n_chunks, max (c_lo, ((run1 + 255) >> 6) + 1)) : c_lo;
+          if (c_lo > 0)
+            publish (c_lo - 1);                            // nothing below is ever waited for by a live sync frame
+        }
+      for (int c = c_lo; c < c_hi; c++)
+        {
+          if (c >= c_lo + INFLIGHT)
             {
               asm volatile ("s_waitcnt vmcnt(%0)" :: "n" (PIECES * (INFLIGHT - 1)) : "memory");   // vmcnt counts the pieces in issue order:
               publish (c - INFLIGHT);                                                             // all but the youngest chunk(s) have landed
             }
-          if (c >= SLOTS)
+          if (c >= c_lo + SLOTS)
             wait_room (c);
           issue (c);
         }
       asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
-      publish (n_chunks - 1);
+      publish (HAVE ? 0xffffff : n_chunks - 1);       // (HAVE: whatever a chain may still ask for)
     }
   else
     {
@@ -187,6 +237,8 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
           w[i] = tr[i];                                    // no arithmetic here: the scalar load stays in flight until the row starts
       };
       auto row = [&] (const unsigned (&w)[8], int fr) {
+        if (!live (fr))
+          return;
         while (loaded < fr + 256)
           {
             loaded = __hip_atomic_load (&s_loaded, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -225,19 +277,43 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
           __hip_atomic_store (&s_progress[wv], next_frame, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       };
       auto next_frame = [] (const unsigned (&w)[8]) { const int f = int (w[7] >> 16); return f == 0xffff ? 0x7fffffff : f; };
-      int fr = R > 0 ? ((const_int_ptr) a.table.packed)[(size_t) (wv >> 1) * R * 64 + 60] : 0x7fffffff;
-      if (R > 0)
-        load_row (rowdesc[0], 0);
-      for (int r = 0; r < R; r += 2)
+      // rows [r_lo, r_hi) of this chain: all of them, or (HAVE) the live ones -- the frames of a bit's rows ascend.  (Walking the
+      // silent rows one by one costs a scalar load latency each with nothing to hide it behind: 3 x the time of the live ones.)
+      const_int_ptr frames = ((const_int_ptr) a.table.packed) + (size_t) (wv >> 1) * R * 64 + 60;
+      int r_lo = 0, r_hi = R;
+      if (HAVE)
         {
-          if (r + 1 < R)
+          auto rows_below = [&] (int x) {
+            int lo = 0, hi = R;
+            while (lo < hi)
+              {
+                const int mid = (lo + hi) >> 1;
+                if (frames[(size_t) mid * 64] < x)
+                  lo = mid + 1;
+                else
+                  hi = mid;
+              }
+            return lo;
+          };
+          r_lo = rows_below (run0 - 255);
+          r_hi = run1 > run0 ? rows_below (run1) : r_lo;
+        }
+      int fr = r_lo < r_hi ? frames[(size_t) r_lo * 64] : 0x7fffffff;
+      if (r_lo < r_hi)
+        {
+          done_with (fr);
+          load_row (rowdesc[0], r_lo);
+        }
+      for (int r = r_lo; r < r_hi; r += 2)
+        {
+          if (r + 1 < r_hi)
             load_row (rowdesc[1], r + 1);
           row (rowdesc[0], fr);
           fr = next_frame (rowdesc[0]);
           done_with (fr);
-          if (r + 1 < R)
+          if (r + 1 < r_hi)
             {
-              if (r + 2 < R)
+              if (r + 2 < r_hi)
                 load_row (rowdesc[0], r + 2);
               row (rowdesc[1], fr);
               fr = next_frame (rowdesc[1]);
@@ -249,14 +325,38 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
   __syncthreads();                                         // ring is dead: chain sums -> s_sum[chain][candidate of the tile]
 
   float (*s_sum)[256] = reinterpret_cast<float (*)[256]> (s_win);
+  int *s_frames = reinterpret_cast<int *> (s_win + NCHAIN * 256);      // HAVE: frame of every row, [bit][R]
   if (wv < NCHAIN)
     *reinterpret_cast<float4 *> (&s_sum[wv][4 * lane]) = make_float4 (acc[0], acc[1], acc[2], acc[3]);
+  if (HAVE)
+    for (int i = tid; i < 6 * R; i += 832)
+      s_frames[i] = a.table.packed[(size_t) i * 64 + 60];
   __syncthreads();
   if (tid < QUAD_TILE && sf0 + tid < a.n_lanes)
     {
       double q = 0;
+      int total = 0;
       for (int b = 0; b < 6; b++)
         {
+          int n_b = R;                                    // frame_bit_count: sync frames of the bit inside the run
+          if (HAVE)
+            {
+              // the frames of a bit's rows ascend: rows with frame < x, twice
+              const int *frames = s_frames + b * R;
+              auto rows_below = [&] (int x) {
+                int lo = 0, hi = R;
+                while (lo < hi)
+                  {
+                    const int mid = (lo + hi) >> 1;
+                    if (frames[mid] < x)
+                      lo = mid + 1;
+                    else
+                      hi = mid;
+                  }
+                return lo;
+              };
+              n_b = rows_below (run1 - tid) - rows_below (run0 - tid);
+            }
           const float um = s_sum[2 * b][tid], dm = s_sum[2 * b + 1][tid];
           // SyncFinder::bit_quality (reference syncfinder.cc:94-114): float division and subtraction
           float raw;
@@ -267,10 +367,11 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
           else
             raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
           const double rb = (b & 1) ? double (raw) : -double (raw);
-          q += rb * R;                                    // frame_bit_count == rows of the bit: no frame is skipped here
+          q += rb * n_b;
+          total += n_b;
         }
-      if (R)
-        q /= 6 * R;
+      if (total)
+        q /= total;
       q = q / a.min_delta / 2.9;
       a.quality[plane * a.q_stride + sf0 + tid] = q;
     }
@@ -302,10 +403,14 @@ launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames
     return hipSuccess;
   if (a.row_stride != 1 || a.n_planes > 65535 || (a.band_stride & 63) || a.lane_count)
     return hipErrorInvalidValue;
-  if (a.have || !a.table.chains || total_frames >= 0xffff)
-    return launch_sync_scan (st, a);                      // skipped (silent) frames: the generic kernel handles `have`
+  if ((a.have && !a.have_is_run) || !a.table.chains || total_frames >= 0xffff || a.n_lanes + total_frames > 0x1000000 || a.table.rows_per_bit > 4096)
+    return launch_sync_scan (st, a);                      // arbitrary skipped frames: the generic kernel handles any `have`
   const long long px = ((a.n_lanes + QUAD_TILE - 1) / QUAD_TILE + 7) / 8;
-  hipLaunchKernelGGL (sync_scan_stream_kernel, dim3 ((unsigned) (px * 8), (unsigned) a.n_planes), dim3 (64, NCHAIN + 1), 0, st, a, total_frames);
+  const dim3 grid ((unsigned) (px * 8), (unsigned) a.n_planes), block (64, NCHAIN + 1);
+  if (a.have)
+    hipLaunchKernelGGL (sync_scan_stream_kernel<true>, grid, block, 0, st, a, total_frames);
+  else
+    hipLaunchKernelGGL (sync_scan_stream_kernel<false>, grid, block, 0, st, a, total_frames);
   return hipGetLastError();
 }
 

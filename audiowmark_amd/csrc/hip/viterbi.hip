@@ -18,11 +18,25 @@
 // (K = 5: 29 rounds of 10.6 us for eight AB decodes alone on the GPU, 3 600 straight-line instructions per lane; K = 4: 36
 // rounds of about half that with twice the lanes -- 1.33 -> 1.25 ms per step of the 60 min bench.)
 //
+// One chain instead of two (rounds after step 15, finite input).  The code bits of a transition depend on the successor state
+// only, so both predecessors add the SAME terms, and float addition is monotone: the chain that starts from min (old0, old1)
+// ends at the new metric, whichever predecessor wins.  The decision is old1 < old0 unless rounding merges the two chains (the
+// low predecessor then keeps the tie); chains that start further apart than 16 ulp of the largest possible sum cannot merge, a
+// lane that is closer makes its wave repeat that step's decisions with both chains (a few percent of the wave-steps).  The
+// additions are v_pk_add_f32 with op_sel picking the halves of ONE register pair { cost if the bit is as expected, cost if
+// flipped } per generator: 768 -> 384 packed additions per lane and round for an AB block, 256 -> 82 registers.  Measured: no
+// change for the 60 min bench (36 dependent launches of ~11 us each: launch bound), 0.273 -> 0.255 ms per clip in the clip batch
+// (320 AB decodes per launch: throughput bound).  Tried and dropped: K = 5 with the lighter step (29 rounds, 125 registers:
+// same time), one workgroup per block with the metrics in LDS (no launches per round, but 16 waves per decode on one compute
+// unit: 1 ms per AB block, 2.5 x slower for both workloads).
+//
 // Survivors: lane L's decision words of a round describe the whole K-step history of the 2^K states it produced, so the
 // trace back needs ONE 16-byte load per round (36 dependent loads instead of 143).
 //
 // Bit-exactness: sums and ties exactly as above; decoded bits and the error value are bit-identical to the oracle.
 #include "kernels.hh"
+#include <type_traits>
+#include <utility>
 
 namespace awmk {
 
@@ -41,6 +55,24 @@ __device__ constexpr unsigned v_parity (unsigned v) { v ^= v >> 16; v ^= v >> 8;
 
 typedef float v2f __attribute__ ((ext_vector_type (2)));
 
+/* d + { pair[a], pair[b] } in one v_pk_add_f32: the operand halves are picked by op_sel / op_sel_hi, so ONE register pair
+ * { cost if the code bit is as the lane expects, cost if it is flipped } per generator serves every successor state (the
+ * compiler builds a register pair per combination instead: 4 x 12 pairs for an AB block, and spills) */
+__device__ __forceinline__ v2f
+pk_add_sel (v2f d, v2f pair, bool a, bool b)
+{
+  v2f r;
+  if (!a && !b)
+    asm ("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v" (r) : "v" (d), "v" (pair));
+  else if (a && !b)
+    asm ("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0]" : "=v" (r) : "v" (d), "v" (pair));
+  else if (!a && b)
+    asm ("v_pk_add_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,1]" : "=v" (r) : "v" (d), "v" (pair));
+  else
+    asm ("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v" (r) : "v" (d), "v" (pair));
+  return r;
+}
+
 /* workspace of one block: [metrics A][metrics B][decision words of all rounds] */
 constexpr size_t V_METRIC_BYTES = V_STATES * sizeof (float);
 
@@ -54,23 +86,27 @@ struct RoundPlan           // host side description of one launch
 /* words per lane and round in the decision area (a power of two, so that a lane's words are one aligned load) */
 constexpr int dec_words (int k) { return k <= 4 ? 4 : 8; }
 
-/* K trellis steps of the 2^K states { L + j 2^(15-K) } -> the 2^K states { L 2^K + loc } */
+template<class F, int... Is> __device__ __forceinline__ void
+for_each_step (F& f, std::integer_sequence<int, Is...>)
+{
+  (f (std::integral_constant<int, Is + 1>()), ...);
+}
+
+/* K trellis steps in registers: m = metrics of the 2^K states { L + j 2^(15-K) } on entry, of the 2^K states { L 2^K + loc } on
+ * return; words[i] = decisions of step i (bit loc: the predecessor with the top state bit set won) */
 template<int BT, int K, bool PLAIN> __device__ __forceinline__ void
-viterbi_round (const float *coded, int step0, const float *m_in, float *m_out, unsigned int *dec, int L)
+viterbi_steps (const float *coded, int step0, float (&m)[1 << K], unsigned int (&words)[K], int L)
 {
   constexpr int rate = BT == 2 ? 12 : 6;
   constexpr int NS = 1 << K;                               // states per lane
-  constexpr int GROUPS = V_STATES >> K;                    // lanes per block, stride of a lane's states on input
-  float m[NS];
-#pragma unroll
-  for (int j = 0; j < NS; j++)
-    m[j] = m_in[L + j * GROUPS];
-  unsigned int words[K];
-#pragma unroll
-  for (int i = 1; i <= K; i++)
+  // one trellis step; the step number within the round is a compile time constant (the loop form is not unrolled by the compiler
+  // once the additions are inline assembly, and everything below depends on it being constant)
+  auto step = [&] (auto step_number)
     {
+      constexpr int i = decltype (step_number)::value;
       // squared distances of this step's code bits to 0 and 1 (wave uniform), and which of them a lane's states take:
       // expected bit = parity ((L << i) & G)  ^  compile time part
+      v2f cost[rate];                                          // .x: code bit as the lane part predicts, .y: flipped
       float cost_same[rate], cost_flip[rate];
 #pragma unroll
       for (int g = 0; g < rate; g++)
@@ -81,57 +117,108 @@ viterbi_round (const float *coded, int step0, const float *m_in, float *m_out, u
           const bool lp = __popc ((unsigned (L) << i) & v_gen<BT> (g)) & 1;
           cost_same[g] = lp ? e1 : e0;
           cost_flip[g] = lp ? e0 : e1;
+          cost[g] = (v2f) { cost_same[g], cost_flip[g] };
         }
       float n[NS];
       unsigned int word = 0;
-#pragma unroll
-      for (int jp = 0; jp < NS / 2; jp++)
+      // expected code bits of the successors loc = 2 jp + b: the state  (L << i) | (loc >> i) << (15 - K + i) | (loc & (2^i - 1)),
+      // lane part above, compile time part here
+      constexpr int hi_shift = V_ORDER - K;
+      auto flips = [] (int loc, int ii, int g) {
+        const unsigned st = (unsigned (loc >> ii) << (hi_shift + ii)) | unsigned (loc & ((1 << ii) - 1));
+        return bool (v_parity (st & v_gen<BT> (g)));
+      };
+      if (PLAIN)
         {
-          const float old0 = m[jp], old1 = m[jp + NS / 2];                  // predecessors without / with the top state bit
-          // running sums for predecessors {low, high}: .x / .y; one pair per successor bit; term by term like the reference
-          v2f d0 = { old0, old1 }, d1 = d0;
+          // Both predecessors of a successor add the SAME terms (the code bits depend on the successor state only), and a float
+          // addition is monotone: the chain that starts from the smaller metric ends at the smaller or equal sum, so the new metric
+          // is the chain of min (old0, old1) -- one chain instead of two, the two successors of a pair packed into one register
+          // pair.  The decision "high predecessor wins" is old1 < old0 unless rounding merges the two chains (then the low one
+          // keeps the tie, convcode.cc:168-185).  Chains that start further apart than 16 ulp of the largest possible sum cannot
+          // merge (each of the <= 12 additions moves them together by at most one ulp); the rare lane that is closer makes its
+          // wave repeat the step's decisions with both chains.
+          float sum_max = 0.f;
 #pragma unroll
           for (int g = 0; g < rate; g++)
+            sum_max += fmaxf (cost_same[g], cost_flip[g]);
+          bool risky = false;
+#pragma unroll
+          for (int jp = 0; jp < NS / 2; jp++)
             {
-              // successor loc = 2 jp + b is the state  (L << i) | (loc >> i) << (15 - K + i) | (loc & (2^i - 1))
-              constexpr int hi_shift = V_ORDER - K;
-              const unsigned s0 = (unsigned ((2 * jp) >> i) << (hi_shift + i)) | unsigned ((2 * jp) & ((1 << i) - 1));
-              const unsigned s1 = (unsigned ((2 * jp + 1) >> i) << (hi_shift + i)) | unsigned ((2 * jp + 1) & ((1 << i) - 1));
-              const bool c0 = v_parity (s0 & v_gen<BT> (g));
-              const bool c1 = v_parity (s1 & v_gen<BT> (g));
-              const float ea = c0 ? cost_flip[g] : cost_same[g];
-              const float eb = c1 ? cost_flip[g] : cost_same[g];
-              d0 += (v2f) { ea, ea };
-              d1 += (v2f) { eb, eb };
+              const float old0 = m[jp], old1 = m[jp + NS / 2];              // predecessors without / with the top state bit
+              const bool high = old1 < old0;
+              const float lo = high ? old1 : old0, hi = high ? old0 : old1;
+              v2f d = { lo, lo };                                            // .x: successor 2 jp, .y: successor 2 jp + 1
+#pragma unroll
+              for (int g = 0; g < rate; g++)
+                d = pk_add_sel (d, cost[g], flips (2 * jp, i, g), flips (2 * jp + 1, i, g));
+              n[2 * jp] = d.x;
+              n[2 * jp + 1] = d.y;
+              risky = risky || (high && !(__fsub_rn (hi, lo) > __fmul_rn (0x1p-19f, __fadd_rn (hi, sum_max))));
+              word |= high ? (3u << (2 * jp)) : 0u;
             }
-          unsigned c0, c1;
-          float best0, best1;
-          if (PLAIN)
+          if (__builtin_amdgcn_ballot_w64 (risky))
             {
-              // strict "<": the low predecessor is visited first by the reference and keeps ties
-              c0 = d0.y < d0.x;
-              c1 = d1.y < d1.x;
-              best0 = c0 ? d0.y : d0.x;
-              best1 = c1 ? d1.y : d1.x;
+              word = 0;
+#pragma unroll
+              for (int jp = 0; jp < NS / 2; jp++)
+                {
+                  const float old0 = m[jp], old1 = m[jp + NS / 2];
+                  v2f d0 = { old0, old1 }, d1 = d0;
+#pragma unroll
+                  for (int g = 0; g < rate; g++)
+                    {
+                      d0 = pk_add_sel (d0, cost[g], flips (2 * jp, i, g), flips (2 * jp, i, g));
+                      d1 = pk_add_sel (d1, cost[g], flips (2 * jp + 1, i, g), flips (2 * jp + 1, i, g));
+                    }
+                  // strict "<": the low predecessor is visited first by the reference and keeps ties
+                  word |= (unsigned (d0.y < d0.x) << (2 * jp)) | (unsigned (d1.y < d1.x) << (2 * jp + 1));
+                }
             }
-          else
+        }
+      else
+        {
+#pragma unroll
+          for (int jp = 0; jp < NS / 2; jp++)
             {
+              const float old0 = m[jp], old1 = m[jp + NS / 2];              // predecessors without / with the top state bit
+              // running sums for predecessors {low, high}: .x / .y; one pair per successor bit; term by term like the reference
+              v2f d0 = { old0, old1 }, d1 = d0;
+#pragma unroll
+              for (int g = 0; g < rate; g++)
+                {
+                  d0 = pk_add_sel (d0, cost[g], flips (2 * jp, i, g), flips (2 * jp, i, g));
+                  d1 = pk_add_sel (d1, cost[g], flips (2 * jp + 1, i, g), flips (2 * jp + 1, i, g));
+                }
               // states that cannot be reached from state 0 at step 0 carry -1 (also what a NaN metric turns into a skip)
               const bool r0 = old0 >= 0.f, r1 = old1 >= 0.f;
-              c0 = r0 ? (r1 && d0.y < d0.x) : (r1 ? 1u : 0u);
-              c1 = r0 ? (r1 && d1.y < d1.x) : (r1 ? 1u : 0u);
-              best0 = c0 ? d0.y : (r0 ? d0.x : -1.f);
-              best1 = c1 ? d1.y : (r0 ? d1.x : -1.f);
+              const unsigned c0 = r0 ? (r1 && d0.y < d0.x) : (r1 ? 1u : 0u);
+              const unsigned c1 = r0 ? (r1 && d1.y < d1.x) : (r1 ? 1u : 0u);
+              word |= (c0 << (2 * jp)) | (c1 << (2 * jp + 1));
+              n[2 * jp] = c0 ? d0.y : (r0 ? d0.x : -1.f);
+              n[2 * jp + 1] = c1 ? d1.y : (r0 ? d1.x : -1.f);
             }
-          word |= (c0 << (2 * jp)) | (c1 << (2 * jp + 1));
-          n[2 * jp] = best0;
-          n[2 * jp + 1] = best1;
         }
       words[i - 1] = word;
 #pragma unroll
       for (int j = 0; j < NS; j++)
         m[j] = n[j];
-    }
+    };
+  for_each_step (step, std::make_integer_sequence<int, K>());
+}
+
+/* a round through global memory: lane L of the block's 2^(15-K) */
+template<int BT, int K, bool PLAIN> __device__ __forceinline__ void
+viterbi_round (const float *coded, int step0, const float *m_in, float *m_out, unsigned int *dec, int L)
+{
+  constexpr int NS = 1 << K;
+  constexpr int GROUPS = V_STATES >> K;                    // lanes per block, stride of a lane's states on input
+  float m[NS];
+#pragma unroll
+  for (int j = 0; j < NS; j++)
+    m[j] = m_in[L + j * GROUPS];
+  unsigned int words[K];
+  viterbi_steps<BT, K, PLAIN> (coded, step0, m, words, L);
   float4 *out4 = reinterpret_cast<float4 *> (m_out + (size_t) L * NS);
 #pragma unroll
   for (int j = 0; j < NS / 4; j++)
@@ -310,16 +397,19 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
     }
   b.n_steps = int (n_steps);
   b.block_ws_bytes = viterbi_workspace_bytes (n_steps * 6, 6, 1);          // the layout does not depend on the rate
-  hipLaunchKernelGGL (viterbi_init_kernel, dim3 (V_STATES / 256, (unsigned) total), dim3 (256), 0, st, b);
   TracePlan tp {};
   tp.n_rounds = int (rounds.size());
+  for (size_t r = 0; r < rounds.size(); r++)
+    {
+      tp.k[r] = (unsigned char) rounds[r].k;
+      tp.step0[r] = rounds[r].step0;
+      tp.dec_offset[r] = (unsigned int) rounds[r].dec_offset;
+    }
+  hipLaunchKernelGGL (viterbi_init_kernel, dim3 (V_STATES / 256, (unsigned) total), dim3 (256), 0, st, b);
   int parity = 0;
   for (size_t r = 0; r < rounds.size(); r++)
     {
       const RoundPlan& rp = rounds[r];
-      tp.k[r] = (unsigned char) rp.k;
-      tp.step0[r] = rp.step0;
-      tp.dec_offset[r] = (unsigned int) rp.dec_offset;
       // after V_ORDER steps every state is reachable and, for finite input, all metrics are >= 0: plain compare-select
       const bool plain = rp.step0 >= V_ORDER;
       const dim3 grid ((V_STATES >> rp.k) / V_WG, (unsigned) total);

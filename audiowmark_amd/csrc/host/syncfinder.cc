@@ -139,6 +139,7 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   awmk::SyncScanArgs sa {};
   sa.db = m_lane->ws_db.as<float>();
   sa.have = clip ? m_lane->ws_have.as<char>() : nullptr;     // BLOCK mode never skips a frame
+  sa.have_is_run = 1;                                         // (K4 skips by the non-silent range: one run, absent frames +0)
   sa.plane_stride = plane;
   sa.have_plane_stride = ld;
   sa.row_stride = 1;
@@ -838,6 +839,7 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
   awmk::SyncScanArgs sa {};
   sa.db = m_lane->ws_db.as<float>();
   sa.have = m_lane->ws_have.as<char>();
+  sa.have_is_run = 1;
   sa.plane_stride = plane;
   sa.have_plane_stride = ld;
   sa.row_stride = 1;

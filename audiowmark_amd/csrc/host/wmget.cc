@@ -36,8 +36,10 @@ normalize_soft_bits (const std::vector<float>& soft_bits)
  * block i (if ok[i]) is slot[i] of ctx->ws_soft ([slots][858] floats) */
 int
 block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
-                     std::vector<int>& slot_of, std::vector<char>& ok)
+                     std::vector<int>& slot_of, std::vector<char>& ok, const long long *slice_range = nullptr, size_t slice_frames = 0)
 {
+  // slice_range (a row of padded clips, kernels.hh launch_clip_pad): frames in the padding are not transformed, their dB values
+  // are written directly (a frame of zeros transforms to exactly -96 dB per band)
   const size_t count = mark_block_frame_count();
   const int n_bits = mark_data_frame_count() / Params::frames_per_bit;
   const int C = wav.n_channels;
@@ -58,10 +60,15 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
   const long long block_stride = (long long) C * Params::n_bands * ld;
   const size_t max_batch = std::max<size_t> (1, (size_t (2) << 30) / (block_stride * sizeof (float)));
   if (int rc = lane->ws_soft.reserve (bases.size() * n_bits * sizeof (float))) return rc;
-  if (int rc = lane->ws_idx.reserve (bases.size() * sizeof (long long))) return rc;
-  if (int rc = lane->pin_blocks.reserve (bases.size() * sizeof (long long))) return rc;
+  const size_t idx_bytes = bases.size() * (sizeof (long long) + sizeof (int));
+  if (int rc = lane->ws_idx.reserve (idx_bytes)) return rc;
+  if (int rc = lane->pin_blocks.reserve (idx_bytes)) return rc;
   std::copy (bases.begin(), bases.end(), lane->pin_blocks.as<long long>());
-  AWM_HIP_CHECK (hipMemcpyAsync (lane->ws_idx.ptr, lane->pin_blocks.ptr, bases.size() * sizeof (long long), hipMemcpyHostToDevice, st));
+  int *slice_of = reinterpret_cast<int *> (lane->pin_blocks.as<long long>() + bases.size());
+  for (size_t i = 0; i < bases.size(); i++)
+    slice_of[i] = slice_frames ? int (size_t (bases[i]) / slice_frames) : 0;
+  AWM_HIP_CHECK (hipMemcpyAsync (lane->ws_idx.ptr, lane->pin_blocks.ptr, idx_bytes, hipMemcpyHostToDevice, st));
+  const int *d_slice_of = reinterpret_cast<const int *> (lane->ws_idx.as<long long>() + bases.size());
   for (size_t b0 = 0; b0 < bases.size(); b0 += max_batch)
     {
       const size_t nb = std::min (max_batch, bases.size() - b0);
@@ -81,6 +88,13 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
       da.have = nullptr;
       da.first = 0;
       da.last = (long long) wav.n_values();      // mix_decode uses plain run_fft: no silence skipping
+      if (slice_range && slice_frames)
+        {
+          da.stream_range = slice_range;
+          da.range_index = d_slice_of + b0;
+          da.range_div = 1;
+          da.silent_frames_are_zero = 1;
+        }
       da.tile_frames = 32;
       {
         ProfScope ps (ctx, PROF_BLOCK_DB, double (nb) * count * C * (4096.0 + 324.0), st);
@@ -1042,7 +1056,7 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
             }
           std::vector<int> slot_of;
           std::vector<char> ok;
-          if (int rc = block_soft_bits_dev (ctx, lane, kt, group, index, slot_of, ok))
+          if (int rc = block_soft_bits_dev (ctx, lane, kt, group, index, slot_of, ok, d_range, slice_frames))
             return rc;
           DecodeJob decode;
           for (size_t k = 0; k < cands.size(); k++)

@@ -14,9 +14,12 @@ int
 main (int argc, char **argv)
 {
   setvbuf (stdout, nullptr, _IONBF, 0);
-  const long long n_db = argc > 1 ? atoll (argv[1]) : 55500;      // ~21.5 min of frames
+  const long long n_db = argc > 1 && atoll (argv[1]) > 0 ? atoll (argv[1]) : 55500;      // ~21.5 min of frames
   const int reps = argc > 2 ? atoi (argv[2]) : 10;
-  const int R = 85, total = 2226, n_planes = 4;
+  // argv[3] = "clip": the CLIP search of padded 30 s clips -- 6692 frames per plane, two blocks (R = 170 rows per bit over 4452
+  // frames), only the frames [3170, 4462) transformed (have = 1), zeros elsewhere; 256 planes = 64 clips x 4 shifts
+  const bool clip = argc > 3 && !strcmp (argv[3], "clip");
+  const int R = clip ? 170 : 85, total = clip ? 4452 : 2226, n_planes = clip ? 256 : 4;
   std::mt19937_64 rng (42);
   std::vector<int> packed (6 * R * 64, 0);
   for (int bit = 0; bit < 6; bit++)
@@ -43,6 +46,24 @@ main (int argc, char **argv)
   std::vector<float> db (n_planes * plane);
   std::uniform_real_distribution<float> dist (-70.f, -5.f);
   for (auto& v : db) v = dist (rng);
+  std::vector<char> have (size_t (n_planes) * ld, 0);
+  const long long run0 = argc > 4 ? atoll (argv[4]) : 3170, run1 = argc > 5 ? atoll (argv[5]) : 4462;
+  if (clip)
+    for (int p = 0; p < n_planes; p++)
+      for (long long f = 0; f < ld; f++)
+        {
+          const bool in_run = f >= run0 + (p & 3) && f < run1 + (p % 5);       // (not the same run in every plane)
+          have[p * ld + f] = in_run && f < n_db;
+          if (!in_run)
+            for (int b = 0; b < 81; b++)
+              db[p * plane + b * ld + f] = 0.f;
+        }
+  char *d_have = nullptr;
+  if (clip)
+    {
+      CK (hipMalloc (&d_have, have.size()));
+      CK (hipMemcpy (d_have, have.data(), have.size(), hipMemcpyHostToDevice));
+    }
   std::vector<unsigned> chains (12 * R * 8);
   awmk::pack_scan_chains (packed.data(), R, chains.data());
   unsigned *d_chains;
@@ -58,6 +79,7 @@ main (int argc, char **argv)
   sa.db = d_db; sa.plane_stride = plane; sa.have_plane_stride = ld; sa.row_stride = 1; sa.band_stride = ld; sa.have_row_stride = 1;
   sa.n_lanes = S; sa.n_planes = n_planes; sa.min_delta = 0.01; sa.quality = d_q; sa.q_stride = q_stride;
   sa.table.packed = d_tab; sa.table.rows_per_bit = R; sa.table.chains = d_chains;
+  sa.have = d_have;
   hipStream_t st; CK (hipStreamCreate (&st));
   hipEvent_t e0, e1; CK (hipEventCreate (&e0)); CK (hipEventCreate (&e1));
   std::vector<double> ref (n_planes * q_stride), got (n_planes * q_stride);
@@ -68,7 +90,12 @@ main (int argc, char **argv)
       switch (variant)
         {
         case 0:  return awmk::launch_sync_scan (st, sa);
-        default: return awmk::launch_sync_scan_window (st, sa, total);
+        default:
+          {
+            awmk::SyncScanArgs w = sa;
+            w.have_is_run = 1;
+            return awmk::launch_sync_scan_window (st, w, total);
+          }
         }
     };
     CK (launch());
