@@ -121,6 +121,7 @@ lib.awm_get_watermark_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_size
 lib.awm_resample_frames.argtypes = [_vp, C.c_size_t, C.c_int, C.c_int]
 lib.awm_resample_frames.restype = C.c_size_t
 lib.awm_resample_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]
+lib.awm_add_watermark_batch_d.argtypes = [_vp, _vp, C.c_char_p, C.c_size_t, _vp, _vp, _vp, C.c_int]
 lib.awm_get_watermark_batch_d.argtypes = [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
 lib.awm_decode_chunk_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _vp]
 lib.awm_tab_up_down.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
@@ -434,6 +435,24 @@ class Context:
         _check(lib.awm_add_watermark_d(self._h, key_bytes(key), payload_hex.encode(), _dev_ptr(pcm), _dev_ptr(out), n, ch,
                                        sample_rate), "awm_add_watermark_d")
         return out
+
+    def add_watermark_batch(self, key, payload_hex, clips, outs=None):
+        """add_watermark of many independent resident clips (44.1 kHz, same channel count) with one key and payload, dealt to
+        the context's work lanes; returns the list of outputs."""
+        import torch
+        if not clips:
+            return []
+        shapes = [_pcm_shape(c) for c in clips]
+        ch = shapes[0][1]
+        assert all(s[1] == ch for s in shapes)
+        if outs is None:
+            outs = [torch.empty_like(c) for c in clips]
+        src = (C.c_void_p * len(clips))(*[_dev_ptr(c) for c in clips])
+        dst = (C.c_void_p * len(clips))(*[_dev_ptr(o) for o in outs])
+        frames = (C.c_size_t * len(clips))(*[s[0] for s in shapes])
+        _check(lib.awm_add_watermark_batch_d(self._h, key_bytes(key), payload_hex.encode(), len(clips), src, dst, frames, ch),
+               "awm_add_watermark_batch_d")
+        return outs
 
     # ---- file level: the reference's add_watermark / get_watermark (wmcommon.hh:226-228) ----
     def add_watermark_file(self, key, payload_hex, in_path, out_path, raw_in=None, raw_out=None):

@@ -137,8 +137,10 @@ awm_add_init_block_max_d (awm_ctx *ctx, float *block_max_d, size_t n_blocks)
 static int
 add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
               const int8_t *frame_mod_dev, double water_delta, size_t first_frame,
-              const float *halo_before_d, const float *halo_after_d, float *block_max_d, size_t first_block, size_t n_blocks)
+              const float *halo_before_d, const float *halo_after_d, float *block_max_d, size_t first_block, size_t n_blocks,
+              WorkLane *lane = nullptr)
 {
+  hipStream_t st = lane ? lane->stream : ctx->stream;
   awmk::AddMixArgs a {};
   a.pcm_in = pcm_in_d;
   a.out = out_d;
@@ -158,8 +160,8 @@ add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames
   a.block_frames = int (mark_block_frame_count());
   a.frames_pad_start = int (Params::frames_pad_start);
   a.frames_per_span = frames_per_span (ctx, (long long) (n_frames + 1023) / 1024);
-  ProfScope ps (ctx, PROF_ADD_MIX, double (n_frames) * n_channels * 8.0);     // read + write every sample once
-  AWM_HIP_CHECK (awmk::launch_add_mix (ctx->stream, ctx->tabs, a));
+  ProfScope ps (ctx, PROF_ADD_MIX, double (n_frames) * n_channels * 8.0, st);     // read + write every sample once
+  AWM_HIP_CHECK (awmk::launch_add_mix (st, ctx->tabs, a));
   return 0;
 }
 
@@ -196,23 +198,35 @@ awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels, si
   return 0;
 }
 
+/* whole stream on one lane (stream + block maxima + limiter table of that lane; the context itself is lane 0) */
 static int
 add_full (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
-          const int8_t *frame_mod_dev, double water_delta, int use_limiter)
+          const int8_t *frame_mod_dev, double water_delta, int use_limiter, WorkLane *lane = nullptr)
 {
+  if (!lane)
+    lane = ctx;
+  hipStream_t st = lane->stream;
   float *block_max = nullptr;
   const size_t n_blocks = n_frames / LIMITER_BLOCK + 2;
   if (use_limiter)
     {
-      if (int rc = ctx->ws_block_max.reserve (n_blocks * sizeof (float))) return rc;
-      block_max = ctx->ws_block_max.as<float>();
-      if (int rc = awm_add_init_block_max_d (ctx, block_max, n_blocks)) return rc;
+      if (int rc = lane->ws_block_max.reserve (n_blocks * sizeof (float))) return rc;
+      block_max = lane->ws_block_max.as<float>();
+      unsigned int bits;
+      std::memcpy (&bits, &LIMITER_CEILING, sizeof (bits));
+      AWM_HIP_CHECK (awmk::launch_fill_u32 (st, reinterpret_cast<unsigned int *> (block_max), bits, n_blocks));
     }
   if (int rc = add_mix_impl (ctx, pcm_in_d, out_d, n_frames, n_channels, frame_mod_dev, water_delta, 0, nullptr, nullptr,
-                             block_max, 0, n_blocks))
+                             block_max, 0, n_blocks, lane))
     return rc;
   if (use_limiter)
-    return awm_add_limit_d (ctx, out_d, n_frames, n_channels, 0, block_max, 0, n_blocks);
+    {
+      const size_t tab_entries = awmk::limiter_tab_entries ((long long) n_frames, 0, LIMITER_BLOCK);
+      if (int rc = lane->ws_limit_tab.reserve ((tab_entries + 1) * sizeof (float2))) return rc;
+      ProfScope ps (ctx, PROF_LIMITER, double (n_frames) * n_channels * 8.0, st);
+      AWM_HIP_CHECK (awmk::launch_limiter (st, out_d, (long long) n_frames, n_channels, 0, block_max, 0, (long long) n_blocks, LIMITER_BLOCK,
+                                           LIMITER_CEILING, lane->ws_limit_tab.as<float2>(), tab_entries));
+    }
   return 0;
 }
 
@@ -768,6 +782,56 @@ awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_he
   if (sample_rate != Params::mark_sample_rate)
     return add_full_rate (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter, sample_rate);
   return add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter);
+}
+
+/* add_watermark for many independent inputs with one key and payload (BASELINE config 5: a batch of short clips).  A 30 s clip
+ * is five launches of a few microseconds of work each: alone on a stream they run one after the other with the GPU mostly idle
+ * (65 us per clip), so the clips are dealt to eight lanes.  Ordered after the work queued on the context's stream; the context's
+ * stream is ordered after the batch. */
+int
+awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
+                           float *const *out_d, const size_t *n_frames, int n_channels)
+{
+  if (int rc = check_ctx (ctx)) return rc;
+  if (n_clips && (!pcm_in_d || !out_d || !n_frames || n_channels < 1))
+    {
+      set_error ("awm_add_watermark_batch_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  FrameModTable *fm = ctx->get_frame_mod (capi_key (key), payload_hex ? payload_hex : "");
+  if (!fm)
+    return AWM_ERR_ARG;
+  constexpr int ADD_LANES = 8;
+  const int n_lanes = int (std::min<size_t> (ADD_LANES, n_clips));
+  std::vector<WorkLane *> lanes;
+  for (int i = 0; i < n_lanes; i++)
+    {
+      WorkLane *l = ctx->lane (i);
+      if (!l)
+        {
+          set_error ("cannot create a work lane (stream)");
+          return AWM_ERR_HIP;
+        }
+      if (!l->ev_sync)
+        AWM_HIP_CHECK (hipEventCreateWithFlags (&l->ev_sync, hipEventDisableTiming));
+      lanes.push_back (l);
+    }
+  if (n_lanes > 1)
+    {
+      AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));
+      for (int i = 1; i < n_lanes; i++)
+        AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ctx->ev_sync, 0));
+    }
+  int rc = 0;
+  for (size_t i = 0; i < n_clips && !rc; i++)
+    rc = add_full (ctx, pcm_in_d[i], out_d[i], n_frames[i], n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter,
+                   lanes[i % n_lanes]);
+  for (int i = 1; i < n_lanes; i++)
+    {
+      AWM_HIP_CHECK (hipEventRecord (lanes[i]->ev_sync, lanes[i]->stream));
+      AWM_HIP_CHECK (hipStreamWaitEvent (ctx->stream, lanes[i]->ev_sync, 0));
+    }
+  return rc;
 }
 
 int

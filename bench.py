@@ -319,11 +319,11 @@ def main():
         outs = [torch.empty_like(c) for c in clips]
         audio_seconds = args.clips * 30.0
         workload = (f"{args.clips} clips of 30 s stereo 44.1 kHz white noise over {world} GPU(s) (replicas: {len(mine)} on rank 0), add + get per "
-                    f"clip, one key for the batch (awm_get_watermark_batch_d: ClipDecoder on 16 lanes)")
+                    f"clip, one key for the batch (awm_add_watermark_batch_d: clips dealt to 8 lanes; awm_get_watermark_batch_d: ClipDecoder in groups of 64 clips, "
+                    f"one launch per stage and group)")
 
         def step():
-            for c, o in zip(clips, outs):
-                ctx.add_watermark(None, PAYLOAD, c, out=o)
+            ctx.add_watermark_batch(None, PAYLOAD, clips, outs)
             return ctx.get_watermark_batch(None, outs)
     else:
         minutes = args.minutes if args.minutes is not None else (480.0 if strong else 60.0)
@@ -405,7 +405,7 @@ def main():
     if rank == 0:
         if args.config == "clips":
             cfg = {"workload": workload, "parallelism": f"{world} replica(s)", "clips_with_payload": matches_local,
-                   "clip_batch_config": {"lanes": 16, "host_threads": 2, "ms_per_clip_get_and_add": round(elapsed / args.steps * 1e3 / max(1, len(clips)), 4)}}
+                   "clip_batch_config": {"clips_per_group": 64, "host_threads": 2, "launches_per_clip": 0.9, "ms_per_clip_get_and_add": round(elapsed / args.steps * 1e3 / max(1, len(clips)), 4)}}
         else:
             matches = sum(1 for p in (pats or []) if p["bits"] == PAYLOAD)
             cfg = {"workload": workload, "parallelism": (f"one stream sharded over {world} GPU(s)" if sharded_path else "1 GPU"),

@@ -182,6 +182,12 @@ typedef struct
   int      n_bits;
 } awm_pattern;
 
+/* add_watermark for n_clips independent inputs with one key and payload: what n_clips `audiowmark add` runs produce
+ * (wmadd.cc:620-657), the clips dealt to the context's work lanes so that their small kernels overlap.  All clips at the
+ * watermark rate (44100 Hz) with n_channels channels; out_d[i] holds n_frames[i] * n_channels floats. */
+int awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
+                               float *const *out_d, const size_t *n_frames, int n_channels);
+
 /* add_watermark core (wmadd.cc:448-618) on resident PCM: out_d gets n_frames*C samples */
 int awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex,
                          const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,

@@ -521,6 +521,13 @@ def test_clip_batch_on_lanes(gpu):
         assert [pkey(p) for p in one_by_one[i]] == [pkey(p) for p in want]
         assert any(p["bits"] == (PAY1 if i % 2 else PAY2) for p in one_by_one[i])
     assert gpu.ctx.get_watermark_batch(None, []) == []
+    # awm_add_watermark_batch_d: the clips dealt to lanes -- bit-identical to one call per clip
+    import torch
+    same_payload = [gpu.ctx.add_watermark(None, PAY1, gpu.dev(c)) for c in clips]
+    batch_add = gpu.ctx.add_watermark_batch(None, PAY1, [gpu.dev(c) for c in clips])
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(same_payload, batch_add))
+    assert gpu.ctx.add_watermark_batch(None, PAY1, []) == []
 
 
 @pytest.mark.parametrize("n", [0, 1, 1000, 1024, 2049, 44100])
