@@ -48,14 +48,14 @@ PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 KERNELS = {
     "add_mix_kernel": ("add_mix_kernel_w3<2>", "HBM <-> FP32 issue (3 300 VALU instructions per stereo frame, 3 waves / SIMD)"),
     "limiter_kernel": ("limiter_apply_kernel<2>", "HBM"),
-    "sync_db_kernel(approx)": ("sync_db_kernel<2, false>", "FP32 issue (the 4 shifts of a tile share one XCD's L2: PCM read once)"),
-    "sync_scan_kernel(approx)": ("sync_scan_stream_kernel", "LDS gathers (ds_read_b128, 256 B/clk/CU) in the reference's summation order"),
+    "sync_db_kernel(approx)": ("sync_db_kernel<2, false, 33>", "FP32 issue (the 4 shifts of a tile share one XCD's L2: PCM read once)"),
+    "sync_scan_kernel(approx)": ("sync_scan_stream_kernel<false>", "LDS gathers (ds_read_b128, 256 B/clk/CU) in the reference's summation order"),
     "local_mean_kernel": ("local_mean_kernel", "latency"),
     "sync_db_kernel(refine)": ("sync_db_sliding_kernel<2>", "FP64 issue + sequential recurrence (65 steps per wave)"),
     "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (150 workgroups)"),
-    "sync_db_kernel(block)": ("sync_db_kernel<2, true>", "FP32 issue"),
-    "soft_bits_kernel": ("soft_bits_kernel", "latency of scattered reads"),
-    "viterbi_kernel": ("viterbi_round_kernel<4, true>", "FP32 add issue: 2 x 2^15 x rate sequential float adds per trellis step and decode, 4 steps per launch in registers"),
+    "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue"),
+    "soft_bits_kernel": ("soft_bits_wave_kernel", "L2 sectors of scattered reads"),
+    "viterbi_kernel": ("viterbi_round_kernel<4, true>", "36 dependent launches per batch of decodes (launch bound); per launch: one chain of `rate` float additions per successor pair, 4 steps in registers"),
 }
 
 
@@ -237,8 +237,10 @@ def e2e_leg(torch, awm, ctx, x, resident_ms):
                       "    _, status, ru = os.wait4(pid, 0)\n"
                       "    return time.perf_counter() - t0, ru.ru_maxrss / 1024.0, os.waitstatus_to_exitcode(status), text.decode(errors='replace')\n"
                       "cmds = json.loads(sys.argv[1]); print(json.dumps([child(c) for c in cmds]))\n")
+            # (the queue count this process asked the HIP runtime for is its own business: the command line picks its own)
+            child_env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "HSA_ENABLE_SDMA")}
             r = subprocess.run([sys.executable, "-c", helper, json.dumps([[cli, "add", "-q"] + fmt + [src, dst2, PAYLOAD], [cli, "get"] + fmt + [dst2]])],
-                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                               stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=child_env)
             (ta, rss_a, rc_a, _), (tg, rss_g, rc_g, text) = json.loads(r.stdout.decode())
             text = text.encode()
             out["cli"] = {"add_s": round(ta, 3), "get_s": round(tg, 3), "xRT_incl_process_start": round(seconds / (ta + tg), 1),
