@@ -1,6 +1,7 @@
 #include "wmget.hh"
 #include "wmspeed.hh"
 #include <atomic>
+#include <memory>
 #include <thread>
 #include "utils.hh"
 #include <algorithm>
@@ -522,9 +523,8 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
   const size_t count = mark_block_frame_count();
   std::vector<SyncFinder::Score> first_scores;
   /* The chunks of a stream are independent until their patterns are merged, so each one runs on its own lane (stream +
-   * workspaces) and up to MAX_LANES of them are in flight: while one chunk waits for its candidate list, runs its
-   * 150-workgroup refinement scan or its one-CU-per-block Viterbi decodes, the wide kernels of the others fill the
-   * machine.  The host issues the stages lane by lane and only ever waits for the lane whose result it needs next.
+   * workspaces) and up to CHUNK_LANES of them are in flight: while one chunk waits for its candidate list, runs its
+   * 150-workgroup refinement scan or its chain of Viterbi rounds, the wide kernels of the others fill the machine.
    * A single chunk (short files) runs on the context's own stream. */
   // `spread` = use the context's lanes 0 .. CHUNK_LANES - 1 (the caller owns the whole context); otherwise everything
   // stays on `home` (a batch of clips runs one clip per lane, each driven by its own host thread)
@@ -570,74 +570,146 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
     cw.n_frames = chunks[c].n_frames;
     return cw;
   };
-  for (size_t g0 = 0; g0 < chunks.size(); g0 += lanes.size())              // groups of chunks, one lane each
-    {
-      // every key of the list on this group before the lanes move on: the approximate dB matrices of a chunk are computed
-      // once and shared by the keys (reference syncfinder.cc:171-256)
-      for (size_t ki = 0; ki < key_list.size(); ki++)
+  /* Every chunk walks through: approximate search -> (candidate list on the host) -> refinement -> (sync positions on the
+   * host) -> block dB, soft bits, Viterbi -> (bits on the host), key after key (the approximate dB matrices of a chunk are
+   * computed once and shared by its keys, reference syncfinder.cc:171-256).  Chunk c lives on lane c mod n; the host polls the
+   * lanes and advances whichever chunk has its device results ready.
+   * (Tried: starting a chunk's approximate search only when the previous chunk's is through, so that a chunk's decode chain --
+   * ~40 small dependent launches -- runs beside the wide kernels of its successors instead of beside the other chains at the end.
+   * 6.13 -> 6.45 ms for the 60 min step: the wide kernels do not fill the GPU alone -- 846 scan tiles are 3.3 rounds on 256
+   * CUs --, running three chunks' kernels side by side is what fills it.) */
+  struct ChunkState
+  {
+    size_t c;
+    WorkLane *lane;
+    size_t ki = 0;
+    int stage = 0;                       // 0: to start (next key), 1: approximate search issued, 2: refinement issued, 3: decode issued, 4: done
+    std::unique_ptr<SyncFinder> finder;  // keeps the non-silent range of the chunk between the stages
+    SyncFinder::SearchJob job;
+    DecodeJob decode;
+  };
+  std::vector<ChunkState> active;
+  std::vector<char> lane_busy (lanes.size(), 0);
+  size_t next_chunk = 0;
+  auto advance = [&] (ChunkState& cs) -> int {
+    const Key& key = key_list[cs.ki];
+    KeyTables *kt = ctx->get_key_tables (key);
+    if (!kt)
+      return AWM_ERR_HIP;
+    if (!cs.finder)
+      cs.finder = std::make_unique<SyncFinder> (ctx, cs.lane);
+    SyncFinder& finder = *cs.finder;
+    const size_t c = cs.c;
+    switch (cs.stage)
+      {
+      case 0:
         {
-          const Key& key = key_list[ki];
-          KeyTables *kt = ctx->get_key_tables (key);
-          if (!kt)
-            return AWM_ERR_HIP;
-          const size_t gn = std::min (lanes.size(), chunks.size() - g0);
-          std::vector<SyncFinder> finders;
-          std::vector<SyncFinder::SearchJob> jobs (gn);
-          std::vector<DecodeJob> decodes (gn);
-          for (size_t i = 0; i < gn; i++)
-            finders.emplace_back (ctx, lanes[i]);
-          for (size_t i = 0; i < gn; i++)
-            // (the dB matrices of this chunk are still in the lane's workspace from the previous key: nothing else writes there)
-            if (int rc = finders[i].approx_launch (key, chunk_wav (g0 + i), SyncFinder::Mode::BLOCK, jobs[i], /* prepared */ false, /* db_ready */ ki > 0))
-              return rc;
-          for (size_t i = 0; i < gn; i++)
-            if (int rc = finders[i].select_refine (jobs[i]))
-              return rc;
-          for (size_t i = 0; i < gn; i++)
-            {
-              const size_t c = g0 + i;
-              std::vector<SyncFinder::Score> scores;
-              if (int rc = finders[i].search_finish (jobs[i], scores))
-                return rc;
-              if (ki == 0 && c == 0)
-                first_scores = scores;
-              // blocks of this chunk: fft_range refuses blocks that run past the end OF THE CHUNK (reference wmcommon.cc:128-130)
-              std::vector<size_t> wanted;
-              std::vector<const SyncFinder::Score *> wanted_score;
-              for (const auto& sc : scores)
-                if (chunks[c].n_frames >= sc.index + count * Params::frame_size)
-                  {
-                    wanted.push_back (chunks[c].first_frame + sc.index);
-                    wanted_score.push_back (&sc);
-                  }
-              std::vector<int> slot_of;
-              std::vector<char> ok;
-              if (int rc = block_soft_bits_dev (ctx, lanes[i], kt, stream, wanted, slot_of, ok))
-                return rc;
-              std::vector<PatternRawBits> pattern_raw_vec;
-              auto& pending = decodes[i].pending;
-              for (size_t w = 0; w < wanted.size(); w++)
-                {
-                  if (!ok[w])
-                    continue;
-                  const SyncFinder::Score& sc = *wanted_score[w];
-                  PatternRawBits rb;
-                  rb.index = sc.index;
-                  rb.quality = sc.quality;
-                  rb.slot = slot_of[w];
-                  rb.block_type = sc.block_type;
-                  pending.push_back ({ rb.block_type, 0, { { rb.slot, 0 } }, 0, 0, double (rb.index) / stream.sample_rate,
-                                       sc, ResultSet::Type::BLOCK, c });
-                  pattern_raw_vec.push_back (rb);
-                }
-              combine_blocks (pattern_raw_vec, stream, c, pending);
-              if (int rc = decode_launch (ctx, lanes[i], kt, decodes[i]))
-                return rc;
-            }
-          for (size_t i = 0; i < gn; i++)
-            if (int rc = decode_finish (lanes[i], key, decodes[i], result_sets, speed))
-              return rc;
+          // (ki > 0: the dB matrices of this chunk are still in the lane's workspace from the previous key: nothing else writes there)
+          if (int rc = finder.approx_launch (key, chunk_wav (c), SyncFinder::Mode::BLOCK, cs.job, /* prepared */ false, /* db_ready */ cs.ki > 0))
+            return rc;
+          cs.stage = 1;
+          return 0;
         }
+      case 1:
+        if (int rc = finder.select_refine (cs.job))
+          return rc;
+        cs.stage = 2;
+        return 0;
+      case 2:
+        {
+          std::vector<SyncFinder::Score> scores;
+          if (int rc = finder.search_finish (cs.job, scores))
+            return rc;
+          if (cs.ki == 0 && c == 0)
+            first_scores = scores;
+          // blocks of this chunk: fft_range refuses blocks that run past the end OF THE CHUNK (reference wmcommon.cc:128-130)
+          std::vector<size_t> wanted;
+          std::vector<const SyncFinder::Score *> wanted_score;
+          for (const auto& sc : scores)
+            if (chunks[c].n_frames >= sc.index + count * Params::frame_size)
+              {
+                wanted.push_back (chunks[c].first_frame + sc.index);
+                wanted_score.push_back (&sc);
+              }
+          std::vector<int> slot_of;
+          std::vector<char> ok;
+          if (int rc = block_soft_bits_dev (ctx, cs.lane, kt, stream, wanted, slot_of, ok))
+            return rc;
+          std::vector<PatternRawBits> pattern_raw_vec;
+          cs.decode = DecodeJob();
+          auto& pending = cs.decode.pending;
+          for (size_t w = 0; w < wanted.size(); w++)
+            {
+              if (!ok[w])
+                continue;
+              const SyncFinder::Score& sc = *wanted_score[w];
+              PatternRawBits rb;
+              rb.index = sc.index;
+              rb.quality = sc.quality;
+              rb.slot = slot_of[w];
+              rb.block_type = sc.block_type;
+              pending.push_back ({ rb.block_type, 0, { { rb.slot, 0 } }, 0, 0, double (rb.index) / stream.sample_rate,
+                                   sc, ResultSet::Type::BLOCK, c });
+              pattern_raw_vec.push_back (rb);
+            }
+          combine_blocks (pattern_raw_vec, stream, c, pending);
+          if (int rc = decode_launch (ctx, cs.lane, kt, cs.decode))
+            return rc;
+          cs.stage = 3;
+          return 0;
+        }
+      default:
+        if (int rc = decode_finish (cs.lane, key, cs.decode, result_sets, speed))
+          return rc;
+        cs.ki++;
+        cs.stage = cs.ki < key_list.size() ? 0 : 4;
+        return 0;
+      }
+  };
+  while (next_chunk < chunks.size() || !active.empty())
+    {
+      bool progressed = false;
+      // start chunks on free lanes, in order
+      while (next_chunk < chunks.size() && !lane_busy[next_chunk % lanes.size()] && !key_list.empty())
+        {
+          ChunkState cs;
+          cs.c = next_chunk;
+          cs.lane = lanes[next_chunk % lanes.size()];
+          lane_busy[next_chunk % lanes.size()] = 1;
+          active.push_back (std::move (cs));
+          if (int rc = advance (active.back()))
+            return rc;
+          next_chunk++;
+          progressed = true;
+        }
+      if (key_list.empty())
+        break;
+      for (auto& cs : active)
+        {
+          // a stage that waits for the device is entered when the lane has run dry (its results are in page-locked memory then);
+          // with a single chunk in flight there is nothing else to do: let the stage itself wait
+          // (any answer other than "not ready" lets the stage run: its own wait reports a failed stream)
+          if (cs.stage >= 1 && cs.stage <= 3 && (active.size() == 1 || hipStreamQuery (cs.lane->stream) != hipErrorNotReady))
+            {
+              if (int rc = advance (cs))
+                return rc;
+              if (cs.stage == 0)                   // next key of the same chunk
+                if (int rc = advance (cs))
+                  return rc;
+              progressed = true;
+            }
+        }
+      for (size_t i = 0; i < active.size(); )
+        if (active[i].stage == 4)
+          {
+            lane_busy[active[i].c % lanes.size()] = 0;
+            active.erase (active.begin() + i);
+            progressed = true;
+          }
+        else
+          i++;
+      if (!progressed)
+        std::this_thread::yield();
     }
   drain.ok = true;
   if (debug_sync_first_chunk)
