@@ -493,11 +493,11 @@ def test_many_chunks_on_lanes(gpu):
         assert len(gpu.awm.plan_chunks(len(x))) > 4
         w = gpu.ctx.add_watermark(None, PAY1, gpu.dev(x))
         got = gpu.ctx.get_watermark(None, w)
-        os.environ["AWM_ONE_LANE"] = "1"
+        gpu.awm.lib.awm_ctx_set_chunk_lanes(gpu.ctx._h, 1)
         try:
             one = gpu.ctx.get_watermark(None, w)
         finally:
-            del os.environ["AWM_ONE_LANE"]
+            gpu.awm.lib.awm_ctx_set_chunk_lanes(gpu.ctx._h, 4)
         want = orc.get(None, w.cpu().numpy(), 2)
         assert [pkey(p) for p in got] == [pkey(p) for p in one] == [pkey(p) for p in want]
         assert sum(p["bits"] == PAY1 for p in got) >= 10
