@@ -530,6 +530,36 @@ def test_clip_batch_on_lanes(gpu):
     assert gpu.ctx.add_watermark_batch(None, PAY1, []) == []
 
 
+def test_clip_batch_groups(gpu):
+    """The group path of awm_get_watermark_batch_d (padded clips side by side, one launch per stage and group): more clips than one
+    group holds, lengths from 3 s to 50 s, mono and stereo mixed (groups are per channel count), digital silence (no candidate at
+    all), very short material (the selection falls back to the single-clip search) -- clip by clip what one call per clip gives."""
+    import torch
+    rng = np.random.default_rng(77)
+    clips = []
+    for i in range(70):
+        seconds = [30, 30, 30, 12, 50, 3, 30, 21][i % 8]
+        ch = 1 if i % 9 == 4 else 2
+        x = noise(1500 + i, seconds * 44100 + 13 * i, ch)
+        if i % 16 == 7:
+            x[:] = 0
+        if i % 10 == 3:
+            x[len(x) // 3: len(x) // 2] = 0          # a gap of digital silence inside
+        clips.append(x)
+    marked = []
+    for i, c in enumerate(clips):
+        marked.append(gpu.ctx.add_watermark(None, PAY1 if i % 2 else PAY2, gpu.dev(c)) if len(c) >= 20 * 44100 and c.any() else gpu.dev(c))
+    # (mixed channel counts: one batch call per channel count, as the binding asserts equal shapes)
+    for ch in (1, 2):
+        sel = [m for m, c in zip(marked, clips) if c.shape[1] == ch]
+        one_by_one = [gpu.ctx.get_watermark(None, m) for m in sel]
+        batch = gpu.ctx.get_watermark_batch(None, sel)
+        assert len(batch) == len(sel)
+        assert batch == one_by_one
+        if ch == 2:
+            assert sum(any(p["bits"] in (PAY1, PAY2) for p in b) for b in batch) >= 20
+
+
 @pytest.mark.parametrize("n", [0, 1, 1000, 1024, 2049, 44100])
 def test_get_on_tiny_inputs(gpu, n):
     """Inputs far too short to carry a block: the reference pads and searches anyway (ClipDecoder); results must agree."""
