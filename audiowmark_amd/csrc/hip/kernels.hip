@@ -1144,15 +1144,15 @@ constexpr int SL_TILE = 16;                                   // fine offsets bu
 __device__ __forceinline__ double
 dpp_from_lower_lane (double v)                                // lane i receives lane i - 1's value
 {
-  const int lo = __builtin_amdgcn_update_dpp (0, __double2loint (v), 0x138, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp (0, __double2hiint (v), 0x138, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp (0, __double2loint (v), 0x138, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp (0, __double2hiint (v), 0x138, 0xf, 0xf, true);
   return __hiloint2double (hi, lo);
 }
 __device__ __forceinline__ double
 dpp_from_upper_lane (double v)                                // lane i receives lane i + 1's value
 {
-  const int lo = __builtin_amdgcn_update_dpp (0, __double2loint (v), 0x130, 0xf, 0xf, false);
-  const int hi = __builtin_amdgcn_update_dpp (0, __double2hiint (v), 0x130, 0xf, 0xf, false);
+  const int lo = __builtin_amdgcn_update_dpp (0, __double2loint (v), 0x130, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp (0, __double2hiint (v), 0x130, 0xf, 0xf, true);
   return __hiloint2double (hi, lo);
 }
 
