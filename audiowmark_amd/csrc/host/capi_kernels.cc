@@ -1106,7 +1106,7 @@ awm_speed_clip_location_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm
                            double seconds, int candidates, double *location)
 {
   if (int rc = check_ctx (ctx)) return rc;
-  return speed_clip_location (ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), seconds, candidates, location);
+  return speed_clip_location (ctx, ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), seconds, candidates, location);
 }
 
 int
@@ -1116,7 +1116,7 @@ awm_speed_mags_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_
   if (int rc = check_ctx (ctx)) return rc;
   std::vector<float> m;
   int rows = 0;
-  if (int rc = speed_mags (ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), clip_location, center, seconds, m, &rows))
+  if (int rc = speed_mags (ctx, ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), clip_location, center, seconds, m, &rows))
     return rc;
   std::copy (m.begin(), m.begin() + std::min<size_t> (rows, max_rows) * 510 * 2, out);
   return rows;
@@ -1129,7 +1129,7 @@ awm_speed_scan_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_
 {
   if (int rc = check_ctx (ctx)) return rc;
   std::vector<SpeedScore> scores;
-  if (int rc = speed_scan (ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), clip_location,
+  if (int rc = speed_scan (ctx, ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), clip_location,
                            { seconds, step, n_steps, n_center_steps }, std::vector<double> (speeds, speeds + n_speeds), scores))
     return rc;
   std::sort (scores.begin(), scores.end(), [] (const SpeedScore& a, const SpeedScore& b) { return a.speed < b.speed; });
@@ -1150,7 +1150,7 @@ awm_detect_speed_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, siz
   Params::detect_speed_patient = patient != 0;
   std::vector<DetectSpeedResult> results;
   double speed = 0, quality = 0;
-  const int rc = detect_speed (ctx, { capi_key (key) }, make_wav_rate (pcm_d, n_frames, n_channels, rate), false, results, &speed, &quality);
+  const int rc = detect_speed (ctx, ctx, { capi_key (key) }, make_wav_rate (pcm_d, n_frames, n_channels, rate), nullptr, results, &speed, &quality);
   Params::detect_speed_patient = old_patient;
   if (rc)
     return rc;

@@ -91,6 +91,7 @@ awm::WorkLane::release_lane()
   if (ev_sync)
     (void) hipEventDestroy (ev_sync);
   ev_sync = nullptr;
+  awm::speed_scratch_free (this);
 }
 
 awm::WorkLane *

@@ -118,6 +118,9 @@ std::vector<float> zita_table (double frel, unsigned hl, unsigned np);
 int upload_sync (DevBuffer& buf, const void *src, size_t bytes, hipStream_t st);
 
 struct SpeedWorkspace;            // wmspeed.hh
+struct SpeedScratch;
+struct WorkLane;
+void speed_scratch_free (WorkLane *lane);
 } struct awm_ctx; namespace awm {
 void speed_workspace_free (awm_ctx *ctx);
 
@@ -154,6 +157,7 @@ struct WorkLane
   PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits, pin_small, pin_group;
   hipEvent_t   ev_refine[2] = { nullptr, nullptr };
   hipEvent_t   ev_sync = nullptr;        // cross-lane ordering (input ready / lane done)
+  SpeedScratch *speed_scratch = nullptr; // buffers of a speed search on this lane (wmspeed.cc), created on first use
   void release_lane();
 };
 constexpr int MAX_LANES = 16;       // lanes a context can own (batch of clips: one clip per lane)

@@ -875,14 +875,14 @@ clip_decoder_run (awm_ctx *ctx, WorkLane *lane, bool spread, const std::vector<K
  * normal and speed results we get".  Runs before the normal decoders of the chunk, like in the reference. */
 static int
 decode_speed (awm_ctx *ctx, WorkLane *home, bool spread, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav,
-              bool first_chunk, bool print_results)
+              bool first_chunk, std::string *report)
 {
   if (!(Params::detect_speed || Params::detect_speed_patient || Params::try_speed > 0))
     return 0;
   std::vector<DetectSpeedResult> speed_results;
   if (Params::detect_speed || Params::detect_speed_patient)
     {
-      if (int rc = detect_speed (ctx, key_list, wav, print_results, speed_results))
+      if (int rc = detect_speed (ctx, home, key_list, wav, report, speed_results))
         return rc;
     }
   else
@@ -894,10 +894,11 @@ decode_speed (awm_ctx *ctx, WorkLane *home, bool spread, ResultSet& result_set, 
     {
       // resample_ratio (wav, speed, mark_sample_rate * speed)
       size_t n_out = 0;
-      if (int rc = resample_ratio_device (ctx, home, wav, sr.speed, -1, speed_stretch_buffer (ctx), &n_out))
+      DevBuffer& stretched = speed_stretch_buffer (home);
+      if (int rc = resample_ratio_device (ctx, home, wav, sr.speed, -1, stretched, &n_out))
         return rc;
       DeviceWav sw;
-      sw.data = speed_stretch_buffer (ctx).as<float>();
+      sw.data = stretched.as<float>();
       sw.n_frames = n_out;
       sw.n_channels = wav.n_channels;
       sw.sample_rate = int (Params::mark_sample_rate * sr.speed);
@@ -915,8 +916,11 @@ bool speed_print_results = false;       // decode() passes !orig_bits.empty(): s
 int
 decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav, bool first_chunk)
 {
-  if (int rc = decode_speed (ctx, ctx, true, result_set, key_list, wav, first_chunk, speed_print_results))
-    return rc;
+  std::string report;
+  const int speed_rc = decode_speed (ctx, ctx, true, result_set, key_list, wav, first_chunk, speed_print_results ? &report : nullptr);
+  fputs (report.c_str(), stdout);
+  if (speed_rc)
+    return speed_rc;
   std::string debug_sync;
   if (int rc = block_decoder_run (ctx, ctx, true, key_list, wav, { ChunkRange { 0, wav.n_frames, 0.0 } }, { &result_set }, 1, &debug_sync))
     return rc;
@@ -972,13 +976,77 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
   std::vector<ResultSet *> ptrs;
   for (auto& cs : chunk_sets)
     ptrs.push_back (&cs);
-  for (size_t c = 0; c < chunks.size(); c++)
+  if (Params::detect_speed || Params::detect_speed_patient || Params::try_speed > 0)
     {
-      DeviceWav cw = wav;
-      cw.data = wav.data + chunks[c].first_frame * wav.n_channels;
-      cw.n_frames = chunks[c].n_frames;
-      if (int rc = decode_speed (ctx, home, spread, chunk_sets[c], key_list, cw, c == 0 && first_is_stream_start, speed_print_results))
-        return rc;
+      /* The speed part of decode() for every chunk (reference wmget.cc:886-927) -- speed search, stretched copy, block and clip
+       * decoder on the stretched copy -- is a long chain with a dozen host round trips (three search passes, each waiting for
+       * its scores) that keeps the GPU busy for two thirds of its duration.  The chunks are independent: each one runs the
+       * chain on its own lane, driven by its own host thread (buffers of a search are per lane, the tables shared). */
+      const size_t n_par = !spread ? 1 : std::min<size_t> (chunks.size(), size_t (std::max (1, std::min (ctx->chunk_lanes, CHUNK_LANES))));
+      std::vector<WorkLane *> lanes;
+      for (size_t i = 0; i < n_par; i++)
+        {
+          WorkLane *l = spread ? ctx->lane (int (i)) : home;
+          if (!l)
+            {
+              set_error ("cannot create a work lane (stream)");
+              return AWM_ERR_HIP;
+            }
+          lanes.push_back (l);
+        }
+      if (lanes.size() > 1)
+        {
+          // the PCM may still be in flight on the context's stream
+          if (!ctx->ev_sync)
+            AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
+          AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));
+          for (size_t i = 1; i < lanes.size(); i++)
+            AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ctx->ev_sync, 0));
+        }
+      std::vector<std::string> reports (chunks.size());
+      std::vector<int> rcs (chunks.size(), 0);
+      std::vector<std::string> messages (chunks.size());
+      auto run_chunk = [&] (size_t c, WorkLane *lane) {
+        DeviceWav cw = wav;
+        cw.data = wav.data + chunks[c].first_frame * wav.n_channels;
+        cw.n_frames = chunks[c].n_frames;
+        rcs[c] = decode_speed (ctx, lane, false, chunk_sets[c], key_list, cw, c == 0 && first_is_stream_start,
+                               speed_print_results ? &reports[c] : nullptr);
+        if (rcs[c])
+          messages[c] = last_error();
+      };
+      if (lanes.size() == 1)
+        for (size_t c = 0; c < chunks.size() && !(c && rcs[c - 1]); c++)
+          run_chunk (c, lanes[0]);
+      else
+        {
+          std::atomic<size_t> next { 0 };
+          std::vector<std::thread> workers;
+          const int device = ctx->device;
+          for (size_t li = 0; li < lanes.size(); li++)
+            workers.emplace_back ([&, li] {
+              if (hipSetDevice (device) != hipSuccess)
+                return;
+              for (;;)
+                {
+                  const size_t c = next.fetch_add (1);
+                  if (c >= chunks.size())
+                    break;
+                  run_chunk (c, lanes[li]);
+                }
+            });
+          for (auto& w : workers)
+            w.join();
+        }
+      for (size_t c = 0; c < chunks.size(); c++)
+        {
+          fputs (reports[c].c_str(), stdout);          // in chunk order, as the reference prints them
+          if (rcs[c])
+            {
+              set_error (messages[c]);
+              return rcs[c];
+            }
+        }
     }
   std::string debug_sync;
   if (int rc = block_decoder_run (ctx, home, spread, key_list, wav, chunks, ptrs, 1, &debug_sync))

@@ -20,9 +20,34 @@ SpeedWorkspace::release()
       t->col_frame.release();
       t->col_first.release();
     }
-  for (DevBuffer *b : { &window512, &sub, &mags, &centers, &items, &best, &gather_pos, &gather_out, &ranges, &energy, &stretched })
+  window512.release();
+}
+
+void
+SpeedScratch::release()
+{
+  for (DevBuffer *b : { &sub, &mags, &centers, &items, &best, &gather_pos, &gather_out, &ranges, &energy, &stretched })
     b->release();
   pin.release();
+}
+
+SpeedScratch *
+speed_scratch (WorkLane *lane)
+{
+  if (!lane->speed_scratch)
+    lane->speed_scratch = new SpeedScratch();
+  return lane->speed_scratch;
+}
+
+void
+speed_scratch_free (WorkLane *lane)
+{
+  if (lane->speed_scratch)
+    {
+      lane->speed_scratch->release();
+      delete lane->speed_scratch;
+      lane->speed_scratch = nullptr;
+    }
 }
 
 void
@@ -76,6 +101,7 @@ var_geometry (double ratio)
 int
 get_var_tables (awm_ctx *ctx, const std::vector<double>& ratios, std::vector<VarResampleTable *>& out)
 {
+  std::lock_guard<std::mutex> lock (ctx->speed_mutex);        // the table caches are shared by the lanes
   SpeedWorkspace *ws = workspace (ctx);
   out.assign (ratios.size(), nullptr);
   std::vector<size_t> missing;
@@ -127,8 +153,10 @@ get_var_tables (awm_ctx *ctx, const std::vector<double>& ratios, std::vector<Var
       ws->var_tables.push_back (std::move (vt));
       // Bounded cache.  The grids of the first pass (57 centres each for the normal and the patient search) never change
       // and are the first entries ever made: they stay; the oldest of the data dependent refinement ratios goes.
-      // (Nothing handed out by this call is dropped: a call either finds all its ratios, or adds the missing ones last.)
-      constexpr size_t keep_first = 128, max_tables = 512;
+      // (Nothing handed out by this call is dropped: a call either finds all its ratios, or adds the missing ones last.  Up to
+      // CHUNK_LANES searches run side by side, each with ~100 ratios of its own in use: the cache is an order of magnitude
+      // larger than that, so the oldest entry is never one a running search holds.  A table is ~20 KB.)
+      constexpr size_t keep_first = 128, max_tables = 4096;
       if (ws->var_tables.size() > max_tables)
         {
           ws->var_tables[keep_first]->ctab.release();
@@ -166,6 +194,7 @@ center_dev (const VarResampleTable *vt, double ratio, long long n_in, long long 
 SpeedKeyTables *
 get_speed_key_tables (awm_ctx *ctx, const Key& key)
 {
+  std::lock_guard<std::mutex> lock (ctx->speed_mutex);
   SpeedWorkspace *ws = workspace (ctx);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& t : ws->key_tables)
@@ -213,6 +242,7 @@ get_speed_key_tables (awm_ctx *ctx, const Key& key)
 int
 ensure_window (awm_ctx *ctx)
 {
+  std::lock_guard<std::mutex> lock (ctx->speed_mutex);
   SpeedWorkspace *ws = workspace (ctx);
   if (ws->window512.ptr)
     return 0;
@@ -236,10 +266,10 @@ struct ScanCenter { double speed; VarResampleTable *table; long long n_in, n_out
 
 /* resample + STFT + column sums of all centres of a pass; leaves the matrices in ws->mags */
 int
-prepare_mags (awm_ctx *ctx, const Key& key, const DeviceWav& clip, double seconds, std::vector<ScanCenter>& centers,
+prepare_mags (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& clip, double seconds, std::vector<ScanCenter>& centers,
               long long *ld_out, long long *center_stride_out)
 {
-  SpeedWorkspace *ws = workspace (ctx);
+  SpeedScratch *ws = speed_scratch (lane);
   SpeedKeyTables *skt = get_speed_key_tables (ctx, key);
   if (!skt)
     return AWM_ERR_HIP;
@@ -285,7 +315,7 @@ prepare_mags (awm_ctx *ctx, const Key& key, const DeviceWav& clip, double second
     return rc;
   if (int rc = ws->pin.reserve (std::max<size_t> (cds.size() * sizeof (awmk::SpeedCenterDev), 1 << 16)))
     return rc;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = lane->stream;
   std::memcpy (ws->pin.ptr, cds.data(), cds.size() * sizeof (awmk::SpeedCenterDev));
   AWM_HIP_CHECK (hipMemcpyAsync (ws->centers.ptr, ws->pin.ptr, cds.size() * sizeof (awmk::SpeedCenterDev), hipMemcpyHostToDevice, st));
   awmk::VarResampleArgs ra {};
@@ -302,7 +332,7 @@ prepare_mags (awm_ctx *ctx, const Key& key, const DeviceWav& clip, double second
   ma.sub_stride = sub_stride;
   ma.n_channels = C;
   ma.centers = ra.centers;
-  ma.window512 = ws->window512.as<float>();
+  ma.window512 = workspace (ctx)->window512.as<float>();        // (built by ensure_window above; never replaced)
   ma.cols = skt->cols.as<unsigned int>();
   ma.mags = ws->mags.as<float2>();
   ma.mags_center_stride = center_stride;
@@ -317,10 +347,9 @@ prepare_mags (awm_ctx *ctx, const Key& key, const DeviceWav& clip, double second
 } // namespace
 
 DevBuffer&
-speed_stretch_buffer (awm_ctx *ctx)
+speed_stretch_buffer (WorkLane *lane)
 {
-  std::lock_guard<std::mutex> lock (ctx->speed_mutex);
-  return workspace (ctx)->stretched;
+  return speed_scratch (lane)->stretched;
 }
 
 VarResampleGeometry
@@ -342,8 +371,7 @@ var_resample_geometry (double ratio)
 int
 resample_var_device (awm_ctx *ctx, WorkLane *lane, const float *in_d, size_t n_in, int n_channels, double ratio, float *out_d, size_t n_out)
 {
-  std::lock_guard<std::mutex> lock (ctx->speed_mutex);
-  SpeedWorkspace *ws = workspace (ctx);
+  SpeedScratch *ws = speed_scratch (lane);
   std::vector<VarResampleTable *> tables;
   if (int rc = get_var_tables (ctx, { ratio }, tables))
     return rc;
@@ -388,11 +416,11 @@ resample_ratio_device (awm_ctx *ctx, WorkLane *lane, const DeviceWav& wav, doubl
 }
 
 int
-speed_clip_location (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double seconds, int candidates, double *location)
+speed_clip_location (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& wav, double seconds, int candidates, double *location)
 {
-  std::lock_guard<std::mutex> lock (ctx->speed_mutex);
-  SpeedWorkspace *ws = workspace (ctx);
-  hipStream_t st = ctx->stream;
+  (void) ctx;
+  SpeedScratch *ws = speed_scratch (lane);
+  hipStream_t st = lane->stream;
   /* get_clip_locations (reference wmspeed.cc:533-553): hash a sparse subset of the samples */
   Random rng (key, 0, Random::Stream::speed_clip);
   std::vector<unsigned long long> pos;
@@ -461,11 +489,10 @@ speed_clip_location (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double 
 }
 
 int
-speed_scan (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_location, const SpeedScanParams& sp,
+speed_scan (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& wav, double clip_location, const SpeedScanParams& sp,
             const std::vector<double>& speeds, std::vector<SpeedScore>& scores)
 {
-  std::lock_guard<std::mutex> lock (ctx->speed_mutex);
-  SpeedWorkspace *ws = workspace (ctx);
+  SpeedScratch *ws = speed_scratch (lane);
   scores.clear();
   /* SpeedSearch::get_jobs (reference wmspeed.cc:461-492): "speed is between 0.8 and 1.25, so we use a clip seconds
    * factor of 1.3 to provide enough samples" */
@@ -481,7 +508,7 @@ speed_scan (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_loca
   if (centers.empty())
     return 0;
   long long ld = 0, center_stride = 0;
-  if (int rc = prepare_mags (ctx, key, clip, sp.seconds, centers, &ld, &center_stride))
+  if (int rc = prepare_mags (ctx, lane, key, clip, sp.seconds, centers, &ld, &center_stride))
     return rc;
   SpeedKeyTables *skt = get_speed_key_tables (ctx, key);
   /* SpeedSync::get_jobs (reference wmspeed.cc:172-192): relative speeds step^p, p = -n_steps .. n_steps, per centre */
@@ -506,7 +533,7 @@ speed_scan (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_loca
     return rc;
   if (int rc = ws->pin.reserve (std::max<size_t> (std::max (items_bytes, best_bytes), 1 << 16)))
     return rc;
-  hipStream_t st = ctx->stream;
+  hipStream_t st = lane->stream;
   std::memcpy (ws->pin.ptr, items.data(), items_bytes);
   AWM_HIP_CHECK (hipMemcpyAsync (ws->items.ptr, ws->pin.ptr, items_bytes, hipMemcpyHostToDevice, st));
   AWM_HIP_CHECK (hipMemsetAsync (ws->best.ptr, 0, best_bytes, st));
@@ -547,11 +574,10 @@ speed_scan (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_loca
 }
 
 int
-speed_mags (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_location, double center, double seconds,
+speed_mags (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& wav, double clip_location, double center, double seconds,
             std::vector<float>& out, int *rows)
 {
-  std::lock_guard<std::mutex> lock (ctx->speed_mutex);
-  SpeedWorkspace *ws = workspace (ctx);
+  SpeedScratch *ws = speed_scratch (lane);
   size_t start_point, end_point;
   speed_clip_range (clip_location, wav, seconds * 1.3, &start_point, &end_point);
   DeviceWav clip = wav;
@@ -559,7 +585,7 @@ speed_mags (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_loca
   clip.n_frames = end_point - start_point;
   std::vector<ScanCenter> centers { { center, nullptr, 0, 0, 0 } };
   long long ld = 0, center_stride = 0;
-  if (int rc = prepare_mags (ctx, key, clip, seconds, centers, &ld, &center_stride))
+  if (int rc = prepare_mags (ctx, lane, key, clip, seconds, centers, &ld, &center_stride))
     return rc;
   KeyTables *kt = ctx->get_key_tables (key);
   const SyncTable& stab = kt->sync[0].host;
@@ -630,7 +656,7 @@ score_smooth_find_best (const std::vector<SpeedScore>& in_scores, double step, d
 }
 
 int
-detect_speed (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, bool print_results,
+detect_speed (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const DeviceWav& wav, std::string *report,
               std::vector<DetectSpeedResult>& results, double *best_speed_out, double *best_quality_out)
 {
   results.clear();
@@ -650,32 +676,32 @@ detect_speed (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& w
   for (const Key& key : key_list)
     {
       double clip_location = 0;
-      if (int rc = speed_clip_location (ctx, key, wav, scan1.seconds, clip_candidates, &clip_location))
+      if (int rc = speed_clip_location (ctx, lane, key, wav, scan1.seconds, clip_candidates, &clip_location))
         return rc;
       std::vector<SpeedScore> scores;
-      if (int rc = speed_scan (ctx, key, wav, clip_location, scan1, { 1.0 }, scores))
+      if (int rc = speed_scan (ctx, lane, key, wav, clip_location, scan1, { 1.0 }, scores))
         return rc;
       select_n_best_scores (scores, n_best);
       std::vector<double> speeds;
       for (const auto& s : scores)
         speeds.push_back (s.speed);
-      if (int rc = speed_scan (ctx, key, wav, clip_location, scan2, speeds, scores))
+      if (int rc = speed_scan (ctx, lane, key, wav, clip_location, scan2, speeds, scores))
         return rc;
       select_n_best_scores (scores, 1);
       if (scores.empty())
         continue;
-      if (int rc = speed_scan (ctx, key, wav, clip_location, scan3, { scores[0].speed }, scores))
+      if (int rc = speed_scan (ctx, lane, key, wav, clip_location, scan3, { scores[0].speed }, scores))
         return rc;
       const double best_speed = score_smooth_find_best (scores, 1 - scan3.step, scan3_smooth_distance);
       double best_quality = 0;
       for (const auto& s : scores)
         best_quality = std::max (best_quality, s.quality);
-      if (print_results)
+      if (report)
         {
           double delta = -1;
           if (Params::test_speed > 0)
             delta = 100 * std::fabs (best_speed - Params::test_speed) / Params::test_speed;
-          printf ("detect_speed %f %f %.4f\n", best_speed, best_quality, delta);
+          *report += string_printf ("detect_speed %f %f %.4f\n", best_speed, best_quality, delta);
         }
       if (best_speed_out)
         *best_speed_out = best_speed;

@@ -50,15 +50,24 @@ struct SpeedKeyTables
   DevBuffer col_first;      // [6][block frames + 2] uint8: columns of the bit with frame < f
 };
 
+/* tables shared by all lanes of a context (read-only once built; lookups and construction under awm_ctx::speed_mutex) */
 struct SpeedWorkspace
 {
   std::vector<std::unique_ptr<VarResampleTable>> var_tables;
   std::vector<std::unique_ptr<SpeedKeyTables>>   key_tables;
   DevBuffer    window512;
+  void release();
+};
+
+/* buffers of ONE speed search / stretch: per work lane, so that the chunks of a stream can run their searches side by side */
+struct SpeedScratch
+{
   DevBuffer    sub, mags, centers, items, best, gather_pos, gather_out, ranges, energy, stretched;
   PinnedBuffer pin;
   void release();
 };
+SpeedScratch *speed_scratch (WorkLane *lane);      // created on first use
+void speed_scratch_free (WorkLane *lane);
 
 /* VResampler::setup (ratio, nchan, 16) as the closed form the kernel uses: output m reads the input window that starts at
  * (m * mant) >> shift (in the stream "hl - 1 null frames, the input, null frames"), 2 hl taps */
@@ -81,27 +90,28 @@ int resample_var_device (awm_ctx *ctx, WorkLane *lane, const float *in_d, size_t
 int resample_ratio_device (awm_ctx *ctx, WorkLane *lane, const DeviceWav& wav, double ratio, double max_in_seconds,
                            DevBuffer& out, size_t *n_out_frames);
 
-/* the context's buffer for a chunk stretched to the detected speed (decode() keeps one at a time) */
-DevBuffer& speed_stretch_buffer (awm_ctx *ctx);
+/* the lane's buffer for a chunk stretched to the detected speed (decode() keeps one at a time) */
+DevBuffer& speed_stretch_buffer (WorkLane *lane);
 
 /* get_best_clip_location (reference wmspeed.cc:533-577) */
-int speed_clip_location (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double seconds, int candidates, double *location);
+int speed_clip_location (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& wav, double seconds, int candidates, double *location);
 
 /* one pass of run_search for one key (reference wmspeed.cc:461-492, 683-719): scores of every centre x relative speed,
  * in the order centres (speeds x -n_center_steps..n_center_steps) x steps -n_steps..n_steps */
-int speed_scan (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_location, const SpeedScanParams& scan_params,
+int speed_scan (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& wav, double clip_location, const SpeedScanParams& scan_params,
                 const std::vector<double>& speeds, std::vector<SpeedScore>& scores);
 
 /* magnitude matrix of one centre speed (tests): rows x 510 x (umag, dmag), columns in the reference's order (sorted by frame) */
-int speed_mags (awm_ctx *ctx, const Key& key, const DeviceWav& wav, double clip_location, double center, double seconds,
+int speed_mags (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& wav, double clip_location, double center, double seconds,
                 std::vector<float>& out, int *rows);
 
 void   select_n_best_scores (std::vector<SpeedScore>& scores, size_t n);                          // reference wmspeed.cc:494-531
 double score_smooth_find_best (const std::vector<SpeedScore>& scores, double step, double distance); // reference wmspeed.cc:397-428
 
-/* detect_speed (reference wmspeed.cc:622-781).  best_speed / best_quality (optional) receive the last key's values
- * whether or not they pass the thresholds. */
-int detect_speed (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, bool print_results,
+/* detect_speed (reference wmspeed.cc:622-781) on a lane.  best_speed / best_quality (optional) receive the last key's values
+ * whether or not they pass the thresholds.  `report` (optional) receives the "detect_speed ..." lines the reference prints
+ * with print_results (the caller prints them: several chunks may be searching at the same time). */
+int detect_speed (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const DeviceWav& wav, std::string *report,
                   std::vector<DetectSpeedResult>& results, double *best_speed = nullptr, double *best_quality = nullptr);
 
 } // namespace awm
