@@ -793,7 +793,7 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
   const long long n_db = frame_count - 1;          // as approx_device, per slice
   const long long S = n_db - total_frames (mode);
   const int k = Params::get_n_best + 1;
-  if (n_slices <= 0 || n_db <= 0 || S <= 0)
+  if (n_slices <= 0 || n_db <= 0 || S <= 0 || Params::test_no_sync)       // (--test-no-sync: CLIP mode finds nothing, see approx_launch)
     return 0;
   if (gj.slice_frames % Params::frame_size || k > TOPK_MAX)
     {
