@@ -1203,6 +1203,15 @@ dpp_from_upper_lane (double v)                                // lane i receives
   return __hiloint2double (hi, lo);
 }
 
+/* a value that is the same in every lane of the wave, moved to scalar registers: address arithmetic and comparisons on it then
+ * run on the scalar unit instead of taking VALU issue slots (this kernel is bound by those) */
+__device__ __forceinline__ long long
+wave_uniform (long long v)
+{
+  const int lo = __builtin_amdgcn_readfirstlane (int (v)), hi = __builtin_amdgcn_readfirstlane (int (v >> 32));
+  return (long long) (((unsigned long long) (unsigned int) hi << 32) | (unsigned int) lo);
+}
+
 template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
 sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 {
@@ -1226,13 +1235,15 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
   if (stream >= a.n_streams)
     return;
   // where this stream's rows go
-  const long long out_slot = a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane + a.row_perm[stream % a.rows_per_plane] : stream;
-  const long long base = sync_stream_base (a, stream);
-  const int count = a.stream_count ? a.stream_count[stream] : a.count0;
+  const long long out_slot = wave_uniform (a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane + a.row_perm[stream % a.rows_per_plane] : stream);
+  const long long base = wave_uniform (sync_stream_base (a, stream));
+  const int count = __builtin_amdgcn_readfirstlane (a.stream_count ? a.stream_count[stream] : a.count0);
   if (count <= 0)
     return;
   long long sil_first, sil_last;
   sync_stream_range (a, stream, sil_first, sil_last);
+  sil_first = wave_uniform (sil_first);
+  sil_last = wave_uniform (sil_last);
   // every fine offset of this row inside the leading / trailing silence (syncfinder.cc:583-585; CLIP: the padding of a
   // padded clip): nothing to transform, the row is marked absent
   if (a.have && ((base + 8LL * (count - 1) + 1024) * CV < sil_first || base * CV > sil_last))
@@ -1269,7 +1280,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
           cnt += in[j] != 0.f;
         for (int o = 32; o > 0; o >>= 1)
           cnt += __shfl_xor (cnt, o);
-        nz[c] = cnt;
+        nz[c] = __builtin_amdgcn_readfirstlane (cnt);
         // in double: the recurrence carries the rounding of this transform through all fine offsets, and the Hann window is
         // applied in the frequency domain afterwards -- a float transform (1e-7 of the unwindowed content) shows where the
         // windowed content is tiny, e.g. for windows that slide into a gap of digital silence
@@ -1365,7 +1376,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
           for (int c = 0; c < CV; c++)
             {
               // every sample that carries weight is zero (position 0 has none): exactly zero frame in the reference
-              if (nz[c] - s_x0[wave][(step % SL_TILE) * CV + c] == 0)
+              if (nz[c] - __builtin_amdgcn_readfirstlane (s_x0[wave][(step % SL_TILE) * CV + c]) == 0)
                 {
                   dbA = __fadd_rn (dbA, -96.f);
                   dbB = __fadd_rn (dbB, -96.f);
@@ -1438,7 +1449,7 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
                   const double2 r = tw[b][7];
                   R[c][b] = make_double2 (acc[b].x * r.x - acc[b].y * r.y, acc[b].x * r.y + acc[b].y * r.x);
                 }
-              nz[c] += s_nzd[wave][(step % SL_TILE) * CV + c];
+              nz[c] += __builtin_amdgcn_readfirstlane (s_nzd[wave][(step % SL_TILE) * CV + c]);
               if (nz[c] == 0)
                 R[c][0] = R[c][1] = make_double2 (0.0, 0.0);
             }
