@@ -23,6 +23,7 @@ def key(p):
 
 bad = 0
 t0 = time.time()
+kept = {}                                                   # channel count -> [(device tensor, single result)]: the batch check below
 for case in range(n_cases):
     ch = int(rng.choice([1, 2, 2, 2, 3]))
     seconds = float(rng.uniform(8, max_seconds))
@@ -41,6 +42,7 @@ for case in range(n_cases):
         x[:, ch - 1] = 0                                   # one silent channel
     xd = torch.from_numpy(np.ascontiguousarray(x)).cuda()
     got = ctx.get_watermark(None, xd)
+    kept.setdefault(ch, []).append((xd, got))
     want = orc.get(None, x, ch)
     dq = max([abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(got, want)] + [0.0])
     ok = [key(p) for p in got] == [key(p) for p in want] and dq < 1e-4
@@ -53,6 +55,12 @@ for case in range(n_cases):
             if key(g) != key(w) or abs(g["sync_quality"] - w["sync_quality"]) >= 1e-4:
                 print("    gpu", key(g), g["sync_quality"], "\n    orc", key(w), w["sync_quality"])
                 break
+# the same material through awm_get_watermark_batch_d (groups of padded clips for the short ones, one per lane for the others)
+for ch, items in kept.items():
+    batch = ctx.get_watermark_batch(None, [x for x, _ in items])
+    same = sum(b == g for b, (_, g) in zip(batch, items))
+    print("batch of %d clips with %d channel(s): %d identical to one call per clip" % (len(items), ch, same), flush=True)
+    bad += len(items) - same
 for case in range(n_cases):
     ch = int(rng.choice([1, 2, 3]))
     n = int(rng.integers(1, 300000))
