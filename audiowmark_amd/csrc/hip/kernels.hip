@@ -1777,13 +1777,20 @@ constexpr int SB_WAVES = 4;           // bits per workgroup
 constexpr int SB_MAX_ITEMS = 256;     // frames_per_bit * C * 30 terms per bit (stereo: 120); more -> one thread per bit kernel
 
 __global__ void __launch_bounds__ (64 * SB_WAVES)
-soft_bits_wave_kernel (SoftBitsArgs a)
+soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
 {
   __shared__ float4 s_item[SB_WAVES][SB_MAX_ITEMS];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const long long blk = blockIdx.y;
+  // XCD-aware order (1-D grid): workgroup id runs on XCD id % 8, and all workgroups of a block go to ONE XCD, so that the
+  // block's dB matrix (1.4 MB for stereo) is fetched into one L2 instead of eight (PMC FETCH_SIZE: 278 -> 38 MB fetched per launch for
+  // 53 MB of matrices; blockIdx.y = block spread every block over all eight)
+  const long long slot = blockIdx.x >> 3;
+  const long long blk = (slot / groups_per_block) * 8 + (blockIdx.x & 7);
+  const int group = int (slot % groups_per_block);
+  if (blk >= a.n_blocks)
+    return;
   const int n_bits = a.n_data_frames / a.frames_per_bit;
-  const int bit = blockIdx.x * SB_WAVES + wave;
+  const int bit = group * SB_WAVES + wave;
   if (bit >= n_bits)
     return;
   const float *db = a.db + blk * a.block_stride;
@@ -1827,9 +1834,14 @@ launch_soft_bits (hipStream_t st, const SoftBitsArgs& a)
   const int n_bits = a.n_data_frames / a.frames_per_bit;
   if (a.frames_per_bit * a.n_channels * 30 <= SB_MAX_ITEMS)
     {
-      const dim3 grid (unsigned ((n_bits + SB_WAVES - 1) / SB_WAVES), unsigned (a.n_blocks));
-      hipLaunchKernelGGL (soft_bits_wave_kernel, grid, dim3 (64 * SB_WAVES), 0, st, a);
-      return hipGetLastError();
+      const int groups = (n_bits + SB_WAVES - 1) / SB_WAVES;
+      const long long rounds = (a.n_blocks + 7) / 8;                   // 8 blocks (one per XCD) at a time
+      const long long wgs = rounds * groups * 8;
+      if (wgs < (1LL << 31))
+        {
+          hipLaunchKernelGGL (soft_bits_wave_kernel, dim3 (unsigned (wgs)), dim3 (64 * SB_WAVES), 0, st, a, groups);
+          return hipGetLastError();
+        }
     }
   const dim3 grid (unsigned ((n_bits + 127) / 128), unsigned (a.n_blocks));
   hipLaunchKernelGGL (soft_bits_kernel, grid, dim3 (128), 0, st, a);
