@@ -209,9 +209,11 @@ int awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d
                          int n_channels, size_t max_out, awm_pattern *out);
 /* get_watermark for a batch of independent inputs (BASELINE config 5: many short clips; the reference would run one
  * `audiowmark get` process per file, wmget.cc:886-1013 each).  Clip i = n_frames[i] frames at pcm_d[i] (device pointers),
- * all with n_channels channels.  The clips are spread over the context's work lanes (n_threads host threads, <= 0: all
- * lanes).  Patterns of clip i go to out[i * max_out_per_clip ...], their number (possibly > max_out_per_clip) to n_out[i];
- * every clip's result equals awm_get_watermark_d on it.  Returns 0 or an error code. */
+ * all with n_channels channels.  Clips shorter than one block + 2 frames (51.7 s: only the ClipDecoder's START pass has work,
+ * wmget.cc:769-884) are processed in groups of 64 whose padded copies lie side by side in one buffer -- every stage of the CLIP
+ * search and of the decode is one launch per group; longer clips are spread over the context's work lanes (n_threads host
+ * threads, <= 0: all lanes).  Patterns of clip i go to out[i * max_out_per_clip ...], their number (possibly >
+ * max_out_per_clip) to n_out[i]; every clip's result equals awm_get_watermark_d on it.  Returns 0 or an error code. */
 int awm_get_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], size_t n_clips, const float *const *pcm_d,
                                const size_t *n_frames, int n_channels, int n_threads, size_t max_out_per_clip,
                                awm_pattern *out, int *n_out);
