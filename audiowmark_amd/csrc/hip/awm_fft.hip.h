@@ -84,17 +84,44 @@ radix8 (float2 (&a)[8])
   a[7] = make_float2 (fmaf (-t3.x, r, e3.x), fmaf (-t3.y, r, e3.y));
 }
 
+// Twiddles of the wave FFT in LDS.  With the plain table W[k] = e^{-2 pi i k / 512} the reads W[lane kb] and W[8 (lane & 7) kd]
+// have power-of-two strides: up to 8 lanes on one bank (PMC: 18 - 23 % of the LDS cycles of the FFT kernels were bank
+// conflicts, profiles/r02/pmc_lds_valu.txt).  The same VALUES are therefore stored in the order the lanes read them:
+//   s_tw[(kb - 1) 64 + lane]              = W[lane kb],        kb = 1..7   (unit stride over the lanes)
+//   s_tw[FFT_TW2 + (kd - 1) 8 + (lane & 7)] = W[8 (lane & 7) kd],  kd = 1..7   (8 consecutive entries, the rest broadcast)
+// and, for the inverse transform only, a second table
+//   s_tw3[nd 64 + lane]                   = W[((lane & 7) + 8 nd) (lane >> 3)],  nd = 0..7
+constexpr int FFT_TW2 = 448;
+constexpr int FFT_TW_ENTRIES = 504;     // of a float2[512]
+
+__device__ __forceinline__ void
+fft512_load_twiddles (const float2 *w512, float2 *s_tw)        // all threads of the workgroup
+{
+  for (int i = threadIdx.x; i < FFT_TW_ENTRIES; i += blockDim.x)
+    {
+      const int k = i < FFT_TW2 ? (i & 63) * ((i >> 6) + 1) : 8 * ((i - FFT_TW2) & 7) * (((i - FFT_TW2) >> 3) + 1);
+      s_tw[i] = w512[k];
+    }
+}
+
+__device__ __forceinline__ void
+fft512_load_twiddles_inverse (const float2 *w512, float2 *s_tw3)
+{
+  for (int i = threadIdx.x; i < 512; i += blockDim.x)
+    s_tw3[i] = w512[((i & 7) + 8 * (i >> 6)) * ((i & 63) >> 3)];
+}
+
 // Forward complex FFT-512 of one wave.
 //   in : z[j]  = element (lane + 64 j)
 //   out: z[kc] = Z[64 kc + 8 (lane & 7) + (lane >> 3)]
-// tw512[k] = e^{-2 pi i k / 512} (LDS or global, 512 entries); xbuf: wave-private LDS tile.
+// tw512: the LDS table of fft512_load_twiddles; xbuf: wave-private LDS tile.
 __device__ __forceinline__ void
 fft512_forward (float2 (&z)[8], float2 *xbuf, const float2 *tw512, int lane)
 {
   radix8<false> (z);
 #pragma unroll
   for (int kb = 1; kb < 8; kb++)
-    z[kb] = cmul (z[kb], tw512[lane * kb]);
+    z[kb] = cmul (z[kb], tw512[(kb - 1) * 64 + lane]);
 #pragma unroll
   for (int kb = 0; kb < 8; kb++)
     xbuf[kb * XROW + lane] = z[kb];
@@ -107,7 +134,7 @@ fft512_forward (float2 (&z)[8], float2 *xbuf, const float2 *tw512, int lane)
   radix8<false> (z);
 #pragma unroll
   for (int kd = 1; kd < 8; kd++)
-    z[kd] = cmul (z[kd], tw512[8 * lo * kd]);
+    z[kd] = cmul (z[kd], tw512[FFT_TW2 + (kd - 1) * 8 + lo]);
 #pragma unroll
   for (int kd = 0; kd < 8; kd++)
     xbuf[hi * XROW + 9 * kd + lo] = z[kd];
@@ -123,13 +150,13 @@ fft512_forward (float2 (&z)[8], float2 *xbuf, const float2 *tw512, int lane)
 //   in : z[kc] = Zd[64 kc + 8 (lane & 7) + (lane >> 3)]
 //   out: z[j]  = time element (lane + 64 j)
 __device__ __forceinline__ void
-fft512_inverse (float2 (&z)[8], float2 *xbuf, const float2 *tw512, int lane)
+fft512_inverse (float2 (&z)[8], float2 *xbuf, const float2 *tw512, const float2 *tw3, int lane)
 {
   const int lo = lane & 7, hi = lane >> 3;
   radix8<true> (z);
 #pragma unroll
   for (int nc = 1; nc < 8; nc++)
-    z[nc] = cmulc (z[nc], tw512[8 * nc * lo]);
+    z[nc] = cmulc (z[nc], tw512[FFT_TW2 + (nc - 1) * 8 + lo]);
 #pragma unroll
   for (int nc = 0; nc < 8; nc++)
     xbuf[hi * XROW + 9 * lo + nc] = z[nc];
@@ -141,7 +168,7 @@ fft512_inverse (float2 (&z)[8], float2 *xbuf, const float2 *tw512, int lane)
   radix8<true> (z);
 #pragma unroll
   for (int nd = 0; nd < 8; nd++)
-    z[nd] = cmulc (z[nd], tw512[(lo + 8 * nd) * hi]);
+    z[nd] = cmulc (z[nd], tw3[nd * 64 + lane]);
 #pragma unroll
   for (int nd = 0; nd < 8; nd++)
     xbuf[hi * XROW + nd * 8 + lo] = z[nd];

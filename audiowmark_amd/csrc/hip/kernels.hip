@@ -32,8 +32,7 @@ typedef const int __attribute__ ((address_space (4))) *const_int_ptr;
 __device__ __forceinline__ void
 load_shared_tables (const DevTables& t, float2 *s_tw, float *s_win, float2 *s_twb)
 {
-  for (int i = threadIdx.x; i < 512; i += blockDim.x)
-    s_tw[i] = t.tw512[i];
+  fft512_load_twiddles (t.tw512, s_tw);
   for (int i = threadIdx.x; i < 1024; i += blockDim.x)
     s_win[i] = t.window[i];
   if (s_twb)
@@ -187,7 +186,7 @@ zdpos (int k)
 // one frame-channel: windowed samples -> delta signal d (time domain, unnormalised c2r like FFTW)
 __device__ __forceinline__ void
 frame_delta (float2 (&z)[8], const int8_t *mod_row, float nd_up, float nd_down,
-             float2 *xbuf, float2 *zd, const float2 *s_tw, const float2 *s_twb, int lane)
+             float2 *xbuf, float2 *zd, const float2 *s_tw, const float2 *s_tw3, const float2 *s_twb, int lane)
 {
   fft512_forward (z, xbuf, s_tw, lane);
   xbuf[0 * 64 + lane] = z[0];
@@ -229,7 +228,7 @@ frame_delta (float2 (&z)[8], const int8_t *mod_row, float nd_up, float nd_down,
   z[6] = zd[2 * 64 + lane];
   z[7] = zd[3 * 64 + lane];
   wave_sync();
-  fft512_inverse (z, xbuf, s_tw, lane);
+  fft512_inverse (z, xbuf, s_tw, s_tw3, lane);
 }
 
 __device__ __forceinline__ float
@@ -245,6 +244,7 @@ template<int CV, bool OPAQUE> __device__ __forceinline__ void
 add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, int block_frames)
 {
   __shared__ float2 s_tw[512];
+  __shared__ float2 s_tw3[512];                            // twiddles of the inverse transform's last stage (awm_fft.hip.h)
   __shared__ float  s_win[1024];
   __shared__ float2 s_twb[NB];
   __shared__ float2 s_x[WAVES][XBUF_ELEMS];
@@ -252,6 +252,7 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
   const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
   int lane = lane0;
   load_shared_tables (t, s_tw, s_win, s_twb);
+  fft512_load_twiddles_inverse (t.tw512, s_tw3);
   for (int i = lane; i < 256; i += 64)
     s_zd[wave][i] = make_float2 (0.f, 0.f);
   __syncthreads();
@@ -326,7 +327,7 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
           for (int c = 0; c < CV; c++)
             {
               window_pack (in[c], s_win, lane, d[c]);
-              frame_delta (d[c], mod_row, a.neg_delta_up, a.neg_delta_down, xbuf, zd, s_tw, s_twb, lane);
+              frame_delta (d[c], mod_row, a.neg_delta_up, a.neg_delta_down, xbuf, zd, s_tw, s_tw3, s_twb, lane);
             }
         }
       else

@@ -187,11 +187,9 @@ speed_mags_kernel (DevTables t, SpeedMagsArgs a)
   const int row0 = blockIdx.x * SPEED_TILE;
   if (row0 >= cd.rows)
     return;
+  fft512_load_twiddles (t.tw512, s_tw);
   for (int i = threadIdx.x; i < 512; i += blockDim.x)
-    {
-      s_tw[i] = t.tw512[i];
-      s_win[i] = a.window512[i];
-    }
+    s_win[i] = a.window512[i];
   __syncthreads();
 
   const int C = a.n_channels;
