@@ -132,7 +132,8 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   da.tile_frames = 32;
   if (!db_ready)                                     // (else: another key of the same `get` left these matrices in the workspace)
     {
-      ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_shifts) * n_db * (4096.0 * wav.n_channels + 324.0), st);
+      // algorithmic bytes: the samples ONCE (the four shifts of a tile read the same samples; they share one XCD's L2) + one dB row per frame and shift
+      ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_db) * 4096.0 * wav.n_channels + double (n_shifts) * n_db * 324.0, st);
       AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
     }
 
@@ -833,7 +834,7 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
   da.have_stream_stride = ld;
   da.tile_frames = 32;
   {
-    ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_planes) * n_db * (4096.0 * group.n_channels + 324.0), st);
+    ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_slices) * n_db * 4096.0 * group.n_channels + double (n_planes) * n_db * 324.0, st);
     AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
   }
   awmk::SyncScanArgs sa {};
