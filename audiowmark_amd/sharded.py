@@ -236,9 +236,10 @@ def gather_patterns(dist, my_chunk_patterns):
         k = min(len(mine), capacity)
         block[16:16 + k * rec.itemsize] = mine[:k].view(np.uint8).reshape(-1)
         t = torch.from_numpy(block).to(dev)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        comm.all_gather(parts, t)
-        blocks = [p.cpu().numpy() for p in parts]
+        gathered = torch.empty((world, t.numel()), dtype=t.dtype, device=t.device)     # one buffer, one copy back
+        comm.all_gather(list(gathered.unbind(0)), t)
+        host = gathered.cpu().numpy()
+        blocks = [host[r] for r in range(world)]
         counts = [int(np.frombuffer(b[:8].tobytes(), np.int64)[0]) for b in blocks]
         return blocks, counts
 
