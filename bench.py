@@ -5,7 +5,9 @@ One step = `add` (STFT -> band edit -> inverse -> overlap-add -> mix -> limiter)
 search + refine, soft-bit extraction, Viterbi, merge) over synthetic white noise that is already resident in HBM.
 
   python bench.py --gpus 1 --steps K --warmup W                     BASELINE.json configs[1]: 60 min stereo per GPU
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W                     N > 1 without a launcher: bench.py starts its N ranks itself
+                                                                    (re-executes under torch.distributed.run, 127.0.0.1 rendezvous)
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W     (ranks from the launcher)
   ... bench.py --gpus N --config 8h                                 configs[3]: ONE 8 h stream over the N ranks (strong scaling)
   ... bench.py --gpus N --config clips                              configs[4]: 1024 clips of 30 s over the N ranks (replicas)
 
@@ -268,6 +270,57 @@ def read_prof(awm, ctx):
     return prof
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def ensure_ranks(args, argv):
+    """`--gpus N` is the number of ranks of the job.  Under a launcher (WORLD_SIZE set) the two must agree; without one and
+    N > 1 this process REPLACES itself by `python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py <same
+    arguments>` (one rank per GPU, rendezvous on 127.0.0.1), so that the plain command `python bench.py --gpus N` yields a line
+    with n_gpus == ranks_seen == N.  Fails loudly when the node has fewer than N GPUs."""
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:
+        if int(env_world) != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks")
+        return
+    if args.gpus <= 1:
+        return
+    if not args.rank_check_only:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but this node has {have} visible GPU(s)")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os.execv(sys.executable, cmd)
+
+
+def rank_check(args):
+    """--rank-check-only: the rendezvous of the N ranks and nothing else, over gloo, without touching a GPU (CPU test of the
+    launch path: `python bench.py --gpus 2 --rank-check-only` must report ranks_seen == 2)."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        dist.init_process_group("gloo")
+        t = torch.ones(1, dtype=torch.float64)
+        dist.all_reduce(t)
+        seen = int(t.item())
+        rank = dist.get_rank()
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen, rank = 1, 0
+    if rank == 0:
+        print(json.dumps({"rank_check_only": True, "n_gpus": world, "ranks_seen": seen, "gpus_argument": args.gpus}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -285,7 +338,12 @@ def main():
     ap.add_argument("--lanes", type=int, default=4, help="lanes `get` spreads the chunks of a stream over (1: kernels back to back, for profiling)")
     ap.add_argument("--sharded", action="store_true",
                     help="debug: take the multi-GPU (ShardedStream / torch.distributed) code path even with one process")
+    ap.add_argument("--rank-check-only", action="store_true",
+                    help="start the ranks (as --gpus N does), count them over gloo and stop: CPU test of the launch path")
     args = ap.parse_args()
+    ensure_ranks(args, sys.argv[1:])
+    if args.rank_check_only:
+        return rank_check(args)
 
     import torch
     import audiowmark_amd as awm
