@@ -19,9 +19,8 @@ def library_path():
     return os.path.join(_HERE, "libawm_hip.so")
 
 
-# more hardware queues than the default 4, so that the lanes of `get` do not share one (see bench.py); only effective if the
-# HIP runtime has not been initialised yet by whoever imported us
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# (Runtime settings are the application's business, not this module's: a process that wants every lane of `get` on a hardware
+# queue of its own exports GPU_MAX_HW_QUEUES=16 before its first HIP call -- bench.py and tests/conftest.py do.)
 
 
 def _load_hip_runtime():
@@ -167,6 +166,38 @@ lib.awm_speed_clip_location_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.
 lib.awm_speed_mags_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_size_t, _vp]
 lib.awm_speed_scan_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double, C.c_int, C.c_int,
                                  _vp, C.c_int, C.c_size_t, _vp, _vp]
+
+
+class Params(C.Structure):
+    """awm_params (include/awm_hip.h): the reference's Params, process-wide or per context"""
+    _fields_ = [("struct_size", C.c_size_t), ("water_delta", C.c_double), ("mix", C.c_int), ("hard", C.c_int), ("strict", C.c_int),
+                ("snr", C.c_int), ("payload_size", C.c_int), ("frames_per_bit", C.c_int), ("sync_threshold2", C.c_double),
+                ("get_n_best", C.c_int), ("get_chunk_size", C.c_double), ("detect_speed", C.c_int), ("detect_speed_patient", C.c_int),
+                ("try_speed", C.c_double), ("test_speed", C.c_double), ("test_cut", C.c_int), ("test_no_sync", C.c_int),
+                ("test_no_limiter", C.c_int), ("test_truncate", C.c_int)]
+
+    def __init__(self, **kw):
+        super().__init__()
+        lib.awm_params_init(C.byref(self))
+        for k, v in kw.items():
+            if k not in dict(self._fields_):
+                raise TypeError(f"awm_params has no field {k}")
+            setattr(self, k, v)
+
+
+lib.awm_params_init.argtypes = [C.POINTER(Params)]
+lib.awm_params_init.restype = None
+lib.awm_set_global_params.argtypes = [C.POINTER(Params)]
+lib.awm_ctx_set_params.argtypes = [_vp, C.POINTER(Params)]
+lib.awm_ctx_get_params.argtypes = [_vp, C.POINTER(Params)]
+lib.awm_get_watermark_keys_d.argtypes = [_vp, _vp, C.c_int, _vp, C.c_size_t, C.c_int, C.c_size_t, _vp, _vp]
+lib.awm_get_watermark_keys_file.argtypes = [_vp, _vp, C.c_int, C.c_char_p, C.POINTER(RawFormat), C.c_size_t, _vp, _vp]
+
+
+def set_global_params(**kw):
+    """the process-wide parameter set from the reference's defaults + the given fields (awm_set_global_params)"""
+    p = Params(**kw)
+    _check(lib.awm_set_global_params(C.byref(p)), "awm_set_global_params")
 
 
 def _check(rc, what):
@@ -662,6 +693,45 @@ class Context:
     def get_watermark(self, key, pcm):
         n, ch = _pcm_shape(pcm)
         return self._patterns(lib.awm_get_watermark_d, "awm_get_watermark_d", self._h, key_bytes(key), _dev_ptr(pcm), n, ch)
+
+    def set_params(self, params=None, **kw):
+        """Give this context its own parameter set (awm_ctx_set_params): a Params object, or the fields that differ from what is
+        in force now as keywords; set_params() without anything returns the context to the process-wide set."""
+        if params is None and kw:
+            params = self.get_params()
+            for k, v in kw.items():
+                if k not in dict(Params._fields_):
+                    raise TypeError(f"awm_params has no field {k}")
+                setattr(params, k, v)
+        _check(lib.awm_ctx_set_params(self._h, C.byref(params) if params is not None else None), "awm_ctx_set_params")
+
+    def get_params(self):
+        p = Params()
+        _check(lib.awm_ctx_get_params(self._h, C.byref(p)), "awm_ctx_get_params")
+        return p
+
+    def _patterns_keys(self, fn, what, keys, *args, max_out=4096):
+        flat = b"".join(key_bytes(k) for k in keys)
+        while True:
+            buf = self._pattern_buffer(max_out)
+            which = (C.c_int * max_out)()
+            cnt = _check(fn(self._h, flat, len(keys), *args, max_out, C.cast(buf, C.c_void_p), which), what)
+            if cnt <= max_out:
+                pats = patterns_to_dicts(buf, cnt)
+                for p, k in zip(pats, which):
+                    p["key_index"] = int(k)
+                return pats
+            max_out = cnt
+
+    def get_watermark_keys(self, keys, pcm):
+        """get_watermark with the reference's key LIST (`--key a --key b`): one pass over the material, every pattern tells the
+        position of its key in the list ("key_index")."""
+        n, ch = _pcm_shape(pcm)
+        return self._patterns_keys(lib.awm_get_watermark_keys_d, "awm_get_watermark_keys_d", keys, _dev_ptr(pcm), n, ch)
+
+    def get_watermark_keys_file(self, keys, in_path, raw_in=None):
+        return self._patterns_keys(lib.awm_get_watermark_keys_file, "awm_get_watermark_keys_file", keys, os.fsencode(in_path),
+                                   C.byref(raw_in) if raw_in is not None else None)
 
     def get_watermark_batch(self, key, clips, n_threads=0, max_out_per_clip=64):
         """get_watermark of many independent resident clips (same channel count), spread over the context's work lanes;

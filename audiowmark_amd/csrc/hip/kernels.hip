@@ -206,11 +206,15 @@ frame_delta (float2 (&z)[8], const int8_t *mod_row, float nd_up, float nd_down,
           float2 D = make_float2 (0.f, 0.f);
           if (mod)
             {
-              // apply_frame_mod (reference wmadd.cc:61-84)
-              const float mag = hypotf (X.x, X.y);
-              if (mag > 1e-7f)
+              // apply_frame_mod (reference wmadd.cc:61-84): D = X (|X|^e - 1) for |X| > 1e-7, e = -+ water_delta.
+              // |X|^e = exp2 (e / 2 * log2 (|X|^2)) on the hardware's v_log_f32 / v_exp_f32 (1 ulp each; the exponent
+              // e / 2 * log2 is at most ~0.3 in magnitude, so the factor is good to ~2e-7 relative and the watermark
+              // signal -- 1 % of the spectrum -- to ~1e-8 of the sample scale; libm's hypotf + powf cost 250 VALU
+              // instructions per pass here, a sixth of the kernel).  |X|^2 of a bin that passes the test is a normal float.
+              const float abs2 = X.x * X.x + X.y * X.y;
+              if (abs2 > 1e-14f)
                 {
-                  const float s = powf (mag, mod == 1 ? nd_up : nd_down) - 1.0f;
+                  const float s = __builtin_amdgcn_exp2f (__builtin_amdgcn_logf (abs2) * (0.5f * (mod == 1 ? nd_up : nd_down))) - 1.0f;
                   D = make_float2 (X.x * s, X.y * s);
                 }
             }
@@ -249,7 +253,9 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
   __shared__ float2 s_twb[NB];
   __shared__ float2 s_x[WAVES][XBUF_ELEMS];
   __shared__ float2 s_zd[WAVES][256];
-  const int lane0 = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wave index is wave-uniform: in a scalar register, the frame loop's counters, bounds tests and base addresses run on the
+  // scalar unit (the compiler cannot see that threadIdx.x >> 6 is the same for all lanes)
+  const int lane0 = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
   int lane = lane0;
   load_shared_tables (t, s_tw, s_win, s_twb);
   fft512_load_twiddles_inverse (t.tw512, s_tw3);
@@ -391,8 +397,30 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
           tail_in[c][1] = in[c][15];
         }
 
-      // stores (bounded by the span's sample count) + maxima
-      if (own)
+      // stores (bounded by the span's sample count) + maxima.  Common case (all but the last frame of the stream, and 42 of 43
+      // frames have no limiter block boundary inside): plain stores and ONE running maximum, no per-value bounds tests.
+      const bool whole_m = (m + 1) * 1024 <= a.n_frames;
+      if (own && whole_m && bound >= 1024)
+        {
+          const long long base = m * 1024;
+#pragma unroll
+          for (int j = 0; j < 7; j++)
+            {
+              const long long ls = base + 2 * (lane + 64 * j);
+              if (CV == 2)
+                *reinterpret_cast<float4 *> (a.out + ls * 2) = make_float4 (o[0][2 * j], o[CV - 1][2 * j], o[0][2 * j + 1], o[CV - 1][2 * j + 1]);
+              else
+                {
+                  float *p = a.out + ls * C + ch0;
+                  p[0] = o[0][2 * j];
+                  p[C] = o[0][2 * j + 1];
+                }
+#pragma unroll
+              for (int c = 0; c < CV; c++)
+                max0 = fmaxf (max0, fmaxf (fabsf (o[c][2 * j]), fabsf (o[c][2 * j + 1])));
+            }
+        }
+      else if (own)
         {
           const long long base = m * 1024;
 #pragma unroll
@@ -426,7 +454,22 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
                 }
             }
         }
-      if (own_prev)
+      if (own_prev && m * 1024 <= a.n_frames && pbound >= 1024)
+        {
+          const long long ls = (m - 1) * 1024 + 896 + 2 * lane;
+          if (CV == 2)
+            *reinterpret_cast<float4 *> (a.out + ls * 2) = make_float4 (o[0][14], o[CV - 1][14], o[0][15], o[CV - 1][15]);
+          else
+            {
+              float *p = a.out + ls * C + ch0;
+              p[0] = o[0][14];
+              p[C] = o[0][15];
+            }
+#pragma unroll
+          for (int c = 0; c < CV; c++)
+            pmax0 = fmaxf (pmax0, fmaxf (fabsf (o[c][14]), fabsf (o[c][15])));
+        }
+      else if (own_prev)
         {
           const int x = 896 + 2 * lane;
           const long long ls = (m - 1) * 1024 + x;

@@ -159,19 +159,24 @@ is_regular (FILE *f)
 
 /* returns bytes read (short only at EOF / on error, `failed` tells which) */
 size_t
-bulk_read (FILE *f, unsigned char *buf, size_t bytes, bool& failed)
+bulk_read (FILE *f, unsigned char *buf, size_t bytes, bool& failed, int *err_out = nullptr)
 {
   failed = false;
+  if (err_out)
+    *err_out = 0;
   const off_t pos = ftello (f);
   if (pos < 0)
     {
       failed = true;
+      if (err_out)
+        *err_out = errno;
       return 0;
     }
   const int fd = fileno (f);
   const size_t part = (bytes / BULK_IO_THREADS + 4095) & ~size_t (4095);
   size_t done[BULK_IO_THREADS] = {};
   bool bad[BULK_IO_THREADS] = {};
+  int  err[BULK_IO_THREADS] = {};                          // errno is per thread: every worker keeps its own
   auto work = [&] (int t) {
     const size_t lo = std::min (bytes, part * t), hi = std::min (bytes, part * (t + 1));
     size_t n = 0;
@@ -183,6 +188,7 @@ bulk_read (FILE *f, unsigned char *buf, size_t bytes, bool& failed)
         if (r <= 0)
           {
             bad[t] = r < 0;
+            err[t] = r < 0 ? errno : 0;
             break;
           }
         n += size_t (r);
@@ -198,13 +204,16 @@ bulk_read (FILE *f, unsigned char *buf, size_t bytes, bool& failed)
   size_t total = 0;
   for (int t = 0; t < BULK_IO_THREADS; t++)
     {
+      if (bad[t] && !failed && err_out)
+        *err_out = err[t];
       failed = failed || bad[t];
       const size_t want = std::min (bytes, part * (t + 1)) - std::min (bytes, part * t);
       total += done[t];
       if (done[t] < want)
         break;                                             // EOF inside this part: later parts lie beyond it
     }
-  fseeko (f, pos + off_t (total), SEEK_SET);
+  if (!failed)                                             // (after an error the caller discards the data: the position stays)
+    fseeko (f, pos + off_t (total), SEEK_SET);
   return total;
 }
 
@@ -464,6 +473,14 @@ public:
     if (err)
       return err;
     m_format = format;
+    if (!pipe_mode && data_size && is_regular (m_file))
+      {
+        // a header may claim more than the file holds (truncated files, crafted ds64 sizes): what can be read is what counts
+        struct stat sb;
+        const off_t pos = ftello (m_file);
+        if (pos >= 0 && fstat (fileno (m_file), &sb) == 0 && sb.st_size >= pos)
+          data_size = std::min<uint64_t> (data_size, uint64_t (sb.st_size - pos));
+      }
     if (!pipe_mode && data_size && format.n_channels)
       m_n_frames = m_frames_left = data_size / (size_t (format.n_channels) * m_codec->sample_width());
     return Error::Code::NONE;
@@ -510,9 +527,10 @@ public:
     if (max_frames * frame_bytes >= BULK_IO_MIN && is_regular (m_file))
       {
         bool failed;
-        got_frames = bulk_read (m_file, dst, max_frames * frame_bytes, failed) / frame_bytes;
+        int err = 0;
+        got_frames = bulk_read (m_file, dst, max_frames * frame_bytes, failed, &err) / frame_bytes;
         if (failed)
-          return Error (string_printf ("error reading wav input sample data: %s", strerror (errno)));
+          return Error (string_printf ("error reading wav input sample data: %s", strerror (err)));
       }
     else
       got_frames = max_frames ? fread (dst, frame_bytes, max_frames, m_file) : 0;
@@ -708,7 +726,7 @@ public:
 std::unique_ptr<AudioInputStream>
 AudioInputStream::create (const std::string& filename, Error& err)
 {
-  if (Params::input_format == Format::RAW)
+  if (params().input_format == Format::RAW)
     {
       auto s = std::make_unique<RawInputStream>();
       err = s->open (filename, StreamParams::raw_input_format);
@@ -716,10 +734,10 @@ AudioInputStream::create (const std::string& filename, Error& err)
         return nullptr;
       return s;
     }
-  if (Params::input_format == Format::AUTO || Params::input_format == Format::WAV_PIPE)
+  if (params().input_format == Format::AUTO || params().input_format == Format::WAV_PIPE)
     {
       auto s = std::make_unique<WavInputStream>();
-      err = s->open (filename, Params::input_format == Format::WAV_PIPE);
+      err = s->open (filename, params().input_format == Format::WAV_PIPE);
       if (err)
         return nullptr;
       return s;
@@ -732,7 +750,7 @@ std::unique_ptr<AudioOutputStream>
 AudioOutputStream::create (const std::string& filename, int n_channels, int sample_rate, int bit_depth, Encoding encoding,
                            size_t n_frames, Error& err)
 {
-  if (Params::output_format == Format::RAW)
+  if (params().output_format == Format::RAW)
     {
       auto s = std::make_unique<RawOutputStream>();
       err = s->open (filename, StreamParams::raw_output_format);
@@ -741,8 +759,8 @@ AudioOutputStream::create (const std::string& filename, int n_channels, int samp
       return s;
     }
   auto s = std::make_unique<WavOutputStream>();
-  err = s->open (filename, n_channels, sample_rate, bit_depth, encoding, n_frames, Params::output_format == Format::WAV_PIPE,
-                 Params::output_format == Format::RF64);
+  err = s->open (filename, n_channels, sample_rate, bit_depth, encoding, n_frames, params().output_format == Format::WAV_PIPE,
+                 params().output_format == Format::RF64);
   if (err)
     return nullptr;
   return s;

@@ -158,10 +158,10 @@ shared_options()
   return {
     { Option::VALUE, "--short", [] (const string&) { die ("audiowmark: --short payloads are not supported by the GPU path\n"); } },
     { Option::VALUE, "--frames-per-bit", [] (const string& v) {
-        if (to_int (v) != Params::frames_per_bit)
-          die (string_printf ("audiowmark: --frames-per-bit other than %d is not supported by the GPU path\n", Params::frames_per_bit));
+        if (to_int (v) != params().frames_per_bit)
+          die (string_printf ("audiowmark: --frames-per-bit other than %d is not supported by the GPU path\n", params().frames_per_bit));
       } },
-    { Option::FLAG, "--linear", [] (const string&) { Params::mix = false; } },
+    { Option::FLAG, "--linear", [] (const string&) { params().mix = false; } },
   };
 }
 
@@ -171,14 +171,14 @@ stream_options (bool with_output)
   RawFormat& in = StreamParams::raw_input_format;
   RawFormat& out = StreamParams::raw_output_format;
   Options o {
-    { Option::VALUE, "--input-format", [] (const string& v) { Params::input_format = to_format (v); } },
+    { Option::VALUE, "--input-format", [] (const string& v) { params().input_format = to_format (v); } },
   };
   if (with_output)
-    o.push_back ({ Option::VALUE, "--output-format", [] (const string& v) { Params::output_format = to_format (v); } });
+    o.push_back ({ Option::VALUE, "--output-format", [] (const string& v) { params().output_format = to_format (v); } });
   o.push_back ({ Option::VALUE, "--format", [with_output] (const string& v) {
-      Params::input_format = to_format (v);
+      params().input_format = to_format (v);
       if (with_output)
-        Params::output_format = Params::input_format;
+        params().output_format = params().input_format;
     } });
   const Options raw {
     { Option::VALUE, "--raw-input-endian", [&in] (const string& v) { in.endian = to_endian (v); } },
@@ -200,7 +200,7 @@ stream_options (bool with_output)
 void
 check_stream_options()
 {
-  if (Params::input_format == Format::RF64)
+  if (params().input_format == Format::RF64)
     die ("audiowmark: using rf64 as input format has no effect\n");
 }
 
@@ -216,11 +216,11 @@ key_options (vector<Key>& keys)
 Options
 add_options()
 {
-  Options o { { Option::FLAG, "--snr", [] (const string&) { Params::snr = true; } } };
+  Options o { { Option::FLAG, "--snr", [] (const string&) { params().snr = true; } } };
   const Options s = stream_options (true);
   o.insert (o.end(), s.begin(), s.end());
-  o.push_back ({ Option::FLAG, "--test-no-limiter", [] (const string&) { Params::test_no_limiter = true; } });
-  o.push_back ({ Option::VALUE, "--strength", [] (const string& v) { Params::water_delta = to_float (v) / 1000; } });
+  o.push_back ({ Option::FLAG, "--test-no-limiter", [] (const string&) { params().test_no_limiter = true; } });
+  o.push_back ({ Option::VALUE, "--strength", [] (const string& v) { params().water_delta = to_float (v) / 1000; } });
   return o;
 }
 
@@ -228,29 +228,29 @@ Options
 get_options (int& speed_options)
 {
   Options o {
-    { Option::VALUE, "--test-cut", [] (const string& v) { Params::test_cut = to_int (v); } },
-    { Option::VALUE, "--test-truncate", [] (const string& v) { Params::test_truncate = to_int (v); } },
-    { Option::FLAG, "--hard", [] (const string&) { Params::hard = true; } },
-    { Option::FLAG, "--test-no-sync", [] (const string&) { Params::test_no_sync = true; } },
-    { Option::FLAG, "--detect-speed", [&speed_options] (const string&) { Params::detect_speed = true; speed_options++; } },
-    { Option::FLAG, "--detect-speed-patient", [&speed_options] (const string&) { Params::detect_speed_patient = true; speed_options++; } },
-    { Option::VALUE, "--try-speed", [&speed_options] (const string& v) { Params::try_speed = to_float (v); speed_options++; } },
-    { Option::VALUE, "--test-speed", [] (const string& v) { Params::test_speed = to_float (v); } },
-    { Option::VALUE, "--json", [] (const string& v) { Params::json_output = v; } },
+    { Option::VALUE, "--test-cut", [] (const string& v) { params().test_cut = to_int (v); } },
+    { Option::VALUE, "--test-truncate", [] (const string& v) { params().test_truncate = to_int (v); } },
+    { Option::FLAG, "--hard", [] (const string&) { params().hard = true; } },
+    { Option::FLAG, "--test-no-sync", [] (const string&) { params().test_no_sync = true; } },
+    { Option::FLAG, "--detect-speed", [&speed_options] (const string&) { params().detect_speed = true; speed_options++; } },
+    { Option::FLAG, "--detect-speed-patient", [&speed_options] (const string&) { params().detect_speed_patient = true; speed_options++; } },
+    { Option::VALUE, "--try-speed", [&speed_options] (const string& v) { params().try_speed = to_float (v); speed_options++; } },
+    { Option::VALUE, "--test-speed", [] (const string& v) { params().test_speed = to_float (v); } },
+    { Option::VALUE, "--json", [] (const string& v) { params().json_output = v; } },
     { Option::VALUE, "--chunk-size", [] (const string& v) {
         const float minutes = to_float (v);
         if (minutes < 10)
           die ("audiowmark: --chunk-size needs to be at least 10 minutes\n");
-        Params::get_chunk_size = minutes;
+        params().get_chunk_size = minutes;
       } },
-    { Option::VALUE, "--sync-threshold", [] (const string& v) { Params::sync_threshold2 = to_float (v); } },
+    { Option::VALUE, "--sync-threshold", [] (const string& v) { params().sync_threshold2 = to_float (v); } },
     { Option::VALUE, "--n-best", [] (const string& v) {
         const int n = to_int (v);
         if (n < 0)
           die ("audiowmark: --n-best should not be a negative number\n");
-        Params::get_n_best = n;
+        params().get_n_best = n;
       } },
-    { Option::VALUE, "--strength", [] (const string& v) { Params::water_delta = to_float (v) / 1000; } },
+    { Option::VALUE, "--strength", [] (const string& v) { params().water_delta = to_float (v) / 1000; } },
   };
   // the reference's get / cmp always open the input through libsndfile; this build has the input options of add instead
   const Options s = stream_options (false);
@@ -282,7 +282,7 @@ print_usage()
     "Options for add / get / cmp:\n"
     "  --key <file>            load watermarking key from file\n";
   fputs (text, stdout);
-  printf ("  --strength <s>          set watermark strength              [%.6g]\n\n", Params::water_delta * 1000);
+  printf ("  --strength <s>          set watermark strength              [%.6g]\n\n", params().water_delta * 1000);
   fputs ("  --input-format raw      use raw stream as input\n"
          "  --output-format raw     use raw stream as output\n"
          "  --format raw            use raw stream as input and output\n\n"
@@ -355,7 +355,7 @@ cmd_get (vector<string>& args, bool cmp)
     die ("audiowmark: can only use one option: --detect-speed or --detect-speed-patient or --try-speed\n");
   check_stream_options();
   if (cmp)
-    apply_options (args, { { Option::VALUE, "--expect-matches", [] (const string& v) { Params::expect_matches = to_int (v); } } });
+    apply_options (args, { { Option::VALUE, "--expect-matches", [] (const string& v) { params().expect_matches = to_int (v); } } });
   apply_options (args, key_options (keys));
   const auto pos = cmp ? positional ("cmp", args, { "watermarked_wav", "message_hex" }) : positional ("get", args, { "watermarked_wav" });
   Gpu gpu;
@@ -475,7 +475,7 @@ main (int argc, char **argv)
   apply_options (args, {
     { Option::FLAG, "--quiet", [] (const string&) { set_log_level (Log::WARNING); } },
     { Option::FLAG, "-q", [] (const string&) { set_log_level (Log::WARNING); } },
-    { Option::FLAG, "--strict", [] (const string&) { Params::strict = true; } },
+    { Option::FLAG, "--strict", [] (const string&) { params().strict = true; } },
   });
   if (args.empty())
     {

@@ -33,7 +33,7 @@ check_ctx (awm_ctx *ctx)
       set_error ("hipSetDevice: " + hip_error_string (e));
       return AWM_ERR_HIP;
     }
-  if (Params::frames_per_bit != 2 || Params::payload_size != 128)
+  if (params().frames_per_bit != 2 || params().payload_size != 128)
     {
       // the kernels are specialised for the default block geometry (2226 frames); the reference's undocumented
       // --frames-per-bit and the deprecated --short payloads are out of scope
@@ -42,6 +42,12 @@ check_ctx (awm_ctx *ctx)
     }
   return 0;
 }
+
+// prologue of every entry point that takes a context: the context's own settings (if it has any) are in force for the calling
+// thread until the entry point returns, the device is selected, unsupported block geometries are refused
+#define AWM_ENTER(ctx) \
+  awm::ParamsBind params_bind__ ((ctx) ? (ctx)->own_params.get() : nullptr); \
+  if (int rc__ = check_ctx (ctx)) return rc__
 
 int
 frames_per_span (awm_ctx *ctx, long long n_frames1024)
@@ -107,7 +113,7 @@ int
 awm_stft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, size_t start_index, size_t hop,
             size_t frame_count, float *out_d)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (!pcm_d || !out_d || n_channels < 1)
     {
       set_error ("awm_stft_d: bad argument");
@@ -127,7 +133,7 @@ awm_stft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, s
 int
 awm_add_init_block_max_d (awm_ctx *ctx, float *block_max_d, size_t n_blocks)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   unsigned int bits;
   std::memcpy (&bits, &LIMITER_CEILING, sizeof (bits));
   AWM_HIP_CHECK (awmk::launch_fill_u32 (ctx->stream, reinterpret_cast<unsigned int *> (block_max_d), bits, n_blocks));
@@ -147,7 +153,7 @@ add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames
   a.n_frames = (long long) n_frames;
   a.n_channels = n_channels;
   a.frame_mod = frame_mod_dev;
-  // powf (mag, -Params::water_delta * data_bit_sign): double product converted to float (reference wmadd.cc:79)
+  // powf (mag, -params().water_delta * data_bit_sign): double product converted to float (reference wmadd.cc:79)
   a.neg_delta_up = float (-water_delta * 1);
   a.neg_delta_down = float (-water_delta * -1);
   a.first_frame = (long long) first_frame;
@@ -171,7 +177,7 @@ awm_add_mix_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frame
                const float *halo_before_d, const float *halo_after_d,
                float *block_max_d, size_t first_block, size_t n_blocks)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (!pcm_in_d || !out_d || !frame_mod || n_channels < 1)
     {
       set_error ("awm_add_mix_d: bad argument");
@@ -188,7 +194,7 @@ int
 awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels, size_t first_sample,
                  const float *block_max_d, size_t first_block, size_t n_blocks)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   const size_t tab_entries = awmk::limiter_tab_entries ((long long) n_frames, (long long) first_sample, LIMITER_BLOCK);
   if (int rc = ctx->ws_limit_tab.reserve ((tab_entries + 1) * sizeof (float2))) return rc;
   ProfScope ps (ctx, PROF_LIMITER, double (n_frames) * n_channels * 8.0);
@@ -304,7 +310,7 @@ int
 awm_resample_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_channels, int rate_in, int rate_out,
                 float *out_d, size_t n_out_frames)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   const RateConverter conv = rate_converter (ctx, rate_in, rate_out);
   if (!conv.ok())
     return AWM_ERR_ARG;
@@ -424,7 +430,7 @@ int
 awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, int n_channels, size_t tile_frames1024,
                        awm_add_stream **out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (!out || n_channels < 1 || tile_frames1024 < 128)
     {
       set_error ("awm_add_stream_create: bad argument (a tile is at least 128 frames: the limiter looks one second ahead)");
@@ -437,7 +443,7 @@ awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_
   s->ctx = ctx;
   s->C = n_channels;
   s->tile = tile_frames1024 * Params::frame_size;
-  s->limiter = !Params::test_no_limiter;
+  s->limiter = !params().test_no_limiter;
   const size_t table_bytes = 2 * mark_block_frame_count() * Params::n_bands;
   auto fail = [&] (int rc) { awm_add_stream_destroy (s.release()); return rc; };
   if (int rc = s->table.reserve (table_bytes)) return fail (rc);
@@ -486,7 +492,7 @@ awm_add_stream_push (awm_add_stream *s, size_t n_frames, int last, const float *
       return AWM_ERR_ARG;
     }
   awm_ctx *ctx = s->ctx;
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (s->finished || n_frames > s->tile || (!last && n_frames != s->tile))
     {
       set_error ("awm_add_stream_push: every tile but the last one must be full, nothing may follow the last one");
@@ -508,7 +514,7 @@ awm_add_stream_push (awm_add_stream *s, size_t n_frames, int last, const float *
       return 0;
     const float *before = k > 0 ? s->in[slot (k - 1)].as<float>() + (s->tile - N) * C : nullptr;
     const float *after = has_next ? s->in[slot (k + 1)].as<float>() : nullptr;
-    return add_mix_impl (ctx, s->in[slot (k)].as<float>(), s->mix[slot (k)].as<float>(), n, C, s->table.as<int8_t>(), Params::water_delta,
+    return add_mix_impl (ctx, s->in[slot (k)].as<float>(), s->mix[slot (k)].as<float>(), n, C, s->table.as<int8_t>(), params().water_delta,
                          size_t (k) * (s->tile / N), before, after, s->limiter ? s->block_max.as<float>() : nullptr, 0, s->n_blocks);
   };
   auto limit_tile = [&] (long long k) -> int {
@@ -548,7 +554,7 @@ int
 awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
            const int8_t *frame_mod, double water_delta, int use_limiter)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (!pcm_in_d || !out_d || !frame_mod || n_channels < 1)
     {
       set_error ("awm_add_d: bad argument");
@@ -571,7 +577,7 @@ pcm_format_ok (int bit_depth, int encoding)
 int
 awm_pcm_decode_d (awm_ctx *ctx, const void *bytes_d, size_t n_values, int bit_depth, int encoding, int big_endian, float *out_d)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (!pcm_format_ok (bit_depth, encoding))
     {
       set_error ("awm_pcm_decode_d: unsupported sample format");
@@ -585,7 +591,7 @@ awm_pcm_decode_d (awm_ctx *ctx, const void *bytes_d, size_t n_values, int bit_de
 int
 awm_pcm_encode_d (awm_ctx *ctx, const float *in_d, size_t n_values, int bit_depth, int encoding, int big_endian, int direct16, void *bytes_d)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (!pcm_format_ok (bit_depth, encoding))
     {
       set_error ("awm_pcm_encode_d: unsupported sample format");
@@ -601,7 +607,7 @@ int
 awm_sync_fft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, size_t index, size_t frame_count,
                 const char *want_frames, size_t first, size_t last, float *db_out_d, char *have_out_d)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (n_frames < index + frame_count * Params::frame_size)
     {
       set_error ("awm_sync_fft_d: read past end");       // the reference returns empty vectors here
@@ -686,7 +692,7 @@ int
 awm_sync_search_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int clip_mode,
                    size_t max_out, uint64_t *index, double *quality, int *block_type)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   SyncFinder sf (ctx);
   std::vector<SyncFinder::Score> scores;
   if (int rc = sf.search (capi_key (key), make_wav (pcm_d, n_frames, n_channels),
@@ -705,7 +711,7 @@ long
 awm_search_approx_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int clip_mode,
                      size_t max_out, uint64_t *index, double *raw_quality, double *local_mean)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   KeyTables *kt = ctx->get_key_tables (capi_key (key));
   if (!kt)
     return AWM_ERR_HIP;
@@ -729,7 +735,7 @@ int
 awm_block_soft_bits_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
                        const uint64_t *index, size_t n_blocks, float *out, int *ok)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   KeyTables *kt = ctx->get_key_tables (capi_key (key));
   if (!kt)
     return AWM_ERR_HIP;
@@ -738,7 +744,7 @@ awm_block_soft_bits_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, 
   std::vector<char> okv;
   if (int rc = block_soft_bits (ctx, kt, make_wav (pcm_d, n_frames, n_channels), idx, raw, okv))
     return rc;
-  const size_t n_bits = mark_data_frame_count() / Params::frames_per_bit;
+  const size_t n_bits = mark_data_frame_count() / params().frames_per_bit;
   for (size_t i = 0; i < n_blocks; i++)
     {
       ok[i] = okv[i];
@@ -753,7 +759,7 @@ awm_block_soft_bits_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, 
 int
 awm_viterbi_decode (awm_ctx *ctx, int block_type, const float *soft, size_t coded_len, size_t n, int *bits_out, float *error_out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (block_type < 0 || block_type > 2)
     return AWM_ERR_ARG;
   std::vector<std::vector<float>> in (n);
@@ -775,13 +781,13 @@ int
 awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const float *pcm_in_d, float *out_d,
                      size_t n_frames, int n_channels, int sample_rate)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   FrameModTable *fm = ctx->get_frame_mod (capi_key (key), payload_hex ? payload_hex : "");
   if (!fm)
     return AWM_ERR_ARG;
   if (sample_rate != Params::mark_sample_rate)
-    return add_full_rate (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter, sample_rate);
-  return add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter);
+    return add_full_rate (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), params().water_delta, !params().test_no_limiter, sample_rate);
+  return add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), params().water_delta, !params().test_no_limiter);
 }
 
 /* add_watermark for many independent inputs with one key and payload (BASELINE config 5: a batch of short clips).  A 30 s clip
@@ -792,7 +798,7 @@ int
 awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
                            float *const *out_d, const size_t *n_frames, int n_channels)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (n_clips && (!pcm_in_d || !out_d || !n_frames || n_channels < 1))
     {
       set_error ("awm_add_watermark_batch_d: bad argument");
@@ -824,7 +830,7 @@ awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payl
     }
   int rc = 0;
   for (size_t i = 0; i < n_clips && !rc; i++)
-    rc = add_full (ctx, pcm_in_d[i], out_d[i], n_frames[i], n_channels, fm->dev.as<int8_t>(), Params::water_delta, !Params::test_no_limiter,
+    rc = add_full (ctx, pcm_in_d[i], out_d[i], n_frames[i], n_channels, fm->dev.as<int8_t>(), params().water_delta, !params().test_no_limiter,
                    lanes[i % n_lanes]);
   for (int i = 1; i < n_lanes; i++)
     {
@@ -838,7 +844,7 @@ int
 awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
                      size_t max_out, awm_pattern *out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   ResultSet rs;
   if (int rc = get_watermark_device (ctx, { capi_key (key) }, make_wav (pcm_d, n_frames, n_channels), rs))
     return rc;
@@ -847,11 +853,61 @@ awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, si
   return int (rs.patterns.size());
 }
 
+extern "C++" {
+namespace {
+std::vector<Key>
+key_list_from (const uint8_t *keys, int n_keys)
+{
+  std::vector<Key> list;
+  for (int k = 0; k < n_keys; k++)
+    list.push_back (capi_key (keys + size_t (k) * Key::SIZE));
+  return list;
+}
+// patterns of a multi-key `get` -> the C arrays; key_of_pattern[j] = position of pattern j's key in the list
+int
+fill_patterns_keys (const ResultSet& rs, const std::vector<Key>& list, size_t max_out, awm_pattern *out, int *key_of_pattern)
+{
+  for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
+    {
+      fill_pattern (rs.patterns[i], out[i]);
+      if (key_of_pattern)
+        {
+          key_of_pattern[i] = -1;
+          for (size_t k = 0; k < list.size(); k++)
+            if (rs.patterns[i].key == list[k])
+              {
+                key_of_pattern[i] = int (k);
+                break;
+              }
+        }
+    }
+  return int (rs.patterns.size());
+}
+}
+} // extern "C++"
+
+int
+awm_get_watermark_keys_d (awm_ctx *ctx, const uint8_t *keys, int n_keys, const float *pcm_d, size_t n_frames, int n_channels,
+                          size_t max_out, awm_pattern *out, int *key_of_pattern)
+{
+  AWM_ENTER (ctx);
+  if (n_keys < 0 || (n_keys && !keys) || (max_out && !out))
+    {
+      set_error ("awm_get_watermark_keys_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  const std::vector<Key> list = key_list_from (keys, n_keys);
+  ResultSet rs;
+  if (int rc = get_watermark_device (ctx, list, make_wav (pcm_d, n_frames, n_channels), rs))
+    return rc;
+  return fill_patterns_keys (rs, list, max_out, out, key_of_pattern);
+}
+
 int
 awm_get_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], size_t n_clips, const float *const *pcm_d, const size_t *n_frames,
                            int n_channels, int n_threads, size_t max_out_per_clip, awm_pattern *out, int *n_out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (n_clips && (!pcm_d || !n_frames || !n_out || (max_out_per_clip && !out)))
     {
       set_error ("awm_get_watermark_batch_d: bad argument");
@@ -877,7 +933,7 @@ awm_decode_chunks_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, si
                      int n_chunks, const uint64_t *first_frame, const uint64_t *chunk_frames, int first_is_stream_start,
                      size_t max_out, awm_pattern *out, int *chunk_of_pattern)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   std::vector<ChunkRange> chunks;
   for (int i = 0; i < n_chunks; i++)
     {
@@ -915,7 +971,7 @@ namespace {
 // these in the process-global Params, wmcommon.hh:79-83)
 struct FormatScope
 {
-  Format old_in = Params::input_format, old_out = Params::output_format;
+  Format old_in = params().input_format, old_out = params().output_format;
   RawFormat old_raw_in = StreamParams::raw_input_format, old_raw_out = StreamParams::raw_output_format;
   static bool
   apply (const awm_raw_format *f, Format& format, RawFormat& raw)
@@ -937,8 +993,8 @@ struct FormatScope
   }
   ~FormatScope()
   {
-    Params::input_format = old_in;
-    Params::output_format = old_out;
+    params().input_format = old_in;
+    params().output_format = old_out;
     StreamParams::raw_input_format = old_raw_in;
     StreamParams::raw_output_format = old_raw_out;
   }
@@ -949,34 +1005,35 @@ int
 awm_add_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const char *in_path, const char *out_path,
                         const awm_raw_format *raw_in, const awm_raw_format *raw_out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (!payload_hex || !in_path || !out_path)
     {
       set_error ("awm_add_watermark_file: bad argument");
       return AWM_ERR_ARG;
     }
   FormatScope scope;
-  if (!FormatScope::apply (raw_in, Params::input_format, StreamParams::raw_input_format)
-      || !FormatScope::apply (raw_out, Params::output_format, StreamParams::raw_output_format))
+  if (!FormatScope::apply (raw_in, params().input_format, StreamParams::raw_input_format)
+      || !FormatScope::apply (raw_out, params().output_format, StreamParams::raw_output_format))
     {
       set_error ("awm_add_watermark_file: unsupported raw format");
       return AWM_ERR_ARG;
     }
-  return add_watermark (ctx, capi_key (key), in_path, out_path, payload_hex) ? AWM_ERR_ARG : 0;
+  file_fail_reset();
+  return add_watermark (ctx, capi_key (key), in_path, out_path, payload_hex) ? file_fail_kind() : 0;
 }
 
 int
 awm_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *in_path, const awm_raw_format *raw_in,
                         size_t max_out, awm_pattern *out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if (!in_path || (max_out && !out))
     {
       set_error ("awm_get_watermark_file: bad argument");
       return AWM_ERR_ARG;
     }
   FormatScope scope;
-  if (!FormatScope::apply (raw_in, Params::input_format, StreamParams::raw_input_format))
+  if (!FormatScope::apply (raw_in, params().input_format, StreamParams::raw_input_format))
     {
       set_error ("awm_get_watermark_file: unsupported raw format");
       return AWM_ERR_ARG;
@@ -986,15 +1043,48 @@ awm_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *in_path
   if (err)
     {
       set_error (std::string ("error loading ") + in_path + ": " + err.message());
-      return AWM_ERR_ARG;
+      return AWM_ERR_IO;
     }
   ResultSet rs;
   size_t n_values = 0;
+  file_fail_reset();
   if (get_watermark_stream (ctx, { capi_key (key) }, in_stream.get(), false, rs, n_values, in_path))
-    return AWM_ERR_HIP;
+    return file_fail_kind();
   for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
     fill_pattern (rs.patterns[i], out[i]);
   return int (rs.patterns.size());
+}
+
+int
+awm_get_watermark_keys_file (awm_ctx *ctx, const uint8_t *keys, int n_keys, const char *in_path, const awm_raw_format *raw_in,
+                             size_t max_out, awm_pattern *out, int *key_of_pattern)
+{
+  AWM_ENTER (ctx);
+  if (!in_path || n_keys < 0 || (n_keys && !keys) || (max_out && !out))
+    {
+      set_error ("awm_get_watermark_keys_file: bad argument");
+      return AWM_ERR_ARG;
+    }
+  FormatScope scope;
+  if (!FormatScope::apply (raw_in, params().input_format, StreamParams::raw_input_format))
+    {
+      set_error ("awm_get_watermark_keys_file: unsupported raw format");
+      return AWM_ERR_ARG;
+    }
+  Error err;
+  auto in_stream = AudioInputStream::create (in_path, err);
+  if (err)
+    {
+      set_error (std::string ("error loading ") + in_path + ": " + err.message());
+      return AWM_ERR_IO;
+    }
+  const std::vector<Key> list = key_list_from (keys, n_keys);
+  ResultSet rs;
+  size_t n_values = 0;
+  file_fail_reset();
+  if (get_watermark_stream (ctx, list, in_stream.get(), false, rs, n_values, in_path))
+    return file_fail_kind();
+  return fill_patterns_keys (rs, list, max_out, out, key_of_pattern);
 }
 
 int
@@ -1039,7 +1129,7 @@ int
 awm_decode_chunk_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
                     int first_chunk, size_t max_out, awm_pattern *out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   ResultSet rs;
   if (int rc = decode_chunk (ctx, rs, { capi_key (key) }, make_wav (pcm_d, n_frames, n_channels), first_chunk != 0))
     return rc;
@@ -1061,10 +1151,11 @@ make_wav_rate (const float *pcm_d, size_t n_frames, int n_channels, int rate)
 void
 awm_set_speed_params (int detect_speed, int detect_speed_patient, double try_speed, double test_speed)
 {
-  Params::detect_speed = detect_speed != 0;
-  Params::detect_speed_patient = detect_speed_patient != 0;
-  Params::try_speed = try_speed;
-  Params::test_speed = test_speed;
+  ParamValues& g = global_params();
+  g.detect_speed = detect_speed != 0;
+  g.detect_speed_patient = detect_speed_patient != 0;
+  g.try_speed = try_speed;
+  g.test_speed = test_speed;
 }
 
 size_t
@@ -1080,7 +1171,7 @@ int
 awm_resample_ratio_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_channels, int rate, double ratio,
                       double max_in_seconds, float *out_d, size_t n_out_frames)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   if ((n_frames && !pcm_in_d) || (n_out_frames && !out_d) || n_channels < 1 || rate < 1)
     {
       set_error ("awm_resample_ratio_d: bad argument");
@@ -1105,7 +1196,7 @@ int
 awm_speed_clip_location_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
                            double seconds, int candidates, double *location)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   return speed_clip_location (ctx, ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), seconds, candidates, location);
 }
 
@@ -1113,7 +1204,7 @@ int
 awm_speed_mags_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
                   double clip_location, double center, double seconds, size_t max_rows, float *out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   std::vector<float> m;
   int rows = 0;
   if (int rc = speed_mags (ctx, ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), clip_location, center, seconds, m, &rows))
@@ -1127,7 +1218,7 @@ awm_speed_scan_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_
                   double clip_location, double seconds, double step, int n_steps, int n_center_steps,
                   const double *speeds, int n_speeds, size_t max_out, double *out_speed, double *out_quality)
 {
-  if (int rc = check_ctx (ctx)) return rc;
+  AWM_ENTER (ctx);
   std::vector<SpeedScore> scores;
   if (int rc = speed_scan (ctx, ctx, capi_key (key), make_wav_rate (pcm_d, n_frames, n_channels, rate), clip_location,
                            { seconds, step, n_steps, n_center_steps }, std::vector<double> (speeds, speeds + n_speeds), scores))
@@ -1145,13 +1236,13 @@ int
 awm_detect_speed_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels, int rate,
                     int patient, double *speed_out, double *quality_out)
 {
-  if (int rc = check_ctx (ctx)) return rc;
-  const bool old_patient = Params::detect_speed_patient;
-  Params::detect_speed_patient = patient != 0;
+  AWM_ENTER (ctx);
+  const bool old_patient = params().detect_speed_patient;
+  params().detect_speed_patient = patient != 0;
   std::vector<DetectSpeedResult> results;
   double speed = 0, quality = 0;
   const int rc = detect_speed (ctx, ctx, { capi_key (key) }, make_wav_rate (pcm_d, n_frames, n_channels, rate), nullptr, results, &speed, &quality);
-  Params::detect_speed_patient = old_patient;
+  params().detect_speed_patient = old_patient;
   if (rc)
     return rc;
   if (speed_out)

@@ -4,6 +4,7 @@
 #include "wmspeed.hh"
 #include "random.hh"
 #include <cstring>
+#include <memory>
 
 using namespace awm;
 
@@ -193,13 +194,119 @@ void
 awm_set_params (double water_delta, int mix, int frames_per_bit, int test_no_limiter,
                 double sync_threshold2, int n_best, double chunk_size_min)
 {
-  Params::water_delta = water_delta;
-  Params::mix = mix != 0;
-  Params::frames_per_bit = frames_per_bit;
-  Params::test_no_limiter = test_no_limiter != 0;
-  Params::sync_threshold2 = sync_threshold2;
-  Params::get_n_best = n_best;
-  Params::get_chunk_size = chunk_size_min;
+  ParamValues& g = global_params();
+  g.water_delta = water_delta;
+  g.mix = mix != 0;
+  g.frames_per_bit = frames_per_bit;
+  g.test_no_limiter = test_no_limiter != 0;
+  g.sync_threshold2 = sync_threshold2;
+  g.get_n_best = n_best;
+  g.get_chunk_size = chunk_size_min;
+}
+
+/* ---- the whole parameter set, process-wide or per context (awm_hip.h: awm_params) ---- */
+static void
+params_to_c (const ParamValues& v, awm_params *p)
+{
+  p->struct_size = sizeof (awm_params);
+  p->water_delta = v.water_delta;
+  p->mix = v.mix;
+  p->hard = v.hard;
+  p->strict = v.strict;
+  p->snr = v.snr;
+  p->payload_size = int (v.payload_size);
+  p->frames_per_bit = v.frames_per_bit;
+  p->sync_threshold2 = v.sync_threshold2;
+  p->get_n_best = v.get_n_best;
+  p->get_chunk_size = v.get_chunk_size;
+  p->detect_speed = v.detect_speed;
+  p->detect_speed_patient = v.detect_speed_patient;
+  p->try_speed = v.try_speed;
+  p->test_speed = v.test_speed;
+  p->test_cut = v.test_cut;
+  p->test_no_sync = v.test_no_sync;
+  p->test_no_limiter = v.test_no_limiter;
+  p->test_truncate = v.test_truncate;
+}
+
+static int
+params_from_c (const awm_params *p, ParamValues& v)
+{
+  if (!p || p->struct_size != sizeof (awm_params))
+    {
+      set_error ("awm_params: struct_size does not match this library (use awm_params_init)");
+      return AWM_ERR_ARG;
+    }
+  if (!(p->water_delta >= 0) || p->payload_size < 1 || p->frames_per_bit < 1 || p->get_n_best < 1 || !(p->get_chunk_size > 0))
+    {
+      set_error ("awm_params: value out of range");
+      return AWM_ERR_ARG;
+    }
+  v.water_delta = p->water_delta;
+  v.mix = p->mix != 0;
+  v.hard = p->hard != 0;
+  v.strict = p->strict != 0;
+  v.snr = p->snr != 0;
+  v.payload_size = size_t (p->payload_size);
+  v.frames_per_bit = p->frames_per_bit;
+  v.sync_threshold2 = p->sync_threshold2;
+  v.get_n_best = p->get_n_best;
+  v.get_chunk_size = p->get_chunk_size;
+  v.detect_speed = p->detect_speed != 0;
+  v.detect_speed_patient = p->detect_speed_patient != 0;
+  v.try_speed = p->try_speed;
+  v.test_speed = p->test_speed;
+  v.test_cut = p->test_cut;
+  v.test_no_sync = p->test_no_sync != 0;
+  v.test_no_limiter = p->test_no_limiter != 0;
+  v.test_truncate = p->test_truncate;
+  return 0;
+}
+
+void
+awm_params_init (awm_params *p)
+{
+  if (p)
+    params_to_c (ParamValues(), p);
+}
+
+int
+awm_set_global_params (const awm_params *p)
+{
+  ParamValues v = global_params();          // (what awm_params does not carry -- formats, json output -- stays)
+  if (int rc = params_from_c (p, v))
+    return rc;
+  global_params() = v;
+  return 0;
+}
+
+int
+awm_ctx_set_params (awm_ctx *ctx, const awm_params *p)
+{
+  if (!ctx)
+    {
+      set_error ("null context");
+      return AWM_ERR_ARG;
+    }
+  if (!p)
+    {
+      ctx->own_params.reset();
+      return 0;
+    }
+  auto v = std::make_unique<ParamValues> (ctx->own_params ? *ctx->own_params : global_params());
+  if (int rc = params_from_c (p, *v))
+    return rc;
+  ctx->own_params = std::move (v);
+  return 0;
+}
+
+int
+awm_ctx_get_params (const awm_ctx *ctx, awm_params *out)
+{
+  if (!out)
+    return AWM_ERR_ARG;
+  params_to_c (ctx && ctx->own_params ? *ctx->own_params : global_params(), out);
+  return 0;
 }
 
 /* -q / --quiet of the command line (reference audiowmark.cc:1020-1023): information messages off */

@@ -17,6 +17,11 @@ DevBuffer::reserve (size_t want)
 {
   if (want <= bytes)
     return 0;
+  if (want > MAX_BYTES)
+    {
+      set_error ("device buffer of " + std::to_string (want) + " bytes requested (size overflow?)");
+      return AWM_ERR_ARG;
+    }
   release();
   // round up generously: workspaces are reused across calls, HBM is plentiful
   size_t cap = size_t (1) << 20;
@@ -206,7 +211,7 @@ awm_ctx::get_key_tables (const Key& key)
   std::lock_guard<std::mutex> lock (table_mutex);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& kt : key_tables)
-    if (kt->key == kb && kt->mix == Params::mix)
+    if (kt->key == kb && kt->mix == params().mix)
       {
         kt->last_use = ++table_clock;
         return kt.get();
@@ -224,7 +229,7 @@ awm_ctx::get_key_tables (const Key& key)
   auto kt = std::make_unique<KeyTables>();
   kt->last_use = ++table_clock;
   kt->key = kb;
-  kt->mix = Params::mix;
+  kt->mix = params().mix;
   for (int clip = 0; clip < 2; clip++)
     {
       auto& s = kt->sync[clip];
@@ -272,7 +277,7 @@ awm_ctx::get_key_tables (const Key& key)
   if (upload (kt->mix_frame, kt->mix_host.frame.data(), kt->mix_host.frame.size() * sizeof (int16_t), stream)) return nullptr;
   if (upload (kt->mix_up, kt->mix_host.up.data(), kt->mix_host.up.size(), stream)) return nullptr;
   if (upload (kt->mix_down, kt->mix_host.down.data(), kt->mix_host.down.size(), stream)) return nullptr;
-  kt->bit_order_a = bit_order (key, code_size (ConvBlockType::a, Params::payload_size));
+  kt->bit_order_a = bit_order (key, code_size (ConvBlockType::a, params().payload_size));
   {
     std::vector<int> inv (kt->bit_order_a.size());
     for (size_t i = 0; i < inv.size(); i++)
@@ -341,7 +346,7 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
   std::lock_guard<std::mutex> lock (table_mutex);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& t : frame_mod_tables)
-    if (t->key == kb && t->payload == payload_hex && t->mix == Params::mix)
+    if (t->key == kb && t->payload == payload_hex && t->mix == params().mix)
       {
         t->last_use = ++table_clock;
         return t.get();
@@ -356,7 +361,7 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
   auto t = std::make_unique<FrameModTable>();
   t->key = kb;
   t->payload = payload_hex;
-  t->mix = Params::mix;
+  t->mix = params().mix;
   t->last_use = ++table_clock;
   if (upload (t->dev, table.data(), table.size(), stream))
     return nullptr;
@@ -456,9 +461,10 @@ ctx_create (int device, bool own_stream, hipStream_t given, awm_ctx **ctx_out)
   if (!ctx_out)
     return AWM_ERR_ARG;
   *ctx_out = nullptr;
-  // lanes are HIP streams; the runtime maps streams to GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one
-  // queue serialise.  No effect if the runtime is already initialised (e.g. inside a PyTorch process: set it there).
-  setenv ("GPU_MAX_HW_QUEUES", "16", 0);   // 16 lanes in the clip batch mode: 0.64 -> 0.535 ms per clip over 8 queues
+  // Lanes are HIP streams; the runtime maps streams to GPU_MAX_HW_QUEUES hardware queues (default 4) and streams on one queue
+  // serialise.  The library does not touch its host's environment: a process that wants all lanes on queues of their own (the
+  // clip batch mode: 0.64 -> 0.535 ms per clip over 8 queues) exports GPU_MAX_HW_QUEUES=16 itself before its first HIP call
+  // (awm_hip.h, "runtime settings"; bench.py does).
   int n_dev = 0;
   hipError_t e = hipGetDeviceCount (&n_dev);
   if (e != hipSuccess || n_dev <= 0)

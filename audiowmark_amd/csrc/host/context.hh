@@ -64,6 +64,7 @@ struct DevBuffer
 {
   void  *ptr = nullptr;
   size_t bytes = 0;
+  static constexpr size_t MAX_BYTES = size_t (1) << 40;     // no device holds more: larger requests are arithmetic gone wrong
   int reserve (size_t want);     // 0 ok
   void release();
   template<class T> T *as() const { return static_cast<T *> (ptr); }
@@ -85,7 +86,7 @@ struct KeyTables
 {
   std::vector<unsigned char> key;
   unsigned long last_use = 0;
-  bool mix = true;                 // Params::mix the data tables were built for (--linear: per-frame up / down bands)
+  bool mix = true;                 // params().mix the data tables were built for (--linear: per-frame up / down bands)
   // sync tables, BLOCK and CLIP flavour
   struct Sync
   {
@@ -179,6 +180,7 @@ struct awm_ctx : awm::WorkLane
   awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
   hipStream_t    copy_stream = nullptr;  // H2D / D2H staging of the file level paths (created on first use)
   hipStream_t    get_copy_stream();
+  std::unique_ptr<awm::ParamValues> own_params;   // settings of this context (awm_ctx_set_params); null: the process-wide ones
   int            chunk_lanes = awm::CHUNK_LANES;   // lanes the chunks of one stream may be spread over (awm_ctx_set_chunk_lanes)
 
   awm::SpeedWorkspace *speed = nullptr;  // tables and buffers of the speed detection (wmspeed.cc), created on first use

@@ -148,7 +148,7 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
   sa.have_row_stride = 1;
   sa.n_lanes = S;
   sa.n_planes = n_shifts;
-  sa.min_delta = std::min (Params::water_delta, 0.080);
+  sa.min_delta = std::min (params().water_delta, 0.080);
   sa.quality = m_lane->ws_q.as<double>();
   sa.q_stride = q_stride;
   sa.table.packed = kt->sync[clip].packed_approx.as<int>();
@@ -214,7 +214,7 @@ scores_from_topk (std::vector<awmk::PeakOut> top, double threshold, std::vector<
   std::sort (top.begin(), top.end(), [&] (const awmk::PeakOut& a, const awmk::PeakOut& b) {
     return absq (a) != absq (b) ? absq (a) > absq (b) : a.p < b.p;
   });
-  const size_t nb = size_t (Params::get_n_best);
+  const size_t nb = size_t (params().get_n_best);
   if (top.size() > nb && absq (top[nb - 1]) == absq (top[nb]))
     return false;
   if (top.size() > nb)
@@ -244,7 +244,7 @@ SyncFinder::select_launch (long long n_scores, double threshold, bool speculate_
   // one round trip for the counter and the first peaks (usually all of them), through page-locked memory
   if (int rc = m_lane->pin_peaks.reserve (256 + cap * sizeof (awmk::PeakOut) + TOPK_MAX * TOPK_SLICES * sizeof (awmk::PeakOut))) return rc;
   AWM_HIP_CHECK (hipMemcpyAsync (m_lane->pin_peaks.ptr, d_count, 256 + PEAK_HEAD * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
-  if (speculate_n_best && Params::get_n_best + 1 <= TOPK_MAX)
+  if (speculate_n_best && params().get_n_best + 1 <= TOPK_MAX)
     {
       // Short material rarely has n_best peaks above the threshold: queue the fallback (all unmasked maxima, reduced to
       // the n_best + 1 largest per slice) right away, so that select_finish finds both answers after ONE wait.
@@ -252,7 +252,7 @@ SyncFinder::select_launch (long long n_scores, double threshold, bool speculate_
       if (int rc = m_lane->ws_refine.reserve (size_t (big_cap) * sizeof (awmk::PeakOut))) return rc;
       auto *d_all = m_lane->ws_refine.as<awmk::PeakOut>();
       AWM_HIP_CHECK (awmk::launch_peak_select (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, -1.0, d_count, d_all, big_cap));
-      const int k = Params::get_n_best + 1;
+      const int k = params().get_n_best + 1;
       AWM_HIP_CHECK (awmk::launch_peak_topk (st, d_all, d_count, big_cap, d_out, k, TOPK_SLICES));      // the threshold list is already on its way
       AWM_HIP_CHECK (hipMemcpyAsync (m_lane->pin_peaks.as<char>() + 256 + cap * sizeof (awmk::PeakOut), d_out,
                                      size_t (k) * TOPK_SLICES * sizeof (awmk::PeakOut), hipMemcpyDeviceToHost, st));
@@ -274,7 +274,7 @@ SyncFinder::select_finish (long long n_scores, double threshold, std::vector<Sea
   char *pin = m_lane->pin_peaks.as<char>();
   AWM_HIP_CHECK (stream_wait (st));
   unsigned int count = *reinterpret_cast<unsigned int *> (pin);
-  if (int (count) >= Params::get_n_best && count <= cap)
+  if (int (count) >= params().get_n_best && count <= cap)
     {
       if (count > head)
         {
@@ -288,7 +288,7 @@ SyncFinder::select_finish (long long n_scores, double threshold, std::vector<Sea
   // fewer than n_best peaks above the threshold: the reference then keeps the n_best largest unmasked maxima.
   // Fetch ALL unmasked local maxima (threshold -1) from the device and finish the selection here.
   const unsigned int big_cap = unsigned (std::min<long long> (n_scores, 1 << 22));
-  speculated = speculated && Params::get_n_best + 1 <= TOPK_MAX;
+  speculated = speculated && params().get_n_best + 1 <= TOPK_MAX;
   if (int rc = m_lane->ws_refine.reserve (size_t (big_cap) * sizeof (awmk::PeakOut))) return rc;
   auto *d_all = m_lane->ws_refine.as<awmk::PeakOut>();
   if (!speculated)
@@ -296,9 +296,9 @@ SyncFinder::select_finish (long long n_scores, double threshold, std::vector<Sea
   // Only the n_best largest survive select_threshold_and_n_best here (fewer than n_best are above the threshold), so
   // reduce the list on the device: n_best + 1 per slice, so that a tie across the cut is visible -- in that case
   // (degenerate input) the complete list goes through the same std::sort as in the reference instead.
-  const int k = Params::get_n_best + 1;
+  const int k = params().get_n_best + 1;
   constexpr int n_slices = TOPK_SLICES;
-  const bool fewer_than_n_best = int (count) < Params::get_n_best;      // (not: more than `cap` above the threshold)
+  const bool fewer_than_n_best = int (count) < params().get_n_best;      // (not: more than `cap` above the threshold)
   if (fewer_than_n_best && k <= TOPK_MAX)
     {
       std::vector<awmk::PeakOut> top (size_t (k) * n_slices);
@@ -400,10 +400,10 @@ SyncFinder::select_threshold_and_n_best (std::vector<SearchScore>& scores, doubl
   int i = 0;
   while (i < int (scores.size()) && scores[i].abs_quality() > threshold)
     i++;
-  if (i >= Params::get_n_best)
+  if (i >= params().get_n_best)
     scores.resize (i);
-  else if (int (scores.size()) > Params::get_n_best)
-    scores.resize (Params::get_n_best);
+  else if (int (scores.size()) > params().get_n_best)
+    scores.resize (params().get_n_best);
 }
 
 /* reference syncfinder.cc:385-391 */
@@ -582,7 +582,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           ga.n_lanes = max_count;
           ga.lane_count = d_lanes;
           ga.n_planes = (long long) nb;
-          ga.min_delta = std::min (Params::water_delta, 0.080);
+          ga.min_delta = std::min (params().water_delta, 0.080);
           ga.quality = m_lane->ws_q.as<double>();
           ga.q_stride = QS;
           ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 4.0 * row_values, st);
@@ -601,7 +601,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           sa.n_lanes = max_count;
           sa.lane_count = d_lanes;
           sa.n_planes = (long long) nb;
-          sa.min_delta = std::min (Params::water_delta, 0.080);
+          sa.min_delta = std::min (params().water_delta, 0.080);
           sa.quality = m_lane->ws_q.as<double>();
           sa.q_stride = QS;
           sa.table.packed = sync.packed_refine.as<int>();
@@ -667,18 +667,18 @@ SyncFinder::prepare (const DeviceWav& wav, Mode mode)
 
 /* reference syncfinder.cc:487-558 */
 int
-SyncFinder::search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out)
+SyncFinder::search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out, bool db_ready)
 {
   SearchJob job;
-  if (int rc = search_launch (key, wav, mode, job))
+  if (int rc = search_launch (key, wav, mode, job, db_ready))
     return rc;
   return search_finish (job, out);
 }
 
 int
-SyncFinder::search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job)
+SyncFinder::search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool db_ready)
 {
-  if (int rc = approx_launch (key, wav, mode, job))
+  if (int rc = approx_launch (key, wav, mode, job, /* prepared */ db_ready, db_ready))
     return rc;
   return select_refine (job);
 }
@@ -693,7 +693,7 @@ SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, Sear
   KeyTables *kt = m_ctx->get_key_tables (key);
   if (!kt)
     return AWM_ERR_HIP;
-  if (Params::test_no_sync)
+  if (params().test_no_sync)
     {
       if (mode == Mode::BLOCK)       // fake_sync, reference syncfinder.cc:460-485
         {
@@ -716,7 +716,7 @@ SyncFinder::approx_launch (const Key& key, const DeviceWav& wav, Mode mode, Sear
   if (int rc = approx_device (kt, wav, mode, job.n_scores, db_ready))
     return rc;
   job.speculate_n_best = mode == Mode::CLIP;            // clips hold one or two sync peaks: the n_best fallback is the rule
-  if (int rc = select_launch (job.n_scores, Params::sync_threshold2 * 0.75, job.speculate_n_best))
+  if (int rc = select_launch (job.n_scores, params().sync_threshold2 * 0.75, job.speculate_n_best))
     return rc;
   job.done = false;
   job.select_pending = true;
@@ -729,10 +729,10 @@ SyncFinder::select_refine (SearchJob& job)
   if (job.done || !job.select_pending)
     return 0;
   job.select_pending = false;
-  if (int rc = select_finish (job.n_scores, Params::sync_threshold2 * 0.75, job.candidates, job.speculate_n_best))
+  if (int rc = select_finish (job.n_scores, params().sync_threshold2 * 0.75, job.candidates, job.speculate_n_best))
     return rc;
   if (job.mode == Mode::CLIP)
-    select_truncate_n (job.candidates, std::max (Params::get_n_best, 5));
+    select_truncate_n (job.candidates, std::max (params().get_n_best, 5));
   return refine_launch (job.kt, job.wav, job.mode, job);
 }
 
@@ -749,7 +749,7 @@ SyncFinder::search_finish (SearchJob& job, std::vector<Score>& out)
   if (int rc = refine_finish (job, scores))
     return rc;
   job.done = true;
-  select_threshold_and_n_best (scores, Params::sync_threshold2);
+  select_threshold_and_n_best (scores, params().sync_threshold2);
   std::sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
   for (const auto& s : scores)
     {
@@ -778,7 +778,7 @@ struct GroupLayout
 }
 
 int
-SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_slices, const long long *d_range, GroupJob& gj)
+SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_slices, const long long *d_range, GroupJob& gj, bool db_ready)
 {
   gj.n_slices = n_slices;
   gj.kt = kt;
@@ -793,8 +793,8 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
   const long long frame_count = gj.slice_frames / Params::frame_size;
   const long long n_db = frame_count - 1;          // as approx_device, per slice
   const long long S = n_db - total_frames (mode);
-  const int k = Params::get_n_best + 1;
-  if (n_slices <= 0 || n_db <= 0 || S <= 0 || Params::test_no_sync)       // (--test-no-sync: CLIP mode finds nothing, see approx_launch)
+  const int k = params().get_n_best + 1;
+  if (n_slices <= 0 || n_db <= 0 || S <= 0 || params().test_no_sync)       // (--test-no-sync: CLIP mode finds nothing, see approx_launch)
     return 0;
   if (gj.slice_frames % Params::frame_size || k > TOPK_MAX)
     {
@@ -833,10 +833,11 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
   da.have = m_lane->ws_have.as<char>();
   da.have_stream_stride = ld;
   da.tile_frames = 32;
-  {
-    ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_slices) * n_db * 4096.0 * group.n_channels + double (n_planes) * n_db * 324.0, st);
-    AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
-  }
+  if (!db_ready)                                     // (else: another key of the same `get` left the group's matrices in the workspace)
+    {
+      ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_slices) * n_db * 4096.0 * group.n_channels + double (n_planes) * n_db * 324.0, st);
+      AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
+    }
   awmk::SyncScanArgs sa {};
   sa.db = m_lane->ws_db.as<float>();
   sa.have = m_lane->ws_have.as<char>();
@@ -848,7 +849,7 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
   sa.have_row_stride = 1;
   sa.n_lanes = S;
   sa.n_planes = n_planes;
-  sa.min_delta = std::min (Params::water_delta, 0.080);
+  sa.min_delta = std::min (params().water_delta, 0.080);
   sa.quality = m_lane->ws_q.as<double>();
   sa.q_stride = q_stride;
   sa.table.packed = kt->sync[1].packed_approx.as<int>();
@@ -873,7 +874,7 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
     auto *d_th = reinterpret_cast<awmk::PeakOut *> (base + lay.off_th);
     auto *d_top = reinterpret_cast<awmk::PeakOut *> (base + lay.off_top);
     auto *d_all = m_lane->ws_refine.as<awmk::PeakOut>();
-    const double threshold = Params::sync_threshold2 * 0.75;
+    const double threshold = params().sync_threshold2 * 0.75;
     AWM_HIP_CHECK (hipMemsetAsync (d_count, 0, size_t (n_slices) * 2 * sizeof (unsigned int), st));
     AWM_HIP_CHECK (awmk::launch_peak_select_slices (st, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>(), n_scores, threshold,
                                                     d_count, 2, d_th, GROUP_HEAD, n_slices));
@@ -891,14 +892,14 @@ SyncFinder::group_select_refine (GroupJob& gj)
 {
   if (gj.n_scores <= 0)
     return 0;
-  const int k = Params::get_n_best + 1;
+  const int k = params().get_n_best + 1;
   const GroupLayout lay (gj.n_slices, k);
   AWM_HIP_CHECK (stream_wait (m_lane->stream));
   const char *pin = m_lane->pin_peaks.as<char>();
   const auto *count = reinterpret_cast<const unsigned int *> (pin);
   const auto *th = reinterpret_cast<const awmk::PeakOut *> (pin + lay.off_th);
   const auto *top = reinterpret_cast<const awmk::PeakOut *> (pin + lay.off_top);
-  const double threshold = Params::sync_threshold2 * 0.75;
+  const double threshold = params().sync_threshold2 * 0.75;
   SearchJob& job = gj.refine;
   for (int i = 0; i < gj.n_slices; i++)
     {
@@ -906,9 +907,9 @@ SyncFinder::group_select_refine (GroupJob& gj)
         continue;
       std::vector<SearchScore> cands;                      // select_finish for this slice
       const unsigned int c_th = count[2 * i];
-      if (int (c_th) >= Params::get_n_best && c_th <= GROUP_HEAD)
+      if (int (c_th) >= params().get_n_best && c_th <= GROUP_HEAD)
         scores_from_threshold_list (th + size_t (i) * GROUP_HEAD, c_th, cands);
-      else if (int (c_th) < Params::get_n_best)
+      else if (int (c_th) < params().get_n_best)
         {
           const awmk::PeakOut *t0 = top + size_t (i) * GROUP_TOPK_SLICES * k;
           if (!scores_from_topk (std::vector<awmk::PeakOut> (t0, t0 + size_t (GROUP_TOPK_SLICES) * k), threshold, cands))
@@ -918,7 +919,7 @@ SyncFinder::group_select_refine (GroupJob& gj)
         gj.fallback[i] = 1;
       if (gj.fallback[i])
         continue;
-      select_truncate_n (cands, std::max (Params::get_n_best, 5));     // select_refine, Mode::CLIP
+      select_truncate_n (cands, std::max (params().get_n_best, 5));     // select_refine, Mode::CLIP
       for (const auto& c : cands)
         {
           job.candidates.push_back (c);
@@ -945,7 +946,7 @@ SyncFinder::group_finish (GroupJob& gj, std::vector<std::vector<Score>>& out)
     {
       auto& scores = per_slice[i];
       std::stable_sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
-      select_threshold_and_n_best (scores, Params::sync_threshold2);
+      select_threshold_and_n_best (scores, params().sync_threshold2);
       std::sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
       for (const auto& s : scores)
         {

@@ -38,7 +38,9 @@ public:
 
   explicit SyncFinder (awm_ctx *ctx, WorkLane *lane = nullptr) : m_ctx (ctx), m_lane (lane ? lane : ctx) {}
 
-  int search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out);
+  // db_ready: the dB matrices (and the non-silent range) of a previous search of the SAME material by this object are still in the
+  // lane's workspace -- the next key of a multi-key `get` shares them (reference syncfinder.cc:171-256)
+  int search (const Key& key, const DeviceWav& wav, Mode mode, std::vector<Score>& out, bool db_ready = false);
   int prepare (const DeviceWav& wav, Mode mode);     // silence scan (CLIP) / full range (BLOCK)
   // the same without waiting for the device; [scan_lo, scan_hi) = values that can be non-zero at all (a caller that padded
   // the buffer itself knows where the data is: the silence scan then skips the padding)
@@ -79,7 +81,7 @@ public:
     size_t           slice_frames = 0;      // 0: no slices
     const long long *slice_range = nullptr; // device, [slices][2]: non-silent value range of every slice (kernels.hh launch_clip_pad)
   };
-  int search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job);     // = approx_launch + select_refine
+  int search_launch (const Key& key, const DeviceWav& wav, Mode mode, SearchJob& job, bool db_ready = false);     // = approx_launch + select_refine
   int search_finish (SearchJob& job, std::vector<Score>& out);
   // finer steps for callers that drive several lanes: approx_launch never waits for the device,
   // select_refine waits for this lane's candidate list and queues the refinement
@@ -103,7 +105,7 @@ public:
     SearchJob  refine;
     std::vector<char> fallback;
   };
-  int group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_slices, const long long *d_range, GroupJob& gj);
+  int group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_slices, const long long *d_range, GroupJob& gj, bool db_ready = false);
   int group_select_refine (GroupJob& gj);
   int group_finish (GroupJob& gj, std::vector<std::vector<Score>>& out);
 

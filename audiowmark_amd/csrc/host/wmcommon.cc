@@ -5,30 +5,16 @@
 
 namespace awm {
 
-int         Params::frames_per_bit  = 2;
-double      Params::water_delta     = 0.01;
-std::string Params::json_output;
-bool        Params::strict          = false;
-bool        Params::mix             = true;
-bool        Params::hard            = false;
-bool        Params::snr             = false;
-size_t      Params::payload_size    = 128;
-double      Params::sync_threshold2 = 0.35;
-int         Params::get_n_best      = 8;
-double      Params::get_chunk_size  = 30;
-bool        Params::detect_speed    = false;
-bool        Params::detect_speed_patient = false;
-double      Params::try_speed       = -1;
-double      Params::test_speed      = -1;
-int         Params::test_cut        = 0;
-bool        Params::test_no_sync    = false;
-bool        Params::test_no_limiter = false;
-int         Params::test_truncate   = 0;
-int         Params::expect_matches  = -1;
-Format      Params::input_format    = Format::AUTO;
-Format      Params::output_format   = Format::AUTO;
+namespace {
+ParamValues g_params;                               // the process-wide settings (reference: the static members of Params)
+thread_local ParamValues *tl_bound = nullptr;       // settings of the context whose entry point this thread is inside, if it has its own
+}
+ParamValues& global_params() { return g_params; }
+ParamValues& params() { ParamValues *p = tl_bound; return p ? *p : g_params; }
+ParamsBind::ParamsBind (ParamValues *p) : m_prev (tl_bound) { if (p) tl_bound = p; }
+ParamsBind::~ParamsBind() { tl_bound = m_prev; }
 
-size_t mark_data_frame_count() { return code_size (ConvBlockType::a, Params::payload_size) * Params::frames_per_bit; }
+size_t mark_data_frame_count() { return code_size (ConvBlockType::a, params().payload_size) * params().frames_per_bit; }
 size_t mark_sync_frame_count() { return Params::sync_bits * Params::sync_frames_per_bit; }
 
 void
@@ -95,19 +81,19 @@ parse_payload (const std::string& bits)
       error ("audiowmark: cannot parse bits '%s'\n", bits.c_str());
       return {};
     }
-  if (Params::strict && bitvec.size() != Params::payload_size)
+  if (params().strict && bitvec.size() != params().payload_size)
     {
-      error ("audiowmark: number of message bits must match payload size (%zd bits)\n", Params::payload_size);
+      error ("audiowmark: number of message bits must match payload size (%zd bits)\n", params().payload_size);
       return {};
     }
-  if (bitvec.size() > Params::payload_size)
+  if (bitvec.size() > params().payload_size)
     {
       error ("audiowmark: number of bits in message '%s' larger than payload size\n", bits.c_str());
       return {};
     }
-  if (bitvec.size() < Params::payload_size)     // repeat short messages up to the payload size
+  if (bitvec.size() < params().payload_size)     // repeat short messages up to the payload size
     {
-      std::vector<int> expanded (Params::payload_size);
+      std::vector<int> expanded (params().payload_size);
       for (size_t i = 0; i < expanded.size(); i++)
         expanded[i] = bitvec[i % bitvec.size()];
       bitvec = expanded;
@@ -189,14 +175,14 @@ build_frame_mod_table (const Key& key, const std::vector<int>& payload_bits)
         }
       // data frames
       const int n_data = mark_data_frame_count();
-      if (Params::mix)
+      if (params().mix)
         {
           const auto entries = gen_mix_entries (key);
           for (int f = 0; f < n_data; f++)
             for (size_t j = 0; j < Params::bands_per_frame; j++)
               {
                 const MixEntry& e = entries[f * Params::bands_per_frame + j];
-                set_bands (block + size_t (e.frame) * NB, e.up, e.down, fec[f / Params::frames_per_bit]);
+                set_bands (block + size_t (e.frame) * NB, e.up, e.down, fec[f / params().frames_per_bit]);
               }
         }
       else
@@ -208,7 +194,7 @@ build_frame_mod_table (const Key& key, const std::vector<int>& payload_bits)
               data_gen.get (f, up, down);
               int8_t *row = block + size_t (bit_pos_gen.data_frame (f)) * NB;
               for (size_t i = 0; i < up.size(); i++)
-                set_bands (row, up[i], down[i], fec[f / Params::frames_per_bit]);
+                set_bands (row, up[i], down[i], fec[f / params().frames_per_bit]);
             }
         }
     }
@@ -267,7 +253,7 @@ MixTable
 build_mix_table (const Key& key)
 {
   MixTable t;
-  if (!Params::mix)
+  if (!params().mix)
     {
       // --linear (reference wmget.cc:110-152 linear_decode): data frame f uses its own 30 up / 30 down bands.  Written as the
       // entry list mix_decode consumes -- frame f's entries in band order -- the two decoders are the same computation:

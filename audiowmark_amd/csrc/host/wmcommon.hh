@@ -14,51 +14,67 @@ namespace awm {
 
 enum class Format { AUTO = 1, RAW, RF64, WAV_PIPE };
 
+/* The settings of the reference's Params that can change at run time (wmcommon.hh:33-89, same names and defaults).  The reference
+ * keeps them as static members, i.e. one set per process; here there is one process-wide set (global_params(): what the command
+ * line writes, what awm_set_params changes) and, optionally, one per context (awm_ctx_set_params).  Code reads the set in force
+ * through params(): the context's own set while a thread is inside one of that context's entry points (ParamsBind), else the
+ * process-wide one.  Helper threads bind what their parent had in force. */
+struct ParamValues
+{
+  int         frames_per_bit  = 2;
+  double      water_delta     = 0.01;
+  std::string json_output;
+  bool        strict          = false;
+  bool        mix             = true;
+  bool        hard            = false;
+  bool        snr             = false;
+  size_t      payload_size    = 128;
+  double      sync_threshold2 = 0.35;
+  int         get_n_best      = 8;
+  double      get_chunk_size  = 30;      // minutes
+  bool        detect_speed    = false;   // --detect-speed (reference wmcommon.hh:49-52)
+  bool        detect_speed_patient = false;
+  double      try_speed       = -1;      // --try-speed: manual speed correction
+  double      test_speed      = -1;      // --test-speed: expected speed, for the detect_speed report line
+  int         test_cut        = 0;
+  bool        test_no_sync    = false;
+  bool        test_no_limiter = false;
+  int         test_truncate   = 0;
+  int         expect_matches  = -1;
+  Format      input_format    = Format::AUTO;
+  Format      output_format   = Format::AUTO;
+};
+ParamValues& global_params();
+ParamValues& params();
+class ParamsBind           // nullptr: keep what is in force
+{
+  ParamValues *m_prev;
+public:
+  explicit ParamsBind (ParamValues *p);
+  ~ParamsBind();
+  ParamsBind (const ParamsBind&) = delete;
+  ParamsBind& operator= (const ParamsBind&) = delete;
+};
+
+// the constants (reference wmcommon.hh:36-68)
 struct Params
 {
   static constexpr size_t frame_size      = 1024;
-  static int              frames_per_bit;
   static constexpr size_t bands_per_frame = 30;
   static constexpr int    max_band        = 100;
   static constexpr int    min_band        = 20;
   static constexpr int    n_bands         = max_band - min_band + 1;   // 81
 
-  static double      water_delta;
-  static std::string json_output;
-  static bool        strict;
-  static bool        mix;
-  static bool        hard;
-  static bool        snr;
-  static size_t      payload_size;
-
   static constexpr int sync_bits           = 6;
   static constexpr int sync_frames_per_bit = 85;
   static constexpr int sync_search_step    = 256;
   static constexpr int sync_search_fine    = 8;
-  static double        sync_threshold2;
-  static int           get_n_best;
 
   static constexpr size_t frames_pad_start = 250;
   static constexpr int    mark_sample_rate = 44100;
 
   static constexpr double limiter_block_size_ms = 1000;
   static constexpr double limiter_ceiling       = 0.99;
-
-  static double get_chunk_size;     // minutes
-
-  static bool   detect_speed;          // --detect-speed (reference wmcommon.hh:49-52)
-  static bool   detect_speed_patient;  // --detect-speed-patient
-  static double try_speed;             // --try-speed: manual speed correction
-  static double test_speed;            // --test-speed: expected speed, for the detect_speed report line
-
-  static int  test_cut;
-  static bool test_no_sync;
-  static bool test_no_limiter;
-  static int  test_truncate;
-  static int  expect_matches;
-
-  static Format input_format;
-  static Format output_format;
 };
 
 size_t mark_data_frame_count();

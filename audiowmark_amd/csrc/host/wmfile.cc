@@ -11,6 +11,14 @@
 
 namespace awm {
 
+// The file level functions return 0 / 1 like the reference's (the value becomes the exit code of the command line); the C ABI
+// wants to tell argument, I/O and GPU failures apart: every failure path notes its kind for the calling thread.
+static thread_local int tl_fail_kind = 0;
+int file_fail_kind() { return tl_fail_kind ? tl_fail_kind : AWM_ERR_GENERIC; }
+void file_fail_reset() { tl_fail_kind = 0; }
+static int fail (int kind) { tl_fail_kind = kind; return 1; }
+
+
 namespace {
 
 /* File <-> HBM staging with BOUNDED host memory: the stream crosses PCIe chunk by chunk through two page-locked
@@ -106,7 +114,12 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
   Staging st (ctx, STAGE_FRAMES * unit, raw);
   if (!st.ok)
     return Error ("out of memory for input staging");
-  size_t cap_frames = in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN ? in_stream->n_frames() + 1 : STAGE_FRAMES * 4;
+  // The announced length only sizes the first allocation (the loop below grows the buffer when more arrives).  A length whose
+  // float32 size would not fit a device buffer -- a crafted ds64 / RIFF size on a pipe, where it cannot be checked against the
+  // file -- is treated like an unknown one: cap_frames * C * 4 must never wrap.
+  const size_t announced = in_stream->n_frames();
+  const size_t max_frames = DevBuffer::MAX_BYTES / (size_t (C) * sizeof (float));
+  size_t cap_frames = (announced != AudioInputStream::N_FRAMES_UNKNOWN && announced < max_frames) ? announced + 1 : STAGE_FRAMES * 4;
   if (d_pcm.reserve (cap_frames * C * sizeof (float)))
     return Error (awm_last_error());
   size_t frames = 0;
@@ -126,6 +139,8 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
           // stream of unknown (or understated) length: move to a buffer twice the size
           DevBuffer bigger;
           cap_frames = std::max (cap_frames * 2, frames + got);
+          if (cap_frames >= max_frames)
+            return Error ("input stream is too long for device memory");
           if (hipStreamSynchronize (st.copy) != hipSuccess || hipStreamSynchronize (ctx->stream) != hipSuccess
               || bigger.reserve (cap_frames * C * sizeof (float))
               || hipMemcpy (bigger.ptr, d_pcm.ptr, frames * C * sizeof (float), hipMemcpyDeviceToDevice) != hipSuccess)
@@ -402,7 +417,7 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   if (awm_add_stream_create (ctx, key.aes_key(), payload_hex.c_str(), C, TILE_FRAMES1024, &add))
     {
       error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
-      return 1;
+      return fail (AWM_ERR_HIP);
     }
   struct Guard { awm_add_stream *s; ~Guard() { awm_add_stream_destroy (s); } } guard { add };
   RawFormat fmt;
@@ -413,7 +428,7 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   if (!st.ok || !stage.ok)
     {
       error ("audiowmark: out of memory for the staging buffers\n");
-      return 1;
+      return fail (AWM_ERR_HIP);
     }
   SnrMeter snr;
   std::vector<const float *> snr_in;                       // --snr: the input slots of the tiles in flight (device pointers)
@@ -424,14 +439,14 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       if (k >= 2 && hipEventSynchronize (st.ev_copied[b]) != hipSuccess)
         {
           error ("audiowmark: GPU transfer failed\n");
-          return 1;
+          return fail (AWM_ERR_HIP);
         }
       size_t got = 0;
       Error err = read_chunk (in_stream, raw, unit, st.host[b].as<unsigned char>(), tile, got);
       if (err)
         {
           error ("audiowmark: input stream read failed: %s\n", err.message());
-          return 1;
+          return fail (AWM_ERR_IO);
         }
       eof = got < tile;
       float *slot = awm_add_stream_input (add);
@@ -456,26 +471,26 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       if (n_done < 0)
         {
           error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
-          return 1;
+          return fail (AWM_ERR_HIP);
         }
-      if (Params::snr)
+      if (params().snr)
         snr_in.push_back (slot);
       for (int i = 0; i < n_done; i++)
         {
-          if (Params::snr)
+          if (params().snr)
             {
               // finished tiles come out in stream order: the oldest input slot still listed belongs to this one
               if (!snr.add (snr_in.front(), done[i], done_frames[i] * C, ctx->stream))
                 {
                   error ("audiowmark: GPU transfer failed\n");
-                  return 1;
+                  return fail (AWM_ERR_HIP);
                 }
               snr_in.erase (snr_in.begin());
             }
           if (!stage.put (done[i], done_frames[i]))
             {
               error ("audiowmark: GPU staging failed: %s\n", awm_last_error());
-              return 1;
+              return fail (AWM_ERR_HIP);
             }
         }
       n_frames += got;
@@ -483,15 +498,15 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   if (hipStreamSynchronize (ctx->stream) != hipSuccess)
     {
       error ("audiowmark: GPU watermarking failed\n");
-      return 1;
+      return fail (AWM_ERR_HIP);
     }
   Error err = stage.finish();
   if (err)
     {
       error ("audiowmark output write failed: %s\n", err.message());
-      return 1;
+      return fail (AWM_ERR_IO);
     }
-  if (Params::snr && n_frames)
+  if (params().snr && n_frames)
     snr.report();
   return 0;
 }
@@ -510,7 +525,7 @@ add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   if (err)
     {
       error ("audiowmark: input stream read failed: %s\n", err.message());
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   n_frames = n_values / C;
   if (!n_values)
@@ -519,15 +534,15 @@ add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       || awm_add_watermark_d (ctx, key.aes_key(), payload_hex.c_str(), d_in.as<float>(), d_out.as<float>(), n_frames, C, in_stream->sample_rate()) != 0)
     {
       error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
-      return 1;
+      return fail (AWM_ERR_HIP);
     }
-  if (Params::snr)
+  if (params().snr)
     {
       SnrMeter snr;
       if (!snr.add (d_in.as<float>(), d_out.as<float>(), n_values, ctx->stream))
         {
           error ("audiowmark: GPU transfer failed\n");
-          return 1;
+          return fail (AWM_ERR_HIP);
         }
       snr.report();
     }
@@ -535,7 +550,7 @@ add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   if (err)
     {
       error ("audiowmark output write failed: %s\n", err.message());
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   return 0;
 }
@@ -548,21 +563,21 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
 {
   auto bitvec = parse_payload (bits);
   if (bitvec.empty())
-    return 1;
+    return fail (AWM_ERR_ARG);
   if (in_stream->sample_rate() != out_stream->sample_rate())
     {
       error ("audiowmark: input sample rate (%d) and output sample rate (%d) don't match\n", in_stream->sample_rate(), out_stream->sample_rate());
-      return 1;
+      return fail (AWM_ERR_ARG);
     }
   if (in_stream->n_channels() != out_stream->n_channels())
     {
       error ("audiowmark: input channels (%d) and output channels (%d) don't match\n", in_stream->n_channels(), out_stream->n_channels());
-      return 1;
+      return fail (AWM_ERR_ARG);
     }
   if (zero_frames)
     {
       error ("audiowmark: zero_frames (HLS segment watermarking) is not supported by the GPU path\n");
-      return 1;
+      return fail (AWM_ERR_HIP);
     }
   if (in_stream->sample_rate() != Params::mark_sample_rate
       && (!awm_resample_frames (ctx, 1024, in_stream->sample_rate(), Params::mark_sample_rate)
@@ -570,10 +585,10 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
     {
       // the reference falls back to zita's VResampler for such ratios (resample.cc:233-270)
       error ("audiowmark: resampling from old_rate=%d to new_rate=%d not implemented\n", in_stream->sample_rate(), Params::mark_sample_rate);
-      return 1;
+      return fail (AWM_ERR_ARG);
     }
   info ("Message:      %s\n", bit_vec_to_str (bitvec).c_str());
-  info ("Strength:     %.6g\n\n", Params::water_delta * 1000);
+  info ("Strength:     %.6g\n\n", params().water_delta * 1000);
   if (in_stream->n_frames() == AudioInputStream::N_FRAMES_UNKNOWN)
     info ("Time:         unknown\n");
   else
@@ -592,14 +607,14 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
   if (rc)
     return rc;
   (void) C;
-  info ("Data Blocks:  %d\n", count_data_blocks (n_frames, in_stream->sample_rate(), !Params::test_no_limiter));
+  info ("Data Blocks:  %d\n", count_data_blocks (n_frames, in_stream->sample_rate(), !params().test_no_limiter));
   if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN && n_frames != in_stream->n_frames())
     {
       auto msg = string_printf ("unexpected EOF; input frames (%zd) != output frames (%zd)", in_stream->n_frames(), n_frames);
-      if (Params::strict)
+      if (params().strict)
         {
           error ("audiowmark: error: %s\n", msg.c_str());
-          return 1;
+          return fail (AWM_ERR_IO);
         }
       warning ("audiowmark: warning: %s\n", msg.c_str());
     }
@@ -607,7 +622,7 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
   if (err)
     {
       error ("audiowmark: closing output stream failed: %s\n", err.message());
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   return 0;
 }
@@ -628,7 +643,7 @@ add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const st
   if (err)
     {
       error ("audiowmark: error opening %s: %s\n", infile.c_str(), err.message());
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   int out_bit_depth = in_stream->bit_depth();
   Encoding out_encoding = in_stream->encoding();
@@ -642,13 +657,13 @@ add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const st
   if (err)
     {
       error ("audiowmark: error writing to %s: %s\n", outfile.c_str(), err.message());
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   info ("Input:        %s\n", infile.c_str());
-  if (Params::input_format == Format::RAW)
+  if (params().input_format == Format::RAW)
     info_format ("Raw Input", StreamParams::raw_input_format);
   info ("Output:       %s\n", outfile.c_str());
-  if (Params::output_format == Format::RAW)
+  if (params().output_format == Format::RAW)
     info_format ("Raw Output", StreamParams::raw_output_format);
   return add_stream_watermark (ctx, key, in_stream.get(), out_stream.get(), bits, 0);
 }
@@ -666,7 +681,7 @@ get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInput
     {
       error ("audiowmark: error loading %s: %s\n", what.c_str(), err.message());
       d_in.release();
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   if (in_stream->sample_rate() != Params::mark_sample_rate)
     {
@@ -680,15 +695,15 @@ get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInput
           error ("audiowmark: resampling from old_rate=%d to new_rate=%d not implemented\n", in_stream->sample_rate(), Params::mark_sample_rate);
           d_in.release();
           d_res.release();
-          return 1;
+          return fail (AWM_ERR_ARG);
         }
       (void) hipStreamSynchronize (ctx->stream);
       d_in.release();
       d_in = d_res;
       n_values = out_frames * C;
     }
-  if (Params::test_truncate)
-    n_values = std::min (n_values, size_t (Params::mark_sample_rate) * C * Params::test_truncate);
+  if (params().test_truncate)
+    n_values = std::min (n_values, size_t (Params::mark_sample_rate) * C * params().test_truncate);
   const size_t n_frames = n_values / C;
   n_values_out = n_values;
   if (n_frames)
@@ -704,7 +719,7 @@ get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInput
         {
           error ("audiowmark: GPU detection failed: %s\n", awm_last_error());
           d_in.release();
-          return 1;
+          return fail (AWM_ERR_HIP);
         }
     }
   else
@@ -721,14 +736,14 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
     {
       orig_bitvec = parse_payload (orig_pattern);
       if (orig_bitvec.empty())
-        return 1;
+        return fail (AWM_ERR_ARG);
     }
   Error err;
   auto in_stream = AudioInputStream::create (infile, err);
   if (err)
     {
       error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   const int C = in_stream->n_channels();
   ResultSet result_set;
@@ -738,18 +753,18 @@ get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string
   const size_t time_length = lrint (double (n_values) / (double (Params::mark_sample_rate) * C));
 
   /* report (reference wmget.cc:941-969) */
-  if (!Params::json_output.empty())
-    result_set.print_json (time_length, Params::json_output);
-  if (Params::json_output != "-")
+  if (!params().json_output.empty())
+    result_set.print_json (time_length, params().json_output);
+  if (params().json_output != "-")
     result_set.print();
   if (!orig_bitvec.empty())
     {
       const int match_count = result_set.print_match_count (orig_bitvec);
       result_set.print_debug_sync();
-      if (Params::expect_matches >= 0)
+      if (params().expect_matches >= 0)
         {
-          printf ("expect_matches %d\n", Params::expect_matches);
-          if (match_count != Params::expect_matches)
+          printf ("expect_matches %d\n", params().expect_matches);
+          if (match_count != params().expect_matches)
             return 1;
         }
       else if (!match_count)
@@ -767,7 +782,7 @@ test_change_speed (awm_ctx *ctx, const std::string& infile, const std::string& o
   if (err)
     {
       error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   const int C = in_stream->n_channels();
   DevBuffer d_in, d_out;
@@ -777,7 +792,7 @@ test_change_speed (awm_ctx *ctx, const std::string& infile, const std::string& o
     {
       error ("audiowmark: error loading %s: %s\n", infile.c_str(), err.message());
       d_in.release();
-      return 1;
+      return fail (AWM_ERR_IO);
     }
   const size_t in_frames = n_values / C;
   const size_t out_frames = awm_resample_ratio_frames (in_frames, C, in_stream->sample_rate(), 1 / speed, -1);
@@ -787,7 +802,7 @@ test_change_speed (awm_ctx *ctx, const std::string& infile, const std::string& o
       error ("audiowmark: failed to setup vresampler with ratio=%f\n", 1 / speed);
       d_in.release();
       d_out.release();
-      return 1;
+      return fail (AWM_ERR_ARG);
     }
   auto out_stream = AudioOutputStream::create (outfile, C, in_stream->sample_rate(), in_stream->bit_depth() < 16 ? 16 : in_stream->bit_depth(),
                                                in_stream->bit_depth() < 16 ? Encoding::SIGNED : in_stream->encoding(), out_frames, err);
@@ -800,7 +815,7 @@ test_change_speed (awm_ctx *ctx, const std::string& infile, const std::string& o
   if (err)
     {
       error ("audiowmark: error saving %s: %s\n", outfile.c_str(), err.message());
-      return 1;
+      return fail (AWM_ERR_ARG);
     }
   return 0;
 }

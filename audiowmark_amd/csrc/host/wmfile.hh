@@ -17,6 +17,10 @@ class ResultSet;
 int get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInputStream *in_stream, bool print_speed, ResultSet& result_set,
                           size_t& n_values_out, const std::string& what);
 
+// kind of the last failure of the functions above on this thread (AWM_ERR_ARG / AWM_ERR_IO / AWM_ERR_HIP) for the C ABI
+int  file_fail_kind();
+void file_fail_reset();
+
 int test_change_speed (awm_ctx *ctx, const std::string& infile, const std::string& outfile, double speed);   // reference audiowmark.cc:419-437
 
 } // namespace awm

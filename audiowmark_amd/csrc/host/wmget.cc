@@ -18,7 +18,7 @@ normalize_soft_bits (const std::vector<float>& soft_bits)
 {
   std::vector<float> norm;
   norm.reserve (soft_bits.size());
-  if (Params::hard)
+  if (params().hard)
     {
       for (float v : soft_bits)
         norm.push_back (v > 0 ? 1.0 : 0.0);
@@ -42,7 +42,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
   // slice_range (a row of padded clips, kernels.hh launch_clip_pad): frames in the padding are not transformed, their dB values
   // are written directly (a frame of zeros transforms to exactly -96 dB per band)
   const size_t count = mark_block_frame_count();
-  const int n_bits = mark_data_frame_count() / Params::frames_per_bit;
+  const int n_bits = mark_data_frame_count() / params().frames_per_bit;
   const int C = wav.n_channels;
   slot_of.assign (index.size(), -1);
   ok.assign (index.size(), 0);
@@ -111,7 +111,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
       sb.mix_up = kt->mix_up.as<uint8_t>();
       sb.mix_down = kt->mix_down.as<uint8_t>();
       sb.n_data_frames = mark_data_frame_count();
-      sb.frames_per_bit = Params::frames_per_bit;
+      sb.frames_per_bit = params().frames_per_bit;
       sb.block_frames = int (count);
       sb.n_blocks = (long long) nb;
       sb.out = lane->ws_soft.as<float>() + b0 * n_bits;
@@ -128,7 +128,7 @@ int
 block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
                  std::vector<std::vector<float>>& raw_bits, std::vector<char>& ok)
 {
-  const int n_bits = mark_data_frame_count() / Params::frames_per_bit;
+  const int n_bits = mark_data_frame_count() / params().frames_per_bit;
   std::vector<int> slot_of;
   raw_bits.assign (index.size(), {});
   if (int rc = block_soft_bits_dev (ctx, ctx, kt, wav, index, slot_of, ok))
@@ -296,7 +296,7 @@ decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job)
   if (job.pending.empty())
     return 0;
   hipStream_t st = lane->stream;
-  const int n_bits = mark_data_frame_count() / Params::frames_per_bit;                 // 858
+  const int n_bits = mark_data_frame_count() / params().frames_per_bit;                 // 858
   const size_t n_steps = size_t (n_bits) / 6;                                          // trellis steps (payload + 15)
   job.n_out = n_steps - conv_order;
   for (size_t i = 0; i < job.pending.size(); i++)
@@ -354,7 +354,7 @@ decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job)
   pa.jobs = lane->ws_jobs.as<awmk::SoftJobDev>();
   pa.src = reinterpret_cast<const int2 *> (lane->ws_jobs.as<char>() + jobs_bytes);
   pa.n_jobs = (long long) n_jobs;
-  pa.hard = Params::hard ? 1 : 0;
+  pa.hard = params().hard ? 1 : 0;
   pa.out = lane->ws_viterbi_in.as<float>();
   const float *d_soft[3];
   unsigned char *d_ws[3];
@@ -723,7 +723,7 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
           int sync_match = 0;
           for (int expect_index = expect0; expect_index + expect_step < expect_end; expect_index += expect_step)
             for (const auto& s : first_scores)
-              if (std::abs (int (s.index + Params::test_cut) - expect_index) < int (Params::frame_size / 2))
+              if (std::abs (int (s.index + params().test_cut) - expect_index) < int (Params::frame_size / 2))
                 {
                   sync_match++;
                   break;
@@ -742,13 +742,16 @@ clip_run_padded (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list,
 {
   SyncFinder sync_finder (ctx, lane);
   const size_t count = mark_block_frame_count();
-  for (const Key& key : key_list)
+  for (size_t ki = 0; ki < key_list.size(); ki++)
     {
+      const Key& key = key_list[ki];
       KeyTables *kt = ctx->get_key_tables (key);
       if (!kt)
         return AWM_ERR_HIP;
       std::vector<SyncFinder::Score> sync_scores;
-      if (int rc = sync_finder.search (key, wav, SyncFinder::Mode::CLIP, sync_scores))
+      // (the dB matrices of the padded clip are computed for the first key and shared by the others: nothing between two searches
+      // writes the lane's ws_db / ws_have)
+      if (int rc = sync_finder.search (key, wav, SyncFinder::Mode::CLIP, sync_scores, /* db_ready */ ki > 0))
         return rc;
       std::vector<size_t> index;
       for (const auto& s : sync_scores)
@@ -842,7 +845,9 @@ clip_decoder_run (awm_ctx *ctx, WorkLane *lane, bool spread, const std::vector<K
       int end_rc = 0;
       std::string end_err;
       const int device = ctx->device;
+      ParamValues *const pv = &params();           // helper threads run under the settings in force here
       std::thread helper ([&] {
+        ParamsBind bind (pv);
         if (hipSetDevice (device) != hipSuccess)
           {
             end_rc = AWM_ERR_HIP;
@@ -877,10 +882,10 @@ static int
 decode_speed (awm_ctx *ctx, WorkLane *home, bool spread, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav,
               bool first_chunk, std::string *report)
 {
-  if (!(Params::detect_speed || Params::detect_speed_patient || Params::try_speed > 0))
+  if (!(params().detect_speed || params().detect_speed_patient || params().try_speed > 0))
     return 0;
   std::vector<DetectSpeedResult> speed_results;
-  if (Params::detect_speed || Params::detect_speed_patient)
+  if (params().detect_speed || params().detect_speed_patient)
     {
       if (int rc = detect_speed (ctx, home, key_list, wav, report, speed_results))
         return rc;
@@ -888,7 +893,7 @@ decode_speed (awm_ctx *ctx, WorkLane *home, bool spread, ResultSet& result_set, 
   else
     {
       for (const Key& key : key_list)
-        speed_results.push_back ({ key, Params::try_speed });
+        speed_results.push_back ({ key, params().try_speed });
     }
   for (const auto& sr : speed_results)
     {
@@ -936,7 +941,7 @@ std::vector<ChunkRange>
 plan_chunks (size_t n_frames, int n_channels)
 {
   const size_t rate = Params::mark_sample_rate;
-  const size_t max_size = size_t (lrint (Params::get_chunk_size * 60 * rate));
+  const size_t max_size = size_t (lrint (params().get_chunk_size * 60 * rate));
   const double block_seconds = mark_block_frame_count() * Params::frame_size / double (rate);
   const size_t overlap = size_t (lrint (2 * block_seconds * 1.3 * rate));
   (void) n_channels;
@@ -976,7 +981,7 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
   std::vector<ResultSet *> ptrs;
   for (auto& cs : chunk_sets)
     ptrs.push_back (&cs);
-  if (Params::detect_speed || Params::detect_speed_patient || Params::try_speed > 0)
+  if (params().detect_speed || params().detect_speed_patient || params().try_speed > 0)
     {
       /* The speed part of decode() for every chunk (reference wmget.cc:886-927) -- speed search, stretched copy, block and clip
        * decoder on the stretched copy -- is a long chain with a dozen host round trips (three search passes, each waiting for
@@ -1023,8 +1028,10 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
           std::atomic<size_t> next { 0 };
           std::vector<std::thread> workers;
           const int device = ctx->device;
+          ParamValues *const pv = &params();
           for (size_t li = 0; li < lanes.size(); li++)
             workers.emplace_back ([&, li] {
+              ParamsBind bind (pv);
               if (hipSetDevice (device) != hipSuccess)
                 return;
               for (;;)
@@ -1157,6 +1164,7 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
       std::vector<ResultSet *> ptrs;
       for (auto& cs : chunk_sets)
         ptrs.push_back (&cs);
+      bool db_ready = false;                 // the group's dB matrices are shared by the keys
       for (const Key& key : key_list)
         {
           KeyTables *kt = ctx->get_key_tables (key);
@@ -1165,7 +1173,8 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
           SyncFinder finder (ctx, lane);
           SyncFinder::GroupJob gj;
           std::vector<std::vector<SyncFinder::Score>> scores;
-          if (int rc = finder.group_approx_launch (kt, group, int (gn), d_range, gj)) return rc;
+          if (int rc = finder.group_approx_launch (kt, group, int (gn), d_range, gj, db_ready)) return rc;
+          db_ready = gj.n_scores > 0;
           if (int rc = finder.group_select_refine (gj)) return rc;
           if (int rc = finder.group_finish (gj, scores)) return rc;
           // soft bits and Viterbi decodes of ALL clips of the group in one batch
@@ -1182,6 +1191,7 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
                   slice.n_frames = slice_frames;
                   if (int rc = clip_run_padded (ctx, lane, { key }, slice, chunk_sets[g0 + i], 0.0, 1))
                     return rc;
+                  db_ready = false;              // (that search used the lane's dB workspace)
                   continue;
                 }
               for (const auto& sc : scores[i])
@@ -1242,7 +1252,7 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
     return 0;
   // short clips: staged over the lanes from this thread; everything else: one clip per lane and host thread
   std::vector<size_t> staged, threaded;
-  if (Params::detect_speed || Params::detect_speed_patient || Params::try_speed > 0)
+  if (params().detect_speed || params().detect_speed_patient || params().try_speed > 0)
     {
       // the speed search and the stretched copy of a clip live in per-context buffers: one clip after the other
       for (size_t i = 0; i < clips.size(); i++)
@@ -1281,8 +1291,10 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
       std::vector<int> rcs (n_staged_threads, 0);
       std::vector<std::string> messages (n_staged_threads);          // the error text is per thread
       std::vector<std::thread> workers;
+      ParamValues *const pv = &params();
       for (int t = 1; t < n_staged_threads; t++)
         workers.emplace_back ([&, t] {
+          ParamsBind bind (pv);
           (void) hipSetDevice (ctx->device);
           rcs[t] = clip_batch_staged (ctx, staged_lanes[t], key_list, clips, share[t], result_sets);
           if (rcs[t])
@@ -1325,7 +1337,9 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
   std::atomic<size_t> next { 0 };
   std::vector<int> rc (lanes.size(), 0);
   std::vector<std::string> err (lanes.size());
+  ParamValues *const pv = &params();
   auto worker = [&] (size_t li) {
+    ParamsBind bind (pv);
     const bool was_blocking = wait_blocking();
     wait_blocking() = lanes.size() > 1;
     struct Restore { bool v; ~Restore() { wait_blocking() = v; } } restore { was_blocking };

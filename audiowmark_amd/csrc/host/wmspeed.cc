@@ -553,7 +553,7 @@ speed_scan (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& wav, 
   ca.steps_per_frame = steps_per_frame;
   ca.pad_start = frames_per_block * steps_per_frame + steps_per_frame;      // "a bit of overlap to handle boundaries"
   ca.rows_per_bit = Params::sync_frames_per_bit;
-  ca.min_delta = std::min (Params::water_delta, 0.080);
+  ca.min_delta = std::min (params().water_delta, 0.080);
   ca.best = ws->best.as<unsigned long long>();
   AWM_HIP_CHECK (awmk::launch_speed_compare (st, ca, int (items.size())));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
@@ -664,7 +664,7 @@ detect_speed (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, co
   const double in_seconds = double (wav.n_frames) / wav.sample_rate;
   if (in_seconds < 0.25)
     return 0;
-  const bool patient = Params::detect_speed_patient;
+  const bool patient = params().detect_speed_patient;
   // first pass: grid over 0.8 .. 1.25; second: improve the n best; third: fast refinement around the best
   const SpeedScanParams scan1 = patient ? SpeedScanParams { 50, 1.00035, 11, 28 } : SpeedScanParams { 25, 1.0007, 5, 28 };
   const SpeedScanParams scan2 = patient ? SpeedScanParams { 50, 1.000175, 1, 0 } : SpeedScanParams { 50, 1.00035, 1, 0 };
@@ -699,8 +699,8 @@ detect_speed (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, co
       if (report)
         {
           double delta = -1;
-          if (Params::test_speed > 0)
-            delta = 100 * std::fabs (best_speed - Params::test_speed) / Params::test_speed;
+          if (params().test_speed > 0)
+            delta = 100 * std::fabs (best_speed - params().test_speed) / params().test_speed;
           *report += string_printf ("detect_speed %f %f %.4f\n", best_speed, best_quality, delta);
         }
       if (best_speed_out)

@@ -29,6 +29,7 @@ extern "C" {
 #define AWM_ERR_NO_DEVICE  (-2)
 #define AWM_ERR_ARG        (-3)
 #define AWM_ERR_HIP        (-4)
+#define AWM_ERR_IO         (-5)    /* a file could not be opened / read / written (file level entry points) */
 
 #define AWM_FRAME_SIZE      1024
 #define AWM_N_BANDS         81      /* bins 20..100, wmcommon.hh:39-40 */
@@ -207,6 +208,12 @@ int awm_resample_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_
  * ClipDecoder, merge + sort.  Returns the pattern count (<= max_out filled). */
 int awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
                          int n_channels, size_t max_out, awm_pattern *out);
+/* The reference's get_watermark takes a LIST of keys (wmcommon.hh:228, `--key a --key b`, tests/key-test.sh:13-37): the file is
+ * read once, the approximate dB matrices of a chunk / of a padded clip are computed once and shared by the keys
+ * (syncfinder.cc:171-256), patterns are sorted by time with the key list order breaking ties (wmget.cc:288-316).
+ * keys = n_keys * 16 bytes; key_of_pattern[j] (may be NULL) = position in that list of the key pattern j was found with. */
+int awm_get_watermark_keys_d (awm_ctx *ctx, const uint8_t *keys, int n_keys, const float *pcm_d, size_t n_frames, int n_channels,
+                              size_t max_out, awm_pattern *out, int *key_of_pattern);
 /* get_watermark for a batch of independent inputs (BASELINE config 5: many short clips; the reference would run one
  * `audiowmark get` process per file, wmget.cc:886-1013 each).  Clip i = n_frames[i] frames at pcm_d[i] (device pointers),
  * all with n_channels channels.  Clips shorter than one block + 2 frames (51.7 s: only the ClipDecoder's START pass has work,
@@ -241,6 +248,8 @@ int awm_add_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *pay
                             const awm_raw_format *raw_in, const awm_raw_format *raw_out);
 int awm_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *in_path, const awm_raw_format *raw_in,
                             size_t max_out, awm_pattern *out);
+int awm_get_watermark_keys_file (awm_ctx *ctx, const uint8_t *keys, int n_keys, const char *in_path, const awm_raw_format *raw_in,
+                                 size_t max_out, awm_pattern *out, int *key_of_pattern);
 
 /* chunk plan of WavChunkLoader (wavchunkloader.cc:54-163) for a stream of n_frames samples per channel:
  * chunk i covers [first_frame[i], first_frame[i] + chunk_frames[i]) and reports times offset by
@@ -294,9 +303,35 @@ int    awm_speed_clip_candidates (const uint8_t key[16], const float *hashed_val
 /* --quiet (reference audiowmark.cc:1020-1023): the "Input: / Output: / Message: ..." information lines of add_watermark off */
 void awm_set_quiet (int quiet);
 
-/* global parameters (reference Params, wmcommon.hh:33-89) */
+/* ---- parameters (reference Params, wmcommon.hh:33-89) ------------------------------------------------------------------
+ * The reference keeps its settings in static members of Params: one set per process.  This library has one process-wide set
+ * with the same names and defaults -- awm_set_params / awm_set_speed_params / awm_set_global_params change it -- and every
+ * context may carry its OWN set (awm_ctx_set_params), which is in force for all work entered through that context, also on the
+ * helper threads the library starts for it.  Two contexts with different strength / thresholds / --hard can therefore work side
+ * by side in one process; a context without its own set follows the process-wide one as of each call. */
 void awm_set_params (double water_delta, int mix, int frames_per_bit, int test_no_limiter,
                      double sync_threshold2, int n_best, double chunk_size_min);
+typedef struct
+{
+  size_t struct_size;            /* sizeof (awm_params), filled by awm_params_init / awm_ctx_get_params */
+  double water_delta;            /* --strength / 1000            (Params::water_delta, default 0.01) */
+  int    mix;                    /* 0 = --linear                 (Params::mix, 1) */
+  int    hard;                   /* --hard: hard decode bits     (Params::hard, 0; wmget.cc:40-65) */
+  int    strict;                 /* --strict: message length must equal payload_size, `add` refuses clipped input (Params::strict, 0) */
+  int    snr;                    /* --snr: `add` reports the SNR (Params::snr, 0; file level only) */
+  int    payload_size;           /* bits (Params::payload_size, 128; other sizes are refused by the compute entry points) */
+  int    frames_per_bit;         /* (Params::frames_per_bit, 2; other values are refused by the compute entry points) */
+  double sync_threshold2;        /* --sync-threshold (Params::sync_threshold2, 0.35) */
+  int    get_n_best;             /* (Params::get_n_best, 8) */
+  double get_chunk_size;         /* --chunk-size, minutes (Params::get_chunk_size, 30) */
+  int    detect_speed, detect_speed_patient;   /* --detect-speed, --detect-speed-patient */
+  double try_speed, test_speed;  /* --try-speed, --test-speed (-1: unset) */
+  int    test_cut, test_no_sync, test_no_limiter, test_truncate;     /* the reference's --test-* knobs */
+} awm_params;
+void awm_params_init (awm_params *p);                               /* the reference's defaults */
+int  awm_set_global_params (const awm_params *p);                   /* the process-wide set */
+int  awm_ctx_set_params (awm_ctx *ctx, const awm_params *p);        /* p == NULL: back to the process-wide set */
+int  awm_ctx_get_params (const awm_ctx *ctx, awm_params *out);      /* the set in force for ctx (ctx == NULL: the process-wide one) */
 
 #ifdef __cplusplus
 }

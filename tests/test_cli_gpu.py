@@ -244,3 +244,82 @@ def test_malformed_wav_headers_are_rejected(tmp_path):
                       + b"data" + struct.pack("<I", 400) + b"\0" * 400)
         r = run([AWM, "test-snr", str(f), str(f)], check=False)
         assert r.returncode == 1 and what in r.stderr
+
+
+def _ref_lines(args, stdin=None):
+    r = run([_ref.BIN] + args, stdin=stdin)
+    return [l.split() for l in r.stdout.decode().splitlines() if l.startswith("pattern")]
+
+
+def test_hard_option_through_the_c_abi(work):
+    """--hard without the command line: a context with its own parameter set (awm_ctx_set_params) next to one that follows the
+    process-wide defaults, in one process; the patterns of both equal the reference binary's with / without --hard"""
+    import ctypes as C
+    import audiowmark_amd as awm
+    d, _, marked = work
+    soft_ctx, hard_ctx = awm.Context(0), awm.Context(0)
+    hard_ctx.set_params(hard=1)
+    assert hard_ctx.get_params().hard == 1 and soft_ctx.get_params().hard == 0
+    hard = hard_ctx.get_watermark_file(None, str(marked))
+    soft = soft_ctx.get_watermark_file(None, str(marked))
+    again = hard_ctx.get_watermark_file(None, str(marked))                     # the other context's call changed nothing
+    assert [p["bits"] for p in again] == [p["bits"] for p in hard]
+    assert [p["decode_error"] for p in hard] != [p["decode_error"] for p in soft]
+    assert sum(p["bits"] == PAY for p in hard) >= 5
+    if os.path.exists(_ref.BIN):
+        for ours, opt in ((hard, ["--hard"]), (soft, [])):
+            theirs = _ref_lines(["get"] + opt + ["--x-in-wav-pipe", str(marked)])
+            assert len(theirs) == len(ours)
+            for a, b in zip(ours, theirs):                                      # pattern time bits quality error type
+                assert a["bits"] == b[2] and "%.3f" % a["sync_quality"] == b[3] and "%.3f" % a["decode_error"] == b[4]
+    hard_ctx.set_params()                                                       # back to the process-wide set
+    assert [p["decode_error"] for p in hard_ctx.get_watermark_file(None, str(marked))] == [p["decode_error"] for p in soft]
+    # a parameter the kernels are not built for is refused at the entry point, not silently ignored
+    soft_ctx.set_params(frames_per_bit=3)
+    with pytest.raises(awm.AwmError):
+        soft_ctx.get_watermark_file(None, str(marked))
+
+
+def test_two_keys_in_one_get_through_the_c_abi(tmp_path):
+    """tests/key-test.sh:13-37 (double watermark with two different keys) through awm_get_watermark_keys_d / _file only: one pass
+    over the material, every pattern names its key; equal to one call per key and to the reference binary with two --test-key"""
+    import torch
+    import audiowmark_amd as awm
+    msg2 = "0123456789abcdef0123456789abcdef"
+    ctx = awm.Context(0)
+    k_default, k42, k7 = None, awm.test_key(42), awm.test_key(7)
+    n = 30 * 44100
+    x = torch.from_numpy((np.clip(np.trunc(awm.binding.gen_noise(None, 2 * n).astype(np.float64) * 32768), -32768, 32767) / 32768)
+                         .astype(np.float32).reshape(n, 2)).cuda()
+    both = ctx.add_watermark(k42, msg2, ctx.add_watermark(k_default, PAY, x))
+    pats = ctx.get_watermark_keys([k42, k7, k_default], both)
+    by_key = lambda i: [p for p in pats if p["key_index"] == i]
+    assert any(p["bits"] == msg2 for p in by_key(0)) and not any(p["bits"] == PAY for p in by_key(0))
+    assert any(p["bits"] == PAY for p in by_key(2)) and not any(p["bits"] == msg2 for p in by_key(2))
+    assert not any(p["bits"] in (PAY, msg2) for p in by_key(1))                # key 7 marks nothing
+    strip = lambda ps: [{k: v for k, v in p.items() if k != "key_index"} for p in ps]
+    for i, k in enumerate([k42, k7, k_default]):
+        assert strip(by_key(i)) == ctx.get_watermark(k, both)                  # same patterns as one call per key
+    # the file level entry point on the same material (s16 raw) and the reference binary with the same key list
+    raw = tmp_path / "both.raw"
+    ctx.pcm_encode(both.reshape(-1), 16, 0, False, True).cpu().numpy().tofile(raw)
+    rf = awm.binding.RawFormat(2, 44100, 16, 0, 0)
+    from_file = ctx.get_watermark_keys_file([k42, k_default], str(raw), rf)
+    assert any(p["bits"] == msg2 and p["key_index"] == 0 for p in from_file)
+    assert any(p["bits"] == PAY and p["key_index"] == 1 for p in from_file)
+    if os.path.exists(_ref.BIN):
+        r = run([_ref.BIN, "get", "--x-in-raw", "--test-key", "42", "--test-key", "0", "-"], stdin=raw.read_bytes(), check=False)
+        if r.returncode == 0:
+            theirs = [l.split() for l in r.stdout.decode().splitlines() if l.startswith(("pattern", "key"))]
+            ours, last = [], None
+            for p in from_file:
+                if p["key_index"] != last:
+                    ours.append(["key", "test-key-%d" % (42, 0)[p["key_index"]]])
+                    last = p["key_index"]
+                ours.append(p)
+            assert len(ours) == len(theirs)
+            for a, b in zip(ours, theirs):
+                if b[0] == "key":
+                    assert a == b
+                else:
+                    assert a["bits"] == b[2] and "%.3f" % a["sync_quality"] == b[3]

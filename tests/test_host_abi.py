@@ -167,3 +167,39 @@ def test_speed_host_pieces_match_oracle():
         return float((c * c).sum())
     best = max(loc, key=energy)
     assert orc.speed_clip_location(key, x, 2, 25.0) == best
+
+
+def test_params_struct_round_trip_and_validation():
+    """awm_params (reference Params, wmcommon.hh:33-89): defaults, the process-wide set, refusal of a foreign struct size"""
+    p = awm.binding.Params()
+    assert (p.water_delta, p.mix, p.hard, p.strict, p.snr, p.payload_size, p.frames_per_bit) == (0.01, 1, 0, 0, 0, 128, 2)
+    assert (p.sync_threshold2, p.get_n_best, p.get_chunk_size, p.try_speed, p.test_speed) == (0.35, 8, 30.0, -1.0, -1.0)
+    try:
+        awm.binding.set_global_params(hard=1, water_delta=0.02, get_n_best=5)
+        q = awm.binding.Params()
+        assert awm.lib.awm_ctx_get_params(None, C.byref(q)) == 0
+        assert (q.hard, q.water_delta, q.get_n_best, q.mix) == (1, 0.02, 5, 1)
+        # the legacy setters address the same process-wide set
+        awm.set_params(water_delta=0.015)
+        awm.lib.awm_ctx_get_params(None, C.byref(q))
+        assert q.water_delta == 0.015 and q.hard == 1
+        bad = awm.binding.Params()
+        bad.struct_size = 8
+        assert awm.lib.awm_set_global_params(C.byref(bad)) == -3 and b"struct_size" in awm.lib.awm_last_error()
+        bad = awm.binding.Params(get_n_best=0)
+        assert awm.lib.awm_set_global_params(C.byref(bad)) == -3
+        assert awm.lib.awm_ctx_set_params(None, C.byref(p)) == -3               # no context
+    finally:
+        awm.binding.set_global_params()
+    awm.lib.awm_ctx_get_params(None, C.byref(q))
+    assert (q.hard, q.water_delta, q.get_n_best) == (0, 0.01, 8)
+
+
+def test_library_leaves_the_environment_alone():
+    """awm_ctx_create used to export GPU_MAX_HW_QUEUES into its host's environment"""
+    import subprocess, sys
+    code = ("import os, ctypes as C, sys; sys.path.insert(0, %r); os.environ.pop('GPU_MAX_HW_QUEUES', None);"
+            "import audiowmark_amd as awm; h = C.c_void_p(); awm.lib.awm_ctx_create(0, C.byref(h));"
+            "print('GPU_MAX_HW_QUEUES' in os.environ, C.CDLL(None).getenv(b'GPU_MAX_HW_QUEUES'))" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, timeout=300).stdout.split()
+    assert out == ["False", "0"], out

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (the library leaves the environment alone)
 """16 clips decoded one at a time (no concurrency between clips) for a rocprofv3 kernel trace: stand-alone kernel durations of a clip's `get`"""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (the library leaves the environment alone)
 """a batch of CLIPS (default 256) watermarked 30 s clips through get_watermark_batch, for a rocprofv3 kernel trace:
 cd /tmp && rocprofv3 --kernel-trace --stats -d <dir> -- python tools/gpu_clip_trace.py"""
 import os, sys, time

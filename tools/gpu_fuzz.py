@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (the library leaves the environment alone)
 """Randomised cross-check on a GPU box: short clips with random lengths, channel counts, digital silence at the edges and in
 the middle, watermarked or not -- `get` through the HIP path against the oracle (pattern lists must be identical), and the
 variable-ratio resampler against the restated zita class on random ratios / lengths."""

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (the library leaves the environment alone)
 """Peak resident set size of the command line binary for `add` and `get` on s16 raw files of several lengths
 (bounded-memory check of the streamed paths).  usage: python tools/gpu_rss.py [minutes ...]"""
 import os

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (the library leaves the environment alone)
 """Development check of the speed detection path on a GPU box: every stage against the oracle, with timings."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))

@@ -1,3 +1,4 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")   # before the HIP runtime starts (the library leaves the environment alone)
 """detect_speed on a replayed 30 s stereo clip, a few times: for rocprofv3 --kernel-trace --stats and host timing."""
 import os, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
