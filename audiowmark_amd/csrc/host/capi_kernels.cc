@@ -171,6 +171,19 @@ add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames
   return 0;
 }
 
+} // extern "C"
+namespace awm {
+int
+add_mix_device (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels, const int8_t *frame_mod_dev,
+                double water_delta, size_t first_frame, const float *halo_before_d, const float *halo_after_d, float *block_max_d,
+                size_t first_block, size_t n_blocks)
+{
+  return add_mix_impl (ctx, pcm_in_d, out_d, n_frames, n_channels, frame_mod_dev, water_delta, first_frame, halo_before_d, halo_after_d,
+                       block_max_d, first_block, n_blocks);
+}
+}
+extern "C" {
+
 int
 awm_add_mix_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
                const int8_t *frame_mod, double water_delta, size_t first_frame,

@@ -92,7 +92,7 @@ SyncFinder::fetch_scores (long long n_scores, std::vector<SearchScore>& out)
 }
 
 int
-SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores, bool db_ready)
+SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores, bool db_ready, bool scores_only)
 {
   n_scores = 0;
   const int clip = mode == Mode::CLIP;
@@ -159,12 +159,25 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
     ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0, st);
     AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));
   }
-  {
-    ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_shifts) * S * 24.0, st);
-    AWM_HIP_CHECK (awmk::launch_local_mean (st, m_lane->ws_q.as<double>(), q_stride, S, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>()));
-  }
-
   n_scores = (long long) n_shifts * S;
+  if (scores_only)
+    return 0;
+  ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_shifts) * S * 24.0, st);
+  AWM_HIP_CHECK (awmk::launch_local_mean (st, m_lane->ws_q.as<double>(), q_stride, S, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>()));
+  return 0;
+}
+
+int
+SyncFinder::scores_loaded (long long S)
+{
+  if (S <= 0)
+    return 0;
+  const int n_shifts = Params::frame_size / Params::sync_search_step;
+  const long long q_stride = (S + 63) & ~63LL;
+  if (int rc = m_lane->ws_raw.reserve (size_t (n_shifts) * S * sizeof (double))) return rc;
+  if (int rc = m_lane->ws_mean.reserve (size_t (n_shifts) * S * sizeof (double))) return rc;
+  ProfScope ps (m_ctx, PROF_LOCAL_MEAN, double (n_shifts) * S * 24.0, m_lane->stream);
+  AWM_HIP_CHECK (awmk::launch_local_mean (m_lane->stream, m_lane->ws_q.as<double>(), q_stride, S, m_lane->ws_raw.as<double>(), m_lane->ws_mean.as<double>()));
   return 0;
 }
 
@@ -757,6 +770,21 @@ SyncFinder::search_finish (SearchJob& job, std::vector<Score>& out)
       out.push_back ({ s.index, std::fabs (q), q > 0 ? ConvBlockType::a : ConvBlockType::b });
     }
   return 0;
+}
+
+/* refine_finish + the end of search_finish for refined scores that were collected elsewhere (candidate order) */
+void
+SyncFinder::finish_scores (std::vector<SearchScore> scores, std::vector<Score>& out)
+{
+  out.clear();
+  std::stable_sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
+  select_threshold_and_n_best (scores, params().sync_threshold2);
+  std::sort (scores.begin(), scores.end(), [] (const SearchScore& a, const SearchScore& b) { return a.index < b.index; });
+  for (const auto& s : scores)
+    {
+      const double q = s.raw_quality - s.local_mean;
+      out.push_back ({ s.index, std::fabs (q), q > 0 ? ConvBlockType::a : ConvBlockType::b });
+    }
 }
 
 /* ---- CLIP search for a group of padded clips (syncfinder.hh GroupJob) -------------------------------------------------------- */

@@ -48,7 +48,11 @@ public:
   int prepare_finish();                                   // ... and the wait
   int search_approx (KeyTables *kt, const DeviceWav& wav, Mode mode, std::vector<SearchScore>& out);
   // kernels of search_approx only: scores stay on the device (ws_raw / ws_mean, index order); n_scores = 4 * start frames
-  int approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores, bool db_ready = false);
+  // scores_only: stop after the scan (raw qualities [shift][q_stride] in ws_q, q_stride = start frames rounded up to 64): the multi-GPU
+  // protocol computes a chunk's scores in parts and runs the local mean on the assembled list (scores_loaded)
+  int approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long long& n_scores, bool db_ready = false, bool scores_only = false);
+  // ws_q holds the raw qualities of n_start_frames start frames x 4 shifts (assembled by the caller): local mean -> ws_raw / ws_mean
+  int scores_loaded (long long n_start_frames);
   // local maxima + mask + threshold (+ n_best fallback): the candidate list search_refine works on
   int select_candidates (long long n_scores, double threshold, std::vector<SearchScore>& out);
   int select_launch (long long n_scores, double threshold, bool speculate_n_best = false);   // device part of it, not waited for
@@ -109,6 +113,12 @@ public:
   int group_select_refine (GroupJob& gj);
   int group_finish (GroupJob& gj, std::vector<std::vector<Score>>& out);
 
+  // refinement of job.candidates in two halves (job.refined: candidate order); the multi-GPU protocol refines a chunk's candidates in parts
+  int refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, SearchJob& job);
+  int refine_collect (SearchJob& job) { return refine_batch_finish (job); }
+  // the end of search(): refined scores in candidate order -> final sync positions (reference syncfinder.cc:527-557)
+  static void finish_scores (std::vector<SearchScore> refined, std::vector<Score>& out);
+
   static void select_local_maxima (std::vector<SearchScore>& scores);
   static void mask_avg_false_positives (std::vector<SearchScore>& scores);
   static void select_threshold_and_n_best (std::vector<SearchScore>& scores, double threshold);
@@ -121,7 +131,6 @@ private:
   bool     m_prepare_pending = false;
   int scan_silence (const DeviceWav& wav);
   int fetch_scores (long long n_scores, std::vector<SearchScore>& out);
-  int refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, SearchJob& job);
   int refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, SearchJob& job, size_t c0, size_t nb, size_t batch);
   int refine_batch_finish (SearchJob& job);
   int refine_finish (SearchJob& job, std::vector<SearchScore>& scores);

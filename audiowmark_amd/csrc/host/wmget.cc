@@ -1,4 +1,5 @@
 #include "wmget.hh"
+#include "wmdecode.hh"
 #include "wmspeed.hh"
 #include <atomic>
 #include <memory>
@@ -37,7 +38,7 @@ normalize_soft_bits (const std::vector<float>& soft_bits)
  * block i (if ok[i]) is slot[i] of ctx->ws_soft ([slots][858] floats) */
 int
 block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
-                     std::vector<int>& slot_of, std::vector<char>& ok, const long long *slice_range = nullptr, size_t slice_frames = 0)
+                     std::vector<int>& slot_of, std::vector<char>& ok, const long long *slice_range, size_t slice_frames)
 {
   // slice_range (a row of padded clips, kernels.hh launch_clip_pad): frames in the padding are not transformed, their dB values
   // are written directly (a frame of zeros transforms to exactly -96 dB per band)
@@ -253,40 +254,6 @@ viterbi_decode (awm_ctx *ctx, ConvBlockType block_type, const std::vector<std::v
 
 /* ---- BlockDecoder (reference wmget.cc:492-735) ---------------------------------------- */
 
-namespace {
-
-struct PatternRawBits      // a decoded block: where its raw soft bits live on the device
-{
-  size_t        index;
-  double        quality;
-  int           slot;        // row of ctx->ws_soft
-  ConvBlockType block_type;
-};
-
-struct PendingDecode       // one Viterbi job and what to do with its result
-{
-  ConvBlockType      code_type;
-  int                mode;            // awmk::SoftJobDev::mode
-  std::vector<std::pair<int, int>> src;      // (slot, half)
-  int                norm0, norm1;
-  double             time;
-  SyncFinder::Score  score;
-  ResultSet::Type    type;
-  size_t             chunk = 0;       // which chunk's ResultSet receives the pattern
-};
-
-// Every pending decode goes to the GPU in one pass: K7b builds the normalised decoder inputs from the raw soft bits that
-// are already on the device, K8 decodes A, B and AB blocks side by side; only payload bits come back.
-// decode_launch queues all of it on the lane's stream without waiting, decode_finish collects the payloads.
-struct DecodeJob
-{
-  std::vector<PendingDecode> pending;
-  std::vector<size_t> which[3];
-  size_t nb[3] = { 0, 0, 0 }, bits_off[3] = { 0, 0, 0 }, err_off[3] = { 0, 0, 0 };
-  size_t bits_total = 0, err_total = 0, n_out = 0;
-  bool   launched = false;
-};
-
 int
 decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job)
 {
@@ -384,7 +351,8 @@ decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job)
 }
 
 int
-decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::vector<ResultSet *>& result_sets, double speed)
+decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::vector<ResultSet *>& result_sets, double speed,
+               std::vector<DecodedPattern> *patterns_out)
 {
   if (!job.launched)
     return 0;
@@ -405,7 +373,11 @@ decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::vector
   for (size_t i = 0; i < job.pending.size(); i++)
     {
       const PendingDecode& p = job.pending[i];
-      if (!bits[i].empty())
+      if (bits[i].empty())
+        continue;
+      if (patterns_out)
+        patterns_out->push_back ({ i, bits[i], errors[i] });
+      else
         result_sets[p.chunk]->add_pattern (key, p.time, p.score, bits[i], errors[i], p.type, speed);
     }
   return 0;
@@ -511,6 +483,8 @@ combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const Device
       pending.push_back ({ ConvBlockType::ab, 2, src, norm[0], norm[1], 0.0, score_all, ResultSet::Type::ALL, chunk });
     }
 }
+
+namespace {
 
 /* BlockDecoder::run (reference wmget.cc:502-706) for several chunks of one resident stream at once.  Every chunk
  * is searched and combined on its own exactly like the reference does; only the device work is batched across

@@ -262,6 +262,56 @@ int awm_plan_chunks (size_t n_frames, size_t max_out, uint64_t *first_frame, uin
 int awm_merge_patterns (const uint8_t key[16], const awm_pattern *patterns, const int *chunk_count, int n_chunks,
                         size_t max_out, awm_pattern *out);
 
+/* ---- one stream over several GPUs -------------------------------------------------------------------------------------------
+ * The stream is the concatenation of the ranks' spans (rank order; every span but the last non-empty one a whole number of
+ * 1024-sample frames), one context per GPU.  What the algorithm couples across a span boundary is all that travels:
+ *   add   one frame each way (3-frame overlap-add, wmadd.cc:228-238) and the limiter's per-second maxima of the seconds that
+ *         straddle span edges (limiter.cc:90-124): one exchange of edge frames + one max-reduction.
+ *   get   The reference's chunks (wavchunkloader.cc:75-84) stay the semantic unit -- local mean, n_best and the A / B
+ *         combination are per chunk -- but the WORK of a chunk is split by position: a rank computes the sync scores
+ *         (syncfinder.cc:171-256), refines (:393-458) and extracts the soft bits (wmget.cc:67-108) of the candidate starts that lie in its
+ *         span, for which it needs one block + 2 frames of its successor's samples (the "overlap stitch", 18 MB for stereo);
+ *         the ranks that share a chunk exchange its raw scores (32 B per frame of audio: the "score gather"), select the
+ *         candidates redundantly (deterministic), exchange the few refined scores and the blocks' soft bits (3.4 KB per block),
+ *         and share the Viterbi decodes.  Rank 0 merges the patterns (wmget.cc:288-316).  Work per rank is proportional to its
+ *         span (balanced to within a block), results are identical to awm_get_watermark_d on the whole stream.
+ * The transport is the caller's: three callbacks (RCCL / torch.distributed in audiowmark_amd/sharded.py, hipMemcpyPeer between the
+ * threads of one process in awm_multi_*).  Every rank calls the entry point with the same span list; all sizes are known on both
+ * sides of every transfer.  Each callback returns 0 or an error (the entry point then fails with AWM_ERR_GENERIC). */
+typedef struct awm_comm
+{
+  void *user;
+  int   rank, world;
+  /* point-to-point round: all transfers posted together, complete on return.  *_d: device memory (the data is ready on the
+   * context's stream when the callback is entered, and the callback's writes are visible to that stream when it returns);
+   * *_h: host memory (small control data). */
+  int (*exchange_d) (void *user, int n_send, const void *const *send, const size_t *send_bytes, const int *send_to,
+                     int n_recv, void *const *recv, const size_t *recv_bytes, const int *recv_from);
+  int (*exchange_h) (void *user, int n_send, const void *const *send, const size_t *send_bytes, const int *send_to,
+                     int n_recv, void *const *recv, const size_t *recv_bytes, const int *recv_from);
+  /* element-wise maximum over all ranks of n unsigned 32 bit words in device memory, in place (the limiter maxima: non-negative
+   * floats order like their bit patterns) */
+  int (*all_reduce_max_u32_d) (void *user, uint32_t *data, size_t n);
+} awm_comm;
+/* add_watermark core for this rank's span (out_d: span_frames[rank] * C floats); 44.1 kHz streams only */
+int awm_sharded_add_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const float *pcm_in_d, float *out_d, int n_channels,
+                       const uint64_t *span_frames /* [world] */, const awm_comm *comm);
+/* get_watermark core; the merged pattern list arrives on rank 0 (return value = its length, at most max_out written), the other
+ * ranks return 0 */
+int awm_sharded_get_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, int n_channels, const uint64_t *span_frames /* [world] */,
+                       const awm_comm *comm, size_t max_out, awm_pattern *out);
+/* the plan behind awm_sharded_get_d, for tests and balance checks (pure host): for every (chunk, rank) the range of candidate start
+ * frames [first_sf, first_sf + n_sf) of the chunk that rank works on.  Returns the number of entries (chunks * world). */
+int awm_sharded_plan (const uint64_t *span_frames, int world, size_t max_out, int *chunk, int *rank, uint64_t *first_sf, uint64_t *n_sf);
+
+/* The same on the GPUs of ONE process (the command line's --gpus / AWM_DEVICES): one context per device, one host thread per
+ * context inside the call, hipMemcpyPeer as transport.  span i lives on ctxs[i]'s device at pcm_d[i] (several contexts may share
+ * a device). */
+int awm_multi_add_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], const char *payload_hex, const float *const *pcm_in_d,
+                     float *const *out_d, int n_channels, const uint64_t *span_frames);
+int awm_multi_get_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], const float *const *pcm_d, int n_channels,
+                     const uint64_t *span_frames, size_t max_out, awm_pattern *out);
+
 /* ---- speed detection (reference wmspeed.cc:622-781) ------------------------------------
  * `get --detect-speed`: the reference looks for the replay speed (0.8 .. 1.25) of the watermark before decoding, by
  * correlating the sync pattern with a half-rate STFT of a 25 / 50 s clip over a grid of speeds, and decodes the stream a

@@ -25,6 +25,29 @@ def run(cmd, stdin=None, check=True):
     return r
 
 
+def same_report(ours, theirs, what=""):
+    """Two `cmp` / `get` reports agree line by line.  One thing may differ: the decode error column of a pattern line whose time,
+    payload, sync quality (as printed) and type agree.  That is a refinement TIE: the sync quality is flat to ~1e-7 over neighbouring
+    fine offsets (8 samples apart) around a block start, the two detectors' FFTs differ at float rounding level (1e-7 relative; two
+    CPU FFT backends under the unmodified reference differ the same way), so strict `>` (syncfinder.cc:441) may
+    keep different neighbours; the block is then read 8 samples apart and its path metric differs in the third digit.  One tie
+    shows in up to three lines (the block, its AB pair, the "all" pattern); more than that fails."""
+    skip = ("key", "expect_matches")
+    a = [l for l in ours if not l.startswith(skip)]
+    b = [l for l in theirs if not l.startswith(skip)]
+    assert len(a) == len(b), (what, a, b)
+    ties = 0
+    for x, y in zip(a, b):
+        if x == y:
+            continue
+        fx, fy = x.split(), y.split()
+        assert fx[0] == fy[0] == "pattern" and len(fx) == len(fy) == 6, (what, x, y)
+        assert fx[:4] == fy[:4] and fx[5] == fy[5] and abs(float(fx[4]) - float(fy[4])) < 0.01, (what, x, y)
+        ties += 1
+    assert ties <= 3, (what, ties, a, b)
+    return ties
+
+
 def wav_samples(path):
     with open(path, "rb") as f:
         data = f.read()
@@ -113,7 +136,7 @@ def test_against_reference_binary(work):
     for f in (marked, ref_marked):
         ours = run([AWM, "cmp", "--input-format", "wav-pipe", str(f), PAY]).stdout.decode().splitlines()
         theirs = run([_ref.BIN, "cmp", "--x-in-wav-pipe", str(f), PAY]).stdout.decode().splitlines()
-        assert [l for l in ours if not l.startswith("key")] == [l for l in theirs if not l.startswith("key")]
+        same_report(ours, theirs, str(f))
 
 
 def test_sample_rate_scenario(tmp_path):
@@ -208,8 +231,7 @@ def test_hard_decision_option(work):
     assert any(l.startswith("pattern") and PAY in l for l in ours)
     if os.path.exists(_ref.BIN):
         theirs = run([_ref.BIN, "cmp", "--hard", "--x-in-wav-pipe", str(marked), PAY]).stdout.decode().splitlines()
-        keep = lambda ls: [l for l in ls if not l.startswith(("key", "expect_matches"))]
-        assert keep(ours) == keep(theirs)
+        same_report(ours, theirs)
 
 
 def test_rf64_output_and_riff_size_limit(work, tmp_path):
@@ -232,8 +254,12 @@ def test_rf64_output_and_riff_size_limit(work, tmp_path):
     n = 5 << 30
     big.write_bytes(b"RF64" + b"\xff" * 4 + b"WAVEds64" + struct.pack("<IQQQI", 28, n + 72, n, n // 4, 0) + b"fmt "
                     + struct.pack("<IHHIIHH", 16, 1, 2, 44100, 44100 * 4, 4, 16) + b"data" + b"\xff" * 4 + b"\0" * 4096)
-    r = run([AWM, "add", "-q", str(big), str(tmp_path / "o.wav"), PAY], check=False)
+    # (through a pipe: the length a REGULAR file announces is clamped to what the file holds, like libsndfile does)
+    r = run([AWM, "add", "-q", "-", str(tmp_path / "o.wav"), PAY], stdin=big.read_bytes(), check=False)
     assert r.returncode == 1 and b"does not fit a RIFF header" in r.stderr
+    # the same header on a regular file of 4 KiB: 1024 frames are what can be read, and what gets written
+    run([AWM, "add", "-q", str(big), str(tmp_path / "o.wav"), PAY])
+    assert os.path.getsize(tmp_path / "o.wav") == 44 + 4096
 
 
 def test_malformed_wav_headers_are_rejected(tmp_path):
@@ -270,8 +296,13 @@ def test_hard_option_through_the_c_abi(work):
         for ours, opt in ((hard, ["--hard"]), (soft, [])):
             theirs = _ref_lines(["get"] + opt + ["--x-in-wav-pipe", str(marked)])
             assert len(theirs) == len(ours)
+            ties = 0
             for a, b in zip(ours, theirs):                                      # pattern time bits quality error type
-                assert a["bits"] == b[2] and "%.3f" % a["sync_quality"] == b[3] and "%.3f" % a["decode_error"] == b[4]
+                assert a["bits"] == b[2] and "%.3f" % a["sync_quality"] == b[3]
+                if "%.3f" % a["decode_error"] != b[4]:                          # a refinement tie (same_report)
+                    assert abs(a["decode_error"] - float(b[4])) < 0.01
+                    ties += 1
+            assert ties <= 3
     hard_ctx.set_params()                                                       # back to the process-wide set
     assert [p["decode_error"] for p in hard_ctx.get_watermark_file(None, str(marked))] == [p["decode_error"] for p in soft]
     # a parameter the kernels are not built for is refused at the entry point, not silently ignored
