@@ -295,12 +295,37 @@ struct Gpu
   awm_ctx *ctx = nullptr;
   Gpu()
   {
-    const char *dev = getenv ("AWM_DEVICE");          // which GPU of the node (default 0)
+    // AWM_DEVICE=n: which GPU of the node (default 0); AWM_DEVICES=a,b,...: `get` spreads long files over these GPUs (the file is
+    // read through the first one, awm_ctx_set_helpers)
+    const char *dev = getenv ("AWM_DEVICE"), *devs = getenv ("AWM_DEVICES");
+    std::vector<int> ids;
+    for (const char *p = devs; p && *p; )
+      {
+        char *end = nullptr;
+        const long v = strtol (p, &end, 10);
+        if (end == p)
+          die ("audiowmark: AWM_DEVICES must be a comma separated list of device numbers\n");
+        ids.push_back (int (v));
+        p = *end == ',' ? end + 1 : end;
+      }
+    if (ids.empty())
+      ids.push_back (dev ? atoi (dev) : 0);
     // on the default stream, chunks of `get` on two lanes: a file level run is bound by file I/O, and every additional HIP stream
     // costs ~190 MB of resident host memory
-    if (awm_ctx_create_on_stream (dev ? atoi (dev) : 0, nullptr, &ctx) != 0)
+    if (awm_ctx_create_on_stream (ids[0], nullptr, &ctx) != 0)
       die (string ("audiowmark: ") + awm_last_error() + "\n");
     awm_ctx_set_chunk_lanes (ctx, 2);
+    std::vector<awm_ctx *> helpers;
+    for (size_t i = 1; i < ids.size(); i++)
+      {
+        awm_ctx *h = nullptr;
+        if (awm_ctx_create (ids[i], &h) != 0)
+          die (string ("audiowmark: ") + awm_last_error() + "\n");
+        awm_ctx_set_chunk_lanes (h, 2);
+        helpers.push_back (h);
+      }
+    if (!helpers.empty())
+      awm_ctx_set_helpers (ctx, helpers.data(), int (helpers.size()));
   }
   // no destructor: the process ends right after the command (finish() below), which returns everything at once; tearing down the
   // context and the HIP runtime piece by piece costs 70-90 ms -- a third of an `add` of one hour of audio

@@ -242,6 +242,24 @@ run_ranks (awm_ctx *const *ctxs, int n_ctx, F fn)
 extern "C" {
 
 int
+awm_ctx_set_helpers (awm_ctx *ctx, awm_ctx *const *helpers, int n_helpers)
+{
+  if (!ctx || n_helpers < 0 || (n_helpers && !helpers))
+    {
+      set_error ("awm_ctx_set_helpers: bad argument");
+      return AWM_ERR_ARG;
+    }
+  ctx->helpers.assign (helpers, helpers + n_helpers);
+  if (std::any_of (ctx->helpers.begin(), ctx->helpers.end(), [ctx] (awm_ctx *h) { return !h || h == ctx; }))
+    {
+      ctx->helpers.clear();
+      set_error ("awm_ctx_set_helpers: a helper must be another context");
+      return AWM_ERR_ARG;
+    }
+  return 0;
+}
+
+int
 awm_sharded_plan (const uint64_t *span_frames, int world, size_t max_out, int *chunk, int *rank, uint64_t *first_sf, uint64_t *n_sf)
 {
   if (!span_frames || world < 1)

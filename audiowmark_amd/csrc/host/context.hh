@@ -156,7 +156,7 @@ struct WorkLane
             ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx, ws_limit_tab, ws_jobs, ws_group;
   DevBuffer ws_shard_edge, ws_shard_tail, ws_shard_q;      // multi-GPU protocol (wmshard.cc): edge frames, stitched tail buffer, score blocks
   // host staging (two refinement slots: see SyncFinder::SearchJob)
-  PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits, pin_small, pin_group, pin_shard;
+  PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits, pin_small, pin_group, pin_shard, pin_shard_up;
   hipEvent_t   ev_refine[2] = { nullptr, nullptr };
   hipEvent_t   ev_sync = nullptr;        // cross-lane ordering (input ready / lane done)
   SpeedScratch *speed_scratch = nullptr; // buffers of a speed search on this lane (wmspeed.cc), created on first use
@@ -181,6 +181,7 @@ struct awm_ctx : awm::WorkLane
   awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
   hipStream_t    copy_stream = nullptr;  // H2D / D2H staging of the file level paths (created on first use)
   hipStream_t    get_copy_stream();
+  std::vector<awm_ctx *> helpers;        // other GPUs the file level `get` may spread a long stream over (awm_ctx_set_helpers; not owned)
   std::unique_ptr<awm::ParamValues> own_params;   // settings of this context (awm_ctx_set_params); null: the process-wide ones
   int            chunk_lanes = awm::CHUNK_LANES;   // lanes the chunks of one stream may be spread over (awm_ctx_set_chunk_lanes)
 

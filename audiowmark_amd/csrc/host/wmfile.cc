@@ -668,6 +668,80 @@ add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const st
   return add_stream_watermark (ctx, key, in_stream.get(), out_stream.get(), bits, 0);
 }
 
+/* A long stream over the context and its helpers (other GPUs, awm_ctx_set_helpers): equal frame spans, the helpers' spans copied
+ * device to device, awm_multi_get_d.  `spread` = false: not applicable (no helpers, several keys, speed detection, or too short to
+ * be worth it) -- the caller decodes on the context alone. */
+static int
+get_watermark_multi (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set, bool& spread)
+{
+  spread = false;
+  const size_t n_ctx = ctx->helpers.size() + 1;
+  const size_t min_span = 4 * mark_block_frame_count() * Params::frame_size;          // at least four blocks per GPU
+  if (n_ctx < 2 || key_list.size() != 1 || params().detect_speed || params().detect_speed_patient || params().try_speed > 0
+      || params().test_no_sync || wav.n_frames < n_ctx * min_span)
+    return 0;
+  const int C = wav.n_channels;
+  std::vector<awm_ctx *> ctxs { ctx };
+  ctxs.insert (ctxs.end(), ctx->helpers.begin(), ctx->helpers.end());
+  std::vector<uint64_t> span (n_ctx);
+  std::vector<const float *> ptr (n_ctx);
+  std::vector<DevBuffer> bufs (n_ctx);
+  const size_t per = wav.n_frames / n_ctx / Params::frame_size * Params::frame_size;
+  size_t pos = 0;
+  int rc = 0;
+  AWM_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  for (size_t i = 0; i < n_ctx && !rc; i++)
+    {
+      span[i] = i + 1 < n_ctx ? per : wav.n_frames - pos;
+      if (i == 0)
+        ptr[i] = wav.data;
+      else
+        {
+          const size_t bytes = size_t (span[i]) * C * sizeof (float);
+          if (hipSetDevice (ctxs[i]->device) != hipSuccess || bufs[i].reserve (std::max<size_t> (1, bytes))
+              || hipMemcpyPeer (bufs[i].ptr, ctxs[i]->device, wav.data + pos * C, ctx->device, bytes) != hipSuccess)
+            {
+              set_error ("cannot place a span of the stream on device " + std::to_string (ctxs[i]->device));
+              rc = AWM_ERR_HIP;
+            }
+          ptr[i] = bufs[i].as<float>();
+        }
+      pos += span[i];
+    }
+  (void) hipSetDevice (ctx->device);
+  std::vector<awm_pattern> pats (rc ? 0 : 4096);
+  int n = 0;
+  if (!rc)
+    {
+      n = awm_multi_get_d (ctxs.data(), int (n_ctx), key_list[0].aes_key(), ptr.data(), C, span.data(), pats.size(), pats.data());
+      if (n > int (pats.size()))
+        {
+          pats.resize (n);
+          n = awm_multi_get_d (ctxs.data(), int (n_ctx), key_list[0].aes_key(), ptr.data(), C, span.data(), pats.size(), pats.data());
+        }
+      if (n < 0)
+        rc = n;
+    }
+  for (size_t i = 1; i < n_ctx; i++)
+    {
+      (void) hipSetDevice (ctxs[i]->device);
+      bufs[i].release();
+    }
+  (void) hipSetDevice (ctx->device);
+  if (rc)
+    return rc;
+  for (int i = 0; i < n; i++)
+    {
+      const awm_pattern& p = pats[i];
+      SyncFinder::Score score { size_t (p.sync_index), p.sync_quality, ConvBlockType (p.block_type) };
+      result_set.add_pattern (key_list[0], p.time, score, std::vector<int> (p.bits, p.bits + p.n_bits), p.decode_error,
+                              ResultSet::Type (p.type), p.speed);
+    }
+  result_set.sort (key_list);
+  spread = true;
+  return 0;
+}
+
 /* body of get_watermark (reference wmget.cc:971-1013): stream -> HBM (bounded host memory), loader resampling, chunk loop */
 int
 get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInputStream *in_stream, bool print_speed, ResultSet& result_set,
@@ -714,7 +788,14 @@ get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInput
       wav.n_channels = C;
       wav.sample_rate = Params::mark_sample_rate;
       speed_print_results = print_speed;                // decode (..., orig_bits, ...): the detect_speed report line of `cmp`
-      const int rc = get_watermark_device (ctx, key_list, wav, result_set);
+      int rc = AWM_ERR_GENERIC;
+      bool spread = false;
+      if (int r = get_watermark_multi (ctx, key_list, wav, result_set, spread))
+        rc = r;
+      else if (spread)
+        rc = 0;
+      else
+        rc = get_watermark_device (ctx, key_list, wav, result_set);
       if (rc)
         {
           error ("audiowmark: GPU detection failed: %s\n", awm_last_error());

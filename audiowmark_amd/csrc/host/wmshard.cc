@@ -166,6 +166,8 @@ run_exchange (const awm_comm *comm, bool device, const std::vector<Msg>& sends, 
   std::vector<int> st, rf;
   for (const Msg& m : sends) { sp.push_back (m.send); sb.push_back (m.bytes); st.push_back (m.peer); }
   for (const Msg& m : recvs) { rp.push_back (m.recv); rb.push_back (m.bytes); rf.push_back (m.peer); }
+  if (comm->world == 1 && sp.empty() && rp.empty())
+    return 0;                                   // (a single rank never has anything to exchange: spare the transport the call)
   auto fn = device ? comm->exchange_d : comm->exchange_h;
   if (fn (comm->user, int (sp.size()), sp.data(), sb.data(), st.data(), int (rp.size()), rp.data(), rb.data(), rf.data()))
     return comm_fail (what);
@@ -500,7 +502,8 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
         DeviceWav sub;
         sub.n_channels = C;
         sub.data = view + (pt->first_sf * FRAME - vf) * C;
-        sub.n_frames = last ? w.N - pt->first_sf * FRAME : (pt->n_sf + block + 1) * FRAME;
+        // whole frames: n_sf + block + 1 of them give n_sf scores (syncfinder.cc:632); a ragged tail of the chunk is never read
+        sub.n_frames = last ? (w.N / FRAME - pt->first_sf) * FRAME : (pt->n_sf + block + 1) * FRAME;
         if (pt->first_sf * FRAME < vf || pt->first_sf * FRAME + sub.n_frames > view_hi (w, pt->tail))
           {
             set_error ("awm_sharded_get_d: internal error (part outside its buffer)");
@@ -640,9 +643,11 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
   /* ---- phase 6: final sync positions of every chunk (SyncFinder::search_finish on the complete refined list, in candidate
    * order), soft bits of MY blocks */
   const int n_bits = int (mark_data_frame_count() / params().frames_per_bit);
-  std::vector<std::unique_ptr<PinnedBuffer>> soft_pins;
-  struct SoftCopy { ChunkWork *w; std::vector<size_t> blocks; std::vector<int> slot_of; PinnedBuffer *pin; };
+  // (device -> host staging of the soft bits: the lane's page-locked buffer, one region per launch; sized for every block of the
+  // lane's chunks up front so that it never moves while copies are in flight)
+  struct SoftCopy { ChunkWork *w; std::vector<size_t> blocks; std::vector<int> slot_of; const float *host; };
   std::vector<SoftCopy> soft_copies;
+  std::map<WorkLane *, size_t> pin_used;
   for (ChunkWork& w : work)
     {
       std::sort (w.refined_all.begin(), w.refined_all.end(), [] (const ScoreRec& a, const ScoreRec& b) { return a.cand < b.cand; });
@@ -654,7 +659,7 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       std::vector<SyncFinder::SearchScore> refined;
       for (const ScoreRec& r : w.refined_all)
         refined.push_back ({ size_t (r.index), r.raw_quality, r.local_mean });
-      std::vector<uint32_t> cand_of;               // which candidate a final score came from: by (index, quality) after the sorts
+      // (which candidate a final score came from: by (index, quality) -- equal twins have the same owner or are interchangeable)
       SyncFinder::finish_scores (refined, w.scores);
       for (const auto& sc : w.scores)
         {
@@ -677,9 +682,19 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       for (size_t k = 0; k < w.scores.size(); k++)
         if (w.N >= w.scores[k].index + block * FRAME)
           w.wanted.push_back (k);
+      pin_used[w.lane] += w.wanted.size() * n_bits * sizeof (float);
+    }
+  for (auto& pu : pin_used)
+    {
+      if (int rc = pu.first->pin_shard.reserve (std::max<size_t> (1, pu.second))) return rc;
+      pu.second = 0;
+    }
+  for (ChunkWork& w : work)
+    {
       for (int tail = 0; tail < 2; tail++)
         {
           SoftCopy sc { &w, {}, {}, nullptr };
+          size_t& used = pin_used[w.lane];
           std::vector<size_t> index;
           for (size_t wi = 0; wi < w.wanted.size(); wi++)
             {
@@ -704,10 +719,10 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
           std::vector<char> ok;
           if (int rc = block_soft_bits_dev (ctx, w.lane, kt, virtual_chunk_wav (view, vf, w.N, C), index, sc.slot_of, ok))
             return rc;
-          soft_pins.push_back (std::make_unique<PinnedBuffer>());
-          sc.pin = soft_pins.back().get();
-          if (int rc = sc.pin->reserve (index.size() * n_bits * sizeof (float))) return rc;
-          AWM_HIP_CHECK (hipMemcpyAsync (sc.pin->ptr, w.lane->ws_soft.ptr, index.size() * n_bits * sizeof (float), hipMemcpyDeviceToHost, w.lane->stream));
+          float *host = reinterpret_cast<float *> (w.lane->pin_shard.as<char>() + used);
+          used += index.size() * n_bits * sizeof (float);
+          sc.host = host;
+          AWM_HIP_CHECK (hipMemcpyAsync (host, w.lane->ws_soft.ptr, index.size() * n_bits * sizeof (float), hipMemcpyDeviceToHost, w.lane->stream));
           soft_copies.push_back (std::move (sc));
         }
     }
@@ -716,10 +731,8 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
     w.soft_all.assign (w.wanted.size() * n_bits, 0.f);
   for (SoftCopy& sc : soft_copies)
     for (size_t j = 0; j < sc.blocks.size(); j++)
-      std::copy (sc.pin->as<float>() + size_t (sc.slot_of[j]) * n_bits, sc.pin->as<float>() + size_t (sc.slot_of[j] + 1) * n_bits,
+      std::copy (sc.host + size_t (sc.slot_of[j]) * n_bits, sc.host + size_t (sc.slot_of[j] + 1) * n_bits,
                  sc.w->soft_all.begin() + sc.blocks[j] * n_bits);
-  for (auto& p : soft_pins)
-    p->release();
 
   /* ---- phase 7: the blocks' soft bits go to the other participants (AB pairs and the "all" chain reach across span edges) */
   {
@@ -793,9 +806,9 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
     if (w.decode.pending.empty())
       return 0;
     if (int rc = w.lane->ws_soft.reserve (std::max<size_t> (1, w.soft_all.size() * sizeof (float)))) return rc;
-    if (int rc = w.lane->pin_shard.reserve (std::max<size_t> (1, w.soft_all.size() * sizeof (float)))) return rc;
-    std::copy (w.soft_all.begin(), w.soft_all.end(), w.lane->pin_shard.as<float>());
-    AWM_HIP_CHECK (hipMemcpyAsync (w.lane->ws_soft.ptr, w.lane->pin_shard.ptr, w.soft_all.size() * sizeof (float), hipMemcpyHostToDevice, w.lane->stream));
+    if (int rc = w.lane->pin_shard_up.reserve (std::max<size_t> (1, w.soft_all.size() * sizeof (float)))) return rc;
+    std::copy (w.soft_all.begin(), w.soft_all.end(), w.lane->pin_shard_up.as<float>());
+    AWM_HIP_CHECK (hipMemcpyAsync (w.lane->ws_soft.ptr, w.lane->pin_shard_up.ptr, w.soft_all.size() * sizeof (float), hipMemcpyHostToDevice, w.lane->stream));
     return decode_launch (ctx, w.lane, kt, w.decode);
   };
   auto decode_collect = [&] (ChunkWork& w) -> int {

@@ -1,20 +1,23 @@
-"""Long streams sharded over the GPUs of one node -- one process per GPU, torch.distributed (RCCL over xGMI).
+"""Long streams sharded over the GPUs of one node -- one process per GPU, torch.distributed (RCCL over xGMI) as transport.
 
-The stream is the concatenation of the ranks' local spans (rank order).  Nothing here touches sample data on the
-host; the only traffic between ranks is what the algorithm itself couples:
+The stream is the concatenation of the ranks' local spans (rank order).  The protocol itself -- what is computed where and what
+travels -- lives behind the C ABI (include/awm_hip.h: awm_sharded_add_d / awm_sharded_get_d, host/wmshard.cc):
 
-  add   every span needs the one 1024-sample frame before and after it (3-frame overlap-add, reference
-        wmadd.cc:228-238) and the limiter needs max|x| of the seconds straddling span edges (limiter.cc:99-124)
-        -> one all_gather of the edge frames (16 KB per rank) + one all_reduce(MAX) of the per-second maxima.
-  get   the reference's own chunks (wavchunkloader.cc:54-163) are the shard unit; a chunk is decoded by the rank
-        that holds its midpoint, the part of it that lives on a neighbour is fetched point-to-point (the "overlap
-        stitch"), found patterns are gathered on rank 0 and merged with ResultSet semantics (wmget.cc:288-316).
+  add   every span needs the one 1024-sample frame before and after it (3-frame overlap-add, reference wmadd.cc:228-238) and the
+        limiter needs max|x| of the seconds straddling span edges (limiter.cc:99-124)
+        -> one exchange of edge frames (8 KB per neighbour) + one max-reduction of the per-second maxima.
+  get   the reference's chunks (wavchunkloader.cc:54-163) stay the semantic unit, the WORK of a chunk is split by position: a rank
+        scores, refines and reads the blocks of the candidate starts inside its span, for which it fetches one block + 2 frames of
+        its successor's samples (the "overlap stitch", 18 MB for stereo); the ranks sharing a chunk exchange its raw scores (the
+        "score gather", 32 B per frame of audio), the refined scores and the blocks' soft bits; rank 0 merges the patterns.
 
-`Partition` and the exchange helpers are backend agnostic (they are exercised with gloo / CPU tensors in
-tests/test_sharded_gloo.py); the compute calls need a GPU.
+This module supplies the transport (`TorchComm`: the three callbacks of awm_comm on top of torch.distributed point-to-point
+and all_reduce) and the convenience class `ShardedStream`.  With the nccl (RCCL) backend device buffers travel GPU to GPU; with gloo
+(CPU tests, and the two-process test on a single-GPU box) they are staged through host memory.
 """
+import ctypes as C
 from dataclasses import dataclass
-from typing import List, Tuple
+from typing import List
 
 import numpy as np
 
@@ -23,83 +26,123 @@ from . import binding as awm
 FRAME = 1024
 LIMITER_BLOCK = 44100
 
+_EXCHANGE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int),
+                        C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_int))
+_REDUCE = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t)
 
-class _Comm:
-    """Thin view of torch.distributed that also works when the process group cannot move device tensors itself
-    (gloo with CUDA tensors: used to test the multi-rank numerics on a single-GPU box).  With the nccl (RCCL) backend
-    every call goes straight to torch.distributed and the data stays on the devices (xGMI)."""
 
-    def __init__(self, dist):
-        self.dist = dist
-        self.stage = dist.get_backend() != "nccl"
+class AwmComm(C.Structure):
+    """awm_comm (include/awm_hip.h)"""
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("exchange_d", _EXCHANGE), ("exchange_h", _EXCHANGE),
+                ("all_reduce_max_u32_d", _REDUCE)]
 
-    def _h(self, t):
-        return t.cpu() if (self.stage and t.is_cuda) else t
 
-    def all_gather(self, outs, t):
-        if not (self.stage and t.is_cuda):
-            return self.dist.all_gather(outs, t)
-        host = [o.cpu() for o in outs]
-        self.dist.all_gather(host, t.cpu())
-        for o, h in zip(outs, host):
-            o.copy_(h)
+awm.lib.awm_sharded_add_d.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(AwmComm)]
+awm.lib.awm_sharded_get_d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(AwmComm), C.c_size_t, C.c_void_p]
+awm.lib.awm_sharded_plan.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+awm.lib.awm_multi_add_d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+awm.lib.awm_multi_get_d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
 
-    def all_reduce_max(self, t):
-        if not (self.stage and t.is_cuda):
-            return self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        h = t.cpu()
-        self.dist.all_reduce(h, op=self.dist.ReduceOp.MAX)
-        t.copy_(h)
 
-    def exchange_start(self, sends, recvs):
-        """Post the copies and return a function that completes them.  With RCCL the transfers run on the collective
-        stream while the caller keeps computing; the staged (gloo) variant is synchronous."""
-        if self.stage:
-            self.exchange(sends, recvs)
-            return lambda: None
-        dist = self.dist
-        ops = [dist.P2POp(dist.isend, t.contiguous(), dst) for t, dst in sends]
-        ops += [dist.P2POp(dist.irecv, t, src) for t, src in recvs]
-        reqs = dist.batch_isend_irecv(ops) if ops else []
+def plan(lengths):
+    """awm_sharded_plan: [(chunk, rank, first_start_frame, n_start_frames)] -- which candidate start frames of which reference
+    chunk every rank works on (pure host)."""
+    spans = np.asarray(lengths, np.uint64)
+    n = awm.lib.awm_sharded_plan(spans.ctypes.data, len(spans), 0, None, None, None, None)
+    chunk, rank = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    first, count = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    awm.lib.awm_sharded_plan(spans.ctypes.data, len(spans), n, chunk.ctypes.data, rank.ctypes.data, first.ctypes.data, count.ctypes.data)
+    return [(int(c), int(r), int(f), int(k)) for c, r, f, k in zip(chunk, rank, first, count)]
 
-        def finish():
-            for r in reqs:
-                r.wait()
-        return finish
 
-    def exchange(self, sends, recvs):
-        """sends: [(tensor, dst)], recvs: [(tensor, src)] -- all posted together, completed before returning."""
-        dist = self.dist
-        host_recv = []
-        ops = []
-        for t, dst in sends:
-            ops.append(dist.P2POp(dist.isend, self._h(t).contiguous(), dst))
-        for t, src in recvs:
-            h = torch_empty_like_host(t) if (self.stage and t.is_cuda) else t
-            host_recv.append((t, h))
-            ops.append(dist.P2POp(dist.irecv, h, src))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-        for t, h in host_recv:
-            if h is not t:
+class TorchComm:
+    """The transport of the sharded entry points on top of a torch.distributed process group.
+
+    exchange_d / exchange_h: one batch_isend_irecv per round.  nccl: device buffers as they are (xGMI), host buffers staged
+    through small device tensors; gloo: host buffers as they are, device buffers staged through host memory.  Messages between
+    the same pair of ranks are posted in the same order on both sides (the protocol enumerates them by chunk)."""
+
+    def __init__(self, dist, device=None, memory="cuda"):
+        # memory="host": what the protocol calls device memory is host memory (CPU tests of the wiring, no GPU involved)
+        import torch
+        self.dist, self.torch = dist, torch
+        self.host_only = memory == "host"
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.nccl = dist.get_backend() == "nccl"
+        self.device = device
+        self.error = None
+        self._cb = (_EXCHANGE(lambda *a: self._exchange(True, *a)), _EXCHANGE(lambda *a: self._exchange(False, *a)),
+                    _REDUCE(self._reduce))                       # (kept alive with the object)
+        self.c = AwmComm(None, self.rank, self.world, *self._cb)
+
+    def _view(self, ptr, nbytes, on_device):
+        if on_device and not self.host_only:
+            return awm._as_tensor(ptr, nbytes)
+        return self.torch.frombuffer((C.c_ubyte * nbytes).from_address(ptr), dtype=self.torch.uint8)
+
+    def _exchange(self, on_device, user, n_send, send, send_bytes, send_to, n_recv, recv, recv_bytes, recv_from):
+        try:
+            torch, dist = self.torch, self.dist
+            ops, copy_back = [], []
+            on_device = on_device and not self.host_only
+            direct = on_device == self.nccl                      # the group moves this kind of memory itself
+            for i in range(n_send):
+                if not send_bytes[i]:
+                    continue
+                t = self._view(send[i], send_bytes[i], on_device)
+                if not direct:
+                    t = t.to(self.device) if self.nccl else t.cpu()
+                ops.append(dist.P2POp(dist.isend, t.contiguous(), send_to[i]))
+            for i in range(n_recv):
+                if not recv_bytes[i]:
+                    continue
+                t = self._view(recv[i], recv_bytes[i], on_device)
+                if not direct:
+                    stage = torch.empty(recv_bytes[i], dtype=torch.uint8, device=self.device if self.nccl else "cpu")
+                    copy_back.append((t, stage))
+                    t = stage
+                ops.append(dist.P2POp(dist.irecv, t, recv_from[i]))
+            if ops:
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+            for t, stage in copy_back:
+                t.copy_(stage)
+            if (self.nccl or on_device) and not self.host_only:
+                torch.cuda.synchronize(self.device)              # the callback's writes are complete when it returns
+            return 0
+        except Exception as e:                                   # (an exception must not travel through the C frames)
+            self.error = e
+            return 1
+
+    def _reduce(self, user, data, n):
+        try:
+            torch, dist = self.torch, self.dist
+            # non-negative floats order like their bit patterns: max of the words
+            t = self._view(data, n * 4, True).view(torch.int32)
+            if self.nccl or self.host_only:
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            else:
+                h = t.cpu()
+                dist.all_reduce(h, op=dist.ReduceOp.MAX)
                 t.copy_(h)
-
-
-def torch_empty_like_host(t):
-    import torch
-    return torch.empty(t.shape, dtype=t.dtype)
+            if not self.host_only:
+                torch.cuda.synchronize(self.device)
+            return 0
+        except Exception as e:
+            self.error = e
+            return 1
 
 
 @dataclass
 class Partition:
-    """Contiguous spans of a stream, one per rank; every span but the last must be a whole number of frames."""
+    """Contiguous spans of a stream, one per rank; every span but the last non-empty one must be a whole number of frames."""
     lengths: List[int]
 
     def __post_init__(self):
-        for n in self.lengths[:-1]:
-            if n % FRAME:
-                raise ValueError("every span except the last one must be a multiple of 1024 samples")
+        last = max((i for i, n in enumerate(self.lengths) if n), default=-1)
+        for i, n in enumerate(self.lengths):
+            if n % FRAME and i != last:
+                raise ValueError("every span except the last non-empty one must be a multiple of 1024 samples")
         self.starts = [0]
         for n in self.lengths:
             self.starts.append(self.starts[-1] + n)
@@ -117,159 +160,12 @@ class Partition:
                 return r
         return len(self.lengths) - 1
 
-    # ---- get: reference chunks ----------------------------------------------------------------
-    def chunk_plan(self):
-        """[(first_frame, n_frames, time_offset, owner_rank)] for the whole stream (computed once: it is consulted several
-        times per `get`, inside the timed region)."""
-        plan = getattr(self, "_plan", None)
-        if plan is None:
-            plan = []
-            for first, count, off in awm.plan_chunks(self.total):
-                plan.append((first, count, off, self.owner_of(first + count // 2)))
-            self._plan = plan
-        return plan
-
-    def chunk_range(self, rank):
-        """(lo, hi, chunks) -- the global sample range rank must hold to decode its chunks; chunks are consecutive."""
-        mine = [(i, c) for i, c in enumerate(self.chunk_plan()) if c[3] == rank]
-        if not mine:
-            return 0, 0, []
-        lo = min(c[0] for _, c in mine)
-        hi = max(c[0] + c[1] for _, c in mine)
-        return lo, hi, mine
-
-    def transfers(self):
-        """All point-to-point copies needed before `get`: (src_rank, dst_rank, global_lo, global_hi)."""
-        cached = getattr(self, "_transfers", None)
-        if cached is not None:
-            return cached
-        out = []
-        for dst in range(len(self.lengths)):
-            lo, hi, _ = self.chunk_range(dst)
-            for src in range(len(self.lengths)):
-                if src == dst:
-                    continue
-                s, e = self.span(src)
-                a, b = max(lo, s), min(hi, e)
-                if a < b:
-                    out.append((src, dst, a, b))
-        self._transfers = out
+    def work(self):
+        """candidate start frames per rank over all chunks (awm_sharded_plan): what the time of `get` is proportional to"""
+        out = [0] * len(self.lengths)
+        for _, r, _, k in plan(self.lengths):
+            out[r] += k
         return out
-
-
-def exchange_edge_frames(dist, local, n_channels, lengths=None):
-    """all_gather of each rank's first and last frame -> (halo_before, halo_after) for this rank (None at the ends).
-    A last frame shorter than 1024 samples is zero padded (it can only be the end of the stream).  Ranks with an EMPTY span
-    are skipped: the halo is the adjacent frame of the stream, i.e. the edge frame of the nearest rank that holds samples.
-    `lengths` = the span lengths of all ranks (Partition.lengths) if the caller knows them, else they are gathered."""
-    import torch
-    rank, world = dist.get_rank(), dist.get_world_size()
-    n = local.shape[0]
-    comm = _Comm(dist)
-    if lengths is None:
-        lens = [torch.zeros(1, dtype=torch.int64, device=local.device) for _ in range(world)]
-        comm.all_gather(lens, torch.tensor([n], dtype=torch.int64, device=local.device))
-        lengths = [int(t.item()) for t in lens]
-    edge = torch.zeros((2, FRAME, n_channels), dtype=local.dtype, device=local.device)
-    view = local.reshape(n, n_channels)
-    edge[0, :min(FRAME, n)] = view[:FRAME]
-    last_start = max(0, ((n - 1) // FRAME) * FRAME) if n else 0
-    tail = view[last_start:]
-    edge[1, :tail.shape[0]] = tail
-    gathered = [torch.empty_like(edge) for _ in range(world)]
-    comm.all_gather(gathered, edge)
-    prev = next((r for r in range(rank - 1, -1, -1) if lengths[r]), None)
-    nxt = next((r for r in range(rank + 1, world) if lengths[r]), None)
-    before = gathered[prev][1].contiguous() if prev is not None else None
-    after = gathered[nxt][0].contiguous() if nxt is not None else None
-    return before, after
-
-
-def fetch_range(dist, part: Partition, local, n_channels):
-    """Assemble the global sample range this rank needs for its chunks: own samples are copied, the rest arrives
-    point-to-point from the neighbours.  Returns (buffer, lo)."""
-    import torch
-    rank = dist.get_rank()
-    lo, hi, _ = part.chunk_range(rank)
-    my_s, my_e = part.span(rank)
-    view = local.reshape(local.shape[0], n_channels)
-    buf = torch.empty((max(0, hi - lo), n_channels), dtype=local.dtype, device=local.device)
-    a, b = max(lo, my_s), min(hi, my_e)
-    if a < b:
-        buf[a - lo:b - lo] = view[a - my_s:b - my_s]
-    sends, recvs = [], []
-    for src, dst, g_lo, g_hi in part.transfers():
-        if src == rank:
-            sends.append((view[g_lo - my_s:g_hi - my_s].contiguous(), dst))
-        elif dst == rank:
-            recvs.append((torch.empty((g_hi - g_lo, n_channels), dtype=local.dtype, device=local.device), src, g_lo))
-    _Comm(dist).exchange(sends, [(t, src) for t, src, _ in recvs])
-    for t, _, g_lo in recvs:
-        buf[g_lo - lo:g_lo - lo + t.shape[0]] = t
-    return buf, lo
-
-
-GATHER_CAPACITY = 512          # records per rank in the one-shot gather (an hour of audio yields ~110 patterns)
-
-
-def gather_patterns(dist, my_chunk_patterns):
-    """{chunk index: structured array (PATTERN_DTYPE)} of this rank -> the union over all ranks, on every rank.
-    ONE collective on plain byte tensors (the "score gather" of the path): every rank contributes a fixed-size block = its record
-    count followed by GATHER_CAPACITY records (chunk index int32 + pattern); only if some rank found more than that, a second
-    all_gather sized for the longest list follows."""
-    import torch
-    comm = _Comm(dist)
-    world = dist.get_world_size()
-    rec = np.dtype([("chunk", np.int32), ("pattern", awm.PATTERN_DTYPE)])
-    mine = np.zeros(sum(len(p) for p in my_chunk_patterns.values()), rec)
-    pos = 0
-    for ci in sorted(my_chunk_patterns):
-        pats = my_chunk_patterns[ci]
-        mine["chunk"][pos:pos + len(pats)] = ci
-        mine["pattern"][pos:pos + len(pats)] = pats
-        pos += len(pats)
-    dev = getattr(dist, "_awm_device", None) or "cpu"
-
-    def gather(capacity):
-        block = np.zeros(16 + capacity * rec.itemsize, np.uint8)
-        block[:8] = np.frombuffer(np.int64(len(mine)).tobytes(), np.uint8)
-        k = min(len(mine), capacity)
-        block[16:16 + k * rec.itemsize] = mine[:k].view(np.uint8).reshape(-1)
-        t = torch.from_numpy(block).to(dev)
-        gathered = torch.empty((world, t.numel()), dtype=t.dtype, device=t.device)     # one buffer, one copy back
-        comm.all_gather(list(gathered.unbind(0)), t)
-        host = gathered.cpu().numpy()
-        blocks = [host[r] for r in range(world)]
-        counts = [int(np.frombuffer(b[:8].tobytes(), np.int64)[0]) for b in blocks]
-        return blocks, counts
-
-    blocks, counts = gather(GATHER_CAPACITY)
-    if max(counts) > GATHER_CAPACITY:
-        blocks, counts = gather(max(counts))
-    out = {}
-    for b, n in zip(blocks, counts):
-        recs = np.frombuffer(b[16:16 + n * rec.itemsize].tobytes(), rec)
-        for ci in np.unique(recs["chunk"]):
-            out[int(ci)] = recs["pattern"][recs["chunk"] == ci].copy()
-    return out
-
-
-def gather_and_merge(dist, part: Partition, key, my_chunk_patterns):
-    """my_chunk_patterns: {global chunk index: patterns with chunk relative times} -> merged list on rank 0 (None elsewhere).
-    The values are structured arrays (binding.PATTERN_DTYPE) or lists of pattern dicts (converted)."""
-    plan = part.chunk_plan()
-    payload = {}
-    for ci, pats in my_chunk_patterns.items():
-        if not isinstance(pats, np.ndarray):
-            pats = awm.patterns_from_dicts(pats)
-        pats = pats.copy()
-        pats["time"] += plan[ci][2]                                            # ResultSet::apply_time_offset
-        payload[ci] = pats
-    everything = gather_patterns(dist, payload)
-    if dist.get_rank() != 0:
-        return None
-    per_chunk = [everything.get(ci, np.zeros(0, awm.PATTERN_DTYPE)) for ci in range(len(plan))]
-    return awm.merge_patterns_raw(key, per_chunk)
 
 
 class ShardedStream:
@@ -279,79 +175,69 @@ class ShardedStream:
         import torch
         self.ctx, self.dist, self.n_channels = ctx, dist, n_channels
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
-        lens = [torch.zeros(1, dtype=torch.int64, device=self._device()) for _ in range(self.world)]
-        _Comm(dist).all_gather(lens, torch.tensor([n_frames_local], dtype=torch.int64, device=self._device()))
+        dev = torch.device("cuda", ctx.device)
+        self.comm = TorchComm(dist, dev)
+        mine = torch.tensor([n_frames_local], dtype=torch.int64, device=dev if self.comm.nccl else "cpu")
+        lens = [torch.zeros_like(mine) for _ in range(self.world)]
+        dist.all_gather(lens, mine)
         self.part = Partition([int(t.item()) for t in lens])
-        self._fm_cache = {}
-        dist._awm_device = self._device() if dist.get_backend() == "nccl" else "cpu"     # where the small collectives live
+        self._spans = np.asarray(self.part.lengths, np.uint64)
 
-    def _device(self):
-        import torch
-        return torch.device("cuda", self.ctx.device)
+    def _fail(self, what):
+        if self.comm.error is not None:
+            err, self.comm.error = self.comm.error, None
+            raise awm.AwmError(f"{what}: transport failed: {err!r}") from err
 
-    def _frame_mod(self, key, payload_hex):
-        k = (awm.key_bytes(key), payload_hex)
-        if k not in self._fm_cache:
-            self._fm_cache[k] = awm.tab_frame_mod(key, payload_hex)
-        return self._fm_cache[k]
-
-    def add_watermark(self, key, payload_hex, local, out, water_delta=0.01, use_limiter=True, sample_rate=44100):
-        import torch
+    def add_watermark(self, key, payload_hex, local, out, sample_rate=44100):
         if sample_rate != 44100:
             # spans are cut in watermark frames and limiter blocks of 44 100 samples; other rates go through the resampled
             # path of the single-GPU add (awm_add_watermark_d), which is not sharded
             raise ValueError("ShardedStream.add_watermark: only 44.1 kHz streams are sharded")
-        dist = self.dist
-        start, _ = self.part.span(self.rank)
-        before, after = exchange_edge_frames(dist, local, self.n_channels, self.part.lengths)
-        block_max = None
-        if use_limiter:
-            n_blocks = self.part.total // LIMITER_BLOCK + 2
-            block_max = torch.empty(n_blocks, dtype=torch.float32, device=local.device)
-            self.ctx.add_init_block_max(block_max)
-        self.ctx.add_mix(local, out, self._frame_mod(key, payload_hex), water_delta, start // FRAME, before, after, block_max)
-        if use_limiter:
-            _Comm(dist).all_reduce_max(block_max)                  # seconds that straddle span edges
-            self.ctx.add_limit(out, start, block_max)
+        rc = awm.lib.awm_sharded_add_d(self.ctx._h, awm.key_bytes(key), payload_hex.encode(), awm._dev_ptr(local), awm._dev_ptr(out),
+                                       self.n_channels, self._spans.ctypes.data, C.byref(self.comm.c))
+        self._fail("awm_sharded_add_d")
+        awm._check(rc, "awm_sharded_add_d")
         return out
 
-    def get_watermark(self, key, local):
-        """Chunks that lie completely inside this rank's span are decoded while the parts of the straddling chunks that
-        live on the neighbours are still in flight (up to half a chunk = 300 MB per boundary for 30 minute chunks: several
-        milliseconds over one xGMI link, about as long as decoding a chunk)."""
-        import torch
-        part, rank, C = self.part, self.rank, self.n_channels
-        lo, hi, mine = part.chunk_range(rank)
-        my_s, my_e = part.span(rank)
-        view = local.reshape(local.shape[0], C)
-        inside = [(ci, c) for ci, c in mine if c[0] >= my_s and c[0] + c[1] <= my_e]
-        cross = [(ci, c) for ci, c in mine if not (c[0] >= my_s and c[0] + c[1] <= my_e)]
-        # post the transfers (every rank serves its neighbours even if it needs nothing itself)
-        sends, recvs = [], []
-        for src, dst, g_lo, g_hi in part.transfers():
-            if src == rank:
-                sends.append((view[g_lo - my_s:g_hi - my_s], dst))
-            elif dst == rank:
-                recvs.append((torch.empty((g_hi - g_lo, C), dtype=local.dtype, device=local.device), src, g_lo))
-        finish = _Comm(self.dist).exchange_start(sends, [(t, src) for t, src, _ in recvs])
-        found = {}
-        if inside:
-            rel = [(c[0] - my_s, c[1]) for _, c in inside]
-            pats, which = self.ctx.decode_chunks_raw(key, view, rel, first_is_stream_start=(inside[0][1][0] == 0))
-            found.update({ci: pats[which == i] for i, (ci, _) in enumerate(inside)})
-        finish()
-        if cross:
-            c_lo = min(c[0] for _, c in cross)
-            c_hi = max(c[0] + c[1] for _, c in cross)
-            buf = torch.empty((c_hi - c_lo, C), dtype=local.dtype, device=local.device)
-            a, b = max(c_lo, my_s), min(c_hi, my_e)
-            if a < b:
-                buf[a - c_lo:b - c_lo] = view[a - my_s:b - my_s]
-            for t, _, g_lo in recvs:
-                a, b = max(c_lo, g_lo), min(c_hi, g_lo + t.shape[0])
-                if a < b:
-                    buf[a - c_lo:b - c_lo] = t[a - g_lo:b - g_lo]
-            rel = [(c[0] - c_lo, c[1]) for _, c in cross]
-            pats, which = self.ctx.decode_chunks_raw(key, buf, rel, first_is_stream_start=(cross[0][1][0] == 0))
-            found.update({ci: pats[which == i] for i, (ci, _) in enumerate(cross)})
-        return gather_and_merge(self.dist, self.part, key, found)
+    def get_watermark(self, key, local, max_out=8192):
+        """merged pattern list on rank 0, None elsewhere (8192 patterns: > 60 h of audio)"""
+        buf = self.ctx._pattern_buffer(max_out)
+        rc = awm.lib.awm_sharded_get_d(self.ctx._h, awm.key_bytes(key), awm._dev_ptr(local), self.n_channels, self._spans.ctypes.data,
+                                       C.byref(self.comm.c), max_out, C.cast(buf, C.c_void_p))
+        self._fail("awm_sharded_get_d")
+        cnt = awm._check(rc, "awm_sharded_get_d")
+        if self.rank != 0:
+            return None
+        if cnt > max_out:
+            raise awm.AwmError("awm_sharded_get_d: more patterns than the buffer holds")
+        return awm.patterns_to_dicts(buf, cnt)
+
+
+def multi_add(ctxs, key, payload_hex, spans_in, spans_out):
+    """awm_multi_add_d: one stream over the contexts of ONE process (span i on ctxs[i]'s device), hipMemcpyPeer as transport"""
+    n = len(ctxs)
+    shapes = [awm._pcm_shape(t) for t in spans_in]
+    ch = shapes[0][1]
+    h = (C.c_void_p * n)(*[c._h for c in ctxs])
+    pin = (C.c_void_p * n)(*[awm._dev_ptr(t) for t in spans_in])
+    pout = (C.c_void_p * n)(*[awm._dev_ptr(t) for t in spans_out])
+    lens = np.asarray([s[0] for s in shapes], np.uint64)
+    awm._check(awm.lib.awm_multi_add_d(h, n, awm.key_bytes(key), payload_hex.encode(), pin, pout, ch, lens.ctypes.data), "awm_multi_add_d")
+    return spans_out
+
+
+def multi_get(ctxs, key, spans, max_out=4096):
+    """awm_multi_get_d: the merged pattern list of one stream whose spans live on the contexts of one process"""
+    n = len(ctxs)
+    shapes = [awm._pcm_shape(t) for t in spans]
+    ch = shapes[0][1]
+    h = (C.c_void_p * n)(*[c._h for c in ctxs])
+    ptr = (C.c_void_p * n)(*[awm._dev_ptr(t) for t in spans])
+    lens = np.asarray([s[0] for s in shapes], np.uint64)
+    while True:
+        buf = ctxs[0]._pattern_buffer(max_out)
+        cnt = awm._check(awm.lib.awm_multi_get_d(h, n, awm.key_bytes(key), ptr, ch, lens.ctypes.data, max_out, C.cast(buf, C.c_void_p)),
+                         "awm_multi_get_d")
+        if cnt <= max_out:
+            return awm.patterns_to_dicts(buf, cnt)
+        max_out = cnt

@@ -312,6 +312,11 @@ int awm_multi_add_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], con
 int awm_multi_get_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], const float *const *pcm_d, int n_channels,
                      const uint64_t *span_frames, size_t max_out, awm_pattern *out);
 
+/* Helpers of a context: contexts on other GPUs that the file level `get` (awm_get_watermark_file / _keys_file, the command line) may
+ * spread a long single-key stream over (awm_multi_get_d after the stream has been read through `ctx`; its spans travel device to
+ * device).  The helpers stay the caller's; n_helpers = 0 takes them away.  The command line fills them from AWM_DEVICES=0,1,... */
+int awm_ctx_set_helpers (awm_ctx *ctx, awm_ctx *const *helpers, int n_helpers);
+
 /* ---- speed detection (reference wmspeed.cc:622-781) ------------------------------------
  * `get --detect-speed`: the reference looks for the replay speed (0.8 .. 1.25) of the watermark before decoding, by
  * correlating the sync pattern with a half-rate STFT of a 25 / 50 s clip over a grid of speeds, and decodes the stream a

@@ -154,6 +154,32 @@ def test_config1_60min_stereo_add_get_equal_reference(gpu):
     print("configs[1]:", rep)
 
 
+def test_130min_stereo_five_chunks_equal_reference(gpu):
+    """Longer than BASELINE configs[1]: 2 h 10 min stereo = FIVE reference chunks (wavchunkloader.cc:75-84), so the four chunk
+    lanes are reused and overlap merging (wmget.cc:288-316) happens four times -- the complete pattern list against the reference.
+    (Why an 8 h run reports the payload in all of its patterns while a 60 min run has four lines without it: the last chunk of 60
+    min is 4.5 minutes = 5 blocks, fewer than n_best = 8, so sync_select_threshold_and_n_best keeps three or four noise peaks
+    whose decodes are printed as well (syncfinder.cc:364-383); the last chunk of 8 h is 8.1 minutes = 9 blocks.  Here the last
+    chunk is 19 minutes: no such lines either -- asserted below.)"""
+    n = 130 * 60 * 44100
+    x = quantise16(gpu.awm.binding.gen_noise(None, 2 * n))
+    t0 = time.perf_counter()
+    ref_w = _ref.add(None, x, 2, PAY1)
+    t1 = time.perf_counter()
+    del x
+    ref_pats = _ref.get(None, ref_w, 2)
+    t2 = time.perf_counter()
+    assert len(gpu.awm.plan_chunks(n)) == 5
+    got = gpu.ctx.get_watermark(None, gpu.dev(ref_w))
+    rep = compare_patterns(got, ref_pats, "130 min get")
+    matches = sum(p["bits"] == PAY1 for p in got)
+    assert matches == len(got) and matches >= 220            # 150 blocks + AB pairs + 5 "all" patterns, no n_best filler
+    rep.update({"payload_matches": matches, "chunks": 5, "reference_add_s": round(t1 - t0, 2), "reference_get_s": round(t2 - t1, 2),
+                "reference_threads": os.cpu_count()})
+    REPORT["stereo_130min_five_chunks"] = rep
+    print("130 min:", rep)
+
+
 def test_config2_60min_48k_detect_speed_equal_reference(gpu):
     """BASELINE.json configs[2]: 60 min stereo 48 kHz, watermarked at 48 kHz, replayed 2 % fast, `get --detect-speed`.
     `add` at 48 kHz is compared with the reference's WatermarkResampler path (wmadd.cc:353-430); the replay (the attacker's
