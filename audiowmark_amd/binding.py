@@ -122,6 +122,8 @@ lib.awm_resample_frames.restype = C.c_size_t
 lib.awm_resample_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]
 lib.awm_add_watermark_batch_d.argtypes = [_vp, _vp, C.c_char_p, C.c_size_t, _vp, _vp, _vp, C.c_int]
 lib.awm_get_watermark_batch_d.argtypes = [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
+lib.awm_add_watermark_batch_keys_d.argtypes = [_vp, _vp, C.c_char_p, C.c_size_t, _vp, _vp, _vp, C.c_int]
+lib.awm_get_watermark_batch_keys_d.argtypes = [_vp, _vp, C.c_size_t, _vp, _vp, C.c_int, C.c_int, C.c_size_t, _vp, _vp]
 lib.awm_decode_chunk_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _vp]
 lib.awm_tab_up_down.argtypes = [_vp, C.c_int, C.c_int, _vp, _vp]
 lib.awm_tab_bit_pos.argtypes = [_vp, _vp]
@@ -484,6 +486,46 @@ class Context:
         _check(lib.awm_add_watermark_batch_d(self._h, key_bytes(key), payload_hex.encode(), len(clips), src, dst, frames, ch),
                "awm_add_watermark_batch_d")
         return outs
+
+    def add_watermark_batch_keys(self, keys, payload_hex, clips, outs=None):
+        """the same with ONE KEY PER CLIP (awm_add_watermark_batch_keys_d; BASELINE configs[4]: `--test-key k` for clip k)"""
+        import torch
+        if not clips:
+            return []
+        assert len(keys) == len(clips)
+        shapes = [_pcm_shape(c) for c in clips]
+        ch = shapes[0][1]
+        assert all(s[1] == ch for s in shapes)
+        if outs is None:
+            outs = [torch.empty_like(c) for c in clips]
+        src = (C.c_void_p * len(clips))(*[_dev_ptr(c) for c in clips])
+        dst = (C.c_void_p * len(clips))(*[_dev_ptr(o) for o in outs])
+        frames = (C.c_size_t * len(clips))(*[s[0] for s in shapes])
+        flat = b"".join(key_bytes(k) for k in keys)
+        _check(lib.awm_add_watermark_batch_keys_d(self._h, flat, payload_hex.encode(), len(clips), src, dst, frames, ch),
+               "awm_add_watermark_batch_keys_d")
+        return outs
+
+    def get_watermark_batch_keys(self, keys, clips, n_threads=0, max_out_per_clip=64):
+        """get_watermark of many independent resident clips, clip i with keys[i] alone (awm_get_watermark_batch_keys_d)"""
+        if not clips:
+            return []
+        assert len(keys) == len(clips)
+        shapes = [_pcm_shape(c) for c in clips]
+        ch = shapes[0][1]
+        assert all(s[1] == ch for s in shapes)
+        ptrs = (C.c_void_p * len(clips))(*[_dev_ptr(c) for c in clips])
+        frames = (C.c_size_t * len(clips))(*[s[0] for s in shapes])
+        n_out = (C.c_int * len(clips))()
+        flat = b"".join(key_bytes(k) for k in keys)
+        while True:
+            buf = self._pattern_buffer(len(clips) * max_out_per_clip)
+            _check(lib.awm_get_watermark_batch_keys_d(self._h, flat, len(clips), ptrs, frames, ch, n_threads, max_out_per_clip,
+                                                      C.cast(buf, C.c_void_p), n_out), "awm_get_watermark_batch_keys_d")
+            most = max(n_out)
+            if most <= max_out_per_clip:
+                return [patterns_to_dicts(buf, n_out[i], i * max_out_per_clip) for i in range(len(clips))]
+            max_out_per_clip = most
 
     # ---- file level: the reference's add_watermark / get_watermark (wmcommon.hh:226-228) ----
     def add_watermark_file(self, key, payload_hex, in_path, out_path, raw_in=None, raw_out=None):

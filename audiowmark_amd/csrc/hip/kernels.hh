@@ -103,6 +103,9 @@ struct SyncDbArgs
   const int           *row_perm = nullptr;
   const unsigned char *band_pos = nullptr;
   int                  rows_per_plane = 0;
+  // a batch of clips with one KEY PER CLIP: the tables of slice i (range_index / range_div as below) follow those of slice i - 1:
+  // row_perm + slice * rows_per_plane, band_pos + slice * rows_per_plane * 81
+  int                  tables_per_slice = 0;
   // Slices (the batched clip search: many padded clips side by side in one buffer).  With streams_per_slice > 0 stream s is
   // stream s % streams_per_slice of slice s / streams_per_slice: base = base0 + (s % sps) * base_stride + (s / sps) * slice_stride.
   // stream_range, if set, replaces first / last by the range of the stream's slice: slice = range_index[s / range_div] if
@@ -134,6 +137,11 @@ struct SyncTableDev
   // K5w only (approximate search): [12 chains = sync bit x (up, down)][rows][8] words = the chain's 30 bands of the row as bytes,
   // then the frame of the chain's NEXT row as u16 (0xffff: none): one 32-byte scalar load per sync frame
   const unsigned *chains = nullptr;
+  // a batch of clips with one key per clip: plane p uses the chains at chains + (p / planes_per_slice) * chains_slice_stride (words)
+  long long       chains_slice_stride = 0;
+  int             planes_per_slice = 1;
+  // ... and the frame of every row, [slice][6][rows] (K5w in CLIP mode looks rows up by frame; one key: packed[..][60] serves)
+  const int      *row_frames = nullptr;
 };
 /* host side of SyncTableDev::chains from a [6][rows][64] packed table */
 void pack_scan_chains (const int *packed, int rows_per_bit, unsigned *out /* [12 * rows_per_bit * 8] */);
@@ -212,6 +220,8 @@ struct SoftBitsArgs
   int            block_frames;  // 2226
   long long      n_blocks;
   float         *out;
+  // one key per clip: block b takes the mix table of slice block_slice[b] (entries at + slice * n_data_frames * 30)
+  const int     *block_slice = nullptr;
 };
 hipError_t launch_soft_bits (hipStream_t st, const SoftBitsArgs& a);
 
@@ -226,6 +236,8 @@ struct SoftJobDev
   int       len;           // 858 or 1716
   int       norm0, norm1;  // mode 2: blocks per half
   long long out_off;       // floats
+  int       order_off;     // inv_order + order_off: the bit order of this job's key (one key per clip: n_bits * slice)
+  int       pad;
 };
 struct SoftPrepArgs
 {

@@ -291,6 +291,45 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
   const int BS = a.limiter_block;
   const long long total_rows = 2LL * block_frames;
 
+  // where frame m comes from (halo before / the span / halo after) and how much of it exists
+  auto frame_source = [&] (long long m, int& avail) -> const float * {
+    const float *src;
+    if (m < 0)
+      {
+        src = a.halo_before;
+        avail = src ? 1024 : 0;
+      }
+    else if (m >= F)
+      {
+        src = a.halo_after;
+        avail = src ? 1024 : 0;
+      }
+    else
+      {
+        src = a.pcm_in + m * 1024 * C;
+        const long long left = a.n_frames - m * 1024;
+        avail = left < 1024 ? int (left) : 1024;
+      }
+    return src;
+  };
+  // Software pipelining (stereo kernel): the samples of frame m + 1 are requested before frame m is transformed, so that the
+  // ~1 us of HBM latency runs beside ~3.5 us of arithmetic of the SAME wave -- with three waves per SIMD there is not always
+  // another wave to switch to (after the band edit went to the native log2 / exp2 the kernel issued VALU only 70 % of the time).
+  // 32 more live registers; still three waves per SIMD.
+  float nxt[CV][16];
+  int nxt_avail = 0;
+  if (OPAQUE)
+    {
+      const float *src0 = frame_source (s - 1, nxt_avail);
+      if (nxt_avail > 0)
+        {
+          if constexpr (CV == 2)
+            fetch_stereo (src0, 0, nxt_avail, lane, nxt[0], nxt[1]);
+          else
+            fetch_channel (src0, 0, nxt_avail, C, ch0, lane, nxt[0]);
+        }
+    }
+
   for (long long m = s - 1; m <= e; m++)
     {
       if (OPAQUE)
@@ -300,32 +339,41 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
           lane = lane0;
           asm volatile ("" : "+v" (lane));
         }
-      const float *src;
       int avail;
-      if (m < 0)
-        {
-          src = a.halo_before;
-          avail = src ? 1024 : 0;
-        }
-      else if (m >= F)
-        {
-          src = a.halo_after;
-          avail = src ? 1024 : 0;
-        }
-      else
-        {
-          src = a.pcm_in + m * 1024 * C;
-          const long long left = a.n_frames - m * 1024;
-          avail = left < 1024 ? int (left) : 1024;
-        }
+      const float *src = frame_source (m, avail);
       float in[CV][16];
       float2 d[CV][8];
+      if (OPAQUE)
+        {
+          // take the prefetched frame, request the next one
+          avail = nxt_avail;
+#pragma unroll
+          for (int c = 0; c < CV; c++)
+#pragma unroll
+            for (int j = 0; j < 16; j++)
+              in[c][j] = nxt[c][j];
+          nxt_avail = 0;
+          if (m < e)
+            {
+              const float *src1 = frame_source (m + 1, nxt_avail);
+              if (nxt_avail > 0)
+                {
+                  if constexpr (CV == 2)
+                    fetch_stereo (src1, 0, nxt_avail, lane0, nxt[0], nxt[1]);
+                  else
+                    fetch_channel (src1, 0, nxt_avail, C, ch0, lane0, nxt[0]);
+                }
+            }
+        }
       if (avail > 0)
         {
-          if constexpr (CV == 2)
-            fetch_stereo (src, 0, avail, lane, in[0], in[1]);
-          else
-            fetch_channel (src, 0, avail, C, ch0, lane, in[0]);
+          if (!OPAQUE)
+            {
+              if constexpr (CV == 2)
+                fetch_stereo (src, 0, avail, lane, in[0], in[1]);
+              else
+                fetch_channel (src, 0, avail, C, ch0, lane, in[0]);
+            }
           const long long g = a.first_frame + m;                       // frame index in the whole stream
           const long long row = (frame_number0 + g) % total_rows;      // reference wmadd.cc:326-344
           const int8_t *mod_row = a.frame_mod + row * NB;
@@ -1269,8 +1317,10 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
     // gathered output (refinement): which row of its 60 the stream's band b goes to; identity otherwise
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
     const long long s = (long long) blockIdx.x * WAVES + w;
+    // (one key per clip: the tables of the stream's slice)
+    const long long tslice = (a.tables_per_slice && s < a.n_streams) ? (a.range_index ? a.range_index[s / a.range_div] : s / a.range_div) : 0;
     for (int b = l; b < NB; b += 64)
-      s_pos[w][b] = (a.band_pos && s < a.n_streams) ? a.band_pos[(s % a.rows_per_plane) * NB + b] : (unsigned char) b;
+      s_pos[w][b] = (a.band_pos && s < a.n_streams) ? a.band_pos[(tslice * a.rows_per_plane + s % a.rows_per_plane) * NB + b] : (unsigned char) b;
   }
   __syncthreads();
 
@@ -1279,7 +1329,9 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
   if (stream >= a.n_streams)
     return;
   // where this stream's rows go
-  const long long out_slot = wave_uniform (a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane + a.row_perm[stream % a.rows_per_plane] : stream);
+  const long long perm_slice = a.tables_per_slice ? (a.range_index ? a.range_index[stream / a.range_div] : stream / a.range_div) : 0;
+  const long long out_slot = wave_uniform (a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane
+                                                        + a.row_perm[perm_slice * a.rows_per_plane + stream % a.rows_per_plane] : stream);
   const long long base = wave_uniform (sync_stream_base (a, stream));
   const int count = __builtin_amdgcn_readfirstlane (a.stream_count ? a.stream_count[stream] : a.count0);
   if (count <= 0)
@@ -1789,6 +1841,9 @@ soft_bits_kernel (SoftBitsArgs a)
     return;
   const float *db = a.db + blk * a.block_stride;
   const int C = a.n_channels;
+  const long long mix0 = a.block_slice ? (long long) a.block_slice[blk] * a.n_data_frames * 30 : 0;
+  const int16_t *mix_frame = a.mix_frame + mix0;
+  const uint8_t *mix_up = a.mix_up + mix0, *mix_down = a.mix_down + mix0;
   double umag = 0, dmag = 0;
   for (int f = bit * a.frames_per_bit; f < (bit + 1) * a.frames_per_bit; f++)
     for (int ch = 0; ch < C; ch++)
@@ -1797,12 +1852,12 @@ soft_bits_kernel (SoftBitsArgs a)
         for (int j = 0; j < 30; j++)
           {
             const int b = f * 30 + j;
-            const int frame = a.mix_frame[b];
+            const int frame = mix_frame[b];
             // neighbours reflected at the block edges (reference wmget.cc:87-88)
             const int next = frame + 1 < a.block_frames ? frame + 1 : frame - 1;
             const int prev = frame - 1 >= 0 ? frame - 1 : frame + 1;
-            const float *pu = plane + (long long) (a.mix_up[b] - MIN_BAND) * a.ld;
-            const float *pd = plane + (long long) (a.mix_down[b] - MIN_BAND) * a.ld;
+            const float *pu = plane + (long long) (mix_up[b] - MIN_BAND) * a.ld;
+            const float *pd = plane + (long long) (mix_down[b] - MIN_BAND) * a.ld;
             umag += pu[frame];
             umag -= double (__fadd_rn (pu[prev], pu[next])) * 0.5;
             dmag += pd[frame];
@@ -1839,19 +1894,22 @@ soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
     return;
   const float *db = a.db + blk * a.block_stride;
   const int C = a.n_channels;
+  const long long mix0 = a.block_slice ? (long long) a.block_slice[blk] * a.n_data_frames * 30 : 0;
+  const int16_t *mix_frame = a.mix_frame + mix0;
+  const uint8_t *mix_up = a.mix_up + mix0, *mix_down = a.mix_down + mix0;
   const int n_items = a.frames_per_bit * C * 30;
   for (int i = lane; i < n_items; i += 64)
     {
       // item order = summation order: frame of the bit, channel, entry
       const int fi = i / (C * 30), ch = (i / 30) % C, j = i % 30;
       const int b = (bit * a.frames_per_bit + fi) * 30 + j;
-      const int frame = a.mix_frame[b];
+      const int frame = mix_frame[b];
       // neighbours reflected at the block edges (reference wmget.cc:87-88)
       const int next = frame + 1 < a.block_frames ? frame + 1 : frame - 1;
       const int prev = frame - 1 >= 0 ? frame - 1 : frame + 1;
       const float *plane = db + (long long) ch * NB * a.ld;
-      const float *pu = plane + (long long) (a.mix_up[b] - MIN_BAND) * a.ld;
-      const float *pd = plane + (long long) (a.mix_down[b] - MIN_BAND) * a.ld;
+      const float *pu = plane + (long long) (mix_up[b] - MIN_BAND) * a.ld;
+      const float *pd = plane + (long long) (mix_down[b] - MIN_BAND) * a.ld;
       s_item[wave][i] = make_float4 (pu[frame], __fadd_rn (pu[prev], pu[next]), pd[frame], __fadd_rn (pd[prev], pd[next]));
     }
   wave_sync();
@@ -1944,13 +2002,14 @@ soft_prep_kernel (SoftPrepArgs a)
   const SoftJobDev job = a.jobs[blockIdx.x];
   const int2 *src = a.src + job.src_off;
   const int nb = a.n_bits;
+  const int *inv_order = a.inv_order + job.order_off;
   if (job.len > 1728)
     return;
   if (job.mode == 0)
     {
       const float *raw = a.raw + (long long) src[0].x * nb;
       for (int k = threadIdx.x; k < nb; k += 256)
-        s_v[k] = raw[a.inv_order[k]];
+        s_v[k] = raw[inv_order[k]];
     }
   else if (job.mode == 1)
     {
@@ -1959,7 +2018,7 @@ soft_prep_kernel (SoftPrepArgs a)
           const float *raw = a.raw + (long long) src[s].x * nb;
           const int half = src[s].y;
           for (int k = threadIdx.x; k < nb; k += 256)
-            s_v[2 * k + half] = raw[a.inv_order[k]];
+            s_v[2 * k + half] = raw[inv_order[k]];
         }
     }
   else
@@ -1967,7 +2026,7 @@ soft_prep_kernel (SoftPrepArgs a)
       const float div0 = float (job.norm0 > 1 ? job.norm0 : 1), div1 = float (job.norm1 > 1 ? job.norm1 : 1);
       for (int k = threadIdx.x; k < nb; k += 256)
         {
-          const int i = a.inv_order[k];
+          const int i = inv_order[k];
           float acc0 = 0.f, acc1 = 0.f;                   // all_bits starts at zero and the blocks are added in list order
           for (int s = 0; s < job.n_src; s++)
             {

@@ -227,7 +227,8 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
   else
     {
       /* ---- one chain ---- */
-      const_uint_ptr tab = (const_uint_ptr) (a.table.chains + (size_t) wv * R * 8);
+      const_uint_ptr tab = (const_uint_ptr) (a.table.chains + (size_t) (blockIdx.y / a.table.planes_per_slice) * a.table.chains_slice_stride
+                                             + (size_t) wv * R * 8);
       int loaded = 0;
       unsigned rowdesc[2][8];                              // 30 band bytes + u16 frame of the next row
       auto load_row = [&] (unsigned (&w)[8], int r) {
@@ -279,7 +280,10 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
       auto next_frame = [] (const unsigned (&w)[8]) { const int f = int (w[7] >> 16); return f == 0xffff ? 0x7fffffff : f; };
       // rows [r_lo, r_hi) of this chain: all of them, or (HAVE) the live ones -- the frames of a bit's rows ascend.  (Walking the
       // silent rows one by one costs a scalar load latency each with nothing to hide it behind: 3 x the time of the live ones.)
-      const_int_ptr frames = ((const_int_ptr) a.table.packed) + (size_t) (wv >> 1) * R * 64 + 60;
+      const int fstride = a.table.row_frames ? 1 : 64;
+      const_int_ptr frames = a.table.row_frames
+                           ? ((const_int_ptr) a.table.row_frames) + ((size_t) (blockIdx.y / a.table.planes_per_slice) * 6 + (wv >> 1)) * R
+                           : ((const_int_ptr) a.table.packed) + (size_t) (wv >> 1) * R * 64 + 60;
       int r_lo = 0, r_hi = R;
       if (HAVE)
         {
@@ -288,7 +292,7 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
             while (lo < hi)
               {
                 const int mid = (lo + hi) >> 1;
-                if (frames[(size_t) mid * 64] < x)
+                if (frames[(size_t) mid * fstride] < x)
                   lo = mid + 1;
                 else
                   hi = mid;
@@ -298,7 +302,7 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
           r_lo = rows_below (run0 - 255);
           r_hi = run1 > run0 ? rows_below (run1) : r_lo;
         }
-      int fr = r_lo < r_hi ? frames[(size_t) r_lo * 64] : 0x7fffffff;
+      int fr = r_lo < r_hi ? frames[(size_t) r_lo * fstride] : 0x7fffffff;
       if (r_lo < r_hi)
         {
           done_with (fr);
@@ -330,7 +334,7 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
     *reinterpret_cast<float4 *> (&s_sum[wv][4 * lane]) = make_float4 (acc[0], acc[1], acc[2], acc[3]);
   if (HAVE)
     for (int i = tid; i < 6 * R; i += 832)
-      s_frames[i] = a.table.packed[(size_t) i * 64 + 60];
+      s_frames[i] = a.table.row_frames ? a.table.row_frames[(size_t) (blockIdx.y / a.table.planes_per_slice) * 6 * R + i] : a.table.packed[(size_t) i * 64 + 60];
   __syncthreads();
   if (tid < QUAD_TILE && sf0 + tid < a.n_lanes)
     {
@@ -404,7 +408,11 @@ launch_sync_scan_window (hipStream_t st, const SyncScanArgs& a, int total_frames
   if (a.row_stride != 1 || a.n_planes > 65535 || (a.band_stride & 63) || a.lane_count)
     return hipErrorInvalidValue;
   if ((a.have && !a.have_is_run) || !a.table.chains || total_frames >= 0xffff || a.n_lanes + total_frames > 0x1000000 || a.table.rows_per_bit > 4096)
-    return launch_sync_scan (st, a);                      // arbitrary skipped frames: the generic kernel handles any `have`
+    {
+      if (a.table.chains_slice_stride)
+        return hipErrorInvalidValue;                      // (per-slice key tables exist for this kernel only)
+      return launch_sync_scan (st, a);                    // arbitrary skipped frames: the generic kernel handles any `have`
+    }
   const long long px = ((a.n_lanes + QUAD_TILE - 1) / QUAD_TILE + 7) / 8;
   const dim3 grid ((unsigned) (px * 8), (unsigned) a.n_planes), block (64, NCHAIN + 1);
   if (a.have)

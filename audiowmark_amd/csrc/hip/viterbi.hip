@@ -275,6 +275,97 @@ viterbi_round_kernel (ViterbiBatch b, int step0, int parity_in, size_t dec_offse
     }
 }
 
+/* THREE rounds of 4 steps in one launch.  The closure that lets a lane run 4 steps in registers holds one level up: the 4096
+ * states that share their low 3 bits at step T determine the 4096 CONSECUTIVE states (those bits shifted to the top) at step
+ * T + 12.  A workgroup of 256 lanes owns such a family (8 workgroups per decode): round 1 reads its metrics from global memory
+ * (stride 8), the 16 x 256 results change hands inside the workgroup through LDS -- the lanes regroup by the next 4 address bits
+ * -- round 2, LDS again, round 3, and 16 consecutive metrics per lane go back to global memory.  One launch and one trip through
+ * L2 per 12 trellis steps instead of three: 143 steps = 11 launches of 12 + the rounds 4, 4, 3 of the single-round kernel (the
+ * chain of a batch of decodes is bound by its dependent launches: 38 -> 16).  Decision words are stored exactly where the three
+ * single rounds would put them (lane = the round's 11 bit group number), so the trace back does not change.
+ *   round 1  group  L1 = lane << 3 | g                          in:  M[L1 + j 2048]
+ *   round 2  group  L2 = (lane >> 4) << 7 | g << 4 | lane & 15  in:  round 1's result of lane' = j << 4 | lane >> 4, state lane & 15
+ *   round 3  group  L3 = g << 8 | lane                          in:  round 2's result of lane' = j << 4 | lane >> 4, state lane & 15
+ * LDS layout of an exchange: value (writer lane w, state loc) at loc * 324 + (w & 15) * 20 + (w >> 4): a reader's 16 values are
+ * contiguous (four ds_read_b128), writes and reads are conflict free (324 = 4 mod 64, 20 a = 16 distinct multiples of 4 mod 64). */
+constexpr int SUPER_LDS = 16 * 324;
+
+template<int BT, int NPF> __device__ __forceinline__ void
+viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_out, unsigned int *dec, const size_t (&dec_off)[3],
+                     int g, int lane, float *lds_a, float *lds_b)
+{
+  float m[16];
+  const int L1 = (lane << 3) | g;
+#pragma unroll
+  for (int j = 0; j < 16; j++)
+    m[j] = m_in[L1 + j * 2048];
+  const int hi = lane >> 4, lo = lane & 15;
+#pragma unroll
+  for (int r = 0; r < 3; r++)
+    {
+      const int L = r == 0 ? L1 : r == 1 ? ((hi << 7) | (g << 4) | lo) : ((g << 8) | lane);
+      unsigned int words[4];
+      if (r < NPF)
+        viterbi_steps<BT, 4, false> (coded, step0 + 4 * r, m, words, L);
+      else
+        viterbi_steps<BT, 4, true> (coded, step0 + 4 * r, m, words, L);
+      reinterpret_cast<uint4 *> (dec + dec_off[r] + (size_t) L * 4)[0] = make_uint4 (words[0], words[1], words[2], words[3]);
+      if (r < 2)
+        {
+          float *x = r == 0 ? lds_a : lds_b;
+#pragma unroll
+          for (int loc = 0; loc < 16; loc++)
+            x[loc * 324 + lo * 20 + hi] = m[loc];
+          __syncthreads();
+          const float4 *src = reinterpret_cast<const float4 *> (x + lo * 324 + hi * 20);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            {
+              const float4 v = src[q];
+              m[4 * q] = v.x; m[4 * q + 1] = v.y; m[4 * q + 2] = v.z; m[4 * q + 3] = v.w;
+            }
+        }
+    }
+  float4 *out4 = reinterpret_cast<float4 *> (m_out + (size_t) ((g << 8) | lane) * 16);
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    out4[q] = make_float4 (m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+}
+
+struct SuperOffsets { size_t off[3]; };
+
+template<int NPF> __global__ void __launch_bounds__ (V_WG)
+viterbi_super_kernel (ViterbiBatch b, int step0, int parity_in, SuperOffsets so)
+{
+  __shared__ float lds_a[SUPER_LDS], lds_b[SUPER_LDS];
+  int blk = blockIdx.y, t = 0;
+  if (blk >= b.n[0]) { blk -= b.n[0]; t = 1; }
+  if (t == 1 && blk >= b.n[1]) { blk -= b.n[1]; t = 2; }
+  const int rate = t == 2 ? 12 : 6;
+  const int g = blockIdx.x, lane = threadIdx.x;
+  unsigned char *ws = b.ws[t] + (size_t) blk * b.block_ws_bytes;
+  const float *m_in = reinterpret_cast<const float *> (ws + (parity_in ? V_METRIC_BYTES : 0));
+  float *m_out = reinterpret_cast<float *> (ws + (parity_in ? 0 : V_METRIC_BYTES));
+  unsigned int *dec = reinterpret_cast<unsigned int *> (ws + 2 * V_METRIC_BYTES);
+  const float *coded = b.soft[t] + (size_t) blk * b.n_steps * rate;
+  const bool finite = coded[0] == coded[0];              // (see viterbi_round_kernel)
+  if (t == 0)
+    {
+      if (finite) viterbi_super_round<0, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+      else        viterbi_super_round<0, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+    }
+  else if (t == 1)
+    {
+      if (finite) viterbi_super_round<1, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+      else        viterbi_super_round<1, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+    }
+  else
+    {
+      if (finite) viterbi_super_round<2, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+      else        viterbi_super_round<2, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+    }
+}
+
 __global__ void __launch_bounds__ (256)
 viterbi_init_kernel (ViterbiBatch b)
 {
@@ -376,6 +467,9 @@ viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks)
   return per_block * size_t (n_blocks);
 }
 
+int g_viterbi_super = 1;         // (debug toggle)
+extern "C" void awm_debug_set_viterbi_super (int on) { g_viterbi_super = on; }
+
 hipError_t
 launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_blocks[3], long long n_steps,
                 unsigned char *const decisions_ws[3], int *const bits_out[3], float *const error_out[3])
@@ -407,9 +501,29 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
     }
   hipLaunchKernelGGL (viterbi_init_kernel, dim3 (V_STATES / 256, (unsigned) total), dim3 (256), 0, st, b);
   int parity = 0;
-  for (size_t r = 0; r < rounds.size(); r++)
+  for (size_t r = 0; r < rounds.size(); )
     {
       const RoundPlan& rp = rounds[r];
+      if (g_viterbi_super && r + 2 < rounds.size() && rounds[r].k == V_K && rounds[r + 1].k == V_K && rounds[r + 2].k == V_K && V_K == 4)
+        {
+          // three rounds in one launch (metrics exchanged through LDS); non-plain rounds = those that start before step V_ORDER
+          int npf = 0;
+          for (int q = 0; q < 3; q++)
+            npf += rounds[r + q].step0 < V_ORDER;
+          const SuperOffsets so { { rounds[r].dec_offset, rounds[r + 1].dec_offset, rounds[r + 2].dec_offset } };
+          const dim3 grid (8, (unsigned) total);
+          if (npf == 0)
+            hipLaunchKernelGGL ((viterbi_super_kernel<0>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, so);
+          else if (npf == 1)
+            hipLaunchKernelGGL ((viterbi_super_kernel<1>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, so);
+          else if (npf == 2)
+            hipLaunchKernelGGL ((viterbi_super_kernel<2>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, so);
+          else
+            hipLaunchKernelGGL ((viterbi_super_kernel<3>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, so);
+          parity ^= 1;                     // one trip through global memory for the three rounds
+          r += 3;
+          continue;
+        }
       // after V_ORDER steps every state is reachable and, for finite input, all metrics are >= 0: plain compare-select
       const bool plain = rp.step0 >= V_ORDER;
       const dim3 grid ((V_STATES >> rp.k) / V_WG, (unsigned) total);
@@ -422,6 +536,7 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
       else
         hipLaunchKernelGGL ((viterbi_round_kernel<3, false>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
       parity ^= 1;
+      r++;
     }
   tp.final_parity = parity;
   hipLaunchKernelGGL (viterbi_trace_kernel, dim3 ((unsigned) ((total + 63) / 64)), dim3 (64), 0, st, b, tp);

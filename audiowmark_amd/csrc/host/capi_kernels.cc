@@ -5,6 +5,9 @@
 #include "wmspeed.hh"
 #include "utils.hh"
 #include "wmfile.hh"
+#include <atomic>
+#include <future>
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -807,6 +810,39 @@ awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_he
  * is five launches of a few microseconds of work each: alone on a stream they run one after the other with the GPU mostly idle
  * (65 us per clip), so the clips are dealt to eight lanes.  Ordered after the work queued on the context's stream; the context's
  * stream is ordered after the batch. */
+extern "C++" {
+namespace {
+std::vector<Key>
+key_list_from (const uint8_t *keys, int n_keys)
+{
+  std::vector<Key> list;
+  for (int k = 0; k < n_keys; k++)
+    list.push_back (capi_key (keys + size_t (k) * Key::SIZE));
+  return list;
+}
+// patterns of a multi-key `get` -> the C arrays; key_of_pattern[j] = position of pattern j's key in the list
+int
+fill_patterns_keys (const ResultSet& rs, const std::vector<Key>& list, size_t max_out, awm_pattern *out, int *key_of_pattern)
+{
+  for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
+    {
+      fill_pattern (rs.patterns[i], out[i]);
+      if (key_of_pattern)
+        {
+          key_of_pattern[i] = -1;
+          for (size_t k = 0; k < list.size(); k++)
+            if (rs.patterns[i].key == list[k])
+              {
+                key_of_pattern[i] = int (k);
+                break;
+              }
+        }
+    }
+  return int (rs.patterns.size());
+}
+}
+} // extern "C++"
+
 int
 awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
                            float *const *out_d, const size_t *n_frames, int n_channels)
@@ -853,6 +889,111 @@ awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payl
   return rc;
 }
 
+/* the same with ONE KEY PER CLIP (BASELINE configs[4]: `--test-key k` per clip).  The frame_mod tables (361 KB per key; 2226 up / down
+ * draws and three shuffles per key on the host: ~3 ms of one core) are built on host threads group by group while the device works on
+ * the previous group, and live in one batch buffer instead of the context's per-key cache. */
+int
+awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
+                                float *const *out_d, const size_t *n_frames, int n_channels)
+{
+  AWM_ENTER (ctx);
+  if (n_clips && (!keys || !pcm_in_d || !out_d || !n_frames || n_channels < 1))
+    {
+      set_error ("awm_add_watermark_batch_keys_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  const std::vector<int> bits = parse_payload (payload_hex ? payload_hex : "");
+  if (bits.empty())
+    {
+      set_error (std::string ("cannot parse payload '") + (payload_hex ? payload_hex : "") + "'");
+      return AWM_ERR_ARG;
+    }
+  const size_t table_bytes = 2 * mark_block_frame_count() * Params::n_bands;
+  constexpr size_t GROUP = 64;
+  constexpr int ADD_LANES = 8;
+  if (int rc = ctx->ws_keytab.reserve (std::max<size_t> (1, n_clips * table_bytes))) return rc;
+  if (int rc = ctx->pin_keytab.reserve (2 * GROUP * table_bytes)) return rc;
+  const int n_lanes = int (std::min<size_t> (ADD_LANES, std::max<size_t> (1, n_clips)));
+  std::vector<WorkLane *> lanes;
+  for (int i = 0; i < n_lanes; i++)
+    {
+      WorkLane *l = ctx->lane (i);
+      if (!l)
+        {
+          set_error ("cannot create a work lane (stream)");
+          return AWM_ERR_HIP;
+        }
+      if (!l->ev_sync)
+        AWM_HIP_CHECK (hipEventCreateWithFlags (&l->ev_sync, hipEventDisableTiming));
+      lanes.push_back (l);
+    }
+  const std::vector<Key> key_list = key_list_from (keys, int (n_clips));
+  ParamValues *const pv = &params();
+  auto build_group = [&, pv] (size_t g0) {
+    ParamsBind bind (pv);
+    const size_t gn = std::min (GROUP, n_clips - g0);
+    std::vector<std::vector<int8_t>> tables (gn);
+    const size_t n_threads = std::max<size_t> (1, std::min<size_t> ({ gn, size_t (32), size_t (std::max (1u, std::thread::hardware_concurrency())) }));
+    std::atomic<size_t> next { 0 };
+    auto work = [&] {
+      ParamsBind b2 (pv);
+      for (size_t i = next.fetch_add (1); i < gn; i = next.fetch_add (1))
+        tables[i] = build_frame_mod_table (key_list[g0 + i], bits);
+    };
+    std::vector<std::thread> threads;
+    for (size_t t = 1; t < n_threads; t++)
+      threads.emplace_back (work);
+    work();
+    for (auto& t : threads)
+      t.join();
+    return tables;
+  };
+  hipEvent_t ev_up[2] = { nullptr, nullptr };
+  struct EvGuard { hipEvent_t (&ev)[2]; ~EvGuard() { for (hipEvent_t e : ev) if (e) (void) hipEventDestroy (e); } } guard { ev_up };
+  for (auto& e : ev_up)
+    AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
+  int rc = 0;
+  std::future<std::vector<std::vector<int8_t>>> next_tables;
+  for (size_t g0 = 0, g = 0; g0 < n_clips && !rc; g0 += GROUP, g++)
+    {
+      const size_t gn = std::min (GROUP, n_clips - g0);
+      std::vector<std::vector<int8_t>> tables = next_tables.valid() ? next_tables.get() : build_group (g0);
+      if (g0 + GROUP < n_clips)
+        next_tables = std::async (std::launch::async, build_group, g0 + GROUP);        // while the device works on this group
+      char *pin = ctx->pin_keytab.as<char>() + (g & 1) * GROUP * table_bytes;
+      if (g >= 2)
+        AWM_HIP_CHECK (hipEventSynchronize (ev_up[g & 1]));                             // the upload out of this staging half is done
+      for (size_t i = 0; i < gn; i++)
+        {
+          if (tables[i].size() != table_bytes)
+            {
+              set_error ("frame_mod table of unexpected size");
+              rc = AWM_ERR_GENERIC;
+              break;
+            }
+          std::memcpy (pin + i * table_bytes, tables[i].data(), table_bytes);
+        }
+      if (rc)
+        break;
+      int8_t *dev = ctx->ws_keytab.as<int8_t>() + g0 * table_bytes;
+      AWM_HIP_CHECK (hipMemcpyAsync (dev, pin, gn * table_bytes, hipMemcpyHostToDevice, ctx->stream));
+      AWM_HIP_CHECK (hipEventRecord (ev_up[g & 1], ctx->stream));
+      for (int i = 1; i < n_lanes; i++)
+        AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ev_up[g & 1], 0));         // (also orders the lanes after the clips' producers)
+      for (size_t i = 0; i < gn && !rc; i++)
+        rc = add_full (ctx, pcm_in_d[g0 + i], out_d[g0 + i], n_frames[g0 + i], n_channels, dev + i * table_bytes, params().water_delta,
+                       !params().test_no_limiter, lanes[(g0 + i) % n_lanes]);
+    }
+  if (next_tables.valid())
+    next_tables.wait();
+  for (int i = 1; i < n_lanes; i++)
+    {
+      AWM_HIP_CHECK (hipEventRecord (lanes[i]->ev_sync, lanes[i]->stream));
+      AWM_HIP_CHECK (hipStreamWaitEvent (ctx->stream, lanes[i]->ev_sync, 0));
+    }
+  return rc;
+}
+
 int
 awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames, int n_channels,
                      size_t max_out, awm_pattern *out)
@@ -866,38 +1007,6 @@ awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, si
   return int (rs.patterns.size());
 }
 
-extern "C++" {
-namespace {
-std::vector<Key>
-key_list_from (const uint8_t *keys, int n_keys)
-{
-  std::vector<Key> list;
-  for (int k = 0; k < n_keys; k++)
-    list.push_back (capi_key (keys + size_t (k) * Key::SIZE));
-  return list;
-}
-// patterns of a multi-key `get` -> the C arrays; key_of_pattern[j] = position of pattern j's key in the list
-int
-fill_patterns_keys (const ResultSet& rs, const std::vector<Key>& list, size_t max_out, awm_pattern *out, int *key_of_pattern)
-{
-  for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
-    {
-      fill_pattern (rs.patterns[i], out[i]);
-      if (key_of_pattern)
-        {
-          key_of_pattern[i] = -1;
-          for (size_t k = 0; k < list.size(); k++)
-            if (rs.patterns[i].key == list[k])
-              {
-                key_of_pattern[i] = int (k);
-                break;
-              }
-        }
-    }
-  return int (rs.patterns.size());
-}
-}
-} // extern "C++"
 
 int
 awm_get_watermark_keys_d (awm_ctx *ctx, const uint8_t *keys, int n_keys, const float *pcm_d, size_t n_frames, int n_channels,
@@ -931,6 +1040,32 @@ awm_get_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], size_t n_clips, 
     clips.push_back (make_wav (pcm_d[i], n_frames[i], n_channels));
   std::vector<ResultSet> sets;
   if (int rc = get_watermark_batch_device (ctx, { capi_key (key) }, clips, sets, n_threads))
+    return rc;
+  for (size_t i = 0; i < n_clips; i++)
+    {
+      n_out[i] = int (sets[i].patterns.size());
+      for (size_t j = 0; j < sets[i].patterns.size() && j < max_out_per_clip; j++)
+        fill_pattern (sets[i].patterns[j], out[i * max_out_per_clip + j]);
+    }
+  return 0;
+}
+
+int
+awm_get_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, size_t n_clips, const float *const *pcm_d, const size_t *n_frames,
+                                int n_channels, int n_threads, size_t max_out_per_clip, awm_pattern *out, int *n_out)
+{
+  AWM_ENTER (ctx);
+  if (n_clips && (!keys || !pcm_d || !n_frames || !n_out || (max_out_per_clip && !out)))
+    {
+      set_error ("awm_get_watermark_batch_keys_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  std::vector<DeviceWav> clips;
+  for (size_t i = 0; i < n_clips; i++)
+    clips.push_back (make_wav (pcm_d[i], n_frames[i], n_channels));
+  const std::vector<Key> clip_keys = key_list_from (keys, int (n_clips));
+  std::vector<ResultSet> sets;
+  if (int rc = get_watermark_batch_device (ctx, {}, clips, sets, n_threads, &clip_keys))
     return rc;
   for (size_t i = 0; i < n_clips; i++)
     {

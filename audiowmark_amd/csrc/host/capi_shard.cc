@@ -141,6 +141,9 @@ local_exchange (void *user, bool device, int n_send, const void *const *send, co
       else
         ok = hipMemcpyPeer (recv[i], w.device_of[me->rank], sp.ptr[k], w.device_of[src], recv_bytes[i]) == hipSuccess;
     }
+  // device-to-device copies may return before they are done, and the lanes (non-blocking streams) do not wait for the null stream
+  if (device && n_recv)
+    ok = ok && hipDeviceSynchronize() == hipSuccess;
   if (!ok)
     {
       std::lock_guard<std::mutex> lock (w.mutex);

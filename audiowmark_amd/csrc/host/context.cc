@@ -83,9 +83,9 @@ void
 awm::WorkLane::release_lane()
 {
   for (DevBuffer *b : { &ws_db, &ws_block_db, &ws_have, &ws_q, &ws_raw, &ws_mean, &ws_misc, &ws_refine, &ws_refine_have, &ws_soft, &ws_viterbi,
-                        &ws_viterbi_in, &ws_viterbi_bits, &ws_viterbi_err, &ws_block_max, &ws_clip, &ws_idx, &ws_limit_tab, &ws_jobs, &ws_group, &ws_shard_edge, &ws_shard_tail, &ws_shard_q })
+                        &ws_viterbi_in, &ws_viterbi_bits, &ws_viterbi_err, &ws_block_max, &ws_clip, &ws_idx, &ws_limit_tab, &ws_jobs, &ws_group, &ws_keytab, &ws_shard_edge, &ws_shard_tail, &ws_shard_q })
     b->release();
-  for (PinnedBuffer *b : { &pin_refine_in[0], &pin_refine_in[1], &pin_refine_q[0], &pin_refine_q[1], &pin_peaks, &pin_blocks, &pin_jobs, &pin_bits, &pin_small, &pin_group, &pin_shard, &pin_shard_up })
+  for (PinnedBuffer *b : { &pin_refine_in[0], &pin_refine_in[1], &pin_refine_q[0], &pin_refine_q[1], &pin_peaks, &pin_blocks, &pin_jobs, &pin_bits, &pin_small, &pin_group, &pin_shard, &pin_shard_up, &pin_keytab })
     b->release();
   for (hipEvent_t& ev : ev_refine)
     if (ev)
@@ -185,6 +185,51 @@ pack_sync_table (const SyncTable& t, const std::vector<int>& want_pos /* empty: 
         row[61] = r + 1 < R ? (want_pos.empty() ? t.frame[src + 1] : want_pos[t.frame[src + 1]]) : 0x7fffffff;
       }
   return packed;
+}
+
+namespace awm {
+ClipKeyHost
+build_clip_key_host (const Key& key)
+{
+  ClipKeyHost h;
+  const SyncTable st = build_sync_table (key, true);
+  const int total = mark_block_frame_count() * 2, R = st.rows_per_bit;
+  std::vector<int> want_pos (total, -1);
+  std::vector<char> want (total, 0);
+  for (int f : st.frame)
+    want[f] = 1;
+  for (int f = 0; f < total; f++)
+    if (want[f])
+      {
+        want_pos[f] = int (h.want.size());
+        h.want.push_back (f);
+      }
+  const auto pa = pack_sync_table (st, {});
+  h.chains.resize (size_t (12) * R * 8);
+  awmk::pack_scan_chains (pa.data(), R, h.chains.data());
+  h.row_frames.assign (st.frame.begin(), st.frame.end());
+  const int NW = int (h.want.size());
+  h.perm.assign (NW, 0);
+  h.pos.assign (size_t (NW) * Params::n_bands, 255);
+  for (int bit = 0; bit < 6; bit++)
+    for (int r = 0; r < R; r++)
+      {
+        const size_t src = size_t (bit) * R + r;
+        const int w = want_pos[st.frame[src]];
+        h.perm[w] = int (src);
+        for (int i = 0; i < 30; i++)
+          {
+            h.pos[size_t (w) * Params::n_bands + st.up[src * 30 + i]] = (unsigned char) i;
+            h.pos[size_t (w) * Params::n_bands + st.down[src * 30 + i]] = (unsigned char) (30 + i);
+          }
+      }
+  h.mix = build_mix_table (key);
+  const auto order = bit_order (key, code_size (ConvBlockType::a, params().payload_size));
+  h.inv_order.resize (order.size());
+  for (size_t i = 0; i < order.size(); i++)
+    h.inv_order[order[i]] = int (i);
+  return h;
+}
 }
 
 static void

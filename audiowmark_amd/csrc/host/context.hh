@@ -94,6 +94,7 @@ struct KeyTables
     DevBuffer packed_approx;       // [6][rows][64] row = frame
     DevBuffer packed_refine;       // [6][rows][64] row = position in the want list
     DevBuffer chains_approx;       // [12][rows][8] words: byte-packed per-chain rows of packed_approx for K5w (scan.hip)
+    DevBuffer row_frames;          // group tables only (KeyTables::slices): [slice][6][rows] frame of every row
     std::vector<int> want_list;    // sorted sync frames (510 or 1020)
     DevBuffer want_list_dev;
     DevBuffer refine_perm;         // [want rows] int: row w of the want list -> bit * rows_per_bit + j (K4s gathered layout)
@@ -103,7 +104,26 @@ struct KeyTables
   DevBuffer mix_frame, mix_up, mix_down;
   std::vector<unsigned> bit_order_a;        // randomize_bit_order permutation for 858 bits
   DevBuffer bit_order_inv_dev;              // int [858]: restored[k] = raw[inv[k]]
+  // A batch of clips with ONE KEY PER CLIP (wmget.cc clip_batch_staged): this object then describes the tables of a whole group --
+  // every device table above holds `slices` tables back to back (slice i = clip i of the group; only sync[1], the mix tables and
+  // the bit order are filled), slice_want[i] = the want list of slice i.  0: one key, the normal case.
+  int slices = 0;
+  std::vector<std::vector<int>> slice_want;
 };
+
+// host side tables of ONE key for the clip batch path with a key per clip (CLIP mode sync tables in the kernels' formats, mix table,
+// bit order): what get_key_tables uploads per key, without device buffers -- the batch path packs a whole group into one upload
+struct ClipKeyHost
+{
+  std::vector<unsigned>      chains;      // [12][170][8]   K5w
+  std::vector<int>           row_frames;  // [6][170]       K5w (CLIP mode: rows by frame)
+  std::vector<int>           want;        // [1020] sorted sync frames of the long block
+  std::vector<int>           perm;        // [1020]         K4s gathered layout
+  std::vector<unsigned char> pos;         // [1020][81]
+  MixTable                   mix;
+  std::vector<int>           inv_order;   // [858]
+};
+ClipKeyHost build_clip_key_host (const Key& key);
 
 // polyphase table of zita-resampler's fixed-ratio Resampler for one (input rate, output rate) pair (hlen 16)
 struct ResampleTable
@@ -153,10 +173,10 @@ struct WorkLane
   bool           own_stream = false;
   // workspaces
   DevBuffer ws_db, ws_block_db, ws_have, ws_q, ws_raw, ws_mean, ws_misc, ws_refine, ws_refine_have, ws_soft,
-            ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx, ws_limit_tab, ws_jobs, ws_group;
+            ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_block_max, ws_clip, ws_idx, ws_limit_tab, ws_jobs, ws_group, ws_keytab;
   DevBuffer ws_shard_edge, ws_shard_tail, ws_shard_q;      // multi-GPU protocol (wmshard.cc): edge frames, stitched tail buffer, score blocks
   // host staging (two refinement slots: see SyncFinder::SearchJob)
-  PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits, pin_small, pin_group, pin_shard, pin_shard_up;
+  PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits, pin_small, pin_group, pin_shard, pin_shard_up, pin_keytab;
   hipEvent_t   ev_refine[2] = { nullptr, nullptr };
   hipEvent_t   ev_sync = nullptr;        // cross-lane ordering (input ready / lane done)
   SpeedScratch *speed_scratch = nullptr; // buffers of a speed search on this lane (wmspeed.cc), created on first use

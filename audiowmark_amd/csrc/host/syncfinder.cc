@@ -450,7 +450,7 @@ SyncFinder::refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, Searc
 {
   const int clip = mode == Mode::CLIP;
   const auto& sync = kt->sync[clip];
-  const int NW = int (sync.want_list.size());
+  const int NW = int (kt->slices ? kt->slice_want[0].size() : sync.want_list.size());
   const size_t n_cand = job.candidates.size();
   job.refined.clear();
   job.batch_pending = false;
@@ -482,7 +482,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
 {
   const int clip = mode == Mode::CLIP;
   const auto& sync = kt->sync[clip];
-  const int NW = int (sync.want_list.size());
+  const int NW = int (kt->slices ? kt->slice_want[0].size() : sync.want_list.size());
   const long long total = total_frames (mode);
   const int TP = REFINE_TP, QS = REFINE_QS;
   hipStream_t st = m_lane->stream;
@@ -530,9 +530,10 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
       // per (candidate, sync frame): a (1024 + 8 (T - 1))-sample window read once, T rows of dB values written
       if (count)
         db_bytes += double (NW) * ((1024.0 + 8.0 * (count - 1)) * 4 * wav.n_channels + 4.0 * row_values * count);
+      const std::vector<int>& want_list = kt->slices ? kt->slice_want[job.cand_slice[c0 + c]] : sync.want_list;
       for (int w = 0; w < NW; w++)
         {
-          stream_base[c * NW + w] = slice0 + start + (long long) sync.want_list[w] * Params::frame_size;
+          stream_base[c * NW + w] = slice0 + start + (long long) want_list[w] * Params::frame_size;
           stream_count[c * NW + w] = count;
         }
     }
@@ -574,6 +575,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           da.stream_range = job.slice_range;
           da.range_index = d_slice_of;
           da.range_div = NW;
+          da.tables_per_slice = kt->slices ? 1 : 0;          // one key per clip: refine_perm / refine_pos of the candidate's slice
         }
       da.tile_frames = TP;
       {
@@ -883,6 +885,13 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
   sa.table.packed = kt->sync[1].packed_approx.as<int>();
   sa.table.rows_per_bit = kt->sync[1].host.rows_per_bit;
   sa.table.chains = kt->sync[1].chains_approx.as<unsigned>();
+  if (kt->slices)
+    {
+      // one key per clip: the chain tables of the slices lie back to back, the planes of a slice are its shifts
+      sa.table.chains_slice_stride = (long long) 12 * sa.table.rows_per_bit * 8;
+      sa.table.planes_per_slice = n_shifts;
+      sa.table.row_frames = kt->sync[1].row_frames.as<int>();
+    }
   {
     ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_planes) * n_db * 324.0 + double (n_planes) * S * 8.0, st);
     AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));

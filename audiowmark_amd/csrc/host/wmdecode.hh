@@ -23,6 +23,7 @@ struct PendingDecode       // one Viterbi job and what to do with its result
   SyncFinder::Score  score;
   ResultSet::Type    type;
   size_t             chunk = 0;       // which chunk's ResultSet receives the pattern
+  int                order_off = 0;   // bit order table of the job's key: bit_order_inv_dev + order_off (a batch with one key per clip)
 };
 
 // Every pending decode goes to the GPU in one pass: K7b builds the normalised decoder inputs from the raw soft bits that

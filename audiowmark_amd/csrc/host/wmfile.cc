@@ -668,6 +668,8 @@ add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const st
   return add_stream_watermark (ctx, key, in_stream.get(), out_stream.get(), bits, 0);
 }
 
+std::string& last_shard_debug_sync();      // wmshard.cc
+
 /* A long stream over the context and its helpers (other GPUs, awm_ctx_set_helpers): equal frame spans, the helpers' spans copied
  * device to device, awm_multi_get_d.  `spread` = false: not applicable (no helpers, several keys, speed detection, or too short to
  * be worth it) -- the caller decodes on the context alone. */
@@ -708,6 +710,9 @@ get_watermark_multi (awm_ctx *ctx, const std::vector<Key>& key_list, const Devic
         }
       pos += span[i];
     }
+  for (size_t i = 1; i < n_ctx && !rc; i++)            // (peer copies may return before they are done)
+    if (hipSetDevice (ctxs[i]->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+      rc = AWM_ERR_HIP;
   (void) hipSetDevice (ctx->device);
   std::vector<awm_pattern> pats (rc ? 0 : 4096);
   int n = 0;
@@ -738,6 +743,7 @@ get_watermark_multi (awm_ctx *ctx, const std::vector<Key>& key_list, const Devic
                               ResultSet::Type (p.type), p.speed);
     }
   result_set.sort (key_list);
+  result_set.set_debug_sync (last_shard_debug_sync());
   spread = true;
   return 0;
 }

@@ -2,6 +2,7 @@
 #include "wmdecode.hh"
 #include "wmspeed.hh"
 #include <atomic>
+#include <future>
 #include <memory>
 #include <thread>
 #include "utils.hh"
@@ -116,6 +117,8 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
       sb.block_frames = int (count);
       sb.n_blocks = (long long) nb;
       sb.out = lane->ws_soft.as<float>() + b0 * n_bits;
+      if (kt->slices && slice_frames)
+        sb.block_slice = d_slice_of + b0;              // one key per clip: the mix table of the block's slice
       {
         ProfScope ps (ctx, PROF_SOFT_BITS, double (nb) * count * C * 324.0, st);
         AWM_HIP_CHECK (awmk::launch_soft_bits (st, sb));
@@ -304,6 +307,8 @@ decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job)
           jobs[j].norm0 = p.norm0;
           jobs[j].norm1 = p.norm1;
           jobs[j].out_off = (long long) (in_off[t] + i * len);
+          jobs[j].order_off = p.order_off;
+          jobs[j].pad = 0;
           for (const auto& sp : p.src)
             srcs[so++] = make_int2 (sp.first, sp.second);
           j++;
@@ -1090,11 +1095,105 @@ clip_is_short (const DeviceWav& w)
   return w.n_frames > 0 && w.n_frames < (mark_block_frame_count() + 2) * Params::frame_size;
 }
 
+/* The key tables of a group of clips with ONE KEY PER CLIP: built on host threads (2226 up / down draws, three shuffles per key:
+ * ~3 ms of one core), packed into one page-locked block, one copy to the device; `kt` then describes the group (KeyTables::slices). */
+namespace {
+constexpr int TABLE_THREADS = 32;
+size_t align256 (size_t n) { return (n + 255) & ~size_t (255); }
+
+std::vector<ClipKeyHost>
+build_group_hosts (const std::vector<Key>& keys)
+{
+  std::vector<ClipKeyHost> hosts (keys.size());
+  const size_t n_threads = std::max<size_t> (1, std::min<size_t> ({ keys.size(), size_t (TABLE_THREADS), size_t (std::max (1u, std::thread::hardware_concurrency())) }));
+  std::atomic<size_t> next { 0 };
+  ParamValues *const pv = &params();
+  auto work = [&] {
+    ParamsBind bind (pv);
+    for (size_t i = next.fetch_add (1); i < keys.size(); i = next.fetch_add (1))
+      hosts[i] = build_clip_key_host (keys[i]);
+  };
+  std::vector<std::thread> threads;
+  for (size_t t = 1; t < n_threads; t++)
+    threads.emplace_back (work);
+  work();
+  for (auto& t : threads)
+    t.join();
+  return hosts;
+}
+
+int
+upload_group_tables (WorkLane *lane, const std::vector<ClipKeyHost>& hosts, KeyTables& kt)
+{
+  const size_t gn = hosts.size();
+  const size_t n_chain = hosts[0].chains.size(), NW = hosts[0].want.size(), n_pos = hosts[0].pos.size(), n_mix = hosts[0].mix.frame.size(),
+               n_ord = hosts[0].inv_order.size();
+  const size_t off_chain = 0, off_perm = align256 (off_chain + gn * n_chain * sizeof (unsigned)), off_pos = align256 (off_perm + gn * NW * sizeof (int)),
+               off_mf = align256 (off_pos + gn * n_pos), off_mu = align256 (off_mf + gn * n_mix * sizeof (int16_t)), off_md = align256 (off_mu + gn * n_mix),
+               off_ord = align256 (off_md + gn * n_mix), off_rf = align256 (off_ord + gn * n_ord * sizeof (int)),
+               n_rf = hosts[0].row_frames.size(), bytes = align256 (off_rf + gn * n_rf * sizeof (int));
+  if (int rc = lane->pin_keytab.reserve (bytes)) return rc;
+  if (int rc = lane->ws_keytab.reserve (bytes)) return rc;
+  char *h = lane->pin_keytab.as<char>();
+  for (size_t i = 0; i < gn; i++)
+    {
+      const ClipKeyHost& k = hosts[i];
+      if (k.chains.size() != n_chain || k.want.size() != NW || k.mix.frame.size() != n_mix)
+        {
+          set_error ("clip batch: key tables of different shapes");
+          return AWM_ERR_GENERIC;
+        }
+      std::copy (k.chains.begin(), k.chains.end(), reinterpret_cast<unsigned *> (h + off_chain) + i * n_chain);
+      std::copy (k.perm.begin(), k.perm.end(), reinterpret_cast<int *> (h + off_perm) + i * NW);
+      std::copy (k.pos.begin(), k.pos.end(), reinterpret_cast<unsigned char *> (h + off_pos) + i * n_pos);
+      std::copy (k.mix.frame.begin(), k.mix.frame.end(), reinterpret_cast<int16_t *> (h + off_mf) + i * n_mix);
+      std::copy (k.mix.up.begin(), k.mix.up.end(), reinterpret_cast<uint8_t *> (h + off_mu) + i * n_mix);
+      std::copy (k.mix.down.begin(), k.mix.down.end(), reinterpret_cast<uint8_t *> (h + off_md) + i * n_mix);
+      std::copy (k.inv_order.begin(), k.inv_order.end(), reinterpret_cast<int *> (h + off_ord) + i * n_ord);
+      std::copy (k.row_frames.begin(), k.row_frames.end(), reinterpret_cast<int *> (h + off_rf) + i * n_rf);
+    }
+  AWM_HIP_CHECK (hipMemcpyAsync (lane->ws_keytab.ptr, h, bytes, hipMemcpyHostToDevice, lane->stream));
+  char *d = lane->ws_keytab.as<char>();
+  auto view = [] (DevBuffer& b, void *ptr, size_t n) { b.ptr = ptr; b.bytes = n; };     // (non-owning: never released through kt)
+  kt = KeyTables();
+  kt.slices = int (gn);
+  kt.mix = params().mix;
+  kt.sync[1].host.rows_per_bit = int (n_chain / (12 * 8));
+  view (kt.sync[1].chains_approx, d + off_chain, gn * n_chain * sizeof (unsigned));
+  view (kt.sync[1].refine_perm, d + off_perm, gn * NW * sizeof (int));
+  view (kt.sync[1].refine_pos, d + off_pos, gn * n_pos);
+  view (kt.mix_frame, d + off_mf, gn * n_mix * sizeof (int16_t));
+  view (kt.mix_up, d + off_mu, gn * n_mix);
+  view (kt.mix_down, d + off_md, gn * n_mix);
+  view (kt.bit_order_inv_dev, d + off_ord, gn * n_ord * sizeof (int));
+  view (kt.sync[1].row_frames, d + off_rf, gn * n_rf * sizeof (int));
+  for (const ClipKeyHost& k : hosts)
+    kt.slice_want.push_back (k.want);
+  return 0;
+}
+}
+
+/* clip_keys (may be null): one key per clip -- clip i is searched and decoded with (*clip_keys)[i] alone (key_list is not used then) */
 static int
 clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips, const std::vector<size_t>& which,
-                   std::vector<ResultSet>& result_sets)
+                   std::vector<ResultSet>& result_sets, const std::vector<Key> *clip_keys = nullptr)
 {
   const size_t count = mark_block_frame_count();
+  const int n_bits_a = int (mark_data_frame_count() / params().frames_per_bit);
+  // the key tables of the NEXT group are built on host threads while the device works on this one
+  std::future<std::vector<ClipKeyHost>> next_hosts;
+  auto group_keys = [&] (size_t g0, size_t gn) {
+    std::vector<Key> keys;
+    for (size_t i = 0; i < gn; i++)
+      keys.push_back ((*clip_keys)[which[g0 + i]]);
+    return keys;
+  };
+  auto group_size = [&] (size_t g0) {
+    size_t gn = 0;
+    while (g0 + gn < which.size() && gn < size_t (CLIP_GROUP) && clips[which[g0 + gn]].n_channels == clips[which[g0]].n_channels)
+      gn++;
+    return gn;
+  };
   hipStream_t st = lane->stream;
   struct LaneDrain
   {
@@ -1138,10 +1237,26 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
       std::vector<ResultSet *> ptrs;
       for (auto& cs : chunk_sets)
         ptrs.push_back (&cs);
-      bool db_ready = false;                 // the group's dB matrices are shared by the keys
-      for (const Key& key : key_list)
+      KeyTables group_kt;
+      std::vector<Key> keys_of_group;
+      if (clip_keys)
         {
-          KeyTables *kt = ctx->get_key_tables (key);
+          keys_of_group = group_keys (g0, gn);
+          std::vector<ClipKeyHost> hosts = next_hosts.valid() ? next_hosts.get() : build_group_hosts (keys_of_group);
+          if (g0 + gn < which.size())
+            {
+              const size_t n0 = g0 + gn;
+              ParamValues *const pv = &params();
+              next_hosts = std::async (std::launch::async, [&, n0, pv] { ParamsBind bind (pv); return build_group_hosts (group_keys (n0, group_size (n0))); });
+            }
+          if (int rc = upload_group_tables (lane, hosts, group_kt))
+            return rc;
+        }
+      bool db_ready = false;                 // the group's dB matrices are shared by the keys
+      const std::vector<Key> one_pass { Key() };
+      for (const Key& key : (clip_keys ? one_pass : key_list))
+        {
+          KeyTables *kt = clip_keys ? &group_kt : ctx->get_key_tables (key);
           if (!kt)
             return AWM_ERR_HIP;
           SyncFinder finder (ctx, lane);
@@ -1163,7 +1278,7 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
                   DeviceWav slice = group;
                   slice.data = group.data + i * slice_values;
                   slice.n_frames = slice_frames;
-                  if (int rc = clip_run_padded (ctx, lane, { key }, slice, chunk_sets[g0 + i], 0.0, 1))
+                  if (int rc = clip_run_padded (ctx, lane, { clip_keys ? keys_of_group[i] : key }, slice, chunk_sets[g0 + i], 0.0, 1))
                     return rc;
                   db_ready = false;              // (that search used the lane's dB workspace)
                   continue;
@@ -1191,11 +1306,24 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
               SyncFinder::Score nopad = cands[k].score;
               nopad.index = 0;                                                     // time offset of the START position is 0
               decode.pending.push_back ({ ConvBlockType::ab, 1, { { slot_of[2 * k], first_half }, { slot_of[2 * k + 1], 1 - first_half } }, 0, 0,
-                                          0.0, nopad, ResultSet::Type::CLIP, g0 + cands[k].clip });
+                                          0.0, nopad, ResultSet::Type::CLIP, g0 + cands[k].clip,
+                                          clip_keys ? int (cands[k].clip) * n_bits_a : 0 });
             }
           if (int rc = decode_launch (ctx, lane, kt, decode))
             return rc;
-          if (int rc = decode_finish (lane, key, decode, ptrs, 1))
+          if (clip_keys)
+            {
+              // every pattern under the key of its clip
+              std::vector<DecodedPattern> decoded;
+              if (int rc = decode_finish (lane, key, decode, ptrs, 1, &decoded))
+                return rc;
+              for (const DecodedPattern& d : decoded)
+                {
+                  const PendingDecode& p = decode.pending[d.pending_index];
+                  ptrs[p.chunk]->add_pattern (keys_of_group[p.chunk - g0], p.time, p.score, d.bits, d.error, p.type, 1);
+                }
+            }
+          else if (int rc = decode_finish (lane, key, decode, ptrs, 1))
             return rc;
         }
       g0 += gn;
@@ -1206,7 +1334,7 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
       ResultSet& rs = result_sets[which[j]];                        // as get_watermark_device: one chunk at offset 0, merge, sort
       chunk_sets[j].apply_time_offset (0.0);
       rs.merge (chunk_sets[j]);
-      rs.sort (key_list);
+      rs.sort (clip_keys ? std::vector<Key> { (*clip_keys)[which[j]] } : key_list);
     }
   return 0;
 }
@@ -1218,8 +1346,10 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
  * get_watermark_device per clip. */
 int
 get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips,
-                            std::vector<ResultSet>& result_sets, int n_threads)
+                            std::vector<ResultSet>& result_sets, int n_threads, const std::vector<Key> *clip_keys)
 {
+  // clip_keys: one key per clip (clip i is decoded with (*clip_keys)[i] alone); else every clip with the whole key_list
+  auto keys_of = [&] (size_t i) { return clip_keys ? std::vector<Key> { (*clip_keys)[i] } : key_list; };
   result_sets.clear();
   result_sets.resize (clips.size());
   if (clips.empty())
@@ -1230,7 +1360,7 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
     {
       // the speed search and the stretched copy of a clip live in per-context buffers: one clip after the other
       for (size_t i = 0; i < clips.size(); i++)
-        if (int rc = get_watermark_on (ctx, ctx, true, key_list, clips[i], result_sets[i]))
+        if (int rc = get_watermark_on (ctx, ctx, true, keys_of (i), clips[i], result_sets[i]))
           return rc;
       return 0;
     }
@@ -1242,9 +1372,10 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
         AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
       AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));                   // the clips may still be in flight there
       const int n_staged_threads = std::max (1, std::min<int> (STAGED_THREADS, int ((staged.size() + CLIP_GROUP - 1) / CLIP_GROUP)));
-      for (const Key& key : key_list)
-        if (!ctx->get_key_tables (key))                 // built once, before the workers start
-          return AWM_ERR_HIP;
+      if (!clip_keys)
+        for (const Key& key : key_list)
+          if (!ctx->get_key_tables (key))               // built once, before the workers start
+            return AWM_ERR_HIP;
       std::vector<WorkLane *> staged_lanes;
       for (int t = 0; t < n_staged_threads; t++)
         {
@@ -1270,11 +1401,11 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
         workers.emplace_back ([&, t] {
           ParamsBind bind (pv);
           (void) hipSetDevice (ctx->device);
-          rcs[t] = clip_batch_staged (ctx, staged_lanes[t], key_list, clips, share[t], result_sets);
+          rcs[t] = clip_batch_staged (ctx, staged_lanes[t], key_list, clips, share[t], result_sets, clip_keys);
           if (rcs[t])
             messages[t] = last_error();
         });
-      rcs[0] = clip_batch_staged (ctx, staged_lanes[0], key_list, clips, share[0], result_sets);
+      rcs[0] = clip_batch_staged (ctx, staged_lanes[0], key_list, clips, share[0], result_sets, clip_keys);
       for (auto& w : workers)
         w.join();
       for (int t = 0; t < n_staged_threads; t++)
@@ -1299,9 +1430,10 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
         }
       lanes.push_back (l);
     }
-  for (const Key& key : key_list)
-    if (!ctx->get_key_tables (key))                 // built once, before the workers start
-      return AWM_ERR_HIP;
+  if (!clip_keys)
+    for (const Key& key : key_list)
+      if (!ctx->get_key_tables (key))               // built once, before the workers start
+        return AWM_ERR_HIP;
   // the clips may still be in flight on the context's stream
   if (!ctx->ev_sync)
     AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
@@ -1329,7 +1461,7 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
         if (t >= threaded.size())
           break;
         const size_t i = threaded[t];
-        if (int r = get_watermark_on (ctx, lanes[li], false, key_list, clips[i], result_sets[i]))
+        if (int r = get_watermark_on (ctx, lanes[li], false, keys_of (i), clips[i], result_sets[i]))
           {
             rc[li] = r;
             err[li] = last_error();

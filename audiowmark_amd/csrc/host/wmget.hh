@@ -54,8 +54,9 @@ int decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceW
 // whole detect pass over resident PCM: chunks, merge, sort
 int get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, ResultSet& result_set);
 // many independent inputs at once (one lane + host thread per input in flight); n_threads <= 0: as many as there are lanes
+// clip_keys: one key per clip instead of the key list for all
 int get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips,
-                                std::vector<ResultSet>& result_sets, int n_threads);
+                                std::vector<ResultSet>& result_sets, int n_threads, const std::vector<Key> *clip_keys = nullptr);
 
 // soft bits of whole blocks (fft_range + mix_decode), raw mix order
 int block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,

@@ -301,6 +301,15 @@ sharded_add (awm_ctx *ctx, const Key& key, const std::string& payload_hex, const
 
 /* ---- get ---------------------------------------------------------------------------------------------------------------- */
 
+// the "sync_match" line of the last sharded get that this thread ran as rank 0 (the C ABI returns patterns only; the file level `cmp`
+// prints the line)
+std::string&
+last_shard_debug_sync()
+{
+  static thread_local std::string s;
+  return s;
+}
+
 namespace {
 
 // what a rank keeps per chunk it takes part in
@@ -540,72 +549,81 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
 
   /* ---- phase 4: selection on the complete list (every participant, same result), then refinement of MY candidates */
   const double threshold = params().sync_threshold2 * 0.75;
-  for (ChunkWork& w : work)
+  // (a lane's buffers -- score lists, peak lists, refinement rows and their page-locked staging -- serve one chunk at a time: rounds of
+  // one chunk per lane)
+  for (size_t w0 = 0; w0 < work.size(); w0 += lanes.size())
     {
-      const size_t q_stride = (size_t (w.S) + 63) & ~size_t (63);
-      if (int rc = w.lane->ws_q.reserve (4 * q_stride * sizeof (double))) return rc;
-      for (size_t i = 0; i < w.ranks.size(); i++)
+      const size_t w1 = std::min (work.size(), w0 + lanes.size());
+      for (size_t wi_ = w0; wi_ < w1; wi_++)
         {
-          const double *src = q_all + (int (i) == w.me ? w.q_off : w.recv_off[i]);
-          AWM_HIP_CHECK (hipMemcpy2DAsync (w.lane->ws_q.as<double>() + (w.rank_first[i] - w.rank_first[0]), q_stride * sizeof (double), src,
-                                           w.rank_n[i] * sizeof (double), w.rank_n[i] * sizeof (double), 4, hipMemcpyDeviceToDevice, w.lane->stream));
-        }
-      if (int rc = w.finder->scores_loaded (w.S)) return rc;
-      if (int rc = w.finder->select_launch (4 * w.S, threshold, false)) return rc;
-    }
-  for (ChunkWork& w : work)
-    {
-      if (int rc = w.finder->select_finish (4 * w.S, threshold, w.candidates, false)) return rc;
-      // whose candidate is it?  (start frame -> participant; interior or tail part for mine)
-      for (size_t k = 0; k < w.candidates.size(); k++)
-        {
-          const size_t sf = w.candidates[k].index / FRAME;
-          int owner = -1;
+          ChunkWork& w = work[wi_];
+          const size_t q_stride = (size_t (w.S) + 63) & ~size_t (63);
+          if (int rc = w.lane->ws_q.reserve (4 * q_stride * sizeof (double))) return rc;
           for (size_t i = 0; i < w.ranks.size(); i++)
-            if (sf >= w.rank_first[i] && sf < w.rank_first[i] + w.rank_n[i])
-              owner = int (i);
-          w.cand_owner.push_back (owner);
-          const bool tail = owner == w.me && w.tail && sf >= w.tail->first_sf;
-          w.cand_tail.push_back (tail);
-          if (owner == w.me)
             {
-              w.refine_job[tail].candidates.push_back (w.candidates[k]);
-              w.refine_cand[tail].push_back (uint32_t (k));
+              const double *src = q_all + (int (i) == w.me ? w.q_off : w.recv_off[i]);
+              AWM_HIP_CHECK (hipMemcpy2DAsync (w.lane->ws_q.as<double>() + (w.rank_first[i] - w.rank_first[0]), q_stride * sizeof (double), src,
+                                               w.rank_n[i] * sizeof (double), w.rank_n[i] * sizeof (double), 4, hipMemcpyDeviceToDevice, w.lane->stream));
             }
+          if (int rc = w.finder->scores_loaded (w.S)) return rc;
+          if (int rc = w.finder->select_launch (4 * w.S, threshold, false)) return rc;
         }
-      for (int tail = 0; tail < 2; tail++)
+      for (size_t wi_ = w0; wi_ < w1; wi_++)
         {
-          if (w.refine_job[tail].candidates.empty())
-            continue;
-          size_t vf = 0;
-          const float *view = part_view (w, tail, vf);
-          const size_t vh = view_hi (w, tail);
-          for (const auto& cand : w.refine_job[tail].candidates)
+          ChunkWork& w = work[wi_];
+          if (int rc = w.finder->select_finish (4 * w.S, threshold, w.candidates, false)) return rc;
+          // whose candidate is it?  (start frame -> participant; interior or tail part for mine)
+          for (size_t k = 0; k < w.candidates.size(); k++)
             {
-              const size_t lo = cand.index > size_t (Params::sync_search_step) ? cand.index - Params::sync_search_step : 0;
-              const size_t hi = std::min (cand.index + Params::sync_search_step + (block + 1) * FRAME, w.N);
-              if (lo < vf || hi > vh)
+              const size_t sf = w.candidates[k].index / FRAME;
+              int owner = -1;
+              for (size_t i = 0; i < w.ranks.size(); i++)
+                if (sf >= w.rank_first[i] && sf < w.rank_first[i] + w.rank_n[i])
+                  owner = int (i);
+              w.cand_owner.push_back (owner);
+              const bool tail = owner == w.me && w.tail && sf >= w.tail->first_sf;
+              w.cand_tail.push_back (tail);
+              if (owner == w.me)
                 {
-                  set_error ("awm_sharded_get_d: internal error (refinement outside the part's buffer)");
-                  return AWM_ERR_GENERIC;
+                  w.refine_job[tail].candidates.push_back (w.candidates[k]);
+                  w.refine_cand[tail].push_back (uint32_t (k));
                 }
             }
-          w.refine_job[tail].slot = tail;
-          const DeviceWav vw = virtual_chunk_wav (view, vf, w.N, C);
-          if (int rc = w.finder->prepare (vw, SyncFinder::Mode::BLOCK)) return rc;
-          if (int rc = w.finder->refine_launch (kt, vw, SyncFinder::Mode::BLOCK, w.refine_job[tail])) return rc;
+          for (int tail = 0; tail < 2; tail++)
+            {
+              if (w.refine_job[tail].candidates.empty())
+                continue;
+              size_t vf = 0;
+              const float *view = part_view (w, tail, vf);
+              const size_t vh = view_hi (w, tail);
+              for (const auto& cand : w.refine_job[tail].candidates)
+                {
+                  const size_t lo = cand.index > size_t (Params::sync_search_step) ? cand.index - Params::sync_search_step : 0;
+                  const size_t hi = std::min (cand.index + Params::sync_search_step + (block + 1) * FRAME, w.N);
+                  if (lo < vf || hi > vh)
+                    {
+                      set_error ("awm_sharded_get_d: internal error (refinement outside the part's buffer)");
+                      return AWM_ERR_GENERIC;
+                    }
+                }
+              w.refine_job[tail].slot = tail;
+              const DeviceWav vw = virtual_chunk_wav (view, vf, w.N, C);
+              if (int rc = w.finder->prepare (vw, SyncFinder::Mode::BLOCK)) return rc;
+              if (int rc = w.finder->refine_launch (kt, vw, SyncFinder::Mode::BLOCK, w.refine_job[tail])) return rc;
+            }
         }
+      for (size_t wi_ = w0; wi_ < w1; wi_++)
+        for (int tail = 0; tail < 2; tail++)
+          {
+            ChunkWork& w = work[wi_];
+            if (w.refine_job[tail].candidates.empty())
+              continue;
+            if (int rc = w.finder->refine_collect (w.refine_job[tail])) return rc;
+            const auto& refined = w.refine_job[tail].refined;               // candidate order
+            for (size_t k = 0; k < refined.size(); k++)
+              w.refined_mine.push_back ({ w.refine_cand[tail][k], 0, uint64_t (refined[k].index), refined[k].raw_quality, refined[k].local_mean });
+          }
     }
-  for (ChunkWork& w : work)
-    for (int tail = 0; tail < 2; tail++)
-      {
-        if (w.refine_job[tail].candidates.empty())
-          continue;
-        if (int rc = w.finder->refine_collect (w.refine_job[tail])) return rc;
-        const auto& refined = w.refine_job[tail].refined;               // candidate order
-        for (size_t k = 0; k < refined.size(); k++)
-          w.refined_mine.push_back ({ w.refine_cand[tail][k], 0, uint64_t (refined[k].index), refined[k].raw_quality, refined[k].local_mean });
-      }
 
   /* ---- phase 5: the refined scores travel to the other participants (a few dozen records per chunk) */
   {
@@ -717,6 +735,10 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
                 return AWM_ERR_GENERIC;
               }
           std::vector<char> ok;
+          // (block_soft_bits_dev stages the block list through the lane's page-locked buffer: a second call on the same lane -- the
+          // tail part after the interior part -- must not refill it before the first copy has run)
+          if (tail)
+            AWM_HIP_CHECK (stream_wait (w.lane->stream));
           if (int rc = block_soft_bits_dev (ctx, w.lane, kt, virtual_chunk_wav (view, vf, w.N, C), index, sc.slot_of, ok))
             return rc;
           float *host = reinterpret_cast<float *> (w.lane->pin_shard.as<char>() + used);
@@ -733,6 +755,25 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
     for (size_t j = 0; j < sc.blocks.size(); j++)
       std::copy (sc.host + size_t (sc.slot_of[j]) * n_bits, sc.host + size_t (sc.slot_of[j] + 1) * n_bits,
                  sc.w->soft_all.begin() + sc.blocks[j] * n_bits);
+
+  // the "sync_match" line of `cmp` (BlockDecoder::run, wmget.cc:708-733): sync positions of the first chunk against where the blocks
+  // of an uncut file start -- every participant of chunk 0 knows them; rank 0 is one unless its span is empty
+  std::string debug_sync;
+  for (ChunkWork& w : work)
+    if (w.c == 0)
+      {
+        const int expect0 = Params::frames_pad_start * Params::frame_size, expect_step = int (block * FRAME);
+        const int expect_end = int (w.N / FRAME) * int (FRAME);
+        int sync_match = 0;
+        for (int expect_index = expect0; expect_index + expect_step < expect_end; expect_index += expect_step)
+          for (const auto& sc : w.scores)
+            if (std::abs (int (sc.index + params().test_cut) - expect_index) < int (FRAME / 2))
+              {
+                sync_match++;
+                break;
+              }
+        debug_sync = string_printf ("sync_match %d %zd\n", sync_match, w.scores.size());
+      }
 
   /* ---- phase 7: the blocks' soft bits go to the other participants (AB pairs and the "all" chain reach across span edges) */
   {
@@ -781,6 +822,24 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
             }
       }
   }
+
+  if (getenv ("AWM_SHARD_DEBUG"))
+    for (ChunkWork& w : work)
+      {
+        std::string line = string_printf ("[shard rank %d chunk %d me %d/%zd S %lld] cand:", rank, w.c, w.me, w.ranks.size(), w.S);
+        for (size_t k = 0; k < w.candidates.size(); k++)
+          line += string_printf (" %zu(o%d%s)", w.candidates[k].index, w.cand_owner[k], w.cand_tail[k] ? "t" : "");
+        line += " | blocks:";
+        for (size_t wi = 0; wi < w.wanted.size(); wi++)
+          {
+            double sum = 0;
+            for (int b = 0; b < n_bits; b++)
+              sum += w.soft_all[wi * n_bits + b] * (1 + b % 7);
+            line += string_printf (" %zu(o%d%s q%.4f s%.3f)", w.scores[w.wanted[wi]].index, w.score_owner[w.wanted[wi]], w.score_tail[w.wanted[wi]] ? "t" : "",
+                                   w.scores[w.wanted[wi]].quality, sum);
+          }
+        fprintf (stderr, "%s\n", line.c_str());
+      }
 
   /* ---- phase 8: the chunk's decode jobs (single blocks, AB pairs, "all": BlockDecoder::run, wmget.cc:554-701), dealt round robin
    * among the participants.  A lane decodes one chunk at a time (its decoder buffers): rounds of one chunk per lane. */
@@ -881,6 +940,8 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       result.merge (chunk);
     }
   result.sort (key_list);
+  result.set_debug_sync (debug_sync);
+  last_shard_debug_sync() = debug_sync;
   return 0;
 }
 

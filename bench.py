@@ -377,19 +377,27 @@ def main():
     gen.manual_seed(1234 + rank)
     strong = args.config == "8h"
     if args.config == "clips":
-        # ---- configs[4]: independent 30 s clips, replicas: rank r takes clips r, r + world, ...; no data-path collective ----
+        # ---- configs[4]: independent 30 s clips, replicas: rank r takes clips r + 1, r + 1 + world, ...; no data-path collective.
+        # clip k is `test-gen-noise` with --test-key k (16 bit), watermarked and decoded with --test-key k.
+        import numpy as np
+        from concurrent.futures import ThreadPoolExecutor
         n_clip = 30 * RATE
-        mine = list(range(rank, args.clips, world))
-        clips = [torch.rand((n_clip, 2), generator=gen, device=dev, dtype=torch.float32) * 2 - 1 for _ in mine]
+        mine = list(range(rank + 1, args.clips + 1, world))
+        keys = [awm.test_key(k) for k in mine]
+
+        def make_clip(k):                                    # (the C call releases the GIL: the generator runs on all host cores)
+            return quantise16(np, awm.binding.gen_noise(awm.test_key(k), 2 * n_clip)).reshape(n_clip, 2)
+        with ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 8)) as pool:
+            clips = [torch.from_numpy(c).to(dev) for c in pool.map(make_clip, mine)]
         outs = [torch.empty_like(c) for c in clips]
         audio_seconds = args.clips * 30.0
-        workload = (f"{args.clips} clips of 30 s stereo 44.1 kHz white noise over {world} GPU(s) (replicas: {len(mine)} on rank 0), add + get per "
-                    f"clip, one key for the batch (awm_add_watermark_batch_d: clips dealt to 8 lanes; awm_get_watermark_batch_d: ClipDecoder in groups of 64 clips, "
-                    f"one launch per stage and group)")
+        workload = (f"{args.clips} clips of 30 s stereo 44.1 kHz test-gen-noise (--test-key k, 16 bit) over {world} GPU(s) (replicas: {len(mine)} on rank 0), "
+                    f"add + get per clip with the clip's own key k (awm_add_watermark_batch_keys_d / awm_get_watermark_batch_keys_d: groups of 64 clips, "
+                    f"key tables of a group built on host threads while the device works on the previous group, one launch per stage and group)")
 
         def step():
-            ctx.add_watermark_batch(None, PAYLOAD, clips, outs)
-            return ctx.get_watermark_batch(None, outs)
+            ctx.add_watermark_batch_keys(keys, PAYLOAD, clips, outs)
+            return ctx.get_watermark_batch_keys(keys, outs)
     else:
         minutes = args.minutes if args.minutes is not None else (480.0 if strong else 60.0)
         n_total = int(minutes * 60 * RATE) * (1 if strong else world)
@@ -469,8 +477,32 @@ def main():
 
     if rank == 0:
         if args.config == "clips":
+            # measured, untimed: profiled launch scopes per clip (one extra pass with the per-kernel events on), the host cost of one
+            # key's tables on one core, and the same batch with ONE key for all clips (what the per-clip keys add)
+            awm.lib.awm_prof_reset(ctx._h)
+            awm.lib.awm_prof_enable(ctx._h, 1)
+            step()
+            sync()
+            awm.lib.awm_prof_enable(ctx._h, 0)
+            scopes = sum(p[2] for p in read_prof(awm, ctx))
+            t0 = time.perf_counter()
+            for k in mine[:8]:
+                awm.tab_frame_mod(awm.test_key(k), PAYLOAD); awm.tab_sync_bits(awm.test_key(k), True); awm.tab_mix_entries(awm.test_key(k))
+            t_tab = (time.perf_counter() - t0) / max(1, len(mine[:8]))
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                ctx.add_watermark_batch(keys[0], PAYLOAD, clips, outs)
+                ctx.get_watermark_batch(keys[0], outs)
+            sync()
+            one_key = (time.perf_counter() - t0) / 2
+            per_clip = elapsed / args.steps * 1e3 / max(1, len(clips))
             cfg = {"workload": workload, "parallelism": f"{world} replica(s)", "clips_with_payload": matches_local,
-                   "clip_batch_config": {"clips_per_group": 64, "host_threads": 2, "launches_per_clip": 0.9, "ms_per_clip_get_and_add": round(elapsed / args.steps * 1e3 / max(1, len(clips)), 4)}}
+                   "clip_batch_config": {"ms_per_clip_add_and_get": round(per_clip, 4),
+                                         "ms_per_clip_with_one_key_for_all": round(one_key * 1e3 / max(1, len(clips)), 4),
+                                         "key_tables_ms_per_clip_amortised": round(per_clip - one_key * 1e3 / max(1, len(clips)), 4),
+                                         "key_tables_host_ms_per_key_on_one_core": round(t_tab * 1e3, 3), "host_cores": os.cpu_count(),
+                                         "profiled_launch_scopes_per_clip": round(scopes / max(1, len(clips)), 3)}}
         else:
             matches = sum(1 for p in (pats or []) if p["bits"] == PAYLOAD)
             cfg = {"workload": workload, "parallelism": (f"one stream sharded over {world} GPU(s)" if sharded_path else "1 GPU"),

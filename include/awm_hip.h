@@ -189,6 +189,17 @@ typedef struct
 int awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
                                float *const *out_d, const size_t *n_frames, int n_channels);
 
+/* The batch entry points with ONE KEY PER CLIP (keys = n_clips * 16 bytes; BASELINE configs[4]: `--test-key k` for clip k).  The key
+ * tables -- frame_mod for `add`; CLIP sync tables, mix table and bit order for `get` (wmcommon.cc:143-202, wmadd.cc:86-162,
+ * syncfinder.cc:30-77) -- are built on host threads for a group of 64 clips at a time while the device works on the previous
+ * group, travel in ONE copy per group and are indexed per clip inside the group's launches; results per clip equal
+ * awm_add_watermark_d / awm_get_watermark_d with that clip's key. */
+int awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
+                                    float *const *out_d, const size_t *n_frames, int n_channels);
+int awm_get_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, size_t n_clips, const float *const *pcm_d,
+                                    const size_t *n_frames, int n_channels, int n_threads, size_t max_out_per_clip,
+                                    awm_pattern *out, int *n_out);
+
 /* add_watermark core (wmadd.cc:448-618) on resident PCM: out_d gets n_frames*C samples */
 int awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex,
                          const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,

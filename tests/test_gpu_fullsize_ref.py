@@ -262,9 +262,23 @@ def test_config4_sample_of_64_clips_equal_reference(gpu):
         worst["pcm_max_abs"] = max(worst["pcm_max_abs"], m)
         for f in ("max_abs_sync_quality_diff", "max_abs_decode_error_diff"):
             worst[f] = max(worst[f], rep[f])
-        if k <= 16:
-            clips.append((d, ref_pats))
+        clips.append((d, ref_pats, gpu.dev(x), w, key))
     assert found >= 60                                                       # clip-decoder-test.sh expects the payload from a 30 s clip
+    # the batch entry points with ONE KEY PER CLIP (awm_add_watermark_batch_keys_d / awm_get_watermark_batch_keys_d: the key tables of
+    # a group travel in one copy and are indexed per clip inside the group's launches): all 64 clips in one call each -- the PCM of the
+    # single calls bit for bit, the reference's pattern lists clip by clip
+    keys = [c[4] for c in clips]
+    outs = gpu.ctx.add_watermark_batch_keys(keys, PAY1, [c[2] for c in clips])
+    for o, c in zip(outs, clips):
+        assert gpu.torch.equal(o, c[3])
+    batch_keys = gpu.ctx.get_watermark_batch_keys(keys, [c[0] for c in clips])
+    batch_ties = 0
+    for k, (b, c) in enumerate(zip(batch_keys, clips), start=1):
+        assert [pkey(p) for p in b] == [pkey(p) for p in gpu.ctx.get_watermark(c[4], c[0])], f"batch clip {k} differs from the single call"
+        batch_ties += compare_patterns(b, c[1], f"batch clip {k} (per-clip keys)")["refinement_ties"]
+    assert sum(any(p["bits"] == PAY1 for p in b) for b in batch_keys) >= 60
+    worst["batch_with_per_clip_keys"] = {"clips": len(clips), "equal_to_single_calls": True, "refinement_ties_vs_reference": batch_ties}
+    clips = clips[:16]
     # the batch entry point (one key for the whole batch): the same 16 clips decoded with key 1 -- clip 1 carries it, the others do not
     key1 = gpu.awm.test_key(1)
     batch = gpu.ctx.get_watermark_batch(key1, [c[0] for c in clips])
