@@ -933,7 +933,7 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
     ParamsBind bind (pv);
     const size_t gn = std::min (GROUP, n_clips - g0);
     std::vector<std::vector<int8_t>> tables (gn);
-    const size_t n_threads = std::max<size_t> (1, std::min<size_t> ({ gn, size_t (32), size_t (std::max (1u, std::thread::hardware_concurrency())) }));
+    const size_t n_threads = std::max<size_t> (1, std::min<size_t> ({ gn, size_t (64), size_t (std::max (1u, std::thread::hardware_concurrency())) }));
     std::atomic<size_t> next { 0 };
     auto work = [&] {
       ParamsBind b2 (pv);

@@ -1,5 +1,6 @@
 #include "random.hh"
 #include <cstring>
+#include <vector>
 #include "utils.hh"
 #include <cinttypes>
 #include <cstdio>
@@ -141,6 +142,18 @@ Key::load_key (const std::string& filename)
       error ("audiowmark: key file '%s' contains no key\n", filename.c_str());
       exit (1);
     }
+}
+
+const unsigned __int128 *
+Random::reciprocals()
+{
+  static const std::vector<unsigned __int128> table = [] {
+    std::vector<unsigned __int128> t (MAX_FAST_DIVISOR + 1, 0);
+    for (size_t d = 1; d <= MAX_FAST_DIVISOR; d++)
+      t[d] = ~(unsigned __int128) 0 / d + 1;
+    return t;
+  }();
+  return table.data();
 }
 
 Random::Random (const Key& key, uint64_t start_seed, Stream stream)

@@ -20,7 +20,7 @@ size_t mark_sync_frame_count() { return Params::sync_bits * Params::sync_frames_
 void
 UpDownGen::get (int f, UpDownArray& up, UpDownArray& down)
 {
-  std::vector<int> bands (Params::n_bands);
+  std::array<int, Params::n_bands> bands;
   for (int i = 0; i < Params::n_bands; i++)
     bands[i] = Params::min_band + i;
   m_random.seed (f, m_stream);            // per-frame seed
@@ -156,28 +156,44 @@ build_frame_mod_table (const Key& key, const std::vector<int>& payload_bits)
     row[up_band - Params::min_band]   = bit ? UP : DOWN;
     row[down_band - Params::min_band] = bit ? DOWN : UP;
   };
+  // what depends on the key alone is drawn once for both block types (A and B differ in the coded bits and the sync sequence only)
+  const int n_sync = int (mark_sync_frame_count()), n_data = mark_data_frame_count();
+  std::vector<UpDownArray> sync_up (n_sync), sync_down (n_sync);
+  {
+    UpDownGen sync_gen (key, Random::Stream::sync_up_down);
+    for (int f = 0; f < n_sync; f++)
+      sync_gen.get (f, sync_up[f], sync_down[f]);
+  }
+  std::vector<MixEntry> entries;
+  std::vector<UpDownArray> data_up, data_down;
+  if (params().mix)
+    entries = gen_mix_entries (key);
+  else
+    {
+      data_up.resize (n_data);
+      data_down.resize (n_data);
+      UpDownGen data_gen (key, Random::Stream::data_up_down);
+      for (int f = 0; f < n_data; f++)
+        data_gen.get (f, data_up[f], data_down[f]);
+    }
+  const std::vector<unsigned> order = bit_order (key, code_size (ConvBlockType::a, params().payload_size));
   for (int ab = 0; ab < 2; ab++)
     {
       int8_t *block = &table[ab * n_block * NB];
       const ConvBlockType block_type = ab ? ConvBlockType::b : ConvBlockType::a;
-      const std::vector<int> fec = randomize_bit_order (key, code_encode (block_type, payload_bits), /* encode */ true);
+      const std::vector<int> fec = apply_bit_order (order, code_encode (block_type, payload_bits), /* encode */ true);
 
       // sync frames: always linear; A carries 010101, B carries 101010
-      UpDownGen sync_gen (key, Random::Stream::sync_up_down);
-      for (int f = 0; f < int (mark_sync_frame_count()); f++)
+      for (int f = 0; f < n_sync; f++)
         {
           const int bit = (f / Params::sync_frames_per_bit + ab) & 1;
-          UpDownArray up, down;
-          sync_gen.get (f, up, down);
           int8_t *row = block + size_t (bit_pos_gen.sync_frame (f)) * NB;
-          for (size_t i = 0; i < up.size(); i++)
-            set_bands (row, up[i], down[i], bit);
+          for (size_t i = 0; i < sync_up[f].size(); i++)
+            set_bands (row, sync_up[f][i], sync_down[f][i], bit);
         }
       // data frames
-      const int n_data = mark_data_frame_count();
       if (params().mix)
         {
-          const auto entries = gen_mix_entries (key);
           for (int f = 0; f < n_data; f++)
             for (size_t j = 0; j < Params::bands_per_frame; j++)
               {
@@ -187,14 +203,11 @@ build_frame_mod_table (const Key& key, const std::vector<int>& payload_bits)
         }
       else
         {
-          UpDownGen data_gen (key, Random::Stream::data_up_down);
           for (int f = 0; f < n_data; f++)
             {
-              UpDownArray up, down;
-              data_gen.get (f, up, down);
               int8_t *row = block + size_t (bit_pos_gen.data_frame (f)) * NB;
-              for (size_t i = 0; i < up.size(); i++)
-                set_bands (row, up[i], down[i], fec[f / params().frames_per_bit]);
+              for (size_t i = 0; i < data_up[f].size(); i++)
+                set_bands (row, data_up[f][i], data_down[f][i], fec[f / params().frames_per_bit]);
             }
         }
     }
@@ -220,20 +233,27 @@ build_sync_table (const Key& key, bool clip_mode)
           const int sf = f + bit * Params::sync_frames_per_bit;
           UpDownArray up, down;
           sync_gen.get (sf, up, down);
+          // band indices minus min_band, ascending (the reference sorts them, syncfinder.cc:52-53): the 30 bands of a list are
+          // distinct members of 0..80, so marking and scanning does it
+          auto ascending = [] (const UpDownArray& bands) {
+            std::array<uint8_t, Params::n_bands> member {};
+            for (int b : bands)
+              member[b - Params::min_band] = 1;
+            std::array<uint8_t, 30> out {};
+            int n = 0;
+            for (int b = 0; b < Params::n_bands && n < 30; b++)
+              if (member[b])
+                out[n++] = uint8_t (b);
+            return out;
+          };
+          const std::array<uint8_t, 30> up_sorted = ascending (up), down_sorted = ascending (down);
           for (int block = 0; block < n_blocks; block++)
             {
               Row r;
               r.frame = bit_pos_gen.sync_frame (sf) + block * block_frames;
               // the second block of a CLIP (AB) pattern carries the inverted sync sequence
-              const UpDownArray& u = block == 0 ? up : down;
-              const UpDownArray& d = block == 0 ? down : up;
-              for (int i = 0; i < 30; i++)
-                {
-                  r.up[i]   = uint8_t (u[i] - Params::min_band);
-                  r.down[i] = uint8_t (d[i] - Params::min_band);
-                }
-              std::sort (r.up.begin(), r.up.end());
-              std::sort (r.down.begin(), r.down.end());
+              r.up = block == 0 ? up_sorted : down_sorted;
+              r.down = block == 0 ? down_sorted : up_sorted;
               rows.push_back (r);
             }
         }

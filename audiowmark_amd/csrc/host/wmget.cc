@@ -1098,7 +1098,7 @@ clip_is_short (const DeviceWav& w)
 /* The key tables of a group of clips with ONE KEY PER CLIP: built on host threads (2226 up / down draws, three shuffles per key:
  * ~3 ms of one core), packed into one page-locked block, one copy to the device; `kt` then describes the group (KeyTables::slices). */
 namespace {
-constexpr int TABLE_THREADS = 32;
+constexpr int TABLE_THREADS = 64;
 size_t align256 (size_t n) { return (n + 255) & ~size_t (255); }
 
 std::vector<ClipKeyHost>
