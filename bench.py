@@ -44,11 +44,23 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 PAYLOAD = "0123456789abcdef0011223344556677"
 RATE = 44100
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8 TB/s spec
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+
+
+def newest_profile_dir():
+    """profiles/rNN with the highest NN that holds a traffic.json (the PMC passes of tools/profile_bench.sh)"""
+    base = os.path.join(ROOT, "profiles")
+    best = None
+    for d in sorted(os.listdir(base)) if os.path.isdir(base) else []:
+        if d.startswith("r") and d[1:].isdigit() and os.path.exists(os.path.join(base, d, "traffic.json")):
+            best = os.path.join(base, d)
+    return best
+
+
+PROFILE_DIR = newest_profile_dir()
 
 # HIP-event scope (awm_prof_name) -> (device kernel in the rocprofv3 summaries, what actually limits it)
 KERNELS = {
-    "add_mix_kernel": ("add_mix_kernel_w3<2>", "HBM <-> FP32 issue (3 300 VALU instructions per stereo frame, 3 waves / SIMD)"),
+    "add_mix_kernel": ("add_mix_kernel_w3<2>", "HBM <-> FP32 issue (1 450 VALU instructions per stereo frame, 3 waves / SIMD, next frame prefetched); the chip runs it at its power budget"),
     "limiter_kernel": ("limiter_apply_kernel<2>", "HBM"),
     "sync_db_kernel(approx)": ("sync_db_kernel<2, false, 33>", "FP32 issue (the 4 shifts of a tile share one XCD's L2: PCM read once)"),
     "sync_scan_kernel(approx)": ("sync_scan_stream_kernel<false>", "LDS gathers (ds_read_b128, 256 B/clk/CU) in the reference's summation order"),
@@ -57,7 +69,7 @@ KERNELS = {
     "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (150 workgroups)"),
     "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue"),
     "soft_bits_kernel": ("soft_bits_wave_kernel", "L2 sectors of scattered reads"),
-    "viterbi_kernel": ("viterbi_round_kernel<4, true>", "36 dependent launches per batch of decodes (launch bound); per launch: one chain of `rate` float additions per successor pair, 4 steps in registers"),
+    "viterbi_kernel": ("viterbi_super_kernel<0>", "16 dependent launches per batch of decodes (11 of them carry 12 trellis steps: three rounds of 4 steps in registers, the metrics change hands through LDS in between)"),
 }
 
 
@@ -65,7 +77,7 @@ def pmc_traffic(prof_name, minutes):
     """HBM bytes per launch of the kernel behind a profiling scope: FETCH_SIZE (x2, gfx950 calibration) + WRITE_SIZE from the
     separate rocprofv3 --pmc passes of this very command (tools/pmc_traffic.py -> profiles/r02/traffic.json; counters cannot be
     read from inside the process).  None if the summary is not there or was taken for another workload."""
-    if minutes != 60.0:
+    if minutes != 60.0 or not PROFILE_DIR:
         return None
     try:
         with open(os.path.join(PROFILE_DIR, "traffic.json")) as f:
@@ -74,6 +86,17 @@ def pmc_traffic(prof_name, minutes):
         return int(e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"])
     except Exception:
         return None
+
+
+def traffic_provenance():
+    """which profile directory roofline.traffic comes from and the commit its PMC passes were taken at (profiles/rNN/COMMIT)"""
+    if not PROFILE_DIR:
+        return None
+    try:
+        commit = open(os.path.join(PROFILE_DIR, "COMMIT")).read().strip()
+    except Exception:
+        commit = None
+    return {"profile_dir": os.path.relpath(PROFILE_DIR, ROOT), "traffic_from_commit": commit}
 
 
 def quantise16(np, x):
@@ -547,6 +570,7 @@ def main():
             "data": "synthetic",
             "config": cfg,
             "roofline": roofline,
+            "traffic_source": traffic_provenance(),
         }
         if serial:
             am = serial.get("add_mix_kernel")
