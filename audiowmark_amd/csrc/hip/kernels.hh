@@ -45,6 +45,7 @@ struct AddMixArgs
   int          delta_only = 0;    // 1: write the watermark signal alone (out = d W..., without "+ in"): WatermarkGen::run for the resampled path
 };
 hipError_t launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a);
+int        add_mix_waves_per_simd();     // occupancy the stereo kernel is built for (sizes the spans: one round of resident waves)
 
 /* K3: limiter ramp, in place */
 hipError_t launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels, long long first_sample,

@@ -312,24 +312,6 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
       }
     return src;
   };
-  // Software pipelining (stereo kernel): the samples of frame m + 1 are requested before frame m is transformed, so that the
-  // ~1 us of HBM latency runs beside ~3.5 us of arithmetic of the SAME wave -- with three waves per SIMD there is not always
-  // another wave to switch to (after the band edit went to the native log2 / exp2 the kernel issued VALU only 70 % of the time).
-  // 32 more live registers; still three waves per SIMD.
-  float nxt[CV][16];
-  int nxt_avail = 0;
-  if (OPAQUE)
-    {
-      const float *src0 = frame_source (s - 1, nxt_avail);
-      if (nxt_avail > 0)
-        {
-          if constexpr (CV == 2)
-            fetch_stereo (src0, 0, nxt_avail, lane, nxt[0], nxt[1]);
-          else
-            fetch_channel (src0, 0, nxt_avail, C, ch0, lane, nxt[0]);
-        }
-    }
-
   for (long long m = s - 1; m <= e; m++)
     {
       if (OPAQUE)
@@ -343,37 +325,12 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
       const float *src = frame_source (m, avail);
       float in[CV][16];
       float2 d[CV][8];
-      if (OPAQUE)
-        {
-          // take the prefetched frame, request the next one
-          avail = nxt_avail;
-#pragma unroll
-          for (int c = 0; c < CV; c++)
-#pragma unroll
-            for (int j = 0; j < 16; j++)
-              in[c][j] = nxt[c][j];
-          nxt_avail = 0;
-          if (m < e)
-            {
-              const float *src1 = frame_source (m + 1, nxt_avail);
-              if (nxt_avail > 0)
-                {
-                  if constexpr (CV == 2)
-                    fetch_stereo (src1, 0, nxt_avail, lane0, nxt[0], nxt[1]);
-                  else
-                    fetch_channel (src1, 0, nxt_avail, C, ch0, lane0, nxt[0]);
-                }
-            }
-        }
       if (avail > 0)
         {
-          if (!OPAQUE)
-            {
-              if constexpr (CV == 2)
-                fetch_stereo (src, 0, avail, lane, in[0], in[1]);
-              else
-                fetch_channel (src, 0, avail, C, ch0, lane, in[0]);
-            }
+          if constexpr (CV == 2)
+            fetch_stereo (src, 0, avail, lane, in[0], in[1]);
+          else
+            fetch_channel (src, 0, avail, C, ch0, lane, in[0]);
           const long long g = a.first_frame + m;                       // frame index in the whole stream
           const long long row = (frame_number0 + g) % total_rows;      // reference wmadd.cc:326-344
           const int8_t *mod_row = a.frame_mod + row * NB;
@@ -581,11 +538,14 @@ add_mix_kernel (DevTables t, AddMixArgs a, long long frame_number0, int block_fr
 {
   add_mix_body<CV, false> (t, a, frame_number0, block_frames);
 }
-template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
-add_mix_kernel_w3 (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
+// stereo: four waves per SIMD (122 registers, 39 KB of LDS per workgroup: four workgroups per CU)
+template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+add_mix_kernel_w4 (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
 {
   add_mix_body<CV, true> (t, a, frame_number0, block_frames);
 }
+int add_mix_waves_per_simd() { return 4; }
+
 hipError_t
 launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
 {
@@ -598,9 +558,9 @@ launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
   const unsigned grid = unsigned ((items + WAVES - 1) / WAVES);
   const int block_frames = a.block_frames;
   const long long frame_number0 = 2LL * block_frames - a.frames_pad_start;       // reference wmadd.cc:293-294
-  // stereo: both channels in one wave, held at 3 waves per SIMD (measured fastest: 0.72 vs 0.87 ms for 60 min)
+  // stereo: both channels in one wave, four waves per SIMD (122 registers; three waves + prefetch of the next frame: 3 - 5 % slower)
   if (stereo)
-    hipLaunchKernelGGL (add_mix_kernel_w3<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
+    hipLaunchKernelGGL (add_mix_kernel_w4<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
   else
     hipLaunchKernelGGL (add_mix_kernel<1>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
   return hipGetLastError();
@@ -1559,6 +1519,249 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
     a.have[out_slot * a.have_stream_stride + 64] = have_64;
 }
 
+/* K4s for stereo with all but 8 lanes at work: a lane carries THREE adjacent bins of ONE channel (lanes 0..27: channel 0, bins
+ * 19 + 3 l .. 21 + 3 l; lanes 28..55: channel 1) instead of two bins of both channels on 42 lanes -- 3 (bin, channel) pairs per lane
+ * instead of 4 for the same 168 pairs: a quarter fewer FP64 instructions per fine offset and wave (the kernel is bound by VALU
+ * issue).  The Hann neighbours of the inner bin are in the lane itself, the outer ones come from the adjacent lanes as before
+ * (at the seam between the channels the neighbours are wrong, but only for bins 19 and 102, which are neighbours themselves and
+ * never output).  The channels' dB values meet in the LDS tile ([offset][channel][band]) and are added when the tile is flushed:
+ * 0 + db0 + db1 in the reference's order.  Everything else -- first transform in double, recurrence in double, non-zero sample
+ * counts, skip rules, output layout -- is sync_db_sliding_kernel's. */
+__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
+sync_db_sliding3_kernel (DevTables t, SyncDbArgs a)
+{
+  constexpr int CV = 2, LPC = 28;                             // lanes per channel
+  constexpr int TILE_FLOATS = 2 * NB * SL_TILE;
+  constexpr int SCRATCH_FLOATS = XBUF_ELEMS * 4 > TILE_FLOATS ? XBUF_ELEMS * 4 : TILE_FLOATS;
+  __shared__ __attribute__ ((aligned (16))) float s_scratch[WAVES][SCRATCH_FLOATS];    // FFT exchange tile (576 double2) / dB tile [offset][channel][band]
+  __shared__ unsigned char s_pos[WAVES][NB + 3];
+  __shared__ __attribute__ ((aligned (16))) double s_delta[WAVES][SL_TILE * 8 * CV];
+  __shared__ int s_nzd[WAVES][SL_TILE * CV];
+  __shared__ int s_x0[WAVES][SL_TILE * CV];
+  {
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    const long long s = (long long) blockIdx.x * WAVES + w;
+    const long long tslice = (a.tables_per_slice && s < a.n_streams) ? (a.range_index ? a.range_index[s / a.range_div] : s / a.range_div) : 0;
+    for (int b = l; b < NB; b += 64)
+      s_pos[w][b] = (a.band_pos && s < a.n_streams) ? a.band_pos[(tslice * a.rows_per_plane + s % a.rows_per_plane) * NB + b] : (unsigned char) b;
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long stream = (long long) blockIdx.x * WAVES + wave;
+  if (stream >= a.n_streams)
+    return;
+  const long long perm_slice = a.tables_per_slice ? (a.range_index ? a.range_index[stream / a.range_div] : stream / a.range_div) : 0;
+  const long long out_slot = wave_uniform (a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane
+                                                        + a.row_perm[perm_slice * a.rows_per_plane + stream % a.rows_per_plane] : stream);
+  const long long base = wave_uniform (sync_stream_base (a, stream));
+  const int count = __builtin_amdgcn_readfirstlane (a.stream_count ? a.stream_count[stream] : a.count0);
+  if (count <= 0)
+    return;
+  long long sil_first, sil_last;
+  sync_stream_range (a, stream, sil_first, sil_last);
+  sil_first = wave_uniform (sil_first);
+  sil_last = wave_uniform (sil_last);
+  if (a.have && ((base + 8LL * (count - 1) + 1024) * CV < sil_first || base * CV > sil_last))
+    {
+      if (lane < count)
+        a.have[out_slot * a.have_stream_stride + lane] = 0;
+      if (lane == 0 && count > 64)
+        a.have[out_slot * a.have_stream_stride + 64] = 0;
+      return;
+    }
+  double2 *xbuf = reinterpret_cast<double2 *> (s_scratch[wave]);
+  float *tile = s_scratch[wave];
+  const bool active = lane < 2 * LPC;
+  const int ch = lane >= LPC ? 1 : 0;                         // (idle lanes ride along as channel 1, bins of lane 0)
+  const int li = active ? lane - LPC * ch : 0;
+  const int kA = 19 + 3 * li;
+
+  // ---- first offset: plain (unwindowed) DFT bins from the wave FFT, in double (see sync_db_sliding_kernel)
+  double2 R[3];
+  int nz0 = 0, nz1 = 0;                                        // non-zero samples of the current window, per channel (wave uniform)
+#pragma unroll
+  for (int c = 0; c < CV; c++)
+    {
+      float in[16];
+      fetch_channel (a.pcm, base, 1024, CV, c, lane, in);
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        cnt += in[j] != 0.f;
+      for (int o = 32; o > 0; o >>= 1)
+        cnt += __shfl_xor (cnt, o);
+      (c == 0 ? nz0 : nz1) = __builtin_amdgcn_readfirstlane (cnt);
+      double2 z[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        z[j] = make_double2 (double (in[2 * j]), double (in[2 * j + 1]));
+      fft512_forward_d (z, xbuf, t.tw512d, lane);
+      xbuf[0 * 64 + lane] = z[0];
+      xbuf[1 * 64 + lane] = z[1];
+      xbuf[6 * 64 + lane] = z[6];
+      xbuf[7 * 64 + lane] = z[7];
+      wave_sync();
+      if (ch == c)
+        {
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            {
+              const int k = kA + b;
+              R[b] = real_split_d (xbuf[zpos (k)], xbuf[zpos (512 - k)], t.slide[(k - 19) * 9 + 1]);
+            }
+        }
+      wave_sync();
+    }
+  double2 tw[3][8];                                           // e^{-2 pi i k j / N}, j = 1..7, then e^{+2 pi i 8 k / N}
+  int k_tab = kA - 19;
+  asm volatile ("" : "+v" (k_tab));                           // keep these 96 registers out of the FFT above (no hoisting)
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+      tw[b][j] = t.slide[(k_tab + b) * 9 + j + 1];
+
+  constexpr int FPL = 2 * CV;
+  float f_in[FPL], f_out[FPL];
+  auto fetch_block = [&] (int q) {
+    const long long s0 = base + 128LL * q;
+#pragma unroll
+    for (int i = 0; i < FPL; i++)
+      {
+        const int e = lane * FPL + i;                             // (transition * 8 + j) * C + c
+        const int trans = SL_TILE * q + e / (8 * CV);
+        const bool need = trans + 1 < count;
+        f_in[i] = need ? a.pcm[(s0 + 1024) * CV + e] : 0.f;
+        f_out[i] = trans < count ? a.pcm[s0 * CV + e] : 0.f;
+      }
+  };
+  auto publish_block = [&] () {
+#pragma unroll
+    for (int i = 0; i < FPL; i++)
+      s_delta[wave][lane * FPL + i] = double (f_in[i]) - double (f_out[i]);
+#pragma unroll
+    for (int c = 0; c < CV; c++)
+      {
+        int dn = (f_in[c] != 0.f) - (f_out[c] != 0.f) + (f_in[CV + c] != 0.f) - (f_out[CV + c] != 0.f);
+        dn += __shfl_xor (dn, 1);
+        dn += __shfl_xor (dn, 2);
+        if ((lane & 3) == 0)
+          {
+            s_nzd[wave][(lane >> 2) * CV + c] = dn;
+            s_x0[wave][(lane >> 2) * CV + c] = f_out[c] != 0.f;
+          }
+      }
+  };
+  fetch_block (0);
+  unsigned long long have_mask = 0;
+  bool have_64 = false;
+
+  for (int step = 0; step < count; step++)
+    {
+      if (step % SL_TILE == 0)
+        {
+          publish_block();
+          wave_sync();
+          fetch_block (step / SL_TILE + 1);
+        }
+      const long long idx = base + 8LL * step;
+      const long long f_first = idx * CV, f_last = (idx + 1024) * CV;
+      const bool skip = (f_last < sil_first) || (f_first > sil_last);
+      const int col = step % SL_TILE;
+      float db[3] = { 0.f, 0.f, 0.f };
+      if (!skip)
+        {
+          if (step < 64)
+            have_mask |= 1ULL << step;
+          else
+            have_64 = true;
+          // every sample that carries weight is zero (position 0 has none): exactly zero frame in the reference (-96 dB per band)
+          const int x0_0 = __builtin_amdgcn_readfirstlane (s_x0[wave][col * CV + 0]), x0_1 = __builtin_amdgcn_readfirstlane (s_x0[wave][col * CV + 1]);
+          const bool zero_frame = ch ? (nz1 - x0_1 == 0) : (nz0 - x0_0 == 0);
+          // neighbours of the outer bins: R[kA - 1] is the third bin of lane - 1, R[kC + 1] the first bin of lane + 1
+          const double2 up = make_double2 (dpp_from_lower_lane (R[2].x), dpp_from_lower_lane (R[2].y));
+          const double2 dn = make_double2 (dpp_from_upper_lane (R[0].x), dpp_from_upper_lane (R[0].y));
+          // X[k] = (2 R[k] - (R[k-1] + R[k+1])) / 1024 (see sync_db_sliding_kernel)
+          const float xa_re = float (fma (2.0, R[0].x, -(up.x + R[1].x))) * 0x1p-10f;
+          const float xa_im = float (fma (2.0, R[0].y, -(up.y + R[1].y))) * 0x1p-10f;
+          const float xb_re = float (fma (2.0, R[1].x, -(R[0].x + R[2].x))) * 0x1p-10f;
+          const float xb_im = float (fma (2.0, R[1].y, -(R[0].y + R[2].y))) * 0x1p-10f;
+          const float xc_re = float (fma (2.0, R[2].x, -(R[1].x + dn.x))) * 0x1p-10f;
+          const float xc_im = float (fma (2.0, R[2].y, -(R[1].y + dn.y))) * 0x1p-10f;
+          db[0] = zero_frame ? -96.f : db_from_complex (make_float2 (xa_re, xa_im));
+          db[1] = zero_frame ? -96.f : db_from_complex (make_float2 (xb_re, xb_im));
+          db[2] = zero_frame ? -96.f : db_from_complex (make_float2 (xc_re, xc_im));
+        }
+      if (active)
+        {
+          // [offset][channel][band], row length 2 x 81 = 162: the 56 writing lanes hit 56 different banks per store
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            {
+              const int band = kA + b - MIN_BAND;                         // -1 .. 82
+              if (band >= 0 && band < NB)
+                tile[(col * 2 + ch) * NB + band] = db[b];
+            }
+        }
+      if (col == SL_TILE - 1 || step == count - 1)
+        {
+          wave_sync();
+          const int t0 = step - col, n_cols = col + 1;
+          float *out = a.out + out_slot * a.out_stream_stride + t0;
+          for (int i = lane; i < NB * SL_TILE; i += 64)
+            {
+              const int band = i / SL_TILE, cc = i % SL_TILE;
+              const int row = s_pos[wave][band];
+              if (cc < n_cols && row != 255)
+                out[row * a.ld + cc] = __fadd_rn (__fadd_rn (0.f, tile[(cc * 2 + 0) * NB + band]), tile[(cc * 2 + 1) * NB + band]);
+            }
+          wave_sync();
+        }
+      // ---- advance by 8 samples
+      if (step + 1 < count)
+        {
+          const double *dl = s_delta[wave] + col * 8 * CV + ch;
+          double2 acc[3] = { R[0], R[1], R[2] };
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            {
+              const double d = dl[j * CV];
+#pragma unroll
+              for (int b = 0; b < 3; b++)
+                {
+                  if (j == 0)
+                    acc[b].x = acc[b].x + d;
+                  else
+                    {
+                      acc[b].x = fma (d, tw[b][j - 1].x, acc[b].x);
+                      acc[b].y = fma (d, tw[b][j - 1].y, acc[b].y);
+                    }
+                }
+            }
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            {
+              const double2 r = tw[b][7];
+              R[b] = make_double2 (acc[b].x * r.x - acc[b].y * r.y, acc[b].x * r.y + acc[b].y * r.x);
+            }
+          nz0 += __builtin_amdgcn_readfirstlane (s_nzd[wave][col * CV + 0]);
+          nz1 += __builtin_amdgcn_readfirstlane (s_nzd[wave][col * CV + 1]);
+          if ((ch ? nz1 : nz0) == 0)
+            R[0] = R[1] = R[2] = make_double2 (0.0, 0.0);
+        }
+      if (col == SL_TILE - 1)
+        wave_sync();
+    }
+  if (a.have && lane < count)
+    a.have[out_slot * a.have_stream_stride + lane] = (have_mask >> lane) & 1;
+  if (a.have && lane == 0 && count > 64)
+    a.have[out_slot * a.have_stream_stride + 64] = have_64;
+}
+
+int g_sliding3 = 1;          // (debug toggle: the three-bins-per-lane stereo kernel)
+extern "C" void awm_debug_set_sliding3 (int on) { g_sliding3 = on; }
+
 hipError_t
 launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
 {
@@ -1567,7 +1770,9 @@ launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
   if (a.hop != 8 || a.count0 > 65 || a.per_channel || (a.n_channels != 1 && a.n_channels != 2))
     return hipErrorInvalidValue;
   const unsigned grid = unsigned ((a.n_streams + WAVES - 1) / WAVES);
-  if (a.n_channels == 2)
+  if (a.n_channels == 2 && g_sliding3)
+    hipLaunchKernelGGL (sync_db_sliding3_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
+  else if (a.n_channels == 2)
     hipLaunchKernelGGL (sync_db_sliding_kernel<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
   else
     hipLaunchKernelGGL (sync_db_sliding_kernel<1>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
@@ -1997,7 +2202,7 @@ nonzero_range_kernel (const float *data, long long n_values, unsigned long long 
 __global__ void __launch_bounds__ (256)
 soft_prep_kernel (SoftPrepArgs a)
 {
-  __shared__ float  s_v[1728];
+  __shared__ __attribute__ ((aligned (16))) float s_v[1728];
   __shared__ double s_mean;
   const SoftJobDev job = a.jobs[blockIdx.x];
   const int2 *src = a.src + job.src_off;
@@ -2050,8 +2255,26 @@ soft_prep_kernel (SoftPrepArgs a)
     }
   if (threadIdx.x == 0)
     {
+      // front to back, one addition after the other (the order is the reference's); the VALUES come 32 at a time, so that the chain
+      // waits for the adder and not for one LDS round trip per term
       double mean = 0;
-      for (int k = 0; k < job.len; k++)
+      int k = 0;
+      for (; k + 32 <= job.len; k += 32)
+        {
+          float4 q[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+            q[i] = reinterpret_cast<const float4 *> (s_v + k)[i];
+#pragma unroll
+          for (int i = 0; i < 8; i++)
+            {
+              mean = __dadd_rn (mean, double (fabsf (q[i].x)));
+              mean = __dadd_rn (mean, double (fabsf (q[i].y)));
+              mean = __dadd_rn (mean, double (fabsf (q[i].z)));
+              mean = __dadd_rn (mean, double (fabsf (q[i].w)));
+            }
+        }
+      for (; k < job.len; k++)
         mean = __dadd_rn (mean, double (fabsf (s_v[k])));
       s_mean = __ddiv_rn (mean, double (job.len));
     }

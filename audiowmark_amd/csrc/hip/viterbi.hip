@@ -292,13 +292,20 @@ constexpr int SUPER_LDS = 16 * 324;
 
 template<int BT, int NPF> __device__ __forceinline__ void
 viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_out, unsigned int *dec, const size_t (&dec_off)[3],
-                     int g, int lane, float *lds_a, float *lds_b)
+                     int g, int lane, float *lds_a, float *lds_b, bool in_perm, bool out_perm)
 {
+  /* Metric layout between two of these launches: PERMUTED, state s at (s & 7) * 4096 + (s >> 3) -- the family a workgroup reads
+   * (states with the low bits g) is then one contiguous 16 KB block, a wave's 64 loads one 256-byte run; in the natural layout
+   * they are 32 bytes apart, and as the producers ran on other XCDs (L2s are not shared) every launch fetched its 4.7 MB of metrics
+   * as 41 MB of sectors from memory (PMC FETCH_SIZE).  The 16 consecutive states a lane produces scatter over the 8 families in
+   * pairs (loc, loc + 8: adjacent places of family loc & 7): eight 8-byte stores per lane, 512 contiguous bytes per wave each.
+   * The first launch reads what viterbi_init wrote (state 0 at index 0 in either layout), the last one writes the natural layout
+   * for the single rounds and the trace back that follow. */
   float m[16];
   const int L1 = (lane << 3) | g;
 #pragma unroll
   for (int j = 0; j < 16; j++)
-    m[j] = m_in[L1 + j * 2048];
+    m[j] = in_perm ? m_in[g * 4096 + ((j << 8) | lane)] : m_in[L1 + j * 2048];
   const int hi = lane >> 4, lo = lane & 15;
 #pragma unroll
   for (int r = 0; r < 3; r++)
@@ -326,13 +333,20 @@ viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_
             }
         }
     }
+  if (out_perm)
+    {
+#pragma unroll
+      for (int f = 0; f < 8; f++)
+        *reinterpret_cast<float2 *> (m_out + f * 4096 + (g << 9) + (lane << 1)) = make_float2 (m[f], m[f + 8]);
+      return;
+    }
   float4 *out4 = reinterpret_cast<float4 *> (m_out + (size_t) ((g << 8) | lane) * 16);
 #pragma unroll
   for (int q = 0; q < 4; q++)
     out4[q] = make_float4 (m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
 }
 
-struct SuperOffsets { size_t off[3]; };
+struct SuperOffsets { size_t off[3]; int in_perm, out_perm; };
 
 template<int NPF> __global__ void __launch_bounds__ (V_WG)
 viterbi_super_kernel (ViterbiBatch b, int step0, int parity_in, SuperOffsets so)
@@ -351,18 +365,18 @@ viterbi_super_kernel (ViterbiBatch b, int step0, int parity_in, SuperOffsets so)
   const bool finite = coded[0] == coded[0];              // (see viterbi_round_kernel)
   if (t == 0)
     {
-      if (finite) viterbi_super_round<0, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
-      else        viterbi_super_round<0, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+      if (finite) viterbi_super_round<0, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
+      else        viterbi_super_round<0, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
     }
   else if (t == 1)
     {
-      if (finite) viterbi_super_round<1, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
-      else        viterbi_super_round<1, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+      if (finite) viterbi_super_round<1, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
+      else        viterbi_super_round<1, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
     }
   else
     {
-      if (finite) viterbi_super_round<2, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
-      else        viterbi_super_round<2, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b);
+      if (finite) viterbi_super_round<2, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
+      else        viterbi_super_round<2, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
     }
 }
 
@@ -510,7 +524,9 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
           int npf = 0;
           for (int q = 0; q < 3; q++)
             npf += rounds[r + q].step0 < V_ORDER;
-          const SuperOffsets so { { rounds[r].dec_offset, rounds[r + 1].dec_offset, rounds[r + 2].dec_offset } };
+          // (permuted metric layout between consecutive launches of this kind; the init kernel's output reads the same either way)
+          const bool next_is_super = r + 5 < rounds.size() && rounds[r + 3].k == V_K && rounds[r + 4].k == V_K && rounds[r + 5].k == V_K;
+          const SuperOffsets so { { rounds[r].dec_offset, rounds[r + 1].dec_offset, rounds[r + 2].dec_offset }, r > 0, next_is_super };
           const dim3 grid (8, (unsigned) total);
           if (npf == 0)
             hipLaunchKernelGGL ((viterbi_super_kernel<0>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, so);

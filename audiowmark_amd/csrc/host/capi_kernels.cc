@@ -58,15 +58,15 @@ frames_per_span (awm_ctx *ctx, long long n_frames1024)
   // Every wave streams through L frames plus 2 halo frames.  All waves of one "round" (CUs x resident waves) start
   // and finish together, so pick the number of rounds k that minimises k * (L + 2) with L = ceil (F / (k * capacity)):
   // long spans amortise the halo, whole rounds avoid a half-empty tail.
-  static int capacity = 0;
-  if (!capacity)
+  static int cus = 0;
+  if (!cus)
     {
       hipDeviceProp_t prop;
-      int cus = 256;
+      cus = 256;
       if (hipGetDeviceProperties (&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0)
         cus = prop.multiProcessorCount;
-      capacity = cus * 12;                     // add_mix_kernel runs 3 waves per SIMD
     }
+  const int capacity = cus * 4 * awmk::add_mix_waves_per_simd();       // resident waves of the fused add kernel
   long long best_l = 4, best_cost = -1;
   for (int k = 1; k <= 16; k++)
     {

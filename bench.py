@@ -60,7 +60,7 @@ PROFILE_DIR = newest_profile_dir()
 
 # HIP-event scope (awm_prof_name) -> (device kernel in the rocprofv3 summaries, what actually limits it)
 KERNELS = {
-    "add_mix_kernel": ("add_mix_kernel_w3<2>", "HBM <-> FP32 issue (1 450 VALU instructions per stereo frame, 3 waves / SIMD, next frame prefetched); the chip runs it at its power budget"),
+    "add_mix_kernel": ("add_mix_kernel_w4<2>", "HBM <-> FP32 issue (1 450 VALU instructions per stereo frame, 4 waves / SIMD)"),
     "limiter_kernel": ("limiter_apply_kernel<2>", "HBM"),
     "sync_db_kernel(approx)": ("sync_db_kernel<2, false, 33>", "FP32 issue (the 4 shifts of a tile share one XCD's L2: PCM read once)"),
     "sync_scan_kernel(approx)": ("sync_scan_stream_kernel<false>", "LDS gathers (ds_read_b128, 256 B/clk/CU) in the reference's summation order"),

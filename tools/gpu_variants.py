@@ -1,0 +1,48 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+"""A / B of kernel variants behind debug toggles: K4s (2 bins x 2
+channels on 42 lanes | 3 bins x 1 channel on 56 lanes); per-kernel times from the HIP events of a one-lane pass, results compared"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import audiowmark_amd as awm
+ctx = awm.Context(0)
+g = torch.Generator(device="cuda"); g.manual_seed(7)
+x = torch.rand((60 * 60 * 44100, 2), generator=g, device="cuda") * 2 - 1
+out = torch.empty_like(x)
+P = "0123456789abcdef0011223344556677"
+awm.lib.awm_prof_name.restype = C.c_char_p
+
+def prof(fn, steps=5):
+    for _ in range(2): fn()
+    torch.cuda.synchronize()
+    awm.lib.awm_prof_reset(ctx._h); awm.lib.awm_prof_enable(ctx._h, 1)
+    for _ in range(steps): r = fn()
+    torch.cuda.synchronize()
+    awm.lib.awm_prof_enable(ctx._h, 0)
+    res = {}
+    for i in range(awm.lib.awm_prof_count()):
+        ms, n, b = C.c_double(), C.c_long(), C.c_double()
+        awm.lib.awm_prof_read(ctx._h, i, C.byref(ms), C.byref(n), C.byref(b))
+        if n.value: res[awm.lib.awm_prof_name(i).decode()] = ms.value / steps
+    return r, res
+
+ctx.add_watermark(None, P, x, out=out)
+ref = out.clone()
+awm.lib.awm_ctx_set_chunk_lanes(ctx._h, 1)
+first = None
+for v in (1, 0):
+    awm.lib.awm_debug_set_sliding3(v)
+    pats, r = prof(lambda: ctx.get_watermark(None, ref), 3)
+    k = [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"]) for p in pats]
+    if first is None: first = k
+    dq = max(abs(a[4] - b[4]) for a, b in zip(k, first)) if len(k) == len(first) else -1
+    print("K4s variant %d: refine db %.4f ms  refine scan %.4f  viterbi %.4f  patterns %d  positions equal %s  max |dq| %.3g" % (v, r["sync_db_kernel(refine)"], r["sync_scan_kernel(refine)"],
+          r["viterbi_kernel"], len(k), [a[:4] for a in k] == [a[:4] for a in first], dq))
+awm.lib.awm_debug_set_sliding3(1)
+base = None
+for v in (1, 0, 1):
+    awm.lib.awm_debug_set_viterbi_super(v)
+    pats, r = prof(lambda: ctx.get_watermark(None, ref), 3)
+    k = [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["decode_error"]) for p in pats]
+    if base is None: base = k
+    print("viterbi super %d: viterbi %.4f ms per step  equal to first: %s" % (v, r["viterbi_kernel"], k == base))
