@@ -48,4 +48,7 @@ int decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::ve
 /* AB pairing and "all" pattern of BlockDecoder::run (reference wmget.cc:554-701) for the blocks of one chunk */
 void combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const DeviceWav& wav, size_t chunk, std::vector<PendingDecode>& pending);
 
+int decode_chunks_blocks_only (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
+                               std::vector<ResultSet>& chunk_sets, std::string *debug_sync_first);
+
 } // namespace awm

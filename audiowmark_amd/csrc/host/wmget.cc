@@ -1050,6 +1050,20 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
   return 0;
 }
 
+/* the BlockDecoder alone for chunks of one resident buffer (the multi-GPU protocol decodes the chunks that lie completely inside a
+ * rank's span this way: plain path, chunks on concurrent lanes) */
+int
+decode_chunks_blocks_only (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
+                           std::vector<ResultSet>& chunk_sets, std::string *debug_sync_first)
+{
+  chunk_sets.clear();
+  chunk_sets.resize (chunks.size());
+  std::vector<ResultSet *> ptrs;
+  for (auto& cs : chunk_sets)
+    ptrs.push_back (&cs);
+  return block_decoder_run (ctx, ctx, true, key_list, wav, chunks, ptrs, 1, debug_sync_first);
+}
+
 int
 decode_chunks (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
                bool first_is_stream_start, std::vector<ResultSet>& chunk_sets)

@@ -426,6 +426,7 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
   }
 
   /* ---- my chunks ---- */
+  std::vector<size_t> local_chunks;
   std::vector<ChunkWork> work;
   size_t q_total = 0;
   for (size_t c = 0; c < plan.chunks.size(); c++)
@@ -452,6 +453,14 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
           w.me = int (i);
       if (w.me < 0)
         continue;
+      // a chunk that lies completely inside my span is mine alone and needs nothing from anybody: it takes the plain path below
+      // (chunks on concurrent lanes, every stage of one chunk overlapping the others' -- the phases here end when ALL chunks of a rank
+      // are through them)
+      if (w.ranks.size() == 1 && plan.chunks[c].first_frame >= my_lo && plan.chunks[c].first_frame + plan.chunks[c].n_frames <= my_hi)
+        {
+          local_chunks.push_back (c);
+          continue;
+        }
       w.recv_off.assign (w.ranks.size(), 0);
       for (size_t i = 0; i < w.ranks.size(); i++)
         {
@@ -823,24 +832,6 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       }
   }
 
-  if (getenv ("AWM_SHARD_DEBUG"))
-    for (ChunkWork& w : work)
-      {
-        std::string line = string_printf ("[shard rank %d chunk %d me %d/%zd S %lld] cand:", rank, w.c, w.me, w.ranks.size(), w.S);
-        for (size_t k = 0; k < w.candidates.size(); k++)
-          line += string_printf (" %zu(o%d%s)", w.candidates[k].index, w.cand_owner[k], w.cand_tail[k] ? "t" : "");
-        line += " | blocks:";
-        for (size_t wi = 0; wi < w.wanted.size(); wi++)
-          {
-            double sum = 0;
-            for (int b = 0; b < n_bits; b++)
-              sum += w.soft_all[wi * n_bits + b] * (1 + b % 7);
-            line += string_printf (" %zu(o%d%s q%.4f s%.3f)", w.scores[w.wanted[wi]].index, w.score_owner[w.wanted[wi]], w.score_tail[w.wanted[wi]] ? "t" : "",
-                                   w.scores[w.wanted[wi]].quality, sum);
-          }
-        fprintf (stderr, "%s\n", line.c_str());
-      }
-
   /* ---- phase 8: the chunk's decode jobs (single blocks, AB pairs, "all": BlockDecoder::run, wmget.cc:554-701), dealt round robin
    * among the participants.  A lane decodes one chunk at a time (its decoder buffers): rounds of one chunk per lane. */
   std::vector<PatternRec> my_patterns;
@@ -884,6 +875,43 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
         if (int rc = decode_start (work[i])) return rc;
       for (size_t i = w0; i < w1; i++)
         if (int rc = decode_collect (work[i])) return rc;
+    }
+
+  /* ---- the chunks inside my span: BlockDecoder as on one GPU (after the shared chunks, whose phases the other ranks wait in) */
+  if (!local_chunks.empty())
+    {
+      std::vector<ChunkRange> ranges;
+      for (size_t c : local_chunks)
+        ranges.push_back ({ plan.chunks[c].first_frame - my_lo, plan.chunks[c].n_frames, 0.0 });
+      DeviceWav lw;
+      lw.data = pcm;
+      lw.n_frames = my_hi - my_lo;
+      lw.n_channels = C;
+      std::vector<ResultSet> sets;
+      std::string dbg;
+      if (int rc = decode_chunks_blocks_only (ctx, key_list, lw, ranges, sets, &dbg))
+        return rc;
+      if (local_chunks[0] == 0)
+        debug_sync = dbg;
+      for (size_t i = 0; i < sets.size(); i++)
+        for (size_t j = 0; j < sets[i].patterns.size(); j++)
+          {
+            const ResultSet::Pattern& p = sets[i].patterns[j];
+            PatternRec rec {};
+            rec.chunk = int32_t (local_chunks[i]);
+            rec.job = int32_t (j);                               // (submission order of the chunk's patterns)
+            rec.pat.time = p.time;
+            rec.pat.sync_index = p.sync_score.index;
+            rec.pat.sync_quality = p.sync_score.quality;
+            rec.pat.block_type = int (p.sync_score.block_type);
+            rec.pat.type = int (p.type);
+            rec.pat.decode_error = p.decode_error;
+            rec.pat.speed = p.speed;
+            rec.pat.n_bits = std::min<int> (int (p.bit_vec.size()), 128);
+            for (int b = 0; b < rec.pat.n_bits; b++)
+              rec.pat.bits[b] = p.bit_vec[b];
+            my_patterns.push_back (rec);
+          }
     }
 
   /* ---- phase 9: rank 0 collects the patterns and merges the chunks (ResultSet, wmget.cc:288-316) */

@@ -63,9 +63,9 @@ KERNELS = {
     "add_mix_kernel": ("add_mix_kernel_w4<2>", "HBM <-> FP32 issue (1 450 VALU instructions per stereo frame, 4 waves / SIMD)"),
     "limiter_kernel": ("limiter_apply_kernel<2>", "HBM"),
     "sync_db_kernel(approx)": ("sync_db_kernel<2, false, 33>", "FP32 issue (the 4 shifts of a tile share one XCD's L2: PCM read once)"),
-    "sync_scan_kernel(approx)": ("sync_scan_stream_kernel<false>", "LDS gathers (ds_read_b128, 256 B/clk/CU) in the reference's summation order"),
+    "sync_scan_kernel(approx)": ("sync_scan_stream_kernel<false>", "works out of LDS, not HBM: 30 ds_read_b128 gathers + 120 float additions per sync frame and wave in the reference's summation order (VALU issue 90 % inside a round, LDS 51 %); 3.3 rounds of tiles"),
     "local_mean_kernel": ("local_mean_kernel", "latency"),
-    "sync_db_kernel(refine)": ("sync_db_sliding_kernel<2>", "FP64 issue + sequential recurrence (65 steps per wave)"),
+    "sync_db_kernel(refine)": ("sync_db_sliding3_kernel", "VALU issue (a third of it FP64) + sequential recurrence (65 steps per wave); three bins of one channel per lane, 56 of 64 lanes busy"),
     "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (150 workgroups)"),
     "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue"),
     "soft_bits_kernel": ("soft_bits_wave_kernel", "L2 sectors of scattered reads"),
@@ -554,7 +554,16 @@ def main():
                 candidates = max(frame_shifts - 4 * 2226 * kl, 0.0)
                 lds_tbps = candidates * 510 * 60 * 4 / (kms * 1e-3) / 1e12
                 roofline["lds_gather_of_the_scan"] = {"achieved": round(lds_tbps, 1), "peak": 150.0, "unit": "TB/s", "frac": round(lds_tbps / 150.0, 3),
-                                                      "note": "peak at 2.4 GHz; the shader clock under this load is ~1.6 GHz (s_memtime)"}
+                                                      "note": "peak at 2.4 GHz; effective clock under this kernel 2.3 GHz (GRBM_GUI_ACTIVE, profiles/r03/effective_clock.txt). "
+                                                              "The kernel issues VALU 90 % of the time inside its rounds (120 dependent-free float additions per sync frame and "
+                                                              "wave, in the reference's order) and its 846 tiles are 3.3 rounds on 256 CUs: the stand-alone time includes a 17 % tail "
+                                                              "that the other lanes fill in the timed configuration"}
+            # every kernel above 5 % of the stand-alone GPU time, same definition (algorithmic bytes / stand-alone duration / 8 TB/s)
+            roofline["all_kernels_above_5_percent"] = [
+                {"kernel": k, "device_kernel": KERNELS.get(k, (k, ""))[0], "share_of_gpu_time_alone": round(v[1] / total_alone, 3),
+                 "achieved_GBps": round(v[3] / (v[1] * 1e-3) / 1e9, 1), "frac": round(v[3] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                 "limited_by": KERNELS.get(k, ("", "?"))[1]}
+                for k, v in sorted(serial.items(), key=lambda kv: -kv[1][1]) if v[1] / total_alone > 0.05]
         res = {
             "metric": "audio seconds watermarked+decoded per wall-second (xRT), 44.1 kHz stereo",
             "value": round(audio_seconds * args.steps / elapsed, 1),

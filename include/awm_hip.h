@@ -366,6 +366,13 @@ double awm_speed_smooth_best (const double *speed, const double *quality, int co
 size_t awm_speed_clip_positions (const uint8_t key[16], size_t n_values, size_t max_out, uint64_t *positions);
 int    awm_speed_clip_candidates (const uint8_t key[16], const float *hashed_values, size_t n, int candidates, double *locations);
 
+/* A / B hooks for measurements (tools/gpu_variants.py): the previous formulation of two kernels stays selectable so that a change can be
+ * timed against it in one process, on the same data, with the same clocks.  Results are bit-identical either way (tests).
+ *   viterbi_super: 1 (default) three trellis rounds per launch with the metrics exchanged through LDS / 0 one round per launch
+ *   sliding3:      1 (default) refinement with three bins of one channel per lane / 0 two bins of both channels (stereo) */
+void awm_debug_set_viterbi_super (int on);
+void awm_debug_set_sliding3 (int on);
+
 /* --quiet (reference audiowmark.cc:1020-1023): the "Input: / Output: / Message: ..." information lines of add_watermark off */
 void awm_set_quiet (int quiet);
 
