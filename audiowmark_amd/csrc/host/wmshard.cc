@@ -408,22 +408,11 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
   const size_t t_lo = plan.tail_lo[rank], t_hi = plan.tail_hi[rank];
   if (int rc = ctx->ws_shard_tail.reserve (std::max<size_t> (1, (t_hi - t_lo) * C * sizeof (float)))) return rc;
   float *tail_buf = ctx->ws_shard_tail.as<float>();
-  {
-    std::vector<Msg> sends, recvs;
-    for (const Transfer& t : tail_transfers (plan))
-      {
-        const size_t bytes = (t.hi - t.lo) * C * sizeof (float);
-        if (t.src == rank && t.dst == rank)
-          AWM_HIP_CHECK (hipMemcpyAsync (tail_buf + (t.lo - t_lo) * C, pcm + (t.lo - my_lo) * C, bytes, hipMemcpyDeviceToDevice, st0));
-        else if (t.src == rank)
-          sends.push_back ({ pcm + (t.lo - my_lo) * C, nullptr, bytes, t.dst });
-        else if (t.dst == rank)
-          recvs.push_back ({ nullptr, tail_buf + (t.lo - t_lo) * C, bytes, t.src });
-      }
-    AWM_HIP_CHECK (stream_wait (st0));                      // (the samples may still be in flight on the context's stream, e.g. add -> get)
-    if (int rc = run_exchange (comm, true, sends, recvs, "exchange_d (overlap stitch)"))
-      return rc;
-  }
+  const std::vector<Transfer> transfers = tail_transfers (plan);
+  for (const Transfer& t : transfers)                       // my own part of my tail buffer
+    if (t.src == rank && t.dst == rank)
+      AWM_HIP_CHECK (hipMemcpyAsync (tail_buf + (t.lo - t_lo) * C, pcm + (t.lo - my_lo) * C, (t.hi - t.lo) * C * sizeof (float), hipMemcpyDeviceToDevice, st0));
+  AWM_HIP_CHECK (stream_wait (st0));                        // (the samples may still be in flight on the context's stream, e.g. add -> get)
 
   /* ---- my chunks ---- */
   std::vector<size_t> local_chunks;
@@ -508,9 +497,12 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
     return std::min (tail ? t_hi : my_hi, first + w.N) - first;
   };
 
-  /* ---- phase 2: scores of my start frames (K4 + K5w on the part's samples), into my block [4][n] of the chunk */
+  /* ---- phase 2: scores of my start frames (K4 + K5w on the part's samples), into my block [4][n] of the chunk.  The INTERIOR parts
+   * need nothing from anybody: their kernels are queued before the stitch, so that the device works while the 18 MB per boundary
+   * travel; the TAIL parts follow when the tail buffer is complete. */
+  auto score_parts = [&] (bool tail_parts) -> int {
   for (ChunkWork& w : work)
-    for (const ShardPart *pt : { w.interior, w.tail })
+    for (const ShardPart *pt : { tail_parts ? w.tail : w.interior })
       {
         if (!pt)
           continue;
@@ -540,6 +532,25 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
         AWM_HIP_CHECK (hipMemcpy2DAsync (q_all + w.q_off + col, mine_n * sizeof (double), w.lane->ws_q.ptr, q_stride * sizeof (double),
                                          pt->n_sf * sizeof (double), 4, hipMemcpyDeviceToDevice, w.lane->stream));
       }
+  return 0;
+  };
+  if (int rc = score_parts (false)) return rc;
+  {
+    std::vector<Msg> sends, recvs;
+    for (const Transfer& t : transfers)
+      {
+        const size_t bytes = (t.hi - t.lo) * C * sizeof (float);
+        if (t.src == rank && t.dst == rank)
+          continue;
+        else if (t.src == rank)
+          sends.push_back ({ pcm + (t.lo - my_lo) * C, nullptr, bytes, t.dst });
+        else if (t.dst == rank)
+          recvs.push_back ({ nullptr, tail_buf + (t.lo - t_lo) * C, bytes, t.src });
+      }
+    if (int rc = run_exchange (comm, true, sends, recvs, "exchange_d (overlap stitch)"))
+      return rc;
+  }
+  if (int rc = score_parts (true)) return rc;
   if (int rc = sync_lanes()) return rc;
 
   /* ---- phase 3: the score gather among the participants of every chunk */
