@@ -184,7 +184,11 @@ struct GatheredScanArgs
   double       min_delta;
   double      *quality;         // [plane][q_stride]
   long long    q_stride;
+  float       *chain_mag;       // scratch [plane][12 chains = (bit, up / down)][128]: the chains' sums
+  int         *chain_n;         // scratch [plane][6 bits][128]: sync frames that counted
+  int          regular_waves, tail_first, tail_lanes;     // set by the launcher
 };
+constexpr size_t GATHERED_SCRATCH_BYTES_PER_PLANE = 18 * 128 * 4;
 hipError_t launch_sync_scan_gathered (hipStream_t st, const GatheredScanArgs& a);
 
 /* K5b: local mean over the index-sorted scores (syncfinder.cc:234-254); q is [4][q_stride] by shift,

@@ -1890,104 +1890,153 @@ launch_sync_scan (hipStream_t st, const SyncScanArgs& a)
   return hipSuccess;
 }
 
-/* K5g: the refinement's sync_decode over the gathered layout (kernels.hh GatheredScanArgs).  One workgroup = one
- * candidate x 64 fine offsets, one wave per sync bit; a wave reads its 85 x 60 rows front to back (every value exactly
- * once, 256 B coalesced per row).  There are only (candidates x 2) workgroups, so a wave must hide the HBM latency
- * itself: the 60 loads of the next sync frame are issued before the 60 dependent adds of the current one. */
-template<bool HAVE> __global__ void __launch_bounds__ (384)
+/* K5g: the refinement's sync_decode over the gathered layout (kernels.hh GatheredScanArgs).  One WAVE = one (sync bit, up / down)
+ * addition chain of one candidate x 64 fine offsets; it reads its 85 x 30 rows front to back (every value exactly once, 256 B
+ * coalesced per row) and adds them in the reference's order.  The chains of a candidate are independent until the six bit
+ * qualities are combined (sync_quality_kernel below), so they are separate single-wave workgroups: a batch of 25 candidates is
+ * 300 waves spread over all CUs -- with the twelve chains in ONE workgroup (rounds 2 and 3a) 25 CUs pulled 8.8 MB each at the
+ * ~55 GB/s one CU gets from HBM, whatever the number of loads in flight.  A wave hides the latency itself: the loads of the next
+ * TWO sync frames are in flight while the 30 dependent adds of the current one issue.
+ * The 65th fine offset: a second wave per chain would run for one lane; instead ONE tail wave per candidate takes the offsets past
+ * the last full 64 for all twelve chains (lane = chain x offset, possible while 12 x offsets <= 64). */
+template<bool HAVE> __global__ void __launch_bounds__ (64)
 sync_scan_gathered_kernel (GatheredScanArgs a)
 {
-  __shared__ float s_u[6][64], s_d[6][64];
-  __shared__ int   s_n[6][64];
   const int lane = threadIdx.x;
-  const int bit = __builtin_amdgcn_readfirstlane (threadIdx.y);
   const long long plane = blockIdx.y;
-  const int cand = blockIdx.x * 64 + lane;
-  const bool active = cand < a.lane_count[plane];
+  const int count = a.lane_count[plane];
+  int chain, cand;
+  if (int (blockIdx.x) < a.regular_waves)
+    {
+      chain = blockIdx.x % 12;
+      cand = (blockIdx.x / 12) * 64 + lane;
+    }
+  else
+    {
+      chain = lane / a.tail_lanes;
+      cand = a.tail_first + lane % a.tail_lanes;
+    }
+  const bool active = chain < 12 && cand < count;
+  if (!__any (active))
+    return;
+  if (!active)
+    chain = 0, cand = 0;
+  const int bit = chain >> 1, down = chain & 1;
   const int R = a.rows_per_bit;
-  const float *p = a.db + plane * a.plane_stride + (long long) bit * R * 60 * a.ld + (active ? cand : 0);
-  const char *hv = HAVE ? a.have + plane * a.have_plane_stride + (long long) bit * R * a.ld + (active ? cand : 0) : nullptr;
   const int ld = a.ld;
+  const float *p = a.db + plane * a.plane_stride + ((long long) bit * R * 60 + down * 30) * ld + cand;
+  const char *hv = HAVE ? a.have + plane * a.have_plane_stride + (long long) bit * R * ld + cand : nullptr;
 
-  float umag = 0.f, dmag = 0.f;
+  float mag = 0.f;
   int n = 0;
-  auto issue = [&] (int r, float (&v)[60], bool& present) {
+  auto issue = [&] (int r, float (&v)[30], bool& present) {
     const float *q = p + (long long) r * 60 * ld;
     present = HAVE ? hv[r * ld] != 0 : true;
     if (HAVE && !__any (present))
       return;                                             // nothing of this row is used by any candidate of the wave
 #pragma unroll
-    for (int i = 0; i < 60; i++)
+    for (int i = 0; i < 30; i++)
       v[i] = q[i * ld];
   };
-  auto accumulate = [&] (const float (&v)[60], bool present) {
+  auto accumulate = [&] (const float (&v)[30], bool present) {
     if (present)
       {
 #pragma unroll
         for (int i = 0; i < 30; i++)
-          {
-            umag = __fadd_rn (umag, v[i]);
-            dmag = __fadd_rn (dmag, v[30 + i]);
-          }
+          mag = __fadd_rn (mag, v[i]);
         n++;
       }
   };
-  float va[60], vb[60];
-  bool pa = false, pb = false;
+  // rows r, r + 1 are in flight in v[0..1] when the loop body starts (60 loads: the wave's counter of outstanding loads holds 63);
+  // the steady state has no branch and the scheduler may not move loads across the fences (the compiler counts outstanding
+  // loads exactly only in straight-line code and in program order), rows past the end are re-reads of the last one
+  float v[3][30];
+  bool pr[3] = { false, false, false };
+  const int last = R - 1;
   int r = 0;
   if (R > 0)
-    issue (0, va, pa);
-  for (; r + 1 < R; r += 2)
     {
-      issue (r + 1, vb, pb);
-      accumulate (va, pa);
-      if (r + 2 < R)
-        issue (r + 2, va, pa);
-      accumulate (vb, pb);
-    }
-  if (r < R)
-    accumulate (va, pa);
-  s_u[bit][lane] = umag;
-  s_d[bit][lane] = dmag;
-  s_n[bit][lane] = n;
-  __syncthreads();
-  if (bit == 0 && active)
-    {
-      double q = 0;
-      int total = 0;
-      for (int b = 0; b < 6; b++)
+#pragma unroll
+      for (int k = 0; k < 2; k++)
         {
-          const float um = s_u[b][lane], dm = s_d[b][lane];
-          float raw;                                      // SyncFinder::bit_quality (reference syncfinder.cc:94-114)
-          if (um == 0 || dm == 0)
-            raw = 0;
-          else if (um < dm)
-            raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
-          else
-            raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
-          const double rb = (b & 1) ? double (raw) : -double (raw);
-          q += rb * s_n[b][lane];
-          total += s_n[b][lane];
+          issue (k < last ? k : last, v[k], pr[k]);
+          __builtin_amdgcn_sched_barrier (0);
         }
-      if (total)
-        q /= total;
-      q = q / a.min_delta / 2.9;
-      a.quality[plane * a.q_stride + cand] = q;
+      for (; r + 3 <= R; r += 3)
+        {
+#pragma unroll
+          for (int k = 0; k < 3; k++)
+            {
+              const int nx = r + k + 2;
+              issue (nx < last ? nx : last, v[(k + 2) % 3], pr[(k + 2) % 3]);
+              __builtin_amdgcn_sched_barrier (0);
+              accumulate (v[k], pr[k]);
+              __builtin_amdgcn_sched_barrier (0);
+            }
+        }
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (r + k < R)
+          accumulate (v[k], pr[k]);
+    }
+  if (active)
+    {
+      a.chain_mag[(plane * 12 + chain) * 128 + cand] = mag;
+      if (!down)
+        a.chain_n[(plane * 6 + bit) * 128 + cand] = n;
     }
 }
 
-hipError_t
-launch_sync_scan_gathered (hipStream_t st, const GatheredScanArgs& a)
+/* SyncFinder::sync_decode's tail for the refinement: six bit qualities -> one sync quality per (candidate, fine offset) */
+__global__ void __launch_bounds__ (64)
+sync_quality_kernel (GatheredScanArgs a)
 {
-  if (a.n_lanes <= 0 || a.n_planes <= 0)
+  const long long plane = blockIdx.y;
+  const int cand = blockIdx.x * 64 + threadIdx.x;
+  if (cand >= a.lane_count[plane])
+    return;
+  double q = 0;
+  int total = 0;
+  for (int b = 0; b < 6; b++)
+    {
+      const float um = a.chain_mag[(plane * 12 + 2 * b) * 128 + cand], dm = a.chain_mag[(plane * 12 + 2 * b + 1) * 128 + cand];
+      const int n = a.chain_n[(plane * 6 + b) * 128 + cand];
+      float raw;                                      // SyncFinder::bit_quality (reference syncfinder.cc:94-114)
+      if (um == 0 || dm == 0)
+        raw = 0;
+      else if (um < dm)
+        raw = __fsub_rn (1.f, __fdiv_rn (um, dm));
+      else
+        raw = __fsub_rn (__fdiv_rn (dm, um), 1.f);
+      const double rb = (b & 1) ? double (raw) : -double (raw);
+      q += rb * n;
+      total += n;
+    }
+  if (total)
+    q /= total;
+  q = q / a.min_delta / 2.9;
+  a.quality[plane * a.q_stride + cand] = q;
+}
+
+hipError_t
+launch_sync_scan_gathered (hipStream_t st, const GatheredScanArgs& a0)
+{
+  if (a0.n_lanes <= 0 || a0.n_planes <= 0)
     return hipSuccess;
-  if (!a.lane_count || a.n_planes > 65535)
+  if (!a0.lane_count || a0.n_planes > 65535 || a0.n_lanes > 128 || !a0.chain_mag || !a0.chain_n)
     return hipErrorInvalidValue;
-  const dim3 grid (unsigned ((a.n_lanes + 63) / 64), unsigned (a.n_planes));
+  GatheredScanArgs a = a0;
+  const int full = a.n_lanes / 64, rem = a.n_lanes % 64;
+  const bool tail = rem > 0 && rem * 12 <= 64;
+  a.regular_waves = 12 * (tail || rem == 0 ? full : full + 1);
+  a.tail_first = 64 * full;
+  a.tail_lanes = tail ? rem : 1;
+  const dim3 grid (unsigned (a.regular_waves + (tail ? 1 : 0)), unsigned (a.n_planes));
   if (a.have)
-    hipLaunchKernelGGL (sync_scan_gathered_kernel<true>, grid, dim3 (64, 6), 0, st, a);
+    hipLaunchKernelGGL (sync_scan_gathered_kernel<true>, grid, dim3 (64), 0, st, a);
   else
-    hipLaunchKernelGGL (sync_scan_gathered_kernel<false>, grid, dim3 (64, 6), 0, st, a);
+    hipLaunchKernelGGL (sync_scan_gathered_kernel<false>, grid, dim3 (64), 0, st, a);
+  hipLaunchKernelGGL (sync_quality_kernel, dim3 (unsigned ((a.n_lanes + 63) / 64), unsigned (a.n_planes)), dim3 (64), 0, st, a);
   return hipGetLastError();
 }
 

@@ -464,7 +464,7 @@ SyncFinder::refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, Searc
   batch = std::min (batch, n_cand);
   if (int rc = m_lane->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
   if (int rc = m_lane->ws_refine_have.reserve (batch * NW * REFINE_TP)) return rc;
-  if (int rc = m_lane->ws_q.reserve (batch * REFINE_QS * sizeof (double))) return rc;
+  if (int rc = m_lane->ws_q.reserve (batch * (REFINE_QS * sizeof (double) + awmk::GATHERED_SCRATCH_BYTES_PER_PLANE))) return rc;    // qualities, then K5g's chain sums
   if (int rc = m_lane->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + 2 * batch * sizeof (int))) return rc;
   for (size_t c0 = 0; c0 < n_cand; c0 += batch)
     {
@@ -600,6 +600,8 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           ga.min_delta = std::min (params().water_delta, 0.080);
           ga.quality = m_lane->ws_q.as<double>();
           ga.q_stride = QS;
+          ga.chain_mag = reinterpret_cast<float *> (ga.quality + batch * QS);
+          ga.chain_n = reinterpret_cast<int *> (ga.chain_mag + batch * 12 * 128);
           ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 4.0 * row_values, st);
           AWM_HIP_CHECK (awmk::launch_sync_scan_gathered (st, ga));
         }
