@@ -192,6 +192,8 @@ lib.awm_params_init.restype = None
 lib.awm_set_global_params.argtypes = [C.POINTER(Params)]
 lib.awm_ctx_set_params.argtypes = [_vp, C.POINTER(Params)]
 lib.awm_ctx_get_params.argtypes = [_vp, C.POINTER(Params)]
+lib.awm_ctx_snr_begin.argtypes = [_vp]
+lib.awm_ctx_snr_end.argtypes = [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
 lib.awm_get_watermark_keys_d.argtypes = [_vp, _vp, C.c_int, _vp, C.c_size_t, C.c_int, C.c_size_t, _vp, _vp]
 lib.awm_get_watermark_keys_file.argtypes = [_vp, _vp, C.c_int, C.c_char_p, C.POINTER(RawFormat), C.c_size_t, _vp, _vp]
 
@@ -751,6 +753,17 @@ class Context:
         p = Params()
         _check(lib.awm_ctx_get_params(self._h, C.byref(p)), "awm_ctx_get_params")
         return p
+
+    def snr_begin(self):
+        """`add --snr`: every add of this context accumulates input and watermark power (before the limiter) until snr_end"""
+        _check(lib.awm_ctx_snr_begin(self._h), "awm_ctx_snr_begin")
+
+    def snr_end(self):
+        """-> SNR in dB = 10 log10 (power of the input / power of the watermark signal), reference wmadd.cc:553-563, 591-592"""
+        import math
+        sig, delta = C.c_double(), C.c_double()
+        _check(lib.awm_ctx_snr_end(self._h, C.byref(sig), C.byref(delta)), "awm_ctx_snr_end")
+        return 10 * math.log10(sig.value / delta.value) if delta.value > 0 else float("inf")
 
     def _patterns_keys(self, fn, what, keys, *args, max_out=4096):
         flat = b"".join(key_bytes(k) for k in keys)

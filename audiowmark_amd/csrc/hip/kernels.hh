@@ -76,6 +76,9 @@ hipError_t launch_resample (hipStream_t st, const ResampleArgs& a);
 hipError_t launch_mix_max (hipStream_t st, const float *orig, const float *wm, float *out, long long n_frames, int n_channels,
                            unsigned int *block_max, long long n_blocks, int limiter_block);
 
+/* `add --snr`: acc[0] += sum (mixed - orig)^2, acc[1] += sum orig^2 in double (reference wmadd.cc:553-563) */
+hipError_t launch_power_sums (hipStream_t st, const float *orig, const float *mixed, long long n_values, double *acc);
+
 /* K4: STFT -> dB of the 81 bands, written band-major ("transposed") so that scans over the
  * frame axis are coalesced.  Stream s (0 <= s < n_streams) consists of count(s) frames starting
  * at base(s) + f * hop.  out[s * out_stream_stride + (plane * 81 + band) * ld + f]. */

@@ -118,7 +118,7 @@ window_pack (const float (&v)[16], const float *s_win, int lane, float2 (&z)[8])
 #pragma unroll
   for (int j = 0; j < 8; j++)
     {
-      const float2 w = w2[lane + 64 * j];
+      const float2 w = lds_ld (&w2[lane + 64 * j]);
       z[j] = make_float2 (__fmul_rn (v[2 * j], w.x), __fmul_rn (v[2 * j + 1], w.y));
     }
 }
@@ -235,6 +235,95 @@ frame_delta (float2 (&z)[8], const int8_t *mod_row, float nd_up, float nd_down,
   fft512_inverse (z, xbuf, s_tw, s_tw3, lane);
 }
 
+// both channels of a stereo frame: the two transforms pipelined over the wave's one exchange tile (fft512_forward2 / fft512_inverse2);
+// the frame_mod row is the same for both, the band edit of a bin runs for both at once
+__device__ __forceinline__ void
+frame_delta2 (float2 (&za)[8], float2 (&zb)[8], const int8_t *mod_row, float nd_up, float nd_down,
+              float2 *xbuf, float2 *zd, const float2 *s_tw, const float2 *s_tw3, const float2 *s_twb, int lane)
+{
+  fft512_forward2 (za, zb, xbuf, s_tw, lane);
+  // rows with the bands and their mirrors: a in rows 0, 1, 6, 7 of the tile (zpos), b in the rows between (zpos + 128 / - 128)
+  lds_st (&xbuf[0 * 64 + lane], za[0]);
+  lds_st (&xbuf[1 * 64 + lane], za[1]);
+  lds_st (&xbuf[6 * 64 + lane], za[6]);
+  lds_st (&xbuf[7 * 64 + lane], za[7]);
+  lds_st (&xbuf[2 * 64 + lane], zb[0]);
+  lds_st (&xbuf[3 * 64 + lane], zb[1]);
+  lds_st (&xbuf[4 * 64 + lane], zb[6]);
+  lds_st (&xbuf[5 * 64 + lane], zb[7]);
+  wave_sync_pinned();
+  auto zposb = [] (int k) { const int p = zpos (k); return p < 128 ? p + 128 : p - 128; };
+  float2 Da[2], Db[2], Oa[2], Ob[2];
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++)
+    {
+      const int k = MIN_BAND + lane + 64 * pass;
+      Da[pass] = Db[pass] = Oa[pass] = Ob[pass] = make_float2 (0.f, 0.f);
+      if (k <= 100)
+        {
+          const float2 w = s_twb[k - MIN_BAND];
+          const float2 Xa = real_split (lds_ld (&xbuf[zpos (k)]), lds_ld (&xbuf[zpos (512 - k)]), w);
+          const float2 Xb = real_split (lds_ld (&xbuf[zposb (k)]), lds_ld (&xbuf[zposb (512 - k)]), w);
+          const int mod = mod_row[k - MIN_BAND];
+          if (mod)
+            {
+              // apply_frame_mod (reference wmadd.cc:61-84), see frame_delta
+              const float e = 0.5f * (mod == 1 ? nd_up : nd_down);
+              const float abs2a = Xa.x * Xa.x + Xa.y * Xa.y, abs2b = Xb.x * Xb.x + Xb.y * Xb.y;
+              if (abs2a > 1e-14f)
+                {
+                  const float s = __builtin_amdgcn_exp2f (__builtin_amdgcn_logf (abs2a) * e) - 1.0f;
+                  Da[pass] = make_float2 (Xa.x * s, Xa.y * s);
+                }
+              if (abs2b > 1e-14f)
+                {
+                  const float s = __builtin_amdgcn_exp2f (__builtin_amdgcn_logf (abs2b) * e) - 1.0f;
+                  Db[pass] = make_float2 (Xb.x * s, Xb.y * s);
+                }
+            }
+          Oa[pass] = cmulc (Da[pass], w);
+          Ob[pass] = cmulc (Db[pass], w);
+        }
+    }
+  wave_sync_pinned();
+  const float2 zero = make_float2 (0.f, 0.f);
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++)
+    {
+      const int k = MIN_BAND + lane + 64 * pass;
+      if (k <= 100)
+        {
+          lds_st (&zd[zdpos (k)],       make_float2 (Da[pass].x - Oa[pass].y, Da[pass].y + Oa[pass].x));
+          lds_st (&zd[zdpos (512 - k)], make_float2 (Da[pass].x + Oa[pass].y, Oa[pass].x - Da[pass].y));
+        }
+    }
+  wave_sync_pinned();
+  za[0] = lds_ld (&zd[0 * 64 + lane]);
+  za[1] = lds_ld (&zd[1 * 64 + lane]);
+  za[2] = zero; za[3] = zero; za[4] = zero; za[5] = zero;
+  za[6] = lds_ld (&zd[2 * 64 + lane]);
+  za[7] = lds_ld (&zd[3 * 64 + lane]);
+  wave_sync_pinned();
+#pragma unroll
+  for (int pass = 0; pass < 2; pass++)
+    {
+      const int k = MIN_BAND + lane + 64 * pass;
+      if (k <= 100)
+        {
+          lds_st (&zd[zdpos (k)],       make_float2 (Db[pass].x - Ob[pass].y, Db[pass].y + Ob[pass].x));
+          lds_st (&zd[zdpos (512 - k)], make_float2 (Db[pass].x + Ob[pass].y, Ob[pass].x - Db[pass].y));
+        }
+    }
+  wave_sync_pinned();
+  zb[0] = lds_ld (&zd[0 * 64 + lane]);
+  zb[1] = lds_ld (&zd[1 * 64 + lane]);
+  zb[2] = zero; zb[3] = zero; zb[4] = zero; zb[5] = zero;
+  zb[6] = lds_ld (&zd[2 * 64 + lane]);
+  zb[7] = lds_ld (&zd[3 * 64 + lane]);
+  wave_sync_pinned();
+  fft512_inverse2 (za, zb, xbuf, s_tw, s_tw3, lane);
+}
+
 __device__ __forceinline__ float
 wave_max (float v)
 {
@@ -244,7 +333,7 @@ wave_max (float v)
   return v;
 }
 
-template<int CV, bool OPAQUE> __device__ __forceinline__ void
+template<int CV, bool OPAQUE, bool PAIR = false> __device__ __forceinline__ void
 add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, int block_frames)
 {
   __shared__ float2 s_tw[512];
@@ -334,11 +423,20 @@ add_mix_body (const DevTables& t, const AddMixArgs& a, long long frame_number0, 
           const long long g = a.first_frame + m;                       // frame index in the whole stream
           const long long row = (frame_number0 + g) % total_rows;      // reference wmadd.cc:326-344
           const int8_t *mod_row = a.frame_mod + row * NB;
-#pragma unroll
-          for (int c = 0; c < CV; c++)
+          if constexpr (CV == 2 && PAIR)
             {
-              window_pack (in[c], s_win, lane, d[c]);
-              frame_delta (d[c], mod_row, a.neg_delta_up, a.neg_delta_down, xbuf, zd, s_tw, s_tw3, s_twb, lane);
+              window_pack (in[0], s_win, lane, d[0]);
+              window_pack (in[1], s_win, lane, d[1]);
+              frame_delta2 (d[0], d[1], mod_row, a.neg_delta_up, a.neg_delta_down, xbuf, zd, s_tw, s_tw3, s_twb, lane);
+            }
+          else
+            {
+#pragma unroll
+              for (int c = 0; c < CV; c++)
+                {
+                  window_pack (in[c], s_win, lane, d[c]);
+                  frame_delta (d[c], mod_row, a.neg_delta_up, a.neg_delta_down, xbuf, zd, s_tw, s_tw3, s_twb, lane);
+                }
             }
         }
       else
@@ -544,7 +642,15 @@ add_mix_kernel_w4 (DevTables t, AddMixArgs a, long long frame_number0, int block
 {
   add_mix_body<CV, true> (t, a, frame_number0, block_frames);
 }
+// the same with the two channels' transforms pipelined over the wave's one exchange tile (frame_delta2)
+__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+add_mix_pair_kernel (DevTables t, AddMixArgs a, long long frame_number0, int block_frames)
+{
+  add_mix_body<2, true, true> (t, a, frame_number0, block_frames);
+}
 int add_mix_waves_per_simd() { return 4; }
+int g_fft_pair = 1;              // (debug toggle: stereo add with frame_delta2)
+extern "C" void awm_debug_set_fft_pair (int on) { g_fft_pair = on; }
 
 hipError_t
 launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
@@ -559,7 +665,9 @@ launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
   const int block_frames = a.block_frames;
   const long long frame_number0 = 2LL * block_frames - a.frames_pad_start;       // reference wmadd.cc:293-294
   // stereo: both channels in one wave, four waves per SIMD (122 registers; three waves + prefetch of the next frame: 3 - 5 % slower)
-  if (stereo)
+  if (stereo && g_fft_pair)
+    hipLaunchKernelGGL (add_mix_pair_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
+  else if (stereo)
     hipLaunchKernelGGL (add_mix_kernel_w4<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
   else
     hipLaunchKernelGGL (add_mix_kernel<1>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
@@ -879,6 +987,48 @@ launch_resample (hipStream_t st, const ResampleArgs& a)
 
 constexpr int MIX_RUN = 2048;            // values per thread group run: 256 threads x 8
 
+/* `add --snr` (reference wmadd.cc:553-563): power of the input and of (mix - input) BEFORE the limiter, in double like the
+ * reference's loop; acc[0] += sum (mix - orig)^2, acc[1] += sum orig^2 */
+__global__ void __launch_bounds__ (256)
+power_sums_kernel (const float *orig, const float *mixed, long long n_values, double *acc)
+{
+  __shared__ double s_d[4], s_s[4];
+  double d2 = 0, s2 = 0;
+  for (long long i = (long long) blockIdx.x * 256 + threadIdx.x; i < n_values; i += (long long) gridDim.x * 256)
+    {
+      const double o = orig[i], d = double (mixed[i]) - o;
+      d2 += d * d;
+      s2 += o * o;
+    }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1)
+    {
+      d2 += __shfl_xor (d2, off);
+      s2 += __shfl_xor (s2, off);
+    }
+  if ((threadIdx.x & 63) == 0)
+    {
+      s_d[threadIdx.x >> 6] = d2;
+      s_s[threadIdx.x >> 6] = s2;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0)
+    {
+      atomicAdd (acc, s_d[0] + s_d[1] + s_d[2] + s_d[3]);
+      atomicAdd (acc + 1, s_s[0] + s_s[1] + s_s[2] + s_s[3]);
+    }
+}
+
+hipError_t
+launch_power_sums (hipStream_t st, const float *orig, const float *mixed, long long n_values, double *acc)
+{
+  if (n_values <= 0)
+    return hipSuccess;
+  const long long blocks = (n_values + 256 * 16 - 1) / (256 * 16);
+  hipLaunchKernelGGL (power_sums_kernel, dim3 (unsigned (blocks < 4096 ? blocks : 4096)), dim3 (256), 0, st, orig, mixed, n_values, acc);
+  return hipGetLastError();
+}
+
 __global__ void __launch_bounds__ (256)
 mix_max_kernel (const float *orig, const float *wm, float *out, long long n_values, int C, unsigned int *block_max, long long n_blocks, int BS)
 {
@@ -1038,34 +1188,47 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
             {
               float in[2][16];
               fetch_stereo (a.pcm, idx, 1024, lane, in[0], in[1]);
-#pragma unroll
-              for (int c = 0; c < 2; c++)
+              float2 za[8], zb[8];
+              window_pack (in[0], s_win, lane, za);
+              window_pack (in[1], s_win, lane, zb);
+              fft512_forward2 (za, zb, xbuf, s_tw, lane);
+              // bins 20 + lane, 84 + lane of both channels: the rows with the bins and their mirrors go through the tile, a then b
+              const int k0 = MIN_BAND + lane, k1 = MIN_BAND + 64 + lane;
+              const bool second = lane < NB - 64;
+              float2 pa[4], pb[4];
+              lds_st (&xbuf[0 * 64 + lane], za[0]);
+              lds_st (&xbuf[1 * 64 + lane], za[1]);
+              lds_st (&xbuf[6 * 64 + lane], za[6]);
+              lds_st (&xbuf[7 * 64 + lane], za[7]);
+              wave_sync();
+              pa[0] = lds_ld (&xbuf[zpos (k0)]);
+              pa[1] = lds_ld (&xbuf[zpos (512 - k0)]);
+              pa[2] = lds_ld (&xbuf[zpos (second ? k1 : k0)]);
+              pa[3] = lds_ld (&xbuf[zpos (512 - (second ? k1 : k0))]);
+              wave_sync();
+              lds_st (&xbuf[0 * 64 + lane], zb[0]);
+              lds_st (&xbuf[1 * 64 + lane], zb[1]);
+              lds_st (&xbuf[6 * 64 + lane], zb[6]);
+              lds_st (&xbuf[7 * 64 + lane], zb[7]);
+              wave_sync();
+              pb[0] = lds_ld (&xbuf[zpos (k0)]);
+              pb[1] = lds_ld (&xbuf[zpos (512 - k0)]);
+              pb[2] = lds_ld (&xbuf[zpos (second ? k1 : k0)]);
+              pb[3] = lds_ld (&xbuf[zpos (512 - (second ? k1 : k0))]);
+              wave_sync();
+              const float2 w0 = s_twb[lane], w1 = s_twb[second ? 64 + lane : lane];
+              acc0 = __fadd_rn (acc0, db_from_complex (real_split (pa[0], pa[1], w0)));
+              if (second)
+                acc1 = __fadd_rn (acc1, db_from_complex (real_split (pa[2], pa[3], w1)));
+              if (SPLIT)
                 {
-                  if (SPLIT && c == 1)
-                    {
-                      split0 = acc0;
-                      split1 = acc1;
-                      acc0 = acc1 = 0.f;
-                    }
-                  float2 z[8];
-                  window_pack (in[c], s_win, lane, z);
-                  fft512_forward (z, xbuf, s_tw, lane);
-                  xbuf[0 * 64 + lane] = z[0];
-                  xbuf[1 * 64 + lane] = z[1];
-                  xbuf[6 * 64 + lane] = z[6];
-                  xbuf[7 * 64 + lane] = z[7];
-                  wave_sync();
-                  {
-                    const int k = MIN_BAND + lane;
-                    acc0 = __fadd_rn (acc0, db_from_complex (real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], s_twb[lane])));
-                  }
-                  if (lane < NB - 64)
-                    {
-                      const int k = MIN_BAND + 64 + lane;
-                      acc1 = __fadd_rn (acc1, db_from_complex (real_split (xbuf[zpos (k)], xbuf[zpos (512 - k)], s_twb[64 + lane])));
-                    }
-                  wave_sync();
+                  split0 = acc0;
+                  split1 = acc1;
+                  acc0 = acc1 = 0.f;
                 }
+              acc0 = __fadd_rn (acc0, db_from_complex (real_split (pb[0], pb[1], w0)));
+              if (second)
+                acc1 = __fadd_rn (acc1, db_from_complex (real_split (pb[2], pb[3], w1)));
             }
           else
             {

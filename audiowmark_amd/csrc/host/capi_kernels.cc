@@ -169,8 +169,12 @@ add_mix_impl (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames
   a.block_frames = int (mark_block_frame_count());
   a.frames_pad_start = int (Params::frames_pad_start);
   a.frames_per_span = frames_per_span (ctx, (long long) (n_frames + 1023) / 1024);
-  ProfScope ps (ctx, PROF_ADD_MIX, double (n_frames) * n_channels * 8.0, st);     // read + write every sample once
-  AWM_HIP_CHECK (awmk::launch_add_mix (st, ctx->tabs, a));
+  {
+    ProfScope ps (ctx, PROF_ADD_MIX, double (n_frames) * n_channels * 8.0, st);     // read + write every sample once
+    AWM_HIP_CHECK (awmk::launch_add_mix (st, ctx->tabs, a));
+  }
+  if (ctx->snr_on)                    // add --snr: the mix before the limiter (reference wmadd.cc:553-563)
+    AWM_HIP_CHECK (awmk::launch_power_sums (st, pcm_in_d, out_d, (long long) (n_frames * n_channels), ctx->ws_snr.as<double>()));
   return 0;
 }
 
@@ -186,6 +190,37 @@ add_mix_device (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_fram
 }
 }
 extern "C" {
+
+int
+awm_ctx_snr_begin (awm_ctx *ctx)
+{
+  AWM_ENTER (ctx);
+  if (int rc = ctx->ws_snr.reserve (2 * sizeof (double))) return rc;
+  AWM_HIP_CHECK (hipMemsetAsync (ctx->ws_snr.ptr, 0, 2 * sizeof (double), ctx->stream));
+  AWM_HIP_CHECK (hipStreamSynchronize (ctx->stream));          // (the lanes' streams start after this)
+  ctx->snr_on = true;
+  return 0;
+}
+
+int
+awm_ctx_snr_end (awm_ctx *ctx, double *signal_power, double *delta_power)
+{
+  AWM_ENTER (ctx);
+  if (!ctx->snr_on)
+    {
+      set_error ("awm_ctx_snr_end without awm_ctx_snr_begin");
+      return AWM_ERR_ARG;
+    }
+  ctx->snr_on = false;
+  double acc[2] = { 0, 0 };
+  AWM_HIP_CHECK (hipDeviceSynchronize());
+  AWM_HIP_CHECK (hipMemcpy (acc, ctx->ws_snr.ptr, sizeof (acc), hipMemcpyDeviceToHost));
+  if (delta_power)
+    *delta_power = acc[0];
+  if (signal_power)
+    *signal_power = acc[1];
+  return 0;
+}
 
 int
 awm_add_mix_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
@@ -390,6 +425,8 @@ add_full_rate (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frame
       if (int rc = awm_add_init_block_max_d (ctx, ctx->ws_block_max.as<float>(), n_blocks)) return rc;
     }
   AWM_HIP_CHECK (awmk::launch_mix_max (ctx->stream, pcm_in_d, wm, out_d, (long long) n_frames, C, block_max, (long long) n_blocks, lim_block));
+  if (ctx->snr_on)
+    AWM_HIP_CHECK (awmk::launch_power_sums (ctx->stream, pcm_in_d, out_d, (long long) (n_frames * C), ctx->ws_snr.as<double>()));
   if (use_limiter)
     {
       const size_t tab_entries = awmk::limiter_tab_entries ((long long) n_frames, 0, lim_block);
@@ -909,10 +946,15 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
       return AWM_ERR_ARG;
     }
   const size_t table_bytes = 2 * mark_block_frame_count() * Params::n_bands;
-  constexpr size_t GROUP = 64;
+  // A key's table costs about a millisecond of one host core and is 360 KB; the device needs 25 us per clip.  So the tables are built
+  // for SUPER clips at a time on up to 64 host threads, straight into one half of a page-locked staging block (the workers copy,
+  // not the launching thread), go to the device in ONE copy per SUPER, and the next SUPER is built while the device works on this one.
+  // (Round 3a: one task per group of 64 with the launching thread copying 23 MB per group into the staging block: 90 ms for 1024
+  // clips where the device needs 25.)
+  constexpr size_t SUPER = 128;
   constexpr int ADD_LANES = 8;
   if (int rc = ctx->ws_keytab.reserve (std::max<size_t> (1, n_clips * table_bytes))) return rc;
-  if (int rc = ctx->pin_keytab.reserve (2 * GROUP * table_bytes)) return rc;
+  if (int rc = ctx->pin_keytab.reserve (2 * SUPER * table_bytes)) return rc;
   const int n_lanes = int (std::min<size_t> (ADD_LANES, std::max<size_t> (1, n_clips)));
   std::vector<WorkLane *> lanes;
   for (int i = 0; i < n_lanes; i++)
@@ -929,16 +971,23 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
     }
   const std::vector<Key> key_list = key_list_from (keys, int (n_clips));
   ParamValues *const pv = &params();
-  auto build_group = [&, pv] (size_t g0) {
-    ParamsBind bind (pv);
-    const size_t gn = std::min (GROUP, n_clips - g0);
-    std::vector<std::vector<int8_t>> tables (gn);
-    const size_t n_threads = std::max<size_t> (1, std::min<size_t> ({ gn, size_t (64), size_t (std::max (1u, std::thread::hardware_concurrency())) }));
+  char *const pin_base = ctx->pin_keytab.as<char>();
+  auto build_super = [&, pv] (size_t s0, int half) -> bool {
+    const size_t sn = std::min (SUPER, n_clips - s0);
+    char *pin = pin_base + size_t (half) * SUPER * table_bytes;
+    const size_t n_threads = std::max<size_t> (1, std::min<size_t> ({ sn, size_t (64), size_t (std::max (1u, std::thread::hardware_concurrency())) }));
     std::atomic<size_t> next { 0 };
+    std::atomic<bool> good { true };
     auto work = [&] {
-      ParamsBind b2 (pv);
-      for (size_t i = next.fetch_add (1); i < gn; i = next.fetch_add (1))
-        tables[i] = build_frame_mod_table (key_list[g0 + i], bits);
+      ParamsBind bind (pv);
+      for (size_t i = next.fetch_add (1); i < sn; i = next.fetch_add (1))
+        {
+          const std::vector<int8_t> table = build_frame_mod_table (key_list[s0 + i], bits);
+          if (table.size() != table_bytes)
+            good = false;
+          else
+            std::memcpy (pin + i * table_bytes, table.data(), table_bytes);
+        }
     };
     std::vector<std::thread> threads;
     for (size_t t = 1; t < n_threads; t++)
@@ -946,46 +995,40 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
     work();
     for (auto& t : threads)
       t.join();
-    return tables;
+    return good;
   };
   hipEvent_t ev_up[2] = { nullptr, nullptr };
   struct EvGuard { hipEvent_t (&ev)[2]; ~EvGuard() { for (hipEvent_t e : ev) if (e) (void) hipEventDestroy (e); } } guard { ev_up };
   for (auto& e : ev_up)
     AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
   int rc = 0;
-  std::future<std::vector<std::vector<int8_t>>> next_tables;
-  for (size_t g0 = 0, g = 0; g0 < n_clips && !rc; g0 += GROUP, g++)
+  std::future<bool> next_built;
+  struct FutureGuard { std::future<bool>& f; ~FutureGuard() { if (f.valid()) f.wait(); } } future_guard { next_built };     // (the task writes into the staging block)
+  for (size_t s0 = 0, sidx = 0; s0 < n_clips && !rc; s0 += SUPER, sidx++)
     {
-      const size_t gn = std::min (GROUP, n_clips - g0);
-      std::vector<std::vector<int8_t>> tables = next_tables.valid() ? next_tables.get() : build_group (g0);
-      if (g0 + GROUP < n_clips)
-        next_tables = std::async (std::launch::async, build_group, g0 + GROUP);        // while the device works on this group
-      char *pin = ctx->pin_keytab.as<char>() + (g & 1) * GROUP * table_bytes;
-      if (g >= 2)
-        AWM_HIP_CHECK (hipEventSynchronize (ev_up[g & 1]));                             // the upload out of this staging half is done
-      for (size_t i = 0; i < gn; i++)
+      const size_t sn = std::min (SUPER, n_clips - s0);
+      const int half = int (sidx & 1);
+      const bool built = next_built.valid() ? next_built.get() : build_super (s0, half);
+      if (!built)
         {
-          if (tables[i].size() != table_bytes)
-            {
-              set_error ("frame_mod table of unexpected size");
-              rc = AWM_ERR_GENERIC;
-              break;
-            }
-          std::memcpy (pin + i * table_bytes, tables[i].data(), table_bytes);
+          set_error ("frame_mod table of unexpected size");
+          return AWM_ERR_GENERIC;
         }
-      if (rc)
-        break;
-      int8_t *dev = ctx->ws_keytab.as<int8_t>() + g0 * table_bytes;
-      AWM_HIP_CHECK (hipMemcpyAsync (dev, pin, gn * table_bytes, hipMemcpyHostToDevice, ctx->stream));
-      AWM_HIP_CHECK (hipEventRecord (ev_up[g & 1], ctx->stream));
+      if (s0 + SUPER < n_clips)
+        {
+          if (sidx >= 1)
+            AWM_HIP_CHECK (hipEventSynchronize (ev_up[half ^ 1]));                      // the upload out of the other half is done
+          next_built = std::async (std::launch::async, build_super, s0 + SUPER, half ^ 1);     // while the device works on this one
+        }
+      int8_t *dev = ctx->ws_keytab.as<int8_t>() + s0 * table_bytes;
+      AWM_HIP_CHECK (hipMemcpyAsync (dev, pin_base + size_t (half) * SUPER * table_bytes, sn * table_bytes, hipMemcpyHostToDevice, ctx->stream));
+      AWM_HIP_CHECK (hipEventRecord (ev_up[half], ctx->stream));
       for (int i = 1; i < n_lanes; i++)
-        AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ev_up[g & 1], 0));         // (also orders the lanes after the clips' producers)
-      for (size_t i = 0; i < gn && !rc; i++)
-        rc = add_full (ctx, pcm_in_d[g0 + i], out_d[g0 + i], n_frames[g0 + i], n_channels, dev + i * table_bytes, params().water_delta,
-                       !params().test_no_limiter, lanes[(g0 + i) % n_lanes]);
+        AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ev_up[half], 0));          // (also orders the lanes after the clips' producers)
+      for (size_t i = 0; i < sn && !rc; i++)
+        rc = add_full (ctx, pcm_in_d[s0 + i], out_d[s0 + i], n_frames[s0 + i], n_channels, dev + i * table_bytes, params().water_delta,
+                       !params().test_no_limiter, lanes[(s0 + i) % n_lanes]);
     }
-  if (next_tables.valid())
-    next_tables.wait();
   for (int i = 1; i < n_lanes; i++)
     {
       AWM_HIP_CHECK (hipEventRecord (lanes[i]->ev_sync, lanes[i]->stream));

@@ -603,6 +603,7 @@ awm_ctx_destroy (awm_ctx *ctx)
   for (auto& t : ctx->resample_tables)
     t->ctab.release();
   awm::speed_workspace_free (ctx);
+  ctx->ws_snr.release();
   ctx->ws_rate_a.release();
   ctx->ws_rate_b.release();
   ctx->ws_rate_c.release();

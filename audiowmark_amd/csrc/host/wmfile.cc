@@ -374,30 +374,25 @@ count_data_blocks (size_t n_frames, int sample_rate, bool limiter)
 
 namespace {
 
-/* SNR report of `add --snr` (reference wmadd.cc:553-563 measures the watermark before the limiter; with the limiter active
- * this is the power of (output - original), which includes the limiter's gain change): accumulated tile by tile in order */
+/* SNR report of `add --snr` (reference wmadd.cc:553-563, 591-592): the watermark is measured BEFORE the limiter, on the device,
+ * by every mix of the context between begin and end (awm_ctx_snr_begin / awm_ctx_snr_end) */
 struct SnrMeter
 {
-  double delta_power = 0, signal_power = 0;
-  std::vector<float> orig, result;
+  awm_ctx *ctx;
+  bool     on = false;
+  explicit SnrMeter (awm_ctx *c) : ctx (c) {}
+  ~SnrMeter() { if (on) (void) awm_ctx_snr_end (ctx, nullptr, nullptr); }
+  bool begin() { on = awm_ctx_snr_begin (ctx) == 0; return on; }
   bool
-  add (const float *d_orig, const float *d_result, size_t n_values, hipStream_t st)
+  report()
   {
-    orig.resize (n_values);
-    result.resize (n_values);
-    if (hipStreamSynchronize (st) != hipSuccess
-        || hipMemcpy (orig.data(), d_orig, n_values * sizeof (float), hipMemcpyDeviceToHost) != hipSuccess
-        || hipMemcpy (result.data(), d_result, n_values * sizeof (float), hipMemcpyDeviceToHost) != hipSuccess)
+    double signal_power = 0, delta_power = 0;
+    on = false;
+    if (awm_ctx_snr_end (ctx, &signal_power, &delta_power))
       return false;
-    for (size_t i = 0; i < n_values; i++)
-      {
-        const double o = orig[i], d = double (result[i]) - o;
-        delta_power += d * d;
-        signal_power += o * o;
-      }
+    info ("SNR:          %f dB\n", 10 * log10 (signal_power / delta_power));
     return true;
   }
-  void report() const { info ("SNR:          %f dB\n", 10 * log10 (signal_power / delta_power)); }
 };
 
 /* `add` at the watermark rate as a tile loop (awm_add_stream, include/awm_hip.h): bounded memory on BOTH sides -- two
@@ -430,8 +425,12 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       error ("audiowmark: out of memory for the staging buffers\n");
       return fail (AWM_ERR_HIP);
     }
-  SnrMeter snr;
-  std::vector<const float *> snr_in;                       // --snr: the input slots of the tiles in flight (device pointers)
+  SnrMeter snr (ctx);
+  if (params().snr && !snr.begin())
+    {
+      error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+      return fail (AWM_ERR_HIP);
+    }
   bool eof = false;
   for (size_t k = 0; !eof; k++)
     {
@@ -473,20 +472,8 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
           error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
           return fail (AWM_ERR_HIP);
         }
-      if (params().snr)
-        snr_in.push_back (slot);
       for (int i = 0; i < n_done; i++)
         {
-          if (params().snr)
-            {
-              // finished tiles come out in stream order: the oldest input slot still listed belongs to this one
-              if (!snr.add (snr_in.front(), done[i], done_frames[i] * C, ctx->stream))
-                {
-                  error ("audiowmark: GPU transfer failed\n");
-                  return fail (AWM_ERR_HIP);
-                }
-              snr_in.erase (snr_in.begin());
-            }
           if (!stage.put (done[i], done_frames[i]))
             {
               error ("audiowmark: GPU staging failed: %s\n", awm_last_error());
@@ -506,8 +493,11 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       error ("audiowmark output write failed: %s\n", err.message());
       return fail (AWM_ERR_IO);
     }
-  if (params().snr && n_frames)
-    snr.report();
+  if (params().snr && n_frames && !snr.report())
+    {
+      error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+      return fail (AWM_ERR_HIP);
+    }
   return 0;
 }
 
@@ -530,21 +520,22 @@ add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   n_frames = n_values / C;
   if (!n_values)
     return 0;
+  SnrMeter snr (ctx);
+  if (params().snr && !snr.begin())
+    {
+      error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+      return fail (AWM_ERR_HIP);
+    }
   if (d_out.reserve (n_values * sizeof (float))
       || awm_add_watermark_d (ctx, key.aes_key(), payload_hex.c_str(), d_in.as<float>(), d_out.as<float>(), n_frames, C, in_stream->sample_rate()) != 0)
     {
       error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
       return fail (AWM_ERR_HIP);
     }
-  if (params().snr)
+  if (params().snr && !snr.report())
     {
-      SnrMeter snr;
-      if (!snr.add (d_in.as<float>(), d_out.as<float>(), n_values, ctx->stream))
-        {
-          error ("audiowmark: GPU transfer failed\n");
-          return fail (AWM_ERR_HIP);
-        }
-      snr.report();
+      error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+      return fail (AWM_ERR_HIP);
     }
   err = store_device_to_stream (ctx, out_stream, d_out.as<float>(), n_values);
   if (err)

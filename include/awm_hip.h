@@ -372,6 +372,7 @@ int    awm_speed_clip_candidates (const uint8_t key[16], const float *hashed_val
  *   sliding3:      1 (default) refinement with three bins of one channel per lane / 0 two bins of both channels (stereo) */
 void awm_debug_set_viterbi_super (int on);
 void awm_debug_set_sliding3 (int on);
+void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transforms pipelined in one wave (default) | one after the other */
 
 /* --quiet (reference audiowmark.cc:1020-1023): the "Input: / Output: / Message: ..." information lines of add_watermark off */
 void awm_set_quiet (int quiet);
@@ -405,6 +406,11 @@ void awm_params_init (awm_params *p);                               /* the refer
 int  awm_set_global_params (const awm_params *p);                   /* the process-wide set */
 int  awm_ctx_set_params (awm_ctx *ctx, const awm_params *p);        /* p == NULL: back to the process-wide set */
 int  awm_ctx_get_params (const awm_ctx *ctx, awm_params *out);      /* the set in force for ctx (ctx == NULL: the process-wide one) */
+
+/* `add --snr` (reference wmadd.cc:553-563, 591-592): between begin and end every `add` of the context accumulates the power of its
+ * input and of the watermark signal (mix - input, BEFORE the limiter, sums in double); SNR = 10 log10 (signal / delta). */
+int  awm_ctx_snr_begin (awm_ctx *ctx);
+int  awm_ctx_snr_end (awm_ctx *ctx, double *signal_power, double *delta_power);
 
 #ifdef __cplusplus
 }

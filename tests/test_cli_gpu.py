@@ -139,6 +139,33 @@ def test_against_reference_binary(work):
         same_report(ours, theirs, str(f))
 
 
+def test_snr_report_equals_reference_with_the_limiter_active(work, tmp_path):
+    """`add --snr` (reference wmadd.cc:553-563, 591-592): the watermark is measured BEFORE the limiter.  test-gen-noise is full-scale
+    noise, so the limiter is at work on every block; the reported figure equals the reference binary's and the one of a run without
+    the limiter (a measurement of output - input would come out several dB lower).  Also at 48 kHz (WatermarkResampler path)."""
+    d, noise, marked = work
+    def snr_of(cmd):
+        r = run(cmd)
+        lines = [l for l in (r.stderr + b"\n" + r.stdout[:4096]).decode(errors="replace").splitlines() if l.startswith("SNR:")]
+        assert len(lines) == 1, (cmd, r.stdout[-500:], r.stderr[-500:])
+        return float(lines[0].split()[1])
+    out = str(tmp_path / "o.wav")
+    ours = snr_of([AWM, "add", "--snr", str(noise), out, PAY])
+    nolim = snr_of([AWM, "add", "--snr", "--test-no-limiter", str(noise), out, PAY])
+    assert abs(ours - nolim) < 1e-6 and ours >= 32.3         # (the float mix; test-snr on the 16 bit files: 32.43, test_block_decoder_scenario)
+    # (the limiter does change the output: that difference is what the old report measured)
+    a, b = wav_samples(str(marked)).astype(np.float64), wav_samples(str(noise)).astype(np.float64)
+    assert 10 * np.log10((b ** 2).sum() / ((a - b) ** 2).sum()) < ours - 1
+    if os.path.exists(_ref.BIN):
+        theirs = snr_of([_ref.BIN, "add", "--snr", "--format", "wav-pipe", str(noise), "-", PAY])      # (the oracle build has no libsndfile)
+        assert abs(ours - theirs) < 2e-3, (ours, theirs)
+    noise48 = tmp_path / "noise48.wav"
+    noise48.write_bytes(run([AWM, "test-gen-noise", "-", "60", "48000"]).stdout)
+    s48 = snr_of([AWM, "add", "--snr", str(noise48), out, PAY])
+    s48n = snr_of([AWM, "add", "--snr", "--test-no-limiter", str(noise48), out, PAY])
+    assert abs(s48 - s48n) < 1e-6 and s48 > 30
+
+
 def test_sample_rate_scenario(tmp_path):
     """tests/sample-rate-test.sh of the reference in miniature: 48 kHz and 96 kHz material through `add` and `cmp`
     (resampling to the 44.1 kHz watermark rate and back happens inside; zita-resampler restated, parity unpinned)."""

@@ -127,6 +127,14 @@ def test_add_snr_bound(gpu):
     d = w.astype(np.float64) - x
     snr = 10 * np.log10((x.astype(np.float64) ** 2).sum() / (d ** 2).sum())
     assert snr >= 32.4
+    # the device-side meter behind `add --snr` (awm_ctx_snr_begin / _end) measures the same thing, also with the limiter at work
+    for no_limiter in (True, False):
+        gpu.awm.set_params(test_no_limiter=no_limiter)
+        gpu.ctx.snr_begin()
+        gpu.ctx.add_watermark(None, PAY2, gpu.dev(x))
+        metered = gpu.ctx.snr_end()
+        gpu.awm.set_params()
+        assert abs(metered - snr) < 1e-6, (no_limiter, metered, snr)
 
 
 def test_add_sharded_spans_equal_whole(gpu):
