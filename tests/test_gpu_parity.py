@@ -463,6 +463,39 @@ def test_multi_context_get_equals_single(gpu, minutes, cuts):
         gpu.awm.set_params()
 
 
+def test_get_right_after_add_is_ordered_behind_it(gpu):
+    """add -> get of the same buffer on one context without a wait in between: the chunks of the `get` run on other streams than the
+    `add` and must still see all of its output (event ordering behind the context's stream).  Same patterns as a `get` after a
+    host-side wait, also for a `get` of a PART of the buffer, repeatedly (a missing wait shows as a changed pattern); and the whole-stream
+    `add` equals the tile loop of the file path (whose limiter runs tile by tile) sample by sample on a stream of three chunks."""
+    torch = gpu.torch
+    n = 61 * 60 * 44100 + 777                           # three chunks
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    x = torch.rand((n, 2), generator=g, device="cuda") * 2 - 1
+    out = torch.empty_like(x)
+    gpu.ctx.add_watermark(None, PAY1, x, out=out)
+    torch.cuda.synchronize()
+    plain = [pkey(p) for p in gpu.ctx.get_watermark(None, out)]
+    assert len(plain) > 100
+    reference = out.clone()
+    for _ in range(4):
+        out.zero_()
+        gpu.ctx.add_watermark(None, PAY1, x, out=out)
+        armed = [pkey(p) for p in gpu.ctx.get_watermark(None, out)]
+        assert armed == plain
+        assert torch.equal(out, reference)
+    # a part of the buffer (offset inside the first chunk's segments, whole frames or not)
+    for off in (1024 * 100, 12345):
+        part = out[off:]
+        torch.cuda.synchronize()
+        want = [pkey(p) for p in gpu.ctx.get_watermark(None, part)]
+        gpu.ctx.add_watermark(None, PAY1, x, out=out)
+        assert [pkey(p) for p in gpu.ctx.get_watermark(None, part)] == want
+    # the tile loop of the file path limits tile by tile: the same samples
+    tiles = gpu.ctx.add_watermark_tiles(None, PAY1, x, tile_frames1024=4096)
+    assert torch.equal(tiles, reference)
+
+
 def test_multi_context_short_stream_and_errors(gpu):
     """a stream in the ClipDecoder's range is decoded by rank 0 alone (same patterns); a failing rank does not hang the others"""
     from audiowmark_amd import sharded
