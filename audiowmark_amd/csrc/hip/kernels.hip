@@ -2289,13 +2289,17 @@ soft_bits_kernel (SoftBitsArgs a)
  * 720 loads of a bit were issued almost one after the other (250 us for 31 000 threads on an otherwise idle GPU); here the
  * lanes of a wave fetch the terms in parallel and stage them in LDS, and lane 0 adds them up in the reference's order
  * (wmget.cc:67-108: double accumulators, terms in entry order), which keeps the result bit-identical. */
-constexpr int SB_WAVES = 4;           // bits per workgroup
+constexpr int SB_WAVES = 4;           // waves per workgroup
+constexpr int SB_BPW = 4;             // bits per wave
 constexpr int SB_MAX_ITEMS = 256;     // frames_per_bit * C * 30 terms per bit (stereo: 120); more -> one thread per bit kernel
 
+/* One wave gathers the terms of SB_BPW bits into LDS (64 lanes, coalesced index reads, one term per lane and pass), then lanes
+ * 0 .. SB_BPW - 1 each add up one bit's terms front to back in double, in the reference's order.  (Round 3a: one bit per wave, its sum
+ * on lane 0 alone -- 600 double precision instructions per bit at 1 / 64 of the SIMD: the launch was bound by those additions.) */
 __global__ void __launch_bounds__ (64 * SB_WAVES)
 soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
 {
-  __shared__ float4 s_item[SB_WAVES][SB_MAX_ITEMS];
+  extern __shared__ __attribute__ ((aligned (16))) float4 s_item_dyn[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // XCD-aware order (1-D grid): workgroup id runs on XCD id % 8, and all workgroups of a block go to ONE XCD, so that the
   // block's dB matrix (1.4 MB for stereo) is fetched into one L2 instead of eight (PMC FETCH_SIZE: 278 -> 38 MB fetched per launch for
@@ -2306,8 +2310,8 @@ soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
   if (blk >= a.n_blocks)
     return;
   const int n_bits = a.n_data_frames / a.frames_per_bit;
-  const int bit = group * SB_WAVES + wave;
-  if (bit >= n_bits)
+  const int bit0 = (group * SB_WAVES + wave) * SB_BPW;
+  if (bit0 >= n_bits)
     return;
   const float *db = a.db + blk * a.block_stride;
   const int C = a.n_channels;
@@ -2315,8 +2319,16 @@ soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
   const int16_t *mix_frame = a.mix_frame + mix0;
   const uint8_t *mix_up = a.mix_up + mix0, *mix_down = a.mix_down + mix0;
   const int n_items = a.frames_per_bit * C * 30;
+  float4 *items = s_item_dyn + (size_t) wave * SB_BPW * n_items;
+  const int n_here = min (SB_BPW, n_bits - bit0);
+  // the passes of the four bits are independent: unrolled, their index loads and then their value loads are in flight together (two
+  // memory round trips per group of four passes instead of per pass)
   for (int i = lane; i < n_items; i += 64)
+#pragma unroll
+  for (int q = 0; q < SB_BPW; q++)
     {
+      const int e = q * n_items + i;
+      const int bit = bit0 + min (q, n_here - 1);            // (past the last bit: the last one again, into a slot nobody adds up -- no branch)
       // item order = summation order: frame of the bit, channel, entry
       const int fi = i / (C * 30), ch = (i / 30) % C, j = i % 30;
       const int b = (bit * a.frames_per_bit + fi) * 30 + j;
@@ -2327,21 +2339,22 @@ soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
       const float *plane = db + (long long) ch * NB * a.ld;
       const float *pu = plane + (long long) (mix_up[b] - MIN_BAND) * a.ld;
       const float *pd = plane + (long long) (mix_down[b] - MIN_BAND) * a.ld;
-      s_item[wave][i] = make_float4 (pu[frame], __fadd_rn (pu[prev], pu[next]), pd[frame], __fadd_rn (pd[prev], pd[next]));
+      items[e] = make_float4 (pu[frame], __fadd_rn (pu[prev], pu[next]), pd[frame], __fadd_rn (pd[prev], pd[next]));
     }
   wave_sync();
-  if (lane == 0)
+  if (lane < n_here)
     {
+      const float4 *mine = items + lane * n_items;
       double umag = 0, dmag = 0;
       for (int i = 0; i < n_items; i++)
         {
-          const float4 t = s_item[wave][i];
+          const float4 t = mine[i];
           umag = __dadd_rn (umag, double (t.x));
           umag = __dsub_rn (umag, __dmul_rn (double (t.y), 0.5));
           dmag = __dadd_rn (dmag, double (t.z));
           dmag = __dsub_rn (dmag, __dmul_rn (double (t.w), 0.5));
         }
-      a.out[blk * n_bits + bit] = float (__dsub_rn (umag, dmag));
+      a.out[blk * n_bits + bit0 + lane] = float (__dsub_rn (umag, dmag));
     }
 }
 
@@ -2353,12 +2366,13 @@ launch_soft_bits (hipStream_t st, const SoftBitsArgs& a)
   const int n_bits = a.n_data_frames / a.frames_per_bit;
   if (a.frames_per_bit * a.n_channels * 30 <= SB_MAX_ITEMS)
     {
-      const int groups = (n_bits + SB_WAVES - 1) / SB_WAVES;
+      const int groups = (n_bits + SB_WAVES * SB_BPW - 1) / (SB_WAVES * SB_BPW);
       const long long rounds = (a.n_blocks + 7) / 8;                   // 8 blocks (one per XCD) at a time
       const long long wgs = rounds * groups * 8;
+      const size_t lds = size_t (SB_WAVES) * SB_BPW * (a.frames_per_bit * a.n_channels * 30) * sizeof (float4);
       if (wgs < (1LL << 31))
         {
-          hipLaunchKernelGGL (soft_bits_wave_kernel, dim3 (unsigned (wgs)), dim3 (64 * SB_WAVES), 0, st, a, groups);
+          hipLaunchKernelGGL (soft_bits_wave_kernel, dim3 (unsigned (wgs)), dim3 (64 * SB_WAVES), lds, st, a, groups);
           return hipGetLastError();
         }
     }
