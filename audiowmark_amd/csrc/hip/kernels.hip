@@ -2459,7 +2459,28 @@ soft_prep_kernel (SoftPrepArgs a)
         {
           const int i = inv_order[k];
           float acc0 = 0.f, acc1 = 0.f;                   // all_bits starts at zero and the blocks are added in list order
-          for (int s = 0; s < job.n_src; s++)
+          int s = 0;
+          for (; s + 8 <= job.n_src; s += 8)              // eight loads in flight, the additions in order behind them
+            {
+              float v[8];
+              int half[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++)
+                {
+                  const int2 sp = src[s + u];
+                  v[u] = a.raw[(long long) sp.x * nb + i];
+                  half[u] = sp.y;
+                }
+#pragma unroll
+              for (int u = 0; u < 8; u++)
+                {
+                  if (half[u])
+                    acc1 = __fadd_rn (acc1, v[u]);
+                  else
+                    acc0 = __fadd_rn (acc0, v[u]);
+                }
+            }
+          for (; s < job.n_src; s++)
             {
               const float v = a.raw[(long long) src[s].x * nb + i];
               if (src[s].y)
