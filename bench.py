@@ -60,15 +60,15 @@ PROFILE_DIR = newest_profile_dir()
 
 # HIP-event scope (awm_prof_name) -> (device kernel in the rocprofv3 summaries, what actually limits it)
 KERNELS = {
-    "add_mix_kernel": ("add_mix_kernel_w4<2>", "HBM <-> FP32 issue (1 450 VALU instructions per stereo frame, 4 waves / SIMD)"),
+    "add_mix_kernel": ("add_mix_pair_kernel", "HBM latency <-> FP32 issue (1 450 VALU instructions per stereo frame, 4 waves / SIMD; both channels' transforms pipelined over one LDS tile)"),
     "limiter_kernel": ("limiter_apply_kernel<2>", "HBM"),
-    "sync_db_kernel(approx)": ("sync_db_kernel<2, false, 33>", "FP32 issue (the 4 shifts of a tile share one XCD's L2: PCM read once)"),
-    "sync_scan_kernel(approx)": ("sync_scan_stream_kernel<false>", "works out of LDS, not HBM: 30 ds_read_b128 gathers + 120 float additions per sync frame and wave in the reference's summation order (VALU issue 90 % inside a round, LDS 51 %); 3.3 rounds of tiles"),
+    "sync_db_kernel(approx)": ("sync_db_kernel<2, false, 33>", "FP32 issue and LDS round trips in turn (VALU issues 55 - 60 % of the time; both channels' transforms pipelined over one LDS tile; the 4 shifts of a tile share one XCD's L2: PCM read once)"),
+    "sync_scan_kernel(approx)": ("sync_scan_stream_kernel<false>", "works out of LDS, not HBM: 30 ds_read_b128 gathers + 120 float additions per sync frame and wave in the reference's summation order (LDS active 51 %, VALU issuing 42 % of the cycles); 3.3 rounds of tiles"),
     "local_mean_kernel": ("local_mean_kernel", "latency"),
     "sync_db_kernel(refine)": ("sync_db_sliding3_kernel", "VALU issue (a third of it FP64) + sequential recurrence (65 steps per wave); three bins of one channel per lane, 56 of 64 lanes busy"),
-    "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (150 workgroups)"),
-    "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue"),
-    "soft_bits_kernel": ("soft_bits_wave_kernel", "L2 sectors of scattered reads"),
+    "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (300 single-wave workgroups, 60 loads in flight each)"),
+    "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue and LDS round trips in turn"),
+    "soft_bits_kernel": ("soft_bits_wave_kernel", "latency of scattered reads + sequential double precision sums (four bits per wave)"),
     "viterbi_kernel": ("viterbi_super_kernel<0>", "16 dependent launches per batch of decodes (11 of them carry 12 trellis steps: three rounds of 4 steps in registers, the metrics change hands through LDS in between)"),
 }
 
@@ -555,9 +555,9 @@ def main():
                 lds_tbps = candidates * 510 * 60 * 4 / (kms * 1e-3) / 1e12
                 roofline["lds_gather_of_the_scan"] = {"achieved": round(lds_tbps, 1), "peak": 150.0, "unit": "TB/s", "frac": round(lds_tbps / 150.0, 3),
                                                       "note": "peak at 2.4 GHz; effective clock under this kernel 2.3 GHz (GRBM_GUI_ACTIVE, profiles/r03/effective_clock.txt). "
-                                                              "The kernel issues VALU 90 % of the time inside its rounds (120 dependent-free float additions per sync frame and "
-                                                              "wave, in the reference's order) and its 846 tiles are 3.3 rounds on 256 CUs: the stand-alone time includes a 17 % tail "
-                                                              "that the other lanes fill in the timed configuration"}
+                                                              "Per sync frame and wave 30 gathers feed 120 float additions in the reference's order: the VALU issues 42 % of the cycles (one "
+                                                              "wave64 FP32 instruction per ~2.5 cycles is the SIMD's rate, tools/valu_rate.hip), the LDS is active 51 %; its 846 tiles are "
+                                                              "3.3 rounds on 256 CUs: the stand-alone time includes a 17 % tail that the other lanes fill in the timed configuration"}
             # every kernel above 5 % of the stand-alone GPU time, same definition (algorithmic bytes / stand-alone duration / 8 TB/s)
             roofline["all_kernels_above_5_percent"] = [
                 {"kernel": k, "device_kernel": KERNELS.get(k, (k, ""))[0], "share_of_gpu_time_alone": round(v[1] / total_alone, 3),
