@@ -34,6 +34,7 @@
 //   this kernel                                       0.37 ms   = 70 TB/s of gathered terms; the shader clock is ~1.6 GHz
 //                                                                 under this load, where 256 B/clk/CU is 105 TB/s
 #include "kernels.hh"
+#include <type_traits>
 
 namespace awmk {
 
@@ -227,15 +228,26 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
   else
     {
       /* ---- one chain ---- */
-      const_uint_ptr tab = (const_uint_ptr) (a.table.chains + (size_t) (blockIdx.y / a.table.planes_per_slice) * a.table.chains_slice_stride
-                                             + (size_t) wv * R * 8);
+      // The row descriptors come through the VECTOR memory path (every lane reads the same 32 bytes, the values go to scalar registers
+      // with v_readfirstlane when the row starts): a scalar load shares its counter with the LDS gathers and returns out of order, so
+      // hipcc waits for it right after issuing it (s_waitcnt lgkmcnt(0)) -- round 2's "requested a row ahead" cost the full load latency
+      // per row, 40 % of the kernel.  vmcnt belongs to the descriptors alone in a chain wave.
+      int vzero = 0;
+      asm volatile ("" : "+v" (vzero));                    // (a uniform address would be turned back into a scalar load)
+      const unsigned *tab = a.table.chains + (size_t) (blockIdx.y / a.table.planes_per_slice) * a.table.chains_slice_stride
+                          + (size_t) wv * R * 8 + vzero;
       int loaded = 0;
-      unsigned rowdesc[2][8];                              // 30 band bytes + u16 frame of the next row
-      auto load_row = [&] (unsigned (&w)[8], int r) {
-        const_uint_ptr tr = tab + r * 8;
+      uint4 rowdesc[2][2];                                 // 30 band bytes + u16 frame of the next row
+      auto load_row = [&] (uint4 (&w)[2], int r) {
+        const uint4 *tr = reinterpret_cast<const uint4 *> (tab + r * 8);
+        w[0] = tr[0];
+        w[1] = tr[1];
+      };
+      auto to_scalar = [] (const uint4 (&v)[2], unsigned (&w)[8]) {
+        const unsigned e[8] = { v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w };
 #pragma unroll
         for (int i = 0; i < 8; i++)
-          w[i] = tr[i];                                    // no arithmetic here: the scalar load stays in flight until the row starts
+          w[i] = __builtin_amdgcn_readfirstlane (e[i]);
       };
       auto row = [&] (const unsigned (&w)[8], int fr) {
         if (!live (fr))
@@ -251,24 +263,41 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
         int phys = (fr - j) % RINGF + 4 * lane;
         phys -= phys >= RINGF ? RINGF : 0;
         const char *base = reinterpret_cast<const char *> (s_win + (phys >> 6) * SLOT_FLOATS + (phys & 63));
+        // 30 gathers + 120 additions in the reference's order, software-pipelined: the gathers of the next batch of bands are in
+        // flight while the additions of this one issue (two buffers of 8 quads; round 2: three batches of 10, each one waiting for
+        // its own gathers first -- the switch over the alignment stood between a batch's additions and the next batch's gathers)
+        auto gather = [&] (float4 (&v)[8], int t0, int n) {
 #pragma unroll
-        for (int h = 0; h < 3; h++)
-          {
-            float4 v[10];
-#pragma unroll
-            for (int i = 0; i < 10; i++)
+          for (int i = 0; i < 8; i++)
+            if (i < n)
               {
-                const int t = 10 * h + i;
+                const int t = t0 + i;
                 const unsigned band = (w[t >> 2] >> (8 * (t & 3))) & 0xff;
                 v[i] = *reinterpret_cast<const float4 *> (base + (band << 8));        // a band of a chunk = 64 floats
               }
-            switch (j)
-              {
-              case 0:  add_terms<0> (acc, v); break;
-              case 1:  add_terms<1> (acc, v); break;
-              case 2:  add_terms<2> (acc, v); break;
-              default: add_terms<3> (acc, v); break;
-              }
+        };
+        auto body = [&] (auto jc) {
+          constexpr int J = decltype (jc)::value;
+          float4 va[8], vb[8];
+          gather (va, 0, 8);
+          gather (vb, 8, 8);
+          add_terms<J, 8> (acc, va);
+          gather (va, 16, 8);
+          add_terms<J, 8> (acc, vb);
+          gather (vb, 24, 6);
+          add_terms<J, 8> (acc, va);
+          float4 vl[6];
+#pragma unroll
+          for (int i = 0; i < 6; i++)
+            vl[i] = vb[i];
+          add_terms<J, 6> (acc, vl);
+        };
+        switch (j)
+          {
+          case 0:  body (std::integral_constant<int, 0>()); break;
+          case 1:  body (std::integral_constant<int, 1>()); break;
+          case 2:  body (std::integral_constant<int, 2>()); break;
+          default: body (std::integral_constant<int, 3>()); break;
           }
       };
       auto done_with = [&] (int next_frame) {
@@ -310,17 +339,20 @@ sync_scan_stream_kernel (SyncScanArgs a, int total_frames)
         }
       for (int r = r_lo; r < r_hi; r += 2)
         {
+          unsigned w[8];
+          to_scalar (rowdesc[0], w);
           if (r + 1 < r_hi)
             load_row (rowdesc[1], r + 1);
-          row (rowdesc[0], fr);
-          fr = next_frame (rowdesc[0]);
+          row (w, fr);
+          fr = next_frame (w);
           done_with (fr);
           if (r + 1 < r_hi)
             {
+              to_scalar (rowdesc[1], w);
               if (r + 2 < r_hi)
                 load_row (rowdesc[0], r + 2);
-              row (rowdesc[1], fr);
-              fr = next_frame (rowdesc[1]);
+              row (w, fr);
+              fr = next_frame (w);
               done_with (fr);
             }
         }

@@ -29,6 +29,9 @@ rate_kernel (float *out, float seed)
 #define PKADD(i) asm volatile ("v_pk_add_f32 %0, %0, %1" : "+v" (p[i]) : "v" (pc));
 #define PKMUL(i) asm volatile ("v_pk_mul_f32 %0, %0, %1" : "+v" (p[i]) : "v" (pm));
 #define PKADDSEL(i) asm volatile ("v_pk_add_f32 %0, %0, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "+v" (p[i]) : "v" (pc));
+#define DPPWAVE(i) asm volatile ("v_add_f32_dpp %0, %1, %0 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v" (a[i]) : "v" (a[(i + 1) & 15]));
+#define DPPROW(i)  asm volatile ("v_add_f32_dpp %0, %1, %0 row_shl:1 row_mask:0xf bank_mask:0xf" : "+v" (a[i]) : "v" (a[(i + 1) & 15]));
+#define DPPQUAD(i) asm volatile ("v_add_f32_dpp %0, %1, %0 quad_perm:[1,2,3,0] row_mask:0xf bank_mask:0xf" : "+v" (a[i]) : "v" (a[(i + 1) & 15]));
 #define F64FMA(i) asm volatile ("v_fma_f64 %0, %0, %1, %2" : "+v" (d[i]) : "v" (dm), "v" (dc));
       if (OP == 0) { R16 (FMA) R16 (FMA) }
       if (OP == 1) { R16 (ADD) R16 (ADD) }
@@ -38,6 +41,9 @@ rate_kernel (float *out, float seed)
       if (OP == 5) { R16 (PKMUL) R16 (PKMUL) }
       if (OP == 6) { R16 (PKADDSEL) R16 (PKADDSEL) }
       if (OP == 7) { R16 (FMA) R16 (PKFMA) }
+      if (OP == 8) { R16 (DPPWAVE) R16 (DPPWAVE) }
+      if (OP == 9) { R16 (DPPROW) R16 (DPPROW) }
+      if (OP == 10) { R16 (DPPQUAD) R16 (DPPQUAD) }
     }
   float s = 0;
   for (int i = 0; i < 16; i++)
@@ -103,6 +109,9 @@ main()
   run ("v_pk_mul_f32", rate_kernel<5>, 2, out);
   run ("v_pk_add_f32 op_sel neg_hi", rate_kernel<6>, 2, out);
   run ("v_fma_f32 + v_pk_fma_f32 (1:1)", rate_kernel<7>, 3, out);
+  run ("v_add_f32_dpp wave_shl:1", rate_kernel<8>, 1, out);
+  run ("v_add_f32_dpp row_shl:1", rate_kernel<9>, 1, out);
+  run ("v_add_f32_dpp quad_perm", rate_kernel<10>, 1, out);
   run ("v_fma_f64", rate_kernel_d<0>, 2, out);
   return 0;
 }
