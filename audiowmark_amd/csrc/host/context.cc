@@ -604,6 +604,11 @@ awm_ctx_destroy (awm_ctx *ctx)
     t->ctab.release();
   awm::speed_workspace_free (ctx);
   ctx->ws_snr.release();
+  ctx->ws_merge_soft.release();
+  for (hipEvent_t e : ctx->merge_events)
+    if (e)
+      (void) hipEventDestroy (e);
+  ctx->merge_events.clear();
   ctx->ws_rate_a.release();
   ctx->ws_rate_b.release();
   ctx->ws_rate_c.release();

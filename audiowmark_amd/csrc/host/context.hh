@@ -203,6 +203,8 @@ struct awm_ctx : awm::WorkLane
   hipStream_t    get_copy_stream();
   std::vector<awm_ctx *> helpers;        // other GPUs the file level `get` may spread a long stream over (awm_ctx_set_helpers; not owned)
   std::unique_ptr<awm::ParamValues> own_params;   // settings of this context (awm_ctx_set_params); null: the process-wide ones
+  awm::DevBuffer ws_merge_soft;          // raw soft bits of the chunks of one `get` whose decodes run as ONE batch at the end (wmget.cc: block_decoder_run)
+  std::vector<hipEvent_t> merge_events;  // one per chunk in flight: its rows are in ws_merge_soft
   awm::DevBuffer ws_snr;                 // `add --snr`: { power of the watermark signal, power of the input } accumulated by every mix while snr_on
   bool           snr_on = false;
   int            chunk_lanes = awm::CHUNK_LANES;   // lanes the chunks of one stream may be spread over (awm_ctx_set_chunk_lanes)

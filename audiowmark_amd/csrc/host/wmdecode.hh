@@ -40,7 +40,8 @@ struct DecodeJob
 
 int block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWav& wav, const std::vector<size_t>& index,
                          std::vector<int>& slot_of, std::vector<char>& ok, const long long *slice_range = nullptr, size_t slice_frames = 0);
-int decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job);
+// raw (optional): the rows the jobs' source slots index, instead of the lane's ws_soft
+int decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job, const float *raw = nullptr);
 // patterns_out (optional): the decoded patterns go there as (position in job.pending, bits, error) instead of into result_sets
 struct DecodedPattern { size_t pending_index; std::vector<int> bits; float error; };
 int decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::vector<ResultSet *>& result_sets, double speed,

@@ -258,7 +258,7 @@ viterbi_decode (awm_ctx *ctx, ConvBlockType block_type, const std::vector<std::v
 /* ---- BlockDecoder (reference wmget.cc:492-735) ---------------------------------------- */
 
 int
-decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job)
+decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job, const float *raw)
 {
   job.launched = false;
   for (auto& w : job.which)
@@ -320,7 +320,7 @@ decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job)
   if (int rc = lane->pin_bits.reserve (job.bits_total * sizeof (int) + job.err_total * sizeof (float))) return rc;
   AWM_HIP_CHECK (hipMemcpyAsync (lane->ws_jobs.ptr, lane->pin_jobs.ptr, table_bytes, hipMemcpyHostToDevice, st));
   awmk::SoftPrepArgs pa {};
-  pa.raw = lane->ws_soft.as<float>();
+  pa.raw = raw ? raw : lane->ws_soft.as<float>();
   pa.n_bits = n_bits;
   pa.inv_order = kt->bit_order_inv_dev.as<int>();
   pa.jobs = lane->ws_jobs.as<awmk::SoftJobDev>();
@@ -491,6 +491,11 @@ combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const Device
 
 namespace {
 
+}  // namespace
+int g_merge_decodes = 0;         // (debug toggle, off: the decodes of all chunks of a `get` as one batch at the end -- see block_decoder_run)
+extern "C" void awm_debug_set_merge_decodes (int on) { g_merge_decodes = on; }
+namespace {
+
 /* BlockDecoder::run (reference wmget.cc:502-706) for several chunks of one resident stream at once.  Every chunk
  * is searched and combined on its own exactly like the reference does; only the device work is batched across
  * chunks (soft bits in one pass, one Viterbi launch per code type). */
@@ -570,6 +575,32 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
   std::vector<ChunkState> active;
   std::vector<char> lane_busy (lanes.size(), 0);
   size_t next_chunk = 0;
+  /* Alternative behind awm_debug_set_merge_decodes (off): for a stream of up to CHUNK_LANES chunks the decodes of ALL chunks run as one
+   * batch per key at the end.  A chunk's ~37 Viterbi jobs are one wave per SIMD, and a single wave gets an instruction out only every
+   * ~5 cycles, so the 16 dependent launches of a batch cost the same for 37 jobs as for 150: stand-alone the decoder of a 60 min step
+   * takes 0.49 instead of 0.92 ms.  The STEP is 3 % slower with it (5.33 - 5.41 against 5.17 - 5.22 ms, alternating in one process,
+   * profiles/r03/variants.txt): per chunk, the decode chains of the first chunks run beside the wide kernels of the others and only the
+   * last chunk's chain is exposed; as one batch the whole chain starts when the last chunk has its soft bits.  (8 h: per chunk 49 ms,
+   * one batch at the end 54, batches of 128 jobs on a lane of their own 61 -- the host thread that feeds all lanes waits for the batch
+   * before.)  A chunk copies the raw soft bits of its blocks into a buffer of the context (its own rows, on its own lane), appends its
+   * jobs to the key's list and goes on; rows that do not fit the buffer are decoded at once, per chunk. */
+  const int n_soft_bits = mark_data_frame_count() / params().frames_per_bit;
+  struct Deferred
+  {
+    DecodeJob job;
+    std::vector<hipEvent_t> rows_ready;
+  };
+  std::vector<Deferred> deferred (key_list.size());
+  size_t merge_rows = 0, merge_capacity = 0;
+  if (g_merge_decodes && chunks.size() > 1 && chunks.size() <= size_t (CHUNK_LANES))
+    {
+      for (const auto& c : chunks)
+        merge_capacity += 2 * (c.n_frames / (count * Params::frame_size) + 4);
+      merge_capacity *= key_list.size();
+      if (ctx->ws_merge_soft.reserve (merge_capacity * n_soft_bits * sizeof (float)))
+        merge_capacity = 0;
+    }
+  size_t merge_events_used = 0;
   auto advance = [&] (ChunkState& cs) -> int {
     const Key& key = key_list[cs.ki];
     KeyTables *kt = ctx->get_key_tables (key);
@@ -632,6 +663,38 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
               pattern_raw_vec.push_back (rb);
             }
           combine_blocks (pattern_raw_vec, stream, c, pending);
+          size_t n_rows = 0;
+          for (size_t w = 0; w < wanted.size(); w++)
+            if (ok[w])
+              n_rows = std::max (n_rows, size_t (slot_of[w]) + 1);
+          if (merge_rows + n_rows <= merge_capacity && !pending.empty())
+            {
+              // rows -> the context's buffer (this lane's stream), jobs -> the key's list with their source rows renumbered
+              hipStream_t st = cs.lane->stream;
+              AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_merge_soft.as<float>() + merge_rows * n_soft_bits, cs.lane->ws_soft.ptr,
+                                             n_rows * n_soft_bits * sizeof (float), hipMemcpyDeviceToDevice, st));
+              if (merge_events_used == ctx->merge_events.size())
+                {
+                  hipEvent_t e = nullptr;
+                  AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
+                  ctx->merge_events.push_back (e);
+                }
+              hipEvent_t ev = ctx->merge_events[merge_events_used++];
+              AWM_HIP_CHECK (hipEventRecord (ev, st));
+              Deferred& d = deferred[cs.ki];
+              d.rows_ready.push_back (ev);
+              for (auto& p : pending)
+                {
+                  for (auto& sp : p.src)
+                    sp.first += int (merge_rows);
+                  d.job.pending.push_back (std::move (p));
+                }
+              merge_rows += n_rows;
+              cs.decode = DecodeJob();
+              cs.ki++;
+              cs.stage = cs.ki < key_list.size() ? 0 : 4;
+              return 0;
+            }
           if (int rc = decode_launch (ctx, cs.lane, kt, cs.decode))
             return rc;
           cs.stage = 3;
@@ -689,6 +752,22 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
           i++;
       if (!progressed)
         std::this_thread::yield();
+    }
+  for (size_t ki = 0; ki < key_list.size(); ki++)
+    {
+      Deferred& d = deferred[ki];
+      if (d.job.pending.empty())
+        continue;
+      KeyTables *kt = ctx->get_key_tables (key_list[ki]);
+      if (!kt)
+        return AWM_ERR_HIP;
+      WorkLane *lane = lanes[0];                           // (every chunk is through: its workspaces are free)
+      for (hipEvent_t ev : d.rows_ready)
+        AWM_HIP_CHECK (hipStreamWaitEvent (lane->stream, ev, 0));
+      if (int rc = decode_launch (ctx, lane, kt, d.job, ctx->ws_merge_soft.as<float>()))
+        return rc;
+      if (int rc = decode_finish (lane, key_list[ki], d.job, result_sets, speed))
+        return rc;
     }
   drain.ok = true;
   if (debug_sync_first_chunk)
