@@ -130,10 +130,19 @@ def cpu_baseline_and_parity(torch, awm, ctx, sample_seconds):
     pats = impl.get(None, w, 2)
     t2 = time.perf_counter()
     ok = sum(p["bits"] == PAYLOAD for p in pats)
-    cores = os.cpu_count() if kind == "reference" else 1
+    threads = os.cpu_count() if kind == "reference" else 1
+    # what the process may actually use: the box gives a container a CPU quota (cgroup cpu.max, e.g. "1600000 100000" = 16 cores)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        pass
+    cores = threads if quota is None else max(1, min(threads, int(round(quota))))
     base = {"value": round(sample_seconds / (t2 - t0), 2), "unit": "xRT", "cores": cores, "kind": kind,
             "sample": f"{sample_seconds / 60:.0f} min stereo 44.1 kHz test-gen-noise, add {t1 - t0:.2f} s (1 thread) + get {t2 - t1:.2f} s "
-                      f"({cores} threads), {ok} of {len(pats)} patterns carry the payload; FFTW replaced by the oracle's double-precision FFT"}
+                      f"({threads} threads" + (f", CPU quota of the process {quota:g} cores" if quota is not None else "") +
+                      f"), {ok} of {len(pats)} patterns carry the payload; FFTW replaced by the oracle's double-precision FFT"}
     # parity of the HIP path against this very run
     xd = torch.from_numpy(x.reshape(n, 2)).cuda()
     wg = ctx.add_watermark(None, PAYLOAD, xd).cpu().numpy().ravel()
