@@ -2358,13 +2358,16 @@ soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
     }
 }
 
+int g_soft_bits_generic = 0;     // (debug toggle: the one-thread-per-bit kernel for every shape)
+extern "C" void awm_debug_set_soft_bits_generic (int on) { g_soft_bits_generic = on; }
+
 hipError_t
 launch_soft_bits (hipStream_t st, const SoftBitsArgs& a)
 {
   if (a.n_blocks <= 0)
     return hipSuccess;
   const int n_bits = a.n_data_frames / a.frames_per_bit;
-  if (a.frames_per_bit * a.n_channels * 30 <= SB_MAX_ITEMS)
+  if (!g_soft_bits_generic && a.frames_per_bit * a.n_channels * 30 <= SB_MAX_ITEMS)
     {
       const int groups = (n_bits + SB_WAVES * SB_BPW - 1) / (SB_WAVES * SB_BPW);
       const long long rounds = (a.n_blocks + 7) / 8;                   // 8 blocks (one per XCD) at a time

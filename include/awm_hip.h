@@ -372,6 +372,7 @@ int    awm_speed_clip_candidates (const uint8_t key[16], const float *hashed_val
  *   sliding3:      1 (default) refinement with three bins of one channel per lane / 0 two bins of both channels (stereo) */
 void awm_debug_set_viterbi_super (int on);
 void awm_debug_set_sliding3 (int on);
+void awm_debug_set_soft_bits_generic (int on); /* K7: one thread per soft bit for every shape (the fallback kernel) | four bits per wave */
 void awm_debug_set_merge_decodes (int on);  /* get of a stream of 2 - 4 chunks: the chunks' Viterbi jobs as ONE batch at the end | per chunk (default: the step is faster) */
 void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transforms pipelined in one wave (default) | one after the other */
 

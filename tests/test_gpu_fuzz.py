@@ -38,9 +38,15 @@ def make_case(rng, max_seconds):
     return np.ascontiguousarray(x), ch, marked
 
 
+JUNK_ERROR = 0.6       # decode error from which on a pattern is a Viterbi decode of noise (tests/test_gpu_fullsize_ref.py)
+
+
 def same_patterns(got, want):
     """identical lists; a refinement tie (neighbouring fine offsets whose qualities agree to float rounding, see
-    tests/test_gpu_fullsize_ref.py compare_patterns) is tolerated once per clip and counted"""
+    tests/test_gpu_fullsize_ref.py compare_patterns) is tolerated once per clip and counted; the 128 bits of a decode of NOISE
+    (oracle decode error >= 0.6: the n_best fallback of a clip without a watermark) hang on path metric differences at float
+    rounding level and may differ with the FFT's rounding -- position, types and quality must still agree (seed 7 of
+    tools/gpu_fuzz.py has one; the one-thread-per-bit soft bit kernel gives the same bits as the wave kernel there)"""
     if len(got) != len(want):
         return False, 0
     ties = 0
@@ -49,6 +55,8 @@ def same_patterns(got, want):
             return False, ties
         if key(g) == key(w):
             continue
+        if key(g)[:4] == key(w)[:4] and w["decode_error"] >= JUNK_ERROR and g["decode_error"] >= JUNK_ERROR:
+            continue
         if (g["type"], g["block_type"], g["bits"]) == (w["type"], w["block_type"], w["bits"]) and abs(int(g["sync_index"]) - int(w["sync_index"])) <= 8:
             ties += 1
             continue
@@ -56,7 +64,7 @@ def same_patterns(got, want):
     return ties <= 3, ties
 
 
-@pytest.mark.parametrize("seed,max_seconds", [(1, 70.0), (2, 125.0)])
+@pytest.mark.parametrize("seed,max_seconds", [(1, 70.0), (2, 125.0), (7, 130.0)])
 def test_random_clips_equal_oracle(seed, max_seconds):
     import torch
     import audiowmark_amd as awm

@@ -15,6 +15,8 @@ n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 16
 max_seconds = float(sys.argv[3]) if len(sys.argv) > 3 else 70.0       # > 110: whole blocks, the BLOCK search (K5w) sees the gaps too
 rng = np.random.default_rng(seed)
 ctx = awm.Context()
+if len(sys.argv) > 4:                                        # A / B of a kernel formulation on the same material
+    awm.lib.awm_debug_set_soft_bits_generic(int(sys.argv[4]))
 PAY = "0123456789abcdef0011223344556677"
 
 
@@ -46,14 +48,16 @@ for case in range(n_cases):
     kept.setdefault(ch, []).append((xd, got))
     want = orc.get(None, x, ch)
     dq = max([abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(got, want)] + [0.0])
-    ok = [key(p) for p in got] == [key(p) for p in want] and dq < 1e-4
+    # (the bits of a decode of NOISE -- decode error >= 0.6 on both sides -- may differ with the FFT's rounding: position and types count)
+    junk = lambda a, b: key(a)[:4] == key(b)[:4] and a["decode_error"] >= 0.6 and b["decode_error"] >= 0.6
+    ok = len(got) == len(want) and all(key(a) == key(b) or junk(a, b) for a, b in zip(got, want)) and dq < 1e-4
     hits = sum(p["bits"] == PAY for p in got)
     print("case %2d: %d ch %5.1f s lead %6d trail %6d marked %d -> %2d patterns, %d with the payload, max |dq| %.2g, %s"
           % (case, ch, len(x) / 44100, lead, trail, marked, len(got), hits, dq, "identical" if ok else "DIFFERENT"), flush=True)
     if not ok:
         bad += 1
         for g, w in zip(got, want):
-            if key(g) != key(w) or abs(g["sync_quality"] - w["sync_quality"]) >= 1e-4:
+            if (key(g) != key(w) and not junk(g, w)) or abs(g["sync_quality"] - w["sync_quality"]) >= 1e-4:
                 print("    gpu", key(g), g["sync_quality"], "\n    orc", key(w), w["sync_quality"])
                 break
 # the same material through awm_get_watermark_batch_d (groups of padded clips for the short ones, one per lane for the others)
