@@ -292,7 +292,7 @@ constexpr int SUPER_LDS = 16 * 324;
 
 template<int BT, int NPF> __device__ __forceinline__ void
 viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_out, unsigned int *dec, const size_t (&dec_off)[3],
-                     int g, int lane, float *lds_a, float *lds_b, bool in_perm, bool out_perm)
+                     int g, int lane, float *lds_a, float *lds_b, bool in_perm, bool out_perm, bool first = false)
 {
   /* Metric layout between two of these launches: PERMUTED, state s at (s & 7) * 4096 + (s >> 3) -- the family a workgroup reads
    * (states with the low bits g) is then one contiguous 16 KB block, a wave's 64 loads one 256-byte run; in the natural layout
@@ -305,7 +305,8 @@ viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_
   const int L1 = (lane << 3) | g;
 #pragma unroll
   for (int j = 0; j < 16; j++)
-    m[j] = in_perm ? m_in[g * 4096 + ((j << 8) | lane)] : m_in[L1 + j * 2048];
+    m[j] = first ? ((L1 | j) == 0 ? 0.f : -1.f)              // start state 0, everything else unreachable (convcode.cc:144-146)
+                 : in_perm ? m_in[g * 4096 + ((j << 8) | lane)] : m_in[L1 + j * 2048];
   const int hi = lane >> 4, lo = lane & 15;
 #pragma unroll
   for (int r = 0; r < 3; r++)
@@ -401,22 +402,13 @@ struct TracePlan
   int final_parity;                                        // which metric buffer holds the last step's metrics
 };
 
-/* one lane per block walks the survivors back, round by round (one aligned load of the lane's decision words per round) */
-__global__ void __launch_bounds__ (64)
-viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
+/* one lane walks the survivors of a decode back, round by round (one aligned load of the lane's decision words per round) */
+__device__ __forceinline__ void
+viterbi_trace_one (const TracePlan& plan, int final_parity, const unsigned char *ws, int n_steps, int rate, int *bits, float *error)
 {
-  const int total = b.n[0] + b.n[1] + b.n[2];
-  int blk = blockIdx.x * 64 + threadIdx.x, t = 0;
-  if (blk >= total)
-    return;
-  if (blk >= b.n[0]) { blk -= b.n[0]; t = 1; }
-  if (t == 1 && blk >= b.n[1]) { blk -= b.n[1]; t = 2; }
-  const int rate = t == 2 ? 12 : 6;
-  const unsigned char *ws = b.ws[t] + (size_t) blk * b.block_ws_bytes;
-  const float *metric = reinterpret_cast<const float *> (ws + (plan.final_parity ? V_METRIC_BYTES : 0));
+  const float *metric = reinterpret_cast<const float *> (ws + (final_parity ? V_METRIC_BYTES : 0));
   const unsigned int *dec = reinterpret_cast<const unsigned int *> (ws + 2 * V_METRIC_BYTES);
-  b.error[t][blk] = metric[0] / float (b.n_steps * rate);  // convcode.cc:197-199: state 0 at the end
-  int *bits = b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER);
+  *error = metric[0] / float (n_steps * rate);             // convcode.cc:197-199: state 0 at the end
   unsigned state = 0;
   for (int r = plan.n_rounds - 1; r >= 0; r--)
     {
@@ -433,12 +425,168 @@ viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
       for (int i = K; i >= 1; i--)
         {
           const int step = plan.step0[r] + i - 1;
-          if (step < b.n_steps - V_ORDER)
+          if (step < n_steps - V_ORDER)
             bits[step] = loc & 1;                          // the input bit of this step is the state's low bit
           const unsigned choose_high = (w[i - 1] >> loc) & 1;
           loc = (loc >> 1) | (choose_high << (K - 1));
         }
       state = L + (loc << (V_ORDER - K));                  // state before the round
+    }
+}
+
+__global__ void __launch_bounds__ (64)
+viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
+{
+  const int total = b.n[0] + b.n[1] + b.n[2];
+  int blk = blockIdx.x * 64 + threadIdx.x, t = 0;
+  if (blk >= total)
+    return;
+  if (blk >= b.n[0]) { blk -= b.n[0]; t = 1; }
+  if (t == 1 && blk >= b.n[1]) { blk -= b.n[1]; t = 2; }
+  viterbi_trace_one (plan, plan.final_parity, b.ws[t] + (size_t) blk * b.block_ws_bytes, b.n_steps, t == 2 ? 12 : 6,
+                     b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER), &b.error[t][blk]);
+}
+
+/* ---- ONE launch per batch of decodes ---------------------------------------------------------------------------------------------
+ * The chain above is 16 dependent launches (init, 11 x 12 steps, 4, 4, 3, trace) of 18 - 30 us each for a chunk's ~37 decodes, and
+ * what a batch costs is decided by the gaps between them: 0.9 ms per bench step from the kernels' own durations, 1.5 - 2.4 ms
+ * between the HIP events on two different boxes.  The launches exist only because the 8 workgroups of a decode must exchange their
+ * metrics every 12 steps -- a barrier among 8 workgroups, not across the grid.  So here a batch is one launch of 8 workgroups per
+ * decode that stay resident for all 143 steps; between two exchanges they meet at a per-decode counter in global memory
+ * (agent-scope release / acquire around a relaxed atomic: the compiler's L2 write-back and invalidate make the metrics and
+ * decision words of the other XCDs' workgroups visible), the first round starts from the initial metrics without reading them,
+ * and the workgroup with family 0 walks the survivors back at the end.
+ *   Which (decode, family) a workgroup works on is NOT its blockIdx: it draws a ticket when it starts (atomic counter), decode =
+ * ticket / 8, family = ticket % 8.  So the workgroups that are resident always hold the lowest tickets, the peers a waiting
+ * workgroup needs are either resident or the very next ones to start, and at most one decode per launch (<= 7 workgroups) can be
+ * waiting for workgroups that are not resident yet -- no deadlock whatever the batch size, the number of lanes launching such
+ * kernels side by side, or other kernels holding compute units (a static blockIdx -> decode map can deadlock when two such
+ * launches oversubscribe the chip: each XCD dispatches its share of a grid on its own).
+ *   The counters are self-cleaning (zero when the launch ends: the family-0 workgroup clears its decode's counter after the last
+ * wait, the last workgroup to leave clears ticket and exit counters), so a lane's sync block is zeroed once, when it is allocated.
+ * A wait that lasts longer than ~2 s of wall time (a fault elsewhere) gives up and marks the batch: every decode then reports the
+ * impossible error value -1 and the host fails the call instead of hanging the GPU.
+ * sync block (unsigned int): [0] ticket, [1] workgroups that left, [2] failure mark, [16 (1 + d)] counter of decode d */
+constexpr int SYNC_STRIDE = 16;
+
+__device__ __forceinline__ void
+decode_barrier (unsigned int *counter, unsigned int target, unsigned int *fail, bool wait = true)
+{
+  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "agent");
+  __syncthreads();
+  if (threadIdx.x == 0)
+    __hip_atomic_fetch_add (counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (!wait)                                               // (arrive only: the last meeting of a workgroup that has nothing left to read)
+    return;
+  if (threadIdx.x == 0)
+    {
+      const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+      while (__hip_atomic_load (counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
+        {
+          __builtin_amdgcn_s_sleep (4);
+          if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull || __hip_atomic_load (fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            {
+              __hip_atomic_store (fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              break;
+            }
+        }
+    }
+  __syncthreads();
+  __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
+}
+
+template<int BT> __device__ __forceinline__ void
+viterbi_persistent_decode (const ViterbiBatch& b, const TracePlan& plan, int n_super, int blk, int g, int lane, unsigned int *counter,
+                           unsigned int *fail, float *lds_a, float *lds_b)
+{
+  constexpr int t = BT, rate = BT == 2 ? 12 : 6;
+  unsigned char *ws = b.ws[t] + (size_t) blk * b.block_ws_bytes;
+  float *metric[2] = { reinterpret_cast<float *> (ws), reinterpret_cast<float *> (ws + V_METRIC_BYTES) };
+  unsigned int *dec = reinterpret_cast<unsigned int *> (ws + 2 * V_METRIC_BYTES);
+  const float *coded = b.soft[t] + (size_t) blk * b.n_steps * rate;
+  const bool finite = coded[0] == coded[0];              // (see viterbi_round_kernel)
+  int parity = 0;
+  unsigned int meetings = 0;
+  if (n_super == 0)
+    {
+      for (int i = g * 4096 + lane; i < (g + 1) * 4096; i += V_WG)
+        metric[0][i] = i == 0 ? 0.f : -1.f;
+      decode_barrier (counter, 8 * ++meetings, fail);
+    }
+  for (int s = 0; s < n_super; s++)
+    {
+      const int r = 3 * s, step0 = plan.step0[r];
+      const size_t off[3] = { plan.dec_offset[r], plan.dec_offset[r + 1], plan.dec_offset[r + 2] };
+      int npf = 0;
+      for (int q = 0; q < 3; q++)
+        npf += plan.step0[r + q] < V_ORDER;
+      if (!finite)
+        npf = 3;
+      const float *m_in = metric[parity];
+      float *m_out = metric[parity ^ 1];
+      const bool in_perm = s > 0, out_perm = s + 1 < n_super, first = s == 0;
+      if (npf == 0)      viterbi_super_round<BT, 0> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
+      else if (npf == 1) viterbi_super_round<BT, 1> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
+      else if (npf == 2) viterbi_super_round<BT, 2> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
+      else               viterbi_super_round<BT, 3> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
+      parity ^= 1;
+      decode_barrier (counter, 8 * ++meetings, fail, g == 0 || r + 3 < plan.n_rounds);
+    }
+  for (int r = 3 * n_super; r < plan.n_rounds; r++)
+    {
+      const int k = plan.k[r], step0 = plan.step0[r];
+      const bool plain = step0 >= V_ORDER && finite;
+      const float *m_in = metric[parity];
+      float *m_out = metric[parity ^ 1];
+      unsigned int *d = dec + plan.dec_offset[r];
+      for (int L = g * V_WG + lane; L < (V_STATES >> k); L += 8 * V_WG)
+        {
+          if (k == 4 && plain)  viterbi_round<BT, 4, true> (coded, step0, m_in, m_out, d, L);
+          else if (k == 4)      viterbi_round<BT, 4, false> (coded, step0, m_in, m_out, d, L);
+          else if (plain)       viterbi_round<BT, 3, true> (coded, step0, m_in, m_out, d, L);
+          else                  viterbi_round<BT, 3, false> (coded, step0, m_in, m_out, d, L);
+        }
+      parity ^= 1;
+      decode_barrier (counter, 8 * ++meetings, fail, g == 0 || r + 1 < plan.n_rounds);       // after the last round only the tracer waits
+    }
+  if (g == 0 && lane == 0)
+    {
+      // (all eight have arrived for the last time and only this workgroup waited: nobody looks at the counter any more)
+      __hip_atomic_store (counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float err;
+      viterbi_trace_one (plan, parity, ws, b.n_steps, rate, b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER), &err);
+      b.error[t][blk] = __hip_atomic_load (fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? -1.f : err;
+    }
+}
+
+__global__ void __launch_bounds__ (V_WG)
+viterbi_persistent_kernel (ViterbiBatch b, TracePlan plan, int n_super, unsigned int *sync)
+{
+  __shared__ float lds_a[SUPER_LDS], lds_b[SUPER_LDS];
+  __shared__ unsigned int my_ticket;
+  const int lane = threadIdx.x;
+  if (lane == 0)
+    my_ticket = __hip_atomic_fetch_add (&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  const unsigned int ticket = my_ticket;
+  const int decode = int (ticket >> 3), g = int (ticket & 7);
+  int blk = decode, t = 0;
+  if (blk >= b.n[0]) { blk -= b.n[0]; t = 1; }
+  if (t == 1 && blk >= b.n[1]) { blk -= b.n[1]; t = 2; }
+  unsigned int *counter = sync + SYNC_STRIDE * (1 + decode), *fail = sync + 2;
+  if (t == 0)      viterbi_persistent_decode<0> (b, plan, n_super, blk, g, lane, counter, fail, lds_a, lds_b);
+  else if (t == 1) viterbi_persistent_decode<1> (b, plan, n_super, blk, g, lane, counter, fail, lds_a, lds_b);
+  else             viterbi_persistent_decode<2> (b, plan, n_super, blk, g, lane, counter, fail, lds_a, lds_b);
+  __syncthreads();
+  if (lane == 0)
+    {
+      // the last workgroup to leave clears the launch-wide counters (all tickets are drawn, all other exits are counted)
+      const unsigned int left = __hip_atomic_fetch_add (&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (left + 1 == gridDim.x)
+        {
+          __hip_atomic_store (&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store (&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -483,10 +631,18 @@ viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks)
 
 int g_viterbi_super = 1;         // (debug toggle)
 extern "C" void awm_debug_set_viterbi_super (int on) { g_viterbi_super = on; }
+int g_viterbi_persistent = 1;    // (debug toggle: 0 = the chain of launches)
+extern "C" void awm_debug_set_viterbi_persistent (int on) { g_viterbi_persistent = on; }
+
+size_t
+viterbi_sync_bytes (long long n_blocks)
+{
+  return size_t (1 + std::max (0ll, n_blocks)) * SYNC_STRIDE * sizeof (unsigned int);
+}
 
 hipError_t
 launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_blocks[3], long long n_steps,
-                unsigned char *const decisions_ws[3], int *const bits_out[3], float *const error_out[3])
+                unsigned char *const decisions_ws[3], int *const bits_out[3], float *const error_out[3], unsigned int *sync_ws)
 {
   const long long total = n_blocks[0] + n_blocks[1] + n_blocks[2];
   if (total <= 0)
@@ -512,6 +668,15 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
       tp.k[r] = (unsigned char) rounds[r].k;
       tp.step0[r] = rounds[r].step0;
       tp.dec_offset[r] = (unsigned int) rounds[r].dec_offset;
+    }
+  if (sync_ws && g_viterbi_persistent)
+    {
+      // one launch: the leading triples of 4-step rounds as 12-step segments, the remaining rounds one by one
+      int n_super = 0;
+      while (V_K == 4 && 3 * n_super + 2 < int (rounds.size()) && rounds[3 * n_super].k == 4 && rounds[3 * n_super + 1].k == 4 && rounds[3 * n_super + 2].k == 4)
+        n_super++;
+      hipLaunchKernelGGL (viterbi_persistent_kernel, dim3 (8u * (unsigned) total), dim3 (V_WG), 0, st, b, tp, n_super, sync_ws);
+      return hipGetLastError();
     }
   hipLaunchKernelGGL (viterbi_init_kernel, dim3 (V_STATES / 256, (unsigned) total), dim3 (256), 0, st, b);
   int parity = 0;

@@ -953,7 +953,9 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
   // clips where the device needs 25.)
   constexpr size_t SUPER = 128;
   constexpr int ADD_LANES = 8;
-  if (int rc = ctx->ws_keytab.reserve (std::max<size_t> (1, n_clips * table_bytes))) return rc;
+  // device side: TWO halves of SUPER tables, like the staging block -- the size does not grow with the batch.  Half h is refilled
+  // (super s, s >= 2) only after every lane has finished the clips of super s - 2: the upload waits for the lanes' events on the device.
+  if (int rc = ctx->ws_keytab.reserve (2 * SUPER * table_bytes)) return rc;
   if (int rc = ctx->pin_keytab.reserve (2 * SUPER * table_bytes)) return rc;
   const int n_lanes = int (std::min<size_t> (ADD_LANES, std::max<size_t> (1, n_clips)));
   std::vector<WorkLane *> lanes;
@@ -1001,7 +1003,11 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
   struct EvGuard { hipEvent_t (&ev)[2]; ~EvGuard() { for (hipEvent_t e : ev) if (e) (void) hipEventDestroy (e); } } guard { ev_up };
   for (auto& e : ev_up)
     AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
-  int rc = 0;
+  std::vector<hipEvent_t> lane_done (2 * size_t (n_lanes), nullptr);                    // [half][lane]: the lane is through the clips of that half
+  struct DoneGuard { std::vector<hipEvent_t>& ev; ~DoneGuard() { for (hipEvent_t e : ev) if (e) (void) hipEventDestroy (e); } } done_guard { lane_done };
+  for (auto& e : lane_done)
+    AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
+  int rc = 0, last_half = -1;
   std::future<bool> next_built;
   struct FutureGuard { std::future<bool>& f; ~FutureGuard() { if (f.valid()) f.wait(); } } future_guard { next_built };     // (the task writes into the staging block)
   for (size_t s0 = 0, sidx = 0; s0 < n_clips && !rc; s0 += SUPER, sidx++)
@@ -1020,7 +1026,10 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
             AWM_HIP_CHECK (hipEventSynchronize (ev_up[half ^ 1]));                      // the upload out of the other half is done
           next_built = std::async (std::launch::async, build_super, s0 + SUPER, half ^ 1);     // while the device works on this one
         }
-      int8_t *dev = ctx->ws_keytab.as<int8_t>() + s0 * table_bytes;
+      int8_t *dev = ctx->ws_keytab.as<int8_t>() + size_t (half) * SUPER * table_bytes;
+      if (sidx >= 2)
+        for (int i = 1; i < n_lanes; i++)                                               // (lane 0 is ctx->stream itself)
+          AWM_HIP_CHECK (hipStreamWaitEvent (ctx->stream, lane_done[size_t (half) * n_lanes + i], 0));
       AWM_HIP_CHECK (hipMemcpyAsync (dev, pin_base + size_t (half) * SUPER * table_bytes, sn * table_bytes, hipMemcpyHostToDevice, ctx->stream));
       AWM_HIP_CHECK (hipEventRecord (ev_up[half], ctx->stream));
       for (int i = 1; i < n_lanes; i++)
@@ -1028,7 +1037,15 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
       for (size_t i = 0; i < sn && !rc; i++)
         rc = add_full (ctx, pcm_in_d[s0 + i], out_d[s0 + i], n_frames[s0 + i], n_channels, dev + i * table_bytes, params().water_delta,
                        !params().test_no_limiter, lanes[(s0 + i) % n_lanes]);
+      for (int i = 1; i < n_lanes && !rc; i++)
+        AWM_HIP_CHECK (hipEventRecord (lane_done[size_t (half) * n_lanes + i], lanes[i]->stream));
+      last_half = half;
     }
+  // The staging block is the context's: the next call (or the clip `get` with per-clip keys, which stages its group tables through the
+  // same block) may write into it as soon as this one returns -- so the last upload out of it has to be through.  Only the copy is
+  // awaited, not the clips' kernels.
+  if (last_half >= 0)
+    AWM_HIP_CHECK (hipEventSynchronize (ev_up[last_half]));
   for (int i = 1; i < n_lanes; i++)
     {
       AWM_HIP_CHECK (hipEventRecord (lanes[i]->ev_sync, lanes[i]->stream));

@@ -270,11 +270,13 @@ awm_sharded_plan (const uint64_t *span_frames, int world, size_t max_out, int *c
   return sharded_plan_c (span_frames, world, max_out, chunk, rank, first_sf, n_sf);
 }
 
-int
-awm_sharded_add_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const float *pcm_in_d, float *out_d, int n_channels,
+/* the entry points proper, with whatever parameter set is in force on the calling thread (awm_sharded_*: the context's own one;
+ * awm_multi_*: ONE set for all ranks -- helpers that carried other settings than the main context would build different plans and
+ * wait for messages that never come) */
+static int
+sharded_add_entry (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const float *pcm_in_d, float *out_d, int n_channels,
                    const uint64_t *span_frames, const awm_comm *comm)
 {
-  ParamsBind bind (ctx ? ctx->own_params.get() : nullptr);
   if (int rc = enter (ctx, comm, span_frames, n_channels))
     return rc;
   if (!payload_hex || (span_frames[comm->rank] && (!pcm_in_d || !out_d)))
@@ -286,10 +288,17 @@ awm_sharded_add_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex,
 }
 
 int
-awm_sharded_get_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, int n_channels, const uint64_t *span_frames,
-                   const awm_comm *comm, size_t max_out, awm_pattern *out)
+awm_sharded_add_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const float *pcm_in_d, float *out_d, int n_channels,
+                   const uint64_t *span_frames, const awm_comm *comm)
 {
   ParamsBind bind (ctx ? ctx->own_params.get() : nullptr);
+  return sharded_add_entry (ctx, key, payload_hex, pcm_in_d, out_d, n_channels, span_frames, comm);
+}
+
+static int
+sharded_get_entry (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, int n_channels, const uint64_t *span_frames,
+                   const awm_comm *comm, size_t max_out, awm_pattern *out)
+{
   if (int rc = enter (ctx, comm, span_frames, n_channels))
     return rc;
   if ((span_frames[comm->rank] && !pcm_d) || (max_out && !out))
@@ -306,6 +315,14 @@ awm_sharded_get_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, int 
 }
 
 int
+awm_sharded_get_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, int n_channels, const uint64_t *span_frames,
+                   const awm_comm *comm, size_t max_out, awm_pattern *out)
+{
+  ParamsBind bind (ctx ? ctx->own_params.get() : nullptr);
+  return sharded_get_entry (ctx, key, pcm_d, n_channels, span_frames, comm, max_out, out);
+}
+
+int
 awm_multi_add_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], const char *payload_hex, const float *const *pcm_in_d,
                  float *const *out_d, int n_channels, const uint64_t *span_frames)
 {
@@ -314,8 +331,9 @@ awm_multi_add_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], const c
       set_error ("awm_multi_add_d: bad argument");
       return AWM_ERR_ARG;
     }
+  ParamsBind bind (ctxs[0]->own_params.get());             // the main context's settings for every rank (run_ranks hands them to its threads)
   return run_ranks (ctxs, n_ctx, [&] (int r, const awm_comm *comm) {
-    return awm_sharded_add_d (ctxs[r], key, payload_hex, pcm_in_d[r], out_d[r], n_channels, span_frames, comm);
+    return sharded_add_entry (ctxs[r], key, payload_hex, pcm_in_d[r], out_d[r], n_channels, span_frames, comm);
   });
 }
 
@@ -329,8 +347,9 @@ awm_multi_get_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], const f
       return AWM_ERR_ARG;
     }
   int count = 0;
+  ParamsBind bind (ctxs[0]->own_params.get());             // (see awm_multi_add_d)
   const int rc = run_ranks (ctxs, n_ctx, [&] (int r, const awm_comm *comm) {
-    const int n = awm_sharded_get_d (ctxs[r], key, pcm_d[r], n_channels, span_frames, comm, r == 0 ? max_out : 0, r == 0 ? out : nullptr);
+    const int n = sharded_get_entry (ctxs[r], key, pcm_d[r], n_channels, span_frames, comm, r == 0 ? max_out : 0, r == 0 ? out : nullptr);
     if (n < 0)
       return n;
     if (r == 0)

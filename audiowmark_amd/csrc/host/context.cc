@@ -83,7 +83,7 @@ void
 awm::WorkLane::release_lane()
 {
   for (DevBuffer *b : { &ws_db, &ws_block_db, &ws_have, &ws_q, &ws_raw, &ws_mean, &ws_misc, &ws_refine, &ws_refine_have, &ws_soft, &ws_viterbi,
-                        &ws_viterbi_in, &ws_viterbi_bits, &ws_viterbi_err, &ws_block_max, &ws_clip, &ws_idx, &ws_limit_tab, &ws_jobs, &ws_group, &ws_keytab, &ws_shard_edge, &ws_shard_tail, &ws_shard_q })
+                        &ws_viterbi_in, &ws_viterbi_bits, &ws_viterbi_err, &ws_viterbi_sync, &ws_block_max, &ws_clip, &ws_idx, &ws_limit_tab, &ws_jobs, &ws_group, &ws_keytab, &ws_shard_edge, &ws_shard_tail, &ws_shard_q })
     b->release();
   for (PinnedBuffer *b : { &pin_refine_in[0], &pin_refine_in[1], &pin_refine_q[0], &pin_refine_q[1], &pin_peaks, &pin_blocks, &pin_jobs, &pin_bits, &pin_small, &pin_group, &pin_shard, &pin_shard_up, &pin_keytab })
     b->release();
@@ -97,6 +97,22 @@ awm::WorkLane::release_lane()
     (void) hipEventDestroy (ev_sync);
   ev_sync = nullptr;
   awm::speed_scratch_free (this);
+}
+
+unsigned int *
+awm::WorkLane::viterbi_sync (size_t n_decodes)
+{
+  // The one-launch Viterbi kernel leaves its counters at zero (hip/viterbi.hip), so the block is cleared only when it is (re)allocated
+  // -- on the lane's own stream, in front of the launch that uses it first.
+  const void *before = ws_viterbi_sync.ptr;
+  if (ws_viterbi_sync.reserve (awmk::viterbi_sync_bytes ((long long) n_decodes)))
+    return nullptr;
+  if (ws_viterbi_sync.ptr != before && hipMemsetAsync (ws_viterbi_sync.ptr, 0, ws_viterbi_sync.bytes, stream) != hipSuccess)
+    {
+      ws_viterbi_sync.release();
+      return nullptr;
+    }
+  return ws_viterbi_sync.as<unsigned int>();
 }
 
 awm::WorkLane *

@@ -152,6 +152,22 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
 }
 
 /* conv_decode_soft for up to three batches (A, B, AB blocks) in ONE launch */
+/* a decode error below zero cannot come out of the arithmetic (a mean of squares): it is the one-launch kernel's mark for "a device-side
+ * wait gave up" (hip/viterbi.hip) -- the batch is void and the lane's sync block has to be cleared before its next use */
+int
+viterbi_check_errors (WorkLane *lane, const float *errors, size_t n)
+{
+  for (size_t i = 0; i < n; i++)
+    if (errors[i] < 0)
+      {
+        if (lane->ws_viterbi_sync.ptr)
+          (void) hipMemsetAsync (lane->ws_viterbi_sync.ptr, 0, lane->ws_viterbi_sync.bytes, lane->stream);
+        set_error ("viterbi: a device-side wait between the workgroups of a decode timed out");
+        return AWM_ERR_HIP;
+      }
+  return 0;
+}
+
 int
 viterbi_decode_all (awm_ctx *ctx, const std::vector<std::vector<float>> soft[3], std::vector<std::vector<int>> bits[3],
                     std::vector<float> errors[3])
@@ -218,15 +234,20 @@ viterbi_decode_all (awm_ctx *ctx, const std::vector<std::vector<float>> soft[3],
           n_blocks[t] = (long long) nb[t];
           bytes += double (nb[t]) * n_steps * (t == 2 ? 12 : 6) * 4.0;
         }
+      unsigned int *sync_ws = ctx->viterbi_sync (nb[0] + nb[1] + nb[2]);
+      if (!sync_ws)
+        return AWM_ERR_HIP;
       {
         ProfScope ps (ctx, PROF_VITERBI, bytes + 2.0 * ws_total);
-        AWM_HIP_CHECK (awmk::launch_viterbi (st, d_soft, n_blocks, (long long) n_steps, d_ws, d_bits, d_err));
+        AWM_HIP_CHECK (awmk::launch_viterbi (st, d_soft, n_blocks, (long long) n_steps, d_ws, d_bits, d_err, sync_ws));
       }
       std::vector<int> hbits (bits_total);
       std::vector<float> herr (err_total);
       AWM_HIP_CHECK (hipMemcpyAsync (hbits.data(), ctx->ws_viterbi_bits.ptr, hbits.size() * sizeof (int), hipMemcpyDeviceToHost, st));
       AWM_HIP_CHECK (hipMemcpyAsync (herr.data(), ctx->ws_viterbi_err.ptr, herr.size() * sizeof (float), hipMemcpyDeviceToHost, st));
       AWM_HIP_CHECK (stream_wait (st));
+      if (int rc = viterbi_check_errors (ctx, herr.data(), herr.size()))
+        return rc;
       for (int t = 0; t < 3; t++)
         {
           for (size_t i = 0; i < nb[t]; i++)
@@ -344,10 +365,13 @@ decode_launch (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, DecodeJob& job, cons
       n_blocks[t] = (long long) job.nb[t];
       bytes += double (job.nb[t]) * n_steps * (t == 2 ? 12 : 6) * 4.0;
     }
+  unsigned int *sync_ws = lane->viterbi_sync (n_jobs);
+  if (!sync_ws)
+    return AWM_ERR_HIP;
   {
     ProfScope ps (ctx, PROF_VITERBI, 2.0 * bytes + 2.0 * ws_total, st);
     AWM_HIP_CHECK (awmk::launch_soft_prep (st, pa));
-    AWM_HIP_CHECK (awmk::launch_viterbi (st, d_soft, n_blocks, (long long) n_steps, d_ws, d_bits, d_err));
+    AWM_HIP_CHECK (awmk::launch_viterbi (st, d_soft, n_blocks, (long long) n_steps, d_ws, d_bits, d_err, sync_ws));
   }
   AWM_HIP_CHECK (hipMemcpyAsync (lane->pin_bits.ptr, lane->ws_viterbi_bits.ptr, job.bits_total * sizeof (int) + job.err_total * sizeof (float),
                                  hipMemcpyDeviceToHost, st));
@@ -365,6 +389,8 @@ decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::vector
   job.launched = false;
   const int *hbits = lane->pin_bits.as<int>();
   const float *herr = reinterpret_cast<const float *> (hbits + job.bits_total);
+  if (int rc = viterbi_check_errors (lane, herr, job.err_total))
+    return rc;
   std::vector<std::vector<int>> bits (job.pending.size());
   std::vector<float> errors (job.pending.size(), 0.f);
   for (int t = 0; t < 3; t++)
@@ -399,99 +425,127 @@ run_pending (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const Key& key, std::v
   return decode_finish (lane, key, job, result_sets, speed);
 }
 
-/* AB pairing and "all" pattern of BlockDecoder::run (reference wmget.cc:554-701) for the blocks of one chunk */
-void
-combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const DeviceWav& wav, size_t chunk, std::vector<PendingDecode>& pending)
-{
-  const size_t block_len = mark_block_frame_count() * Params::frame_size;
-  /* AB: a B block preceded by an A block one block length earlier */
-  for (size_t i = 0; i < pattern_raw_vec.size(); i++)
-    {
-      if (pattern_raw_vec[i].block_type != ConvBlockType::b)
-        continue;
-      int best_j = -1;
-      int best_abs_dist = Params::frame_size / 2;
-      for (size_t j = 0; j < i; j++)
-        if (pattern_raw_vec[j].block_type == ConvBlockType::a)
-          {
-            const int abs_dist = std::abs (int (pattern_raw_vec[i].index - pattern_raw_vec[j].index) - int (block_len));
-            if (abs_dist < best_abs_dist)
-              {
-                best_j = j;
-                best_abs_dist = abs_dist;
-              }
-          }
-      if (best_j < 0)
-        continue;
-      const auto& a_pattern = pattern_raw_vec[best_j];
-      const auto& b_pattern = pattern_raw_vec[i];
-      SyncFinder::Score score_ab { b_pattern.index, (a_pattern.quality + b_pattern.quality) / 2, ConvBlockType::ab };
-      pending.push_back ({ ConvBlockType::ab, 1, { { a_pattern.slot, 0 }, { b_pattern.slot, 1 } }, 0, 0,
-                           double (b_pattern.index) / wav.sample_rate, score_ab, ResultSet::Type::BLOCK, chunk });
-    }
-  /* all: best chain of consecutive, alternating blocks */
-  std::vector<size_t> best_all_blocks;
-  auto sync_sum = [&] (const std::vector<size_t>& blocks) {
-    float sum = 0;
-    for (auto b : blocks)
-      sum += pattern_raw_vec[b].quality;
-    return sum;
-  };
-  for (size_t i = 0; i < pattern_raw_vec.size(); i++)
-    {
-      const size_t max_block_idx = lrint (pattern_raw_vec.back().index / double (block_len) + 0.5);
-      std::vector<size_t> all_blocks { i };
-      size_t block_idx = 1;
-      while (block_idx <= max_block_idx)
-        {
-          const size_t expect_start = pattern_raw_vec[all_blocks.back()].index + block_idx * block_len;
-          int best_j = -1;
-          int best_abs_dist = block_idx * Params::frame_size / 2;
-          auto expect_type = pattern_raw_vec[all_blocks.back()].block_type;
-          if (block_idx & 1)
-            expect_type = expect_type == ConvBlockType::a ? ConvBlockType::b : ConvBlockType::a;
-          for (size_t j = all_blocks.back(); j < pattern_raw_vec.size(); j++)
-            {
-              const int abs_dist = std::abs (int (expect_start) - int (pattern_raw_vec[j].index));
-              if (abs_dist < best_abs_dist && pattern_raw_vec[j].block_type == expect_type)
-                {
-                  best_j = j;
-                  best_abs_dist = abs_dist;
-                }
-            }
-          if (best_j >= 0)
-            {
-              all_blocks.push_back (best_j);
-              block_idx = 1;
-            }
-          else
-            block_idx++;
-        }
-      if (sync_sum (all_blocks) > sync_sum (best_all_blocks))
-        best_all_blocks = all_blocks;
-    }
-  if (best_all_blocks.size() > 1)
-    {
-      // all_bits[2 k + ab] = sum over the chain's blocks of that type (list order) / their number: done by K7b (mode 2)
-      std::vector<std::pair<int, int>> src;
-      int norm[2] = { 0, 0 };
-      SyncFinder::Score score_all { 0, 0, ConvBlockType::a };
-      for (auto bi : best_all_blocks)
-        {
-          const auto& pattern = pattern_raw_vec[bi];
-          score_all.quality += pattern.quality;
-          const int ab = pattern.block_type == ConvBlockType::b ? 1 : 0;
-          src.push_back ({ pattern.slot, ab });
-          norm[ab]++;
-        }
-      score_all.quality /= norm[0] + norm[1];
-      pending.push_back ({ ConvBlockType::ab, 2, src, norm[0], norm[1], 0.0, score_all, ResultSet::Type::ALL, chunk });
-    }
-}
-
+/* What BlockDecoder::run (reference wmget.cc:554-701) derives from the single blocks of one chunk, as decode jobs:
+ *
+ *   AB   every B block whose A partner -- an A block EARLIER in the list that starts one block length before it, to within half a
+ *        frame -- exists; the nearest partner, the earliest one among equally near ones.
+ *   ALL  the chain of blocks with the largest quality sum.  A chain grows from its last member: the block expected `gap` block
+ *        lengths further on has the other type for an odd gap and the same type for an even one; a block found within gap half-frames
+ *        of the expected start is appended (nearest, earliest on ties; searched from the last member's list position on) and the
+ *        gap starts again at 1, otherwise the gap grows until it would pass the end of the list.  The sums are float sums in chain
+ *        order and only a strictly larger sum replaces an earlier start's chain -- both are part of the result.
+ *
+ * The rules are the reference's; the formulation is this file's: one nearest-match helper serves both, chains are grown per start
+ * block by a function of their own. */
 namespace {
 
+constexpr size_t NO_BLOCK = size_t (-1);
+
+struct BlockList
+{
+  const std::vector<PatternRawBits>& blocks;
+  long long block_len;
+
+  /* list position in [lo, hi) of the block of `type` that starts nearest to `target`, strictly closer than `reach`; NO_BLOCK if none */
+  size_t
+  nearest (size_t lo, size_t hi, ConvBlockType type, long long target, long long reach) const
+  {
+    size_t found = NO_BLOCK;
+    for (size_t pos = lo; pos < hi; pos++)
+      {
+        if (blocks[pos].block_type != type)
+          continue;
+        const long long off = std::llabs ((long long) blocks[pos].index - target);
+        if (off < reach)
+          {
+            found = pos;
+            reach = off;                     // (an equally near later block does not replace it)
+          }
+      }
+    return found;
+  }
+
+  static ConvBlockType other (ConvBlockType t) { return t == ConvBlockType::a ? ConvBlockType::b : ConvBlockType::a; }
+
+  std::vector<size_t>
+  chain_from (size_t start) const
+  {
+    const long long half_frame = Params::frame_size / 2;
+    const long long last_gap = lrint (blocks.back().index / double (block_len) + 0.5);
+    std::vector<size_t> chain { start };
+    for (long long gap = 1; gap <= last_gap; )
+      {
+        const PatternRawBits& tail = blocks[chain.back()];
+        const ConvBlockType type = (gap & 1) ? other (tail.block_type) : tail.block_type;
+        const size_t next = nearest (chain.back(), blocks.size(), type, (long long) tail.index + gap * block_len, gap * half_frame);
+        if (next == NO_BLOCK)
+          gap++;
+        else
+          {
+            chain.push_back (next);
+            gap = 1;
+          }
+      }
+    return chain;
+  }
+
+  float
+  quality_sum (const std::vector<size_t>& chain) const
+  {
+    float sum = 0;
+    for (size_t pos : chain)
+      sum += blocks[pos].quality;
+    return sum;
+  }
+};
+
 }  // namespace
+
+void
+combine_blocks (const std::vector<PatternRawBits>& raw_blocks, const DeviceWav& wav, size_t chunk, std::vector<PendingDecode>& pending)
+{
+  const BlockList list { raw_blocks, (long long) (mark_block_frame_count() * Params::frame_size) };
+  for (size_t pos = 0; pos < raw_blocks.size(); pos++)
+    {
+      const PatternRawBits& b = raw_blocks[pos];
+      if (b.block_type != ConvBlockType::b)
+        continue;
+      const size_t partner = list.nearest (0, pos, ConvBlockType::a, (long long) b.index - list.block_len, Params::frame_size / 2);
+      if (partner == NO_BLOCK)
+        continue;
+      const PatternRawBits& a = raw_blocks[partner];
+      const SyncFinder::Score score { b.index, (a.quality + b.quality) / 2, ConvBlockType::ab };
+      pending.push_back ({ ConvBlockType::ab, 1, { { a.slot, 0 }, { b.slot, 1 } }, 0, 0, double (b.index) / wav.sample_rate, score,
+                           ResultSet::Type::BLOCK, chunk });
+    }
+  std::vector<size_t> best;
+  float best_sum = 0;
+  for (size_t start = 0; start < raw_blocks.size(); start++)
+    {
+      std::vector<size_t> chain = list.chain_from (start);
+      const float sum = list.quality_sum (chain);
+      if (sum > best_sum)
+        {
+          best = std::move (chain);
+          best_sum = sum;
+        }
+    }
+  if (best.size() < 2)
+    return;
+  // all_bits[2 k + ab] = sum over the chain's blocks of that type (list order) / their number: done by K7b (mode 2)
+  PendingDecode all { ConvBlockType::ab, 2, {}, 0, 0, 0.0, { 0, 0, ConvBlockType::a }, ResultSet::Type::ALL, chunk };
+  for (size_t pos : best)
+    {
+      const PatternRawBits& blk = raw_blocks[pos];
+      const int ab = blk.block_type == ConvBlockType::b;
+      all.src.push_back ({ blk.slot, ab });
+      (ab ? all.norm1 : all.norm0)++;
+      all.score.quality += blk.quality;
+    }
+  all.score.quality /= all.norm0 + all.norm1;
+  pending.push_back (std::move (all));
+}
+
 int g_merge_decodes = 0;         // (debug toggle, off: the decodes of all chunks of a `get` as one batch at the end -- see block_decoder_run)
 extern "C" void awm_debug_set_merge_decodes (int on) { g_merge_decodes = on; }
 namespace {
@@ -1273,8 +1327,6 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
 {
   const size_t count = mark_block_frame_count();
   const int n_bits_a = int (mark_data_frame_count() / params().frames_per_bit);
-  // the key tables of the NEXT group are built on host threads while the device works on this one
-  std::future<std::vector<ClipKeyHost>> next_hosts;
   auto group_keys = [&] (size_t g0, size_t gn) {
     std::vector<Key> keys;
     for (size_t i = 0; i < gn; i++)
@@ -1287,6 +1339,9 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
       gn++;
     return gn;
   };
+  // the key tables of the NEXT group are built on host threads while the device works on this one.  (Declared after everything the
+  // task could refer to, and the task gets its keys BY VALUE: on an early error return the future's destructor waits for the task.)
+  std::future<std::vector<ClipKeyHost>> next_hosts;
   hipStream_t st = lane->stream;
   struct LaneDrain
   {
@@ -1340,7 +1395,8 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
             {
               const size_t n0 = g0 + gn;
               ParamValues *const pv = &params();
-              next_hosts = std::async (std::launch::async, [&, n0, pv] { ParamsBind bind (pv); return build_group_hosts (group_keys (n0, group_size (n0))); });
+              std::vector<Key> next_keys = group_keys (n0, group_size (n0));
+              next_hosts = std::async (std::launch::async, [pv, keys = std::move (next_keys)] { ParamsBind bind (pv); return build_group_hosts (keys); });
             }
           if (int rc = upload_group_tables (lane, hosts, group_kt))
             return rc;

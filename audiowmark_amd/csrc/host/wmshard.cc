@@ -26,6 +26,7 @@
 #include <cmath>
 #include <cstring>
 #include <map>
+#include <set>
 
 namespace awm {
 
@@ -376,8 +377,11 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
   hipStream_t st0 = ctx->stream;
 
   /* Short streams (the ClipDecoder's domain: less than 3.1 blocks, wmget.cc:769-884) are not worth splitting: rank 0 gets the
-   * samples and decodes alone. */
-  if (total / FRAME < size_t (block * 3.1))
+   * samples and decodes alone.  The same when only the FIRST CHUNK is that short (--chunk-size below ~2.7 minutes): the reference
+   * runs the ClipDecoder on it (wmget.cc:886-1013), which the position-split phases below do not -- rare enough to pay one gather
+   * for "results identical to awm_get_watermark_d" to hold for every chunk size. */
+  const bool first_chunk_is_a_clip = !plan.chunks.empty() && plan.chunks[0].n_frames / FRAME < size_t (block * 3.1);
+  if (total / FRAME < size_t (block * 3.1) || first_chunk_is_a_clip)
     {
       std::vector<Msg> sends, recvs;
       if (int rc = ctx->ws_shard_tail.reserve (std::max<size_t> (1, rank == 0 ? total * C * sizeof (float) : 0))) return rc;
@@ -477,6 +481,17 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       AWM_HIP_CHECK (stream_wait (l->stream));
     return 0;
   };
+  // awm_comm's contract for exchange_d: the callback's writes are visible to the CONTEXT's stream when it returns (a transport may
+  // complete in stream order there).  What was received is consumed on the lanes' streams, so they are ordered behind the context's.
+  auto lanes_after_exchange = [&] () -> int {
+    if (!ctx->ev_sync)
+      AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
+    AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));
+    for (WorkLane *l : lanes)
+      if (l->stream != ctx->stream)
+        AWM_HIP_CHECK (hipStreamWaitEvent (l->stream, ctx->ev_sync, 0));
+    return 0;
+  };
   struct Drain { std::vector<WorkLane *>& lanes; ~Drain() { for (WorkLane *l : lanes) (void) hipStreamSynchronize (l->stream); } } drain { lanes };
   for (size_t i = 0; i < work.size(); i++)
     {
@@ -549,6 +564,7 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       }
     if (int rc = run_exchange (comm, true, sends, recvs, "exchange_d (overlap stitch)"))
       return rc;
+    if (int rc = lanes_after_exchange()) return rc;
   }
   if (int rc = score_parts (true)) return rc;
   if (int rc = sync_lanes()) return rc;
@@ -565,6 +581,7 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
           }
     if (int rc = run_exchange (comm, true, sends, recvs, "exchange_d (score gather)"))
       return rc;
+    if (int rc = lanes_after_exchange()) return rc;
   }
 
   /* ---- phase 4: selection on the complete list (every participant, same result), then refinement of MY candidates */
@@ -727,6 +744,7 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       if (int rc = pu.first->pin_shard.reserve (std::max<size_t> (1, pu.second))) return rc;
       pu.second = 0;
     }
+  std::set<WorkLane *> lanes_in_use;
   for (ChunkWork& w : work)
     {
       for (int tail = 0; tail < 2; tail++)
@@ -755,9 +773,10 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
                 return AWM_ERR_GENERIC;
               }
           std::vector<char> ok;
-          // (block_soft_bits_dev stages the block list through the lane's page-locked buffer: a second call on the same lane -- the
-          // tail part after the interior part -- must not refill it before the first copy has run)
-          if (tail)
+          // (block_soft_bits_dev stages the block list through the lane's page-locked buffer and its soft bits through the lane's
+          // ws_soft: ANY second call on the same lane -- the tail part after the interior part, or the next chunk of a rank that has more
+          // shared chunks than lanes -- must not refill them before the previous call's copies have run)
+          if (!lanes_in_use.insert (w.lane).second)
             AWM_HIP_CHECK (stream_wait (w.lane->stream));
           if (int rc = block_soft_bits_dev (ctx, w.lane, kt, virtual_chunk_wav (view, vf, w.N, C), index, sc.slot_of, ok))
             return rc;

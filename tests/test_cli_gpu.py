@@ -25,13 +25,18 @@ def run(cmd, stdin=None, check=True):
     return r
 
 
-def same_report(ours, theirs, what=""):
-    """Two `cmp` / `get` reports agree line by line.  One thing may differ: the decode error column of a pattern line whose time,
-    payload, sync quality (as printed) and type agree.  That is a refinement TIE: the sync quality is flat to ~1e-7 over neighbouring
-    fine offsets (8 samples apart) around a block start, the two detectors' FFTs differ at float rounding level (1e-7 relative; two
-    CPU FFT backends under the unmodified reference differ the same way), so strict `>` (syncfinder.cc:441) may
-    keep different neighbours; the block is then read 8 samples apart and its path metric differs in the third digit.  One tie
-    shows in up to three lines (the block, its AB pair, the "all" pattern); more than that fails."""
+# The ONE known refinement tie of this suite: in the 200 s fixture watermarked by THIS library's `add`, the
+# block that the reference's detector puts at sync index 2535416 is found at 2535408 here -- neighbouring fine offsets (8 samples)
+# whose qualities are 1.338650118 / 1.338649997, a difference below the two float pipelines' rounding noise; `search_refine` keeps
+# the first strictly better offset (syncfinder.cc:441).  The block is then read 8 samples apart and its path metric differs in the
+# third digit.  One tie shows in up to three report lines (the block, its AB pair, the "all" pattern).  Only the tests that read
+# that fixture pass it; every other comparison is strict.
+KNOWN_TIE = {"ours": 2535408, "reference": 2535416, "max_lines": 3}
+
+
+def same_report(ours, theirs, what="", max_tie_lines=0):
+    """Two `cmp` / `get` reports agree LINE BY LINE (strict by default).  With max_tie_lines > 0 (only for the fixture of KNOWN_TIE)
+    the decode error column of that many pattern lines may differ by < 0.01 while time, payload, printed sync quality and type agree."""
     skip = ("key", "expect_matches")
     a = [l for l in ours if not l.startswith(skip)]
     b = [l for l in theirs if not l.startswith(skip)]
@@ -40,11 +45,12 @@ def same_report(ours, theirs, what=""):
     for x, y in zip(a, b):
         if x == y:
             continue
+        assert max_tie_lines > 0, (what, x, y)
         fx, fy = x.split(), y.split()                   # pattern <time | all> <bits> <quality> <error> [<type>]
         assert fx[0] == fy[0] == "pattern" and len(fx) == len(fy) and len(fx) in (5, 6), (what, x, y)
         assert fx[:4] == fy[:4] and fx[5:] == fy[5:] and abs(float(fx[4]) - float(fy[4])) < 0.01, (what, x, y)
         ties += 1
-    assert ties <= 3, (what, ties, a, b)
+    assert ties <= max_tie_lines, (what, ties, a, b)
     return ties
 
 
@@ -133,10 +139,29 @@ def test_against_reference_binary(work):
     diff = np.abs(a - b)
     assert diff.max() <= 1 and (diff != 0).mean() < 1e-3          # quantisation-boundary flips only
     # both detectors agree on both files, line by line
-    for f in (marked, ref_marked):
+    for f, tie_lines in ((marked, KNOWN_TIE["max_lines"]), (ref_marked, 0)):
         ours = run([AWM, "cmp", "--input-format", "wav-pipe", str(f), PAY]).stdout.decode().splitlines()
         theirs = run([_ref.BIN, "cmp", "--x-in-wav-pipe", str(f), PAY]).stdout.decode().splitlines()
-        same_report(ours, theirs, str(f))
+        same_report(ours, theirs, str(f), max_tie_lines=tie_lines)
+
+
+@pytest.mark.skipif(not _ref.available(), reason="oracle/_ref (compiled reference) not built")
+def test_the_known_refinement_tie_is_exactly_that_one(work):
+    """The fixture's tie, pinned by its sync indices: on the file watermarked by this library every pattern of the compiled
+    reference's detector is found at the SAME sync index here, except the block(s) of KNOWN_TIE -- and if a later change of the
+    arithmetic removes the tie, this test says so (then KNOWN_TIE and the three max_tie_lines arguments go)."""
+    import torch
+    import audiowmark_amd as awm
+    d, _, marked = work
+    x = (wav_samples(str(marked)).astype(np.float32) / 32768.0).reshape(-1, 2)
+    want = _ref.get(None, x, 2)
+    got = awm.Context(0).get_watermark(None, torch.from_numpy(x).cuda())
+    assert len(got) == len(want)
+    moved = [(g["sync_index"], w["sync_index"]) for g, w in zip(got, want) if g["sync_index"] != w["sync_index"]]
+    assert 0 < len(moved) <= KNOWN_TIE["max_lines"] and set(moved) == {(KNOWN_TIE["ours"], KNOWN_TIE["reference"])}, moved
+    for g, w in zip(got, want):
+        assert (g["type"], g["block_type"], g["bits"]) == (w["type"], w["block_type"], w["bits"])
+        assert abs(g["sync_quality"] - w["sync_quality"]) < 1e-5
 
 
 def test_snr_report_equals_reference_with_the_limiter_active(work, tmp_path):
@@ -258,7 +283,7 @@ def test_hard_decision_option(work):
     assert any(l.startswith("pattern") and PAY in l for l in ours)
     if os.path.exists(_ref.BIN):
         theirs = run([_ref.BIN, "cmp", "--hard", "--x-in-wav-pipe", str(marked), PAY]).stdout.decode().splitlines()
-        same_report(ours, theirs)
+        same_report(ours, theirs, "--hard on the fixture of KNOWN_TIE", max_tie_lines=KNOWN_TIE["max_lines"])
 
 
 def test_rf64_output_and_riff_size_limit(work, tmp_path):
@@ -326,10 +351,10 @@ def test_hard_option_through_the_c_abi(work):
             ties = 0
             for a, b in zip(ours, theirs):                                      # pattern time bits quality error type
                 assert a["bits"] == b[2] and "%.3f" % a["sync_quality"] == b[3]
-                if "%.3f" % a["decode_error"] != b[4]:                          # a refinement tie (same_report)
+                if "%.3f" % a["decode_error"] != b[4]:                          # KNOWN_TIE: this is that fixture
                     assert abs(a["decode_error"] - float(b[4])) < 0.01
                     ties += 1
-            assert ties <= 3
+            assert ties <= KNOWN_TIE["max_lines"]
     hard_ctx.set_params()                                                       # back to the process-wide set
     assert [p["decode_error"] for p in hard_ctx.get_watermark_file(None, str(marked))] == [p["decode_error"] for p in soft]
     # a parameter the kernels are not built for is refused at the entry point, not silently ignored

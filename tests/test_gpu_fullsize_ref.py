@@ -44,8 +44,11 @@ def quantise16(x):
 JUNK_ERROR = 0.6      # decode error of a real watermark: 0.10-0.14 (block), 0.33-0.36 (30 s clip); of noise: 0.75-0.79
 
 
-def compare_patterns(got, want, what, speed_tol=None):
-    """Every pattern the reference reports must be reported at the same position with the same types; the payload bits must be
+def compare_patterns(got, want, what, speed_tol=None, max_ties=0):
+    """STRICT by default (max_ties = 0): every pattern the reference reports is reported at the same sync index.  A caller that
+    knows of a refinement tie in its fixture passes max_ties explicitly (none of the full-size configurations does: all measured 0).
+
+    Every pattern the reference reports must be reported at the same position with the same types; the payload bits must be
     identical for every pattern that IS a watermark (reference decode error < 0.6).  The reference also prints its n_best
     fallback candidates: Viterbi decodes of noise (decode error ~0.77), whose 128 bits are decided by path metric differences
     at float rounding level -- there a different FFT rounding (the reference's FFTW vs. the oracle's double FFT vs. this one)
@@ -64,11 +67,12 @@ def compare_patterns(got, want, what, speed_tol=None):
                 f"{what}: pattern position / type differs: {pkey(g)} != {pkey(w)}"
             ties += 1
             tied.append(i)
+            assert ties <= max_ties, f"{what}: sync position differs from the reference's (8 samples away, {ties} so far, {max_ties} allowed): {pkey(g)} != {pkey(w)}"
             continue
         if g["bits"] != w["bits"]:
             assert w["decode_error"] >= JUNK_ERROR, f"{what}: payload bits of a watermark differ: {pkey(g)} != {pkey(w)}"
             junk_diff += 1
-    assert ties <= 3 * max(1, len(want) // 100), f"{what}: {ties} patterns at neighbouring fine offsets"
+    assert ties <= max_ties, f"{what}: {ties} patterns at neighbouring fine offsets, {max_ties} allowed"
     dq = max((abs(g["sync_quality"] - w["sync_quality"]) for g, w in zip(got, want)), default=0.0)
     # (a noise pattern decoded to other bits took another path through the trellis: its error value is another path's; a block read
     # 8 samples apart -- a tie, also inside an AB pair or the "all" pattern -- has another path metric)

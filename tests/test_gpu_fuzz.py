@@ -42,8 +42,8 @@ JUNK_ERROR = 0.6       # decode error from which on a pattern is a Viterbi decod
 
 
 def same_patterns(got, want):
-    """identical lists; a refinement tie (neighbouring fine offsets whose qualities agree to float rounding, see
-    tests/test_gpu_fullsize_ref.py compare_patterns) is tolerated once per clip and counted; the 128 bits of a decode of NOISE
+    """identical lists, sync indices included (strict: no refinement tie is tolerated -- a case that hits one fails and has to be
+    looked at and listed by seed and case); the 128 bits of a decode of NOISE
     (oracle decode error >= 0.6: the n_best fallback of a clip without a watermark) hang on path metric differences at float
     rounding level and may differ with the FFT's rounding -- position, types and quality must still agree (seed 7 of
     tools/gpu_fuzz.py has one; the one-thread-per-bit soft bit kernel gives the same bits as the wave kernel there)"""
@@ -57,11 +57,8 @@ def same_patterns(got, want):
             continue
         if key(g)[:4] == key(w)[:4] and w["decode_error"] >= JUNK_ERROR and g["decode_error"] >= JUNK_ERROR:
             continue
-        if (g["type"], g["block_type"], g["bits"]) == (w["type"], w["block_type"], w["bits"]) and abs(int(g["sync_index"]) - int(w["sync_index"])) <= 8:
-            ties += 1
-            continue
         return False, ties
-    return ties <= 3, ties
+    return True, ties
 
 
 @pytest.mark.parametrize("seed,max_seconds", [(1, 70.0), (2, 125.0), (7, 130.0)])

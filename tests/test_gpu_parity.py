@@ -242,6 +242,35 @@ def test_viterbi_bit_exact(gpu, bt):
     assert np.array_equal(got_err, np.array(want_err, np.float32))         # path metric: same float operations, same order
 
 
+def test_viterbi_one_launch_equals_the_launch_chain(gpu):
+    """K8 as ONE launch (8 resident workgroups per decode meeting at a per-decode counter, tickets instead of blockIdx) against the
+    chain of 16 launches: bits and error values identical, also for a batch that oversubscribes the chip several times (600 decodes
+    = 4800 workgroups; the ticket order is what keeps that free of deadlock), for the three code types mixed in one call, for blocks
+    whose soft bits are NaN (the checked path), and repeated (the counters must be back at zero after every launch)."""
+    rng = np.random.default_rng(77)
+    lib = gpu.awm.lib
+    for n, sigma in ((3, 0.5), (40, 0.7), (600, 1.0)):
+        for bt in (0, 1, 2):
+            bits = rng.integers(0, 2, (n, 128))
+            coded = np.stack([orc.conv_encode(bt, b) for b in bits]).astype(np.float32)
+            soft = (coded + rng.normal(0, sigma, coded.shape)).astype(np.float32)
+            if n == 40:
+                soft[5] = np.nan
+            try:
+                lib.awm_debug_set_viterbi_persistent(0)
+                want_bits, want_err = gpu.ctx.viterbi_decode(bt, soft)
+            finally:
+                lib.awm_debug_set_viterbi_persistent(1)
+            for rep in range(3):
+                got_bits, got_err = gpu.ctx.viterbi_decode(bt, soft)
+                assert np.array_equal(got_bits, want_bits), (n, bt, rep)
+                assert np.array_equal(got_err, want_err, equal_nan=True), (n, bt, rep)
+            if n == 3:
+                for i in range(n):
+                    b, e = orc.conv_decode_soft(bt, soft[i])
+                    assert np.array_equal(got_bits[i], b) and got_err[i] == np.float32(e)
+
+
 # ---- whole decode -----------------------------------------------------------------------------------
 def test_decode_chunk_golden(gpu, golden, stream70):
     j, _ = golden
