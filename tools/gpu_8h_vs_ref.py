@@ -1,0 +1,74 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+"""BASELINE.json configs[3] at FULL size against the compiled reference, once, outside pytest (the reference needs ~3 minutes of the
+box's host cores for `get` of 8 h): 8 h stereo 44.1 kHz `test-gen-noise` input (16 bit), watermarked by the HIP `add`, the 16 bit
+result decoded by both detectors -- the complete pattern list compared STRICTLY (tests/test_gpu_fullsize_ref.py: compare_patterns,
+max_ties = 0), also through the multi-GPU protocol with 2 and 4 contexts on the one device (awm_multi_get_d).
+
+  python tools/gpu_8h_vs_ref.py [hours = 8]     ->  gpurun_out/config3_8h_vs_reference.json  (copy to profiles/rNN/)
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+
+PAY = "0123456789abcdef0011223344556677"
+RATE = 44100
+
+
+def main():
+    hours = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
+    import torch
+    import audiowmark_amd as awm
+    from audiowmark_amd import sharded
+    import _ref
+    from test_gpu_fullsize_ref import compare_patterns, quantise16, pkey
+    assert _ref.available(), "oracle/_ref is not built"
+    ctx = awm.Context(0)
+    n = int(hours * 3600 * RATE)
+    t0 = time.perf_counter()
+    x = quantise16(awm.binding.gen_noise(None, 2 * n))
+    t_gen = time.perf_counter() - t0
+    xd = torch.from_numpy(x.reshape(n, 2)).cuda()
+    del x
+    w = ctx.add_watermark(None, PAY, xd)
+    del xd
+    wq = quantise16(w.cpu().numpy())
+    del w
+    t0 = time.perf_counter()
+    want = _ref.get(None, wq.ravel(), 2)
+    t_ref = time.perf_counter() - t0
+    wd = torch.from_numpy(wq).cuda()
+    del wq
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = ctx.get_watermark(None, wd)
+    torch.cuda.synchronize()
+    t_hip = time.perf_counter() - t0
+    rep = compare_patterns(got, want, "configs[3] 8 h get")
+    rep.update({"hours": hours, "chunks": len(awm.plan_chunks(n)), "payload_matches": sum(p["bits"] == PAY for p in got),
+                "reference_get_s": round(t_ref, 2), "reference_threads": os.cpu_count(), "hip_get_s_first_call": round(t_hip, 3),
+                "input": "test-gen-noise 16 bit, watermarked by the HIP add, 16 bit; both detectors read the same samples",
+                "noise_generation_s": round(t_gen, 2)})
+    # the same stream split over 2 and 4 contexts of this process (the multi-GPU protocol on one device)
+    for parts in (2, 4):
+        ctxs = [ctx] + [awm.Context(0) for _ in range(parts - 1)]
+        per = (n // parts) // 1024 * 1024
+        spans = [wd[i * per: (i + 1) * per if i < parts - 1 else n] for i in range(parts)]
+        multi = sharded.multi_get(ctxs, None, spans, max_out=8192)
+        rep[f"awm_multi_get_d_{parts}_contexts_equal_to_single"] = [pkey(p) + (p["sync_quality"], p["decode_error"]) for p in multi] == \
+            [pkey(p) + (p["sync_quality"], p["decode_error"]) for p in got]
+        for c in ctxs[1:]:
+            c.close()
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "config3_8h_vs_reference.json"), "w") as f:
+        json.dump({"config3_8h_stereo": rep}, f, indent=1)
+    print(json.dumps(rep))
+
+
+if __name__ == "__main__":
+    main()

@@ -46,13 +46,29 @@ for v in (1, 0, 1):
     k = [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["decode_error"]) for p in pats]
     if base is None: base = k
     print("viterbi super %d: viterbi %.4f ms per step  equal to first: %s" % (v, r["viterbi_kernel"], k == base))
+awm.lib.awm_debug_set_viterbi_super(1)
+for v in (1, 0, 1, 0):
+    awm.lib.awm_debug_set_viterbi_persistent(v)
+    pats, r = prof(lambda: ctx.get_watermark(None, ref), 5)
+    k = [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["decode_error"]) for p in pats]
+    print("viterbi one launch %d: viterbi scope %.4f ms per step (one lane)  equal to first: %s" % (v, r["viterbi_kernel"], k == base))
+awm.lib.awm_debug_set_viterbi_persistent(1)
 # the Viterbi jobs of a stream's chunks as one batch at the end (1) | per chunk (0): the timed configuration (chunks on concurrent lanes)
 import time
 awm.lib.awm_ctx_set_chunk_lanes(ctx._h, 4)
 def step():
     ctx.add_watermark(None, P, x, out=out)
     return ctx.get_watermark(None, out)
-for v in (0, 1, 0, 1, 0, 1):
+for v in (1, 0, 1, 0, 1, 0):
+    awm.lib.awm_debug_set_viterbi_persistent(v)
+    for _ in range(3): step()
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(20): pats = step()
+    torch.cuda.synchronize()
+    k = [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["decode_error"]) for p in pats]
+    print("viterbi one launch %d: %.3f ms per step (add + get, four lanes), patterns %d, equal: %s" % (v, (time.perf_counter() - t0) / 20 * 1e3, len(pats), k == base))
+awm.lib.awm_debug_set_viterbi_persistent(1)
+for v in (0, 1, 0, 1):
     awm.lib.awm_debug_set_merge_decodes(v)
     for _ in range(3): step()
     torch.cuda.synchronize(); t0 = time.perf_counter()
