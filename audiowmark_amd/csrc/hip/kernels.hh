@@ -264,7 +264,7 @@ hipError_t launch_soft_prep (hipStream_t st, const SoftPrepArgs& a);
 /* index 0 / 1 / 2 = A / B / AB coded blocks (rate 6 / 6 / 12); every block has n_steps = payload + 15 trellis steps */
 /* sync_ws: viterbi_sync_bytes (all blocks of the call) bytes that are ZERO on entry and zero again when the launch has finished
  * (the one-launch kernel's tickets and per-decode counters; a lane keeps one such block and zeroes it when it allocates it);
- * nullptr: the chain of 16 launches.  A decode that reports error < 0 means a device-side wait gave up: the batch is invalid. */
+ * nullptr: the chain of 16 launches.  A decode that reports error -2 means a device-side wait gave up: the batch is invalid. */
 hipError_t launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_blocks[3], long long n_steps,
                            unsigned char *const decisions_ws[3], int *const bits_out[3], float *const error_out[3], unsigned int *sync_ws);
 size_t viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks);

@@ -73,6 +73,65 @@ pk_add_sel (v2f d, v2f pair, bool a, bool b)
   return r;
 }
 
+/* Device-coherent accesses (relaxed atomics at agent scope: global_load / global_store with sc1).  The one-launch kernel's workgroups
+ * of a decode sit on different XCDs, whose L2s do not see each other's plain stores; an agent-scope fence fixes that by writing back
+ * and invalidating the WHOLE L2 (buffer_wbl2 / buffer_inv sc1) -- with one fence pair per meeting the kernel took 2.3 x the time of the
+ * 16-launch chain (2.13 against 0.92 ms per bench step).  So everything that crosses workgroups -- path metrics, decision words --
+ * is moved with these instead and no cache is ever flushed; COH = false compiles to the plain accesses of the launch chain. */
+typedef __attribute__ ((address_space (1))) float               *gfloat_ptr;       // (global, not flat: the workspace pointers come out of
+typedef __attribute__ ((address_space (1))) unsigned long long  *gu64_ptr;         //  a runtime-indexed array and the compiler loses the space)
+template<bool COH> __device__ __forceinline__ float
+ld_metric (const float *p)
+{
+  if (COH)
+    return __hip_atomic_load ((gfloat_ptr) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return *p;
+}
+template<bool COH> __device__ __forceinline__ void
+st_pair (float *p, float a, float b)                       // 8-byte aligned
+{
+  if (COH)
+    {
+      const unsigned long long v = (unsigned long long) __float_as_uint (a) | ((unsigned long long) __float_as_uint (b) << 32);
+      __hip_atomic_store ((gu64_ptr) p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  else
+    *reinterpret_cast<float2 *> (p) = make_float2 (a, b);
+}
+template<bool COH> __device__ __forceinline__ void
+st_quad (float *p, float a, float b, float c, float d)     // 16-byte aligned
+{
+  if (COH)
+    {
+      st_pair<true> (p, a, b);
+      st_pair<true> (p + 2, c, d);
+    }
+  else
+    *reinterpret_cast<float4 *> (p) = make_float4 (a, b, c, d);
+}
+template<bool COH> __device__ __forceinline__ void
+st_words (unsigned int *p, unsigned int a, unsigned int b, unsigned int c, unsigned int d)     // 16-byte aligned
+{
+  if (COH)
+    {
+      __hip_atomic_store ((gu64_ptr) p, (unsigned long long) a | ((unsigned long long) b << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store ((gu64_ptr) p + 1, (unsigned long long) c | ((unsigned long long) d << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  else
+    *reinterpret_cast<uint4 *> (p) = make_uint4 (a, b, c, d);
+}
+template<bool COH> __device__ __forceinline__ uint4
+ld_words (const unsigned int *p)
+{
+  if (COH)
+    {
+      const unsigned long long lo = __hip_atomic_load ((gu64_ptr) p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long hi = __hip_atomic_load ((gu64_ptr) p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return make_uint4 ((unsigned int) lo, (unsigned int) (lo >> 32), (unsigned int) hi, (unsigned int) (hi >> 32));
+    }
+  return *reinterpret_cast<const uint4 *> (p);
+}
+
 /* workspace of one block: [metrics A][metrics B][decision words of all rounds] */
 constexpr size_t V_METRIC_BYTES = V_STATES * sizeof (float);
 
@@ -208,7 +267,7 @@ viterbi_steps (const float *coded, int step0, float (&m)[1 << K], unsigned int (
 }
 
 /* a round through global memory: lane L of the block's 2^(15-K) */
-template<int BT, int K, bool PLAIN> __device__ __forceinline__ void
+template<int BT, int K, bool PLAIN, bool COH = false> __device__ __forceinline__ void
 viterbi_round (const float *coded, int step0, const float *m_in, float *m_out, unsigned int *dec, int L)
 {
   constexpr int NS = 1 << K;
@@ -216,18 +275,18 @@ viterbi_round (const float *coded, int step0, const float *m_in, float *m_out, u
   float m[NS];
 #pragma unroll
   for (int j = 0; j < NS; j++)
-    m[j] = m_in[L + j * GROUPS];
+    m[j] = ld_metric<COH> (m_in + L + j * GROUPS);
   unsigned int words[K];
   viterbi_steps<BT, K, PLAIN> (coded, step0, m, words, L);
-  float4 *out4 = reinterpret_cast<float4 *> (m_out + (size_t) L * NS);
+  float *out = m_out + (size_t) L * NS;
 #pragma unroll
   for (int j = 0; j < NS / 4; j++)
-    out4[j] = make_float4 (m[4 * j], m[4 * j + 1], m[4 * j + 2], m[4 * j + 3]);
+    st_quad<COH> (out + 4 * j, m[4 * j], m[4 * j + 1], m[4 * j + 2], m[4 * j + 3]);
   constexpr int DW = dec_words (K);
-  uint4 *dec4 = reinterpret_cast<uint4 *> (dec + (size_t) L * DW);
-  dec4[0] = make_uint4 (words[0], words[1], words[2], K > 3 ? words[K > 3 ? 3 : 0] : 0u);
+  unsigned int *d = dec + (size_t) L * DW;
+  st_words<COH> (d, words[0], words[1], words[2], K > 3 ? words[K > 3 ? 3 : 0] : 0u);
   if (DW == 8)
-    dec4[1] = make_uint4 (words[K > 4 ? 4 : 0], 0u, 0u, 0u);
+    st_words<COH> (d + 4, words[K > 4 ? 4 : 0], 0u, 0u, 0u);
 }
 
 // one launch for all three code types: blocks [0, n0) decode A blocks, [n0, n0 + n1) B blocks, the rest AB blocks
@@ -290,7 +349,7 @@ viterbi_round_kernel (ViterbiBatch b, int step0, int parity_in, size_t dec_offse
  * contiguous (four ds_read_b128), writes and reads are conflict free (324 = 4 mod 64, 20 a = 16 distinct multiples of 4 mod 64). */
 constexpr int SUPER_LDS = 16 * 324;
 
-template<int BT, int NPF> __device__ __forceinline__ void
+template<int BT, int NPF, bool COH = false> __device__ __forceinline__ void
 viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_out, unsigned int *dec, const size_t (&dec_off)[3],
                      int g, int lane, float *lds_a, float *lds_b, bool in_perm, bool out_perm, bool first = false)
 {
@@ -306,7 +365,7 @@ viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_
 #pragma unroll
   for (int j = 0; j < 16; j++)
     m[j] = first ? ((L1 | j) == 0 ? 0.f : -1.f)              // start state 0, everything else unreachable (convcode.cc:144-146)
-                 : in_perm ? m_in[g * 4096 + ((j << 8) | lane)] : m_in[L1 + j * 2048];
+                 : ld_metric<COH> (in_perm ? m_in + g * 4096 + ((j << 8) | lane) : m_in + L1 + j * 2048);
   const int hi = lane >> 4, lo = lane & 15;
 #pragma unroll
   for (int r = 0; r < 3; r++)
@@ -317,7 +376,7 @@ viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_
         viterbi_steps<BT, 4, false> (coded, step0 + 4 * r, m, words, L);
       else
         viterbi_steps<BT, 4, true> (coded, step0 + 4 * r, m, words, L);
-      reinterpret_cast<uint4 *> (dec + dec_off[r] + (size_t) L * 4)[0] = make_uint4 (words[0], words[1], words[2], words[3]);
+      st_words<COH> (dec + dec_off[r] + (size_t) L * 4, words[0], words[1], words[2], words[3]);
       if (r < 2)
         {
           float *x = r == 0 ? lds_a : lds_b;
@@ -338,13 +397,13 @@ viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_
     {
 #pragma unroll
       for (int f = 0; f < 8; f++)
-        *reinterpret_cast<float2 *> (m_out + f * 4096 + (g << 9) + (lane << 1)) = make_float2 (m[f], m[f + 8]);
+        st_pair<COH> (m_out + f * 4096 + (g << 9) + (lane << 1), m[f], m[f + 8]);
       return;
     }
-  float4 *out4 = reinterpret_cast<float4 *> (m_out + (size_t) ((g << 8) | lane) * 16);
+  float *out = m_out + (size_t) ((g << 8) | lane) * 16;
 #pragma unroll
   for (int q = 0; q < 4; q++)
-    out4[q] = make_float4 (m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
+    st_quad<COH> (out + 4 * q, m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
 }
 
 struct SuperOffsets { size_t off[3]; int in_perm, out_perm; };
@@ -403,12 +462,12 @@ struct TracePlan
 };
 
 /* one lane walks the survivors of a decode back, round by round (one aligned load of the lane's decision words per round) */
-__device__ __forceinline__ void
+template<bool COH = false> __device__ __forceinline__ void
 viterbi_trace_one (const TracePlan& plan, int final_parity, const unsigned char *ws, int n_steps, int rate, int *bits, float *error)
 {
   const float *metric = reinterpret_cast<const float *> (ws + (final_parity ? V_METRIC_BYTES : 0));
   const unsigned int *dec = reinterpret_cast<const unsigned int *> (ws + 2 * V_METRIC_BYTES);
-  *error = metric[0] / float (n_steps * rate);             // convcode.cc:197-199: state 0 at the end
+  *error = ld_metric<COH> (metric) / float (n_steps * rate);   // convcode.cc:197-199: state 0 at the end
   unsigned state = 0;
   for (int r = plan.n_rounds - 1; r >= 0; r--)
     {
@@ -417,11 +476,11 @@ viterbi_trace_one (const TracePlan& plan, int final_parity, const unsigned char 
       unsigned loc = state & ((1u << K) - 1);
       const int DW = dec_words (K);
       unsigned int w[5] = { 0, 0, 0, 0, 0 };
-      const uint4 *p = reinterpret_cast<const uint4 *> (dec + plan.dec_offset[r] + (size_t) L * DW);
-      const uint4 a = p[0];
+      const unsigned int *p = dec + plan.dec_offset[r] + (size_t) L * DW;
+      const uint4 a = ld_words<COH> (p);
       w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w;
       if (DW == 8)
-        w[4] = p[1].x;
+        w[4] = ld_words<COH> (p + 4).x;
       for (int i = K; i >= 1; i--)
         {
           const int step = plan.step0[r] + i - 1;
@@ -452,10 +511,10 @@ viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
  * what a batch costs is decided by the gaps between them: 0.9 ms per bench step from the kernels' own durations, 1.5 - 2.4 ms
  * between the HIP events on two different boxes.  The launches exist only because the 8 workgroups of a decode must exchange their
  * metrics every 12 steps -- a barrier among 8 workgroups, not across the grid.  So here a batch is one launch of 8 workgroups per
- * decode that stay resident for all 143 steps; between two exchanges they meet at a per-decode counter in global memory
- * (agent-scope release / acquire around a relaxed atomic: the compiler's L2 write-back and invalidate make the metrics and
- * decision words of the other XCDs' workgroups visible), the first round starts from the initial metrics without reading them,
- * and the workgroup with family 0 walks the survivors back at the end.
+ * decode that stay resident for all 143 steps; between two exchanges they meet at a per-decode counter in global memory, the
+ * metrics and decision words cross the XCDs through device-coherent loads and stores (ld_metric above: no cache is flushed), the
+ * first round starts from the initial metrics without reading them, and the workgroup with family 0 walks the survivors back at
+ * the end.
  *   Which (decode, family) a workgroup works on is NOT its blockIdx: it draws a ticket when it starts (atomic counter), decode =
  * ticket / 8, family = ticket % 8.  So the workgroups that are resident always hold the lowest tickets, the peers a waiting
  * workgroup needs are either resident or the very next ones to start, and at most one decode per launch (<= 7 workgroups) can be
@@ -465,14 +524,16 @@ viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
  *   The counters are self-cleaning (zero when the launch ends: the family-0 workgroup clears its decode's counter after the last
  * wait, the last workgroup to leave clears ticket and exit counters), so a lane's sync block is zeroed once, when it is allocated.
  * A wait that lasts longer than ~2 s of wall time (a fault elsewhere) gives up and marks the batch: every decode then reports the
- * impossible error value -1 and the host fails the call instead of hanging the GPU.
+ * impossible error value -2 (a block of NaN soft bits ends at -1 / coded length, nothing lies below that) and the host fails the call instead of hanging the GPU.
  * sync block (unsigned int): [0] ticket, [1] workgroups that left, [2] failure mark, [16 (1 + d)] counter of decode d */
 constexpr int SYNC_STRIDE = 16;
 
 __device__ __forceinline__ void
 decode_barrier (unsigned int *counter, unsigned int target, unsigned int *fail, bool wait = true)
 {
-  __builtin_amdgcn_fence (__ATOMIC_RELEASE, "agent");
+  // every coherent store of this wave has been acknowledged (written through to where the other XCDs read it) before the wave arrives;
+  // __syncthreads collects the workgroup's waves, then ONE lane counts the workgroup in.  No cache maintenance (see ld_metric).
+  asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0)
     __hip_atomic_fetch_add (counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -483,7 +544,7 @@ decode_barrier (unsigned int *counter, unsigned int target, unsigned int *fail, 
       const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
       while (__hip_atomic_load (counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target)
         {
-          __builtin_amdgcn_s_sleep (4);
+          __builtin_amdgcn_s_sleep (2);
           if (__builtin_amdgcn_s_memrealtime() - t0 > 200000000ull || __hip_atomic_load (fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
             {
               __hip_atomic_store (fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -492,7 +553,6 @@ decode_barrier (unsigned int *counter, unsigned int target, unsigned int *fail, 
         }
     }
   __syncthreads();
-  __builtin_amdgcn_fence (__ATOMIC_ACQUIRE, "agent");
 }
 
 template<int BT> __device__ __forceinline__ void
@@ -509,8 +569,8 @@ viterbi_persistent_decode (const ViterbiBatch& b, const TracePlan& plan, int n_s
   unsigned int meetings = 0;
   if (n_super == 0)
     {
-      for (int i = g * 4096 + lane; i < (g + 1) * 4096; i += V_WG)
-        metric[0][i] = i == 0 ? 0.f : -1.f;
+      for (int i = g * 4096 + 2 * lane; i < (g + 1) * 4096; i += 2 * V_WG)
+        st_pair<true> (metric[0] + i, i == 0 ? 0.f : -1.f, -1.f);
       decode_barrier (counter, 8 * ++meetings, fail);
     }
   for (int s = 0; s < n_super; s++)
@@ -525,10 +585,10 @@ viterbi_persistent_decode (const ViterbiBatch& b, const TracePlan& plan, int n_s
       const float *m_in = metric[parity];
       float *m_out = metric[parity ^ 1];
       const bool in_perm = s > 0, out_perm = s + 1 < n_super, first = s == 0;
-      if (npf == 0)      viterbi_super_round<BT, 0> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
-      else if (npf == 1) viterbi_super_round<BT, 1> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
-      else if (npf == 2) viterbi_super_round<BT, 2> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
-      else               viterbi_super_round<BT, 3> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
+      if (npf == 0)      viterbi_super_round<BT, 0, true> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
+      else if (npf == 1) viterbi_super_round<BT, 1, true> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
+      else if (npf == 2) viterbi_super_round<BT, 2, true> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
+      else               viterbi_super_round<BT, 3, true> (coded, step0, m_in, m_out, dec, off, g, lane, lds_a, lds_b, in_perm, out_perm, first);
       parity ^= 1;
       decode_barrier (counter, 8 * ++meetings, fail, g == 0 || r + 3 < plan.n_rounds);
     }
@@ -541,10 +601,10 @@ viterbi_persistent_decode (const ViterbiBatch& b, const TracePlan& plan, int n_s
       unsigned int *d = dec + plan.dec_offset[r];
       for (int L = g * V_WG + lane; L < (V_STATES >> k); L += 8 * V_WG)
         {
-          if (k == 4 && plain)  viterbi_round<BT, 4, true> (coded, step0, m_in, m_out, d, L);
-          else if (k == 4)      viterbi_round<BT, 4, false> (coded, step0, m_in, m_out, d, L);
-          else if (plain)       viterbi_round<BT, 3, true> (coded, step0, m_in, m_out, d, L);
-          else                  viterbi_round<BT, 3, false> (coded, step0, m_in, m_out, d, L);
+          if (k == 4 && plain)  viterbi_round<BT, 4, true, true> (coded, step0, m_in, m_out, d, L);
+          else if (k == 4)      viterbi_round<BT, 4, false, true> (coded, step0, m_in, m_out, d, L);
+          else if (plain)       viterbi_round<BT, 3, true, true> (coded, step0, m_in, m_out, d, L);
+          else                  viterbi_round<BT, 3, false, true> (coded, step0, m_in, m_out, d, L);
         }
       parity ^= 1;
       decode_barrier (counter, 8 * ++meetings, fail, g == 0 || r + 1 < plan.n_rounds);       // after the last round only the tracer waits
@@ -554,8 +614,8 @@ viterbi_persistent_decode (const ViterbiBatch& b, const TracePlan& plan, int n_s
       // (all eight have arrived for the last time and only this workgroup waited: nobody looks at the counter any more)
       __hip_atomic_store (counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       float err;
-      viterbi_trace_one (plan, parity, ws, b.n_steps, rate, b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER), &err);
-      b.error[t][blk] = __hip_atomic_load (fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? -1.f : err;
+      viterbi_trace_one<true> (plan, parity, ws, b.n_steps, rate, b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER), &err);
+      b.error[t][blk] = __hip_atomic_load (fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? -2.f : err;
     }
 }
 

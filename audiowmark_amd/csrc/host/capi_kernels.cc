@@ -255,6 +255,14 @@ awm_add_limit_d (awm_ctx *ctx, float *out_d, size_t n_frames, int n_channels, si
   return 0;
 }
 
+/* (measurement knob, tools/gpu_add_slabs.py) `add` in slabs of this many MB of output: the fused add of slab s, then the limiter for
+ * everything whose look-ahead second is complete -- so that the limiter re-reads what the add has just written while it may still
+ * be in the 256 MB memory-side cache.  0 (default): one add over the whole stream, then one limiter pass.  DESIGN.md section 3 has
+ * the sweep: the fused add needs 4096 resident waves x long spans (the 2 halo frames per span are its overhead), a slab small enough
+ * for the cache starves it. */
+static int g_add_slab_mb = 0;
+extern "C" void awm_debug_set_add_slab_mb (int mb) { g_add_slab_mb = mb < 0 ? 0 : mb; }
+
 /* whole stream on one lane (stream + block maxima + limiter table of that lane; the context itself is lane 0) */
 static int
 add_full (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
@@ -272,6 +280,38 @@ add_full (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, in
       unsigned int bits;
       std::memcpy (&bits, &LIMITER_CEILING, sizeof (bits));
       AWM_HIP_CHECK (awmk::launch_fill_u32 (st, reinterpret_cast<unsigned int *> (block_max), bits, n_blocks));
+    }
+  const size_t FRAME = Params::frame_size;
+  size_t slab = g_add_slab_mb ? (size_t (g_add_slab_mb) << 20) / (n_channels * sizeof (float)) / FRAME * FRAME : 0;    // sample frames
+  if (!use_limiter || pcm_in_d == out_d || slab < 64 * FRAME || n_frames < 2 * slab)
+    slab = 0;
+  if (slab)
+    {
+      // slabs of whole 1024-sample frames, the last one takes the rest; each one is a span with its neighbours' frames as halos
+      // (add_mix_impl: the same entry the multi-GPU spans use -- output bit-identical to the whole-stream launch)
+      const size_t tab_entries = awmk::limiter_tab_entries ((long long) n_frames, 0, LIMITER_BLOCK);
+      if (int rc = lane->ws_limit_tab.reserve ((tab_entries + 1) * sizeof (float2))) return rc;
+      const size_t n_slabs = n_frames / slab;
+      size_t limited = 0;                                  // the limiter has run for samples [0, limited)
+      for (size_t i = 0; i < n_slabs; i++)
+        {
+          const size_t a = i * slab, b = i + 1 == n_slabs ? n_frames : a + slab;
+          if (int rc = add_mix_impl (ctx, pcm_in_d + a * n_channels, out_d + a * n_channels, b - a, n_channels, frame_mod_dev, water_delta,
+                                     a / FRAME, a ? pcm_in_d + (a - FRAME) * n_channels : nullptr, b < n_frames ? pcm_in_d + b * n_channels : nullptr,
+                                     block_max, 0, n_blocks, lane))
+            return rc;
+          // the ramp of limiter block k needs the maxima of k - 1, k, k + 1 (limiter.cc:99-124): complete once the add has passed (k + 2) BS
+          const size_t upto = b == n_frames ? n_frames : (b / LIMITER_BLOCK >= 1 ? (b / LIMITER_BLOCK - 1) * size_t (LIMITER_BLOCK) : 0);
+          if (upto > limited)
+            {
+              ProfScope ps (ctx, PROF_LIMITER, double (upto - limited) * n_channels * 8.0, st);
+              // (the passes share the lane's ramp table: they run in stream order, a pass rebuilds the entries of its own blocks)
+              AWM_HIP_CHECK (awmk::launch_limiter (st, out_d + limited * n_channels, (long long) (upto - limited), n_channels, (long long) limited, block_max, 0,
+                                                   (long long) n_blocks, LIMITER_BLOCK, LIMITER_CEILING, lane->ws_limit_tab.as<float2>(), tab_entries));
+              limited = upto;
+            }
+        }
+      return 0;
     }
   if (int rc = add_mix_impl (ctx, pcm_in_d, out_d, n_frames, n_channels, frame_mod_dev, water_delta, 0, nullptr, nullptr,
                              block_max, 0, n_blocks, lane))

@@ -360,3 +360,128 @@ awm_multi_get_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], const f
 }
 
 } // extern "C"
+
+/* ---- batches of clips over several contexts: replicas, one host thread per context */
+namespace {
+template<class F> int
+run_clip_shares (awm_ctx *const *ctxs, int n_ctx, const int *ctx_of_clip, size_t n_clips, const char *what, F fn)
+{
+  if (!ctxs || n_ctx < 1 || (n_clips && !ctx_of_clip) || std::any_of (ctxs, ctxs + n_ctx, [] (awm_ctx *c) { return !c; }))
+    {
+      set_error (std::string (what) + ": bad argument");
+      return AWM_ERR_ARG;
+    }
+  std::vector<std::vector<size_t>> share (n_ctx);
+  for (size_t i = 0; i < n_clips; i++)
+    {
+      if (ctx_of_clip[i] < 0 || ctx_of_clip[i] >= n_ctx)
+        {
+          set_error (std::string (what) + ": ctx_of_clip out of range");
+          return AWM_ERR_ARG;
+        }
+      share[ctx_of_clip[i]].push_back (i);
+    }
+  ParamsBind bind (ctxs[0]->own_params.get());
+  ParamValues *const pv = &params();
+  std::vector<int> rcs (n_ctx, 0);
+  std::vector<std::string> messages (n_ctx);
+  auto body = [&] (int r) {
+    ParamsBind thread_bind (pv);
+    if (share[r].empty())
+      return;
+    rcs[r] = hipSetDevice (ctxs[r]->device) == hipSuccess ? fn (r, share[r]) : AWM_ERR_HIP;
+    if (rcs[r])
+      messages[r] = last_error();
+  };
+  std::vector<std::thread> threads;
+  for (int r = 1; r < n_ctx; r++)
+    threads.emplace_back (body, r);
+  body (0);
+  for (auto& t : threads)
+    t.join();
+  for (int r = 0; r < n_ctx; r++)
+    if (rcs[r])
+      {
+        set_error (messages[r]);
+        return rcs[r];
+      }
+  return 0;
+}
+
+/* the keys of a share, 16 bytes each (one_key repeated when there is no list) */
+std::vector<uint8_t>
+share_keys (const std::vector<size_t>& idx, const uint8_t *keys, const uint8_t *one_key)
+{
+  std::vector<uint8_t> out (idx.size() * 16);
+  for (size_t j = 0; j < idx.size(); j++)
+    std::memcpy (out.data() + 16 * j, keys ? keys + 16 * idx[j] : one_key, 16);
+  return out;
+}
+} // namespace
+
+extern "C" {
+
+int
+awm_multi_add_watermark_batch_d (awm_ctx *const *ctxs, int n_ctx, const int *ctx_of_clip, const uint8_t *keys, const uint8_t *one_key,
+                                 const char *payload_hex, size_t n_clips, const float *const *pcm_in_d, float *const *out_d,
+                                 const size_t *n_frames, int n_channels)
+{
+  if ((!keys && !one_key) || (n_clips && (!pcm_in_d || !out_d || !n_frames)))
+    {
+      set_error ("awm_multi_add_watermark_batch_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  return run_clip_shares (ctxs, n_ctx, ctx_of_clip, n_clips, "awm_multi_add_watermark_batch_d", [&] (int r, const std::vector<size_t>& idx) {
+    std::vector<const float *> in;
+    std::vector<float *> out;
+    std::vector<size_t> len;
+    for (size_t i : idx)
+      {
+        in.push_back (pcm_in_d[i]);
+        out.push_back (out_d[i]);
+        len.push_back (n_frames[i]);
+      }
+    // (the single-context entry points bind the context's own settings; a helper without its own set follows the calling thread's)
+    if (keys)
+      return awm_add_watermark_batch_keys_d (ctxs[r], share_keys (idx, keys, one_key).data(), payload_hex, idx.size(), in.data(), out.data(), len.data(), n_channels);
+    return awm_add_watermark_batch_d (ctxs[r], one_key, payload_hex, idx.size(), in.data(), out.data(), len.data(), n_channels);
+  });
+}
+
+int
+awm_multi_get_watermark_batch_d (awm_ctx *const *ctxs, int n_ctx, const int *ctx_of_clip, const uint8_t *keys, const uint8_t *one_key,
+                                 size_t n_clips, const float *const *pcm_d, const size_t *n_frames, int n_channels,
+                                 size_t max_out_per_clip, awm_pattern *out, int *n_out)
+{
+  if ((!keys && !one_key) || (n_clips && (!pcm_d || !n_frames || !n_out || (max_out_per_clip && !out))))
+    {
+      set_error ("awm_multi_get_watermark_batch_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  return run_clip_shares (ctxs, n_ctx, ctx_of_clip, n_clips, "awm_multi_get_watermark_batch_d", [&] (int r, const std::vector<size_t>& idx) {
+    std::vector<const float *> in;
+    std::vector<size_t> len;
+    for (size_t i : idx)
+      {
+        in.push_back (pcm_d[i]);
+        len.push_back (n_frames[i]);
+      }
+    std::vector<awm_pattern> pats (idx.size() * max_out_per_clip);
+    std::vector<int> counts (idx.size(), 0);
+    const int rc = keys ? awm_get_watermark_batch_keys_d (ctxs[r], share_keys (idx, keys, one_key).data(), idx.size(), in.data(), len.data(), n_channels, 0,
+                                                          max_out_per_clip, pats.data(), counts.data())
+                        : awm_get_watermark_batch_d (ctxs[r], one_key, idx.size(), in.data(), len.data(), n_channels, 0, max_out_per_clip, pats.data(),
+                                                     counts.data());
+    if (rc)
+      return rc;
+    for (size_t j = 0; j < idx.size(); j++)
+      {
+        n_out[idx[j]] = counts[j];
+        std::copy (pats.begin() + j * max_out_per_clip, pats.begin() + j * max_out_per_clip + std::min<size_t> (size_t (std::max (counts[j], 0)), max_out_per_clip),
+                   out + idx[j] * max_out_per_clip);
+      }
+    return 0;
+  });
+}
+
+} // extern "C"

@@ -50,6 +50,11 @@ int decode_finish (WorkLane *lane, const Key& key, DecodeJob& job, const std::ve
 void combine_blocks (const std::vector<PatternRawBits>& pattern_raw_vec, const DeviceWav& wav, size_t chunk, std::vector<PendingDecode>& pending);
 
 int decode_chunks_blocks_only (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
-                               std::vector<ResultSet>& chunk_sets, std::string *debug_sync_first);
+                               std::vector<ResultSet>& chunk_sets, std::string *debug_sync_first, int lane_base = 0);
+
+/* decode()'s speed part (reference wmget.cc:886-927) for one chunk on one lane: speed search, stretched copy, block (and, for the first
+ * chunk of a stream, clip) decoder on the copy; patterns go to result_set with their speed.  Nothing happens unless speed detection is on. */
+int decode_speed_chunk (awm_ctx *ctx, WorkLane *lane, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& chunk_wav,
+                        bool first_chunk, std::string *report);
 
 } // namespace awm

@@ -670,8 +670,7 @@ get_watermark_multi (awm_ctx *ctx, const std::vector<Key>& key_list, const Devic
   spread = false;
   const size_t n_ctx = ctx->helpers.size() + 1;
   const size_t min_span = 4 * mark_block_frame_count() * Params::frame_size;          // at least four blocks per GPU
-  if (n_ctx < 2 || key_list.size() != 1 || params().detect_speed || params().detect_speed_patient || params().try_speed > 0
-      || params().test_no_sync || wav.n_frames < n_ctx * min_span)
+  if (n_ctx < 2 || key_list.size() != 1 || params().test_no_sync || wav.n_frames < n_ctx * min_span)
     return 0;
   const int C = wav.n_channels;
   std::vector<awm_ctx *> ctxs { ctx };

@@ -152,13 +152,14 @@ block_soft_bits (awm_ctx *ctx, KeyTables *kt, const DeviceWav& wav, const std::v
 }
 
 /* conv_decode_soft for up to three batches (A, B, AB blocks) in ONE launch */
-/* a decode error below zero cannot come out of the arithmetic (a mean of squares): it is the one-launch kernel's mark for "a device-side
- * wait gave up" (hip/viterbi.hip) -- the batch is void and the lane's sync block has to be cleared before its next use */
+/* The smallest decode error the arithmetic can produce is -1 / coded length (a block of NaN soft bits: the end state counts as
+ * unreachable, convcode.cc:144-199); -2 is the one-launch kernel's mark for "a device-side wait gave up" (hip/viterbi.hip) -- the batch
+ * is void and the lane's sync block has to be cleared before its next use */
 int
 viterbi_check_errors (WorkLane *lane, const float *errors, size_t n)
 {
   for (size_t i = 0; i < n; i++)
-    if (errors[i] < 0)
+    if (errors[i] <= -1.5f)
       {
         if (lane->ws_viterbi_sync.ptr)
           (void) hipMemsetAsync (lane->ws_viterbi_sync.ptr, 0, lane->ws_viterbi_sync.bytes, lane->stream);
@@ -556,7 +557,7 @@ namespace {
 int
 block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<Key>& key_list, const DeviceWav& stream,
                    const std::vector<ChunkRange>& chunks, const std::vector<ResultSet *>& result_sets, double speed,
-                   std::string *debug_sync_first_chunk)
+                   std::string *debug_sync_first_chunk, int lane_base = 0)
 {
   const size_t count = mark_block_frame_count();
   std::vector<SyncFinder::Score> first_scores;
@@ -573,7 +574,9 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
   else
     for (int i = 0; i < std::max (n_lanes, 1); i++)
       {
-        WorkLane *l = ctx->lane (i);
+        // lane_base > 0: a second decoder run of the same context beside another one (the multi-GPU protocol's local chunks beside
+        // its shared ones, on a host thread of their own): its own set of lanes, and the caller has made sure the PCM is complete
+        WorkLane *l = ctx->lane (lane_base + i);
         if (!l)
           {
             set_error ("cannot create a work lane (stream)");
@@ -581,7 +584,7 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
           }
         lanes.push_back (l);
       }
-  if (lanes.size() > 1)
+  if (lanes.size() > 1 && lane_base == 0)
     {
       // the PCM may still be in flight on the context's stream (e.g. add -> get): the other lanes wait for it
       if (!ctx->ev_sync)
@@ -1030,6 +1033,14 @@ decode_speed (awm_ctx *ctx, WorkLane *home, bool spread, ResultSet& result_set, 
 
 bool speed_print_results = false;       // decode() passes !orig_bits.empty(): set by the command line front end for `cmp`
 
+/* the speed part of ONE chunk on one lane (the multi-GPU protocol runs it on the rank that owns the chunk, wmshard.cc) */
+int
+decode_speed_chunk (awm_ctx *ctx, WorkLane *lane, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& chunk_wav,
+                    bool first_chunk, std::string *report)
+{
+  return decode_speed (ctx, lane, false, result_set, key_list, chunk_wav, first_chunk, report);
+}
+
 int
 decode_chunk (awm_ctx *ctx, ResultSet& result_set, const std::vector<Key>& key_list, const DeviceWav& wav, bool first_chunk)
 {
@@ -1187,14 +1198,14 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
  * rank's span this way: plain path, chunks on concurrent lanes) */
 int
 decode_chunks_blocks_only (awm_ctx *ctx, const std::vector<Key>& key_list, const DeviceWav& wav, const std::vector<ChunkRange>& chunks,
-                           std::vector<ResultSet>& chunk_sets, std::string *debug_sync_first)
+                           std::vector<ResultSet>& chunk_sets, std::string *debug_sync_first, int lane_base)
 {
   chunk_sets.clear();
   chunk_sets.resize (chunks.size());
   std::vector<ResultSet *> ptrs;
   for (auto& cs : chunk_sets)
     ptrs.push_back (&cs);
-  return block_decoder_run (ctx, ctx, true, key_list, wav, chunks, ptrs, 1, debug_sync_first);
+  return block_decoder_run (ctx, ctx, true, key_list, wav, chunks, ptrs, 1, debug_sync_first, lane_base);
 }
 
 int

@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <future>
 #include <map>
 #include <set>
 
@@ -362,11 +363,12 @@ int
 sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64_t *span_frames, const awm_comm *comm, ResultSet& result)
 {
   const int rank = comm->rank, world = comm->world;
-  if (params().detect_speed || params().detect_speed_patient || params().try_speed > 0 || params().test_no_sync)
+  if (params().test_no_sync)
     {
-      set_error ("awm_sharded_get_d: speed detection / --test-no-sync are not sharded");
+      set_error ("awm_sharded_get_d: --test-no-sync is not sharded");
       return AWM_ERR_ARG;
     }
+  const bool speed_on = params().detect_speed || params().detect_speed_patient || params().try_speed > 0;
   const ShardPlan plan = make_plan (span_frames, world);
   const size_t total = plan.total(), block = plan.block_frames;
   const size_t my_lo = plan.start[rank], my_hi = plan.start[rank + 1];
@@ -418,9 +420,107 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       AWM_HIP_CHECK (hipMemcpyAsync (tail_buf + (t.lo - t_lo) * C, pcm + (t.lo - my_lo) * C, (t.hi - t.lo) * C * sizeof (float), hipMemcpyDeviceToDevice, st0));
   AWM_HIP_CHECK (stream_wait (st0));                        // (the samples may still be in flight on the context's stream, e.g. add -> get)
 
+  /* ---- speed detection (decode()'s speed part, reference wmget.cc:886-927; wmspeed.cc:622-781 works on a whole chunk: clip selection
+   * over the chunk, then the chunk stretched back and decoded) is sharded BY CHUNK: a chunk belongs to the rank that holds most of it,
+   * which fetches the rest (nothing, when the spans follow the chunk grid; at most half a chunk per span edge otherwise) and runs the
+   * part on a host thread and lanes of its own, beside the position-split protocol of the plain decoders below.  Its patterns join
+   * the chunk's list IN FRONT of the plain ones, as in the reference (the order decides which of two equivalent patterns survives
+   * the merge and how the ratings add up). */
+  struct SpeedChunk { size_t c; DevBuffer buf; const float *data; ResultSet set; std::string report; };
+  std::vector<SpeedChunk> speed_chunks;
+  struct SpeedFree { std::vector<SpeedChunk>& v; ~SpeedFree() { for (SpeedChunk& s : v) s.buf.release(); } } speed_free { speed_chunks };
+  std::string speed_error;
+  std::future<int> speed_run;                              // (declared last: on every return path the task ends before the buffers go)
+  if (speed_on)
+    {
+      std::vector<Msg> sends, recvs;
+      for (size_t c = 0; c < plan.chunks.size(); c++)
+        {
+          const size_t c_lo = plan.chunks[c].first_frame, c_hi = c_lo + plan.chunks[c].n_frames;
+          int owner = -1;
+          size_t best = 0;
+          for (int r = 0; r < world; r++)
+            {
+              const size_t lo = std::max (c_lo, plan.start[r]), hi = std::min (c_hi, plan.start[r + 1]);
+              if (hi > lo && hi - lo > best)
+                {
+                  best = hi - lo;
+                  owner = r;
+                }
+            }
+          if (owner < 0)
+            continue;
+          const size_t lo = std::max (c_lo, my_lo), hi = std::min (c_hi, my_hi);      // my part of the chunk
+          if (owner != rank)
+            {
+              if (hi > lo)
+                sends.push_back ({ pcm + (lo - my_lo) * C, nullptr, (hi - lo) * C * sizeof (float), owner });
+              continue;
+            }
+          speed_chunks.emplace_back();
+          SpeedChunk& sc = speed_chunks.back();
+          sc.c = c;
+          if (lo == c_lo && hi == c_hi)
+            {
+              sc.data = pcm + (c_lo - my_lo) * C;               // all of it is here: a view
+              continue;
+            }
+          if (int rc = sc.buf.reserve ((c_hi - c_lo) * C * sizeof (float))) return rc;
+          sc.data = sc.buf.as<float>();
+          AWM_HIP_CHECK (hipMemcpyAsync (sc.buf.as<float>() + (lo - c_lo) * C, pcm + (lo - my_lo) * C, (hi - lo) * C * sizeof (float), hipMemcpyDeviceToDevice, st0));
+          for (int r = 0; r < world; r++)
+            {
+              const size_t rl = std::max (c_lo, plan.start[r]), rh = std::min (c_hi, plan.start[r + 1]);
+              if (r != rank && rh > rl)
+                recvs.push_back ({ nullptr, sc.buf.as<float>() + (rl - c_lo) * C, (rh - rl) * C * sizeof (float), r });
+            }
+        }
+      AWM_HIP_CHECK (stream_wait (st0));
+      if (int rc = run_exchange (comm, true, sends, recvs, "exchange_d (chunks for the speed search)"))
+        return rc;
+      AWM_HIP_CHECK (stream_wait (st0));                   // (the fetched samples are read on other lanes)
+      if (!speed_chunks.empty())
+        {
+          ParamValues *const pv = &params();
+          const int lane_base = 2 * std::max (1, std::min (ctx->chunk_lanes, CHUNK_LANES));       // behind the shared and the local chunks' lanes
+          const bool want_report = speed_print_results;
+          speed_run = std::async (std::launch::async, [&, pv, lane_base, want_report] {
+            ParamsBind bind (pv);
+            if (hipSetDevice (ctx->device) != hipSuccess)
+              return int (AWM_ERR_HIP);
+            WorkLane *lane = ctx->lane (lane_base);
+            if (!lane)
+              {
+                speed_error = "cannot create a work lane (stream)";
+                return int (AWM_ERR_HIP);
+              }
+            for (SpeedChunk& sc : speed_chunks)
+              {
+                DeviceWav cw;
+                cw.data = sc.data;
+                cw.n_frames = plan.chunks[sc.c].n_frames;
+                cw.n_channels = C;
+                cw.sample_rate = Params::mark_sample_rate;
+                if (int rc = decode_speed_chunk (ctx, lane, sc.set, key_list, cw, sc.c == 0, want_report ? &sc.report : nullptr))
+                  {
+                    speed_error = last_error();
+                    return rc;
+                  }
+              }
+            return 0;
+          });
+        }
+    }
+
   /* ---- my chunks ---- */
   std::vector<size_t> local_chunks;
   std::vector<ChunkWork> work;
+  // (state of the local chunks' decoder thread; declared before the future so that it outlives the task on every return path)
+  std::vector<ChunkRange> local_ranges;
+  DeviceWav local_wav;
+  std::vector<ResultSet> local_sets;
+  std::string local_dbg, local_error;
+  std::future<int> local_run;
   size_t q_total = 0;
   for (size_t c = 0; c < plan.chunks.size(); c++)
     {
@@ -549,6 +649,27 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
       }
   return 0;
   };
+  /* ---- the chunks that lie completely inside my span need nothing from anybody: the plain BlockDecoder, on a host thread and a set of
+   * lanes of their own, BESIDE the shared chunks' phases (whose waits -- for the other ranks, for the lanes at the end of a phase --
+   * they fill; until round 4 they ran after phase 8 and a rank's shared and local work were serialised) */
+  if (!local_chunks.empty())
+    {
+      for (size_t c : local_chunks)
+        local_ranges.push_back ({ plan.chunks[c].first_frame - my_lo, plan.chunks[c].n_frames, 0.0 });
+      local_wav.data = pcm;
+      local_wav.n_frames = my_hi - my_lo;
+      local_wav.n_channels = C;
+      ParamValues *const pv = &params();
+      const int lane_base = int (lanes.size());
+      local_run = std::async (std::launch::async, [&, pv, lane_base] {
+        ParamsBind bind (pv);
+        (void) hipSetDevice (ctx->device);
+        const int rc = decode_chunks_blocks_only (ctx, key_list, local_wav, local_ranges, local_sets, &local_dbg, lane_base);
+        if (rc)
+          local_error = last_error();
+        return rc;
+      });
+    }
   if (int rc = score_parts (false)) return rc;
   {
     std::vector<Msg> sends, recvs;
@@ -907,26 +1028,54 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
         if (int rc = decode_collect (work[i])) return rc;
     }
 
-  /* ---- the chunks inside my span: BlockDecoder as on one GPU (after the shared chunks, whose phases the other ranks wait in) */
-  if (!local_chunks.empty())
+  /* ---- the speed part of my chunks: its patterns come first in their chunk's list (job numbers below every plain one) */
+  std::string my_reports;                                  // "chunk <c>\n<report text>" records, merged by rank 0 in chunk order
+  if (speed_run.valid())
     {
-      std::vector<ChunkRange> ranges;
-      for (size_t c : local_chunks)
-        ranges.push_back ({ plan.chunks[c].first_frame - my_lo, plan.chunks[c].n_frames, 0.0 });
-      DeviceWav lw;
-      lw.data = pcm;
-      lw.n_frames = my_hi - my_lo;
-      lw.n_channels = C;
-      std::vector<ResultSet> sets;
-      std::string dbg;
-      if (int rc = decode_chunks_blocks_only (ctx, key_list, lw, ranges, sets, &dbg))
-        return rc;
+      if (int rc = speed_run.get())
+        {
+          set_error (speed_error);
+          return rc;
+        }
+      for (SpeedChunk& sc : speed_chunks)
+        {
+          for (size_t j = 0; j < sc.set.patterns.size(); j++)
+            {
+              const ResultSet::Pattern& p = sc.set.patterns[j];
+              PatternRec rec {};
+              rec.chunk = int32_t (sc.c);
+              rec.job = int32_t (j) - (1 << 24);
+              rec.pat.time = p.time;
+              rec.pat.sync_index = p.sync_score.index;
+              rec.pat.sync_quality = p.sync_score.quality;
+              rec.pat.block_type = int (p.sync_score.block_type);
+              rec.pat.type = int (p.type);
+              rec.pat.decode_error = p.decode_error;
+              rec.pat.speed = p.speed;
+              rec.pat.n_bits = std::min<int> (int (p.bit_vec.size()), 128);
+              for (int b = 0; b < rec.pat.n_bits; b++)
+                rec.pat.bits[b] = p.bit_vec[b];
+              my_patterns.push_back (rec);
+            }
+          if (!sc.report.empty())
+            my_reports += string_printf ("%zu\n", sc.c) + sc.report + '\0';
+        }
+    }
+
+  /* ---- the chunks inside my span: collect what the decoder thread found */
+  if (local_run.valid())
+    {
+      if (int rc = local_run.get())
+        {
+          set_error (local_error);
+          return rc;
+        }
       if (local_chunks[0] == 0)
-        debug_sync = dbg;
-      for (size_t i = 0; i < sets.size(); i++)
-        for (size_t j = 0; j < sets[i].patterns.size(); j++)
+        debug_sync = local_dbg;
+      for (size_t i = 0; i < local_sets.size(); i++)
+        for (size_t j = 0; j < local_sets[i].patterns.size(); j++)
           {
-            const ResultSet::Pattern& p = sets[i].patterns[j];
+            const ResultSet::Pattern& p = local_sets[i].patterns[j];
             PatternRec rec {};
             rec.chunk = int32_t (local_chunks[i]);
             rec.job = int32_t (j);                               // (submission order of the chunk's patterns)
@@ -975,6 +1124,53 @@ sharded_get (awm_ctx *ctx, const Key& key, const float *pcm, int C, const uint64
     if (int rc = run_exchange (comm, false, sends, recvs, "exchange_h (patterns)"))
       return rc;
   }
+  if (speed_on)
+    {
+      // the `detect_speed` report lines of `cmp` (decode() prints one per chunk and key, wmget.cc:902): to rank 0, printed in chunk order
+      std::vector<uint64_t> sizes (world, 0);
+      std::vector<std::string> texts (world);
+      {
+        std::vector<Msg> sends, recvs;
+        uint64_t mine = my_reports.size();
+        if (rank == 0)
+          for (int r = 1; r < world; r++)
+            recvs.push_back ({ nullptr, &sizes[r], sizeof (uint64_t), r });
+        else
+          sends.push_back ({ &mine, nullptr, sizeof (uint64_t), 0 });
+        if (int rc = run_exchange (comm, false, sends, recvs, "exchange_h (report sizes)"))
+          return rc;
+      }
+      {
+        std::vector<Msg> sends, recvs;
+        if (rank == 0)
+          for (int r = 1; r < world; r++)
+            {
+              texts[r].resize (sizes[r]);
+              if (sizes[r])
+                recvs.push_back ({ nullptr, &texts[r][0], size_t (sizes[r]), r });
+            }
+        else if (!my_reports.empty())
+          sends.push_back ({ my_reports.data(), nullptr, my_reports.size(), 0 });
+        if (int rc = run_exchange (comm, false, sends, recvs, "exchange_h (reports)"))
+          return rc;
+      }
+      if (rank == 0)
+        {
+          texts[0] = my_reports;
+          std::map<size_t, std::string> by_chunk;
+          for (const std::string& t : texts)
+            for (size_t pos = 0; pos < t.size(); )
+              {
+                const size_t end = t.find ('\0', pos), nl = t.find ('\n', pos);
+                if (end == std::string::npos || nl == std::string::npos || nl > end)
+                  break;
+                by_chunk[size_t (std::strtoull (t.substr (pos, nl - pos).c_str(), nullptr, 10))] += t.substr (nl + 1, end - nl - 1);
+                pos = end + 1;
+              }
+          for (const auto& kv : by_chunk)
+            fputs (kv.second.c_str(), stdout);
+        }
+    }
   if (rank != 0)
     return 0;
   from[0] = std::move (my_patterns);

@@ -42,6 +42,10 @@ awm.lib.awm_sharded_get_d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_in
 awm.lib.awm_sharded_plan.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
 awm.lib.awm_multi_add_d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
 awm.lib.awm_multi_get_d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t, C.c_void_p]
+awm.lib.awm_multi_add_watermark_batch_d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_int]
+awm.lib.awm_multi_get_watermark_batch_d.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_char_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_void_p,
+                                                    C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
 
 
 def plan(lengths):
@@ -107,8 +111,12 @@ class TorchComm:
                     req.wait()
             for t, stage in copy_back:
                 t.copy_(stage)
-            if (self.nccl or on_device) and not self.host_only:
-                torch.cuda.synchronize(self.device)              # the callback's writes are complete when it returns
+            # awm_comm's contract: the writes are visible to the CONTEXT's stream on return.  nccl + device buffers: req.wait() has
+            # made torch's current stream -- the stream the context works on (binding.Context) -- wait for the transfers, so
+            # everything stays stream ordered and the host does not block (the library orders its lanes behind the context's stream
+            # itself).  Staged paths (gloo, host buffers over nccl) end in blocking copies; a device sync closes those.
+            if not self.host_only and not (self.nccl and on_device):
+                torch.cuda.synchronize(self.device)
             return 0
         except Exception as e:                                   # (an exception must not travel through the C frames)
             self.error = e
@@ -125,7 +133,7 @@ class TorchComm:
                 h = t.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.MAX)
                 t.copy_(h)
-            if not self.host_only:
+            if not self.host_only and not self.nccl:             # (nccl: the current stream waits for the reduction -- stream ordered)
                 torch.cuda.synchronize(self.device)
             return 0
         except Exception as e:
@@ -241,3 +249,48 @@ def multi_get(ctxs, key, spans, max_out=4096):
         if cnt <= max_out:
             return awm.patterns_to_dicts(buf, cnt)
         max_out = cnt
+
+
+def _clip_args(ctxs, keys, clips, owner):
+    n = len(clips)
+    shapes = [awm._pcm_shape(c) for c in clips]
+    ch = shapes[0][1]
+    assert all(s[1] == ch for s in shapes) and len(owner) == n
+    h = (C.c_void_p * len(ctxs))(*[c._h for c in ctxs])
+    own = (C.c_int * n)(*owner)
+    ptrs = (C.c_void_p * n)(*[awm._dev_ptr(c) for c in clips])
+    frames = (C.c_size_t * n)(*[s[0] for s in shapes])
+    if isinstance(keys, (list, tuple)):
+        assert len(keys) == n
+        flat, one = b"".join(awm.key_bytes(k) for k in keys), None
+    else:
+        flat, one = None, awm.key_bytes(keys)
+    return h, own, ptrs, frames, ch, flat, one
+
+
+def multi_add_batch(ctxs, keys, payload_hex, clips, owner, outs=None):
+    """awm_multi_add_watermark_batch_d: independent clips over the contexts of one process; clip i (resident on the device of
+    ctxs[owner[i]]) is watermarked there.  keys: a list with one key per clip, or one key (or None) for all."""
+    import torch
+    if outs is None:
+        outs = [torch.empty_like(c) for c in clips]
+    h, own, src, frames, ch, flat, one = _clip_args(ctxs, keys, clips, owner)
+    dst = (C.c_void_p * len(clips))(*[awm._dev_ptr(o) for o in outs])
+    awm._check(awm.lib.awm_multi_add_watermark_batch_d(h, len(ctxs), own, flat, one, payload_hex.encode(), len(clips), src, dst, frames, ch),
+               "awm_multi_add_watermark_batch_d")
+    return outs
+
+
+def multi_get_batch(ctxs, keys, clips, owner, max_out_per_clip=64):
+    """awm_multi_get_watermark_batch_d: the pattern lists of independent clips, clip i decoded on ctxs[owner[i]]"""
+    h, own, ptrs, frames, ch, flat, one = _clip_args(ctxs, keys, clips, owner)
+    n = len(clips)
+    n_out = (C.c_int * n)()
+    while True:
+        buf = ctxs[0]._pattern_buffer(n * max_out_per_clip)
+        awm._check(awm.lib.awm_multi_get_watermark_batch_d(h, len(ctxs), own, flat, one, n, ptrs, frames, ch, max_out_per_clip,
+                                                           C.cast(buf, C.c_void_p), n_out), "awm_multi_get_watermark_batch_d")
+        most = max(n_out) if n else 0
+        if most <= max_out_per_clip:
+            return [awm.patterns_to_dicts(buf, n_out[i], i * max_out_per_clip) for i in range(n)]
+        max_out_per_clip = most

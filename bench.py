@@ -361,7 +361,7 @@ def ensure_ranks(args, argv):
         return
     if args.gpus <= 1:
         return
-    if not args.rank_check_only:
+    if not args.rank_check_only and not args.same_device:
         import torch
         have = torch.cuda.device_count() if torch.cuda.is_available() else 0
         if have < args.gpus:
@@ -410,6 +410,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=4, help="lanes `get` spreads the chunks of a stream over (1: kernels back to back, for profiling)")
     ap.add_argument("--sharded", action="store_true",
                     help="debug: take the multi-GPU (ShardedStream / torch.distributed) code path even with one process")
+    ap.add_argument("--same-device", action="store_true",
+                    help="debug: the N ranks of --gpus N all use cuda:0 and talk over gloo (host-staged transfers) -- what the multi-GPU "
+                         "protocol itself costs when no second GPU pays anything back; never a scaling number")
     ap.add_argument("--rank-check-only", action="store_true",
                     help="start the ranks (as --gpus N does), count them over gloo and stop: CPU test of the launch path")
     args = ap.parse_args()
@@ -422,7 +425,7 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.same_device else int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the watermark path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -435,6 +438,8 @@ def main():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29533")
             dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        elif args.same_device:
+            dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev)
 
@@ -517,7 +522,7 @@ def main():
         matches_local = sum(any(p["bits"] == PAYLOAD for p in clip) for clip in pats)
     ranks_seen = 1
     if dist is not None:
-        t = torch.tensor([elapsed, float(matches_local), 1.0], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed, float(matches_local), 1.0], device="cpu" if args.same_device else dev, dtype=torch.float64)
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)             # final gather of the per-rank results (clips mode: match counts)
@@ -572,7 +577,8 @@ def main():
                                          "profiled_launch_scopes_per_clip": round(scopes / max(1, len(clips)), 3)}}
         else:
             matches = sum(1 for p in (pats or []) if p["bits"] == PAYLOAD)
-            cfg = {"workload": workload, "parallelism": (f"one stream sharded over {world} GPU(s)" if sharded_path else "1 GPU"),
+            cfg = {"workload": workload, "parallelism": (f"one stream sharded over {world} GPU(s)" if sharded_path else "1 GPU") +
+                   (" -- DEBUG: all ranks on ONE device over gloo (--same-device), not a scaling measurement" if args.same_device else ""),
                    "patterns": len(pats or []), "payload_matches": matches}
         cfg["ranks_seen"] = ranks_seen
         if dist is not None:

@@ -323,6 +323,18 @@ int awm_multi_add_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], con
 int awm_multi_get_d (awm_ctx *const *ctxs, int n_ctx, const uint8_t key[16], const float *const *pcm_d, int n_channels,
                      const uint64_t *span_frames, size_t max_out, awm_pattern *out);
 
+/* Batches of independent clips over the contexts of one process (BASELINE configs[4] on several GPUs): clip i lives on the device of
+ * ctxs[ctx_of_clip[i]] and is handled there -- one host thread per context runs awm_add_watermark_batch_keys_d /
+ * awm_get_watermark_batch_keys_d on its share, results come back in clip order.  Replicas: nothing travels between the devices
+ * (reference: n_clips independent `audiowmark add` / `get` runs, wmadd.cc:620-657, wmget.cc:764-884).  keys = n_clips * 16 bytes, or
+ * NULL with one_key != NULL: that key for every clip.  The settings in force for every context are the calling thread's / ctxs[0]'s. */
+int awm_multi_add_watermark_batch_d (awm_ctx *const *ctxs, int n_ctx, const int *ctx_of_clip, const uint8_t *keys, const uint8_t *one_key,
+                                     const char *payload_hex, size_t n_clips, const float *const *pcm_in_d, float *const *out_d,
+                                     const size_t *n_frames, int n_channels);
+int awm_multi_get_watermark_batch_d (awm_ctx *const *ctxs, int n_ctx, const int *ctx_of_clip, const uint8_t *keys, const uint8_t *one_key,
+                                     size_t n_clips, const float *const *pcm_d, const size_t *n_frames, int n_channels,
+                                     size_t max_out_per_clip, awm_pattern *out, int *n_out);
+
 /* Helpers of a context: contexts on other GPUs that the file level `get` (awm_get_watermark_file / _keys_file, the command line) may
  * spread a long single-key stream over (awm_multi_get_d after the stream has been read through `ctx`; its spans travel device to
  * device).  The helpers stay the caller's; n_helpers = 0 takes them away.  The command line fills them from AWM_DEVICES=0,1,... */
@@ -376,6 +388,7 @@ void awm_debug_set_viterbi_persistent (int on); /* K8: 1 (default) ONE launch pe
 void awm_debug_set_sliding3 (int on);
 void awm_debug_set_soft_bits_generic (int on); /* K7: one thread per soft bit for every shape (the fallback kernel) | four bits per wave */
 void awm_debug_set_merge_decodes (int on);  /* get of a stream of 2 - 4 chunks: the chunks' Viterbi jobs as ONE batch at the end | per chunk (default: the step is faster) */
+void awm_debug_set_add_slab_mb (int mb);   /* add: 0 (default) one fused add over the stream, then the limiter | > 0: in slabs of that many MB (cache experiment) */
 void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transforms pipelined in one wave (default) | one after the other */
 
 /* --quiet (reference audiowmark.cc:1020-1023): the "Input: / Output: / Message: ..." information lines of add_watermark off */

@@ -492,6 +492,33 @@ def test_multi_context_get_equals_single(gpu, minutes, cuts):
         gpu.awm.set_params()
 
 
+def test_multi_context_clip_batches_equal_single_context(gpu):
+    """awm_multi_add_watermark_batch_d / awm_multi_get_watermark_batch_d: 40 clips of 20 - 30 s dealt unevenly to three contexts (all on
+    the one GPU of the box), every clip with its own key and, in a second pass, one key for all: PCM and pattern lists equal the
+    single-context batch calls, in clip order; an empty share is fine."""
+    from audiowmark_amd import sharded
+    t = gpu.torch
+    rng = np.random.default_rng(5)
+    n = 40
+    clips = [gpu.dev(noise(900 + i, int(rng.integers(20, 31)) * 44100 + int(rng.integers(0, 999)), 2)) for i in range(n)]
+    keys = [gpu.awm.test_key(i + 1) for i in range(n)]
+    owner = [0 if i % 5 == 0 else (1 if i % 2 else 2) for i in range(n)]
+    ctxs = [gpu.ctx, gpu.awm.Context(0), gpu.awm.Context(0), gpu.awm.Context(0)]          # (the fourth gets nothing)
+    for key_arg in (keys, keys[3]):
+        per_clip = isinstance(key_arg, list)
+        want_pcm = gpu.ctx.add_watermark_batch_keys(keys, PAY1, clips) if per_clip else gpu.ctx.add_watermark_batch(key_arg, PAY1, clips)
+        got_pcm = sharded.multi_add_batch(ctxs, key_arg, PAY1, clips, owner)
+        assert all(t.equal(a, b) for a, b in zip(got_pcm, want_pcm))
+        want = gpu.ctx.get_watermark_batch_keys(keys, want_pcm) if per_clip else gpu.ctx.get_watermark_batch(key_arg, want_pcm)
+        got = sharded.multi_get_batch(ctxs, key_arg, got_pcm, owner)
+        assert got == want
+        assert sum(any(p["bits"] == PAY1 for p in g) for g in got) >= 35
+    with pytest.raises(gpu.awm.AwmError):
+        sharded.multi_get_batch(ctxs, keys, clips, [9] * n)
+    for c in ctxs[1:]:
+        c.close()
+
+
 def test_get_right_after_add_is_ordered_behind_it(gpu):
     """add -> get of the same buffer on one context without a wait in between: the chunks of the `get` run on other streams than the
     `add` and must still see all of its output (event ordering behind the context's stream).  Same patterns as a `get` after a
@@ -540,10 +567,30 @@ def test_multi_context_short_stream_and_errors(gpu):
     with pytest.raises(gpu.awm.AwmError):
         sharded.multi_add(ctxs, None, PAY1, [whole[:cut + 5].contiguous(), whole[cut + 5:].contiguous()],
                           [t.empty_like(whole[:cut + 5]), t.empty_like(whole[cut + 5:])])
-    # one context with parameters the kernels are not built for: its rank fails, the call returns the error
+    # the MAIN context's settings are in force on every rank (helpers with other settings would build other plans and wait for messages
+    # that never come): a helper's own parameter set is ignored ...
     ctxs[1].set_params(frames_per_bit=3)
-    with pytest.raises(gpu.awm.AwmError):
-        sharded.multi_get(ctxs, None, [whole[:cut].contiguous(), whole[cut:].contiguous()])
+    again = sharded.multi_get(ctxs, None, [whole[:cut].contiguous(), whole[cut:].contiguous()])
+    assert [pkey(p) for p in again] == [pkey(p) for p in want]
+    ctxs[1].set_params()
+    # ... and the main context's unsupported ones fail the call
+    ctxs[0].set_params(frames_per_bit=3)
+    try:
+        with pytest.raises(gpu.awm.AwmError):
+            sharded.multi_get(ctxs, None, [whole[:cut].contiguous(), whole[cut:].contiguous()])
+    finally:
+        ctxs[0].set_params()
+    # ONE failing rank (its span has a length but no samples) does not hang the other: the call returns its error
+    import ctypes as C
+    long_stream = gpu.dev(noise(78, 6 * 60 * 44100, 2))
+    half = long_stream.shape[0] // 2 // 1024 * 1024
+    h = (C.c_void_p * 2)(*[c._h for c in ctxs])
+    first_span = long_stream[:half].contiguous()
+    ptr = (C.c_void_p * 2)(gpu.awm.binding._dev_ptr(first_span), None)
+    lens = np.asarray([half, long_stream.shape[0] - half], np.uint64)
+    buf = ctxs[0]._pattern_buffer(64)
+    rc = gpu.awm.lib.awm_multi_get_d(h, 2, gpu.awm.key_bytes(None), ptr, 2, lens.ctypes.data, 64, C.cast(buf, C.c_void_p))
+    assert rc < 0
 
 
 # ---- sample rates other than 44100 Hz (zita-resampler restated on both sides: parity with zita itself is unpinned) ----

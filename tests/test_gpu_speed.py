@@ -229,6 +229,41 @@ def test_config3_full_size_48k_detect_speed(gpu):
     assert len(plain) > 0 and len(pats) > len(plain)
 
 
+@pytest.mark.parametrize("cuts", [[0.5], [0.27, 0.7]])
+def test_detect_speed_over_several_contexts_equals_single(gpu, cuts):
+    """`get --detect-speed` through the multi-GPU protocol (awm_multi_get_d with 2 / 3 contexts on the one device): the speed part is
+    sharded by chunk (the rank that holds most of a chunk fetches the rest and runs speed search, stretch and the decoders of the
+    stretched copy), the plain decoders by position as always; the merged list -- stretched and plain patterns, their speeds,
+    qualities and error values -- equals the single-context get of the whole stream.  26 minutes at 10 minute chunks, replayed 3 %
+    slow, the cuts inside chunks."""
+    from audiowmark_amd import sharded
+    t = gpu.torch
+    payload, speed = "0123456789abcdef0011223344556677", 0.97
+    g = t.Generator(device="cuda")
+    g.manual_seed(31)
+    x = t.rand((26 * 60 * 44100, 2), generator=g, device="cuda", dtype=t.float32) * 2 - 1
+    y = gpu.ctx.resample_ratio(gpu.ctx.add_watermark(KEY, payload, x), 1 / speed)
+    del x
+    total = y.shape[0]
+    gpu.awm.set_params(chunk_size_min=10.0)
+    gpu.awm.set_speed_params(detect_speed=True)
+    try:
+        want = gpu.ctx.get_watermark(KEY, y)
+        edges = [0] + [int(total * c) // 1024 * 1024 for c in cuts] + [total]
+        spans = [y[a:b].contiguous() for a, b in zip(edges[:-1], edges[1:])]
+        ctxs = [gpu.ctx] + [gpu.awm.Context(0) for _ in spans[1:]]
+        got = sharded.multi_get(ctxs, KEY, spans)
+        for c in ctxs[1:]:
+            c.close()
+    finally:
+        gpu.awm.set_speed_params()
+        gpu.awm.set_params()
+    key = lambda p: (round(p["time"], 6), p["sync_index"], p["type"], p["block_type"], p["bits"], p["speed"], p["sync_quality"], p["decode_error"])
+    assert [key(p) for p in got] == [key(p) for p in want]
+    hits = [p for p in want if p["bits"] == payload]
+    assert len(hits) >= 20 and all(p["speed"] != 1 for p in hits)
+
+
 def test_batch_of_clips_with_detect_speed(gpu, golden, replayed):
     """awm_get_watermark_batch_d with --detect-speed set: the clips are decoded one after the other (the speed search and the
     stretched copy live in per-context buffers) and every clip's result equals awm_get_watermark_d on it."""

@@ -12,7 +12,7 @@ that by measurement: both detectors read BYTE-IDENTICAL input (watermarked once,
    * 30 s clips (ClipDecoder path), every clip with its own key,
 and every pattern pair is compared: same sync index or not, and for every one that differs both indices and both qualities.
 
-  python tools/gpu_tie_census.py [hours per long material = 3.6] [clips = 96]     ->  gpurun_out/tie_census.json  (copy to profiles/rNN/)
+  python tools/gpu_tie_census.py [hours per long material = 3] [clips = 96]     ->  gpurun_out/tie_census.json  (copy to profiles/rNN/)
 """
 import concurrent.futures
 import json
@@ -68,7 +68,7 @@ def compare(got, want, what, out):
 
 
 def main():
-    hours = float(sys.argv[1]) if len(sys.argv) > 1 else 3.6
+    hours = float(sys.argv[1]) if len(sys.argv) > 1 else 3.0
     n_clips = int(sys.argv[2]) if len(sys.argv) > 2 else 96
     import torch
     import audiowmark_amd as awm
@@ -80,11 +80,21 @@ def main():
     out = {}
     timing = {}
 
-    def fir(taps_np, x):
-        """zero-phase FIR over a [frames, 2] tensor (per channel)"""
-        k = torch.from_numpy(taps_np.astype(np.float32)).to(dev).view(1, 1, -1)
-        y = torch.nn.functional.conv1d(x.t().unsqueeze(1), k, padding=k.shape[-1] // 2)
-        return y.squeeze(1).t().contiguous()
+    def q16(t):
+        """16 bit quantisation on the device (truncation towards zero, / 32768: what a 16 bit file holds)"""
+        return (torch.clamp(torch.trunc(t.double() * 32768.0), -32768, 32767) / 32768.0).float()
+
+    def shaped(x, amp_of_f):
+        """noise with the amplitude response amp_of_f (f in Hz), block by block in the frequency domain (blocks of 2^22 frames; the
+        seams are discontinuities of the material, nothing either detector cares about)"""
+        B = 1 << 22
+        out = torch.empty_like(x)
+        for a in range(0, x.shape[0], B):
+            blk = x[a:a + B]
+            spec = torch.fft.rfft(blk, dim=0)
+            f = torch.fft.rfftfreq(blk.shape[0], 1.0 / RATE).to(dev)
+            out[a:a + B] = torch.fft.irfft(spec * amp_of_f(f).unsqueeze(1), n=blk.shape[0], dim=0)
+        return out * (0.5 / float(out.abs().max()))
 
     def material(kind, seed):
         g = torch.Generator(device=dev)
@@ -94,36 +104,32 @@ def main():
             return x
         if kind == "white_minus_40dB":
             return x * 0.01
-        m = 1023
-        f = np.fft.rfftfreq(2048, 1.0 / RATE)
         if kind == "pink":
-            amp = 1.0 / np.sqrt(np.maximum(f, 20.0))                                   # 1 / f power above 20 Hz
-        else:                                                                          # "lowpass_3k"
-            amp = 1.0 / (1.0 + (f / 3000.0) ** 8)
-        h = np.fft.irfft(amp)
-        h = np.roll(h, m // 2)[:m] * np.hanning(m)
-        y = fir(h, x)
-        return y * (0.5 / float(y.abs().max()))
+            return shaped(x, lambda f: 1.0 / torch.sqrt(torch.clamp(f, min=20.0)))     # 1 / f power above 20 Hz
+        return shaped(x, lambda f: 1.0 / (1.0 + (f / 3000.0) ** 8))                   # "lowpass_3k"
 
     for kind, seed in (("white", 11), ("pink", 12), ("lowpass_3k", 13), ("white_minus_40dB", 14)):
-        x = material(kind, seed)
-        x = torch.from_numpy(quantise16(x.cpu().numpy())).to(dev)
+        t_all = time.perf_counter()
+        x = q16(material(kind, seed))
         w = ctx.add_watermark(None, PAY, x)
         del x
-        wq = quantise16(w.cpu().numpy())                                               # the 16 bit file both detectors read
+        wd = q16(w)                                                                   # the 16 bit file both detectors read
         del w
+        wq = wd.cpu().numpy()
         t0 = time.perf_counter()
         want = _ref.get(None, wq.ravel(), 2)
         t_ref = time.perf_counter() - t0
+        del wq
         t0 = time.perf_counter()
-        got = ctx.get_watermark(None, torch.from_numpy(wq).to(dev))
+        got = ctx.get_watermark(None, wd)
         torch.cuda.synchronize()
         timing[kind] = {"reference_get_s": round(t_ref, 2), "hip_get_s": round(time.perf_counter() - t0, 3)}
+        del wd
         compare(got, want, kind, out)
         out[kind]["hours"] = hours
         out[kind]["payload_matches_reference"] = sum(p["bits"] == PAY for p in want)
+        timing[kind]["wall_s_incl_generation"] = round(time.perf_counter() - t_all, 1)
         print(kind, {k: (len(v) if isinstance(v, list) else v) for k, v in out[kind].items()}, timing[kind], flush=True)
-        del wq
 
     # 30 s clips, clip k with --test-key k (noise and watermark), alternating full scale / -40 dB
     clips = []
