@@ -269,6 +269,9 @@ hipError_t launch_viterbi (hipStream_t st, const float *const soft[3], const lon
                            unsigned char *const decisions_ws[3], int *const bits_out[3], float *const error_out[3], unsigned int *sync_ws);
 size_t viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks);
 size_t viterbi_sync_bytes (long long n_blocks);
+/* microseconds per launch of a chain of empty dependent launches on the (idle) stream: decides, per process, between the chain of 16
+ * launches and the one-launch kernel (viterbi.hip) */
+double probe_dependent_launch_us (hipStream_t st);
 
 } // namespace awmk
 

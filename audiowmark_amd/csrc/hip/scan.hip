@@ -31,8 +31,9 @@
 //   generic K5 (4-byte gathers from L2)               1.63 ms
 //   round 1 K5w (ring + barriers, ds_read_b32)        0.62 ms
 //   quads + DPP, still one barrier pair per ring step 0.61 ms   (the gathers were never the limit)
-//   this kernel                                       0.37 ms   = 70 TB/s of gathered terms; the shader clock is ~1.6 GHz
-//                                                                 under this load, where 256 B/clk/CU is 105 TB/s
+//   this kernel                                       0.37 ms   = 70 TB/s of gathered terms of the ~150 TB/s the LDS delivers at 256 B/clk/CU
+//                                                                 (effective clock under this kernel 2.3 GHz, GRBM_GUI_ACTIVE; an earlier
+//                                                                 "1.6 GHz" came from s_memtime, which counts a constant reference clock)
 #include "kernels.hh"
 #include <type_traits>
 

@@ -35,6 +35,7 @@
 //
 // Bit-exactness: sums and ties exactly as above; decoded bits and the error value are bit-identical to the oracle.
 #include "kernels.hh"
+#include <chrono>
 #include <type_traits>
 #include <utility>
 
@@ -493,6 +494,94 @@ viterbi_trace_one (const TracePlan& plan, int final_parity, const unsigned char 
     }
 }
 
+/* The walk back with a WAVE instead of a lane: 36 dependent loads (one per round, each a trip to memory: the decision words were
+ * written by workgroups on other XCDs) become 14.  The state before a round of 4 steps is  (state >> 4) | (choice << 11)  with the 4
+ * choice bits read from the round's decision words, so of the NEXT round's 2048 lanes only 16 can hold the words that will be needed,
+ * and of the one after 256: while the current round's words are on their way, lane c fetches candidate c of the next round and
+ * every lane four candidates of the round after that; three rounds then resolve with register reads (v_readlane).  Same bits,
+ * same order of decisions as the one-lane walk. */
+template<bool COH> __device__ __forceinline__ void
+viterbi_trace_wave (const TracePlan& plan, int final_parity, const unsigned char *ws, int n_steps, int rate, int *bits, float *error, int lane)
+{
+  const float *metric = reinterpret_cast<const float *> (ws + (final_parity ? V_METRIC_BYTES : 0));
+  const unsigned int *dec = reinterpret_cast<const unsigned int *> (ws + 2 * V_METRIC_BYTES);
+  if (lane == 0)
+    *error = ld_metric<COH> (metric) / float (n_steps * rate);   // convcode.cc:197-199: state 0 at the end
+  const int n_out = n_steps - V_ORDER;
+  // one round of K steps from the words w: returns the K choice bits (the top bits of the state before the round)
+  auto walk = [&] (const unsigned int (&w)[4], int K, unsigned loc, int step0) -> unsigned {
+#pragma unroll
+    for (int i = 4; i >= 1; i--)                           // (unrolled with a guard: a run-time index into w would put it in scratch)
+      if (i <= K)
+        {
+          const int step = step0 + i - 1;
+          if (step < n_out && lane == 0)
+            bits[step] = loc & 1;                          // the input bit of this step is the state's low bit
+          const unsigned choose_high = (w[i - 1] >> loc) & 1;
+          loc = (loc >> 1) | (choose_high << (K - 1));
+        }
+    return loc;
+  };
+  auto pick = [] (const uint4& v, unsigned from_lane, unsigned int (&w)[4]) {
+    w[0] = __builtin_amdgcn_readlane (v.x, from_lane);
+    w[1] = __builtin_amdgcn_readlane (v.y, from_lane);
+    w[2] = __builtin_amdgcn_readlane (v.z, from_lane);
+    w[3] = __builtin_amdgcn_readlane (v.w, from_lane);
+  };
+  unsigned state = 0;
+  int r = plan.n_rounds - 1;
+  while (r >= 0)
+    {
+      const int K = plan.k[r];
+      if (r >= 2 && K == 4 && plan.k[r - 1] == 4 && plan.k[r - 2] == 4)
+        {
+          const unsigned L0 = state >> 4;
+          const uint4 a = ld_words<COH> (dec + plan.dec_offset[r] + (size_t) L0 * 4);
+          const unsigned c1 = lane & 15;
+          const uint4 b1 = ld_words<COH> (dec + plan.dec_offset[r - 1] + (size_t) ((L0 >> 4) | (c1 << 7)) * 4);
+          uint4 c2[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            {
+              const unsigned idx = lane + 64 * q, c = idx & 15, e = idx >> 4;
+              c2[q] = ld_words<COH> (dec + plan.dec_offset[r - 2] + (size_t) ((L0 >> 8) | (c << 3) | (e << 7)) * 4);
+            }
+          unsigned int w[4];
+          pick (a, 0, w);
+          const unsigned la = __builtin_amdgcn_readfirstlane (walk (w, 4, state & 15, plan.step0[r]));
+          const unsigned s1 = L0 | (la << 11);
+          pick (b1, la, w);
+          const unsigned lb = __builtin_amdgcn_readfirstlane (walk (w, 4, s1 & 15, plan.step0[r - 1]));
+          const unsigned s2 = (s1 >> 4) | (lb << 11);
+          const unsigned idx = la + 16 * lb;
+          {
+            // (all four quarters are read and the right one chosen among scalars: choosing the vector first makes c2 an indexed
+            // array, i.e. scratch memory)
+            unsigned int w0[4], w1[4], w2[4], w3[4];
+            pick (c2[0], idx & 63, w0);
+            pick (c2[1], idx & 63, w1);
+            pick (c2[2], idx & 63, w2);
+            pick (c2[3], idx & 63, w3);
+            const unsigned qsel = idx >> 6;
+#pragma unroll
+            for (int i = 0; i < 4; i++)
+              w[i] = qsel == 0 ? w0[i] : qsel == 1 ? w1[i] : qsel == 2 ? w2[i] : w3[i];
+          }
+          const unsigned lc = __builtin_amdgcn_readfirstlane (walk (w, 4, s2 & 15, plan.step0[r - 2]));
+          state = (s2 >> 4) | (lc << 11);
+          r -= 3;
+          continue;
+        }
+      const unsigned L = state >> K;
+      const uint4 a = ld_words<COH> (dec + plan.dec_offset[r] + (size_t) L * dec_words (K));      // (K <= 4 here: one 16-byte entry)
+      unsigned int w[4];
+      pick (a, 0, w);
+      const unsigned l = __builtin_amdgcn_readfirstlane (walk (w, K, state & ((1u << K) - 1), plan.step0[r]));
+      state = L | (l << (V_ORDER - K));
+      r--;
+    }
+}
+
 __global__ void __launch_bounds__ (64)
 viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
 {
@@ -609,13 +698,21 @@ viterbi_persistent_decode (const ViterbiBatch& b, const TracePlan& plan, int n_s
       parity ^= 1;
       decode_barrier (counter, 8 * ++meetings, fail, g == 0 || r + 1 < plan.n_rounds);       // after the last round only the tracer waits
     }
-  if (g == 0 && lane == 0)
+  if (g == 0 && lane < 64)
     {
       // (all eight have arrived for the last time and only this workgroup waited: nobody looks at the counter any more)
-      __hip_atomic_store (counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      float err;
-      viterbi_trace_one<true> (plan, parity, ws, b.n_steps, rate, b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER), &err);
-      b.error[t][blk] = __hip_atomic_load (fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? -2.f : err;
+      if (lane == 0)
+        __hip_atomic_store (counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float err = 0.f;
+      bool wide = true;                                    // (the wave walk reads 16-byte entries: rounds of at most 4 steps)
+      for (int r = 0; r < plan.n_rounds; r++)
+        wide = wide && plan.k[r] <= 4;
+      if (wide)
+        viterbi_trace_wave<true> (plan, parity, ws, b.n_steps, rate, b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER), &err, lane);
+      else if (lane == 0)
+        viterbi_trace_one<true> (plan, parity, ws, b.n_steps, rate, b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER), &err);
+      if (lane == 0)
+        b.error[t][blk] = __hip_atomic_load (fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? -2.f : err;
     }
 }
 
@@ -691,8 +788,51 @@ viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks)
 
 int g_viterbi_super = 1;         // (debug toggle)
 extern "C" void awm_debug_set_viterbi_super (int on) { g_viterbi_super = on; }
-int g_viterbi_persistent = 1;    // (debug toggle: 0 = the chain of launches)
+/* Which form runs.  The chain's 16 launches carry ~18 us of work each, so what a batch costs depends on how fast THIS host gets
+ * dependent launches out: 0.92 ms per bench step on boxes where a dependent launch costs a few microseconds, 1.74 ms on the driver's
+ * box of round 3 (same binary, every other kernel within 5 %).  The one-launch kernel costs 0.96 ms everywhere -- but it holds its
+ * compute units for the whole batch (176 VGPRs, 41 KB of LDS per workgroup: no scan tile of another lane fits beside it), which makes the
+ * 60 min STEP 5 % slower than with the chain on a fast-launch box (5.47 against 5.19 ms, alternating in one process,
+ * profiles/r04/variants.txt).  So the choice is made per process from a measurement: awm_ctx_create times a chain of empty
+ * dependent launches on the idle stream (probe_dependent_launch_us), and above ONE_LAUNCH_ABOVE_US per launch the batches take the
+ * one-launch kernel.  awm_debug_set_viterbi_persistent (0 | 1) forces a form, -1 returns to the measurement. */
+int g_viterbi_persistent = -1;
+double g_dependent_launch_us = -1;                       // the smallest value measured by any context of the process (-1: none yet)
+constexpr double ONE_LAUNCH_ABOVE_US = 9.0;
 extern "C" void awm_debug_set_viterbi_persistent (int on) { g_viterbi_persistent = on; }
+extern "C" double awm_debug_dependent_launch_us (void) { return g_dependent_launch_us; }
+static bool
+use_one_launch()
+{
+  return g_viterbi_persistent > 0 || (g_viterbi_persistent < 0 && g_dependent_launch_us > ONE_LAUNCH_ABOVE_US);
+}
+extern "C" int awm_debug_viterbi_one_launch_in_use (void) { return use_one_launch() ? 1 : 0; }
+
+namespace { __global__ void empty_kernel() {} }
+
+/* microseconds per launch of a chain of empty kernels on an idle stream (issue + dispatch + completion hand-over of this host / driver) */
+double
+probe_dependent_launch_us (hipStream_t st)
+{
+  constexpr int N = 48;
+  if (hipStreamSynchronize (st) != hipSuccess)
+    return -1;
+  double best = -1;
+  for (int rep = 0; rep < 3; rep++)                        // (the first repetition also pays for loading the kernel)
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < N; i++)
+        hipLaunchKernelGGL (empty_kernel, dim3 (1), dim3 (64), 0, st);
+      if (hipStreamSynchronize (st) != hipSuccess)
+        return -1;
+      const double us = std::chrono::duration<double, std::micro> (std::chrono::steady_clock::now() - t0).count() / N;
+      if (best < 0 || us < best)
+        best = us;
+    }
+  if (g_dependent_launch_us < 0 || best < g_dependent_launch_us)
+    g_dependent_launch_us = best;
+  return best;
+}
 
 size_t
 viterbi_sync_bytes (long long n_blocks)
@@ -729,7 +869,7 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
       tp.step0[r] = rounds[r].step0;
       tp.dec_offset[r] = (unsigned int) rounds[r].dec_offset;
     }
-  if (sync_ws && g_viterbi_persistent)
+  if (sync_ws && use_one_launch())
     {
       // one launch: the leading triples of 4-step rounds as 12-step segments, the remaining rounds one by one
       int n_super = 0;

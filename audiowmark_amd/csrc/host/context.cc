@@ -592,6 +592,7 @@ ctx_create (int device, bool own_stream, hipStream_t given, awm_ctx **ctx_out)
   ctx->tabs.tw1024 = reinterpret_cast<const float2 *> (base + off_tw1024);
   ctx->tabs.window = base + off_win;
   ctx->tabs.synth = base + off_synth;
+  (void) awmk::probe_dependent_launch_us (ctx->stream);   // (also waits for the uploads above; ~0.5 ms)
   *ctx_out = ctx.release();
   return 0;
 }

@@ -330,6 +330,20 @@ def e2e_leg(torch, awm, ctx, x, resident_ms):
     return out
 
 
+def viterbi_form(awm):
+    """which form of K8 ran: chosen per process from the measured cost of a dependent launch on this host (hip/viterbi.hip)"""
+    import ctypes as C
+    try:
+        awm.lib.awm_debug_dependent_launch_us.restype = C.c_double
+        us = awm.lib.awm_debug_dependent_launch_us()
+        one = bool(awm.lib.awm_debug_viterbi_one_launch_in_use())
+        return {"one_launch_kernel": one, "dependent_launch_us_probe": round(us, 2),
+                "note": "chain of 16 launches where a dependent launch is cheap on this host, the one-launch kernel (8 resident workgroups per decode, "
+                        "per-decode counters) above 9 us per launch; bits and error values identical"}
+    except Exception:
+        return None
+
+
 def read_prof(awm, ctx):
     import ctypes as C
     awm.lib.awm_prof_name.restype = C.c_char_p
@@ -637,6 +651,7 @@ def main():
             "config": cfg,
             "roofline": roofline,
             "scopes_ms_per_step": scopes,
+            "viterbi_form": viterbi_form(awm),
             "traffic_source": traffic_provenance(),
         }
         if serial:

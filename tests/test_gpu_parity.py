@@ -269,6 +269,19 @@ def test_viterbi_one_launch_equals_the_launch_chain(gpu):
                 for i in range(n):
                     b, e = orc.conv_decode_soft(bt, soft[i])
                     assert np.array_equal(got_bits[i], b) and got_err[i] == np.float32(e)
+    # a whole `get` (three chunks on concurrent lanes, each with its own batch of A, B and AB decodes) with either form forced
+    try:
+        x = gpu.dev(noise(4242, 25 * 60 * 44100, 2))
+        gpu.awm.set_params(chunk_size_min=10.0)
+        w = gpu.ctx.add_watermark(None, PAY1, x)
+        lists = []
+        for form in (0, 1, 0, 1):
+            lib.awm_debug_set_viterbi_persistent(form)
+            lists.append([(pkey(p), p["sync_quality"], p["decode_error"]) for p in gpu.ctx.get_watermark(None, w)])
+        assert lists[0] == lists[1] == lists[2] == lists[3] and len(lists[0]) > 40
+    finally:
+        gpu.awm.set_params()
+        lib.awm_debug_set_viterbi_persistent(-1)                 # back to the choice by the measured launch cost
 
 
 # ---- whole decode -----------------------------------------------------------------------------------

@@ -11,6 +11,8 @@ x = torch.rand((60 * 60 * 44100, 2), generator=g, device="cuda") * 2 - 1
 out = torch.empty_like(x)
 P = "0123456789abcdef0011223344556677"
 awm.lib.awm_prof_name.restype = C.c_char_p
+awm.lib.awm_debug_dependent_launch_us.restype = C.c_double
+print("dependent launch probe: %.2f us per empty launch -> one-launch Viterbi in use by default: %d" % (awm.lib.awm_debug_dependent_launch_us(), awm.lib.awm_debug_viterbi_one_launch_in_use()))
 
 def prof(fn, steps=5):
     for _ in range(2): fn()
@@ -52,7 +54,7 @@ for v in (1, 0, 1, 0):
     pats, r = prof(lambda: ctx.get_watermark(None, ref), 5)
     k = [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["decode_error"]) for p in pats]
     print("viterbi one launch %d: viterbi scope %.4f ms per step (one lane)  equal to first: %s" % (v, r["viterbi_kernel"], k == base))
-awm.lib.awm_debug_set_viterbi_persistent(1)
+awm.lib.awm_debug_set_viterbi_persistent(-1)
 # the Viterbi jobs of a stream's chunks as one batch at the end (1) | per chunk (0): the timed configuration (chunks on concurrent lanes)
 import time
 awm.lib.awm_ctx_set_chunk_lanes(ctx._h, 4)
@@ -67,7 +69,7 @@ for v in (1, 0, 1, 0, 1, 0):
     torch.cuda.synchronize()
     k = [(p["sync_index"], p["type"], p["block_type"], p["bits"], p["decode_error"]) for p in pats]
     print("viterbi one launch %d: %.3f ms per step (add + get, four lanes), patterns %d, equal: %s" % (v, (time.perf_counter() - t0) / 20 * 1e3, len(pats), k == base))
-awm.lib.awm_debug_set_viterbi_persistent(1)
+awm.lib.awm_debug_set_viterbi_persistent(-1)
 for v in (0, 1, 0, 1):
     awm.lib.awm_debug_set_merge_decodes(v)
     for _ in range(3): step()
