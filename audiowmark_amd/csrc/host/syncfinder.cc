@@ -136,6 +136,8 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
       ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_db) * 4096.0 * wav.n_channels + double (n_shifts) * n_db * 324.0, st);
       AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
     }
+  if (after_db_event)
+    AWM_HIP_CHECK (hipEventRecord (after_db_event, st));
 
   awmk::SyncScanArgs sa {};
   sa.db = m_lane->ws_db.as<float>();
@@ -159,6 +161,8 @@ SyncFinder::approx_device (KeyTables *kt, const DeviceWav& wav, Mode mode, long 
     ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_shifts) * n_db * 324.0 + double (n_shifts) * S * 8.0, st);
     AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));
   }
+  if (after_scan_event)
+    AWM_HIP_CHECK (hipEventRecord (after_scan_event, st));
   n_scores = (long long) n_shifts * S;
   if (scores_only)
     return 0;

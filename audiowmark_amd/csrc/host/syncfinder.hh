@@ -37,6 +37,10 @@ public:
   static constexpr int local_mean_distance = 20;
 
   explicit SyncFinder (awm_ctx *ctx, WorkLane *lane = nullptr) : m_ctx (ctx), m_lane (lane ? lane : ctx) {}
+  /* recorded on the lane's stream right after the dB kernel of the approximate search (K4) has been queued: the scheduler of `get`
+   * lets the next chunk start there (wmget.cc: block_decoder_run, phase offset between the lanes) */
+  hipEvent_t after_db_event = nullptr;
+  hipEvent_t after_scan_event = nullptr;       // the same after the scan (K5w) has been queued (measurement variant)
 
   // db_ready: the dB matrices (and the non-silent range) of a previous search of the SAME material by this object are still in the
   // lane's workspace -- the next key of a multi-key `get` shares them (reference syncfinder.cc:171-256)

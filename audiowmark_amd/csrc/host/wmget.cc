@@ -549,6 +549,15 @@ combine_blocks (const std::vector<PatternRawBits>& raw_blocks, const DeviceWav& 
 
 int g_merge_decodes = 0;         // (debug toggle, off: the decodes of all chunks of a `get` as one batch at the end -- see block_decoder_run)
 extern "C" void awm_debug_set_merge_decodes (int on) { g_merge_decodes = on; }
+/* Phase offset between the chunk lanes of a `get`.  Equal chunks that start together stay in step, so their latency-bound stages
+ * (candidate round trip, refinement scan, soft bits, the Viterbi chain) coincide and nothing wide runs beside them; out of step, one
+ * chunk's wide kernels fill the other's narrow ones.  1: chunk i + 1 starts when chunk i's FIRST kernel (the dB matrices of the
+ * approximate search, ~0.36 ms for 30 minutes) is through; 2: when its scan is through as well (~0.9 ms).  Measured, alternating in
+ * one process (tools/gpu_stagger.py, profiles/r04/chunk_stagger.txt): 60 min (3 chunks on 3 lanes) 5.18 / 5.10 / 5.33 ms per add + get
+ * for 0 / 1 / 2 -- the big offset serialises wide kernels that do not fill the GPU alone; 8 h (18 chunks over 4 lanes) 40.9 / 39.7 / 39.1.
+ * -1 (default): 1 for streams whose chunks all start at once, 2 for streams with more chunks than lanes.  Results do not depend on it. */
+int g_chunk_stagger = -1;
+extern "C" void awm_debug_set_chunk_stagger (int on) { g_chunk_stagger = on; }
 namespace {
 
 /* BlockDecoder::run (reference wmget.cc:502-706) for several chunks of one resident stream at once.  Every chunk
@@ -658,6 +667,8 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
         merge_capacity = 0;
     }
   size_t merge_events_used = 0;
+  std::vector<hipEvent_t> stagger_events (chunks.size(), nullptr);
+  struct EventsFree { std::vector<hipEvent_t>& ev; ~EventsFree() { for (hipEvent_t e : ev) if (e) (void) hipEventDestroy (e); } } stagger_free { stagger_events };
   auto advance = [&] (ChunkState& cs) -> int {
     const Key& key = key_list[cs.ki];
     KeyTables *kt = ctx->get_key_tables (key);
@@ -671,9 +682,22 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
       {
       case 0:
         {
+          const int stagger = g_chunk_stagger >= 0 ? g_chunk_stagger : (chunks.size() > lanes.size() ? 2 : 1);
+          if (stagger && cs.ki == 0 && spread)
+            {
+              // start behind the previous chunk's dB kernel; leave a mark behind my own
+              if (c > 0 && stagger_events[c - 1])
+                AWM_HIP_CHECK (hipStreamWaitEvent (cs.lane->stream, stagger_events[c - 1], 0));
+              if (c + 1 < chunks.size())
+                {
+                  AWM_HIP_CHECK (hipEventCreateWithFlags (&stagger_events[c], hipEventDisableTiming));
+                  (stagger == 2 ? finder.after_scan_event : finder.after_db_event) = stagger_events[c];
+                }
+            }
           // (ki > 0: the dB matrices of this chunk are still in the lane's workspace from the previous key: nothing else writes there)
           if (int rc = finder.approx_launch (key, chunk_wav (c), SyncFinder::Mode::BLOCK, cs.job, /* prepared */ false, /* db_ready */ cs.ki > 0))
             return rc;
+          finder.after_db_event = finder.after_scan_event = nullptr;
           cs.stage = 1;
           return 0;
         }
