@@ -66,8 +66,8 @@ PROFILE_DIR = newest_profile_dir()
 SINGLE_KERNEL_SCOPES = ("add_mix_kernel", "sync_db_kernel(approx)", "sync_scan_kernel(approx)", "sync_db_kernel(refine)", "sync_db_kernel(block)",
                         "soft_bits_kernel")
 # launches per scope of the others (the limiter: per-second table + apply; local mean + peak selection; refinement scan: chains +
-# qualities; Viterbi: decoder input preparation + ONE launch for the batch of decodes)
-SCOPE_LAUNCHES = {"limiter_kernel": 2, "local_mean_kernel": 3, "sync_scan_kernel(refine)": 2, "viterbi_kernel": 2}
+# qualities; Viterbi: decoder input preparation + the chain of 16 launches or the one-launch kernel, see viterbi_form)
+SCOPE_LAUNCHES = {"limiter_kernel": 2, "local_mean_kernel": 3, "sync_scan_kernel(refine)": 2, "viterbi_kernel": "17 (chain) | 2 (one launch)"}
 
 # HIP-event scope (awm_prof_name) -> (device kernel in the rocprofv3 summaries, what actually limits it)
 KERNELS = {
@@ -80,7 +80,9 @@ KERNELS = {
     "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (300 single-wave workgroups, 60 loads in flight each)"),
     "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue and LDS round trips in turn"),
     "soft_bits_kernel": ("soft_bits_wave_kernel", "latency of scattered reads + sequential double precision sums (four bits per wave)"),
-    "viterbi_kernel": ("viterbi_persistent_kernel", "latency: ONE launch per batch of decodes, 8 resident workgroups per decode (a chunk's ~37 decodes are one wave per SIMD) meeting at a per-decode counter every 12 trellis steps, 143 dependent steps + the walk back"),
+    "viterbi_kernel": ("viterbi_super_kernel<0> (chain of 16 launches) | viterbi_persistent_kernel (one launch): see viterbi_form",
+                       "latency: 143 dependent trellis steps, a chunk's ~37 decodes are one wave per SIMD; 8 workgroups per decode exchange their metrics every 12 steps "
+                       "-- through 16 dependent launches where launches are cheap on the host, through per-decode counters inside ONE launch where they are not"),
 }
 
 
@@ -337,7 +339,7 @@ def viterbi_form(awm):
         awm.lib.awm_debug_dependent_launch_us.restype = C.c_double
         us = awm.lib.awm_debug_dependent_launch_us()
         one = bool(awm.lib.awm_debug_viterbi_one_launch_in_use())
-        return {"one_launch_kernel": one, "dependent_launch_us_probe": round(us, 2),
+        return {"one_launch_kernel": one, "dependent_launch_us_probe": round(us, 2), "forced": False,
                 "note": "chain of 16 launches where a dependent launch is cheap on this host, the one-launch kernel (8 resident workgroups per decode, "
                         "per-decode counters) above 9 us per launch; bits and error values identical"}
     except Exception:
@@ -424,6 +426,9 @@ def main():
     ap.add_argument("--lanes", type=int, default=4, help="lanes `get` spreads the chunks of a stream over (1: kernels back to back, for profiling)")
     ap.add_argument("--sharded", action="store_true",
                     help="debug: take the multi-GPU (ShardedStream / torch.distributed) code path even with one process")
+    ap.add_argument("--viterbi-form", choices=["auto", "chain", "one-launch"], default="auto",
+                    help="K8: auto = chosen per process from the probed cost of a dependent launch (the default of the library); the profile "
+                         "passes force the form the untraced run uses (a tracer makes launches expensive and would flip the choice)")
     ap.add_argument("--same-device", action="store_true",
                     help="debug: the N ranks of --gpus N all use cuda:0 and talk over gloo (host-staged transfers) -- what the multi-GPU "
                          "protocol itself costs when no second GPU pays anything back; never a scaling number")
@@ -458,6 +463,7 @@ def main():
             dist.init_process_group("nccl", device_id=dev)
 
     ctx = awm.Context(local_rank)
+    awm.lib.awm_debug_set_viterbi_persistent({"auto": -1, "chain": 0, "one-launch": 1}[args.viterbi_form])
     awm.lib.awm_ctx_set_chunk_lanes(ctx._h, args.lanes)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
@@ -651,7 +657,7 @@ def main():
             "config": cfg,
             "roofline": roofline,
             "scopes_ms_per_step": scopes,
-            "viterbi_form": viterbi_form(awm),
+            "viterbi_form": dict(viterbi_form(awm) or {}, forced=args.viterbi_form != "auto"),
             "traffic_source": traffic_provenance(),
         }
         if serial:

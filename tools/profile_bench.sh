@@ -9,13 +9,15 @@
 #     GRBM_GUI_ACTIVE                                 -> effective shader clock of every kernel = cycles / stand-alone duration
 # usage: tools/profile_bench.sh <tag>      -> gpurun_out/prof_<tag>/
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 export GPU_MAX_HW_QUEUES=16
-B="python $R/bench.py --no-e2e --no-cpu-baseline --no-detect-speed-config"
+# (--viterbi-form chain: what the untraced run picks on a box with cheap launches; under the tracer a launch costs several times more and
+# the probe would choose the one-launch kernel -- profiles/rNN must show the kernels the bench line's step runs)
+B="python $R/bench.py --no-e2e --no-cpu-baseline --no-detect-speed-config --viterbi-form ${VITERBI_FORM:-chain}"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/lanes -o s -- $B --steps 5 --warmup 3 > $OUT/lanes.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/one_lane -o s -- $B --steps 5 --warmup 3 --lanes 1 > $OUT/one_lane.log 2>&1
 pass () { rocprofv3 --pmc "$@" --output-format csv -d $OUT/pmc_$1 -o s -- $B --steps 2 --warmup 1 --lanes 1 > $OUT/pmc_$1.log 2>&1; }
