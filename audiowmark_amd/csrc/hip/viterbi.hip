@@ -407,7 +407,7 @@ viterbi_super_round (const float *coded, int step0, const float *m_in, float *m_
     st_quad<COH> (out + 4 * q, m[4 * q], m[4 * q + 1], m[4 * q + 2], m[4 * q + 3]);
 }
 
-struct SuperOffsets { size_t off[3]; int in_perm, out_perm; };
+struct SuperOffsets { size_t off[3]; int in_perm, out_perm, first; };     // first: start from the initial metrics without reading them
 
 template<int NPF> __global__ void __launch_bounds__ (V_WG)
 viterbi_super_kernel (ViterbiBatch b, int step0, int parity_in, SuperOffsets so)
@@ -426,18 +426,18 @@ viterbi_super_kernel (ViterbiBatch b, int step0, int parity_in, SuperOffsets so)
   const bool finite = coded[0] == coded[0];              // (see viterbi_round_kernel)
   if (t == 0)
     {
-      if (finite) viterbi_super_round<0, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
-      else        viterbi_super_round<0, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
+      if (finite) viterbi_super_round<0, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0, so.first != 0);
+      else        viterbi_super_round<0, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0, so.first != 0);
     }
   else if (t == 1)
     {
-      if (finite) viterbi_super_round<1, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
-      else        viterbi_super_round<1, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
+      if (finite) viterbi_super_round<1, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0, so.first != 0);
+      else        viterbi_super_round<1, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0, so.first != 0);
     }
   else
     {
-      if (finite) viterbi_super_round<2, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
-      else        viterbi_super_round<2, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0);
+      if (finite) viterbi_super_round<2, NPF> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0, so.first != 0);
+      else        viterbi_super_round<2, 3> (coded, step0, m_in, m_out, dec, so.off, g, lane, lds_a, lds_b, so.in_perm != 0, so.out_perm != 0, so.first != 0);
     }
 }
 
@@ -596,7 +596,7 @@ viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
 }
 
 /* ---- ONE launch per batch of decodes ---------------------------------------------------------------------------------------------
- * The chain above is 16 dependent launches (init, 11 x 12 steps, 4, 4, 3, trace) of 18 - 30 us each for a chunk's ~37 decodes, and
+ * The chain above is 14 dependent launches (11 x 12 steps, 4, 4, 3 + walk back; 16 until the initial metrics and the walk back were folded in) of 18 - 30 us each for a chunk's ~37 decodes, and
  * what a batch costs is decided by the gaps between them: 0.9 ms per bench step from the kernels' own durations, 1.5 - 2.4 ms
  * between the HIP events on two different boxes.  The launches exist only because the 8 workgroups of a decode must exchange their
  * metrics every 12 steps -- a barrier among 8 workgroups, not across the grid.  So here a batch is one launch of 8 workgroups per
@@ -716,6 +716,57 @@ viterbi_persistent_decode (const ViterbiBatch& b, const TracePlan& plan, int n_s
     }
 }
 
+/* The LAST launch of the chain when it is a single round: the round itself with device-coherent stores, then the workgroup that
+ * finishes last for a decode (a counter per decode in the lane's sync block, back at zero afterwards) walks that decode's survivors
+ * back with its first wave -- the separate walk-back launch (one lane per decode, 36 dependent loads, ~30 us) disappears from the chain. */
+template<int K, bool PLAIN> __global__ void __launch_bounds__ (V_WG)
+viterbi_last_round_kernel (ViterbiBatch b, int step0, int parity_in, size_t dec_offset, TracePlan plan, unsigned int *sync)
+{
+  __shared__ int is_last;
+  int blk = blockIdx.y, t = 0;
+  if (blk >= b.n[0]) { blk -= b.n[0]; t = 1; }
+  if (t == 1 && blk >= b.n[1]) { blk -= b.n[1]; t = 2; }
+  const int rate = t == 2 ? 12 : 6;
+  const int L = blockIdx.x * V_WG + threadIdx.x;
+  unsigned char *ws = b.ws[t] + (size_t) blk * b.block_ws_bytes;
+  const float *m_in = reinterpret_cast<const float *> (ws + (parity_in ? V_METRIC_BYTES : 0));
+  float *m_out = reinterpret_cast<float *> (ws + (parity_in ? 0 : V_METRIC_BYTES));
+  unsigned int *dec = reinterpret_cast<unsigned int *> (ws + 2 * V_METRIC_BYTES) + dec_offset;
+  const float *coded = b.soft[t] + (size_t) blk * b.n_steps * rate;
+  const bool finite = coded[0] == coded[0];              // (see viterbi_round_kernel)
+  if (t == 0)
+    {
+      if (PLAIN && finite) viterbi_round<0, K, true, true> (coded, step0, m_in, m_out, dec, L);
+      else                 viterbi_round<0, K, false, true> (coded, step0, m_in, m_out, dec, L);
+    }
+  else if (t == 1)
+    {
+      if (PLAIN && finite) viterbi_round<1, K, true, true> (coded, step0, m_in, m_out, dec, L);
+      else                 viterbi_round<1, K, false, true> (coded, step0, m_in, m_out, dec, L);
+    }
+  else
+    {
+      if (PLAIN && finite) viterbi_round<2, K, true, true> (coded, step0, m_in, m_out, dec, L);
+      else                 viterbi_round<2, K, false, true> (coded, step0, m_in, m_out, dec, L);
+    }
+  // my stores are through (acknowledged device-wide) before the workgroup counts itself in
+  asm volatile ("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  unsigned int *counter = sync + SYNC_STRIDE * (1 + blockIdx.y);
+  if (threadIdx.x == 0)
+    is_last = __hip_atomic_fetch_add (counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1 == gridDim.x;
+  __syncthreads();
+  if (is_last && threadIdx.x < 64)
+    {
+      if (threadIdx.x == 0)
+        __hip_atomic_store (counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      float err = 0.f;
+      viterbi_trace_wave<true> (plan, plan.final_parity, ws, b.n_steps, rate, b.bits[t] + (size_t) blk * (b.n_steps - V_ORDER), &err, threadIdx.x);
+      if (threadIdx.x == 0)
+        b.error[t][blk] = err;
+    }
+}
+
 __global__ void __launch_bounds__ (V_WG)
 viterbi_persistent_kernel (ViterbiBatch b, TracePlan plan, int n_super, unsigned int *sync)
 {
@@ -788,7 +839,7 @@ viterbi_workspace_bytes (long long coded_len, int rate, long long n_blocks)
 
 int g_viterbi_super = 1;         // (debug toggle)
 extern "C" void awm_debug_set_viterbi_super (int on) { g_viterbi_super = on; }
-/* Which form runs.  The chain's 16 launches carry ~18 us of work each, so what a batch costs depends on how fast THIS host gets
+/* Which form runs.  The chain's 14 launches carry ~18 us of work each, so what a batch costs depends on how fast THIS host gets
  * dependent launches out: 0.92 ms per bench step on boxes where a dependent launch costs a few microseconds, 1.74 ms on the driver's
  * box of round 3 (same binary, every other kernel within 5 %).  The one-launch kernel costs 0.96 ms everywhere -- but it holds its
  * compute units for the whole batch (176 VGPRs, 41 KB of LDS per workgroup: no scan tile of another lane fits beside it), which makes the
@@ -878,7 +929,10 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
       hipLaunchKernelGGL (viterbi_persistent_kernel, dim3 (8u * (unsigned) total), dim3 (V_WG), 0, st, b, tp, n_super, sync_ws);
       return hipGetLastError();
     }
-  hipLaunchKernelGGL (viterbi_init_kernel, dim3 (V_STATES / 256, (unsigned) total), dim3 (256), 0, st, b);
+  // (a chain that begins with a 12-step launch starts from the initial metrics inside it: one launch less)
+  const bool fold_init = g_viterbi_super && V_K == 4 && rounds.size() >= 3 && rounds[0].k == V_K && rounds[1].k == V_K && rounds[2].k == V_K;
+  if (!fold_init)
+    hipLaunchKernelGGL (viterbi_init_kernel, dim3 (V_STATES / 256, (unsigned) total), dim3 (256), 0, st, b);
   int parity = 0;
   for (size_t r = 0; r < rounds.size(); )
     {
@@ -891,7 +945,7 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
             npf += rounds[r + q].step0 < V_ORDER;
           // (permuted metric layout between consecutive launches of this kind; the init kernel's output reads the same either way)
           const bool next_is_super = r + 5 < rounds.size() && rounds[r + 3].k == V_K && rounds[r + 4].k == V_K && rounds[r + 5].k == V_K;
-          const SuperOffsets so { { rounds[r].dec_offset, rounds[r + 1].dec_offset, rounds[r + 2].dec_offset }, r > 0, next_is_super };
+          const SuperOffsets so { { rounds[r].dec_offset, rounds[r + 1].dec_offset, rounds[r + 2].dec_offset }, r > 0, next_is_super, r == 0 && fold_init };
           const dim3 grid (8, (unsigned) total);
           if (npf == 0)
             hipLaunchKernelGGL ((viterbi_super_kernel<0>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, so);
@@ -908,6 +962,20 @@ launch_viterbi (hipStream_t st, const float *const soft[3], const long long n_bl
       // after V_ORDER steps every state is reachable and, for finite input, all metrics are >= 0: plain compare-select
       const bool plain = rp.step0 >= V_ORDER;
       const dim3 grid ((V_STATES >> rp.k) / V_WG, (unsigned) total);
+      if (sync_ws && r + 1 == rounds.size() && rp.k <= 4)
+        {
+          // the last round walks the survivors back itself (viterbi_last_round_kernel)
+          tp.final_parity = parity ^ 1;
+          if (rp.k == V_K && plain)
+            hipLaunchKernelGGL ((viterbi_last_round_kernel<V_K, true>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset, tp, sync_ws);
+          else if (rp.k == V_K)
+            hipLaunchKernelGGL ((viterbi_last_round_kernel<V_K, false>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset, tp, sync_ws);
+          else if (plain)
+            hipLaunchKernelGGL ((viterbi_last_round_kernel<3, true>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset, tp, sync_ws);
+          else
+            hipLaunchKernelGGL ((viterbi_last_round_kernel<3, false>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset, tp, sync_ws);
+          return hipGetLastError();
+        }
       if (rp.k == V_K && plain)
         hipLaunchKernelGGL ((viterbi_round_kernel<V_K, true>), grid, dim3 (V_WG), 0, st, b, rp.step0, parity, rp.dec_offset);
       else if (rp.k == V_K)

@@ -66,8 +66,8 @@ PROFILE_DIR = newest_profile_dir()
 SINGLE_KERNEL_SCOPES = ("add_mix_kernel", "sync_db_kernel(approx)", "sync_scan_kernel(approx)", "sync_db_kernel(refine)", "sync_db_kernel(block)",
                         "soft_bits_kernel")
 # launches per scope of the others (the limiter: per-second table + apply; local mean + peak selection; refinement scan: chains +
-# qualities; Viterbi: decoder input preparation + the chain of 16 launches or the one-launch kernel, see viterbi_form)
-SCOPE_LAUNCHES = {"limiter_kernel": 2, "local_mean_kernel": 3, "sync_scan_kernel(refine)": 2, "viterbi_kernel": "17 (chain) | 2 (one launch)"}
+# qualities; Viterbi: decoder input preparation + the chain of 14 launches or the one-launch kernel, see viterbi_form)
+SCOPE_LAUNCHES = {"limiter_kernel": 2, "local_mean_kernel": 3, "sync_scan_kernel(refine)": 2, "viterbi_kernel": "15 (chain) | 2 (one launch)"}
 
 # HIP-event scope (awm_prof_name) -> (device kernel in the rocprofv3 summaries, what actually limits it)
 KERNELS = {
@@ -80,9 +80,9 @@ KERNELS = {
     "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (300 single-wave workgroups, 60 loads in flight each)"),
     "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue and LDS round trips in turn"),
     "soft_bits_kernel": ("soft_bits_wave_kernel", "latency of scattered reads + sequential double precision sums (four bits per wave)"),
-    "viterbi_kernel": ("viterbi_super_kernel<0> (chain of 16 launches) | viterbi_persistent_kernel (one launch): see viterbi_form",
+    "viterbi_kernel": ("viterbi_super_kernel<0> (chain of 14 launches) | viterbi_persistent_kernel (one launch): see viterbi_form",
                        "latency: 143 dependent trellis steps, a chunk's ~37 decodes are one wave per SIMD; 8 workgroups per decode exchange their metrics every 12 steps "
-                       "-- through 16 dependent launches where launches are cheap on the host, through per-decode counters inside ONE launch where they are not"),
+                       "-- through 14 dependent launches where launches are cheap on the host, through per-decode counters inside ONE launch where they are not"),
 }
 
 
@@ -340,7 +340,7 @@ def viterbi_form(awm):
         us = awm.lib.awm_debug_dependent_launch_us()
         one = bool(awm.lib.awm_debug_viterbi_one_launch_in_use())
         return {"one_launch_kernel": one, "dependent_launch_us_probe": round(us, 2), "forced": False,
-                "note": "chain of 16 launches where a dependent launch is cheap on this host, the one-launch kernel (8 resident workgroups per decode, "
+                "note": "chain of 14 launches where a dependent launch is cheap on this host, the one-launch kernel (8 resident workgroups per decode, "
                         "per-decode counters) above 9 us per launch; bits and error values identical"}
     except Exception:
         return None

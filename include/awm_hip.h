@@ -384,7 +384,7 @@ int    awm_speed_clip_candidates (const uint8_t key[16], const float *hashed_val
  *   sliding3:      1 (default) refinement with three bins of one channel per lane / 0 two bins of both channels (stereo) */
 void awm_debug_set_viterbi_super (int on);
 void awm_debug_set_viterbi_persistent (int on); /* K8: 1 ONE launch per batch of decodes (8 resident workgroups per decode meeting at a counter in global
-                                                 * memory every 12 trellis steps) | 0 the chain of 16 dependent launches | -1 (default) chosen per process from
+                                                 * memory every 12 trellis steps) | 0 the chain of 14 dependent launches | -1 (default) chosen per process from
                                                  * the measured cost of a dependent launch on this host (awm_ctx_create probes it): the chain where launches
                                                  * are cheap, the one-launch kernel where they are not.  Bits and error values are identical. */
 double awm_debug_dependent_launch_us (void);    /* the probe's result (microseconds per empty dependent launch; -1 before the first context) */
