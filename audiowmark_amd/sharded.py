@@ -75,6 +75,16 @@ class TorchComm:
         self.nccl = dist.get_backend() == "nccl"
         self.device = device
         self.error = None
+        # The protocol's host-side records (refined scores, soft bits, pattern lists: a few KB per round, six rounds per `get`) over RCCL
+        # would each be staged through device memory with two blocking copies; a second group over gloo (the same ranks, loopback / the
+        # launcher's rendezvous address) carries them as they are.  Every rank creates it (new_group is collective); if that fails
+        # anywhere the records keep going through the staged path.
+        self.host_group = None
+        if self.nccl and not self.host_only and self.world > 1:
+            try:
+                self.host_group = dist.new_group(backend="gloo")
+            except Exception:
+                self.host_group = None
         self._cb = (_EXCHANGE(lambda *a: self._exchange(True, *a)), _EXCHANGE(lambda *a: self._exchange(False, *a)),
                     _REDUCE(self._reduce))                       # (kept alive with the object)
         self.c = AwmComm(None, self.rank, self.world, *self._cb)
@@ -89,14 +99,17 @@ class TorchComm:
             torch, dist = self.torch, self.dist
             ops, copy_back = [], []
             on_device = on_device and not self.host_only
-            direct = on_device == self.nccl                      # the group moves this kind of memory itself
+            group = None
+            if not on_device and self.host_group is not None:    # host records over the gloo side group: no staging
+                group = self.host_group
+            direct = group is not None or on_device == self.nccl # the group moves this kind of memory itself
             for i in range(n_send):
                 if not send_bytes[i]:
                     continue
                 t = self._view(send[i], send_bytes[i], on_device)
                 if not direct:
                     t = t.to(self.device) if self.nccl else t.cpu()
-                ops.append(dist.P2POp(dist.isend, t.contiguous(), send_to[i]))
+                ops.append(dist.P2POp(dist.isend, t.contiguous(), send_to[i], group))
             for i in range(n_recv):
                 if not recv_bytes[i]:
                     continue
@@ -105,7 +118,7 @@ class TorchComm:
                     stage = torch.empty(recv_bytes[i], dtype=torch.uint8, device=self.device if self.nccl else "cpu")
                     copy_back.append((t, stage))
                     t = stage
-                ops.append(dist.P2POp(dist.irecv, t, recv_from[i]))
+                ops.append(dist.P2POp(dist.irecv, t, recv_from[i], group))
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
@@ -115,7 +128,7 @@ class TorchComm:
             # made torch's current stream -- the stream the context works on (binding.Context) -- wait for the transfers, so
             # everything stays stream ordered and the host does not block (the library orders its lanes behind the context's stream
             # itself).  Staged paths (gloo, host buffers over nccl) end in blocking copies; a device sync closes those.
-            if not self.host_only and not (self.nccl and on_device):
+            if not self.host_only and not (self.nccl and on_device) and group is None:
                 torch.cuda.synchronize(self.device)
             return 0
         except Exception as e:                                   # (an exception must not travel through the C frames)
