@@ -273,6 +273,25 @@ size_t viterbi_sync_bytes (long long n_blocks);
  * launches and the one-launch kernel (viterbi.hip) */
 double probe_dependent_launch_us (hipStream_t st);
 
+/* K16 (keytab.hip): frame_mod tables built on the device, one workgroup per key (reference wmadd.cc:86-162, wmcommon.cc:143-202,
+ * random.cc:97-161).  round_keys: 176 bytes per key (the AES-128 key schedule as FIPS-197's byte string, host/aes128.cc); sbox: the
+ * 256 byte S-box; coded: the payload's convolutional code, 858 bytes (0 / 1) for an A block followed by 858 for a B block;
+ * scratch: scratch_slots * key_table_scratch_bytes() bytes (n_keys <= scratch_slots: a launch's keys work side by side);
+ * tables: n_keys * key_table_bytes() bytes, [2 (A, B)][2226 frames][81 bands] int8 KEEP 0 / UP 1 / DOWN 2. */
+struct KeyTableArgs
+{
+  const unsigned char *round_keys;
+  const unsigned char *sbox;
+  const unsigned char *coded;
+  unsigned char       *scratch;
+  int                  scratch_slots;
+  signed char         *tables;
+  long long            n_keys;
+};
+size_t key_table_scratch_bytes();
+size_t key_table_bytes();
+hipError_t launch_frame_mod_tables (hipStream_t st, const KeyTableArgs& a);
+
 } // namespace awmk
 
 namespace awmk {

@@ -1,0 +1,385 @@
+// keytab.hip -- K16: the frame_mod table of `add` built ON THE DEVICE, one workgroup per key.
+//
+// Replaces, for batches with one key per clip (awm_add_watermark_batch_keys_d), the host's build_frame_mod_table
+// (host/wmcommon.cc; reference wmadd.cc:86-162 "init_frame_mod_vec", wmcommon.cc:143-202 UpDownGen / BitPosGen / gen_mix_entries,
+// random.cc:97-161 the AES-128-CTR generator, random.hh:102-113 the shuffle).  A table costs ~1 ms of one host core and a process on
+// the box may use 16 of them: 1024 keys were 64 ms of wall time in front of 25 ms of device work.  Per key the work is
+//   235 000 pseudo random draws = 118 000 AES-128 blocks in counter mode          -- independent: all lanes of the workgroup
+//   2226 + 1716 shuffles of the 81 bands (one per sync / data frame and its seed)  -- independent: one lane per frame
+//   three Fisher-Yates shuffles over the key's own streams (2226 frame positions, 858 coded bits, 51 480 mix entries)
+//     j = i + draw_i mod (n - i): the draws do not depend on the array, so all TARGETS j_i are computed in parallel; only the
+//     swaps are sequential -- but independent of each other far more often than not: a chunk of 64 steps whose targets all lie
+//     beyond the chunk and differ goes through in ONE LDS round trip, every lane its own swap (80 % of the chunks; the test is
+//     exact), else a quarter of 16 the same way, else four steps per round trip after a scalar test, else one by one.  The
+//     permutation lives in LDS (51 480 x u16 = 103 KB: one key per compute unit): 1.1 ms for the mix shuffle (one swap per round
+//     trip: 3.2 ms), 2.3 ms per launch of 256 keys; the tables of the next 256 are built while the first 256 clips are watermarked
+//   the table itself: 2 x 2226 x 81 bytes, every (frame, band) written at most once -- all lanes.
+// Bit-identical to the host's tables (tests/test_gpu_parity.py::test_key_tables_on_the_device).
+#include "kernels.hh"
+
+namespace awmk {
+
+namespace {
+
+constexpr int KT_NB = 81, KT_MIN_BAND = 20, KT_BPF = 30;
+constexpr int KT_SYNC = 510, KT_DATA = 1716, KT_BLOCK = KT_SYNC + KT_DATA;        // frames
+constexpr int KT_SYNC_FPB = 85, KT_CODED = 858, KT_FPB = 2;
+constexpr int KT_MIX = KT_DATA * KT_BPF;                                           // 51 480
+constexpr int KT_WG = 256;
+
+struct Aes
+{
+  const unsigned int *te0;       // LDS: 256 words (2 s, s, s, 3 s)
+  const unsigned char *sbox;     // LDS
+  unsigned int rk[44];           // big-endian round key words
+
+  __device__ __forceinline__ static unsigned int rotr (unsigned int v, int n) { return (v >> n) | (v << (32 - n)); }
+
+  /* AES-128 of the block (s0 .. s3, big-endian words) */
+  __device__ __forceinline__ void
+  encrypt (unsigned int& s0, unsigned int& s1, unsigned int& s2, unsigned int& s3) const
+  {
+    s0 ^= rk[0]; s1 ^= rk[1]; s2 ^= rk[2]; s3 ^= rk[3];
+#pragma unroll
+    for (int r = 1; r < 10; r++)                          // (unrolled: the round keys stay in scalar registers)
+      {
+        const unsigned int t0 = te0[s0 >> 24] ^ rotr (te0[(s1 >> 16) & 0xff], 8) ^ rotr (te0[(s2 >> 8) & 0xff], 16) ^ rotr (te0[s3 & 0xff], 24) ^ rk[4 * r];
+        const unsigned int t1 = te0[s1 >> 24] ^ rotr (te0[(s2 >> 16) & 0xff], 8) ^ rotr (te0[(s3 >> 8) & 0xff], 16) ^ rotr (te0[s0 & 0xff], 24) ^ rk[4 * r + 1];
+        const unsigned int t2 = te0[s2 >> 24] ^ rotr (te0[(s3 >> 16) & 0xff], 8) ^ rotr (te0[(s0 >> 8) & 0xff], 16) ^ rotr (te0[s1 & 0xff], 24) ^ rk[4 * r + 2];
+        const unsigned int t3 = te0[s3 >> 24] ^ rotr (te0[(s0 >> 16) & 0xff], 8) ^ rotr (te0[(s1 >> 8) & 0xff], 16) ^ rotr (te0[s2 & 0xff], 24) ^ rk[4 * r + 3];
+        s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+      }
+    auto sub = [&] (unsigned int a, unsigned int b, unsigned int c, unsigned int d) {
+      return (unsigned (sbox[a >> 24]) << 24) | (unsigned (sbox[(b >> 16) & 0xff]) << 16) | (unsigned (sbox[(c >> 8) & 0xff]) << 8) | unsigned (sbox[d & 0xff]);
+    };
+    const unsigned int t0 = sub (s0, s1, s2, s3) ^ rk[40], t1 = sub (s1, s2, s3, s0) ^ rk[41], t2 = sub (s2, s3, s0, s1) ^ rk[42], t3 = sub (s3, s0, s1, s2) ^ rk[43];
+    s0 = t0; s1 = t1; s2 = t2; s3 = t3;
+  }
+};
+
+/* the generator of one (seed, stream): counter block = AES (seed as big-endian u64 || stream || 7 zero bytes); key stream block n =
+ * AES (counter + n), the counter a 128 bit big-endian integer; draws 2 n, 2 n + 1 = the block's two big-endian u64 (random.cc:97-161) */
+struct Stream
+{
+  unsigned int c0, c1, c2, c3;
+  __device__ __forceinline__ void
+  seed (const Aes& aes, unsigned long long seed, unsigned int stream)
+  {
+    c0 = (unsigned int) (seed >> 32); c1 = (unsigned int) seed; c2 = stream << 24; c3 = 0;
+    aes.encrypt (c0, c1, c2, c3);
+  }
+  __device__ __forceinline__ void
+  block (const Aes& aes, unsigned int n, unsigned long long& d0, unsigned long long& d1) const
+  {
+    unsigned int s3 = c3 + n;
+    unsigned int carry = s3 < n;
+    unsigned int s2 = c2 + carry;
+    carry = carry && s2 == 0;
+    unsigned int s1 = c1 + carry;
+    carry = carry && s1 == 0;
+    unsigned int s0 = c0 + carry;
+    aes.encrypt (s0, s1, s2, s3);
+    d0 = ((unsigned long long) s0 << 32) | s1;
+    d1 = ((unsigned long long) s2 << 32) | s3;
+  }
+};
+
+/* x mod d for a 64 bit x and d < 65536, in 32 bit steps */
+__device__ __forceinline__ unsigned int
+mod_small (unsigned long long x, unsigned int d)
+{
+  unsigned int r = (unsigned int) (x >> 32) % d;
+  r = ((r << 16) | ((unsigned int) (x >> 16) & 0xffff)) % d;
+  r = ((r << 16) | ((unsigned int) x & 0xffff)) % d;
+  return r;
+}
+
+/* the sequential half of a Fisher-Yates shuffle: swap (v[i], v[target[i]]) for i = 0 .. n - 1, by ONE lane */
+template<class T, class TGT> __device__ __forceinline__ void
+apply_swaps (T *v, const TGT *target, int n)
+{
+  for (int i = 0; i < n; i++)
+    {
+      const int j = target[i];
+      const T a = v[i], b = v[j];
+      v[i] = b;
+      v[j] = a;
+    }
+}
+
+}  // namespace
+
+/* scratch per key (global memory): [KT_MIX] u16 mix targets, [KT_BLOCK][60] u8 up / down bands of every frame's seed (sync frames
+ * first), rounded up */
+constexpr size_t KT_SCRATCH_BYTES = ((size_t (KT_MIX) * 2 + size_t (KT_BLOCK) * 60 + 255) / 256) * 256;
+size_t key_table_scratch_bytes() { return KT_SCRATCH_BYTES; }
+size_t key_table_bytes() { return size_t (2) * KT_BLOCK * KT_NB; }
+
+__global__ void __launch_bounds__ (KT_WG)
+frame_mod_table_kernel (KeyTableArgs a)
+{
+  __shared__ unsigned int   s_te0[256];
+  __shared__ unsigned char  s_sbox[256];
+  __shared__ unsigned short s_perm[KT_MIX];                // the mix shuffle's array: entry numbers
+  __shared__ unsigned short s_pos[KT_BLOCK], s_pos_t[KT_BLOCK];      // frame positions and their swap targets
+  __shared__ unsigned short s_order[KT_CODED], s_order_t[KT_CODED];  // bit order and its swap targets
+  // a lane's 81 bands while it shuffles them: in s_perm's memory, which is not needed before the swaps -- 117 KB in all, so that a
+  // workgroup of the fused add kernel (39 KB) fits on the compute unit beside this one: the clips of the previous group of keys are
+  // watermarked WHILE this group's tables are built (with 138 KB the two kernels took turns: 49.8 instead of 31 ms for 1024 clips)
+  unsigned char (*s_bands)[84] = reinterpret_cast<unsigned char (*)[84]> (s_perm);
+  static_assert (sizeof (unsigned char[KT_WG][84]) <= sizeof (unsigned short[KT_MIX]), "the band arrays fit into the permutation's memory");
+  const int tid = threadIdx.x;
+  const long long key = blockIdx.x;
+  for (int i = tid; i < 256; i += KT_WG)
+    {
+      const unsigned int s = a.sbox[i];
+      const unsigned int s2 = ((s << 1) ^ ((s & 0x80) ? 0x1b : 0)) & 0xff;
+      s_sbox[i] = (unsigned char) s;
+      s_te0[i] = (s2 << 24) | (s << 16) | (s << 8) | (s2 ^ s);
+    }
+  Aes aes;
+  aes.te0 = s_te0;
+  aes.sbox = s_sbox;
+  {
+    const unsigned char *rk = a.round_keys + key * 176;
+#pragma unroll
+    for (int i = 0; i < 44; i++)
+      aes.rk[i] = ((unsigned int) rk[4 * i] << 24) | ((unsigned int) rk[4 * i + 1] << 16) | ((unsigned int) rk[4 * i + 2] << 8) | rk[4 * i + 3];
+  }
+  unsigned char *scratch = a.scratch + (key % a.scratch_slots) * KT_SCRATCH_BYTES;
+  unsigned short *mix_t = reinterpret_cast<unsigned short *> (scratch);
+  unsigned char *updown = scratch + size_t (KT_MIX) * 2;                     // [frame: 510 sync, then 1716 data][60]
+  for (int i = tid; i < KT_BLOCK; i += KT_WG)
+    s_pos[i] = (unsigned short) i;
+  for (int i = tid; i < KT_CODED; i += KT_WG)
+    s_order[i] = (unsigned short) i;
+  __syncthreads();
+
+  // ---- the swap targets of the three key-wide shuffles (streams frame_position = 6, bit_order = 5, mix = 4; seed 0)
+  {
+    Stream st;
+    st.seed (aes, 0, 6);
+    for (int b = tid; b < (KT_BLOCK + 1) / 2; b += KT_WG)
+      {
+        unsigned long long d0, d1;
+        st.block (aes, b, d0, d1);
+        const int i0 = 2 * b, i1 = 2 * b + 1;
+        s_pos_t[i0] = (unsigned short) (i0 + mod_small (d0, KT_BLOCK - i0));
+        if (i1 < KT_BLOCK)
+          s_pos_t[i1] = (unsigned short) (i1 + mod_small (d1, KT_BLOCK - i1));
+      }
+    st.seed (aes, 0, 5);
+    for (int b = tid; b < (KT_CODED + 1) / 2; b += KT_WG)
+      {
+        unsigned long long d0, d1;
+        st.block (aes, b, d0, d1);
+        const int i0 = 2 * b, i1 = 2 * b + 1;
+        s_order_t[i0] = (unsigned short) (i0 + mod_small (d0, KT_CODED - i0));
+        if (i1 < KT_CODED)
+          s_order_t[i1] = (unsigned short) (i1 + mod_small (d1, KT_CODED - i1));
+      }
+    st.seed (aes, 0, 4);
+    for (int b = tid; b < KT_MIX / 2; b += KT_WG)
+      {
+        unsigned long long d0, d1;
+        st.block (aes, b, d0, d1);
+        const int i0 = 2 * b, i1 = 2 * b + 1;
+        mix_t[i0] = (unsigned short) (i0 + mod_small (d0, KT_MIX - i0));
+        mix_t[i1] = (unsigned short) (i1 + mod_small (d1, KT_MIX - i1));
+      }
+  }
+  // ---- up / down bands of every frame's seed: UpDownGen::get (f) = the first 60 of the 81 bands shuffled with the stream of
+  // (seed f, sync_up_down = 2 | data_up_down = 1): one lane per frame, its array in LDS
+  for (int fi = tid; fi < KT_BLOCK; fi += KT_WG)
+    {
+      const bool sync = fi < KT_SYNC;
+      const int f = sync ? fi : fi - KT_SYNC;
+      Stream st;
+      st.seed (aes, (unsigned long long) f, sync ? 2 : 1);
+      unsigned char *v = s_bands[tid];
+      for (int i = 0; i < KT_NB; i++)
+        v[i] = (unsigned char) (KT_MIN_BAND + i);
+      // (the shuffle's steps 0 .. 59 settle the 60 places that are used; steps 60 .. 80 only move the rest among themselves: not drawn)
+      for (int b = 0; b < 2 * KT_BPF / 2; b++)
+        {
+          unsigned long long d0, d1;
+          st.block (aes, b, d0, d1);
+          const int i0 = 2 * b, i1 = 2 * b + 1;
+          {
+            const int j = i0 + int (mod_small (d0, KT_NB - i0));
+            const unsigned char x = v[i0]; v[i0] = v[j]; v[j] = x;
+          }
+          {
+            const int j = i1 + int (mod_small (d1, KT_NB - i1));
+            const unsigned char x = v[i1]; v[i1] = v[j]; v[j] = x;
+          }
+        }
+      for (int i = 0; i < 60; i++)
+        updown[size_t (fi) * 60 + i] = v[i];
+    }
+  __threadfence_block();
+  __syncthreads();
+  for (int i = tid; i < KT_MIX; i += KT_WG)               // (the band arrays are done with: the memory becomes the permutation)
+    s_perm[i] = (unsigned short) i;
+  __syncthreads();
+
+  // ---- the sequential swaps: three waves, one shuffle each.  The mix shuffle's targets lie in global memory: the wave fetches 64 at a
+  // time (the next 64 are on their way meanwhile) and lane 0 takes them out of the registers one by one (v_readlane) -- a lane that
+  // loaded its own targets would wait a trip to memory per swap.  What remains per swap is one LDS round trip (read both, write both).
+  if (tid < 64)
+    {
+      static_assert (KT_MIX % 4 == 0, "the swaps are taken four at a time");
+      unsigned int t_next = mix_t[tid];
+      for (int c = 0; c < (KT_MIX + 63) / 64; c++)
+        {
+          const unsigned int t = t_next;
+          const int nx = (c + 1) * 64 + tid;
+          if (nx < KT_MIX)
+            t_next = mix_t[nx];
+          /* A whole chunk of 64 swaps in ONE round trip, every lane its own, when they are independent: every target beyond the
+           * chunk (or the step's own place) and all targets distinct -- 64 targets drawn from tens of thousands of places: most chunks.
+           * The test is exact (32 rotations of the targets through the wave compare every pair); a chunk that fails it goes four
+           * steps at a time (below). */
+          {
+            const int i_mine = c * 64 + tid, last = c * 64 + 63;
+            const int j_mine = int (t);
+            const bool valid = i_mine < KT_MIX;
+            // (a self swap keeps its place whatever the others do: it takes part with a target nobody else can have)
+            const int j_cmp = j_mine == i_mine ? -1 - tid : j_mine;
+            int others[32];
+#pragma unroll
+            for (int sft = 1; sft <= 32; sft++)                              // all rotations first, then the comparisons: no waits in between
+              others[sft - 1] = __shfl (j_cmp, (tid + sft) & 63);
+            int bad = (j_mine <= last) & (j_mine != i_mine);
+#pragma unroll
+            for (int sft = 0; sft < 32; sft++)
+              bad |= others[sft] == j_cmp;
+            if (!__any (bad != 0 && valid) && last < KT_MIX)
+              {
+                const unsigned short x = s_perm[i_mine], y = s_perm[j_mine];
+                s_perm[i_mine] = y;
+                s_perm[j_mine] = x;
+                continue;
+              }
+          }
+          /* A chunk that is not independent as a whole: its four quarters of 16 steps one after the other, each one again all at once
+           * if its 16 steps are independent of each other (targets beyond the quarter, distinct -- decided from the targets alone, so
+           * for all four quarters up front), else four steps per LDS round trip: steps i .. i + 3 with targets j0 .. j3 read { i + k, jk }
+           * and write the same places; if no step reads what an earlier one of the four writes (jm != jk and jm != i + k for m < k;
+           * jk >= i + k > i + m anyway), all eight reads can go out before the first write -- a scalar test, the targets are in scalar
+           * registers; a clash takes the four steps one by one. */
+          const int i_mine = c * 64 + tid;
+          const int j_mine = int (t);
+          const int j_cmp = j_mine == i_mine ? -1 - tid : j_mine;
+          int q_bad = (j_mine <= (i_mine | 15)) & (j_mine != i_mine);
+#pragma unroll
+          for (int sft = 1; sft <= 8; sft++)
+            q_bad |= __shfl (j_cmp, (tid & ~15) | ((tid + sft) & 15)) == j_cmp;
+          const unsigned long long bad_lanes = __ballot (q_bad != 0 || i_mine >= KT_MIX);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            {
+              if (c * 64 + 16 * q >= KT_MIX)
+                continue;
+              if (((bad_lanes >> (16 * q)) & 0xffffull) == 0)
+                {
+                  if ((tid >> 4) == q)
+                    {
+                      const unsigned short x = s_perm[i_mine], y = s_perm[j_mine];
+                      s_perm[i_mine] = y;
+                      s_perm[j_mine] = x;
+                    }
+                  continue;
+                }
+#pragma unroll
+              for (int g4 = 0; g4 < 4; g4++)
+                {
+                  const int g = 4 * q + g4;
+                  const int i0 = c * 64 + 4 * g;
+                  const int j0 = __builtin_amdgcn_readlane (int (t), 4 * g), j1 = __builtin_amdgcn_readlane (int (t), 4 * g + 1);
+                  const int j2 = __builtin_amdgcn_readlane (int (t), 4 * g + 2), j3 = __builtin_amdgcn_readlane (int (t), 4 * g + 3);
+                  if (i0 >= KT_MIX)
+                    continue;
+                  const bool clash = j0 == j1 || j0 == j2 || j0 == j3 || j1 == j2 || j1 == j3 || j2 == j3
+                                  || j0 == i0 + 1 || j0 == i0 + 2 || j0 == i0 + 3 || j1 == i0 + 2 || j1 == i0 + 3 || j2 == i0 + 3;
+                  if (tid == 0)
+                    {
+                      if (!clash)
+                        {
+                          const unsigned short a0 = s_perm[i0], a1 = s_perm[i0 + 1], a2 = s_perm[i0 + 2], a3 = s_perm[i0 + 3];
+                          const unsigned short b0 = s_perm[j0], b1 = s_perm[j1], b2 = s_perm[j2], b3 = s_perm[j3];
+                          s_perm[i0] = b0;     s_perm[j0] = a0;
+                          s_perm[i0 + 1] = b1; s_perm[j1] = a1;
+                          s_perm[i0 + 2] = b2; s_perm[j2] = a2;
+                          s_perm[i0 + 3] = b3; s_perm[j3] = a3;
+                        }
+                      else
+                        {
+                          const int js[4] = { j0, j1, j2, j3 };
+#pragma unroll
+                          for (int k = 0; k < 4; k++)
+                            {
+                              const unsigned short x = s_perm[i0 + k], y = s_perm[js[k]];
+                              s_perm[i0 + k] = y;
+                              s_perm[js[k]] = x;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+  else if (tid == 64)
+    apply_swaps (s_pos, s_pos_t, KT_BLOCK);
+  else if (tid == 128)
+    apply_swaps (s_order, s_order_t, KT_CODED);
+  __syncthreads();
+
+  // ---- the table: KEEP everywhere, then the bands of the sync frames and of the mix entries (wmcommon.cc build_frame_mod_table)
+  signed char *table = a.tables + key * (long long) (2 * KT_BLOCK * KT_NB);
+  {
+    int *t4 = reinterpret_cast<int *> (table);
+    for (int i = tid; i < 2 * KT_BLOCK * KT_NB / 4; i += KT_WG)
+      t4[i] = 0;
+    for (int i = (2 * KT_BLOCK * KT_NB / 4) * 4 + tid; i < 2 * KT_BLOCK * KT_NB; i += KT_WG)
+      table[i] = 0;
+  }
+  __threadfence_block();
+  __syncthreads();
+  constexpr signed char UP = 1, DOWN = 2;
+  for (int ab = 0; ab < 2; ab++)
+    {
+      signed char *block = table + size_t (ab) * KT_BLOCK * KT_NB;
+      const unsigned char *coded = a.coded + ab * KT_CODED;                   // conv code of the payload, block type A / B
+      for (int e = tid; e < KT_SYNC * KT_BPF; e += KT_WG)
+        {
+          const int f = e / KT_BPF, i = e % KT_BPF;
+          const int bit = (f / KT_SYNC_FPB + ab) & 1;                         // A carries 010101, B 101010
+          signed char *row = block + size_t (s_pos[f]) * KT_NB;
+          row[updown[size_t (f) * 60 + i] - KT_MIN_BAND] = bit ? UP : DOWN;
+          row[updown[size_t (f) * 60 + 30 + i] - KT_MIN_BAND] = bit ? DOWN : UP;
+        }
+      for (int p = tid; p < KT_MIX; p += KT_WG)
+        {
+          const int e = s_perm[p];                                            // entry (data frame f, i) that the shuffle put at position p
+          const int f = e / KT_BPF, i = e % KT_BPF;
+          const int bit = coded[s_order[p / (KT_BPF * KT_FPB)]];             // fec[p / 60], fec[k] = coded[order[k]]
+          signed char *row = block + size_t (s_pos[KT_SYNC + f]) * KT_NB;
+          row[updown[size_t (KT_SYNC + f) * 60 + i] - KT_MIN_BAND] = bit ? UP : DOWN;
+          row[updown[size_t (KT_SYNC + f) * 60 + 30 + i] - KT_MIN_BAND] = bit ? DOWN : UP;
+        }
+    }
+}
+
+hipError_t
+launch_frame_mod_tables (hipStream_t st, const KeyTableArgs& a)
+{
+  if (a.n_keys <= 0)
+    return hipSuccess;
+  if (!a.round_keys || !a.sbox || !a.coded || !a.scratch || !a.tables || a.scratch_slots <= 0 || a.n_keys > a.scratch_slots)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL (frame_mod_table_kernel, dim3 ((unsigned) a.n_keys), dim3 (KT_WG), 0, st, a);
+  return hipGetLastError();
+}
+
+}  // namespace awmk

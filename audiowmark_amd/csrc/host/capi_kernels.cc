@@ -969,6 +969,169 @@ awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payl
 /* the same with ONE KEY PER CLIP (BASELINE configs[4]: `--test-key k` per clip).  The frame_mod tables (361 KB per key; 2226 up / down
  * draws and three shuffles per key on the host: ~3 ms of one core) are built on host threads group by group while the device works on
  * the previous group, and live in one batch buffer instead of the context's per-key cache. */
+/* (measurement knob) 1 (default): the frame_mod tables of a batch with one key per clip are built on the device (K16, hip/keytab.hip) |
+ * 0: on host threads */
+static int g_key_tables_on_device = 1;
+extern "C" void awm_debug_set_key_tables_on_device (int on) { g_key_tables_on_device = on; }
+
+/* awm_add_watermark_batch_keys_d with the tables built by K16: groups of GROUP keys (one workgroup = one compute unit per key), two
+ * table areas in turn -- the tables of group g + 1 are built (on a lane of their own) while the clips of group g are watermarked on the
+ * add lanes; what the host contributes per key is the AES key schedule (176 bytes). */
+static int
+add_batch_keys_device_tables (awm_ctx *ctx, const uint8_t *keys, const std::vector<int>& bits, size_t n_clips, const float *const *pcm_in_d,
+                              float *const *out_d, const size_t *n_frames, int n_channels)
+{
+  constexpr size_t GROUP = 256;
+  constexpr int ADD_LANES = 8;
+  const size_t table_bytes = awmk::key_table_bytes();
+  const int n_lanes = int (std::min<size_t> (ADD_LANES, n_clips));
+  std::vector<WorkLane *> lanes;
+  for (int i = 0; i <= n_lanes; i++)                       // lanes 0 .. n_lanes - 1 watermark, lane n_lanes builds tables
+    {
+      WorkLane *l = ctx->lane (i);
+      if (!l)
+        {
+          set_error ("cannot create a work lane (stream)");
+          return AWM_ERR_HIP;
+        }
+      if (!l->ev_sync)
+        AWM_HIP_CHECK (hipEventCreateWithFlags (&l->ev_sync, hipEventDisableTiming));
+      lanes.push_back (l);
+    }
+  hipStream_t table_stream = lanes[n_lanes]->stream;
+  // one page-locked block, one upload: [S-box 256][conv code of the payload, A then B: 2 x 858][key schedules: n x 176]
+  const size_t aux_bytes = 256 + 2 * 858 + n_clips * 176;
+  if (int rc = ctx->pin_keytab.reserve (aux_bytes)) return rc;
+  if (int rc = ctx->ws_keytab_aux.reserve (aux_bytes)) return rc;
+  if (int rc = ctx->ws_keytab.reserve (2 * GROUP * table_bytes)) return rc;
+  if (int rc = ctx->ws_keytab_scratch.reserve (GROUP * awmk::key_table_scratch_bytes())) return rc;
+  unsigned char *aux = ctx->pin_keytab.as<unsigned char>();
+  std::memcpy (aux, Aes128::sbox(), 256);
+  for (int ab = 0; ab < 2; ab++)
+    {
+      const std::vector<int> coded = code_encode (ab ? ConvBlockType::b : ConvBlockType::a, bits);
+      if (coded.size() != 858)
+        {
+          set_error ("conv code of unexpected size");
+          return AWM_ERR_GENERIC;
+        }
+      for (size_t i = 0; i < coded.size(); i++)
+        aux[256 + 858 * ab + i] = (unsigned char) (coded[i] & 1);
+    }
+  for (size_t i = 0; i < n_clips; i++)
+    {
+      Aes128 aes;
+      aes.set_key (keys + 16 * i);
+      std::memcpy (aux + 256 + 2 * 858 + 176 * i, aes.round_keys(), 176);
+    }
+  unsigned char *d_aux = ctx->ws_keytab_aux.as<unsigned char>();
+  AWM_HIP_CHECK (hipMemcpyAsync (d_aux, aux, aux_bytes, hipMemcpyHostToDevice, ctx->stream));
+  hipEvent_t ev_aux = nullptr, ev_tab[2] = { nullptr, nullptr };
+  std::vector<hipEvent_t> lane_done (2 * size_t (n_lanes), nullptr);
+  struct Events
+  {
+    hipEvent_t& a; hipEvent_t (&t)[2]; std::vector<hipEvent_t>& d;
+    ~Events() { if (a) (void) hipEventDestroy (a); for (hipEvent_t e : t) if (e) (void) hipEventDestroy (e); for (hipEvent_t e : d) if (e) (void) hipEventDestroy (e); }
+  } events { ev_aux, ev_tab, lane_done };
+  AWM_HIP_CHECK (hipEventCreateWithFlags (&ev_aux, hipEventDisableTiming));
+  for (auto& e : ev_tab)
+    AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
+  for (auto& e : lane_done)
+    AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
+  AWM_HIP_CHECK (hipEventRecord (ev_aux, ctx->stream));    // (also orders everything behind the clips' producers on the context's stream)
+  AWM_HIP_CHECK (hipStreamWaitEvent (table_stream, ev_aux, 0));
+  for (int i = 1; i < n_lanes; i++)
+    AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ev_aux, 0));
+  int rc = 0;
+  for (size_t g0 = 0, gi = 0; g0 < n_clips && !rc; g0 += GROUP, gi++)
+    {
+      const size_t gn = std::min (GROUP, n_clips - g0);
+      const int half = int (gi & 1);
+      int8_t *dev = ctx->ws_keytab.as<int8_t>() + size_t (half) * GROUP * table_bytes;
+      if (gi >= 2)                                          // the clips of group gi - 2 (same table area) are through on every lane
+        for (int i = 0; i < n_lanes; i++)
+          AWM_HIP_CHECK (hipStreamWaitEvent (table_stream, lane_done[size_t (half) * n_lanes + i], 0));
+      awmk::KeyTableArgs ka {};
+      ka.sbox = d_aux;
+      ka.coded = d_aux + 256;
+      ka.round_keys = d_aux + 256 + 2 * 858 + 176 * g0;
+      ka.scratch = ctx->ws_keytab_scratch.as<unsigned char>();
+      ka.scratch_slots = int (GROUP);
+      ka.tables = reinterpret_cast<signed char *> (dev);
+      ka.n_keys = (long long) gn;
+      AWM_HIP_CHECK (awmk::launch_frame_mod_tables (table_stream, ka));
+      AWM_HIP_CHECK (hipEventRecord (ev_tab[half], table_stream));
+      for (int i = 0; i < n_lanes; i++)
+        AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ev_tab[half], 0));
+      for (size_t i = 0; i < gn && !rc; i++)
+        rc = add_full (ctx, pcm_in_d[g0 + i], out_d[g0 + i], n_frames[g0 + i], n_channels, dev + i * table_bytes, params().water_delta,
+                       !params().test_no_limiter, lanes[(g0 + i) % n_lanes]);
+      for (int i = 0; i < n_lanes && !rc; i++)
+        AWM_HIP_CHECK (hipEventRecord (lane_done[size_t (half) * n_lanes + i], lanes[i]->stream));
+    }
+  for (int i = 1; i < n_lanes; i++)
+    {
+      AWM_HIP_CHECK (hipEventRecord (lanes[i]->ev_sync, lanes[i]->stream));
+      AWM_HIP_CHECK (hipStreamWaitEvent (ctx->stream, lanes[i]->ev_sync, 0));
+    }
+  AWM_HIP_CHECK (hipEventRecord (lanes[n_lanes]->ev_sync, table_stream));
+  AWM_HIP_CHECK (hipStreamWaitEvent (ctx->stream, lanes[n_lanes]->ev_sync, 0));
+  // (the staging block is the context's: its upload has to be through before the next call refills it)
+  AWM_HIP_CHECK (hipEventSynchronize (ev_aux));
+  return rc;
+}
+
+/* the tables K16 builds, copied to the host: n_keys x 2 x 2226 x 81 bytes (for tests: they must equal awm_tab_frame_mod key by key) */
+int
+awm_debug_frame_mod_tables_d (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, const char *payload_hex, int8_t *tables_out)
+{
+  AWM_ENTER (ctx);
+  const std::vector<int> bits = parse_payload (payload_hex ? payload_hex : "");
+  if (bits.empty() || !keys || !tables_out || !params().mix || code_size (ConvBlockType::a, params().payload_size) != 858)
+    {
+      set_error ("awm_debug_frame_mod_tables_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  constexpr size_t GROUP = 256;
+  const size_t table_bytes = awmk::key_table_bytes();
+  const size_t aux_bytes = 256 + 2 * 858 + GROUP * 176;
+  if (int rc = ctx->ws_keytab_aux.reserve (aux_bytes)) return rc;
+  if (int rc = ctx->ws_keytab.reserve (GROUP * table_bytes)) return rc;
+  if (int rc = ctx->ws_keytab_scratch.reserve (GROUP * awmk::key_table_scratch_bytes())) return rc;
+  std::vector<unsigned char> aux (aux_bytes);
+  std::memcpy (aux.data(), Aes128::sbox(), 256);
+  for (int ab = 0; ab < 2; ab++)
+    {
+      const std::vector<int> coded = code_encode (ab ? ConvBlockType::b : ConvBlockType::a, bits);
+      for (size_t i = 0; i < 858 && i < coded.size(); i++)
+        aux[256 + 858 * ab + i] = (unsigned char) (coded[i] & 1);
+    }
+  for (size_t g0 = 0; g0 < n_keys; g0 += GROUP)
+    {
+      const size_t gn = std::min (GROUP, n_keys - g0);
+      for (size_t i = 0; i < gn; i++)
+        {
+          Aes128 aes;
+          aes.set_key (keys + 16 * (g0 + i));
+          std::memcpy (aux.data() + 256 + 2 * 858 + 176 * i, aes.round_keys(), 176);
+        }
+      unsigned char *d_aux = ctx->ws_keytab_aux.as<unsigned char>();
+      AWM_HIP_CHECK (hipMemcpyAsync (d_aux, aux.data(), aux_bytes, hipMemcpyHostToDevice, ctx->stream));
+      awmk::KeyTableArgs ka {};
+      ka.sbox = d_aux;
+      ka.coded = d_aux + 256;
+      ka.round_keys = d_aux + 256 + 2 * 858;
+      ka.scratch = ctx->ws_keytab_scratch.as<unsigned char>();
+      ka.scratch_slots = int (GROUP);
+      ka.tables = ctx->ws_keytab.as<signed char>();
+      ka.n_keys = (long long) gn;
+      AWM_HIP_CHECK (awmk::launch_frame_mod_tables (ctx->stream, ka));
+      AWM_HIP_CHECK (hipMemcpyAsync (tables_out + g0 * table_bytes, ctx->ws_keytab.ptr, gn * table_bytes, hipMemcpyDeviceToHost, ctx->stream));
+      AWM_HIP_CHECK (stream_wait (ctx->stream));
+    }
+  return 0;
+}
+
 int
 awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
                                 float *const *out_d, const size_t *n_frames, int n_channels)
@@ -986,7 +1149,10 @@ awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *p
       return AWM_ERR_ARG;
     }
   const size_t table_bytes = 2 * mark_block_frame_count() * Params::n_bands;
-  // A key's table costs about a millisecond of one host core and is 360 KB; the device needs 25 us per clip.  So the tables are built
+  if (g_key_tables_on_device && params().mix && table_bytes == awmk::key_table_bytes()
+      && code_size (ConvBlockType::a, params().payload_size) == 858 && n_clips)
+    return add_batch_keys_device_tables (ctx, keys, bits, n_clips, pcm_in_d, out_d, n_frames, n_channels);
+  // The host path (--linear, or the device path switched off): a key's table costs about a millisecond of one host core and is 360 KB; the device needs 25 us per clip.  So the tables are built
   // for SUPER clips at a time on up to 64 host threads, straight into one half of a page-locked staging block (the workers copy,
   // not the launching thread), go to the device in ONE copy per SUPER, and the next SUPER is built while the device works on this one.
   // (Round 3a: one task per group of 64 with the launching thread copying 23 MB per group into the staging block: 90 ms for 1024

@@ -83,7 +83,7 @@ void
 awm::WorkLane::release_lane()
 {
   for (DevBuffer *b : { &ws_db, &ws_block_db, &ws_have, &ws_q, &ws_raw, &ws_mean, &ws_misc, &ws_refine, &ws_refine_have, &ws_soft, &ws_viterbi,
-                        &ws_viterbi_in, &ws_viterbi_bits, &ws_viterbi_err, &ws_viterbi_sync, &ws_block_max, &ws_clip, &ws_idx, &ws_limit_tab, &ws_jobs, &ws_group, &ws_keytab, &ws_shard_edge, &ws_shard_tail, &ws_shard_q })
+                        &ws_viterbi_in, &ws_viterbi_bits, &ws_viterbi_err, &ws_viterbi_sync, &ws_block_max, &ws_clip, &ws_idx, &ws_limit_tab, &ws_jobs, &ws_group, &ws_keytab, &ws_keytab_aux, &ws_keytab_scratch, &ws_shard_edge, &ws_shard_tail, &ws_shard_q })
     b->release();
   for (PinnedBuffer *b : { &pin_refine_in[0], &pin_refine_in[1], &pin_refine_q[0], &pin_refine_q[1], &pin_peaks, &pin_blocks, &pin_jobs, &pin_bits, &pin_small, &pin_group, &pin_shard, &pin_shard_up, &pin_keytab })
     b->release();

@@ -173,7 +173,7 @@ struct WorkLane
   bool           own_stream = false;
   // workspaces
   DevBuffer ws_db, ws_block_db, ws_have, ws_q, ws_raw, ws_mean, ws_misc, ws_refine, ws_refine_have, ws_soft,
-            ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_viterbi_sync, ws_block_max, ws_clip, ws_idx, ws_limit_tab, ws_jobs, ws_group, ws_keytab;
+            ws_viterbi, ws_viterbi_in, ws_viterbi_bits, ws_viterbi_err, ws_viterbi_sync, ws_block_max, ws_clip, ws_idx, ws_limit_tab, ws_jobs, ws_group, ws_keytab, ws_keytab_aux, ws_keytab_scratch;
   DevBuffer ws_shard_edge, ws_shard_tail, ws_shard_q;      // multi-GPU protocol (wmshard.cc): edge frames, stitched tail buffer, score blocks
   // host staging (two refinement slots: see SyncFinder::SearchJob)
   PinnedBuffer pin_refine_in[2], pin_refine_q[2], pin_peaks, pin_blocks, pin_jobs, pin_bits, pin_small, pin_group, pin_shard, pin_shard_up, pin_keytab;

@@ -393,6 +393,10 @@ void awm_debug_set_sliding3 (int on);
 void awm_debug_set_soft_bits_generic (int on); /* K7: one thread per soft bit for every shape (the fallback kernel) | four bits per wave */
 void awm_debug_set_chunk_stagger (int mode); /* get: phase offset between the chunk lanes -- 0 all chunks start together | 1 chunk i + 1 behind chunk i's
                                              * dB kernel | 2 behind its scan | -1 (default) 1 for streams of up to `lanes` chunks, 2 for longer ones */
+int  awm_debug_frame_mod_tables_d (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, const char *payload_hex, int8_t *tables_out);
+                                             /* the frame_mod tables as K16 builds them (wmadd.cc:86-162), n_keys x 2 x 2226 x 81 bytes to host memory:
+                                              * for the test that they equal awm_tab_frame_mod key by key */
+void awm_debug_set_key_tables_on_device (int on);   /* batches with one key per clip: the frame_mod tables built by K16 on the device (default) | on host threads */
 void awm_debug_set_merge_decodes (int on);  /* get of a stream of 2 - 4 chunks: the chunks' Viterbi jobs as ONE batch at the end | per chunk (default: the step is faster) */
 void awm_debug_set_add_slab_mb (int mb);   /* add: 0 (default) one fused add over the stream, then the limiter | > 0: in slabs of that many MB (cache experiment) */
 void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transforms pipelined in one wave (default) | one after the other */

@@ -505,6 +505,33 @@ def test_multi_context_get_equals_single(gpu, minutes, cuts):
         gpu.awm.set_params()
 
 
+def test_key_tables_on_the_device(gpu):
+    """K16 (hip/keytab.hip): the frame_mod tables of `add` built on the device -- AES-128-CTR draws, the per-frame band shuffles, the three
+    key-wide Fisher-Yates shuffles (targets in parallel, swaps by one lane), the table fill -- equal the host's awm_tab_frame_mod byte for
+    byte, for 1024 keys (test keys 1 .. 1000, the zero key, random 128 bit keys) and two payloads; and a batch `add` with one key per
+    clip gives the same PCM with the tables from either side."""
+    import ctypes as C
+    rng = np.random.default_rng(99)
+    keys = [gpu.awm.test_key(k) for k in range(1, 1001)] + [bytes(16)] + [bytes(rng.integers(0, 256, 16, dtype=np.uint8)) for _ in range(23)]
+    flat = b"".join(gpu.awm.key_bytes(k) for k in keys)
+    for payload in (PAY1, "ffffffffffffffffffffffffffffffff"):
+        out = np.zeros((len(keys), 2 * 2226 * 81), np.int8)
+        rc = gpu.awm.lib.awm_debug_frame_mod_tables_d(gpu.ctx._h, flat, C.c_size_t(len(keys)), payload.encode(), out.ctypes.data_as(C.c_void_p))
+        assert rc == 0, gpu.awm.lib.awm_last_error()
+        check = range(len(keys)) if payload == PAY1 else range(0, len(keys), 37)
+        for i in check:
+            want = np.asarray(gpu.awm.tab_frame_mod(keys[i], payload), np.int8).ravel()
+            assert np.array_equal(out[i], want), (payload, i)
+    clips = [gpu.dev(noise(500 + i, 20 * 44100 + 13 * i, 2)) for i in range(24)]
+    try:
+        gpu.awm.lib.awm_debug_set_key_tables_on_device(0)
+        host_side = gpu.ctx.add_watermark_batch_keys(keys[:24], PAY1, clips)
+    finally:
+        gpu.awm.lib.awm_debug_set_key_tables_on_device(1)
+    device_side = gpu.ctx.add_watermark_batch_keys(keys[:24], PAY1, clips)
+    assert all(gpu.torch.equal(a, b) for a, b in zip(host_side, device_side))
+
+
 def test_multi_context_clip_batches_equal_single_context(gpu):
     """awm_multi_add_watermark_batch_d / awm_multi_get_watermark_batch_d: 40 clips of 20 - 30 s dealt unevenly to three contexts (all on
     the one GPU of the box), every clip with its own key and, in a second pass, one key for all: PCM and pattern lists equal the
