@@ -485,7 +485,7 @@ def main():
         audio_seconds = args.clips * 30.0
         workload = (f"{args.clips} clips of 30 s stereo 44.1 kHz test-gen-noise (--test-key k, 16 bit) over {world} GPU(s) (replicas: {len(mine)} on rank 0), "
                     f"add + get per clip with the clip's own key k (awm_add_watermark_batch_keys_d / awm_get_watermark_batch_keys_d: groups of 64 clips, "
-                    f"key tables of a group built on host threads while the device works on the previous group, one launch per stage and group)")
+                    f"`add`: the frame_mod tables of 256 keys per launch of the device's table kernel (K16) on its own stream while the previous 256 clips are watermarked; `get`: a group's tables on host threads while the device works on the previous group; one launch per stage and group)")
 
         def step():
             ctx.add_watermark_batch_keys(keys, PAYLOAD, clips, outs)
