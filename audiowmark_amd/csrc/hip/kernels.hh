@@ -338,6 +338,7 @@ struct VarResampleArgs
   float                *out;
   long long             out_stride;    // floats
   int                   max_stride;    // largest table row stride among the centres (sizes the LDS copy)
+  double                max_step;      // largest advance of the input window per output among the centres, in frames (mant / 2^shift); 0: unknown
   int                   lds_floats;    // set by the launcher
 };
 hipError_t launch_resample_var (hipStream_t st, const VarResampleArgs& a, long long max_n_out, int n_centers);

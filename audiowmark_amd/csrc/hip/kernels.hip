@@ -18,6 +18,7 @@
 #include "kernels.hh"
 #include "awm_fft.hip.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace awmk {
 
@@ -915,31 +916,43 @@ resample_output (const ResampleArgs& a, const float *tab, int stride, long long 
 
 /* Neighbouring outputs use different phases, i.e. different coefficient rows: read from global memory every load
  * instruction of a wave touches up to 64 cache lines (first version of this kernel: 41 ms for an hour of stereo at 48 kHz
- * down and up again).  The table ((np + 1) x hl, 10 - 30 KiB for the usual rates) is staged in LDS once per 1024 outputs,
- * with an odd row stride so that equal columns of different rows fall into different banks. */
+ * down and up again).  The table ((np + 1) x hl, 10 - 30 KiB for the usual rates) is staged in LDS, with an odd row stride so
+ * that equal columns of different rows fall into different banks. */
 /* The windows of neighbouring outputs overlap almost completely (36 - 40 taps, the window start advances by ~1 frame per
- * output).  For stereo the input window of the whole tile (in_span frames, zero extended at the ends of the stream: no bounds
+ * output).  For stereo the input window of a whole tile (in_span frames, zero extended at the ends of the stream: no bounds
  * checks in the tap loop) is staged in LDS next to the table, and window start / phase are computed relative to the tile in
- * 32 bits.  Measured: 2.2 -> 2.1 ms for an hour of stereo 48 -> 44.1 kHz -- the kernel is bound by the issue of its unfused
- * multiplies and additions (8 per tap pair, zita's order), not by the L1 traffic the staging removes. */
+ * 32 bits. */
+/* A workgroup keeps its table for `tiles_per_wg` consecutive tiles: staging the table took as long as the taps of one tile
+ * (a dozen dependent global loads per thread for 4 outputs per thread). */
 template<int CT> __global__ void __launch_bounds__ (256)
-resample_kernel (ResampleArgs a, int lds_floats, int in_span)
+resample_kernel (ResampleArgs a, int lds_floats, int in_span, int tiles_per_wg)
 {
   extern __shared__ float s_tab[];                           // lds_floats (launcher): the table, or nothing if it is too large; then the window
-  const long long tile0 = (long long) blockIdx.x * RS_TILE;
-  const int stride = a.hl | 1, rows = a.np + 1;
+  const int stride = a.hl | 1;
   const bool in_lds = lds_floats > 0;
+  const bool staged = CT == 2 && in_lds && in_span > 0;
   float2 *s_in = reinterpret_cast<float2 *> (s_tab + ((lds_floats + 1) & ~1));
-  const long long b0 = (tile0 * a.step) / a.np;
-  const unsigned int r0 = (unsigned int) (tile0 * a.step - b0 * a.np);
-  const long long first0 = b0 - (a.hl - 1);                               // first input frame the tile's first output reads
   if (in_lds)
     {
-      for (int r = threadIdx.x / 32; r < rows; r += 8)         // 32 threads per row (hl <= 64 in practice; loop covers more)
-        for (int c = threadIdx.x & 31; c < a.hl; c += 32)
-          s_tab[r * stride + c] = a.ctab[r * a.hl + c];
-      if (CT == 2 && in_span > 0)
+      const int n = (a.np + 1) * a.hl;
+      for (int i = threadIdx.x; i < n; i += 256)
         {
+          const int r = i / a.hl;
+          s_tab[r * stride + (i - r * a.hl)] = a.ctab[i];
+        }
+    }
+  for (int t = 0; t < tiles_per_wg; t++)
+    {
+      const long long tile0 = ((long long) blockIdx.x * tiles_per_wg + t) * RS_TILE;
+      if (tile0 >= a.n_out)
+        break;                                                                 // (uniform)
+      const long long b0 = (tile0 * a.step) / a.np;
+      const unsigned int r0 = (unsigned int) (tile0 * a.step - b0 * a.np);
+      const long long first0 = b0 - (a.hl - 1);                               // first input frame the tile's first output reads
+      if (staged)
+        {
+          if (t)
+            __syncthreads();                                                   // the previous tile's windows have been read
           const float2 *in2 = reinterpret_cast<const float2 *> (a.in);
           for (int i = threadIdx.x; i < in_span; i += 256)
             {
@@ -947,19 +960,20 @@ resample_kernel (ResampleArgs a, int lds_floats, int in_span)
               s_in[i] = (j >= 0 && j < a.n_in) ? in2[j] : make_float2 (0.f, 0.f);
             }
         }
-      __syncthreads();
-    }
-  for (int q = 0; q < RS_TILE / 256; q++)
-    {
-      const long long m = tile0 + q * 256 + threadIdx.x;
-      if (m >= a.n_out)
-        break;
-      if (CT == 2 && in_lds && in_span > 0)
-        resample_output_staged (a, s_tab, stride, m, s_in, r0 + (unsigned int) (q * 256 + threadIdx.x) * (unsigned int) a.step);
-      else if (in_lds)
-        resample_output<CT> (a, s_tab, stride, m);
-      else
-        resample_output<CT> (a, a.ctab, a.hl, m);
+      if (in_lds && (staged || t == 0))
+        __syncthreads();
+      for (int q = 0; q < RS_TILE / 256; q++)
+        {
+          const long long m = tile0 + q * 256 + threadIdx.x;
+          if (m >= a.n_out)
+            break;
+          if (staged)
+            resample_output_staged (a, s_tab, stride, m, s_in, r0 + (unsigned int) (q * 256 + threadIdx.x) * (unsigned int) a.step);
+          else if (in_lds)
+            resample_output<CT> (a, s_tab, stride, m);
+          else
+            resample_output<CT> (a, a.ctab, a.hl, m);
+        }
     }
 }
 
@@ -968,7 +982,9 @@ launch_resample (hipStream_t st, const ResampleArgs& a)
 {
   if (a.n_out <= 0)
     return hipSuccess;
-  const dim3 grid (unsigned ((a.n_out + RS_TILE - 1) / RS_TILE));
+  const long long n_tiles = (a.n_out + RS_TILE - 1) / RS_TILE;
+  const int tiles_per_wg = int (std::min<long long> (8, std::max<long long> (1, n_tiles / 4096)));     // >= 4096 workgroups first
+  const dim3 grid (unsigned ((n_tiles + tiles_per_wg - 1) / tiles_per_wg));
   const bool aligned = (reinterpret_cast<uintptr_t> (a.in) & 7) == 0 && (reinterpret_cast<uintptr_t> (a.out) & 7) == 0;
   // dynamic LDS of exactly the table size: 10 - 30 KiB for the usual rates leaves room for up to 8 waves per SIMD
   const int want = (a.np + 1) * (a.hl | 1);
@@ -979,9 +995,9 @@ launch_resample (hipStream_t st, const ResampleArgs& a)
   const int in_span = stage ? int (span) : 0;
   const size_t lds_bytes = size_t ((lds_floats + 1) & ~1) * sizeof (float) + size_t (in_span) * sizeof (float2);
   if (a.n_channels == 2 && aligned)
-    hipLaunchKernelGGL (resample_kernel<2>, grid, dim3 (256), lds_bytes, st, a, lds_floats, in_span);
+    hipLaunchKernelGGL (resample_kernel<2>, grid, dim3 (256), lds_bytes, st, a, lds_floats, in_span, tiles_per_wg);
   else
-    hipLaunchKernelGGL (resample_kernel<0>, grid, dim3 (256), lds_bytes, st, a, lds_floats, in_span);
+    hipLaunchKernelGGL (resample_kernel<0>, grid, dim3 (256), lds_bytes, st, a, lds_floats, in_span, tiles_per_wg);
   return hipGetLastError();
 }
 

@@ -11,6 +11,7 @@
 // registers while its neighbours read neighbouring rows (coalesced).
 #include "kernels.hh"
 #include "awm_fft.hip.h"
+#include <algorithm>
 
 namespace awmk {
 
@@ -104,39 +105,93 @@ var_output (const SpeedCenterDev& cd, const float *tab, int stride, const float 
     }
 }
 
-constexpr int RV_TILE = 1024;             // outputs per workgroup
+/* stereo, the input window of the tile staged in LDS (zero extended at the ends of the stream): s_in[0] is input frame first0;
+ * the same products and sums as var_output */
+__device__ __forceinline__ void
+var_output_staged (const SpeedCenterDev& cd, const float *tab, int stride, const VarPhase& v, const float2 *p1, long long m, float *out)
+{
+  const int hl = cd.hl, np = 256;
+  const float *q1 = tab + stride * v.k, *q1n = q1 + stride;
+  const float *q2 = tab + stride * (np - v.k), *q2p = q2 - stride;
+  const float2 *p2 = p1 + 2 * hl - 1;
+  float s0 = 1e-25f, s1 = 1e-25f;
+#pragma unroll 4
+  for (int i = 0; i < hl; i++)
+    {
+      const float c1 = __fadd_rn (__fmul_rn (v.af, q1[i]), __fmul_rn (v.bf, q1n[i]));
+      const float c2 = __fadd_rn (__fmul_rn (v.af, q2[i]), __fmul_rn (v.bf, q2p[i]));
+      const float2 x1 = p1[i], x2 = p2[-i];
+      s0 = __fadd_rn (s0, __fadd_rn (__fmul_rn (x1.x, c1), __fmul_rn (x2.x, c2)));
+      s1 = __fadd_rn (s1, __fadd_rn (__fmul_rn (x1.y, c1), __fmul_rn (x2.y, c2)));
+    }
+  reinterpret_cast<float2 *> (out)[m] = make_float2 (__fsub_rn (s0, 1e-25f), __fsub_rn (s1, 1e-25f));
+}
+
+constexpr int RV_TILE = 512;              // outputs per tile (one staged input window)
 constexpr int RV_MAX_TAB = 12288;         // floats of LDS for the coefficient table (48 KiB): 257 rows of up to 47 floats
+constexpr int RV_MAX_SPAN = 4096;         // input frames of a staged window (32 KiB)
 
 /* Neighbouring outputs have unrelated phases, i.e. every lane reads its own four coefficient rows: from global memory that
  * is 64 different cache lines per load instruction (the first version of this kernel spent 58 % of the whole speed search
  * there).  The table (257 rows, row stride odd so that equal columns of different rows fall into different banks) is
- * therefore staged in LDS once per workgroup of 1024 outputs. */
+ * therefore staged in LDS, once per workgroup, which then works through `tiles_per_wg` consecutive tiles (staging 4 - 9 k
+ * floats took longer than the taps of one tile).  For stereo the input window of a tile goes through LDS as well: the
+ * windows of neighbouring outputs overlap almost completely, read from global memory every tap pair is two load
+ * instructions over 9 - 17 cache lines. */
 template<int CT> __global__ void __launch_bounds__ (256)
-resample_var_kernel (VarResampleArgs a)
+resample_var_kernel (VarResampleArgs a, int tiles_per_wg, int in_span)
 {
-  extern __shared__ float s_tab[];                           // lds_floats: sized for the largest table of the launch (occupancy)
+  extern __shared__ float s_tab[];                           // lds_floats: sized for the largest table of the launch (occupancy); then the window
   const SpeedCenterDev cd = a.centers[blockIdx.y];
-  const long long tile0 = (long long) blockIdx.x * RV_TILE;
-  if (tile0 >= cd.n_out)
+  if ((long long) blockIdx.x * tiles_per_wg * RV_TILE >= cd.n_out)
     return;
   const int stride = cd.stride, n_tab = 257 * stride;
   const bool in_lds = n_tab <= a.lds_floats;
+  const bool staged = CT == 2 && in_lds && in_span > 0;
+  float2 *s_in = reinterpret_cast<float2 *> (s_tab + ((a.lds_floats + 1) & ~1));
   if (in_lds)
-    {
-      for (int i = threadIdx.x; i < n_tab; i += blockDim.x)
-        s_tab[i] = cd.ctab[i];
-      __syncthreads();
-    }
+    for (int i = threadIdx.x; i < n_tab; i += blockDim.x)
+      s_tab[i] = cd.ctab[i];
   float *out = a.out + blockIdx.y * a.out_stride;
-  for (int q = 0; q < RV_TILE / 256; q++)
+  for (int t = 0; t < tiles_per_wg; t++)
     {
-      const long long m = tile0 + q * 256 + threadIdx.x;
-      if (m >= cd.n_out)
-        break;
-      if (in_lds)                                                // two copies of the loop: ds_read vs global_load addressing
-        var_output<CT> (cd, s_tab, stride, a.in, a.n_channels, m, out);
-      else
-        var_output<CT> (cd, cd.ctab, stride, a.in, a.n_channels, m, out);
+      const long long tile0 = ((long long) blockIdx.x * tiles_per_wg + t) * RV_TILE;
+      if (tile0 >= cd.n_out)
+        break;                                                                 // (uniform)
+      long long first0 = 0;
+      if (staged)
+        {
+          first0 = var_phase (cd, tile0).first;                                // window starts do not decrease with m
+          if (t)
+            __syncthreads();                                                   // the previous tile's windows have been read
+          const float2 *in2 = reinterpret_cast<const float2 *> (a.in);
+          for (int i = threadIdx.x; i < in_span; i += 256)
+            {
+              const long long j = first0 + i;
+              s_in[i] = (j >= 0 && j < cd.n_in) ? in2[j] : make_float2 (0.f, 0.f);
+            }
+        }
+      if (in_lds && (staged || t == 0))
+        __syncthreads();
+      for (int q = 0; q < RV_TILE / 256; q++)
+        {
+          const long long m = tile0 + q * 256 + threadIdx.x;
+          if (m >= cd.n_out)
+            break;
+          if (staged)
+            {
+              const VarPhase v = var_phase (cd, m);
+              const long long rel = v.first - first0;
+              if (rel >= 0 && rel + 2 * cd.hl <= in_span)                      // (always, by the launcher's bound; kept as a guard)
+                var_output_staged (cd, s_tab, stride, v, s_in + rel, m, out);
+              else
+                var_output<CT> (cd, s_tab, stride, a.in, a.n_channels, m, out);
+            }
+          else if (in_lds)                                       // two copies of the loop: ds_read vs global_load addressing
+            var_output<CT> (cd, s_tab, stride, a.in, a.n_channels, m, out);
+          else
+            var_output<CT> (cd, cd.ctab, stride, a.in, a.n_channels, m, out);
+        }
     }
 }
 
@@ -147,16 +202,23 @@ launch_resample_var (hipStream_t st, const VarResampleArgs& args, long long max_
     return hipSuccess;
   VarResampleArgs a = args;
   // LDS for the largest table of the launch (a.max_stride): a small table (ratios near 1: 17 KiB) leaves room for 8 waves
-  // per SIMD, which is what hides the load latency of the tap loop; tables beyond 48 KiB stay in global memory
+  // per SIMD; tables beyond 48 KiB stay in global memory
   const int want = 257 * a.max_stride;
   a.lds_floats = want <= RV_MAX_TAB ? want : 0;
-  const dim3 grid (unsigned ((max_n_out + RV_TILE - 1) / RV_TILE), unsigned (n_centers));
-  const size_t lds_bytes = size_t (a.lds_floats) * sizeof (float);
+  const long long n_tiles = (max_n_out + RV_TILE - 1) / RV_TILE;
+  const int tiles_per_wg = int (std::min<long long> (16, std::max<long long> (1, n_tiles * n_centers / 4096)));   // >= 4096 workgroups first
+  const dim3 grid (unsigned ((n_tiles + tiles_per_wg - 1) / tiles_per_wg), unsigned (n_centers));
   const bool aligned = (reinterpret_cast<uintptr_t> (a.in) & 7) == 0 && (reinterpret_cast<uintptr_t> (a.out) & 7) == 0 && (a.out_stride & 1) == 0;
+  // input frames the outputs of a tile read: the window start moves by floor ((RV_TILE - 1) * max_step) + 1 at most (+ 1: var_phase's
+  // round-up case), plus one window (2 hl <= 2 max_stride)
+  const long long span = (long long) ((RV_TILE - 1) * a.max_step) + 3 + 2LL * a.max_stride;
+  const bool stage = a.n_channels == 2 && aligned && a.lds_floats > 0 && a.max_step > 0 && span <= RV_MAX_SPAN;
+  const int in_span = stage ? int (span) : 0;
+  const size_t lds_bytes = size_t ((a.lds_floats + 1) & ~1) * sizeof (float) + size_t (in_span) * sizeof (float2);
   if (a.n_channels == 2 && aligned)
-    hipLaunchKernelGGL (resample_var_kernel<2>, grid, dim3 (256), lds_bytes, st, a);
+    hipLaunchKernelGGL (resample_var_kernel<2>, grid, dim3 (256), lds_bytes, st, a, tiles_per_wg, in_span);
   else
-    hipLaunchKernelGGL (resample_var_kernel<0>, grid, dim3 (256), lds_bytes, st, a);
+    hipLaunchKernelGGL (resample_var_kernel<0>, grid, dim3 (256), lds_bytes, st, a, tiles_per_wg, in_span);
   return hipGetLastError();
 }
 

@@ -325,7 +325,10 @@ prepare_mags (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& cli
   ra.out = ws->sub.as<float>();
   ra.out_stride = sub_stride;
   for (const auto& cd : cds)
-    ra.max_stride = std::max (ra.max_stride, cd.stride);
+    {
+      ra.max_stride = std::max (ra.max_stride, cd.stride);
+      ra.max_step = std::max (ra.max_step, std::ldexp (double (cd.mant), -cd.shift));
+    }
   AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, max_out, int (centers.size())));
   awmk::SpeedMagsArgs ma {};
   ma.sub = ws->sub.as<float>();
@@ -390,6 +393,7 @@ resample_var_device (awm_ctx *ctx, WorkLane *lane, const float *in_d, size_t n_i
   ra.out = out_d;
   ra.out_stride = 0;
   ra.max_stride = cd.stride;
+  ra.max_step = std::ldexp (double (cd.mant), -cd.shift);
   AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, (long long) n_out, 1));
   AWM_HIP_CHECK (hipStreamSynchronize (st));
   return 0;
