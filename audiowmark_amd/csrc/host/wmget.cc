@@ -558,6 +558,9 @@ extern "C" void awm_debug_set_merge_decodes (int on) { g_merge_decodes = on; }
  * -1 (default): 1 for streams whose chunks all start at once, 2 for streams with more chunks than lanes.  Results do not depend on it. */
 int g_chunk_stagger = -1;
 extern "C" void awm_debug_set_chunk_stagger (int on) { g_chunk_stagger = on; }
+/* (measurement knob) get with a speed search: 1 (default) the plain decode of the chunks runs beside the speed part | 0 after it */
+int g_speed_overlap = 1;
+extern "C" void awm_debug_set_speed_overlap (int on) { g_speed_overlap = on; }
 namespace {
 
 /* BlockDecoder::run (reference wmget.cc:502-706) for several chunks of one resident stream at once.  Every chunk
@@ -1128,8 +1131,49 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
   std::vector<ResultSet *> ptrs;
   for (auto& cs : chunk_sets)
     ptrs.push_back (&cs);
+  std::string debug_sync;
+  /* With a speed search the PLAIN decode of the chunks (reference wmget.cc:929: after the speed part) depends on nothing the speed part
+   * produces: it runs beside it, on lanes of its own behind the speed chunks' lanes and driven by a host thread of its own, into pattern
+   * lists of its own that are appended to the chunks' lists afterwards (the reference's order: speed patterns, then block patterns).  The
+   * speed part leaves a third of the GPU's time unused (host round trips between its passes). */
+  std::vector<ResultSet> plain_sets;
+  std::string plain_error;
+  std::future<int> plain_run;                   // (declared after everything its task refers to)
   if (params().detect_speed || params().detect_speed_patient || params().try_speed > 0)
     {
+      const size_t lanes_per_part = size_t (std::max (1, std::min (ctx->chunk_lanes, CHUNK_LANES)));
+      if (spread && g_speed_overlap && !chunks.empty())
+        {
+          const int lane_base = int (std::min<size_t> (chunks.size(), lanes_per_part));          // behind the speed part's lanes
+          const size_t n_plain = std::min<size_t> (chunks.size(), lanes_per_part);
+          if (!ctx->ev_sync)
+            AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
+          AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));                             // the PCM may still be in flight there
+          for (size_t i = 0; i < n_plain; i++)
+            {
+              WorkLane *l = ctx->lane (lane_base + int (i));
+              if (!l)
+                {
+                  set_error ("cannot create a work lane (stream)");
+                  return AWM_ERR_HIP;
+                }
+              AWM_HIP_CHECK (hipStreamWaitEvent (l->stream, ctx->ev_sync, 0));
+            }
+          plain_sets.resize (chunks.size());
+          ParamValues *const pv = &params();
+          plain_run = std::async (std::launch::async, [&, pv, lane_base] {
+            ParamsBind bind (pv);
+            if (hipSetDevice (ctx->device) != hipSuccess)
+              return int (AWM_ERR_HIP);
+            std::vector<ResultSet *> plain_ptrs;
+            for (auto& ps : plain_sets)
+              plain_ptrs.push_back (&ps);
+            const int rc = block_decoder_run (ctx, ctx, true, key_list, wav, chunks, plain_ptrs, 1, &debug_sync, lane_base);
+            if (rc)
+              plain_error = last_error();
+            return rc;
+          });
+        }
       /* The speed part of decode() for every chunk (reference wmget.cc:886-927) -- speed search, stretched copy, block and clip
        * decoder on the stretched copy -- is a long chain with a dozen host round trips (three search passes, each waiting for
        * its scores) that keeps the GPU busy for two thirds of its duration.  The chunks are independent: each one runs the
@@ -1202,8 +1246,17 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
             }
         }
     }
-  std::string debug_sync;
-  if (int rc = block_decoder_run (ctx, home, spread, key_list, wav, chunks, ptrs, 1, &debug_sync))
+  if (plain_run.valid())
+    {
+      if (int rc = plain_run.get())
+        {
+          set_error (plain_error);
+          return rc;
+        }
+      for (size_t c = 0; c < chunks.size(); c++)
+        chunk_sets[c].patterns.insert (chunk_sets[c].patterns.end(), plain_sets[c].patterns.begin(), plain_sets[c].patterns.end());
+    }
+  else if (int rc = block_decoder_run (ctx, home, spread, key_list, wav, chunks, ptrs, 1, &debug_sync))
     return rc;
   if (!chunks.empty() && first_is_stream_start)
     {
