@@ -135,9 +135,9 @@ constexpr int RV_MAX_SPAN = 4096;         // input frames of a staged window (32
  * is 64 different cache lines per load instruction (the first version of this kernel spent 58 % of the whole speed search
  * there).  The table (257 rows, row stride odd so that equal columns of different rows fall into different banks) is
  * therefore staged in LDS, once per workgroup, which then works through `tiles_per_wg` consecutive tiles (staging 4 - 9 k
- * floats took longer than the taps of one tile).  For stereo the input window of a tile goes through LDS as well: the
- * windows of neighbouring outputs overlap almost completely, read from global memory every tap pair is two load
- * instructions over 9 - 17 cache lines. */
+ * floats took longer than the taps of one tile).  For stereo the input window of a tile can go through LDS as well (the
+ * windows of neighbouring outputs overlap almost completely; read from global memory every tap pair is two load
+ * instructions over 9 - 17 cache lines) -- off by default, see g_resample_var_mode. */
 template<int CT> __global__ void __launch_bounds__ (256)
 resample_var_kernel (VarResampleArgs a, int tiles_per_wg, int in_span)
 {
@@ -195,6 +195,14 @@ resample_var_kernel (VarResampleArgs a, int tiles_per_wg, int in_span)
     }
 }
 
+/* (measurement knob) bit 0: the stereo input window of a tile through LDS | bit 1: a workgroup keeps its table for several tiles.
+ * Measured (tools/gpu_resample_var.py, profiles/r04/resample_var_modes.txt): the stretched copy of a 25 min chunk 1.38 / 1.47 / 1.17 / 1.19 ms
+ * for modes 0 / 1 / 2 / 3, get --detect-speed of configs[2] 22.6 - 22.8 / 24.5 / 21.7 / 22.6 ms: keeping the table pays, the window in LDS
+ * does not (the tap loop is 17 VALU + 3 LDS instructions per tap pair either way -- zita's 14 roundings per stereo tap pair -- and the
+ * window costs a third of the workgroups per compute unit when the table is a large one, 35 KB for the half-rate pass).  Default 2. */
+int g_resample_var_mode = 2;
+extern "C" void awm_debug_set_resample_var_mode (int mode) { g_resample_var_mode = mode; }
+
 hipError_t
 launch_resample_var (hipStream_t st, const VarResampleArgs& args, long long max_n_out, int n_centers)
 {
@@ -206,13 +214,13 @@ launch_resample_var (hipStream_t st, const VarResampleArgs& args, long long max_
   const int want = 257 * a.max_stride;
   a.lds_floats = want <= RV_MAX_TAB ? want : 0;
   const long long n_tiles = (max_n_out + RV_TILE - 1) / RV_TILE;
-  const int tiles_per_wg = int (std::min<long long> (16, std::max<long long> (1, n_tiles * n_centers / 4096)));   // >= 4096 workgroups first
+  const int tiles_per_wg = (g_resample_var_mode & 2) ? int (std::min<long long> (16, std::max<long long> (1, n_tiles * n_centers / 4096))) : 1;   // >= 4096 workgroups first
   const dim3 grid (unsigned ((n_tiles + tiles_per_wg - 1) / tiles_per_wg), unsigned (n_centers));
   const bool aligned = (reinterpret_cast<uintptr_t> (a.in) & 7) == 0 && (reinterpret_cast<uintptr_t> (a.out) & 7) == 0 && (a.out_stride & 1) == 0;
   // input frames the outputs of a tile read: the window start moves by floor ((RV_TILE - 1) * max_step) + 1 at most (+ 1: var_phase's
   // round-up case), plus one window (2 hl <= 2 max_stride)
   const long long span = (long long) ((RV_TILE - 1) * a.max_step) + 3 + 2LL * a.max_stride;
-  const bool stage = a.n_channels == 2 && aligned && a.lds_floats > 0 && a.max_step > 0 && span <= RV_MAX_SPAN;
+  const bool stage = (g_resample_var_mode & 1) && a.n_channels == 2 && aligned && a.lds_floats > 0 && a.max_step > 0 && span <= RV_MAX_SPAN;
   const int in_span = stage ? int (span) : 0;
   const size_t lds_bytes = size_t ((a.lds_floats + 1) & ~1) * sizeof (float) + size_t (in_span) * sizeof (float2);
   if (a.n_channels == 2 && aligned)
