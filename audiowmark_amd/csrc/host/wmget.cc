@@ -1216,7 +1216,8 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
           run_chunk (c, lanes[0]);
       else
         {
-          std::atomic<size_t> next { 0 };
+          // chunk c on lane c mod n, whatever the threads' timing: the lanes' workspaces reach their final sizes in the first call (with
+          // "whoever is free takes the next chunk" the pairing changed from call to call and buffers kept growing over several calls)
           std::vector<std::thread> workers;
           const int device = ctx->device;
           ParamValues *const pv = &params();
@@ -1225,12 +1226,11 @@ decode_chunks_on (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<K
               ParamsBind bind (pv);
               if (hipSetDevice (device) != hipSuccess)
                 return;
-              for (;;)
+              for (size_t c = li; c < chunks.size(); c += lanes.size())
                 {
-                  const size_t c = next.fetch_add (1);
-                  if (c >= chunks.size())
-                    break;
                   run_chunk (c, lanes[li]);
+                  if (rcs[c])
+                    break;
                 }
             });
           for (auto& w : workers)
