@@ -977,15 +977,104 @@ resample_kernel (ResampleArgs a, int lds_floats, int in_span, int tiles_per_wg)
     }
 }
 
+/* The fixed ratios 147 / 160 and 160 / 147 (48 <-> 44.1 kHz), stereo: outputs np apart have the SAME phase, i.e. the same two
+ * coefficient rows, and windows exactly `step` input frames apart.  A thread therefore takes one phase, keeps its 2 hl coefficients in
+ * registers for all the outputs it produces, and the tap loop is nothing but window reads (one ds_read2_b64 per tap pair: the windows
+ * of neighbouring threads start 1 - 2 frames apart) and zita's eight unfused operations per tap pair -- no coefficient reads, no
+ * address arithmetic (the generic kernel: 12 bytes of coefficients from LDS per tap pair beside the 16 bytes of samples, and a
+ * third more VALU instructions for indices).  A workgroup = R replicas of the np phases (R np threads busy); a tile = J rounds =
+ * R J np outputs, whose R J step + 2 hl input frames are staged in LDS (zero extended at the ends of the stream); the coefficients
+ * stay in registers over `tiles_per_wg` tiles.  Same products and sums, in the same order, as resample_output. */
+template<int NP, int STEP, int HL, int R, int J> __global__ void __launch_bounds__ ((NP * R + 63) / 64 * 64)
+resample_phase_kernel (ResampleArgs a, int tiles_per_wg)
+{
+  constexpr int SPAN = R * J * STEP + 2 * HL;                 // input frames of a tile
+  constexpr int TILE = R * J * NP;                            // outputs of a tile
+  constexpr int WG = (NP * R + 63) / 64 * 64;
+  __shared__ float2 s_in[SPAN];
+  const int tid = threadIdx.x;
+  const bool active = tid < NP * R;
+  const int rep = active ? tid / NP : 0, p = active ? tid - rep * NP : 0;
+  const int ph = (p * STEP) % NP, b_p = (p * STEP) / NP;      // phase and window start of output p of a tile (tiles start at multiples of np)
+  float c1[HL], c2[HL];
+#pragma unroll
+  for (int i = 0; i < HL; i++)
+    {
+      c1[i] = a.ctab[ph * HL + i];
+      c2[i] = a.ctab[(NP - ph) * HL + i];
+    }
+  const float2 *in2 = reinterpret_cast<const float2 *> (a.in);
+  float2 *out2 = reinterpret_cast<float2 *> (a.out);
+  for (int t = 0; t < tiles_per_wg; t++)
+    {
+      const long long tile = (long long) blockIdx.x * tiles_per_wg + t;
+      const long long tile0 = tile * TILE;
+      if (tile0 >= a.n_out)
+        break;                                                                 // (uniform)
+      const long long first0 = tile * (R * J * STEP) - (HL - 1);              // input frame of s_in[0]
+      if (t)
+        __syncthreads();                                                       // the previous tile's windows have been read
+      for (int i = tid; i < SPAN; i += WG)
+        {
+          const long long j = first0 + i;
+          s_in[i] = (j >= 0 && j < a.n_in) ? in2[j] : make_float2 (0.f, 0.f);
+        }
+      __syncthreads();
+      if (active)
+        {
+#pragma unroll 2
+          for (int j = 0; j < J; j++)
+            {
+              const int q = rep + R * j;                                       // which group of np outputs of the tile
+              const long long m = tile0 + p + NP * q;
+              if (m >= a.n_out)
+                break;
+              const float2 *p1 = s_in + b_p + STEP * q, *p2 = p1 + 2 * HL - 1;
+              float s0 = 1e-20f, s1 = 1e-20f;
+#pragma unroll
+              for (int i = 0; i < HL; i++)
+                {
+                  const float2 x1 = p1[i], x2 = p2[-i];
+                  s0 = __fadd_rn (s0, __fadd_rn (__fmul_rn (x1.x, c1[i]), __fmul_rn (x2.x, c2[i])));
+                  s1 = __fadd_rn (s1, __fadd_rn (__fmul_rn (x1.y, c1[i]), __fmul_rn (x2.y, c2[i])));
+                }
+              out2[m] = make_float2 (__fsub_rn (s0, 1e-20f), __fsub_rn (s1, 1e-20f));
+            }
+        }
+    }
+}
+
+/* (measurement knob) 1 (default): the phase-per-thread kernel for stereo 48 <-> 44.1 kHz | 0: the generic kernel for every ratio */
+int g_resample_phase = 1;
+extern "C" void awm_debug_set_resample_phase (int on) { g_resample_phase = on; }
+
+template<int NP, int STEP, int HL> static hipError_t
+launch_resample_phase (hipStream_t st, const ResampleArgs& a)
+{
+  constexpr int R = 2, J = 8;
+  const long long n_tiles = (a.n_out + R * J * NP - 1) / (R * J * NP);
+  const int tiles_per_wg = int (std::min<long long> (8, std::max<long long> (1, n_tiles / 4096)));     // >= 4096 workgroups first
+  const dim3 grid (unsigned ((n_tiles + tiles_per_wg - 1) / tiles_per_wg));
+  hipLaunchKernelGGL ((resample_phase_kernel<NP, STEP, HL, R, J>), grid, dim3 ((NP * R + 63) / 64 * 64), 0, st, a, tiles_per_wg);
+  return hipGetLastError();
+}
+
 hipError_t
 launch_resample (hipStream_t st, const ResampleArgs& a)
 {
   if (a.n_out <= 0)
     return hipSuccess;
+  const bool aligned = (reinterpret_cast<uintptr_t> (a.in) & 7) == 0 && (reinterpret_cast<uintptr_t> (a.out) & 7) == 0;
+  if (g_resample_phase && a.n_channels == 2 && aligned)
+    {
+      if (a.np == 147 && a.step == 160 && a.hl == 18)
+        return launch_resample_phase<147, 160, 18> (st, a);
+      if (a.np == 160 && a.step == 147 && a.hl == 16)
+        return launch_resample_phase<160, 147, 16> (st, a);
+    }
   const long long n_tiles = (a.n_out + RS_TILE - 1) / RS_TILE;
   const int tiles_per_wg = int (std::min<long long> (8, std::max<long long> (1, n_tiles / 4096)));     // >= 4096 workgroups first
   const dim3 grid (unsigned ((n_tiles + tiles_per_wg - 1) / tiles_per_wg));
-  const bool aligned = (reinterpret_cast<uintptr_t> (a.in) & 7) == 0 && (reinterpret_cast<uintptr_t> (a.out) & 7) == 0;
   // dynamic LDS of exactly the table size: 10 - 30 KiB for the usual rates leaves room for up to 8 waves per SIMD
   const int want = (a.np + 1) * (a.hl | 1);
   const int lds_floats = want <= RS_MAX_TAB ? want : 0;
