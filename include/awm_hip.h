@@ -191,9 +191,11 @@ int awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *
 
 /* The batch entry points with ONE KEY PER CLIP (keys = n_clips * 16 bytes; BASELINE configs[4]: `--test-key k` for clip k).  The key
  * tables -- frame_mod for `add`; CLIP sync tables, mix table and bit order for `get` (wmcommon.cc:143-202, wmadd.cc:86-162,
- * syncfinder.cc:30-77) -- are built on host threads for a group of 64 clips at a time while the device works on the previous
- * group, travel in ONE copy per group and are indexed per clip inside the group's launches; results per clip equal
- * awm_add_watermark_d / awm_get_watermark_d with that clip's key. */
+ * syncfinder.cc:30-77) -- are built group by group while the device works on the previous group and are indexed per clip inside the
+ * group's launches: `add`'s frame_mod tables ON THE DEVICE (K16, hip/keytab.hip: AES-128-CTR streams and the shuffles of one key
+ * per workgroup, 256 keys per launch; the host contributes the AES key schedules, 176 bytes per key), `get`'s tables on host
+ * threads, 64 clips per group, one copy per group.  Results per clip equal awm_add_watermark_d / awm_get_watermark_d with that
+ * clip's key. */
 int awm_add_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
                                     float *const *out_d, const size_t *n_frames, int n_channels);
 int awm_get_watermark_batch_keys_d (awm_ctx *ctx, const uint8_t *keys, size_t n_clips, const float *const *pcm_d,
