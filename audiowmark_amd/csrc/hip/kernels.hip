@@ -982,19 +982,27 @@ resample_kernel (ResampleArgs a, int lds_floats, int in_span, int tiles_per_wg)
  * registers for all the outputs it produces, and the tap loop is nothing but window reads (one ds_read2_b64 per tap pair: the windows
  * of neighbouring threads start 1 - 2 frames apart) and zita's eight unfused operations per tap pair -- no coefficient reads, no
  * address arithmetic (the generic kernel: 12 bytes of coefficients from LDS per tap pair beside the 16 bytes of samples, and a
- * third more VALU instructions for indices).  A workgroup = R replicas of the np phases (R np threads busy); a tile = J rounds =
+ * third more VALU instructions for indices).  A workgroup = R replicas of the np phases; a tile = J rounds =
  * R J np outputs, whose R J step + 2 hl input frames are staged in LDS (zero extended at the ends of the stream); the coefficients
  * stay in registers over `tiles_per_wg` tiles.  Same products and sums, in the same order, as resample_output. */
-template<int NP, int STEP, int HL, int R, int J> __global__ void __launch_bounds__ ((NP * R + 63) / 64 * 64)
+/* Which thread takes which phase: the window of phase p starts at floor (p step / np).  Going DOWN (step > np) these starts skip a value
+ * every ~11 phases, so 16 neighbouring phases span 17 - 18 frames: one 8-byte LDS word too many for 16 lanes' worth of banks, every
+ * window read a two-way conflict (measured: 1.54 ms for an hour at 48 kHz against 0.96 ms for the way up, whose starts never skip).
+ * There the threads are numbered by WINDOW START instead -- `step` slots per replica, the 13 starts that belong to no phase idle --
+ * and neighbouring lanes read neighbouring words.  Going up, neighbouring phases share or succeed each other's start already. */
+template<int NP, int STEP, int HL, int R, int J> __global__ void __launch_bounds__ (((STEP > NP ? STEP : NP) * R + 63) / 64 * 64)
 resample_phase_kernel (ResampleArgs a, int tiles_per_wg)
 {
   constexpr int SPAN = R * J * STEP + 2 * HL;                 // input frames of a tile
   constexpr int TILE = R * J * NP;                            // outputs of a tile
-  constexpr int WG = (NP * R + 63) / 64 * 64;
+  constexpr int SLOTS = STEP > NP ? STEP : NP;                // threads per replica
+  constexpr int WG = (SLOTS * R + 63) / 64 * 64;
   __shared__ float2 s_in[SPAN];
   const int tid = threadIdx.x;
-  const bool active = tid < NP * R;
-  const int rep = active ? tid / NP : 0, p = active ? tid - rep * NP : 0;
+  const int rep = tid < SLOTS * R ? tid / SLOTS : 0, slot = tid < SLOTS * R ? tid - rep * SLOTS : 0;
+  const int p_of_slot = STEP > NP ? (slot * NP + STEP - 1) / STEP : slot;              // the phase whose window starts at frame `slot`, if any
+  const bool active = tid < SLOTS * R && p_of_slot < NP && (STEP <= NP || (p_of_slot * STEP) / NP == slot);
+  const int p = active ? p_of_slot : 0;
   const int ph = (p * STEP) % NP, b_p = (p * STEP) / NP;      // phase and window start of output p of a tile (tiles start at multiples of np)
   float c1[HL], c2[HL];
 #pragma unroll
@@ -1055,7 +1063,7 @@ launch_resample_phase (hipStream_t st, const ResampleArgs& a)
   const long long n_tiles = (a.n_out + R * J * NP - 1) / (R * J * NP);
   const int tiles_per_wg = int (std::min<long long> (8, std::max<long long> (1, n_tiles / 4096)));     // >= 4096 workgroups first
   const dim3 grid (unsigned ((n_tiles + tiles_per_wg - 1) / tiles_per_wg));
-  hipLaunchKernelGGL ((resample_phase_kernel<NP, STEP, HL, R, J>), grid, dim3 ((NP * R + 63) / 64 * 64), 0, st, a, tiles_per_wg);
+  hipLaunchKernelGGL ((resample_phase_kernel<NP, STEP, HL, R, J>), grid, dim3 (((STEP > NP ? STEP : NP) * R + 63) / 64 * 64), 0, st, a, tiles_per_wg);
   return hipGetLastError();
 }
 
