@@ -1,9 +1,9 @@
-"""Randomised cross-check (seeded; a 30 s budget): short clips with random lengths, channel counts, levels, digital silence at
+"""Randomised cross-check (seeded, a FIXED number of cases per seed -- the former time budget ran 4 to 6 cases depending on the host's
+speed, one slow case away from its own `cases >= 4` assertion, and a case only a faster host reaches is a case nobody has checked):
+short clips with random lengths, channel counts, levels, digital silence at
 the edges and INSIDE the material, one silent channel, watermarked or not -- `get` through the HIP path against the oracle, the
 same material through the batch entry point, and the variable-ratio resampler against the restated zita class.  This is the check
 that found the digital-silence bugs of round 2 (tools/gpu_fuzz.py runs the same generator for longer)."""
-import time
-
 import numpy as np
 import pytest
 
@@ -12,7 +12,7 @@ import _oracle as orc
 pytestmark = pytest.mark.gpu
 
 PAY = "0123456789abcdef0011223344556677"
-BUDGET_S = 30.0
+CASES = 4              # per seed (the oracle's `get` of a case takes 1 - 10 s of one host core)
 
 
 def key(p):
@@ -67,9 +67,8 @@ def test_random_clips_equal_oracle(seed, max_seconds):
     import audiowmark_amd as awm
     rng = np.random.default_rng(seed)
     ctx = awm.Context(0)
-    t0 = time.time()
     kept, cases, ties, marked_found = {}, 0, 0, 0
-    while time.time() - t0 < BUDGET_S / 2 and cases < 24:
+    while cases < CASES:
         x, ch, marked = make_case(rng, max_seconds)
         xd = torch.from_numpy(x).cuda()
         got = ctx.get_watermark(None, xd)
@@ -80,7 +79,7 @@ def test_random_clips_equal_oracle(seed, max_seconds):
         marked_found += any(p["bits"] == PAY for p in got)
         kept.setdefault(ch, []).append((xd, got))
         cases += 1
-    assert cases >= 4 and marked_found >= 1, (cases, marked_found)
+    assert marked_found >= 1, (cases, marked_found)
     # the same material through awm_get_watermark_batch_d (groups of padded clips for the short ones, one per lane for the others)
     for ch, items in kept.items():
         batch = ctx.get_watermark_batch(None, [x for x, _ in items])
