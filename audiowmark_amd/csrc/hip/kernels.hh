@@ -5,6 +5,13 @@
 #include <cstddef>
 #include <cstdint>
 
+// The kernels are written for ONE target.  They rely on gfx950's 160 KB of LDS per workgroup (K16: 117 KB static, K5w's ring 150 KB),
+// on `sc1` device-coherent loads / stores with `s_waitcnt vmcnt(0)` for the cross-XCD meetings of the one-launch Viterbi kernel, on
+// `global_load_lds_dwordx4` and on gfx9 buffer descriptors (K14).  Another --offload-arch must not build silently.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "audiowmark_amd's HIP kernels are written for gfx950 (MI355X) only"
+#endif
+
 namespace awmk {
 
 // constant tables resident in HBM for the lifetime of a context
@@ -272,6 +279,7 @@ size_t viterbi_sync_bytes (long long n_blocks);
 /* microseconds per launch of a chain of empty dependent launches on the (idle) stream: decides, per process, between the chain of 16
  * launches and the one-launch kernel (viterbi.hip) */
 double probe_dependent_launch_us (hipStream_t st);
+const char *viterbi_form_description();          // which form the batches take and why (for error messages)
 
 /* K16 (keytab.hip): frame_mod tables built on the device, one workgroup per key (reference wmadd.cc:86-162, wmcommon.cc:143-202,
  * random.cc:97-161).  round_keys: 176 bytes per key (the AES-128 key schedule as FIPS-197's byte string, host/aes128.cc); sbox: the

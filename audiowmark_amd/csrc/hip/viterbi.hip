@@ -35,7 +35,10 @@
 //
 // Bit-exactness: sums and ties exactly as above; decoded bits and the error value are bit-identical to the oracle.
 #include "kernels.hh"
+#include <atomic>
 #include <chrono>
+#include <cstdio>
+#include <mutex>
 #include <type_traits>
 #include <utility>
 
@@ -847,15 +850,32 @@ extern "C" void awm_debug_set_viterbi_super (int on) { g_viterbi_super = on; }
  * profiles/r04/variants.txt).  So the choice is made per process from a measurement: awm_ctx_create times a chain of empty
  * dependent launches on the idle stream (probe_dependent_launch_us), and above ONE_LAUNCH_ABOVE_US per launch the batches take the
  * one-launch kernel.  awm_debug_set_viterbi_persistent (0 | 1) forces a form, -1 returns to the measurement. */
-int g_viterbi_persistent = -1;
-double g_dependent_launch_us = -1;                       // the smallest value measured by any context of the process (-1: none yet)
+/* The measurement is LATCHED: the first context of the process that gets a valid probe through decides for the process (contexts are
+ * created and decodes run from several host threads: both values are atomics, the probe itself runs under a mutex), so the form
+ * cannot flip in mid-process because a helper context was created under a tracer or on a busy host.  A failed probe (-1) leaves the
+ * question open for the next context; until then the chain runs. */
+std::atomic<int>    g_viterbi_persistent { -1 };
+std::atomic<double> g_dependent_launch_us { -1.0 };      // the latched measurement (-1: none yet)
+std::mutex          g_probe_mutex;
 constexpr double ONE_LAUNCH_ABOVE_US = 9.0;
-extern "C" void awm_debug_set_viterbi_persistent (int on) { g_viterbi_persistent = on; }
-extern "C" double awm_debug_dependent_launch_us (void) { return g_dependent_launch_us; }
+extern "C" void awm_debug_set_viterbi_persistent (int on) { g_viterbi_persistent.store (on, std::memory_order_relaxed); }
+extern "C" double awm_debug_dependent_launch_us (void) { return g_dependent_launch_us.load (std::memory_order_relaxed); }
 static bool
 use_one_launch()
 {
-  return g_viterbi_persistent > 0 || (g_viterbi_persistent < 0 && g_dependent_launch_us > ONE_LAUNCH_ABOVE_US);
+  const int forced = g_viterbi_persistent.load (std::memory_order_relaxed);
+  return forced > 0 || (forced < 0 && g_dependent_launch_us.load (std::memory_order_relaxed) > ONE_LAUNCH_ABOVE_US);
+}
+/* for error messages: which form the batches of this process take and why */
+const char *
+viterbi_form_description()
+{
+  static thread_local char text[160];
+  const int forced = g_viterbi_persistent.load (std::memory_order_relaxed);
+  snprintf (text, sizeof (text), "viterbi form: %s (%s; dependent launch probe %.1f us, one launch above %.1f us)",
+            use_one_launch() ? "one launch per batch" : "launch chain", forced < 0 ? "chosen by the probe" : "forced by awm_debug_set_viterbi_persistent",
+            g_dependent_launch_us.load (std::memory_order_relaxed), ONE_LAUNCH_ABOVE_US);
+  return text;
 }
 extern "C" int awm_debug_viterbi_one_launch_in_use (void) { return use_one_launch() ? 1 : 0; }
 
@@ -866,6 +886,10 @@ double
 probe_dependent_launch_us (hipStream_t st)
 {
   constexpr int N = 48;
+  std::lock_guard<std::mutex> lock (g_probe_mutex);
+  const double latched = g_dependent_launch_us.load (std::memory_order_relaxed);
+  if (latched >= 0)
+    return latched;
   if (hipStreamSynchronize (st) != hipSuccess)
     return -1;
   double best = -1;
@@ -880,8 +904,8 @@ probe_dependent_launch_us (hipStream_t st)
       if (best < 0 || us < best)
         best = us;
     }
-  if (g_dependent_launch_us < 0 || best < g_dependent_launch_us)
-    g_dependent_launch_us = best;
+  if (best >= 0)
+    g_dependent_launch_us.store (best, std::memory_order_relaxed);
   return best;
 }
 

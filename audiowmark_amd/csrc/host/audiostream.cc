@@ -217,6 +217,40 @@ bulk_read (FILE *f, unsigned char *buf, size_t bytes, bool& failed, int *err_out
   return total;
 }
 
+/* raw_region of the input streams: a regular file, positioned at the next sample byte */
+bool
+input_region (FILE *f, size_t frame_bytes, size_t frames_left /* N_FRAMES_UNKNOWN: until the end of the file */, int& fd, uint64_t& byte_offset,
+              size_t& frames_available)
+{
+  struct stat st;
+  if (!f || !frame_bytes || fstat (fileno (f), &st) != 0 || !S_ISREG (st.st_mode))
+    return false;
+  const off_t pos = ftello (f);
+  if (pos < 0 || st.st_size < pos)
+    return false;
+  fd = fileno (f);
+  byte_offset = uint64_t (pos);
+  frames_available = size_t (st.st_size - pos) / frame_bytes;
+  if (frames_left != AudioInputStream::N_FRAMES_UNKNOWN)
+    frames_available = std::min (frames_available, frames_left);
+  return true;
+}
+
+/* raw_region of the output streams: a regular file of our own; stdio's buffer is flushed so that the descriptor can be used beside it */
+bool
+output_region (FILE *f, bool own_file, int& fd, uint64_t& byte_offset)
+{
+  struct stat st;
+  if (!f || !own_file || fflush (f) != 0 || fstat (fileno (f), &st) != 0 || !S_ISREG (st.st_mode))
+    return false;
+  const off_t pos = ftello (f);
+  if (pos < 0)
+    return false;
+  fd = fileno (f);
+  byte_offset = uint64_t (pos);
+  return true;
+}
+
 class RawInputStream : public AudioInputStream
 {
   RawFormat m_format;
@@ -280,6 +314,17 @@ public:
       return Error ("error reading sample data");
     return Error::Code::NONE;
   }
+  bool
+  raw_region (int& fd, uint64_t& byte_offset, size_t& frames_available) override
+  {
+    const size_t frame_bytes = size_t (m_format.n_channels) * m_codec->sample_width();
+    return input_region (m_file, frame_bytes, N_FRAMES_UNKNOWN, fd, byte_offset, frames_available);
+  }
+  void
+  raw_region_consume (size_t n_frames) override
+  {
+    fseeko (m_file, off_t (n_frames * size_t (m_format.n_channels) * m_codec->sample_width()), SEEK_CUR);
+  }
 };
 
 class RawOutputStream : public AudioOutputStream
@@ -334,6 +379,14 @@ public:
     const size_t n = n_frames * m_format.n_channels * m_codec->sample_width();
     fwrite (bytes, 1, n, m_file);
     if (ferror (m_file))
+      return Error ("write sample data failed");
+    return Error::Code::NONE;
+  }
+  bool raw_region (int& fd, uint64_t& byte_offset) override { return output_region (m_file, m_close, fd, byte_offset); }
+  Error
+  raw_region_written (size_t n_frames) override
+  {
+    if (fseeko (m_file, off_t (n_frames * m_format.n_channels * m_codec->sample_width()), SEEK_CUR) != 0)
       return Error ("write sample data failed");
     return Error::Code::NONE;
   }
@@ -540,6 +593,19 @@ public:
       m_frames_left -= got_frames;
     return Error::Code::NONE;
   }
+  bool
+  raw_region (int& fd, uint64_t& byte_offset, size_t& frames_available) override
+  {
+    const size_t frame_bytes = size_t (m_format.n_channels) * m_codec->sample_width();
+    return input_region (m_file, frame_bytes, m_frames_left, fd, byte_offset, frames_available);
+  }
+  void
+  raw_region_consume (size_t n_frames) override
+  {
+    fseeko (m_file, off_t (n_frames * size_t (m_format.n_channels) * m_codec->sample_width()), SEEK_CUR);
+    if (m_frames_left != N_FRAMES_UNKNOWN)
+      m_frames_left -= std::min (m_frames_left, n_frames);
+  }
 };
 
 class WavOutputStream : public AudioOutputStream
@@ -671,6 +737,16 @@ public:
     const size_t n = n_frames * m_n_channels * (m_bit_depth / 8);
     fwrite (bytes, 1, n, m_file);
     if (ferror (m_file))
+      return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
+    m_bytes_written += n;
+    return Error::Code::NONE;
+  }
+  bool raw_region (int& fd, uint64_t& byte_offset) override { return output_region (m_file, m_close, fd, byte_offset); }
+  Error
+  raw_region_written (size_t n_frames) override
+  {
+    const size_t n = n_frames * m_n_channels * (m_bit_depth / 8);
+    if (fseeko (m_file, off_t (n), SEEK_CUR) != 0)
       return Error (string_printf ("write sample data failed (%s)", strerror (errno)));
     m_bytes_written += n;
     return Error::Code::NONE;

@@ -8,6 +8,7 @@
 // libsndfile / mpg123 backed streams are outside the scope of this path:
 // Format::AUTO opens WAV files with the built-in parser.
 #pragma once
+#include <cstdint>
 #include <cstdio>
 #include <memory>
 #include <string>
@@ -65,6 +66,12 @@ public:
   // awm_pcm_decode_d with the same rules as read_frames).  Default: not available.
   virtual bool     raw_access (RawFormat& format) const { (void) format; return false; }
   virtual Error    read_raw (unsigned char *dst, size_t max_frames, size_t& got_frames) { (void) dst; (void) max_frames; got_frames = 0; return Error ("raw access not supported"); }
+  // optional, for streams whose sample bytes lie in a REGULAR file: the descriptor, the file offset of the next unread frame and
+  // how many frames lie behind it (bounded by the file's size).  The caller then reads the bytes itself -- pread, any thread, any
+  // order (host/wmfile.cc: several workers fill a ring of page-locked tiles ahead of the GPU) -- and tells the stream how many
+  // frames it took with raw_region_consume(), after which read_raw / read_frames continue behind them.
+  virtual bool     raw_region (int& fd, uint64_t& byte_offset, size_t& frames_available) { (void) fd; (void) byte_offset; (void) frames_available; return false; }
+  virtual void     raw_region_consume (size_t n_frames) { (void) n_frames; }
 };
 
 class AudioOutputStream : public AudioStream
@@ -78,6 +85,12 @@ public:
   // of the reference's two 16 bit rules this stream's own write_frames applies
   virtual bool  raw_access (RawFormat& format, bool& direct16) const { (void) format; (void) direct16; return false; }
   virtual Error write_raw (const unsigned char *bytes, size_t n_frames) { (void) bytes; (void) n_frames; return Error ("raw access not supported"); }
+  // optional, for streams that write to a REGULAR file of their own: everything written so far is flushed, `byte_offset` is where
+  // the next sample byte belongs.  The caller places the bytes of the following frames there itself (any thread, any order:
+  // host/wmfile.cc copies into a shared mapping from several workers -- buffered write() calls on one file serialise on the
+  // inode) and reports them with raw_region_written(), after which write_raw / write_frames / close() continue behind them.
+  virtual bool  raw_region (int& fd, uint64_t& byte_offset) { (void) fd; (void) byte_offset; return false; }
+  virtual Error raw_region_written (size_t n_frames) { (void) n_frames; return Error ("raw access not supported"); }
 };
 
 // global stream format selection, as in the reference's Params (wmcommon.hh:79-83)

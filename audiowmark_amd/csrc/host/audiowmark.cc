@@ -5,6 +5,7 @@
 // test-gen-noise / test-snr / test-change-speed on raw and WAV data.  The structure is this file's own: every command
 // is described by a table of option specifications (name, kind, action); one generic pass extracts the options a
 // command knows from the argument list, whatever is left must be its positional arguments.
+#include <chrono>
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
@@ -290,11 +291,28 @@ print_usage()
          "or --raw-channels) are the reference's.\n", stdout);
 }
 
+// AWM_TIMING=1: milliseconds since the start of main() on stderr -- at the first HIP call's return (runtime initialisation), when the
+// context exists, and at the end of the command (bench.py's e2e.cli leg: what of the wall time is the HIP runtime's, what is ours)
+static const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+static void
+timing_mark (const char *what)
+{
+  static const bool on = getenv ("AWM_TIMING") != nullptr;
+  if (on)
+    fprintf (stderr, "awm_timing %s %.3f\n", what, std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - g_t0).count());
+}
+
 struct Gpu
 {
   awm_ctx *ctx = nullptr;
   Gpu()
   {
+    timing_mark ("main");
+    {
+      int n = 0;
+      (void) hipGetDeviceCount (&n);              // the first HIP call initialises the runtime (and loads the code object)
+      timing_mark ("hip_runtime_up");
+    }
     // AWM_DEVICE=n: which GPU of the node (default 0); AWM_DEVICES=a,b,...: `get` spreads long files over these GPUs (the file is
     // read through the first one, awm_ctx_set_helpers)
     const char *dev = getenv ("AWM_DEVICE"), *devs = getenv ("AWM_DEVICES");
@@ -326,6 +344,7 @@ struct Gpu
       }
     if (!helpers.empty())
       awm_ctx_set_helpers (ctx, helpers.data(), int (helpers.size()));
+    timing_mark ("context_ready");
   }
   // no destructor: the process ends right after the command (finish() below), which returns everything at once; tearing down the
   // context and the HIP runtime piece by piece costs 70-90 ms -- a third of an `add` of one hour of audio
@@ -335,6 +354,7 @@ struct Gpu
 [[noreturn]] void
 finish (int rc)
 {
+  timing_mark ("command_done");
   fflush (nullptr);
   _exit (rc);
 }

@@ -384,6 +384,7 @@ resample_device (awm_ctx *ctx, const RateConverter& conv, const float *in_d, siz
   ra.step = t.step;
   ra.out = out_d;
   ra.n_out = (long long) n_out;
+  ProfScope ps (ctx, PROF_RESAMPLE, double (n_in + n_out) * n_channels * 4.0);      // every input and output sample once
   AWM_HIP_CHECK (awmk::launch_resample (ctx->stream, ra));
   return 0;
 }
@@ -1059,6 +1060,7 @@ add_batch_keys_device_tables (awm_ctx *ctx, const uint8_t *keys, const std::vect
       ka.scratch_slots = int (GROUP);
       ka.tables = reinterpret_cast<signed char *> (dev);
       ka.n_keys = (long long) gn;
+      ProfScope ps (ctx, PROF_KEYTAB, double (gn) * table_bytes, table_stream);          // the table out, once (360 KB per key)
       AWM_HIP_CHECK (awmk::launch_frame_mod_tables (table_stream, ka));
       AWM_HIP_CHECK (hipEventRecord (ev_tab[half], table_stream));
       for (int i = 0; i < n_lanes; i++)

@@ -1,5 +1,7 @@
 #include "context.hh"
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdlib>
 #include "utils.hh"
 #include <cmath>
@@ -11,6 +13,20 @@ static thread_local std::string g_last_error;
 void set_error (const std::string& msg) { g_last_error = msg; }
 const std::string& last_error() { return g_last_error; }
 std::string hip_error_string (hipError_t e) { return std::string (hipGetErrorName (e)) + " (" + hipGetErrorString (e) + ")"; }
+
+// allocation census (awm_debug_alloc_stats): how many device / page-locked allocations the calls of this process made and how long
+// the runtime took for them -- what a FIRST call pays before its workspaces exist
+static std::atomic<long>   g_dev_allocs { 0 }, g_pin_allocs { 0 };
+static std::atomic<double> g_dev_alloc_ms { 0.0 }, g_pin_alloc_ms { 0.0 };
+static void
+note_alloc (std::atomic<long>& count, std::atomic<double>& ms, std::chrono::steady_clock::time_point t0)
+{
+  const double dt = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count();
+  count.fetch_add (1, std::memory_order_relaxed);
+  double cur = ms.load (std::memory_order_relaxed);
+  while (!ms.compare_exchange_weak (cur, cur + dt, std::memory_order_relaxed))
+    ;
+}
 
 int
 DevBuffer::reserve (size_t want)
@@ -28,7 +44,9 @@ DevBuffer::reserve (size_t want)
   while (cap < want)
     cap += cap / 2 > (size_t (1) << 30) ? (size_t (1) << 30) : cap / 2 + 1;
   cap = (cap + 255) & ~size_t (255);
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipMalloc (&ptr, cap);
+  note_alloc (g_dev_allocs, g_dev_alloc_ms, t0);
   if (e != hipSuccess)
     {
       ptr = nullptr;
@@ -48,7 +66,9 @@ PinnedBuffer::reserve (size_t want)
   size_t cap = size_t (64) << 10;
   while (cap < want)
     cap *= 2;
+  const auto t0 = std::chrono::steady_clock::now();
   hipError_t e = hipHostMalloc (&ptr, cap, hipHostMallocDefault);
+  note_alloc (g_pin_allocs, g_pin_alloc_ms, t0);
   if (e != hipSuccess)
     {
       ptr = nullptr;
@@ -79,6 +99,15 @@ DevBuffer::release()
 
 } // namespace awm
 
+extern "C" void
+awm_debug_alloc_stats (long *dev_allocs, double *dev_ms, long *pinned_allocs, double *pinned_ms)
+{
+  if (dev_allocs) *dev_allocs = awm::g_dev_allocs.load();
+  if (dev_ms) *dev_ms = awm::g_dev_alloc_ms.load();
+  if (pinned_allocs) *pinned_allocs = awm::g_pin_allocs.load();
+  if (pinned_ms) *pinned_ms = awm::g_pin_alloc_ms.load();
+}
+
 void
 awm::WorkLane::release_lane()
 {
@@ -104,10 +133,11 @@ awm::WorkLane::viterbi_sync (size_t n_decodes)
 {
   // The one-launch Viterbi kernel leaves its counters at zero (hip/viterbi.hip), so the block is cleared only when it is (re)allocated
   // -- on the lane's own stream, in front of the launch that uses it first.
-  const void *before = ws_viterbi_sync.ptr;
+  // (growth is detected by CAPACITY: a freed block may come back from hipMalloc at the same address, larger)
+  const size_t before = ws_viterbi_sync.bytes;
   if (ws_viterbi_sync.reserve (awmk::viterbi_sync_bytes ((long long) n_decodes)))
     return nullptr;
-  if (ws_viterbi_sync.ptr != before && hipMemsetAsync (ws_viterbi_sync.ptr, 0, ws_viterbi_sync.bytes, stream) != hipSuccess)
+  if (ws_viterbi_sync.bytes != before && hipMemsetAsync (ws_viterbi_sync.ptr, 0, ws_viterbi_sync.bytes, stream) != hipSuccess)
     {
       ws_viterbi_sync.release();
       return nullptr;
@@ -457,7 +487,8 @@ awm_ctx::prof_collect()
 static const char *prof_names[awm::PROF_COUNT] = {
   "add_mix_kernel", "limiter_kernel", "sync_db_kernel(approx)", "sync_scan_kernel(approx)", "local_mean_kernel",
   "sync_db_kernel(refine)", "sync_scan_kernel(refine)", "sync_db_kernel(block)", "soft_bits_kernel", "viterbi_kernel",
-  "stft_full_kernel"
+  "stft_full_kernel",
+  "resample_kernel", "resample_var_kernel", "speed_mags_kernel", "speed_compare_kernel", "frame_mod_table_kernel"
 };
 
 extern "C" {
@@ -539,6 +570,18 @@ ctx_create (int device, bool own_stream, hipStream_t given, awm_ctx **ctx_out)
       return AWM_ERR_ARG;
     }
   AWM_HIP_CHECK (hipSetDevice (device));
+  {
+    // the code object holds gfx950 code only, and several kernels need its 160 KB of LDS per workgroup: say so here instead of
+    // failing at the first launch
+    hipDeviceProp_t prop;
+    AWM_HIP_CHECK (hipGetDeviceProperties (&prop, device));
+    if (std::strncmp (prop.gcnArchName, "gfx950", 6) != 0 || prop.sharedMemPerBlock < size_t (160) * 1024)
+      {
+        set_error (std::string ("device ") + std::to_string (device) + " is " + prop.gcnArchName + " with " + std::to_string (prop.sharedMemPerBlock)
+                   + " bytes of LDS per workgroup; this library is built for gfx950 (MI355X, 160 KB) only");
+        return AWM_ERR_NO_DEVICE;
+      }
+  }
   auto ctx = std::make_unique<awm_ctx>();
   ctx->device = device;
   if (own_stream)
@@ -592,7 +635,12 @@ ctx_create (int device, bool own_stream, hipStream_t given, awm_ctx **ctx_out)
   ctx->tabs.tw1024 = reinterpret_cast<const float2 *> (base + off_tw1024);
   ctx->tabs.window = base + off_win;
   ctx->tabs.synth = base + off_synth;
-  (void) awmk::probe_dependent_launch_us (ctx->stream);   // (also waits for the uploads above; ~0.5 ms)
+  // (also waits for the uploads above; ~0.5 ms for the first context of the process, which latches the result)
+  if (awmk::probe_dependent_launch_us (ctx->stream) < 0 && hipStreamSynchronize (ctx->stream) != hipSuccess)
+    {
+      set_error ("awm_ctx_create: the device does not complete work on the context's stream");
+      return AWM_ERR_HIP;
+    }
   *ctx_out = ctx.release();
   return 0;
 }

@@ -159,7 +159,8 @@ struct FrameModTable
 namespace awm {
 // per-kernel timing with HIP events on the context's stream (awm_prof_* in awm_hip.h)
 enum ProfId { PROF_ADD_MIX, PROF_LIMITER, PROF_SYNC_DB, PROF_SYNC_SCAN, PROF_LOCAL_MEAN, PROF_REFINE_DB, PROF_REFINE_SCAN,
-              PROF_BLOCK_DB, PROF_SOFT_BITS, PROF_VITERBI, PROF_STFT, PROF_COUNT };
+              PROF_BLOCK_DB, PROF_SOFT_BITS, PROF_VITERBI, PROF_STFT,
+              PROF_RESAMPLE, PROF_RESAMPLE_VAR, PROF_SPEED_MAGS, PROF_SPEED_COMPARE, PROF_KEYTAB, PROF_COUNT };
 struct ProfPending { int id; hipEvent_t start, stop; };
 }
 

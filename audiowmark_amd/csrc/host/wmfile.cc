@@ -3,11 +3,20 @@
 #include "wmget.hh"
 #include "utils.hh"
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <cmath>
 #include <condition_variable>
+#include <cstring>
 #include <deque>
+#include <functional>
 #include <mutex>
 #include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/statvfs.h>
+#include <unistd.h>
 
 namespace awm {
 
@@ -21,10 +30,104 @@ static int fail (int kind) { tl_fail_kind = kind; return 1; }
 
 namespace {
 
-/* File <-> HBM staging with BOUNDED host memory: the stream crosses PCIe chunk by chunk through two page-locked
- * buffers (the read of chunk k + 1 overlaps the copy of chunk k), in its own sample format where the stream can hand
- * out its bytes (raw / WAV): conversion is RawConverter's arithmetic on the device (awm_pcm_decode_d / awm_pcm_encode_d). */
-constexpr size_t STAGE_FRAMES = size_t (1) << 22;       // frames per staging chunk (16 MiB of 16 bit stereo)
+/* File <-> HBM staging with BOUNDED host memory: the stream crosses PCIe tile by tile through small rings of page-locked buffers,
+ * in its own sample format where the stream can hand out its bytes (raw / WAV): conversion is RawConverter's arithmetic on the
+ * device (awm_pcm_decode_d / awm_pcm_encode_d).
+ *
+ * The HOST side of that is memory copies between the page cache and the rings, and one thread moves ~5 - 10 GB/s -- an hour of
+ * 16 bit stereo is 635 MB each way, a few milliseconds of GPU work.  So the copies run on a pool of workers:
+ *   input   regular files (AudioInputStream::raw_region): the tiles are read AHEAD of the consumer, every tile split over the
+ *           workers (pread); pipes and streams without byte access: one reader thread, still ahead of the consumer;
+ *   output  regular files (AudioOutputStream::raw_region): the file is grown with ftruncate and the workers copy into a shared
+ *           mapping of the tile's range -- page faults of different ranges allocate in parallel, while buffered write() calls on one
+ *           file serialise on its inode lock (pwrite from N threads is as fast as one thread; measured, tools/io_probe.cc);
+ *           pipes / stdout / streams without byte access: one writer thread in stream order.                                        */
+constexpr size_t STAGE_FRAMES = size_t (1) << 22;       // frames per staging tile of the whole-stream loaders (16 MiB of 16 bit stereo)
+constexpr int    IN_RING = 4, OUT_RING = 4;             // page-locked tiles per direction
+constexpr size_t IO_PART_MIN = size_t (1) << 20;        // a worker's share of a tile is at least this many bytes
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23                          // (Linux 5.14; older headers)
+#endif
+enum { IO_REGIONS = 1, IO_MAP_OUTPUT = 2, IO_POPULATE = 4 };
+static std::atomic<int> g_io_threads { 0 };             // 0: default
+static std::atomic<int> g_io_flags { IO_REGIONS | IO_MAP_OUTPUT | IO_POPULATE };
+int
+io_threads()
+{
+  const int n = g_io_threads.load (std::memory_order_relaxed);
+  if (n > 0)
+    return std::min (n, 64);
+  const unsigned hw = std::thread::hardware_concurrency();
+  return int (std::max (2u, std::min (8u, hw ? hw : 4u)));
+}
+
+/* worker threads for the host side copies; one pool per process, started at the first file level call and resized when the setting
+ * changes between calls */
+class IoPool
+{
+  std::vector<std::thread> m_threads;
+  std::mutex               m_mutex;
+  std::condition_variable  m_cond;
+  std::deque<std::function<void()>> m_jobs;
+  bool                     m_quit = false;
+  void
+  run()
+  {
+    for (;;)
+      {
+        std::function<void()> job;
+        {
+          std::unique_lock<std::mutex> lock (m_mutex);
+          m_cond.wait (lock, [&] { return m_quit || !m_jobs.empty(); });
+          if (m_jobs.empty())
+            return;
+          job = std::move (m_jobs.front());
+          m_jobs.pop_front();
+        }
+        job();
+      }
+  }
+  void
+  stop()
+  {
+    {
+      std::lock_guard<std::mutex> lock (m_mutex);
+      m_quit = true;
+      m_cond.notify_all();
+    }
+    for (auto& t : m_threads)
+      if (t.joinable())
+        t.join();
+    m_threads.clear();
+    m_quit = false;
+  }
+public:
+  ~IoPool() { stop(); }
+  static IoPool&
+  get()
+  {
+    static IoPool pool;
+    static std::mutex create_mutex;
+    std::lock_guard<std::mutex> lock (create_mutex);
+    const size_t want = size_t (io_threads());
+    if (pool.m_threads.size() != want)
+      {
+        pool.stop();                                       // (queued jobs are finished first: workers leave only on an empty queue)
+        for (size_t i = 0; i < want; i++)
+          pool.m_threads.emplace_back ([p = &pool] { p->run(); });
+      }
+    return pool;
+  }
+  size_t size() const { return m_threads.size(); }
+  void
+  submit (std::function<void()> job)
+  {
+    std::lock_guard<std::mutex> lock (m_mutex);
+    m_jobs.push_back (std::move (job));
+    m_cond.notify_one();
+  }
+};
 
 bool
 device_codec_supported (const RawFormat& f)
@@ -69,40 +172,257 @@ read_chunk (AudioInputStream *in, bool raw, size_t unit_bytes, unsigned char *ds
   return Error::Code::NONE;
 }
 
-/* One copy stream per context serves both directions: every additional HIP stream costs ~190 MB of resident host memory
- * on this runtime (tools/rss_probe), and a staging chunk crosses PCIe in well under a millisecond -- far less than the file
- * I/O it overlaps with. */
-struct Staging
+/* Input tiles, read AHEAD of the consumer into a ring of page-locked buffers.
+ *   next()     hands out tile 0, 1, 2, ... in order (blocks until it is in memory); frames < tile_frames: the stream ends there
+ *   recycle()  the consumer has queued its last use of the slot (an H2D copy) and recorded `done` behind it: the slot is refilled
+ *              with the tile IN_RING further on as soon as `done` has happened
+ * One copy stream per context serves both directions: every additional HIP stream costs ~190 MB of resident host memory
+ * on this runtime (tools/rss_probe), and a tile crosses PCIe in well under a millisecond. */
+class TileReader
 {
-  hipStream_t copy = nullptr;
-  hipEvent_t  ev_copied[2] = { nullptr, nullptr }, ev_used[2] = { nullptr, nullptr };
-  PinnedBuffer host[2];
-  DevBuffer    dev[2];
+  struct Slot
+  {
+    PinnedBuffer host;
+    DevBuffer    dev;                        // raw formats: the tile's bytes on the device, in front of the sample decode
+    hipEvent_t   ev_copied = nullptr, ev_used = nullptr;
+    // state of the tile the slot currently holds (guarded by m_mutex)
+    long long    tile = -1;                  // which tile has been scheduled into the slot
+    int          parts_left = 0;
+    std::vector<size_t> part_got;            // bytes per part (region mode: a short part = the file ends inside it)
+    bool         failed = false;
+    int          err_no = 0;
+    size_t       frames = 0;                 // sequential mode: frames read
+    Error        error = Error::Code::NONE;
+  };
+  awm_ctx          *m_ctx;
+  AudioInputStream *m_in;
+  bool              m_raw;
+  size_t            m_unit, m_tile_frames;
+  Slot              m_slots[IN_RING];
+  std::mutex              m_mutex;
+  std::condition_variable m_cond;
+  long long         m_next = 0;              // next tile next() hands out
+  bool              m_ended = false;         // a short tile has been handed out
+  // region mode
+  bool              m_region = false;
+  int               m_fd = -1;
+  uint64_t          m_offset = 0;
+  size_t            m_total_frames = 0, m_consumed = 0;
+  long long         m_n_tiles = 0;
+  // sequential mode (pipes, streams without byte access): one reader thread
+  std::thread       m_thread;
+  std::deque<std::pair<int, hipEvent_t>> m_free;      // slots the reader may fill, with the event to wait for first (nullptr: none)
+  bool              m_quit = false;
+
+  void
+  schedule_region (int slot, long long tile, hipEvent_t after)
+  {
+    Slot& s = m_slots[slot];
+    const size_t first = size_t (tile) * m_tile_frames;
+    const size_t frames = std::min (m_tile_frames, m_total_frames - first);
+    const size_t bytes = frames * m_unit;
+    IoPool& pool = IoPool::get();
+    const size_t n_parts = std::max<size_t> (1, std::min (pool.size(), bytes / IO_PART_MIN));
+    const size_t part = ((bytes + n_parts - 1) / n_parts + 4095) & ~size_t (4095);
+    {
+      std::lock_guard<std::mutex> lock (m_mutex);
+      s.tile = tile;
+      s.parts_left = int (n_parts);
+      s.part_got.assign (n_parts, 0);
+      s.failed = false;
+    }
+    const int device = m_ctx->device;
+    auto read_part = [this, &s, part, bytes, first] (size_t i) {
+      const size_t lo = std::min (bytes, part * i), hi = std::min (bytes, part * (i + 1));
+      unsigned char *dst = s.host.as<unsigned char>() + lo;
+      size_t n = 0;
+      bool bad = false;
+      int err = 0;
+      while (lo + n < hi)
+        {
+          const ssize_t r = pread (m_fd, dst + n, hi - lo - n, off_t (m_offset + first * m_unit + lo + n));
+          if (r < 0 && errno == EINTR)
+            continue;
+          if (r <= 0)
+            {
+              bad = r < 0;
+              err = r < 0 ? errno : 0;
+              break;
+            }
+          n += size_t (r);
+        }
+      std::lock_guard<std::mutex> lock (m_mutex);
+      s.part_got[i] = n;
+      if (bad && !s.failed)
+        {
+          s.failed = true;
+          s.err_no = err;
+        }
+      if (--s.parts_left == 0)
+        m_cond.notify_all();
+    };
+    // the first job waits for the slot's previous contents to have crossed PCIe, then fans the parts out
+    pool.submit ([=, &pool] {
+      if (after)
+        {
+          (void) hipSetDevice (device);
+          (void) hipEventSynchronize (after);
+        }
+      for (size_t i = 1; i < n_parts; i++)
+        pool.submit ([=] { read_part (i); });
+      read_part (0);
+    });
+  }
+  void
+  run_sequential()
+  {
+    (void) hipSetDevice (m_ctx->device);
+    for (long long tile = 0; ; tile++)
+      {
+        std::pair<int, hipEvent_t> f;
+        {
+          std::unique_lock<std::mutex> lock (m_mutex);
+          m_cond.wait (lock, [&] { return m_quit || !m_free.empty(); });
+          if (m_quit)
+            return;
+          f = m_free.front();
+          m_free.pop_front();
+        }
+        if (f.second)
+          (void) hipEventSynchronize (f.second);
+        Slot& s = m_slots[f.first];
+        size_t got = 0;
+        Error err = read_chunk (m_in, m_raw, m_unit, s.host.as<unsigned char>(), m_tile_frames, got);
+        std::lock_guard<std::mutex> lock (m_mutex);
+        s.tile = tile;
+        s.frames = got;
+        s.error = err;
+        s.parts_left = 0;
+        m_cond.notify_all();
+        if (err || got < m_tile_frames)
+          return;
+      }
+  }
+public:
   bool ok = false;
-  Staging (awm_ctx *ctx, size_t bytes, bool need_dev)
+  hipStream_t copy = nullptr;
+  TileReader (awm_ctx *ctx, AudioInputStream *in, bool raw, size_t unit_bytes, size_t tile_frames, bool need_dev)
+    : m_ctx (ctx), m_in (in), m_raw (raw), m_unit (unit_bytes), m_tile_frames (tile_frames)
   {
     copy = ctx->get_copy_stream();
     ok = copy != nullptr;
-    for (int i = 0; i < 2 && ok; i++)
-      ok = hipEventCreateWithFlags (&ev_copied[i], hipEventDisableTiming) == hipSuccess
-        && hipEventCreateWithFlags (&ev_used[i], hipEventDisableTiming) == hipSuccess
-        && host[i].reserve (bytes) == 0 && (!need_dev || dev[i].reserve (bytes) == 0);
+    for (int i = 0; i < IN_RING && ok; i++)
+      ok = hipEventCreateWithFlags (&m_slots[i].ev_copied, hipEventDisableTiming) == hipSuccess
+        && hipEventCreateWithFlags (&m_slots[i].ev_used, hipEventDisableTiming) == hipSuccess
+        && m_slots[i].host.reserve (tile_frames * unit_bytes) == 0 && (!need_dev || m_slots[i].dev.reserve (tile_frames * unit_bytes) == 0);
+    if (!ok)
+      return;
+    m_region = raw && (g_io_flags.load (std::memory_order_relaxed) & IO_REGIONS) != 0 && in->raw_region (m_fd, m_offset, m_total_frames);
+    if (m_region)
+      {
+        m_n_tiles = (long long) ((m_total_frames + tile_frames - 1) / tile_frames);
+        for (int i = 0; i < IN_RING && i < m_n_tiles; i++)
+          schedule_region (i, i, nullptr);
+      }
+    else
+      {
+        for (int i = 0; i < IN_RING; i++)
+          m_free.emplace_back (i, nullptr);
+        for (auto& s : m_slots)
+          s.parts_left = 1;                  // "not there yet"
+        m_thread = std::thread ([this] { run_sequential(); });
+      }
   }
-  ~Staging()
+  ~TileReader()
   {
+    {
+      std::unique_lock<std::mutex> lock (m_mutex);
+      m_quit = true;
+      m_cond.notify_all();
+      if (m_region)                          // reads in flight still write into the ring
+        m_cond.wait (lock, [&] { for (auto& s : m_slots) if (s.tile >= 0 && s.parts_left) return false; return true; });
+    }
+    if (m_thread.joinable())
+      m_thread.join();
+    if (m_region && m_consumed)
+      m_in->raw_region_consume (m_consumed);
     if (copy)
       (void) hipStreamSynchronize (copy);
-    for (int i = 0; i < 2; i++)
+    for (auto& s : m_slots)
       {
-        if (ev_copied[i]) (void) hipEventDestroy (ev_copied[i]);
-        if (ev_used[i]) (void) hipEventDestroy (ev_used[i]);
-        host[i].release();
-        dev[i].release();
+        if (s.ev_copied) (void) hipEventDestroy (s.ev_copied);
+        if (s.ev_used) (void) hipEventDestroy (s.ev_used);
+        s.host.release();
+        s.dev.release();
+      }
+  }
+  size_t announced_frames() const { return m_region ? m_total_frames : m_in->n_frames(); }
+  unsigned char *host (int slot) { return m_slots[slot].host.as<unsigned char>(); }
+  void          *dev (int slot) { return m_slots[slot].dev.ptr; }
+  hipEvent_t     ev_copied (int slot) { return m_slots[slot].ev_copied; }
+  hipEvent_t     ev_used (int slot) { return m_slots[slot].ev_used; }
+  /* the next tile: its slot and its frames (0 at / after the end of the stream) */
+  Error
+  next (int& slot, size_t& frames)
+  {
+    frames = 0;
+    slot = int (m_next % IN_RING);
+    if (m_ended || (m_region && m_next >= m_n_tiles))
+      return Error::Code::NONE;
+    Slot& s = m_slots[slot];
+    std::unique_lock<std::mutex> lock (m_mutex);
+    m_cond.wait (lock, [&] { return s.tile == m_next && s.parts_left == 0; });
+    if (m_region)
+      {
+        if (s.failed)
+          return Error (string_printf ("error reading sample data: %s", strerror (s.err_no)));
+        const size_t first = size_t (m_next) * m_tile_frames;
+        const size_t want = std::min (m_tile_frames, m_total_frames - first) * m_unit;
+        const size_t n_parts = s.part_got.size();
+        const size_t part = ((want + n_parts - 1) / n_parts + 4095) & ~size_t (4095);
+        size_t bytes = 0;
+        for (size_t i = 0; i < n_parts; i++)
+          {
+            bytes += s.part_got[i];
+            if (s.part_got[i] < std::min (want, part * (i + 1)) - std::min (want, part * i))
+              break;                                             // the file ends inside this part: later parts lie beyond it
+          }
+        frames = bytes / m_unit;
+        m_consumed += frames;
+      }
+    else
+      {
+        if (s.error)
+          return s.error;
+        frames = s.frames;
+      }
+    if (frames < m_tile_frames)
+      m_ended = true;
+    m_next++;
+    return Error::Code::NONE;
+  }
+  void
+  recycle (int slot, hipEvent_t done)
+  {
+    if (m_ended)
+      return;
+    if (m_region)
+      {
+        const long long tile = m_slots[slot].tile + IN_RING;
+        if (tile < m_n_tiles)
+          schedule_region (slot, tile, done);
+      }
+    else
+      {
+        std::lock_guard<std::mutex> lock (m_mutex);
+        m_slots[slot].parts_left = 1;
+        m_free.emplace_back (slot, done);
+        m_cond.notify_all();
       }
   }
 };
 
-/* Whole stream -> float32 PCM in HBM (288 GB hold days of audio; what is bounded is the HOST side: two staging chunks). */
+/* Whole stream -> float32 PCM in HBM (288 GB hold days of audio; what is bounded is the HOST side: the ring of staging tiles). */
 Error
 load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_pcm, size_t& n_values)
 {
@@ -111,13 +431,13 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
   RawFormat fmt;
   const bool raw = in_stream->raw_access (fmt) && device_codec_supported (fmt);
   const size_t unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
-  Staging st (ctx, STAGE_FRAMES * unit, raw);
-  if (!st.ok)
+  TileReader rd (ctx, in_stream, raw, unit, STAGE_FRAMES, raw);
+  if (!rd.ok)
     return Error ("out of memory for input staging");
   // The announced length only sizes the first allocation (the loop below grows the buffer when more arrives).  A length whose
   // float32 size would not fit a device buffer -- a crafted ds64 / RIFF size on a pipe, where it cannot be checked against the
   // file -- is treated like an unknown one: cap_frames * C * 4 must never wrap.
-  const size_t announced = in_stream->n_frames();
+  const size_t announced = rd.announced_frames();
   const size_t max_frames = DevBuffer::MAX_BYTES / (size_t (C) * sizeof (float));
   size_t cap_frames = (announced != AudioInputStream::N_FRAMES_UNKNOWN && announced < max_frames) ? announced + 1 : STAGE_FRAMES * 4;
   if (d_pcm.reserve (cap_frames * C * sizeof (float)))
@@ -125,11 +445,9 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
   size_t frames = 0;
   for (size_t k = 0; ; k++)
     {
-      const int b = int (k & 1);
-      if (k >= 2 && hipEventSynchronize (st.ev_copied[b]) != hipSuccess)      // the copy out of this host buffer is done
-        return Error ("GPU transfer failed");
+      int b = 0;
       size_t got = 0;
-      Error err = read_chunk (in_stream, raw, unit, st.host[b].as<unsigned char>(), STAGE_FRAMES, got);
+      Error err = rd.next (b, got);
       if (err)
         return err;
       if (!got)
@@ -141,7 +459,7 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
           cap_frames = std::max (cap_frames * 2, frames + got);
           if (cap_frames >= max_frames)
             return Error ("input stream is too long for device memory");
-          if (hipStreamSynchronize (st.copy) != hipSuccess || hipStreamSynchronize (ctx->stream) != hipSuccess
+          if (hipStreamSynchronize (rd.copy) != hipSuccess || hipStreamSynchronize (ctx->stream) != hipSuccess
               || bigger.reserve (cap_frames * C * sizeof (float))
               || hipMemcpy (bigger.ptr, d_pcm.ptr, frames * C * sizeof (float), hipMemcpyDeviceToDevice) != hipSuccess)
             return Error ("out of device memory while loading the stream");
@@ -152,42 +470,65 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
       bool ok;
       if (raw)
         {
-          ok = (k < 2 || hipStreamWaitEvent (st.copy, st.ev_used[b], 0) == hipSuccess)          // the decode of chunk k - 2 has read dev[b]
-            && hipMemcpyAsync (st.dev[b].ptr, st.host[b].ptr, got * unit, hipMemcpyHostToDevice, st.copy) == hipSuccess
-            && hipEventRecord (st.ev_copied[b], st.copy) == hipSuccess
-            && hipStreamWaitEvent (ctx->stream, st.ev_copied[b], 0) == hipSuccess
-            && awm_pcm_decode_d (ctx, st.dev[b].ptr, got * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, dst) == 0
-            && hipEventRecord (st.ev_used[b], ctx->stream) == hipSuccess;
+          // (dev[b] was last read by the decode of the tile IN_RING earlier: the copy stream waits for that decode)
+          ok = (k < size_t (IN_RING) || hipStreamWaitEvent (rd.copy, rd.ev_used (b), 0) == hipSuccess)
+            && hipMemcpyAsync (rd.dev (b), rd.host (b), got * unit, hipMemcpyHostToDevice, rd.copy) == hipSuccess
+            && hipEventRecord (rd.ev_copied (b), rd.copy) == hipSuccess
+            && hipStreamWaitEvent (ctx->stream, rd.ev_copied (b), 0) == hipSuccess
+            && awm_pcm_decode_d (ctx, rd.dev (b), got * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, dst) == 0
+            && hipEventRecord (rd.ev_used (b), ctx->stream) == hipSuccess;
         }
       else
-        ok = hipMemcpyAsync (dst, st.host[b].ptr, got * unit, hipMemcpyHostToDevice, st.copy) == hipSuccess
-          && hipEventRecord (st.ev_copied[b], st.copy) == hipSuccess;
+        ok = hipMemcpyAsync (dst, rd.host (b), got * unit, hipMemcpyHostToDevice, rd.copy) == hipSuccess
+          && hipEventRecord (rd.ev_copied (b), rd.copy) == hipSuccess;
       if (!ok)
         return Error (std::string ("GPU staging failed: ") + awm_last_error());
+      rd.recycle (b, rd.ev_copied (b));
       frames += got;
+      if (got < STAGE_FRAMES)
+        break;
     }
-  if (hipStreamSynchronize (st.copy) != hipSuccess || hipStreamSynchronize (ctx->stream) != hipSuccess)
+  if (hipStreamSynchronize (rd.copy) != hipSuccess || hipStreamSynchronize (ctx->stream) != hipSuccess)
     return Error ("GPU transfer failed");
   n_values = frames * C;
   return Error::Code::NONE;
 }
 
-/* Completed output chunks are written by a second host thread, so that file writes overlap file reads and GPU work. */
+/* Completed output tiles leave the ring on other host threads, so that file writes overlap file reads and GPU work.
+ *   wait_slot (b)   until the bytes of slot b have been written (the buffer may be reused)
+ *   submit (...)    the D2H copy of slot b has been queued and `ready` recorded behind it
+ * Streams in order (pipes, stdout, float samples through write_frames): one writer thread.  Regular files: the workers of the pool
+ * copy into a shared mapping of the tile's byte range (see the head of this file). */
 class ChunkWriter
 {
   struct Job { const unsigned char *bytes; size_t frames; hipEvent_t ready; int slot; bool raw; };
   AudioOutputStream *m_out;
-  int                m_channels;
+  int                m_channels, m_device;
   std::thread        m_thread;
   std::mutex         m_mutex;
   std::condition_variable m_cond;
   std::deque<Job>    m_jobs;
-  std::vector<char>  m_busy;          // per slot: handed to the writer and not yet written
-  bool               m_quit = false;
+  std::vector<int>   m_busy;          // per slot: handed to the writer(s) and not yet written
+  std::vector<int>   m_parts;         // region mode, per slot: parts of the tile still being copied
+  bool               m_quit = false, m_finished = false;
   Error              m_error = Error::Code::NONE;
+  // region mode
+  bool               m_region = false;
+  int                m_fd = -1;
+  uint64_t           m_offset = 0;     // file offset of the next tile's first byte
+  uint64_t           m_file_size = 0;  // what the file has been grown to
+  size_t             m_unit = 0, m_frames_placed = 0;
+  bool               m_use_map = true;
+  void
+  note_error (const Error& err)
+  {
+    if (err && !m_error)
+      m_error = err;
+  }
   void
   run()
   {
+    (void) hipSetDevice (m_device);
     for (;;)
       {
         Job job;
@@ -210,16 +551,123 @@ class ChunkWriter
             err = m_out->write_frames (std::vector<float> (f, f + job.frames * m_channels));
           }
         std::lock_guard<std::mutex> lock (m_mutex);
-        if (err && !m_error)
-          m_error = err;
+        note_error (err);
         m_busy[job.slot] = 0;
         m_cond.notify_all();
       }
   }
-public:
-  ChunkWriter (AudioOutputStream *out, int n_slots) : m_out (out), m_channels (out->n_channels()), m_busy (n_slots, 0)
+  /* bytes [lo, hi) of a tile that starts at file offset `at`, through the mapping `map` (of the page containing `at` onwards) or pwrite */
+  static Error
+  place (int fd, unsigned char *map, size_t map_delta, uint64_t at, const unsigned char *src, size_t lo, size_t hi, bool populate)
   {
-    m_thread = std::thread ([this] { run(); });
+    if (map)
+      {
+        // (one call instead of a trap per page; not available on every kernel / file system: ignored then)
+        const size_t a = (map_delta + lo) & ~size_t (4095);
+        if (populate)
+          (void) madvise (map + a, map_delta + hi - a, MADV_POPULATE_WRITE);
+        std::memcpy (map + map_delta + lo, src + lo, hi - lo);
+        return Error::Code::NONE;
+      }
+    size_t n = lo;
+    while (n < hi)
+      {
+        const ssize_t r = pwrite (fd, src + n, hi - n, off_t (at + n));
+        if (r < 0 && errno == EINTR)
+          continue;
+        if (r <= 0)
+          return Error (string_printf ("write sample data failed (%s)", strerror (r < 0 ? errno : ENOSPC)));
+        n += size_t (r);
+      }
+    return Error::Code::NONE;
+  }
+  void
+  submit_region (const unsigned char *bytes, size_t frames, hipEvent_t ready, int slot)
+  {
+    const size_t n = frames * m_unit;
+    const uint64_t at = m_offset;
+    m_offset += n;
+    m_frames_placed += frames;
+    IoPool& pool = IoPool::get();
+    const size_t n_parts = std::max<size_t> (1, std::min (pool.size(), n / IO_PART_MIN));
+    const size_t part = ((n + n_parts - 1) / n_parts + 4095) & ~size_t (4095);
+    // grow the file over the tile, then map the tile's range (from the start of the page it begins in).  A mapping of a sparse
+    // range cannot report "no space left" -- it raises SIGBUS -- so the mapping is used only while the file system has room for
+    // the tile with a margin; otherwise (and where mmap is refused) the parts go through pwrite, which reports errors.
+    unsigned char *map = nullptr;
+    size_t map_delta = 0, map_len = 0;
+    bool grown = true;
+    if (at + n > m_file_size)
+      {
+        grown = ftruncate (m_fd, off_t (at + n)) == 0;
+        if (grown)
+          m_file_size = at + n;
+      }
+    if (grown && m_use_map)
+      {
+        struct statvfs vfs;
+        const bool room = fstatvfs (m_fd, &vfs) == 0 && uint64_t (vfs.f_bavail) * vfs.f_frsize > uint64_t (n) * 2 + (uint64_t (64) << 20);
+        if (room)
+          {
+            map_delta = size_t (at & 4095);
+            map_len = n + map_delta;
+            void *m = mmap (nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, m_fd, off_t (at - map_delta));
+            if (m != MAP_FAILED)
+              map = static_cast<unsigned char *> (m);
+            else
+              m_use_map = false;
+          }
+      }
+    {
+      std::lock_guard<std::mutex> lock (m_mutex);
+      m_busy[slot] = 1;
+      m_parts[slot] = int (n_parts);
+    }
+    const int device = m_device, fd = m_fd;
+    const bool populate = (g_io_flags.load (std::memory_order_relaxed) & IO_POPULATE) != 0;
+    auto write_part = [=] (size_t i) {
+      const size_t lo = std::min (n, part * i), hi = std::min (n, part * (i + 1));
+      Error err = hi > lo ? place (fd, map, map_delta, at, bytes, lo, hi, populate) : Error (Error::Code::NONE);
+      bool last;
+      {
+        std::lock_guard<std::mutex> lock (m_mutex);
+        note_error (err);
+        last = --m_parts[slot] == 0;
+      }
+      if (last)
+        {
+          if (map)
+            (void) munmap (map, map_len);               // (before the slot is given back: bounds the mapped memory to the ring)
+          std::lock_guard<std::mutex> lock (m_mutex);
+          m_busy[slot] = 0;
+          m_cond.notify_all();
+        }
+    };
+    pool.submit ([=, &pool] {
+      (void) hipSetDevice (device);
+      if (hipEventSynchronize (ready) != hipSuccess)
+        {
+          std::lock_guard<std::mutex> lock (m_mutex);
+          note_error (Error ("GPU transfer failed"));
+        }
+      for (size_t i = 1; i < n_parts; i++)
+        pool.submit ([=] { write_part (i); });
+      write_part (0);
+    });
+  }
+public:
+  ChunkWriter (AudioOutputStream *out, int n_slots, int device, bool raw, size_t unit_bytes)
+    : m_out (out), m_channels (out->n_channels()), m_device (device), m_busy (n_slots, 0), m_parts (n_slots, 0), m_unit (unit_bytes)
+  {
+    m_use_map = (g_io_flags.load (std::memory_order_relaxed) & IO_MAP_OUTPUT) != 0;
+    m_region = raw && (g_io_flags.load (std::memory_order_relaxed) & IO_REGIONS) != 0 && out->raw_region (m_fd, m_offset);
+    if (m_region)
+      {
+        struct stat st;
+        m_file_size = fstat (m_fd, &st) == 0 ? uint64_t (st.st_size) : 0;
+      }
+    else
+      m_thread = std::thread ([this] { run(); });
   }
   ~ChunkWriter() { finish(); }
   void
@@ -231,6 +679,11 @@ public:
   void
   submit (const unsigned char *bytes, size_t frames, hipEvent_t ready, int slot, bool raw)
   {
+    if (m_region)
+      {
+        submit_region (bytes, frames, ready, slot);
+        return;
+      }
     std::lock_guard<std::mutex> lock (m_mutex);
     m_busy[slot] = 1;
     m_jobs.push_back ({ bytes, frames, ready, slot, raw });
@@ -239,6 +692,19 @@ public:
   Error
   finish()
   {
+    if (m_finished)
+      return m_error;
+    m_finished = true;
+    if (m_region)
+      {
+        {
+          std::unique_lock<std::mutex> lock (m_mutex);
+          m_cond.wait (lock, [&] { for (int b : m_busy) if (b) return false; return true; });
+        }
+        Error err = m_out->raw_region_written (m_frames_placed);
+        note_error (err);
+        return m_error;
+      }
     {
       std::lock_guard<std::mutex> lock (m_mutex);
       m_quit = true;
@@ -250,7 +716,7 @@ public:
   }
 };
 
-/* float32 PCM in HBM -> output stream: encode, copy and write chunk by chunk (mirror image of load_stream_to_device).
+/* float32 PCM in HBM -> output stream: encode, copy and write tile by tile (mirror image of load_stream_to_device).
  * `OutputStage` is also what the tile loop of `add` uses for its finished tiles. */
 struct OutputStage
 {
@@ -260,7 +726,7 @@ struct OutputStage
   RawFormat fmt;
   bool direct16 = false, raw = false;
   size_t unit = 0, chunk_frames;
-  static constexpr int SLOTS = 3;
+  static constexpr int SLOTS = OUT_RING;
   hipStream_t copy = nullptr;
   hipEvent_t  ev_encoded[SLOTS] = {}, ev_copied[SLOTS] = {};
   PinnedBuffer host[SLOTS];
@@ -279,7 +745,7 @@ struct OutputStage
         && hipEventCreateWithFlags (&ev_copied[i], hipEventDisableTiming) == hipSuccess
         && host[i].reserve (chunk_frames * unit) == 0 && (!raw || dev[i].reserve (chunk_frames * unit) == 0);
     if (ok)
-      writer = std::make_unique<ChunkWriter> (out, SLOTS);
+      writer = std::make_unique<ChunkWriter> (out, SLOTS, ctx->device, raw, unit);
   }
   ~OutputStage()
   {
@@ -337,6 +803,13 @@ store_device_to_stream (awm_ctx *ctx, AudioOutputStream *out_stream, const float
       return Error (std::string ("GPU staging failed: ") + awm_last_error());
   return stage.finish();
 }
+
+} // namespace
+
+extern "C" void awm_set_io_threads (int n) { g_io_threads.store (n < 0 ? 0 : n, std::memory_order_relaxed); }
+extern "C" void awm_debug_set_io_flags (int flags) { g_io_flags.store (flags, std::memory_order_relaxed); }
+
+namespace {
 
 /* "Data Blocks" counter of WatermarkGen (reference wmadd.cc:311-313, 346-351): depends only on how many frames the
  * streaming loop of the reference pushes through the generator, i.e. on the latency of synth + limiter */
@@ -418,9 +891,9 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   RawFormat fmt;
   const bool raw = in_stream->raw_access (fmt) && device_codec_supported (fmt);
   const size_t unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
-  Staging st (ctx, tile * unit, raw);
+  TileReader rd (ctx, in_stream, raw, unit, tile, raw);
   OutputStage stage (ctx, out_stream, tile);
-  if (!st.ok || !stage.ok)
+  if (!rd.ok || !stage.ok)
     {
       error ("audiowmark: out of memory for the staging buffers\n");
       return fail (AWM_ERR_HIP);
@@ -434,14 +907,9 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   bool eof = false;
   for (size_t k = 0; !eof; k++)
     {
-      const int b = int (k & 1);
-      if (k >= 2 && hipEventSynchronize (st.ev_copied[b]) != hipSuccess)
-        {
-          error ("audiowmark: GPU transfer failed\n");
-          return fail (AWM_ERR_HIP);
-        }
+      int b = 0;
       size_t got = 0;
-      Error err = read_chunk (in_stream, raw, unit, st.host[b].as<unsigned char>(), tile, got);
+      Error err = rd.next (b, got);                        // (read ahead by the I/O workers / the reader thread)
       if (err)
         {
           error ("audiowmark: input stream read failed: %s\n", err.message());
@@ -451,19 +919,21 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       float *slot = awm_add_stream_input (add);
       bool ok = true;
       if (got && raw)
-        ok = (k < 2 || hipStreamWaitEvent (st.copy, st.ev_used[b], 0) == hipSuccess)
-          && hipMemcpyAsync (st.dev[b].ptr, st.host[b].ptr, got * unit, hipMemcpyHostToDevice, st.copy) == hipSuccess
-          && hipEventRecord (st.ev_copied[b], st.copy) == hipSuccess
-          && hipStreamWaitEvent (ctx->stream, st.ev_copied[b], 0) == hipSuccess
-          && awm_pcm_decode_d (ctx, st.dev[b].ptr, got * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, slot) == 0
-          && hipEventRecord (st.ev_used[b], ctx->stream) == hipSuccess;
+        ok = (k < size_t (IN_RING) || hipStreamWaitEvent (rd.copy, rd.ev_used (b), 0) == hipSuccess)
+          && hipMemcpyAsync (rd.dev (b), rd.host (b), got * unit, hipMemcpyHostToDevice, rd.copy) == hipSuccess
+          && hipEventRecord (rd.ev_copied (b), rd.copy) == hipSuccess
+          && hipStreamWaitEvent (ctx->stream, rd.ev_copied (b), 0) == hipSuccess
+          && awm_pcm_decode_d (ctx, rd.dev (b), got * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, slot) == 0
+          && hipEventRecord (rd.ev_used (b), ctx->stream) == hipSuccess;
       else if (got)
         // the slot was last read by kernels queued on the compute stream: the copy must not overtake them
-        ok = hipEventRecord (st.ev_used[b], ctx->stream) == hipSuccess
-          && hipStreamWaitEvent (st.copy, st.ev_used[b], 0) == hipSuccess
-          && hipMemcpyAsync (slot, st.host[b].ptr, got * unit, hipMemcpyHostToDevice, st.copy) == hipSuccess
-          && hipEventRecord (st.ev_copied[b], st.copy) == hipSuccess
-          && hipStreamWaitEvent (ctx->stream, st.ev_copied[b], 0) == hipSuccess;
+        ok = hipEventRecord (rd.ev_used (b), ctx->stream) == hipSuccess
+          && hipStreamWaitEvent (rd.copy, rd.ev_used (b), 0) == hipSuccess
+          && hipMemcpyAsync (slot, rd.host (b), got * unit, hipMemcpyHostToDevice, rd.copy) == hipSuccess
+          && hipEventRecord (rd.ev_copied (b), rd.copy) == hipSuccess
+          && hipStreamWaitEvent (ctx->stream, rd.ev_copied (b), 0) == hipSuccess;
+      if (ok && got)
+        rd.recycle (b, rd.ev_copied (b));
       const float *done[3];
       size_t done_frames[3];
       int n_done = ok ? awm_add_stream_push (add, got, eof, done, done_frames) : -1;

@@ -163,7 +163,8 @@ viterbi_check_errors (WorkLane *lane, const float *errors, size_t n)
       {
         if (lane->ws_viterbi_sync.ptr)
           (void) hipMemsetAsync (lane->ws_viterbi_sync.ptr, 0, lane->ws_viterbi_sync.bytes, lane->stream);
-        set_error ("viterbi: a device-side wait between the workgroups of a decode timed out");
+        set_error (std::string ("viterbi: a device-side wait between the workgroups of a decode timed out; ") + awmk::viterbi_form_description()
+                   + " -- awm_debug_set_viterbi_persistent (0) selects the launch chain");
         return AWM_ERR_HIP;
       }
   return 0;

@@ -329,7 +329,16 @@ prepare_mags (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& cli
       ra.max_stride = std::max (ra.max_stride, cd.stride);
       ra.max_step = std::max (ra.max_step, std::ldexp (double (cd.mant), -cd.shift));
     }
-  AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, max_out, int (centers.size())));
+  double var_bytes = 0, mags_bytes = 0;
+  for (const auto& c : centers)
+    {
+      var_bytes += double (c.n_in + c.n_out) * C * 4.0;                   // K12: the clip in, the resampled clip out, per centre speed
+      mags_bytes += double (c.n_out) * C * 4.0 + double (c.rows) * 510 * 8.0;   // K13: the resampled clip once, { umag, dmag } per row and sync frame out
+    }
+  {
+    ProfScope ps (ctx, PROF_RESAMPLE_VAR, var_bytes, st);
+    AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, max_out, int (centers.size())));
+  }
   awmk::SpeedMagsArgs ma {};
   ma.sub = ws->sub.as<float>();
   ma.sub_stride = sub_stride;
@@ -340,7 +349,10 @@ prepare_mags (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& cli
   ma.mags = ws->mags.as<float2>();
   ma.mags_center_stride = center_stride;
   ma.ld = ld;
-  AWM_HIP_CHECK (awmk::launch_speed_mags (st, ctx->tabs, ma, max_rows, int (centers.size())));
+  {
+    ProfScope ps (ctx, PROF_SPEED_MAGS, mags_bytes, st);
+    AWM_HIP_CHECK (awmk::launch_speed_mags (st, ctx->tabs, ma, max_rows, int (centers.size())));
+  }
   AWM_HIP_CHECK (hipStreamSynchronize (st));               // the pinned staging area is reused by the caller
   *ld_out = ld;
   *center_stride_out = center_stride;
@@ -394,7 +406,10 @@ resample_var_device (awm_ctx *ctx, WorkLane *lane, const float *in_d, size_t n_i
   ra.out_stride = 0;
   ra.max_stride = cd.stride;
   ra.max_step = std::ldexp (double (cd.mant), -cd.shift);
-  AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, (long long) n_out, 1));
+  {
+    ProfScope ps (ctx, PROF_RESAMPLE_VAR, double (n_in + n_out) * n_channels * 4.0, st);
+    AWM_HIP_CHECK (awmk::launch_resample_var (st, ra, (long long) n_out, 1));
+  }
   AWM_HIP_CHECK (hipStreamSynchronize (st));
   return 0;
 }
@@ -559,7 +574,14 @@ speed_scan (awm_ctx *ctx, WorkLane *lane, const Key& key, const DeviceWav& wav, 
   ca.rows_per_bit = Params::sync_frames_per_bit;
   ca.min_delta = std::min (params().water_delta, 0.080);
   ca.best = ws->best.as<unsigned long long>();
-  AWM_HIP_CHECK (awmk::launch_speed_compare (st, ca, int (items.size())));
+  {
+    // K14: every centre's { umag, dmag } matrix once (its 2 n_steps + 1 relative speeds share it) + one best score per item
+    double bytes = double (items.size()) * 8.0;
+    for (const auto& c : centers)
+      bytes += double (c.rows) * 510 * 8.0;
+    ProfScope ps (ctx, PROF_SPEED_COMPARE, bytes, st);
+    AWM_HIP_CHECK (awmk::launch_speed_compare (st, ca, int (items.size())));
+  }
   AWM_HIP_CHECK (hipStreamSynchronize (st));
   AWM_HIP_CHECK (hipMemcpyAsync (ws->pin.ptr, ws->best.ptr, best_bytes, hipMemcpyDeviceToHost, st));
   AWM_HIP_CHECK (hipStreamSynchronize (st));

@@ -66,10 +66,15 @@ class TorchComm:
     through small device tensors; gloo: host buffers as they are, device buffers staged through host memory.  Messages between
     the same pair of ranks are posted in the same order on both sides (the protocol enumerates them by chunk)."""
 
-    def __init__(self, dist, device=None, memory="cuda"):
+    def __init__(self, dist, device=None, memory="cuda", ctx=None):
         # memory="host": what the protocol calls device memory is host memory (CPU tests of the wiring, no GPU involved)
+        # ctx: the awm context whose entry points will call back into this transport.  awm_comm's contract is "the received bytes are
+        # visible to the CONTEXT's stream on return": with it the RCCL operations are issued ON that stream (torch.cuda.ExternalStream
+        # of awm_ctx_stream), whatever torch's current stream is at that moment; without it they run on torch's current stream and a
+        # device synchronisation closes every exchange (correct for any stream, but the host blocks).
         import torch
         self.dist, self.torch = dist, torch
+        self.ctx = ctx
         self.host_only = memory == "host"
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         self.nccl = dist.get_backend() == "nccl"
@@ -79,12 +84,24 @@ class TorchComm:
         # would each be staged through device memory with two blocking copies; a second group over gloo (the same ranks, loopback / the
         # launcher's rendezvous address) carries them as they are.  Every rank creates it (new_group is collective); if that fails
         # anywhere the records keep going through the staged path.
+        # The group is used only if EVERY rank has it: a rank that went on alone over the staged path while the others use gloo
+        # would hang the first exchange_h.  The agreement is a MIN-reduction of a success flag on the default group; a failure is
+        # reported on stderr (the path still works, slower), never silent.
         self.host_group = None
         if self.nccl and not self.host_only and self.world > 1:
+            group, why = None, ""
             try:
-                self.host_group = dist.new_group(backend="gloo")
-            except Exception:
-                self.host_group = None
+                group = dist.new_group(backend="gloo")
+            except Exception as e:                                # noqa: BLE001 -- any failure means "no side group here"
+                why = repr(e)
+            flag = torch.tensor([1 if group is not None else 0], dtype=torch.int32, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                self.host_group = group
+            else:
+                import sys
+                print(f"audiowmark_amd.sharded: rank {self.rank}: no gloo side group on every rank ({why or 'another rank failed'}); "
+                      "host records travel staged through device memory over RCCL", file=sys.stderr, flush=True)
         self._cb = (_EXCHANGE(lambda *a: self._exchange(True, *a)), _EXCHANGE(lambda *a: self._exchange(False, *a)),
                     _REDUCE(self._reduce))                       # (kept alive with the object)
         self.c = AwmComm(None, self.rank, self.world, *self._cb)
@@ -94,7 +111,26 @@ class TorchComm:
             return awm._as_tensor(ptr, nbytes)
         return self.torch.frombuffer((C.c_ubyte * nbytes).from_address(ptr), dtype=self.torch.uint8)
 
+    def _ctx_stream(self):
+        """torch view of the context's HIP stream (None: unknown -- no context given, or host memory only)"""
+        if self.ctx is None or self.host_only:
+            return None
+        h = awm.lib.awm_ctx_stream(self.ctx._h)
+        # (the null stream has handle 0: torch's default stream of the device is that stream)
+        return self.torch.cuda.ExternalStream(h, device=self.device) if h else self.torch.cuda.default_stream(self.device)
+
     def _exchange(self, on_device, user, n_send, send, send_bytes, send_to, n_recv, recv, recv_bytes, recv_from):
+        try:
+            stream = self._ctx_stream()
+            if stream is None:
+                return self._exchange_on_current(on_device, n_send, send, send_bytes, send_to, n_recv, recv, recv_bytes, recv_from, False)
+            with self.torch.cuda.stream(stream):
+                return self._exchange_on_current(on_device, n_send, send, send_bytes, send_to, n_recv, recv, recv_bytes, recv_from, True)
+        except Exception as e:                                   # (an exception must not travel through the C frames)
+            self.error = e
+            return 1
+
+    def _exchange_on_current(self, on_device, n_send, send, send_bytes, send_to, n_recv, recv, recv_bytes, recv_from, on_ctx_stream):
         try:
             torch, dist = self.torch, self.dist
             ops, copy_back = [], []
@@ -125,10 +161,13 @@ class TorchComm:
             for t, stage in copy_back:
                 t.copy_(stage)
             # awm_comm's contract: the writes are visible to the CONTEXT's stream on return.  nccl + device buffers: req.wait() has
-            # made torch's current stream -- the stream the context works on (binding.Context) -- wait for the transfers, so
-            # everything stays stream ordered and the host does not block (the library orders its lanes behind the context's stream
-            # itself).  Staged paths (gloo, host buffers over nccl) end in blocking copies; a device sync closes those.
-            if not self.host_only and not (self.nccl and on_device) and group is None:
+            # made torch's CURRENT stream wait for the transfers -- that is the context's stream when the caller handed the context
+            # over (on_ctx_stream), so everything stays stream ordered and the host does not block (the library orders its lanes
+            # behind the context's stream itself).  Without the context nothing says the two streams are the same one: a device
+            # synchronisation then closes the exchange.  Staged paths (gloo, host buffers over nccl) end in blocking copies; a
+            # device sync closes those as well.
+            stream_ordered = self.nccl and on_device and on_ctx_stream
+            if not self.host_only and not stream_ordered and group is None:
                 torch.cuda.synchronize(self.device)
             return 0
         except Exception as e:                                   # (an exception must not travel through the C frames)
@@ -138,15 +177,20 @@ class TorchComm:
     def _reduce(self, user, data, n):
         try:
             torch, dist = self.torch, self.dist
+            stream = self._ctx_stream()
             # non-negative floats order like their bit patterns: max of the words
             t = self._view(data, n * 4, True).view(torch.int32)
             if self.nccl or self.host_only:
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                if stream is not None:
+                    with torch.cuda.stream(stream):               # the reduction is ordered on the CONTEXT's stream
+                        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                else:
+                    dist.all_reduce(t, op=dist.ReduceOp.MAX)
             else:
                 h = t.cpu()
                 dist.all_reduce(h, op=dist.ReduceOp.MAX)
                 t.copy_(h)
-            if not self.host_only and not self.nccl:             # (nccl: the current stream waits for the reduction -- stream ordered)
+            if not self.host_only and not (self.nccl and stream is not None):   # (nccl on the context's stream: stream ordered)
                 torch.cuda.synchronize(self.device)
             return 0
         except Exception as e:
@@ -197,7 +241,7 @@ class ShardedStream:
         self.ctx, self.dist, self.n_channels = ctx, dist, n_channels
         self.rank, self.world = dist.get_rank(), dist.get_world_size()
         dev = torch.device("cuda", ctx.device)
-        self.comm = TorchComm(dist, dev)
+        self.comm = TorchComm(dist, dev, ctx=ctx)
         mine = torch.tensor([n_frames_local], dtype=torch.int64, device=dev if self.comm.nccl else "cpu")
         lens = [torch.zeros_like(mine) for _ in range(self.world)]
         dist.all_gather(lens, mine)

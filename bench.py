@@ -80,6 +80,12 @@ KERNELS = {
     "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (300 single-wave workgroups, 60 loads in flight each)"),
     "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue and LDS round trips in turn"),
     "soft_bits_kernel": ("soft_bits_wave_kernel", "latency of scattered reads + sequential double precision sums (four bits per wave)"),
+    "resample_kernel": ("resample_phase_kernel<147, 160, 18> / <160, 147, 16> (stereo 48 <-> 44.1 kHz) | resample_kernel",
+                        "LDS window reads <-> VALU issue: a thread owns one phase; per output 18 ds_read2_b64 + 146 VALU (zita's 8 unfused operations per tap pair)"),
+    "resample_var_kernel": ("resample_var_kernel", "VALU issue <-> LDS coefficient reads: 17 VALU (zita's 14 roundings + 3) and 3 LDS instructions per stereo tap pair"),
+    "speed_mags_kernel": ("speed_mags_kernel", "LDS gathers in the reference's summation order (60 per time step and sync frame) + load latency"),
+    "speed_compare_kernel": ("speed_compare_kernel", "VALU issue: 7 instructions per (column, speed); the matrix is served by L2 (11 relative speeds per centre share it)"),
+    "frame_mod_table_kernel": ("frame_mod_table_kernel", "the serial swap chain of the 51 480-entry shuffle: LDS round trips (64 / 16 / 4 / 1 swaps per trip)"),
     "viterbi_kernel": ("viterbi_super_kernel<0> (chain of 14 launches) | viterbi_persistent_kernel (one launch): see viterbi_form",
                        "latency: 143 dependent trellis steps, a chunk's ~37 decodes are one wave per SIMD; 8 workgroups per decode exchange their metrics every 12 steps "
                        "-- through 14 dependent launches where launches are cheap on the host, through per-decode counters inside ONE launch where they are not"),
@@ -202,7 +208,7 @@ def cpu_baseline_and_parity(torch, awm, ctx, sample_seconds):
     return base, parity
 
 
-def detect_speed_config(torch, awm, ctx, key, payload, minutes):
+def detect_speed_config(torch, awm, ctx, key, payload, minutes, lanes=4):
     """BASELINE.json configs[2] (reported next to the headline number, never part of `value`): `minutes` of stereo 48 kHz,
     watermarked at 48 kHz (timed), replayed 2 % fast (untimed: that is the attacker's part), then what `get --detect-speed`
     does with the 48 kHz file (timed): loader resampling to 44.1 kHz, speed search per 30-minute chunk, decode of the stream
@@ -214,9 +220,16 @@ def detect_speed_config(torch, awm, ctx, key, payload, minutes):
     g.manual_seed(4711)
     x = torch.rand((n, 2), generator=g, device="cuda", dtype=torch.float32) * 2 - 1
 
-    def timed(fn, reps=3):
-        for _ in range(3):                                 # untimed, like the headline's warm-up steps: the first call allocates the lanes'
-            fn()                                           # workspaces, the next two still run ~35 % slower (tools: 95 / 27 / 27 / 19.8 / 19.8 ... ms)
+    first = {}
+
+    def timed(fn, reps=3, what=None):
+        for i in range(3):                                 # untimed, like the headline's warm-up steps; the FIRST call is reported on its
+            torch.cuda.synchronize()                       # own (first_call_ms: workspaces are sized from the stream's upper bounds when a
+            t0 = time.perf_counter()                       # context first sees a stream length, so it should be close to the steady state)
+            fn()
+            torch.cuda.synchronize()
+            if i == 0 and what:
+                first[what] = round((time.perf_counter() - t0) * 1e3, 3)
         best = None
         for _ in range(reps):
             torch.cuda.synchronize()
@@ -227,13 +240,32 @@ def detect_speed_config(torch, awm, ctx, key, payload, minutes):
             best = dt if best is None else min(best, dt)
         return out, best
 
-    w, t_add = timed(lambda: ctx.add_watermark(key, payload, x, sample_rate=rate))
+    w, t_add = timed(lambda: ctx.add_watermark(key, payload, x, sample_rate=rate), what="add_48k")
     del x
     fast = ctx.resample_ratio(w, 1 / speed, rate=rate)
     del w
     awm.set_speed_params(detect_speed=True)
+    kernels = None
     try:
-        pats, t_get = timed(lambda: ctx.get_watermark(key, ctx.resample(fast, rate, 44100)))
+        pats, t_get = timed(lambda: ctx.get_watermark(key, ctx.resample(fast, rate, 44100)), what="get_detect_speed")
+        # stand-alone durations: ONE lane, the plain decode after the speed part instead of beside it, per-kernel HIP events
+        # (the rocprofv3 summary of the same pass: profiles/rNN/rocprofv3_kernel_stats_config2_one_lane.csv)
+        calls = 2
+        awm.lib.awm_ctx_set_chunk_lanes(ctx._h, 1)
+        awm.lib.awm_debug_set_speed_overlap(0)
+        try:
+            ctx.get_watermark(key, ctx.resample(fast, rate, 44100))
+            awm.lib.awm_prof_reset(ctx._h)
+            awm.lib.awm_prof_enable(ctx._h, 1)
+            for _ in range(calls):
+                ctx.get_watermark(key, ctx.resample(fast, rate, 44100))
+            torch.cuda.synchronize()
+            awm.lib.awm_prof_enable(ctx._h, 0)
+            kernels = scope_table(read_prof(awm, ctx), calls)
+        finally:
+            awm.lib.awm_debug_set_speed_overlap(1)
+            awm.lib.awm_ctx_set_chunk_lanes(ctx._h, lanes)
+            awm.lib.awm_prof_reset(ctx._h)
     finally:
         awm.set_speed_params()
     hits = [p for p in pats if p["bits"] == payload]
@@ -243,7 +275,9 @@ def detect_speed_config(torch, awm, ctx, key, payload, minutes):
                         "search per chunk, decode of the stretched + the plain stream)" % (minutes, speed),
             "value": round((n / rate + seconds) / 2 / (t_add + t_get), 1), "unit": "xRT",
             "add_ms": round(t_add * 1e3, 3), "get_detect_speed_ms": round(t_get * 1e3, 3),
-            "payload_matches": len(hits), "detected_speeds": speeds, "zita_resampler": "restated (parity with the library unpinned)"}
+            "first_call_ms": first,
+            "payload_matches": len(hits), "detected_speeds": speeds, "zita_resampler": "restated (parity with the library unpinned)",
+            "kernels_one_lane": kernels}
 
 
 def e2e_leg(torch, awm, ctx, x, resident_ms):
@@ -346,6 +380,26 @@ def viterbi_form(awm):
                         "per-decode counters) above 9 us per launch; bits and error values identical"}
     except Exception:
         return None
+
+
+def scope_table(rows, calls):
+    """HIP-event scopes of a profiled one-lane pass -> per-kernel roofline objects, largest share first: stand-alone average duration,
+    algorithmic bytes per scope (SURVEY.md 8(d) / DESIGN.md section 3 figures x the units the scope processed), the same ratio
+    against 8 TB/s as `roofline.frac`, and what actually limits the kernel.  Reproducible from the rocprofv3 --kernel-trace --stats
+    summary of the same pass (profiles/rNN): avg_ms there == avg_ms here."""
+    total = sum(r[1] for r in rows) or 1.0
+    out = []
+    for name, ms, launches, nbytes in sorted(rows, key=lambda r: -r[1]):
+        gbps = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out.append({"kernel": KERNELS.get(name, (name, ""))[0], "scope": name, "single_launch_scope": name in SINGLE_KERNEL_SCOPES or name in SPEED_SINGLE_SCOPES,
+                    "scopes_per_call": round(launches / calls, 2), "avg_ms": round(ms / launches, 4), "ms_per_call": round(ms / calls, 4),
+                    "share_of_gpu_time_alone": round(ms / total, 3), "algorithmic_bytes_per_scope": int(nbytes / launches),
+                    "achieved_GBps": round(gbps, 1), "frac": round(gbps / HBM_PEAK_GBS, 4), "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "limited_by": KERNELS.get(name, ("", "?"))[1]})
+    return out
+
+
+SPEED_SINGLE_SCOPES = ("resample_kernel", "resample_var_kernel", "speed_mags_kernel", "speed_compare_kernel", "frame_mod_table_kernel")
 
 
 def read_prof(awm, ctx):
@@ -579,6 +633,23 @@ def main():
             sync()
             awm.lib.awm_prof_enable(ctx._h, 0)
             scopes = sum(p[2] for p in read_prof(awm, ctx))
+            # stand-alone durations of the batch kernels: ONE group of 64 clips = one lane of `get` (the groups of a larger batch run
+            # on several lanes side by side), per-kernel HIP events; `add` of the same 64 clips (its lanes run side by side: K2's
+            # duration there is a concurrent one and says so)
+            g = min(64, len(clips))
+            calls = 3
+            ctx.get_watermark_batch_keys(keys[:g], outs[:g])
+            awm.lib.awm_prof_reset(ctx._h)
+            awm.lib.awm_prof_enable(ctx._h, 1)
+            for _ in range(calls):
+                ctx.add_watermark_batch_keys(keys[:g], PAYLOAD, clips[:g], outs[:g])
+                ctx.get_watermark_batch_keys(keys[:g], outs[:g])
+            sync()
+            awm.lib.awm_prof_enable(ctx._h, 0)
+            one_group = scope_table(read_prof(awm, ctx), calls)
+            for k in one_group:
+                if k["scope"] in ("add_mix_kernel", "limiter_kernel"):
+                    k["note"] = "add runs one clip per lane on up to 16 lanes: concurrent duration, not a stand-alone one"
             t0 = time.perf_counter()
             for k in mine[:8]:
                 awm.tab_frame_mod(awm.test_key(k), PAYLOAD); awm.tab_sync_bits(awm.test_key(k), True); awm.tab_mix_entries(awm.test_key(k))
@@ -596,7 +667,8 @@ def main():
                                          "ms_per_clip_with_one_key_for_all": round(one_key * 1e3 / max(1, len(clips)), 4),
                                          "key_tables_ms_per_clip_amortised": round(per_clip - one_key * 1e3 / max(1, len(clips)), 4),
                                          "key_tables_host_ms_per_key_on_one_core": round(t_tab * 1e3, 3), "host_cores": os.cpu_count(),
-                                         "profiled_launch_scopes_per_clip": round(scopes / max(1, len(clips)), 3)}}
+                                         "profiled_launch_scopes_per_clip": round(scopes / max(1, len(clips)), 3),
+                                         "kernels_one_group_of_64_clips": one_group}}
         else:
             matches = sum(1 for p in (pats or []) if p["bits"] == PAYLOAD)
             cfg = {"workload": workload, "parallelism": (f"one stream sharded over {world} GPU(s)" if sharded_path else "1 GPU") +
@@ -685,7 +757,7 @@ def main():
                     res["e2e"] = {"error": str(e)}
             if not args.no_detect_speed_config:
                 try:
-                    res["detect_speed_config"] = detect_speed_config(torch, awm, ctx, None, PAYLOAD, args.minutes if args.minutes is not None else 60.0)
+                    res["detect_speed_config"] = detect_speed_config(torch, awm, ctx, None, PAYLOAD, args.minutes if args.minutes is not None else 60.0, args.lanes)
                 except Exception as e:                       # reported, never fatal for the headline line
                     res["detect_speed_config"] = {"error": str(e)}
             if not args.no_cpu_baseline:

@@ -407,6 +407,18 @@ void awm_debug_set_key_tables_on_device (int on);   /* batches with one key per 
 void awm_debug_set_merge_decodes (int on);  /* get of a stream of 2 - 4 chunks: the chunks' Viterbi jobs as ONE batch at the end | per chunk (default: the step is faster) */
 void awm_debug_set_add_slab_mb (int mb);   /* add: 0 (default) one fused add over the stream, then the limiter | > 0: in slabs of that many MB (cache experiment) */
 void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transforms pipelined in one wave (default) | one after the other */
+void awm_debug_alloc_stats (long *dev_allocs, double *dev_ms, long *pinned_allocs, double *pinned_ms);
+                                           /* process-wide census of hipMalloc / hipHostMalloc calls made by the library's grow-only buffers and the
+                                            * time the runtime took for them (what a first call pays); any pointer may be NULL */
+void awm_debug_set_io_flags (int flags);   /* file level add / get, host side (host/wmfile.cc): bit 0 regular files are read / written by the I/O workers
+                                            * through the streams' raw_region (else one reader / writer thread in stream order, as for pipes) | bit 1 output
+                                            * through a shared mapping of the tile's range (else pwrite per part) | bit 2 MADV_POPULATE_WRITE before the
+                                            * copy into the mapping.  Default 7.  The bytes written are the same either way. */
+
+/* Host threads that copy between the page cache and the page-locked staging rings of the file level calls (awm_add_watermark_file,
+ * awm_get_watermark_file, the command line): 0 (default) = min (8, cores); one pool per process.  The reference reads and writes on
+ * its one thread (wavchunkloader.cc:196-222, rawconverter.cc, stdoutwavoutputstream.cc). */
+void awm_set_io_threads (int n);
 
 /* --quiet (reference audiowmark.cc:1020-1023): the "Input: / Output: / Message: ..." information lines of add_watermark off */
 void awm_set_quiet (int quiet);

@@ -8,9 +8,22 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PATH = os.path.join(ROOT, "oracle", "_ref", "libawm_ref.so")
+PATH_MKL = os.path.join(ROOT, "oracle", "_ref", "libawm_ref_mkl.so")   # same sources, fftwf_* from MKL's float FFTW wrapper (`make -C oracle ref_mkl`)
 BIN = os.path.join(ROOT, "oracle", "_ref", "audiowmark_ref")
 
 _lib = None
+_backend = "double"
+_libs = {}
+
+
+def use_backend(name):
+    """switch every wrapper below between the two builds of the reference: "double" (oracle/ref_shim/fftw_shim.cc, the default and the
+    only one the tests use) and "mkl" (MKL's single-precision FFTW3 wrapper; calibration only: tools/ref_backend_census.py)"""
+    global _lib, _backend
+    assert name in ("double", "mkl")
+    _libs[_backend] = _lib
+    _backend = name
+    _lib = _libs.get(name)
 
 
 def available():
@@ -35,7 +48,7 @@ class Pattern(C.Structure):
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(PATH)
+        _lib = C.CDLL(PATH if _backend == "double" else PATH_MKL)
         _lib.ref_sync_decode.restype = C.c_double
         _lib.ref_mix_entries.restype = C.c_size_t
         _lib.ref_conv_encode.restype = C.c_size_t

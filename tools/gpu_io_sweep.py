@@ -1,0 +1,106 @@
+import os as _os; _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+"""File level add / get of 60 min stereo s16 raw in /dev/shm: I/O worker count x mode sweep (awm_set_io_threads, awm_debug_set_io_flags),
+output bytes compared across all modes, first-call allocation census, and the command line's AWM_TIMING marks.
+
+  python tools/gpu_io_sweep.py [minutes = 60]   ->  gpurun_out/io_sweep.json  (copy to profiles/rNN/)
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, ROOT)
+PAY = "0123456789abcdef0011223344556677"
+RATE = 44100
+
+
+def alloc_stats(awm):
+    a, b, c, d = C.c_long(), C.c_double(), C.c_long(), C.c_double()
+    awm.lib.awm_debug_alloc_stats(C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+    return {"dev_allocs": a.value, "dev_ms": round(b.value, 2), "pinned_allocs": c.value, "pinned_ms": round(d.value, 2)}
+
+
+def delta(a, b):
+    return {k: round(b[k] - a[k], 2) for k in a}
+
+
+def main():
+    minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+    import torch
+    import audiowmark_amd as awm
+    ctx = awm.Context(0)
+    n = int(minutes * 60 * RATE)
+    g = torch.Generator(device="cuda"); g.manual_seed(1234)
+    x = torch.rand((n, 2), generator=g, device="cuda") * 2 - 1
+    d = "/dev/shm" if os.access("/dev/shm", os.W_OK) else "/tmp"
+    src, dst = os.path.join(d, "awm_io_in.raw"), os.path.join(d, "awm_io_out.raw")
+    ctx.pcm_encode(x.reshape(-1), 16, 0, False, True).cpu().numpy().tofile(src)
+    rf = awm.binding.RawFormat(2, RATE, 16, 0, 0)
+    awm.lib.awm_set_quiet(1)
+    out = {"minutes": minutes, "dir": d, "file_bytes": os.path.getsize(src), "host_cpus_visible": os.cpu_count(), "runs": []}
+    # first calls on a fresh context: what they pay in allocations
+    s0 = alloc_stats(awm)
+    t0 = time.perf_counter(); ctx.add_watermark_file(None, PAY, src, dst, rf, rf); t_first_add = time.perf_counter() - t0
+    s1 = alloc_stats(awm)
+    t0 = time.perf_counter(); pats = ctx.get_watermark_file(None, dst, rf); t_first_get = time.perf_counter() - t0
+    s2 = alloc_stats(awm)
+    out["first_calls"] = {"add_file_ms": round(t_first_add * 1e3, 2), "add_allocs": delta(s0, s1), "get_file_ms": round(t_first_get * 1e3, 2), "get_allocs": delta(s1, s2)}
+    ref_md5 = hashlib.md5(open(dst, "rb").read()).hexdigest()
+    ref_pats = [(p["sync_index"], p["bits"]) for p in pats]
+    for flags, what in ((7, "regions + mmap + populate"), (3, "regions + mmap"), (1, "regions + pwrite"), (0, "one reader / one writer thread")):
+        for threads in ((2, 4, 6, 8, 12, 16) if flags else (8,)):
+            awm.lib.awm_set_io_threads(threads)
+            awm.lib.awm_debug_set_io_flags(flags)
+            best_add = best_get = None
+            for _ in range(3):
+                if os.path.exists(dst):
+                    os.remove(dst)
+                t0 = time.perf_counter()
+                ctx.add_watermark_file(None, PAY, src, dst, rf, rf)
+                t1 = time.perf_counter()
+                pats = ctx.get_watermark_file(None, dst, rf)
+                t2 = time.perf_counter()
+                best_add = t1 - t0 if best_add is None else min(best_add, t1 - t0)
+                best_get = t2 - t1 if best_get is None else min(best_get, t2 - t1)
+            same = hashlib.md5(open(dst, "rb").read()).hexdigest() == ref_md5 and [(p["sync_index"], p["bits"]) for p in pats] == ref_pats
+            rec = {"mode": what, "flags": flags, "threads": threads, "add_file_ms": round(best_add * 1e3, 2), "get_file_ms": round(best_get * 1e3, 2),
+                   "file_to_file_xRT": round(minutes * 60 / (best_add + best_get), 1), "output_and_patterns_identical": bool(same)}
+            out["runs"].append(rec)
+            print(rec, flush=True)
+    awm.lib.awm_set_io_threads(0)
+    awm.lib.awm_debug_set_io_flags(7)
+    # the command line with timing marks (process start, HIP runtime up, context ready, command done)
+    cli = os.path.join(ROOT, "audiowmark_amd", "audiowmark")
+    fmt = ["--format", "raw", "--raw-rate", str(RATE), "--raw-channels", "2", "--raw-bits", "16"]
+    env = dict(os.environ, AWM_TIMING="1")
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    marks = {}
+    for name, cmd in (("add", [cli, "add", "-q"] + fmt + [src, dst, PAY]), ("get", [cli, "get"] + fmt + [dst])):
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+            wall = (time.perf_counter() - t0) * 1e3
+            m = {l.split()[1]: float(l.split()[2]) for l in r.stderr.decode().splitlines() if l.startswith("awm_timing")}
+            m["wall_ms_incl_exec"] = round(wall, 2)
+            m["rc"] = r.returncode
+            if best is None or wall < best["wall_ms_incl_exec"]:
+                best = m
+        marks[name] = best
+    out["cli_timing_ms"] = marks
+    out["cli_xRT"] = round(minutes * 60 / ((marks["add"]["wall_ms_incl_exec"] + marks["get"]["wall_ms_incl_exec"]) * 1e-3), 1)
+    for f in (src, dst):
+        if os.path.exists(f):
+            os.remove(f)
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "io_sweep.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps({k: v for k, v in out.items() if k != "runs"}))
+
+
+if __name__ == "__main__":
+    main()
