@@ -355,6 +355,13 @@ struct Gpu
 finish (int rc)
 {
   timing_mark ("command_done");
+  if (getenv ("AWM_TIMING"))
+    {
+      double ms[8];
+      awm_debug_file_timing (ms);       // (`add` at the watermark rate only; zeros otherwise)
+      fprintf (stderr, "awm_timing add_calling_thread setup %.2f wait_input %.2f wait_output_slot %.2f queue_gpu_work %.2f final_gpu_wait %.2f "
+                       "final_writer_wait %.2f teardown %.2f hand_on_output %.2f\n", ms[0], ms[1], ms[2], ms[3], ms[4], ms[5], ms[6], ms[7]);
+    }
   fflush (nullptr);
   _exit (rc);
 }

@@ -108,6 +108,39 @@ awm_debug_alloc_stats (long *dev_allocs, double *dev_ms, long *pinned_allocs, do
   if (pinned_ms) *pinned_ms = awm::g_pin_alloc_ms.load();
 }
 
+bool
+awm::FileStaging::ensure_events()
+{
+  if (have_events)
+    return true;
+  for (int i = 0; i < RING; i++)
+    for (hipEvent_t *e : { &in_copied[i], &in_used[i], &out_encoded[i], &out_copied[i] })
+      if (!*e && hipEventCreateWithFlags (e, hipEventDisableTiming) != hipSuccess)
+        return false;
+  have_events = true;
+  return true;
+}
+
+void
+awm::FileStaging::release()
+{
+  for (int i = 0; i < RING; i++)
+    {
+      for (hipEvent_t *e : { &in_copied[i], &in_used[i], &out_encoded[i], &out_copied[i] })
+        if (*e)
+          {
+            (void) hipEventDestroy (*e);
+            *e = nullptr;
+          }
+      in_host[i].release();
+      out_host[i].release();
+      in_dev[i].release();
+      out_dev[i].release();
+    }
+  pcm.release();
+  have_events = false;
+}
+
 void
 awm::WorkLane::release_lane()
 {
@@ -689,6 +722,9 @@ awm_ctx_destroy (awm_ctx *ctx)
           (void) hipStreamDestroy (l->stream);
       }
   ctx->release_lane();
+  if (ctx->copy_stream)
+    (void) hipStreamSynchronize (ctx->copy_stream);
+  ctx->file_staging.release();
   if (ctx->copy_stream)
     (void) hipStreamDestroy (ctx->copy_stream);
   if (ctx->own_stream && ctx->stream)

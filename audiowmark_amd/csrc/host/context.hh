@@ -145,6 +145,21 @@ void speed_scratch_free (WorkLane *lane);
 } struct awm_ctx; namespace awm {
 void speed_workspace_free (awm_ctx *ctx);
 
+// Staging of the file level calls (host/wmfile.cc), kept by the context between calls like every other workspace: rings of
+// page-locked tiles and their device-side twins for both directions, the events that order them, and the float32 PCM of a whole
+// stream for `get` (hipHostMalloc / hipMalloc + the frees of these cost 20 - 80 ms per call when done call by call).
+struct FileStaging
+{
+  static constexpr int RING = 4;
+  PinnedBuffer in_host[RING], out_host[RING];
+  DevBuffer    in_dev[RING], out_dev[RING];
+  DevBuffer    pcm;
+  hipEvent_t   in_copied[RING] = {}, in_used[RING] = {}, out_encoded[RING] = {}, out_copied[RING] = {};
+  bool         have_events = false;
+  bool         ensure_events();
+  void         release();
+};
+
 struct FrameModTable
 {
   std::vector<unsigned char> key;
@@ -201,6 +216,7 @@ struct awm_ctx : awm::WorkLane
   awm::DevBuffer ws_rate_a, ws_rate_b, ws_rate_c;                          // resampled input / watermark signals of the other-rate add path
   std::unique_ptr<awm::WorkLane> extra_lanes[awm::MAX_LANES - 1];
   awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
+  awm::FileStaging file_staging;         // rings + whole-stream buffer of the file level calls (grow-only, like the workspaces)
   hipStream_t    copy_stream = nullptr;  // H2D / D2H staging of the file level paths (created on first use)
   hipStream_t    get_copy_stream();
   std::vector<awm_ctx *> helpers;        // other GPUs the file level `get` may spread a long stream over (awm_ctx_set_helpers; not owned)

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cerrno>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstring>
@@ -43,23 +44,39 @@ namespace {
  *           file serialise on its inode lock (pwrite from N threads is as fast as one thread; measured, tools/io_probe.cc);
  *           pipes / stdout / streams without byte access: one writer thread in stream order.                                        */
 constexpr size_t STAGE_FRAMES = size_t (1) << 22;       // frames per staging tile of the whole-stream loaders (16 MiB of 16 bit stereo)
-constexpr int    IN_RING = 4, OUT_RING = 4;             // page-locked tiles per direction
+constexpr int    IN_RING = FileStaging::RING, OUT_RING = FileStaging::RING;   // page-locked tiles per direction (kept by the context)
 constexpr size_t IO_PART_MIN = size_t (1) << 20;        // a worker's share of a tile is at least this many bytes
 
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23                          // (Linux 5.14; older headers)
 #endif
 enum { IO_REGIONS = 1, IO_MAP_OUTPUT = 2, IO_POPULATE = 4 };
+// where the wall time of the last file level add / load of this thread went (awm_debug_file_timing): milliseconds the calling thread
+// spent { setting up (streams, rings, tables), waiting for input tiles, waiting for a free output slot, queueing GPU work, in the
+// final wait for the GPU, in the final wait for the writers, tearing down, handing output tiles on (incl. the wait for a slot) }
+static thread_local double tl_file_ms[8] = { 0 };
+struct Lap
+{
+  std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+  void to (int i) { const auto n = std::chrono::steady_clock::now(); tl_file_ms[i] += std::chrono::duration<double, std::milli> (n - t).count(); t = n; }
+};
 static std::atomic<int> g_io_threads { 0 };             // 0: default
-static std::atomic<int> g_io_flags { IO_REGIONS | IO_MAP_OUTPUT | IO_POPULATE };
+enum { IO_REGIONS_OUT = 8 };
+// Default: input regions only.  OUTPUT through the workers (IO_REGIONS_OUT) is a measured negative on the target box: creating the page
+// cache pages of ONE file is serial in the kernel whatever the number of writers -- 640 MB into a fresh tmpfs file: one thread with
+// write() 85 - 100 ms, 8 threads with pwrite 190 - 260 ms, 8 threads through a shared mapping 180 - 190 ms, while 8 threads writing 8
+// SEPARATE files take 16 ms (tools/io_probe.cc -> profiles/r05/io_probe.txt).  The ordered writer thread is at that floor.
+static std::atomic<int> g_io_flags { IO_REGIONS };
 int
 io_threads()
 {
   const int n = g_io_threads.load (std::memory_order_relaxed);
   if (n > 0)
     return std::min (n, 64);
+  // (reads of a tile scale with the workers up to ~16 on the box this was tuned on: 640 MB from tmpfs in 70 / 18 / 9 / 7 ms with
+  // 1 / 4 / 8 / 16 threads, tools/io_probe.cc; the workers sleep while the GPU and the writer are busy)
   const unsigned hw = std::thread::hardware_concurrency();
-  return int (std::max (2u, std::min (8u, hw ? hw : 4u)));
+  return int (std::max (2u, std::min (16u, hw ? hw : 4u)));
 }
 
 /* worker threads for the host side copies; one pool per process, started at the first file level call and resized when the setting
@@ -182,9 +199,7 @@ class TileReader
 {
   struct Slot
   {
-    PinnedBuffer host;
-    DevBuffer    dev;                        // raw formats: the tile's bytes on the device, in front of the sample decode
-    hipEvent_t   ev_copied = nullptr, ev_used = nullptr;
+    unsigned char *host = nullptr;           // the context's page-locked tile (FileStaging)
     // state of the tile the slot currently holds (guarded by m_mutex)
     long long    tile = -1;                  // which tile has been scheduled into the slot
     int          parts_left = 0;
@@ -234,7 +249,7 @@ class TileReader
     const int device = m_ctx->device;
     auto read_part = [this, &s, part, bytes, first] (size_t i) {
       const size_t lo = std::min (bytes, part * i), hi = std::min (bytes, part * (i + 1));
-      unsigned char *dst = s.host.as<unsigned char>() + lo;
+      unsigned char *dst = s.host + lo;
       size_t n = 0;
       bool bad = false;
       int err = 0;
@@ -292,7 +307,7 @@ class TileReader
           (void) hipEventSynchronize (f.second);
         Slot& s = m_slots[f.first];
         size_t got = 0;
-        Error err = read_chunk (m_in, m_raw, m_unit, s.host.as<unsigned char>(), m_tile_frames, got);
+        Error err = read_chunk (m_in, m_raw, m_unit, s.host, m_tile_frames, got);
         std::lock_guard<std::mutex> lock (m_mutex);
         s.tile = tile;
         s.frames = got;
@@ -310,11 +325,13 @@ public:
     : m_ctx (ctx), m_in (in), m_raw (raw), m_unit (unit_bytes), m_tile_frames (tile_frames)
   {
     copy = ctx->get_copy_stream();
-    ok = copy != nullptr;
+    FileStaging& fs = ctx->file_staging;
+    ok = copy != nullptr && fs.ensure_events();
     for (int i = 0; i < IN_RING && ok; i++)
-      ok = hipEventCreateWithFlags (&m_slots[i].ev_copied, hipEventDisableTiming) == hipSuccess
-        && hipEventCreateWithFlags (&m_slots[i].ev_used, hipEventDisableTiming) == hipSuccess
-        && m_slots[i].host.reserve (tile_frames * unit_bytes) == 0 && (!need_dev || m_slots[i].dev.reserve (tile_frames * unit_bytes) == 0);
+      {
+        ok = fs.in_host[i].reserve (tile_frames * unit_bytes) == 0 && (!need_dev || fs.in_dev[i].reserve (tile_frames * unit_bytes) == 0);
+        m_slots[i].host = fs.in_host[i].as<unsigned char>();
+      }
     if (!ok)
       return;
     m_region = raw && (g_io_flags.load (std::memory_order_relaxed) & IO_REGIONS) != 0 && in->raw_region (m_fd, m_offset, m_total_frames);
@@ -347,20 +364,13 @@ public:
     if (m_region && m_consumed)
       m_in->raw_region_consume (m_consumed);
     if (copy)
-      (void) hipStreamSynchronize (copy);
-    for (auto& s : m_slots)
-      {
-        if (s.ev_copied) (void) hipEventDestroy (s.ev_copied);
-        if (s.ev_used) (void) hipEventDestroy (s.ev_used);
-        s.host.release();
-        s.dev.release();
-      }
+      (void) hipStreamSynchronize (copy);               // (the rings stay with the context; nothing of this call may still use them)
   }
   size_t announced_frames() const { return m_region ? m_total_frames : m_in->n_frames(); }
-  unsigned char *host (int slot) { return m_slots[slot].host.as<unsigned char>(); }
-  void          *dev (int slot) { return m_slots[slot].dev.ptr; }
-  hipEvent_t     ev_copied (int slot) { return m_slots[slot].ev_copied; }
-  hipEvent_t     ev_used (int slot) { return m_slots[slot].ev_used; }
+  unsigned char *host (int slot) { return m_slots[slot].host; }
+  void          *dev (int slot) { return m_ctx->file_staging.in_dev[slot].ptr; }
+  hipEvent_t     ev_copied (int slot) { return m_ctx->file_staging.in_copied[slot]; }
+  hipEvent_t     ev_used (int slot) { return m_ctx->file_staging.in_used[slot]; }
   /* the next tile: its slot and its frames (0 at / after the end of the stream) */
   Error
   next (int& slot, size_t& frames)
@@ -497,8 +507,12 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
 /* Completed output tiles leave the ring on other host threads, so that file writes overlap file reads and GPU work.
  *   wait_slot (b)   until the bytes of slot b have been written (the buffer may be reused)
  *   submit (...)    the D2H copy of slot b has been queued and `ready` recorded behind it
- * Streams in order (pipes, stdout, float samples through write_frames): one writer thread.  Regular files: the workers of the pool
- * copy into a shared mapping of the tile's byte range (see the head of this file). */
+ * Streams in order (pipes, stdout, float samples through write_frames, outputs of unknown length): one writer thread.
+ * Regular files of KNOWN length: the file is grown to its final size and mapped ONCE; the workers of the pool copy every tile into its
+ * range of the mapping and drop the range's page table entries afterwards (MADV_DONTNEED on a shared mapping: the pages stay in the page
+ * cache, the resident set stays bounded by the ring).  Nothing on the calling thread per tile but the queueing: a per-tile ftruncate /
+ * mmap / munmap there costs 2 - 3 ms each while the workers fault pages in (inode and address-space locks: measured 90 - 130 ms of
+ * the calling thread for an hour of audio, profiles/r05/io_sweep.json). */
 class ChunkWriter
 {
   struct Job { const unsigned char *bytes; size_t frames; hipEvent_t ready; int slot; bool raw; };
@@ -516,9 +530,10 @@ class ChunkWriter
   bool               m_region = false;
   int                m_fd = -1;
   uint64_t           m_offset = 0;     // file offset of the next tile's first byte
-  uint64_t           m_file_size = 0;  // what the file has been grown to
+  uint64_t           m_region_start = 0, m_region_bytes = 0;
   size_t             m_unit = 0, m_frames_placed = 0;
-  bool               m_use_map = true;
+  unsigned char     *m_map = nullptr;  // the sample bytes' range of the file, from the start of the page m_region_start lies in
+  size_t             m_map_delta = 0, m_map_len = 0;
   void
   note_error (const Error& err)
   {
@@ -556,23 +571,26 @@ class ChunkWriter
         m_cond.notify_all();
       }
   }
-  /* bytes [lo, hi) of a tile that starts at file offset `at`, through the mapping `map` (of the page containing `at` onwards) or pwrite */
-  static Error
-  place (int fd, unsigned char *map, size_t map_delta, uint64_t at, const unsigned char *src, size_t lo, size_t hi, bool populate)
+  /* bytes [lo, hi) of a tile that starts at file offset `at`: through the mapping, or (no mapping) with pwrite */
+  Error
+  place (uint64_t at, const unsigned char *src, size_t lo, size_t hi, bool populate)
   {
-    if (map)
+    if (m_map)
       {
-        // (one call instead of a trap per page; not available on every kernel / file system: ignored then)
-        const size_t a = (map_delta + lo) & ~size_t (4095);
+        unsigned char *dst = m_map + m_map_delta + (at - m_region_start);
         if (populate)
-          (void) madvise (map + a, map_delta + hi - a, MADV_POPULATE_WRITE);
-        std::memcpy (map + map_delta + lo, src + lo, hi - lo);
+          {
+            // (one call instead of a trap per page; not available on every kernel / file system: ignored then)
+            const uintptr_t a = reinterpret_cast<uintptr_t> (dst + lo) & ~uintptr_t (4095);
+            (void) madvise (reinterpret_cast<void *> (a), reinterpret_cast<uintptr_t> (dst + hi) - a, MADV_POPULATE_WRITE);
+          }
+        std::memcpy (dst + lo, src + lo, hi - lo);
         return Error::Code::NONE;
       }
     size_t n = lo;
     while (n < hi)
       {
-        const ssize_t r = pwrite (fd, src + n, hi - n, off_t (at + n));
+        const ssize_t r = pwrite (m_fd, src + n, hi - n, off_t (at + n));
         if (r < 0 && errno == EINTR)
           continue;
         if (r <= 0)
@@ -591,43 +609,19 @@ class ChunkWriter
     IoPool& pool = IoPool::get();
     const size_t n_parts = std::max<size_t> (1, std::min (pool.size(), n / IO_PART_MIN));
     const size_t part = ((n + n_parts - 1) / n_parts + 4095) & ~size_t (4095);
-    // grow the file over the tile, then map the tile's range (from the start of the page it begins in).  A mapping of a sparse
-    // range cannot report "no space left" -- it raises SIGBUS -- so the mapping is used only while the file system has room for
-    // the tile with a margin; otherwise (and where mmap is refused) the parts go through pwrite, which reports errors.
-    unsigned char *map = nullptr;
-    size_t map_delta = 0, map_len = 0;
-    bool grown = true;
-    if (at + n > m_file_size)
-      {
-        grown = ftruncate (m_fd, off_t (at + n)) == 0;
-        if (grown)
-          m_file_size = at + n;
-      }
-    if (grown && m_use_map)
-      {
-        struct statvfs vfs;
-        const bool room = fstatvfs (m_fd, &vfs) == 0 && uint64_t (vfs.f_bavail) * vfs.f_frsize > uint64_t (n) * 2 + (uint64_t (64) << 20);
-        if (room)
-          {
-            map_delta = size_t (at & 4095);
-            map_len = n + map_delta;
-            void *m = mmap (nullptr, map_len, PROT_READ | PROT_WRITE, MAP_SHARED, m_fd, off_t (at - map_delta));
-            if (m != MAP_FAILED)
-              map = static_cast<unsigned char *> (m);
-            else
-              m_use_map = false;
-          }
-      }
     {
       std::lock_guard<std::mutex> lock (m_mutex);
       m_busy[slot] = 1;
       m_parts[slot] = int (n_parts);
+      if (at + n > m_region_start + m_region_bytes)        // (more frames than announced: cannot happen through add_tiles / store)
+        note_error (Error ("output stream is longer than announced"));
     }
-    const int device = m_device, fd = m_fd;
+    const int device = m_device;
     const bool populate = (g_io_flags.load (std::memory_order_relaxed) & IO_POPULATE) != 0;
+    const bool inside = at + n <= m_region_start + m_region_bytes;
     auto write_part = [=] (size_t i) {
       const size_t lo = std::min (n, part * i), hi = std::min (n, part * (i + 1));
-      Error err = hi > lo ? place (fd, map, map_delta, at, bytes, lo, hi, populate) : Error (Error::Code::NONE);
+      Error err = hi > lo && inside ? place (at, bytes, lo, hi, populate) : Error (Error::Code::NONE);
       bool last;
       {
         std::lock_guard<std::mutex> lock (m_mutex);
@@ -636,8 +630,15 @@ class ChunkWriter
       }
       if (last)
         {
-          if (map)
-            (void) munmap (map, map_len);               // (before the slot is given back: bounds the mapped memory to the ring)
+          if (m_map && inside)
+            {
+              // the tile is in the page cache: drop its page table entries (whole pages inside the tile; the two edge pages are
+              // shared with the neighbouring tiles and go with the final munmap)
+              unsigned char *dst = m_map + m_map_delta + (at - m_region_start);
+              const uintptr_t a = (reinterpret_cast<uintptr_t> (dst) + 4095) & ~uintptr_t (4095), b = reinterpret_cast<uintptr_t> (dst + n) & ~uintptr_t (4095);
+              if (b > a)
+                (void) madvise (reinterpret_cast<void *> (a), b - a, MADV_DONTNEED);
+            }
           std::lock_guard<std::mutex> lock (m_mutex);
           m_busy[slot] = 0;
           m_cond.notify_all();
@@ -656,15 +657,33 @@ class ChunkWriter
     });
   }
 public:
-  ChunkWriter (AudioOutputStream *out, int n_slots, int device, bool raw, size_t unit_bytes)
+  /* total_frames: how many frames the caller is going to hand over (AudioInputStream::N_FRAMES_UNKNOWN: unknown -> stream order) */
+  ChunkWriter (AudioOutputStream *out, int n_slots, int device, bool raw, size_t unit_bytes, size_t total_frames)
     : m_out (out), m_channels (out->n_channels()), m_device (device), m_busy (n_slots, 0), m_parts (n_slots, 0), m_unit (unit_bytes)
   {
-    m_use_map = (g_io_flags.load (std::memory_order_relaxed) & IO_MAP_OUTPUT) != 0;
-    m_region = raw && (g_io_flags.load (std::memory_order_relaxed) & IO_REGIONS) != 0 && out->raw_region (m_fd, m_offset);
+    const int flags = g_io_flags.load (std::memory_order_relaxed);
+    m_region = raw && (flags & IO_REGIONS_OUT) != 0 && total_frames != AudioInputStream::N_FRAMES_UNKNOWN && total_frames > 0
+            && out->raw_region (m_fd, m_offset);
     if (m_region)
       {
+        m_region_start = m_offset;
+        m_region_bytes = uint64_t (total_frames) * unit_bytes;
+        // the file at its final length (sparse until the tiles arrive).  A mapping of a sparse range cannot report "no space
+        // left" -- it raises SIGBUS -- so the mapping is used only if the file system has room for the whole output with a
+        // margin now; otherwise (and where mmap is refused) the parts go through pwrite, which reports errors.
         struct stat st;
-        m_file_size = fstat (m_fd, &st) == 0 ? uint64_t (st.st_size) : 0;
+        const uint64_t have = fstat (m_fd, &st) == 0 ? uint64_t (st.st_size) : 0;
+        const bool grown = have >= m_region_start + m_region_bytes || ftruncate (m_fd, off_t (m_region_start + m_region_bytes)) == 0;
+        struct statvfs vfs;
+        const bool room = fstatvfs (m_fd, &vfs) == 0 && uint64_t (vfs.f_bavail) * vfs.f_frsize > m_region_bytes + (uint64_t (256) << 20);
+        if (grown && room && (flags & IO_MAP_OUTPUT))
+          {
+            m_map_delta = size_t (m_region_start & 4095);
+            m_map_len = size_t (m_region_bytes) + m_map_delta;
+            void *m = mmap (nullptr, m_map_len, PROT_READ | PROT_WRITE, MAP_SHARED, m_fd, off_t (m_region_start - m_map_delta));
+            if (m != MAP_FAILED)
+              m_map = static_cast<unsigned char *> (m);
+          }
       }
     else
       m_thread = std::thread ([this] { run(); });
@@ -701,6 +720,12 @@ public:
           std::unique_lock<std::mutex> lock (m_mutex);
           m_cond.wait (lock, [&] { for (int b : m_busy) if (b) return false; return true; });
         }
+        if (m_map)
+          (void) munmap (m_map, m_map_len);
+        m_map = nullptr;
+        if (m_frames_placed * m_unit < m_region_bytes)       // fewer frames than announced (a truncated input): the file ends with them
+          if (ftruncate (m_fd, off_t (m_region_start + m_frames_placed * m_unit)) != 0)
+            note_error (Error (string_printf ("write sample data failed (%s)", strerror (errno))));
         Error err = m_out->raw_region_written (m_frames_placed);
         note_error (err);
         return m_error;
@@ -728,37 +753,34 @@ struct OutputStage
   size_t unit = 0, chunk_frames;
   static constexpr int SLOTS = OUT_RING;
   hipStream_t copy = nullptr;
-  hipEvent_t  ev_encoded[SLOTS] = {}, ev_copied[SLOTS] = {};
-  PinnedBuffer host[SLOTS];
-  DevBuffer    dev[SLOTS];
+  hipEvent_t *ev_encoded = nullptr, *ev_copied = nullptr;
+  PinnedBuffer *host = nullptr;
+  DevBuffer    *dev = nullptr;
   std::unique_ptr<ChunkWriter> writer;
   size_t k = 0;
   bool ok = false;
-  OutputStage (awm_ctx *c, AudioOutputStream *o, size_t frames_per_chunk) : ctx (c), out (o), C (o->n_channels()), chunk_frames (frames_per_chunk)
+  OutputStage (awm_ctx *c, AudioOutputStream *o, size_t frames_per_chunk, size_t total_frames)
+    : ctx (c), out (o), C (o->n_channels()), chunk_frames (frames_per_chunk)
   {
     raw = out->raw_access (fmt, direct16) && device_codec_supported (fmt);
     unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
     copy = ctx->get_copy_stream();
-    ok = copy != nullptr;
+    FileStaging& fs = ctx->file_staging;
+    ok = copy != nullptr && fs.ensure_events();
+    ev_encoded = fs.out_encoded;
+    ev_copied = fs.out_copied;
+    host = fs.out_host;
+    dev = fs.out_dev;
     for (int i = 0; i < SLOTS && ok; i++)
-      ok = hipEventCreateWithFlags (&ev_encoded[i], hipEventDisableTiming) == hipSuccess
-        && hipEventCreateWithFlags (&ev_copied[i], hipEventDisableTiming) == hipSuccess
-        && host[i].reserve (chunk_frames * unit) == 0 && (!raw || dev[i].reserve (chunk_frames * unit) == 0);
+      ok = host[i].reserve (chunk_frames * unit) == 0 && (!raw || dev[i].reserve (chunk_frames * unit) == 0);
     if (ok)
-      writer = std::make_unique<ChunkWriter> (out, SLOTS, ctx->device, raw, unit);
+      writer = std::make_unique<ChunkWriter> (out, SLOTS, ctx->device, raw, unit, total_frames);
   }
   ~OutputStage()
   {
     writer.reset();
     if (copy)
-      (void) hipStreamSynchronize (copy);
-    for (int i = 0; i < SLOTS; i++)
-      {
-        if (ev_encoded[i]) (void) hipEventDestroy (ev_encoded[i]);
-        if (ev_copied[i]) (void) hipEventDestroy (ev_copied[i]);
-        host[i].release();
-        dev[i].release();
-      }
+      (void) hipStreamSynchronize (copy);                 // (the ring stays with the context)
   }
   /* n_frames <= chunk_frames of finished float32 samples at d_pcm (produced on ctx->stream) */
   bool
@@ -767,7 +789,11 @@ struct OutputStage
     if (!n_frames)
       return true;
     const int b = int (k++ % SLOTS);
-    writer->wait_slot (b);                       // host[b] written out; its copy and encode are long done
+    {
+      Lap lap;
+      writer->wait_slot (b);                     // host[b] written out; its copy and encode are long done
+      lap.to (2);
+    }
     bool good;
     if (raw)
       good = awm_pcm_encode_d (ctx, d_pcm, n_frames * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, direct16, dev[b].ptr) == 0
@@ -795,7 +821,7 @@ store_device_to_stream (awm_ctx *ctx, AudioOutputStream *out_stream, const float
     return Error::Code::NONE;
   const int C = out_stream->n_channels();
   const size_t n_frames = n_values / C;
-  OutputStage stage (ctx, out_stream, STAGE_FRAMES);
+  OutputStage stage (ctx, out_stream, STAGE_FRAMES, n_frames);
   if (!stage.ok)
     return Error ("out of memory for output staging");
   for (size_t pos = 0; pos < n_frames; pos += STAGE_FRAMES)
@@ -808,6 +834,7 @@ store_device_to_stream (awm_ctx *ctx, AudioOutputStream *out_stream, const float
 
 extern "C" void awm_set_io_threads (int n) { g_io_threads.store (n < 0 ? 0 : n, std::memory_order_relaxed); }
 extern "C" void awm_debug_set_io_flags (int flags) { g_io_flags.store (flags, std::memory_order_relaxed); }
+extern "C" void awm_debug_file_timing (double ms_out[8]) { for (int i = 0; i < 8; i++) ms_out[i] = tl_file_ms[i]; }
 
 namespace {
 
@@ -881,18 +908,24 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   const size_t tile = TILE_FRAMES1024 * Params::frame_size;
   const int C = in_stream->n_channels();
   n_frames = 0;
+  for (double& v : tl_file_ms)
+    v = 0;
+  Lap lap;
+  struct TeardownLap { Lap& l; ~TeardownLap() { l.to (6); } };
   awm_add_stream *add = nullptr;
   if (awm_add_stream_create (ctx, key.aes_key(), payload_hex.c_str(), C, TILE_FRAMES1024, &add))
     {
       error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
       return fail (AWM_ERR_HIP);
     }
+  TeardownLap teardown_lap { lap };                       // (declared before the guard and the rings: runs after their destructors)
   struct Guard { awm_add_stream *s; ~Guard() { awm_add_stream_destroy (s); } } guard { add };
   RawFormat fmt;
   const bool raw = in_stream->raw_access (fmt) && device_codec_supported (fmt);
   const size_t unit = raw ? size_t (C) * (fmt.bit_depth / 8) : size_t (C) * sizeof (float);
   TileReader rd (ctx, in_stream, raw, unit, tile, raw);
-  OutputStage stage (ctx, out_stream, tile);
+  // (the output is as long as the input: known for files and announced lengths, unknown for pipes -- those are written in order)
+  OutputStage stage (ctx, out_stream, tile, rd.ok ? rd.announced_frames() : AudioInputStream::N_FRAMES_UNKNOWN);
   if (!rd.ok || !stage.ok)
     {
       error ("audiowmark: out of memory for the staging buffers\n");
@@ -905,11 +938,13 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       return fail (AWM_ERR_HIP);
     }
   bool eof = false;
+  lap.to (0);
   for (size_t k = 0; !eof; k++)
     {
       int b = 0;
       size_t got = 0;
       Error err = rd.next (b, got);                        // (read ahead by the I/O workers / the reader thread)
+      lap.to (1);
       if (err)
         {
           error ("audiowmark: input stream read failed: %s\n", err.message());
@@ -942,6 +977,7 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
           error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
           return fail (AWM_ERR_HIP);
         }
+      lap.to (3);
       for (int i = 0; i < n_done; i++)
         {
           if (!stage.put (done[i], done_frames[i]))
@@ -950,6 +986,7 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
               return fail (AWM_ERR_HIP);
             }
         }
+      lap.to (7);                                          // (output tiles handed on: includes [2], the wait for a free slot)
       n_frames += got;
     }
   if (hipStreamSynchronize (ctx->stream) != hipSuccess)
@@ -957,7 +994,9 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       error ("audiowmark: GPU watermarking failed\n");
       return fail (AWM_ERR_HIP);
     }
+  lap.to (4);
   Error err = stage.finish();
+  lap.to (5);
   if (err)
     {
       error ("audiowmark output write failed: %s\n", err.message());
@@ -1214,13 +1253,14 @@ get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInput
                       size_t& n_values_out, const std::string& what)
 {
   const int C = in_stream->n_channels();
-  DevBuffer d_in;
+  // the stream's float32 PCM lives in a buffer the context keeps between calls (grow-only, like the workspaces: a hipMalloc of
+  // 1.3 GB per hour of audio costs 1 - 70 ms, its hipFree as much again)
+  DevBuffer& d_in = ctx->file_staging.pcm;
   size_t n_values = 0;
   Error err = load_stream_to_device (ctx, in_stream, d_in, n_values);
   if (err)
     {
       error ("audiowmark: error loading %s: %s\n", what.c_str(), err.message());
-      d_in.release();
       return fail (AWM_ERR_IO);
     }
   if (in_stream->sample_rate() != Params::mark_sample_rate)
@@ -1233,7 +1273,6 @@ get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInput
           || awm_resample_d (ctx, d_in.as<float>(), in_frames, C, in_stream->sample_rate(), Params::mark_sample_rate, d_res.as<float>(), out_frames))
         {
           error ("audiowmark: resampling from old_rate=%d to new_rate=%d not implemented\n", in_stream->sample_rate(), Params::mark_sample_rate);
-          d_in.release();
           d_res.release();
           return fail (AWM_ERR_ARG);
         }
@@ -1265,13 +1304,11 @@ get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInput
       if (rc)
         {
           error ("audiowmark: GPU detection failed: %s\n", awm_last_error());
-          d_in.release();
           return fail (AWM_ERR_HIP);
         }
     }
   else
     result_set.sort (key_list);
-  d_in.release();
   return 0;
 }
 

@@ -410,13 +410,20 @@ void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transfo
 void awm_debug_alloc_stats (long *dev_allocs, double *dev_ms, long *pinned_allocs, double *pinned_ms);
                                            /* process-wide census of hipMalloc / hipHostMalloc calls made by the library's grow-only buffers and the
                                             * time the runtime took for them (what a first call pays); any pointer may be NULL */
-void awm_debug_set_io_flags (int flags);   /* file level add / get, host side (host/wmfile.cc): bit 0 regular files are read / written by the I/O workers
-                                            * through the streams' raw_region (else one reader / writer thread in stream order, as for pipes) | bit 1 output
-                                            * through a shared mapping of the tile's range (else pwrite per part) | bit 2 MADV_POPULATE_WRITE before the
-                                            * copy into the mapping.  Default 7.  The bytes written are the same either way. */
+void awm_debug_file_timing (double ms_out[8]);
+                                           /* where the calling thread's time went in its last file level `add` at the watermark rate (milliseconds):
+                                            * [0] set-up (add stream, rings), [1] waiting for input tiles, [2] waiting for a free output slot, [3] queueing GPU
+                                            * work, [4] the final wait for the GPU, [5] the final wait for the writers, [6] tear-down, [7] handing output tiles on
+                                            * (includes [2]) */
+void awm_debug_set_io_flags (int flags);   /* file level add / get, host side (host/wmfile.cc): bit 0 regular INPUT files are read by the I/O workers through the
+                                            * stream's raw_region (else one reader thread in stream order, as for pipes) | bit 3 regular OUTPUT files of known
+                                            * length are written by the workers (else one writer thread in stream order) -- then bit 1: through ONE shared mapping
+                                            * of the file (else pwrite per part), bit 2: MADV_POPULATE_WRITE before the copy.  Default 1: creating the pages of
+                                            * one file is serial in the kernel, the writer thread is at that floor (profiles/r05/io_probe.txt); the bytes written
+                                            * are the same either way. */
 
 /* Host threads that copy between the page cache and the page-locked staging rings of the file level calls (awm_add_watermark_file,
- * awm_get_watermark_file, the command line): 0 (default) = min (8, cores); one pool per process.  The reference reads and writes on
+ * awm_get_watermark_file, the command line): 0 (default) = min (16, cores); one pool per process.  The reference reads and writes on
  * its one thread (wavchunkloader.cc:196-222, rawconverter.cc, stdoutwavoutputstream.cc). */
 void awm_set_io_threads (int n);
 

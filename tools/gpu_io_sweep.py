@@ -46,13 +46,20 @@ def main():
     s0 = alloc_stats(awm)
     t0 = time.perf_counter(); ctx.add_watermark_file(None, PAY, src, dst, rf, rf); t_first_add = time.perf_counter() - t0
     s1 = alloc_stats(awm)
+    timing0 = (C.c_double * 8)()
+    awm.lib.awm_debug_file_timing(timing0)
     t0 = time.perf_counter(); pats = ctx.get_watermark_file(None, dst, rf); t_first_get = time.perf_counter() - t0
     s2 = alloc_stats(awm)
-    out["first_calls"] = {"add_file_ms": round(t_first_add * 1e3, 2), "add_allocs": delta(s0, s1), "get_file_ms": round(t_first_get * 1e3, 2), "get_allocs": delta(s1, s2)}
+    out["first_calls"] = {"add_file_ms": round(t_first_add * 1e3, 2), "add_allocs": delta(s0, s1), "add_calling_thread_ms": [round(v, 2) for v in timing0], "get_file_ms": round(t_first_get * 1e3, 2), "get_allocs": delta(s1, s2)}
     ref_md5 = hashlib.md5(open(dst, "rb").read()).hexdigest()
     ref_pats = [(p["sync_index"], p["bits"]) for p in pats]
-    for flags, what in ((7, "regions + mmap + populate"), (3, "regions + mmap"), (1, "regions + pwrite"), (0, "one reader / one writer thread")):
-        for threads in ((2, 4, 6, 8, 12, 16) if flags else (8,)):
+    quick = len(sys.argv) > 2 and sys.argv[2] == "quick"
+    t0 = time.perf_counter(); os.remove(dst); out["remove_output_file_ms"] = round((time.perf_counter() - t0) * 1e3, 2)
+    timing = (C.c_double * 8)()
+    names = ["setup", "wait_input", "wait_output_slot", "queue_gpu_work", "final_gpu_wait", "final_writer_wait", "teardown", "hand_on_output_incl_slot_wait"]
+    for flags, what in ((1, "input by the workers, one writer thread (default)"), (15, "input + output by the workers: one shared mapping + populate"),
+                        (11, "input + output by the workers: one shared mapping"), (9, "input + output by the workers: pwrite"), (0, "one reader / one writer thread")):
+        for threads in (((8, 16) if quick else (2, 4, 8, 12, 16)) if flags else (8,)):
             awm.lib.awm_set_io_threads(threads)
             awm.lib.awm_debug_set_io_flags(flags)
             best_add = best_get = None
@@ -64,15 +71,19 @@ def main():
                 t1 = time.perf_counter()
                 pats = ctx.get_watermark_file(None, dst, rf)
                 t2 = time.perf_counter()
+                if best_add is None or t1 - t0 < best_add:
+                    awm.lib.awm_debug_file_timing(timing)
+                    where = {n: round(timing[i], 2) for i, n in enumerate(names)}
                 best_add = t1 - t0 if best_add is None else min(best_add, t1 - t0)
                 best_get = t2 - t1 if best_get is None else min(best_get, t2 - t1)
             same = hashlib.md5(open(dst, "rb").read()).hexdigest() == ref_md5 and [(p["sync_index"], p["bits"]) for p in pats] == ref_pats
             rec = {"mode": what, "flags": flags, "threads": threads, "add_file_ms": round(best_add * 1e3, 2), "get_file_ms": round(best_get * 1e3, 2),
-                   "file_to_file_xRT": round(minutes * 60 / (best_add + best_get), 1), "output_and_patterns_identical": bool(same)}
+                   "file_to_file_xRT": round(minutes * 60 / (best_add + best_get), 1), "output_and_patterns_identical": bool(same),
+                   "add_calling_thread_ms": where}
             out["runs"].append(rec)
             print(rec, flush=True)
     awm.lib.awm_set_io_threads(0)
-    awm.lib.awm_debug_set_io_flags(7)
+    awm.lib.awm_debug_set_io_flags(1)
     # the command line with timing marks (process start, HIP runtime up, context ready, command done)
     cli = os.path.join(ROOT, "audiowmark_amd", "audiowmark")
     fmt = ["--format", "raw", "--raw-rate", str(RATE), "--raw-channels", "2", "--raw-bits", "16"]
@@ -85,7 +96,8 @@ def main():
             t0 = time.perf_counter()
             r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
             wall = (time.perf_counter() - t0) * 1e3
-            m = {l.split()[1]: float(l.split()[2]) for l in r.stderr.decode().splitlines() if l.startswith("awm_timing")}
+            m = {l.split()[1]: float(l.split()[2]) for l in r.stderr.decode().splitlines() if l.startswith("awm_timing") and "add_calling_thread" not in l}
+            m["add_calling_thread"] = [l.split(None, 2)[2] for l in r.stderr.decode().splitlines() if "add_calling_thread" in l]
             m["wall_ms_incl_exec"] = round(wall, 2)
             m["rc"] = r.returncode
             if best is None or wall < best["wall_ms_incl_exec"]:

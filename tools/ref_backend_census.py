@@ -18,6 +18,7 @@ Both backends run `SyncFinder::search` (BLOCK mode) on every piece; every sync s
       -> profiles/r05/ref_backend_census.json  (summary + every differing position + the complete score lists of both backends)
 """
 import concurrent.futures
+import hashlib
 import json
 import multiprocessing
 import os
@@ -81,7 +82,11 @@ def work(item):
     t0 = time.perf_counter()
     w = watermarked_piece(kind, piece).ravel()
     t_gen = time.perf_counter() - t0
-    res = {"kind": kind, "piece": piece}
+    # md5 of the 16 bit samples: tools/gpu_census_three_way.py regenerates the piece on the GPU box and compares the HIP detector with
+    # BOTH lists below only if it holds the same bytes
+    import hashlib
+    md5 = hashlib.md5(np.round(w.astype(np.float64) * 32768.0).astype(np.int16).tobytes()).hexdigest()
+    res = {"kind": kind, "piece": piece, "md5_int16": md5}
     for backend in ("double", "mkl"):
         _ref.use_backend(backend)
         t0 = time.perf_counter()
