@@ -381,14 +381,19 @@ def _hip_memcpy_dtod(ctx, dst, src, nbytes):
     _as_tensor(dst, nbytes).copy_(_as_tensor(src, nbytes))       # views over raw device pointers; torch's current stream == ctx stream
 
 
-def _as_tensor(ptr, nbytes):
+def _as_tensor(ptr, nbytes, device=None):
+    """uint8 VIEW over raw device memory (no copy).  `device`: the torch device the memory lives on (default: the current one) -- a view
+    created under another current device would silently become a copy, and bytes received into it would never reach the buffer."""
     import torch
 
     class _Iface:
         pass
     o = _Iface()
     o.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
-    return torch.as_tensor(o, device="cuda")
+    t = torch.as_tensor(o, device=device if device is not None else "cuda")
+    if nbytes and t.data_ptr() != int(ptr):
+        raise AwmError("_as_tensor: torch copied the buffer instead of viewing it (wrong device?)")
+    return t
 
 
 # ---- device side ---------------------------------------------------------------------------

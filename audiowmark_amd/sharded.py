@@ -108,7 +108,7 @@ class TorchComm:
 
     def _view(self, ptr, nbytes, on_device):
         if on_device and not self.host_only:
-            return awm._as_tensor(ptr, nbytes)
+            return awm._as_tensor(ptr, nbytes, self.device)
         return self.torch.frombuffer((C.c_ubyte * nbytes).from_address(ptr), dtype=self.torch.uint8)
 
     def _ctx_stream(self):

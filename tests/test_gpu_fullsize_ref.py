@@ -184,6 +184,59 @@ def test_130min_stereo_five_chunks_equal_reference(gpu):
     print("130 min:", rep)
 
 
+# BASELINE configs[3] holds the ONE refinement tie of the full-size configurations: in chunk 9 (4 h 28 min into the stream) the block the
+# reference build of oracle/_ref (double-precision FFT) puts at sync index 48 075 408 of its chunk is found at 48 075 400 here -- neighbouring
+# fine offsets with qualities 1.8e-6 apart; `search_refine` keeps the first strictly better one (syncfinder.cc:441).  The reference does
+# the same to ITSELF when only its FFT library changes: its double-FFT build and its MKL float-FFT build (oracle/Makefile: ref, ref_mkl)
+# pick different fine offsets for 1 block in 1630 on byte-identical input, with qualities up to 3.9e-6 apart
+# (tools/ref_backend_census.py -> profiles/r05/ref_backend_census.json; this detector against either build:
+# profiles/r05/census_three_way.json).  The tie is pinned: that block, 8 samples, its AB pair -- anything else fails.
+KNOWN_8H_TIE = {"ours": 48075400, "reference": 48075408, "max_pattern_lines": 3}
+
+
+def test_config3_8h_stereo_equal_reference(gpu):
+    """BASELINE.json configs[3] at FULL size on one GPU: 8 h stereo 44.1 kHz (18 reference chunks), watermarked by the REFERENCE, decoded
+    by both detectors from the same samples: the complete pattern list (836 lines) -- payload bits everywhere, sync index and types
+    everywhere except the one pinned tie; the HIP `add` of the same 8 h against the reference's PCM; the multi-GPU protocol with 2
+    contexts on the one device equal to the single-GPU list.  (~3.5 minutes: the reference's `add` + `get` of 8 h on the host cores.)"""
+    from audiowmark_amd import sharded
+    n = 8 * 3600 * 44100
+    x = quantise16(gpu.awm.binding.gen_noise(None, 2 * n))
+    t0 = time.perf_counter()
+    ref_w = _ref.add(None, x, 2, PAY1)
+    t1 = time.perf_counter()
+    ref_pats = _ref.get(None, ref_w, 2)
+    t2 = time.perf_counter()
+    assert len(gpu.awm.plan_chunks(n)) == 18
+    wd = gpu.dev(ref_w)
+    got = gpu.ctx.get_watermark(None, wd)
+    rep = compare_patterns(got, ref_pats, "configs[3] 8 h get", max_ties=KNOWN_8H_TIE["max_pattern_lines"])
+    moved = sorted({(g["sync_index"], w["sync_index"]) for g, w in zip(got, ref_pats) if g["sync_index"] != w["sync_index"]})
+    assert moved in ([], [(KNOWN_8H_TIE["ours"], KNOWN_8H_TIE["reference"])]), f"sync positions beside the reference's other than the pinned tie: {moved}"
+    matches = sum(p["bits"] == PAY1 for p in got)
+    assert matches == len(got) == len(ref_pats) and matches >= 830            # 557 blocks + AB pairs + 18 "all" patterns, no n_best filler
+    # the HIP add of the same 8 h
+    w = gpu.ctx.add_watermark(None, PAY1, gpu.dev(x))
+    del x
+    r, m = rms_max(w.cpu().numpy(), ref_w)
+    assert r < RMS_TOL and m < 4e-6, f"8 h embedded PCM differs from the reference: rms {r}, max {m}"
+    del w, ref_w
+    # the multi-GPU protocol: the stream in two spans on two contexts of this device == the single-GPU list, to the last bit
+    ctx2 = gpu.awm.Context(0)
+    try:
+        per = (n // 2) // 1024 * 1024
+        multi = sharded.multi_get([gpu.ctx, ctx2], None, [wd[:per], wd[per:]], max_out=8192)
+    finally:
+        ctx2.close()
+    full = lambda p: pkey(p) + (p["sync_quality"], p["decode_error"])
+    assert [full(p) for p in multi] == [full(p) for p in got]
+    rep.update({"single_blocks": sum(1 for p in ref_pats if p["type"] == 0 and p["block_type"] < 2), "moved_blocks": moved, "pcm_rms": r, "pcm_max_abs": m,
+                "payload_matches": matches, "chunks": 18, "awm_multi_get_d_2_contexts_equal_to_single": True,
+                "reference_add_s": round(t1 - t0, 2), "reference_get_s": round(t2 - t1, 2), "reference_threads": os.cpu_count()})
+    REPORT["config3_8h_stereo"] = rep
+    print("configs[3]:", rep)
+
+
 def test_config2_60min_48k_detect_speed_equal_reference(gpu):
     """BASELINE.json configs[2]: 60 min stereo 48 kHz, watermarked at 48 kHz, replayed 2 % fast, `get --detect-speed`.
     `add` at 48 kHz is compared with the reference's WatermarkResampler path (wmadd.cc:353-430); the replay (the attacker's

@@ -65,8 +65,11 @@ def main():
     import audiowmark_amd as awm
     import _ref
     assert _ref.available(), "oracle/_ref is not built"
-    with open(os.path.join(ROOT, "profiles", "r05", "ref_backend_census_scores.json")) as f:
-        recorded = {(r["kind"], r["piece"]): r for r in json.load(f)}
+    import glob
+    recorded = {}
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "ref_backend_census_scores*.json"))):     # (every batch of the census)
+        with open(path) as f:
+            recorded.update({(r["kind"], r["piece"]): r for r in json.load(f)})
     items = [k for k in recorded if k[0] != "testgen_8h"]
     t_all = time.perf_counter()
     if with_8h and any(k[0] == "testgen_8h" for k in recorded):

@@ -14,7 +14,7 @@ Material, every piece 30 minutes of stereo 44.1 kHz, watermarked by the referenc
      numpy's PCG64 with a seed per piece (so tools/gpu_census_three_way.py regenerates the same bytes on the GPU box).
 Both backends run `SyncFinder::search` (BLOCK mode) on every piece; every sync score pair is compared.
 
-  python tools/ref_backend_census.py [pieces per synthetic kind = 8] [workers = 6] [skip_8h = 0]
+  python tools/ref_backend_census.py [pieces per synthetic kind = 8] [workers = 6] [skip_8h = 0] [first piece = 0]
       -> profiles/r05/ref_backend_census.json  (summary + every differing position + the complete score lists of both backends)
 """
 import concurrent.futures
@@ -125,6 +125,7 @@ def main():
     pieces = int(sys.argv[1]) if len(sys.argv) > 1 else 8
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     skip_8h = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
+    first_piece = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # a second batch: other seeds, results into *_from<N>.json
     os.environ.setdefault("MKL_THREADING_LAYER", "SEQUENTIAL")
     os.environ["AWM_REF_THREADS"] = "1"
     import _ref
@@ -142,7 +143,8 @@ def main():
         timing["testgen_8h_generate_and_reference_add_s"] = round(time.perf_counter() - t0, 1)
         print("8 h stream ready", timing, flush=True)
         items += [("testgen_8h", p) for p in range(16)]
-    items += [(k, p) for p in range(pieces) for k in KINDS]
+    items += [(k, p) for p in range(first_piece, first_piece + pieces) for k in KINDS]
+    suffix = "_from%d" % first_piece if first_piece else ""
     out = {}
     lists = []
     t0 = time.perf_counter()
@@ -172,9 +174,9 @@ def main():
                        "(double-precision FFT rounded once vs MKL's float FFTW wrapper); a tie = same block type, sync index <= 16 samples "
                        "apart, qualities < 1e-5 apart"}
     os.makedirs(os.path.join(ROOT, "profiles", "r05"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", "r05", "ref_backend_census.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r05", "ref_backend_census%s.json" % suffix), "w") as f:
         json.dump({"summary": summary, "materials": out, "timing": timing, "piece_minutes": 30, "payload": PAY}, f, indent=1)
-    with open(os.path.join(ROOT, "profiles", "r05", "ref_backend_census_scores.json"), "w") as f:
+    with open(os.path.join(ROOT, "profiles", "r05", "ref_backend_census_scores%s.json" % suffix), "w") as f:
         json.dump(lists, f, separators=(",", ":"))
     print(json.dumps(summary))
 
