@@ -120,3 +120,78 @@ def test_file_wav_in_wav_out(gpu, tmp_path):
     want = gpu.ctx.pcm_encode(gpu.ctx.add_watermark(None, PAY, x_file).reshape(-1), 16, 0, False, False).cpu().numpy()
     assert np.array_equal(out[44:], want)
     assert any(p["bits"] == PAY for p in gpu.ctx.get_watermark_file(None, dst))
+
+
+def _wav(pcm_bytes, announce=None, channels=2, rate=44100, bits=16):
+    import struct
+    n = len(pcm_bytes) if announce is None else announce
+    return b"RIFF" + struct.pack("<I", 36 + n) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, channels, rate, rate * channels * bits // 8, channels * bits // 8, bits) \
+        + b"data" + struct.pack("<I", n) + pcm_bytes
+
+
+def test_file_io_modes_write_the_same_bytes(gpu, tmp_path):
+    """host side of the file level calls (host/wmfile.cc): input by the I/O workers through AudioInputStream::raw_region (pread of tile
+    parts, read ahead of the GPU) or by one reader thread; output by one writer thread or by the workers (one shared mapping of the
+    output / pwrite) -- every combination, with 3 and 16 workers, writes the file of the default mode byte for byte: a 16 bit WAV (a
+    44 byte header: no tile starts on a page boundary of the file) of 500 s = 6 tiles; `get` of it finds the same patterns in every mode"""
+    awm, t = gpu.awm, gpu.torch
+    n = 500 * 44100 + 77
+    x = noise(gpu, n, 2, 21) * 0.9
+    pcm = gpu.ctx.pcm_encode(x.reshape(-1), 16, 0, False, True).cpu().numpy().tobytes()
+    src = tmp_path / "in.wav"
+    src.write_bytes(_wav(pcm))
+    ref_bytes = ref_pats = None
+    key = lambda p: (round(p["time"], 6), p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
+    try:
+        for threads in (0, 3, 16):
+            for flags in (1, 0, 9, 11, 15):
+                awm.lib.awm_set_io_threads(threads)
+                awm.lib.awm_debug_set_io_flags(flags)
+                dst = tmp_path / f"out_{threads}_{flags}.wav"
+                gpu.ctx.add_watermark_file(None, PAY, src, dst)
+                data = dst.read_bytes()
+                pats = [key(p) for p in gpu.ctx.get_watermark_file(None, dst)]
+                if ref_bytes is None:
+                    ref_bytes, ref_pats = data, pats
+                    assert len(data) == 44 + len(pcm) and any(p[4] == PAY for p in pats)
+                assert data == ref_bytes, (threads, flags)
+                assert pats == ref_pats, (threads, flags)
+                dst.unlink()
+    finally:
+        awm.lib.awm_set_io_threads(0)
+        awm.lib.awm_debug_set_io_flags(1)
+
+
+def test_file_shorter_than_its_header_says_and_input_from_a_pipe(gpu, tmp_path):
+    """a WAV file cut off in the middle (the header announces 300 s, the file holds 211.3 s): `add` writes what it got -- the samples of the
+    whole-buffer path for those frames -- in every I/O mode; the same stream through a FIFO (length unknown to the reader: the ordered
+    reader / writer threads) gives the same sample bytes"""
+    import threading
+    awm, t = gpu.awm, gpu.torch
+    n_full, n_have = 300 * 44100, int(211.3 * 44100)
+    x = noise(gpu, n_have, 2, 23) * 0.9
+    pcm = gpu.ctx.pcm_encode(x.reshape(-1), 16, 0, False, True).cpu().numpy().tobytes()
+    src = tmp_path / "cut.wav"
+    src.write_bytes(_wav(pcm, announce=n_full * 4))
+    x_file = gpu.ctx.pcm_decode(t.from_numpy(np.frombuffer(pcm, np.uint8).copy()).cuda(), 16, 0, False).reshape(n_have, 2)
+    want = gpu.ctx.pcm_encode(gpu.ctx.add_watermark(None, PAY, x_file).reshape(-1), 16, 0, False, False).cpu().numpy().tobytes()
+    try:
+        for flags in (1, 0, 15):
+            awm.lib.awm_debug_set_io_flags(flags)
+            dst = tmp_path / f"cut_out_{flags}.wav"
+            gpu.ctx.add_watermark_file(None, PAY, src, dst)
+            out = dst.read_bytes()
+            assert out[44:] == want, flags
+    finally:
+        awm.lib.awm_debug_set_io_flags(1)
+    # a FIFO as input (raw samples): the reader thread, output of unknown length
+    fifo = tmp_path / "in.fifo"
+    os.mkfifo(fifo)
+    feeder = threading.Thread(target=lambda: open(fifo, "wb").write(pcm))
+    feeder.start()
+    rf = awm.binding.RawFormat(2, 44100, 16, 0, 0)
+    dst = tmp_path / "fifo_out.raw"
+    gpu.ctx.add_watermark_file(None, PAY, fifo, dst, rf, rf)
+    feeder.join()
+    want_raw = gpu.ctx.pcm_encode(gpu.ctx.add_watermark(None, PAY, x_file).reshape(-1), 16, 0, False, True).cpu().numpy().tobytes()
+    assert dst.read_bytes() == want_raw
