@@ -117,6 +117,7 @@ lib.awm_block_soft_bits_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, _vp, C
 lib.awm_viterbi_decode.argtypes = [_vp, C.c_int, _vp, C.c_size_t, C.c_size_t, _vp, _vp]
 lib.awm_add_watermark_d.argtypes = [_vp, _vp, C.c_char_p, _vp, _vp, C.c_size_t, C.c_int, C.c_int]
 lib.awm_get_watermark_d.argtypes = [_vp, _vp, _vp, C.c_size_t, C.c_int, C.c_size_t, _vp]
+lib.awm_add_get_watermark_d.argtypes = [_vp, _vp, C.c_char_p, _vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_size_t, _vp]
 lib.awm_resample_frames.argtypes = [_vp, C.c_size_t, C.c_int, C.c_int]
 lib.awm_resample_frames.restype = C.c_size_t
 lib.awm_resample_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, C.c_int, C.c_int, _vp, C.c_size_t]
@@ -742,6 +743,14 @@ class Context:
     def get_watermark(self, key, pcm):
         n, ch = _pcm_shape(pcm)
         return self._patterns(lib.awm_get_watermark_d, "awm_get_watermark_d", self._h, key_bytes(key), _dev_ptr(pcm), n, ch)
+
+    def add_get_watermark(self, key, payload_hex, pcm, out, sample_rate=44100):
+        """awm_add_get_watermark_d: add_watermark into `out`, then get_watermark of `out`, as one call (`get` starts a chunk as soon as
+        the limiter has passed it); returns the pattern list -- the results of the two separate calls."""
+        n, ch = _pcm_shape(pcm)
+        assert _pcm_shape(out) == (n, ch) and out.data_ptr() != pcm.data_ptr()
+        return self._patterns(lib.awm_add_get_watermark_d, "awm_add_get_watermark_d", self._h, key_bytes(key), payload_hex.encode(),
+                              _dev_ptr(pcm), _dev_ptr(out), n, ch, sample_rate)
 
     def set_params(self, params=None, **kw):
         """Give this context its own parameter set (awm_ctx_set_params): a Params object, or the fields that differ from what is

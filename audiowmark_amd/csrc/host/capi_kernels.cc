@@ -266,10 +266,16 @@ extern "C" void awm_debug_set_add_slab_mb (int mb) { g_add_slab_mb = mb < 0 ? 0 
 /* whole stream on one lane (stream + block maxima + limiter table of that lane; the context itself is lane 0) */
 static int
 add_full (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, int n_channels,
-          const int8_t *frame_mod_dev, double water_delta, int use_limiter, WorkLane *lane = nullptr)
+          const int8_t *frame_mod_dev, double water_delta, int use_limiter, WorkLane *lane = nullptr, ReadyMarks *marks = nullptr)
 {
   if (!lane)
     lane = ctx;
+  if (marks)
+    {
+      marks->disarm();
+      marks->base = out_d;
+      marks->n_frames = n_frames;
+    }
   hipStream_t st = lane->stream;
   float *block_max = nullptr;
   const size_t n_blocks = n_frames / LIMITER_BLOCK + 2;
@@ -316,14 +322,60 @@ add_full (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frames, in
   if (int rc = add_mix_impl (ctx, pcm_in_d, out_d, n_frames, n_channels, frame_mod_dev, water_delta, 0, nullptr, nullptr,
                              block_max, 0, n_blocks, lane))
     return rc;
+  // With marks (awm_add_get_watermark_d) the limiter runs in one pass per range of `get`'s chunk ends (every block maximum is known
+  // after the mix: a pass needs nothing from the passes after it) and leaves an event behind each: the chunk that ends there may start.
+  std::vector<size_t> ends;
+  if (marks)
+    for (const ChunkRange& c : plan_chunks (n_frames, n_channels))
+      {
+        size_t e = std::min (n_frames, (c.first_frame + c.n_frames + LIMITER_BLOCK - 1) / LIMITER_BLOCK * size_t (LIMITER_BLOCK));
+        if (e < n_frames && n_frames - e < size_t (LIMITER_BLOCK))          // (no sliver of a last pass)
+          e = n_frames;
+        if (ends.empty() || e > ends.back())
+          ends.push_back (e);
+      }
+  if (ends.empty() || ends.back() != n_frames)
+    ends.push_back (n_frames);
   if (use_limiter)
     {
       const size_t tab_entries = awmk::limiter_tab_entries ((long long) n_frames, 0, LIMITER_BLOCK);
       if (int rc = lane->ws_limit_tab.reserve ((tab_entries + 1) * sizeof (float2))) return rc;
-      ProfScope ps (ctx, PROF_LIMITER, double (n_frames) * n_channels * 8.0, st);
-      AWM_HIP_CHECK (awmk::launch_limiter (st, out_d, (long long) n_frames, n_channels, 0, block_max, 0, (long long) n_blocks, LIMITER_BLOCK,
-                                           LIMITER_CEILING, lane->ws_limit_tab.as<float2>(), tab_entries));
+      size_t limited = 0;
+      for (size_t e : ends)
+        {
+          {
+            ProfScope ps (ctx, PROF_LIMITER, double (e - limited) * n_channels * 8.0, st);
+            // (the passes share the lane's ramp table: they run in stream order, a pass rebuilds the entries of its own blocks)
+            AWM_HIP_CHECK (awmk::launch_limiter (st, out_d + limited * n_channels, (long long) (e - limited), n_channels, (long long) limited, block_max, 0,
+                                                 (long long) n_blocks, LIMITER_BLOCK, LIMITER_CEILING, lane->ws_limit_tab.as<float2>(), tab_entries));
+          }
+          limited = e;
+          if (marks)
+            {
+              hipEvent_t ev = marks->next_event();
+              if (!ev)
+                {
+                  set_error ("cannot create an event");
+                  return AWM_ERR_HIP;
+                }
+              AWM_HIP_CHECK (hipEventRecord (ev, st));
+              marks->marks.push_back ({ e, ev });
+            }
+        }
     }
+  else if (marks)
+    {
+      hipEvent_t ev = marks->next_event();
+      if (!ev)
+        {
+          set_error ("cannot create an event");
+          return AWM_ERR_HIP;
+        }
+      AWM_HIP_CHECK (hipEventRecord (ev, st));
+      marks->marks.push_back ({ n_frames, ev });
+    }
+  if (marks)
+    marks->armed = true;
   return 0;
 }
 
@@ -882,6 +934,56 @@ awm_add_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_he
   if (sample_rate != Params::mark_sample_rate)
     return add_full_rate (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), params().water_delta, !params().test_no_limiter, sample_rate);
   return add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), params().water_delta, !params().test_no_limiter);
+}
+
+/* add_watermark followed by get_watermark of its output ("watermark, then verify") as ONE call: the library owns the order of the two
+ * halves, so `get` may start chunk c as soon as the limiter has passed the chunk's last sample -- its first dB kernel (bound by FP32
+ * issue) runs beside the limiter passes of the later ranges (bound by HBM) -- instead of behind the whole `add`, which is all that two
+ * separate calls on the caller's stream can promise.  PCM and pattern list are those of the two calls (tests). */
+int
+awm_add_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const float *pcm_in_d, float *out_d,
+                         size_t n_frames, int n_channels, int sample_rate, size_t max_out, awm_pattern *out)
+{
+  AWM_ENTER (ctx);
+  if (max_out && !out)
+    {
+      set_error ("awm_add_get_watermark_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  FrameModTable *fm = ctx->get_frame_mod (capi_key (key), payload_hex ? payload_hex : "");
+  if (!fm)
+    return AWM_ERR_ARG;
+  int rc;
+  const bool hand_over = sample_rate == Params::mark_sample_rate && pcm_in_d != out_d && !g_add_slab_mb && n_frames > 0;
+  if (sample_rate != Params::mark_sample_rate)
+    rc = add_full_rate (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), params().water_delta, !params().test_no_limiter, sample_rate);
+  else
+    rc = add_full (ctx, pcm_in_d, out_d, n_frames, n_channels, fm->dev.as<int8_t>(), params().water_delta, !params().test_no_limiter, nullptr,
+                   hand_over ? &ctx->ready : nullptr);
+  if (rc)
+    {
+      ctx->ready.disarm();
+      return rc;
+    }
+  ResultSet rs;
+  if (sample_rate != Params::mark_sample_rate)
+    {
+      // the reference's loader resamples to the watermark rate before anything else (wavchunkloader.cc:70-71)
+      const size_t n44 = awm_resample_frames (ctx, n_frames, sample_rate, Params::mark_sample_rate);
+      if (n_frames && !n44)
+        return AWM_ERR_ARG;
+      if (int r = ctx->ws_rate_c.reserve (std::max<size_t> (1, n44 * n_channels * sizeof (float)))) return r;
+      if (int r = awm_resample_d (ctx, out_d, n_frames, n_channels, sample_rate, Params::mark_sample_rate, ctx->ws_rate_c.as<float>(), n44)) return r;
+      rc = get_watermark_device (ctx, { capi_key (key) }, make_wav (ctx->ws_rate_c.as<float>(), n44, n_channels), rs);
+    }
+  else
+    rc = get_watermark_device (ctx, { capi_key (key) }, make_wav (out_d, n_frames, n_channels), rs);
+  ctx->ready.disarm();
+  if (rc)
+    return rc;
+  for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
+    fill_pattern (rs.patterns[i], out[i]);
+  return int (rs.patterns.size());
 }
 
 /* add_watermark for many independent inputs with one key and payload (BASELINE config 5: a batch of short clips).  A 30 s clip

@@ -108,6 +108,28 @@ awm_debug_alloc_stats (long *dev_allocs, double *dev_ms, long *pinned_allocs, do
   if (pinned_ms) *pinned_ms = awm::g_pin_alloc_ms.load();
 }
 
+hipEvent_t
+awm::ReadyMarks::next_event()
+{
+  if (used == pool.size())
+    {
+      hipEvent_t e = nullptr;
+      if (hipEventCreateWithFlags (&e, hipEventDisableTiming) != hipSuccess)
+        return nullptr;
+      pool.push_back (e);
+    }
+  return pool[used++];
+}
+
+void
+awm::ReadyMarks::release()
+{
+  disarm();
+  for (hipEvent_t e : pool)
+    (void) hipEventDestroy (e);
+  pool.clear();
+}
+
 bool
 awm::FileStaging::ensure_events()
 {
@@ -725,6 +747,7 @@ awm_ctx_destroy (awm_ctx *ctx)
   if (ctx->copy_stream)
     (void) hipStreamSynchronize (ctx->copy_stream);
   ctx->file_staging.release();
+  ctx->ready.release();
   if (ctx->copy_stream)
     (void) hipStreamDestroy (ctx->copy_stream);
   if (ctx->own_stream && ctx->stream)

@@ -160,6 +160,22 @@ struct FileStaging
   void         release();
 };
 
+// awm_add_get_watermark_d ("watermark, then verify"): `add` leaves marks on the context's stream -- the limiter has passed sample
+// `upto` of the output -- so that `get` of the same buffer can start a chunk behind ITS mark instead of behind the whole add.  Only
+// the fused entry point arms them: two separate calls cannot know what the caller queued on the stream in between.
+struct ReadyMarks
+{
+  const float *base = nullptr;           // the output buffer the marks belong to
+  size_t       n_frames = 0;
+  bool         armed = false;
+  std::vector<std::pair<size_t, hipEvent_t>> marks;    // (samples per channel that are final, event) in stream order
+  std::vector<hipEvent_t> pool;          // events kept between calls
+  size_t       used = 0;
+  hipEvent_t   next_event();             // nullptr on failure
+  void         disarm() { armed = false; marks.clear(); used = 0; base = nullptr; n_frames = 0; }
+  void         release();
+};
+
 struct FrameModTable
 {
   std::vector<unsigned char> key;
@@ -217,6 +233,7 @@ struct awm_ctx : awm::WorkLane
   std::unique_ptr<awm::WorkLane> extra_lanes[awm::MAX_LANES - 1];
   awm::WorkLane *lane (int i);           // 0 = the context itself; others are created on first use (nullptr on failure)
   awm::FileStaging file_staging;         // rings + whole-stream buffer of the file level calls (grow-only, like the workspaces)
+  awm::ReadyMarks ready;                 // add -> get hand-over of awm_add_get_watermark_d
   hipStream_t    copy_stream = nullptr;  // H2D / D2H staging of the file level paths (created on first use)
   hipStream_t    get_copy_stream();
   std::vector<awm_ctx *> helpers;        // other GPUs the file level `get` may spread a long stream over (awm_ctx_set_helpers; not owned)

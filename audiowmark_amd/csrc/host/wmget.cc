@@ -597,7 +597,14 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
           }
         lanes.push_back (l);
       }
-  if (lanes.size() > 1 && lane_base == 0)
+  // awm_add_get_watermark_d: the stream is the output of the `add` this call queued, with marks "final up to sample n" on the
+  // context's stream -- a chunk starts behind the mark that covers its last sample.  The context's own stream (lane 0) is behind
+  // the whole add anyway: it gets the LAST of the first round of chunks.
+  const ReadyMarks *marks = (spread && lane_base == 0 && lanes.size() > 1 && ctx->ready.armed && ctx->ready.base == stream.data
+                             && ctx->ready.n_frames == stream.n_frames && !ctx->ready.marks.empty()) ? &ctx->ready : nullptr;
+  if (marks)
+    std::rotate (lanes.begin(), lanes.begin() + 1, lanes.end());
+  else if (lanes.size() > 1 && lane_base == 0)
     {
       // the PCM may still be in flight on the context's stream (e.g. add -> get): the other lanes wait for it
       if (!ctx->ev_sync)
@@ -606,6 +613,18 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
       for (size_t i = 1; i < lanes.size(); i++)
         AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ctx->ev_sync, 0));
     }
+  auto wait_for_mark = [&] (WorkLane *lane, size_t last_sample_plus_one) -> int {
+    if (!marks || lane->stream == ctx->stream)
+      return 0;
+    for (const auto& m : marks->marks)
+      if (m.first >= last_sample_plus_one)
+        {
+          AWM_HIP_CHECK (hipStreamWaitEvent (lane->stream, m.second, 0));
+          return 0;
+        }
+    AWM_HIP_CHECK (hipStreamWaitEvent (lane->stream, marks->marks.back().second, 0));
+    return 0;
+  };
   // an error return must not leave kernels in flight on lanes whose buffers the next call will reuse
   struct LaneDrain
   {
@@ -686,6 +705,9 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
       {
       case 0:
         {
+          if (cs.ki == 0)
+            if (int rc = wait_for_mark (cs.lane, chunks[c].first_frame + chunks[c].n_frames))
+              return rc;
           const int stagger = g_chunk_stagger >= 0 ? g_chunk_stagger : (chunks.size() > lanes.size() ? 2 : 1);
           if (stagger && cs.ki == 0 && spread)
             {

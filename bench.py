@@ -488,6 +488,8 @@ def main():
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-detect-speed-config", action="store_true", help="skip the 48 kHz --detect-speed configuration (BASELINE configs[2])")
     ap.add_argument("--lanes", type=int, default=4, help="lanes `get` spreads the chunks of a stream over (1: kernels back to back, for profiling)")
+    ap.add_argument("--one-call", action="store_true",
+                    help="a step = awm_add_get_watermark_d (add, then get of its output, as one call) instead of the two entry points")
     ap.add_argument("--sharded", action="store_true",
                     help="debug: take the multi-GPU (ShardedStream / torch.distributed) code path even with one process")
     ap.add_argument("--viterbi-form", choices=["auto", "chain", "one-launch"], default="auto",
@@ -568,7 +570,8 @@ def main():
         out = torch.empty_like(x)
         audio_seconds = (n_total if strong or not sharded_path else n * world) / RATE
         workload = (f"{minutes:g} min stereo 44.1 kHz white noise " + ("in total" if strong else "per GPU") +
-                    f" resident in HBM, add+get incl. payload decode, payload {PAYLOAD}, strength 10")
+                    f" resident in HBM, add+get incl. payload decode, payload {PAYLOAD}, strength 10" +
+                    (", a step = awm_add_get_watermark_d (add, then get of its output, one call)" if args.one_call and not sharded_path else ""))
         if sharded_path:
             from audiowmark_amd import sharded
             pipe = sharded.ShardedStream(ctx, dist, n_frames_local=n, n_channels=2)
@@ -576,6 +579,12 @@ def main():
             def step():
                 pipe.add_watermark(None, PAYLOAD, x, out)
                 return pipe.get_watermark(None, out)
+        elif args.one_call:
+            # add + get of the output as ONE call (awm_add_get_watermark_d): the same kernels and results; `get` may start a chunk behind
+            # the limiter pass that covers it instead of behind the whole `add` (measured: 5.25 against 5.29 ms -- the step is bound by the
+            # sum of its kernels' work, not by where `get` starts; profiles/r05/README.md)
+            def step():
+                return ctx.add_get_watermark(None, PAYLOAD, x, out)
         else:
             def step():
                 ctx.add_watermark(None, PAYLOAD, x, out=out)
@@ -625,6 +634,22 @@ def main():
 
     single_stream = args.config == "60min" and world == 1 and not args.sharded
     prof = read_prof(awm, ctx)
+    two_calls_ms = None
+    if world == 1 and not args.sharded and args.config != "clips" and not args.one_call:
+        # the same step as ONE call (awm_add_get_watermark_d; untimed extra): what the add -> get hand-over per chunk is worth
+        awm.lib.awm_prof_enable(ctx._h, 0)
+        def two():
+            return ctx.add_get_watermark(None, PAYLOAD, x, out)
+        two()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(max(3, args.steps // 2)):
+            pats2 = two()
+        sync()
+        two_calls_ms = round((time.perf_counter() - t0) / max(3, args.steps // 2) * 1e3, 3)
+        key2 = lambda p: (p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
+        if [key2(p) for p in pats2] != [key2(p) for p in (pats or [])]:
+            raise SystemExit("bench.py: awm_add_get_watermark_d and the two separate calls disagree")
     serial, serial_steps = {}, 3
     if args.config != "clips":
         # the same kernels one after the other (a single lane), outside the timed region: the duration a kernel has when it
@@ -741,6 +766,7 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "first_step_ms": first_step_ms,
+            "ms_per_step_as_one_call": two_calls_ms,
             "higher_is_better": True,
             "scaling": "strong" if strong or args.config == "clips" else "weak",
             "vs_baseline": None,

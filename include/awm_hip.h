@@ -221,6 +221,14 @@ int awm_resample_d (awm_ctx *ctx, const float *pcm_in_d, size_t n_frames, int n_
  * ClipDecoder, merge + sort.  Returns the pattern count (<= max_out filled). */
 int awm_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d, size_t n_frames,
                          int n_channels, size_t max_out, awm_pattern *out);
+/* add_watermark followed by get_watermark of its output, one key ("watermark, then verify that the payload decodes": wmadd.cc:448-618
+ * then wmget.cc:886-1013, the two commands the reference runs one after the other in its own tests, tests/block-decoder-test.sh:8-18).
+ * out_d receives the watermarked stream (pcm_in_d != out_d), `out` the pattern list of `get` on it: exactly what
+ * awm_add_watermark_d + awm_get_watermark_d return.  As ONE call the library owns the order of the two halves on the context's stream:
+ * `get` starts a chunk as soon as the limiter has passed the chunk's last sample instead of behind the whole `add` (two separate calls
+ * cannot: the caller may have queued other work on the buffer in between).  Returns the pattern count or an error code. */
+int awm_add_get_watermark_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const float *pcm_in_d, float *out_d,
+                             size_t n_frames, int n_channels, int sample_rate, size_t max_out, awm_pattern *out);
 /* The reference's get_watermark takes a LIST of keys (wmcommon.hh:228, `--key a --key b`, tests/key-test.sh:13-37): the file is
  * read once, the approximate dB matrices of a chunk / of a padded clip are computed once and shared by the keys
  * (syncfinder.cc:171-256), patterns are sorted by time with the key list order breaking ties (wmget.cc:288-316).

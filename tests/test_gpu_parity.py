@@ -947,3 +947,34 @@ def test_one_clean_gap_is_exact(gpu):
     want = orc.get(None, x, 2)
     assert [pkey(p) for p in got] == [pkey(p) for p in want]
     assert max([abs(g["sync_quality"] - w["sync_quality"]) for g, w in zip(got, want)] + [0]) < QUALITY_TOL
+
+
+@pytest.mark.parametrize("minutes,limiter", [(61, True), (61, False), (95, True), (0.9, True)])
+def test_add_get_as_one_call_equals_the_two_calls(gpu, minutes, limiter):
+    """awm_add_get_watermark_d (add, then get of its output, one call: `get` starts a chunk behind the limiter pass that covers it, on
+    other streams than the add): the PCM of awm_add_watermark_d bit for bit and the pattern list of awm_get_watermark_d on it, incl.
+    quality and error values -- three chunks, four chunks (more chunks than a first round of lanes), a clip (one chunk: no hand-over),
+    with and without the limiter; repeated, with the output buffer cleared in between (a chunk that started too early would read
+    zeros or unlimited samples and change the list)."""
+    torch = gpu.torch
+    n = int(minutes * 60 * 44100) + 333
+    g = torch.Generator(device="cuda"); g.manual_seed(17)
+    x = torch.rand((n, 2), generator=g, device="cuda") * 2 - 1
+    full = lambda p: pkey(p) + (p["sync_quality"], p["decode_error"])
+    gpu.awm.set_params(test_no_limiter=not limiter)
+    try:
+        want_pcm = gpu.ctx.add_watermark(None, PAY1, x)
+        want = [full(p) for p in gpu.ctx.get_watermark(None, want_pcm)]
+        assert any(p[4] == PAY1 for p in want)
+        out = torch.empty_like(x)
+        for _ in range(4):
+            out.zero_()
+            got = [full(p) for p in gpu.ctx.add_get_watermark(None, PAY1, x, out)]
+            assert got == want
+            assert torch.equal(out, want_pcm)
+        # the separate calls afterwards are unaffected (the marks are disarmed when the call returns)
+        out.zero_()
+        gpu.ctx.add_watermark(None, PAY1, x, out=out)
+        assert [full(p) for p in gpu.ctx.get_watermark(None, out)] == want
+    finally:
+        gpu.awm.set_params()
