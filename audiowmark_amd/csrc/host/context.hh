@@ -212,6 +212,9 @@ struct WorkLane
   hipEvent_t   ev_refine[2] = { nullptr, nullptr };
   hipEvent_t   ev_sync = nullptr;        // cross-lane ordering (input ready / lane done)
   SpeedScratch *speed_scratch = nullptr; // buffers of a speed search on this lane (wmspeed.cc), created on first use
+  // Groups of padded clips (wmget.cc clip_batch_staged): the share of a padded slice's frames that carry samples.  The kernels skip the
+  // silent frames of the padding (syncfinder.cc:578-590), so the ALGORITHMIC bytes the profiling scopes report for a group are scaled by it.
+  double       prof_live_fraction = 1.0;
   unsigned int *viterbi_sync (size_t n_decodes);          // the one-launch Viterbi kernel's sync block (zero between launches); nullptr on failure
   void release_lane();
 };

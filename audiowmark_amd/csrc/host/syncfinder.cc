@@ -583,7 +583,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
         }
       da.tile_frames = TP;
       {
-        ProfScope ps (m_ctx, PROF_REFINE_DB, db_bytes, st);
+        ProfScope ps (m_ctx, PROF_REFINE_DB, (slices ? m_lane->prof_live_fraction : 1.0) * db_bytes, st);
         if (gathered)
           AWM_HIP_CHECK (awmk::launch_sync_db_sliding (st, m_ctx->tabs, da));       // K4s: sliding DFT over the fine offsets
         else
@@ -606,7 +606,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           ga.q_stride = QS;
           ga.chain_mag = reinterpret_cast<float *> (ga.quality + batch * QS);
           ga.chain_n = reinterpret_cast<int *> (ga.chain_mag + batch * 12 * 128);
-          ProfScope ps (m_ctx, PROF_REFINE_SCAN, double (n_items) * 4.0 * row_values, st);
+          ProfScope ps (m_ctx, PROF_REFINE_SCAN, (slices ? m_lane->prof_live_fraction : 1.0) * double (n_items) * 4.0 * row_values, st);
           AWM_HIP_CHECK (awmk::launch_sync_scan_gathered (st, ga));
         }
       else
@@ -871,7 +871,8 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
   da.tile_frames = 32;
   if (!db_ready)                                     // (else: another key of the same `get` left the group's matrices in the workspace)
     {
-      ProfScope ps (m_ctx, PROF_SYNC_DB, double (n_slices) * n_db * 4096.0 * group.n_channels + double (n_planes) * n_db * 324.0, st);
+      // (only the frames that carry samples are transformed and written: prof_live_fraction of the padded slices)
+      ProfScope ps (m_ctx, PROF_SYNC_DB, m_lane->prof_live_fraction * (double (n_slices) * n_db * 4096.0 * group.n_channels + double (n_planes) * n_db * 324.0), st);
       AWM_HIP_CHECK (awmk::launch_sync_db (st, m_ctx->tabs, da));
     }
   awmk::SyncScanArgs sa {};
@@ -899,7 +900,7 @@ SyncFinder::group_approx_launch (KeyTables *kt, const DeviceWav& group, int n_sl
       sa.table.row_frames = kt->sync[1].row_frames.as<int>();
     }
   {
-    ProfScope ps (m_ctx, PROF_SYNC_SCAN, double (n_planes) * n_db * 324.0 + double (n_planes) * S * 8.0, st);
+    ProfScope ps (m_ctx, PROF_SYNC_SCAN, m_lane->prof_live_fraction * double (n_planes) * n_db * 324.0 + double (n_planes) * S * 8.0, st);
     AWM_HIP_CHECK (awmk::launch_sync_scan_window (st, sa, total_frames (mode)));
   }
   {

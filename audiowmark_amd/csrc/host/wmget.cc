@@ -100,7 +100,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
         }
       da.tile_frames = 32;
       {
-        ProfScope ps (ctx, PROF_BLOCK_DB, double (nb) * count * C * (4096.0 + 324.0), st);
+        ProfScope ps (ctx, PROF_BLOCK_DB, ((slice_range && slice_frames) ? lane->prof_live_fraction : 1.0) * double (nb) * count * C * (4096.0 + 324.0), st);
         AWM_HIP_CHECK (awmk::launch_sync_db (st, ctx->tabs, da));
       }
 
@@ -120,7 +120,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
       if (kt->slices && slice_frames)
         sb.block_slice = d_slice_of + b0;              // one key per clip: the mix table of the block's slice
       {
-        ProfScope ps (ctx, PROF_SOFT_BITS, double (nb) * count * C * 324.0, st);
+        ProfScope ps (ctx, PROF_SOFT_BITS, ((slice_range && slice_frames) ? lane->prof_live_fraction : 1.0) * double (nb) * count * C * 324.0, st);
         AWM_HIP_CHECK (awmk::launch_soft_bits (st, sb));
       }
     }
@@ -1471,6 +1471,13 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
       const size_t n = (count + 5) * Params::frame_size * C;                       // in values
       const size_t slice_values = 3 * n;                                            // pad_start + len + n with pad_start = n + (n - len)
       const size_t slice_frames = slice_values / C;
+      {
+        // (profiling only) frames of the group's slices that carry samples: a clip's own frames + one at each edge
+        double live = 0;
+        for (size_t i = 0; i < gn; i++)
+          live += double (clips[which[g0 + i]].n_frames) / Params::frame_size + 2;
+        lane->prof_live_fraction = std::min (1.0, live / (double (gn) * double (slice_frames) / Params::frame_size));
+      }
       // stage 0: padded copies (reference wmget.cc:830-867, START position: data + padding cover one long block) and the
       // non-silent range of every slice
       if (int rc = lane->ws_clip.reserve (gn * slice_values * sizeof (float))) return rc;

@@ -12,7 +12,7 @@ export GPU_MAX_HW_QUEUES=16
 bash tools/profile_bench.sh $TAG > $O/profile.log 2>&1; tail -14 $O/profile.log
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 400 $O/bench_n1.json
 timeout 600 python bench.py --steps 10 --warmup 3 --sharded --no-e2e --no-cpu-baseline --no-detect-speed-config > $O/bench_n1_sharded.json 2>/dev/null
-timeout 900 python bench.py --config 8h --steps 8 --warmup 2 > $O/bench_8h.json 2>/dev/null; tail -c 300 $O/bench_8h.json
+timeout 900 python bench.py --config 8h --steps 8 --warmup 5 > $O/bench_8h.json 2>/dev/null; tail -c 300 $O/bench_8h.json
 timeout 900 python bench.py --config clips --steps 3 --warmup 1 > $O/bench_clips.json 2>/dev/null; tail -c 600 $O/bench_clips.json
 timeout 600 python bench.py --gpus 2 --same-device --steps 5 --warmup 2 > $O/bench_same_device_2.json 2>/dev/null; tail -c 300 $O/bench_same_device_2.json
 timeout 300 python tools/gpu_sharded_prof.py 60 2>&1 | grep -v "amdgpu.ids\|RCCL version\|HIP version\|ROCm version\|Hostname\|Librccl\|socket" > $O/sharded_prof.txt; cat $O/sharded_prof.txt

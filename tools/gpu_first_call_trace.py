@@ -20,13 +20,15 @@ for name in ("librocprofiler-sdk-roctx.so", "libroctx64.so"):
         pass
 PAY = "0123456789abcdef0011223344556677"
 ctx = awm.Context(0)
-n = 60 * 60 * 44100
+minutes = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+calls = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+n = int(minutes * 60 * 44100)
 g = torch.Generator(device="cuda"); g.manual_seed(5)
 x = torch.rand((n, 2), generator=g, device="cuda") * 2 - 1
 out = torch.empty_like(x)
 ctx.add_watermark(None, PAY, x, out=out)
 torch.cuda.synchronize()
-for i in range(4):
+for i in range(calls):
     if tx:
         tx.roctxRangePushA(("get_call_%d" % (i + 1)).encode())
     ctx.get_watermark(None, out)
