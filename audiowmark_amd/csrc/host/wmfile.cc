@@ -39,10 +39,12 @@ namespace {
  * 16 bit stereo is 635 MB each way, a few milliseconds of GPU work.  So the copies run on a pool of workers:
  *   input   regular files (AudioInputStream::raw_region): the tiles are read AHEAD of the consumer, every tile split over the
  *           workers (pread); pipes and streams without byte access: one reader thread, still ahead of the consumer;
- *   output  regular files (AudioOutputStream::raw_region): the file is grown with ftruncate and the workers copy into a shared
- *           mapping of the tile's range -- page faults of different ranges allocate in parallel, while buffered write() calls on one
- *           file serialise on its inode lock (pwrite from N threads is as fast as one thread; measured, tools/io_probe.cc);
- *           pipes / stdout / streams without byte access: one writer thread in stream order.                                        */
+ *   output  ONE writer thread in stream order.  Creating the page cache pages of one file is serial in the kernel whatever the number of
+ *           writers (a fresh 640 MB tmpfs file: 85 - 105 ms with one thread's write(), 109 - 258 ms with 4 - 16 threads' pwrite -- the inode
+ *           lock --, 180 - 196 ms with 4 - 16 threads copying into a shared mapping -- the file's page tree --, 14 - 32 ms when the same
+ *           threads write SEPARATE files: tools/io_probe.cc -> profiles/r05/io_probe.txt), so the ordered writer is at the floor.  The
+ *           worker path for regular output files of known length (AudioOutputStream::raw_region: the file grown to its final size and
+ *           mapped once, tiles copied by the workers) exists behind awm_debug_set_io_flags, writes the same bytes and is not faster.      */
 constexpr size_t STAGE_FRAMES = size_t (1) << 22;       // frames per staging tile of the whole-stream loaders (16 MiB of 16 bit stereo)
 constexpr int    IN_RING = FileStaging::RING, OUT_RING = FileStaging::RING;   // page-locked tiles per direction (kept by the context)
 constexpr size_t IO_PART_MIN = size_t (1) << 20;        // a worker's share of a tile is at least this many bytes
@@ -50,7 +52,7 @@ constexpr size_t IO_PART_MIN = size_t (1) << 20;        // a worker's share of a
 #ifndef MADV_POPULATE_WRITE
 #define MADV_POPULATE_WRITE 23                          // (Linux 5.14; older headers)
 #endif
-enum { IO_REGIONS = 1, IO_MAP_OUTPUT = 2, IO_POPULATE = 4 };
+enum { IO_REGIONS = 1, IO_MAP_OUTPUT = 2, IO_POPULATE = 4, IO_REGIONS_OUT = 8 };          // awm_debug_set_io_flags
 // where the wall time of the last file level add / load of this thread went (awm_debug_file_timing): milliseconds the calling thread
 // spent { setting up (streams, rings, tables), waiting for input tiles, waiting for a free output slot, queueing GPU work, in the
 // final wait for the GPU, in the final wait for the writers, tearing down, handing output tiles on (incl. the wait for a slot) }
@@ -61,12 +63,7 @@ struct Lap
   void to (int i) { const auto n = std::chrono::steady_clock::now(); tl_file_ms[i] += std::chrono::duration<double, std::milli> (n - t).count(); t = n; }
 };
 static std::atomic<int> g_io_threads { 0 };             // 0: default
-enum { IO_REGIONS_OUT = 8 };
-// Default: input regions only.  OUTPUT through the workers (IO_REGIONS_OUT) is a measured negative on the target box: creating the page
-// cache pages of ONE file is serial in the kernel whatever the number of writers -- 640 MB into a fresh tmpfs file: one thread with
-// write() 85 - 100 ms, 8 threads with pwrite 190 - 260 ms, 8 threads through a shared mapping 180 - 190 ms, while 8 threads writing 8
-// SEPARATE files take 16 ms (tools/io_probe.cc -> profiles/r05/io_probe.txt).  The ordered writer thread is at that floor.
-static std::atomic<int> g_io_flags { IO_REGIONS };
+static std::atomic<int> g_io_flags { IO_REGIONS };      // default: input through the workers, output by the ordered writer thread (see above)
 int
 io_threads()
 {
@@ -80,7 +77,7 @@ io_threads()
 }
 
 /* worker threads for the host side copies; one pool per process, started at the first file level call and resized when the setting
- * changes between calls */
+ * changes BETWEEN calls (awm_set_io_threads is not meant to be called while another thread is inside a file level call) */
 class IoPool
 {
   std::vector<std::thread> m_threads;
