@@ -129,6 +129,9 @@ struct SyncDbArgs
   // 1: a frame in the silence outside the range is not skipped but gets the dB values of a transformed frame of zeros (exactly
   // what the transform would deliver: -96 per band and channel) -- the block decoder's fft_range knows no skipping
   int                  silent_frames_are_zero = 0;
+  // with silent_frames_are_zero: a tile all of whose frames, and the two frames on either side of it, lie in that silence is not
+  // written at all -- for the one consumer that never reads such frames (K7 with SoftBitsArgs::stream_range)
+  int                  skip_unread_silent_tiles = 0;
 };
 hipError_t launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs& a);
 /* K4s: same output as K4 for streams whose frames advance by 8 samples (search_refine): instead of one FFT per fine
@@ -237,6 +240,14 @@ struct SoftBitsArgs
   float         *out;
   // one key per clip: block b takes the mix table of slice block_slice[b] (entries at + slice * n_data_frames * 30)
   const int     *block_slice = nullptr;
+  // Blocks cut out of padded slices (clip batches): block b starts at sample block_base[b] of the buffer; the values of its slice that are
+  // not digital silence are [stream_range[2 s], stream_range[2 s + 1]) with s = range_index[b] (first < 0: nothing but silence) -- the
+  // arrays K4b got (SyncDbArgs).  A frame outside that range has -96 dB in every band and channel (K4b writes exactly that,
+  // silent_frames_are_zero), so an item whose frame AND both neighbours are such frames is known without a load: (-96, -192, -96, -192).
+  // Four fifths of a 30 s clip's padded block are such items.  The sums are the same operations on the same values.
+  const long long *block_base = nullptr;
+  const long long *stream_range = nullptr;
+  const int       *range_index = nullptr;
 };
 hipError_t launch_soft_bits (hipStream_t st, const SoftBitsArgs& a);
 

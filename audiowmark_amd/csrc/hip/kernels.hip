@@ -1259,6 +1259,32 @@ sync_db_kernel (DevTables t, SyncDbArgs a)
   __shared__ float  s_tile[NB * TILE_LD];
   __shared__ char   s_have[TILE_MAX];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (a.silent_frames_are_zero && a.skip_unread_silent_tiles)
+    {
+      // (before the tables are loaded: workgroup uniform)  Blocks of padded slices for K7: a tile whose frames all lie in the padding's
+      // silence, the two frames before and the two after it included, is never read -- K7 takes an item whose frame and both neighbours
+      // are silent as (-96, -192, -96, -192) without a load -- so it is not written either.  Four fifths of a 30 s clip's blocks.
+      long long stream = blockIdx.y, tile_idx = blockIdx.x;
+      if (a.xcd_interleave)
+        {
+          const long long j = blockIdx.x >> 3;
+          stream = j % a.n_streams;
+          tile_idx = (j / a.n_streams) * 8 + (blockIdx.x & 7);
+        }
+      const long long base = sync_stream_base (a, stream);
+      const int count = a.stream_count ? a.stream_count[stream] : a.count0;
+      long long sil_first, sil_last;
+      sync_stream_range (a, stream, sil_first, sil_last);
+      const long long tile0 = tile_idx * a.tile_frames;
+      if (tile0 >= count)
+        return;
+      const long long n_here = (count - tile0) < a.tile_frames ? count - tile0 : a.tile_frames;
+      // (K7 reads the neighbours of every item whose frame or whose neighbour is live: frames up to TWO away from a live one)
+      const long long idx_before = base + (tile0 - 2) * a.hop, idx_after = base + (tile0 + n_here + 1) * a.hop;
+      const int C = a.n_channels;
+      if ((idx_after + 1024) * C < sil_first || idx_before * C > sil_last)
+        return;
+    }
   load_shared_tables (t, s_tw, s_win, s_twb);
   __syncthreads();
 
@@ -2434,6 +2460,26 @@ soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
   const int n_items = a.frames_per_bit * C * 30;
   float4 *items = s_item_dyn + (size_t) wave * SB_BPW * n_items;
   const int n_here = min (SB_BPW, n_bits - bit0);
+  // blocks of padded slices: the frames [live_lo, live_hi] of the block are the ones K4b transformed (its rule, sync_db_kernel: a frame is
+  // skipped if it ends before the first or starts after the last value that is not silence); the others hold -96 dB everywhere
+  int live_lo = 0, live_hi = 0x7fffffff;
+  if (a.stream_range)
+    {
+      const long long sl = a.range_index[blk];
+      const long long first = a.stream_range[2 * sl], last = a.stream_range[2 * sl + 1];
+      live_lo = a.block_frames;                                // (first < 0: nothing but silence in the slice)
+      live_hi = -1;
+      if (first >= 0)
+        {
+          const long long base = a.block_base[blk];
+          // frame f is live  <=>  (base + 1024 f + 1024) C >= first  and  (base + 1024 f) C <= last
+          const long long lo_num = (first + C - 1) / C - 1024 - base, hi_num = last / C - base;   // 1024 f >= lo_num, 1024 f <= hi_num
+          const long long lo = lo_num <= 0 ? 0 : (lo_num + 1023) / 1024, hi = hi_num < 0 ? -1 : hi_num / 1024;
+          live_lo = int (lo < a.block_frames ? lo : a.block_frames);
+          live_hi = int (hi < a.block_frames ? hi : a.block_frames - 1);
+        }
+    }
+  const float zero_db = db_from_complex (make_float2 (0.f, 0.f));
   // the passes of the four bits are independent: unrolled, their index loads and then their value loads are in flight together (two
   // memory round trips per group of four passes instead of per pass)
   for (int i = lane; i < n_items; i += 64)
@@ -2449,6 +2495,12 @@ soft_bits_wave_kernel (SoftBitsArgs a, int groups_per_block)
       // neighbours reflected at the block edges (reference wmget.cc:87-88)
       const int next = frame + 1 < a.block_frames ? frame + 1 : frame - 1;
       const int prev = frame - 1 >= 0 ? frame - 1 : frame + 1;
+      // the frame and both neighbours (as reflected at the block's edges) lie in the silence of the padding
+      if (max (frame, max (prev, next)) < live_lo || min (frame, min (prev, next)) > live_hi)
+        {
+          items[e] = make_float4 (zero_db, __fadd_rn (zero_db, zero_db), zero_db, __fadd_rn (zero_db, zero_db));
+          continue;
+        }
       const float *plane = db + (long long) ch * NB * a.ld;
       const float *pu = plane + (long long) (mix_up[b] - MIN_BAND) * a.ld;
       const float *pd = plane + (long long) (mix_down[b] - MIN_BAND) * a.ld;

@@ -97,6 +97,7 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
           da.range_index = d_slice_of + b0;
           da.range_div = 1;
           da.silent_frames_are_zero = 1;
+          da.skip_unread_silent_tiles = 1;           // (K7 below gets the same ranges: it does not read what is not written)
         }
       da.tile_frames = 32;
       {
@@ -119,6 +120,13 @@ block_soft_bits_dev (awm_ctx *ctx, WorkLane *lane, KeyTables *kt, const DeviceWa
       sb.out = lane->ws_soft.as<float>() + b0 * n_bits;
       if (kt->slices && slice_frames)
         sb.block_slice = d_slice_of + b0;              // one key per clip: the mix table of the block's slice
+      if (slice_range && slice_frames)
+        {
+          // blocks of padded slices: the items in the padding's silence are known without a load (kernels.hh SoftBitsArgs)
+          sb.block_base = lane->ws_idx.as<long long>() + b0;
+          sb.stream_range = slice_range;
+          sb.range_index = d_slice_of + b0;
+        }
       {
         ProfScope ps (ctx, PROF_SOFT_BITS, ((slice_range && slice_frames) ? lane->prof_live_fraction : 1.0) * double (nb) * count * C * 324.0, st);
         AWM_HIP_CHECK (awmk::launch_soft_bits (st, sb));
