@@ -330,7 +330,12 @@ hipError_t launch_nonzero_range (hipStream_t st, const float *data, long long n_
  * slice i = [pad_start_i zeros][clip i][pad zeros], slice_values each, and the non-silent range of every slice
  * (range[2 i] = first non-zero value, absolute index in dst, -1 if there is none; range[2 i + 1] = last + 1). */
 struct ClipSrc { const float *data; long long n_values; long long pad_start; };
-hipError_t launch_clip_pad (hipStream_t st, const ClipSrc *src /* device */, int n_clips, float *dst, long long slice_values, long long *range);
+/* Of the padding only `margin_values` on either side of a clip are written (the rest of a slice keeps whatever the buffer held): every
+ * consumer of the slices skips the frames outside the non-silent range -- K4 / K4b per frame, K4s per row of fine offsets, K7 per item --
+ * and the frames it does read reach at most 1024 + 8 * 64 frames (K4s: a row of 65 fine offsets, plus its read-ahead) beyond that range.
+ * margin_values >= slice_values writes whole slices. */
+hipError_t launch_clip_pad (hipStream_t st, const ClipSrc *src /* device */, int n_clips, float *dst, long long slice_values, long long margin_values,
+                            long long *range);
 }
 
 namespace awmk {

@@ -2723,14 +2723,19 @@ launch_nonzero_range (hipStream_t st, const float *data, long long n_values, uns
 
 /* kernels.hh launch_clip_pad: grid (parts, clips); slice_values % 4 == 0, 16-byte stores */
 __global__ void __launch_bounds__ (256)
-clip_pad_kernel (const ClipSrc *src, float *dst, long long slice_values, unsigned long long *range)
+clip_pad_kernel (const ClipSrc *src, float *dst, long long slice_values, long long margin_values, unsigned long long *range)
 {
   const ClipSrc c = src[blockIdx.y];
   float4 *out = reinterpret_cast<float4 *> (dst + (long long) blockIdx.y * slice_values);
   const long long slice0 = (long long) blockIdx.y * slice_values;
   const long long stride = (long long) gridDim.x * blockDim.x;
   unsigned long long first = ~0ULL, last = 0;
-  for (long long q = (long long) blockIdx.x * blockDim.x + threadIdx.x; q < slice_values / 4; q += stride)
+  // only [pad_start - margin, pad_start + n_values + margin) of the slice is written: the consumers skip every frame that lies
+  // outside the non-silent range found here (which is inside the clip) and read at most `margin` values beyond it
+  long long q_lo = (c.pad_start - margin_values) / 4, q_hi = (c.pad_start + c.n_values + margin_values + 3) / 4;
+  q_lo = q_lo < 0 ? 0 : q_lo;
+  q_hi = q_hi > slice_values / 4 ? slice_values / 4 : q_hi;
+  for (long long q = q_lo + (long long) blockIdx.x * blockDim.x + threadIdx.x; q < q_hi; q += stride)
     {
       const long long k = 4 * q - c.pad_start;              // source index of the quad's first value
       float v[4] = { 0.f, 0.f, 0.f, 0.f };
@@ -2790,16 +2795,24 @@ clip_range_init_kernel (unsigned long long *range, int n_clips)
     }
 }
 
+/* (test knob) the slices are filled with NaNs before the padded copies are written: a consumer that reads a value the copy
+ * kernel left out -- which would be stale data of an earlier group -- shows up as a changed result */
+int g_clip_poison = 0;
+extern "C" void awm_debug_set_clip_poison (int on) { g_clip_poison = on; }
+
 hipError_t
-launch_clip_pad (hipStream_t st, const ClipSrc *src, int n_clips, float *dst, long long slice_values, long long *range)
+launch_clip_pad (hipStream_t st, const ClipSrc *src, int n_clips, float *dst, long long slice_values, long long margin_values, long long *range)
 {
   if (n_clips <= 0 || slice_values <= 0)
     return hipSuccess;
-  if (slice_values % 4 || (reinterpret_cast<uintptr_t> (dst) & 15))
+  if (slice_values % 4 || margin_values < 0 || (reinterpret_cast<uintptr_t> (dst) & 15))
     return hipErrorInvalidValue;
+  if (g_clip_poison)
+    if (hipError_t e = hipMemsetAsync (dst, 0xff, size_t (n_clips) * size_t (slice_values) * sizeof (float), st))
+      return e;
   auto *r = reinterpret_cast<unsigned long long *> (range);
   hipLaunchKernelGGL (clip_range_init_kernel, dim3 (unsigned ((n_clips + 255) / 256)), dim3 (256), 0, st, r, n_clips);
-  hipLaunchKernelGGL (clip_pad_kernel, dim3 (128, unsigned (n_clips)), dim3 (256), 0, st, src, dst, slice_values, r);
+  hipLaunchKernelGGL (clip_pad_kernel, dim3 (128, unsigned (n_clips)), dim3 (256), 0, st, src, dst, slice_values, margin_values, r);
   return hipGetLastError();
 }
 

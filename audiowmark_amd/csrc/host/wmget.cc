@@ -1439,6 +1439,16 @@ upload_group_tables (WorkLane *lane, const std::vector<ClipKeyHost>& hosts, KeyT
 }
 }
 
+/* frames of zeros written on either side of a clip in its padded slice (kernels.hh launch_clip_pad: the consumers read at most
+ * 1024 + 8 * 64 + read-ahead frames beyond the clip) */
+constexpr int CLIP_PAD_MARGIN = 2048;
+/* (measurement knob) another margin, in frames; one slice or more = whole slices are written, as before this margin existed */
+static int g_clip_pad_margin = CLIP_PAD_MARGIN;
+extern "C" void awm_debug_set_clip_pad_margin (int frames) { g_clip_pad_margin = frames > 0 ? frames : CLIP_PAD_MARGIN; }
+/* (test knob) every clip of a group takes the sequential selection */
+static int g_group_force_fallback = 0;
+extern "C" void awm_debug_set_group_fallback (int on) { g_group_force_fallback = on; }
+
 /* clip_keys (may be null): one key per clip -- clip i is searched and decoded with (*clip_keys)[i] alone (key_list is not used then) */
 static int
 clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips, const std::vector<size_t>& which,
@@ -1502,7 +1512,9 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
       auto *d_desc = lane->ws_group.as<awmk::ClipSrc>();
       auto *d_range = reinterpret_cast<long long *> (lane->ws_group.as<char>() + desc_bytes);
       AWM_HIP_CHECK (hipMemcpyAsync (d_desc, desc, desc_bytes, hipMemcpyHostToDevice, st));
-      AWM_HIP_CHECK (awmk::launch_clip_pad (st, d_desc, int (gn), lane->ws_clip.as<float>(), (long long) slice_values, d_range));
+      // (only CLIP_PAD_MARGIN frames of zeros on either side of a clip are written: nothing further out is read -- kernels.hh)
+      const long long margin_values = (long long) std::max (g_clip_pad_margin, CLIP_PAD_MARGIN) * C;
+      AWM_HIP_CHECK (awmk::launch_clip_pad (st, d_desc, int (gn), lane->ws_clip.as<float>(), (long long) slice_values, margin_values, d_range));
       DeviceWav group;
       group.data = lane->ws_clip.as<float>();
       group.n_frames = gn * slice_frames;
@@ -1547,12 +1559,20 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
           std::vector<Cand> cands;
           for (size_t i = 0; i < gn; i++)
             {
-              if (gj.fallback[i])
+              if (gj.fallback[i] || g_group_force_fallback)
                 {
                   // the rare sequential selection: this clip's slice on its own (same result set, same order of keys)
                   DeviceWav slice = group;
                   slice.data = group.data + i * slice_values;
                   slice.n_frames = slice_frames;
+                  // (that search scans and transforms the whole slice: the zeros the padded copy left out are written now)
+                  const long long lo = std::max<long long> (0, (desc[i].pad_start - margin_values) / 4 * 4);
+                  const long long hi = std::min<long long> ((long long) slice_values, (desc[i].pad_start + desc[i].n_values + margin_values + 3) / 4 * 4);
+                  float *slice_w = lane->ws_clip.as<float>() + i * slice_values;
+                  if (lo > 0)
+                    AWM_HIP_CHECK (hipMemsetAsync (slice_w, 0, size_t (lo) * sizeof (float), st));
+                  if (hi < (long long) slice_values)
+                    AWM_HIP_CHECK (hipMemsetAsync (slice_w + hi, 0, size_t ((long long) slice_values - hi) * sizeof (float), st));
                   if (int rc = clip_run_padded (ctx, lane, { clip_keys ? keys_of_group[i] : key }, slice, chunk_sets[g0 + i], 0.0, 1))
                     return rc;
                   db_ready = false;              // (that search used the lane's dB workspace)

@@ -415,6 +415,12 @@ void awm_debug_set_key_tables_on_device (int on);   /* batches with one key per 
 void awm_debug_set_merge_decodes (int on);  /* get of a stream of 2 - 4 chunks: the chunks' Viterbi jobs as ONE batch at the end | per chunk (default: the step is faster) */
 void awm_debug_set_add_slab_mb (int mb);   /* add: 0 (default) one fused add over the stream, then the limiter | > 0: in slabs of that many MB (cache experiment) */
 void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transforms pipelined in one wave (default) | one after the other */
+void awm_debug_set_clip_poison (int on);    /* clip batches: the padded slices are filled with NaNs before the copies are written (the copy writes a clip and 2048
+                                            * frames of zeros on either side, not the rest of the padding: a consumer that read further would change its result) */
+void awm_debug_set_clip_pad_margin (int frames); /* clip batches: frames of zeros written on either side of a clip (default and minimum 2048; one slice = 6693 frames
+                                            * or more: whole slices, the A side of the measurement in tools/gpu_clip_margin_ab.py) */
+void awm_debug_set_group_fallback (int on); /* clip batches: every clip takes the sequential peak selection on its own slice (normally the rare clips whose peak
+                                            * lists overflow the grouped selection) */
 void awm_debug_alloc_stats (long *dev_allocs, double *dev_ms, long *pinned_allocs, double *pinned_ms);
                                            /* process-wide census of hipMalloc / hipHostMalloc calls made by the library's grow-only buffers and the
                                             * time the runtime took for them (what a first call pays); any pointer may be NULL */

@@ -739,7 +739,10 @@ def test_clip_batch_on_lanes(gpu):
 def test_clip_batch_groups(gpu):
     """The group path of awm_get_watermark_batch_d (padded clips side by side, one launch per stage and group): more clips than one
     group holds, lengths from 3 s to 50 s, mono and stereo mixed (groups are per channel count), digital silence (no candidate at
-    all), very short material (the selection falls back to the single-clip search) -- clip by clip what one call per clip gives."""
+    all), very short material (the selection falls back to the single-clip search) -- clip by clip what one call per clip gives.
+    The padded copy of a clip carries 2048 frames of zeros on either side and leaves the rest of the slice alone: with the slices
+    poisoned (NaNs) before the copy the results must stay the same -- nobody reads past those zeros -- also when every clip is made to
+    take the sequential selection, which does read whole slices and zeroes them first."""
     import torch
     rng = np.random.default_rng(77)
     clips = []
@@ -751,6 +754,10 @@ def test_clip_batch_groups(gpu):
             x[:] = 0
         if i % 10 == 3:
             x[len(x) // 3: len(x) // 2] = 0          # a gap of digital silence inside
+        if i % 10 == 6:
+            x[:len(x) // 4] = 0                      # ... at the start
+        if i % 10 == 8:
+            x[-(len(x) // 5):] = 0                   # ... at the end
         clips.append(x)
     marked = []
     for i, c in enumerate(clips):
@@ -764,6 +771,14 @@ def test_clip_batch_groups(gpu):
         assert batch == one_by_one
         if ch == 2:
             assert sum(any(p["bits"] in (PAY1, PAY2) for p in b) for b in batch) >= 20
+        try:
+            gpu.awm.lib.awm_debug_set_clip_poison(1)
+            assert gpu.ctx.get_watermark_batch(None, sel) == one_by_one
+            gpu.awm.lib.awm_debug_set_group_fallback(1)
+            assert gpu.ctx.get_watermark_batch(None, sel) == one_by_one
+        finally:
+            gpu.awm.lib.awm_debug_set_clip_poison(0)
+            gpu.awm.lib.awm_debug_set_group_fallback(0)
 
 
 @pytest.mark.parametrize("n", [0, 1, 1000, 1024, 2049, 44100])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call F: K7 without the loads of the padding's silence -- clip tests against the reference + the clips bench
+# round 5, GPU call F: clip path changes (K7 padding skip, trimmed padded copies) -- clip tests against the reference + the clips bench
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 timeout 900 python -m pytest tests/test_gpu_fullsize_ref.py tests/test_gpu_parity.py tests/test_gpu_fuzz.py -x -q -m gpu -k "clip or config4 or batch or fuzz or silence" 2>&1 | tail -3
