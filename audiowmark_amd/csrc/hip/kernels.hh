@@ -311,6 +311,29 @@ size_t key_table_scratch_bytes();
 size_t key_table_bytes();
 hipError_t launch_frame_mod_tables (hipStream_t st, const KeyTableArgs& a);
 
+/* K16g: the tables `get` needs for a clip with a key of its own (CLIP mode; reference syncfinder.cc:30-77 init_up_down, wmget.cc:52-108
+ * mix_decode's entries, wmcommon.hh randomize_bit_order), from the same draws and shuffles as K16, one workgroup per key -- what the
+ * host's build_clip_key_host produces (host/context.cc), table for table and byte for byte:
+ *   chains      [key][12][170][8] u32   K5w: chain 2 bit + (0 up | 1 down), rows by frame: 30 band bytes + the next row's frame (u16)
+ *   row_frames  [key][6][170] int       frame of every row (bit-major, by frame)
+ *   want        [key][1020] int         the sync frames of the long block (two blocks), ascending
+ *   perm        [key][1020] int         row w of the want list -> bit * 170 + row
+ *   pos         [key][1020][81] u8      band -> 0 .. 29 (up), 30 .. 59 (down), 255 (not used) of want row w
+ *   mix_frame   [key][51480] i16, mix_up / mix_down [key][51480] u8 (absolute band 20 .. 100): mix entry p
+ *   inv_order   [key][858] int          inverse of the bit order permutation
+ * KeyTableArgs::coded and ::tables are not used. */
+struct ClipKeyTableOut
+{
+  unsigned int  *chains;
+  int           *row_frames, *want, *perm;
+  unsigned char *pos;
+  short         *mix_frame;
+  unsigned char *mix_up, *mix_down;
+  int           *inv_order;
+};
+constexpr int CLIP_KEY_ROWS = 170, CLIP_KEY_WANT = 1020, CLIP_KEY_MIX = 51480, CLIP_KEY_CODED = 858;
+hipError_t launch_clip_key_tables (hipStream_t st, const KeyTableArgs& a, const ClipKeyTableOut& out);
+
 } // namespace awmk
 
 namespace awmk {

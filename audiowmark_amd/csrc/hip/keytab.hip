@@ -1,4 +1,5 @@
-// keytab.hip -- K16: the frame_mod table of `add` built ON THE DEVICE, one workgroup per key.
+// keytab.hip -- K16: the frame_mod table of `add` built ON THE DEVICE, one workgroup per key; K16g: the same draws and shuffles turned
+// into the tables `get` needs for a clip with a key of its own (clip_key_tables_tail below).
 //
 // Replaces, for batches with one key per clip (awm_add_watermark_batch_keys_d), the host's build_frame_mod_table
 // (host/wmcommon.cc; reference wmadd.cc:86-162 "init_frame_mod_vec", wmcommon.cc:143-202 UpDownGen / BitPosGen / gen_mix_entries,
@@ -115,8 +116,99 @@ constexpr size_t KT_SCRATCH_BYTES = ((size_t (KT_MIX) * 2 + size_t (KT_BLOCK) * 
 size_t key_table_scratch_bytes() { return KT_SCRATCH_BYTES; }
 size_t key_table_bytes() { return size_t (2) * KT_BLOCK * KT_NB; }
 
-__global__ void __launch_bounds__ (KT_WG)
-frame_mod_table_kernel (KeyTableArgs a)
+static_assert (CLIP_KEY_ROWS == 2 * KT_SYNC_FPB && CLIP_KEY_WANT == 2 * KT_SYNC && CLIP_KEY_MIX == KT_MIX && CLIP_KEY_CODED == KT_CODED, "clip key table shapes");
+
+/* K16g's own part, after the shuffles: s_perm = the mix permutation, s_pos = the frame positions, s_order = the bit order (LDS),
+ * updown = [frame: 510 sync, 1716 data][30 up, 30 down] bands as drawn (global scratch, written by this workgroup) */
+__device__ __forceinline__ void
+clip_key_tables_tail (const ClipKeyTableOut& o, long long key, int tid, unsigned short *s_perm, const unsigned short *s_pos, const unsigned short *s_order,
+                      const unsigned char *updown)
+{
+  constexpr int R = CLIP_KEY_ROWS, NW = CLIP_KEY_WANT;
+  // ---- mix entries in shuffled order (wmcommon.cc build_mix_table) and the inverse bit order
+  for (int p = tid; p < KT_MIX; p += KT_WG)
+    {
+      const int e = s_perm[p];
+      const int f = e / KT_BPF, i = e % KT_BPF;
+      const unsigned char *ud = updown + size_t (KT_SYNC + f) * 60;
+      o.mix_frame[key * KT_MIX + p] = short (s_pos[KT_SYNC + f]);
+      o.mix_up[key * KT_MIX + p] = ud[i];
+      o.mix_down[key * KT_MIX + p] = ud[30 + i];
+    }
+  for (int i = tid; i < KT_CODED; i += KT_WG)
+    o.inv_order[key * KT_CODED + s_order[i]] = i;
+  __syncthreads();                                          // (the permutation is done with: its memory holds the lists below)
+  // ---- the 510 sync frames' bands, each list ascending and relative to the first band (wmcommon.cc build_sync_table; the reference
+  // sorts them, syncfinder.cc:52-53): the 30 bands of a list are distinct members of 0 .. 80 -- mark and scan
+  unsigned char (*s_list)[60] = reinterpret_cast<unsigned char (*)[60]> (s_perm);                 // 30 600 bytes
+  unsigned short *s_rf = s_perm + 16384;                                                          // [6][170] frame of a row (from byte 32 768)
+  unsigned short *s_item = s_rf + 6 * R;                                                          // [6][170] (sync frame, block) of a row
+  for (int sf = tid; sf < KT_SYNC; sf += KT_WG)
+    for (int half = 0; half < 2; half++)
+      {
+        const unsigned char *ud = updown + size_t (sf) * 60 + 30 * half;
+        unsigned int m[3] = { 0, 0, 0 };
+        for (int i = 0; i < 30; i++)
+          {
+            const int b = ud[i] - KT_MIN_BAND;
+            m[b >> 5] |= 1u << (b & 31);
+          }
+        int n = 0;
+        for (int w = 0; w < 3; w++)
+          for (unsigned int bits = m[w]; bits; bits &= bits - 1)
+            s_list[sf][30 * half + n++] = (unsigned char) (32 * w + __builtin_ctz (bits));
+      }
+  __syncthreads();
+  // ---- a row = (sync frame, block 0 | 1 of the long block); within its bit the rows are ordered by frame, the want list orders all
+  // 1020: block 1 lies behind block 0, so both ranks come from comparing the 510 positions.  Block 1 carries the inverted sequence:
+  // its up list is the frame's down list.
+  for (int item = tid; item < NW; item += KT_WG)
+    {
+      const int block = item >= KT_SYNC, sf = item - KT_SYNC * block, bit = sf / KT_SYNC_FPB;
+      const int my = s_pos[sf];
+      int r = 0, w = 0;
+      for (int j = 0; j < KT_SYNC_FPB; j++)
+        r += s_pos[bit * KT_SYNC_FPB + j] < my;
+      for (int j = 0; j < KT_SYNC; j++)
+        w += s_pos[j] < my;
+      r += block * KT_SYNC_FPB;
+      w += block * KT_SYNC;
+      const int frame = my + block * KT_BLOCK, src = bit * R + r;
+      s_rf[src] = (unsigned short) frame;
+      s_item[src] = (unsigned short) item;
+      o.row_frames[key * NW + src] = frame;
+      o.want[key * NW + w] = frame;
+      o.perm[key * NW + w] = src;
+      unsigned char *prow = o.pos + (key * NW + w) * KT_NB;
+      for (int b = 0; b < KT_NB; b++)
+        prow[b] = 255;
+      const unsigned char *up = s_list[sf] + 30 * block, *down = s_list[sf] + 30 * (1 - block);
+      for (int i = 0; i < 30; i++)
+        {
+          prow[up[i]] = (unsigned char) i;
+          prow[down[i]] = (unsigned char) (30 + i);
+        }
+    }
+  __syncthreads();
+  // ---- K5w's chains (scan.hip pack_scan_chains): per (bit, up | down) the rows by frame, 30 band bytes + the NEXT row's frame
+  for (int src = tid; src < 6 * R; src += KT_WG)
+    {
+      const int bit = src / R, r = src - bit * R;
+      const int item = s_item[src], block = item >= KT_SYNC, sf = item - KT_SYNC * block;
+      const unsigned int next = r + 1 < R ? s_rf[src + 1] : 0xffffu;
+      for (int ud = 0; ud < 2; ud++)
+        {
+          const unsigned char *list = s_list[sf] + 30 * (ud ^ block);
+          unsigned int *out = o.chains + ((key * 12 + 2 * bit + ud) * R + r) * 8;
+          for (int i = 0; i < 7; i++)
+            out[i] = list[4 * i] | list[4 * i + 1] << 8 | list[4 * i + 2] << 16 | (unsigned int) list[4 * i + 3] << 24;
+          out[7] = list[28] | list[29] << 8 | (next & 0xff) << 16 | (next >> 8) << 24;
+        }
+    }
+}
+
+template<bool GET> __device__ __forceinline__ void
+key_tables_body (const KeyTableArgs& a, const ClipKeyTableOut& o)
 {
   __shared__ unsigned int   s_te0[256];
   __shared__ unsigned char  s_sbox[256];
@@ -335,6 +427,11 @@ frame_mod_table_kernel (KeyTableArgs a)
     apply_swaps (s_order, s_order_t, KT_CODED);
   __syncthreads();
 
+  if (GET)
+    {
+      clip_key_tables_tail (o, key, tid, s_perm, s_pos, s_order, updown);
+      return;
+    }
   // ---- the table: KEEP everywhere, then the bands of the sync frames and of the mix entries (wmcommon.cc build_frame_mod_table)
   signed char *table = a.tables + key * (long long) (2 * KT_BLOCK * KT_NB);
   {
@@ -371,6 +468,18 @@ frame_mod_table_kernel (KeyTableArgs a)
     }
 }
 
+__global__ void __launch_bounds__ (KT_WG)
+frame_mod_table_kernel (KeyTableArgs a)
+{
+  key_tables_body<false> (a, ClipKeyTableOut {});
+}
+
+__global__ void __launch_bounds__ (KT_WG)
+clip_key_table_kernel (KeyTableArgs a, ClipKeyTableOut o)
+{
+  key_tables_body<true> (a, o);
+}
+
 hipError_t
 launch_frame_mod_tables (hipStream_t st, const KeyTableArgs& a)
 {
@@ -379,6 +488,18 @@ launch_frame_mod_tables (hipStream_t st, const KeyTableArgs& a)
   if (!a.round_keys || !a.sbox || !a.coded || !a.scratch || !a.tables || a.scratch_slots <= 0 || a.n_keys > a.scratch_slots)
     return hipErrorInvalidValue;
   hipLaunchKernelGGL (frame_mod_table_kernel, dim3 ((unsigned) a.n_keys), dim3 (KT_WG), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t
+launch_clip_key_tables (hipStream_t st, const KeyTableArgs& a, const ClipKeyTableOut& o)
+{
+  if (a.n_keys <= 0)
+    return hipSuccess;
+  if (!a.round_keys || !a.sbox || !a.scratch || a.scratch_slots <= 0 || a.n_keys > a.scratch_slots
+      || !o.chains || !o.row_frames || !o.want || !o.perm || !o.pos || !o.mix_frame || !o.mix_up || !o.mix_down || !o.inv_order)
+    return hipErrorInvalidValue;
+  hipLaunchKernelGGL (clip_key_table_kernel, dim3 ((unsigned) a.n_keys), dim3 (KT_WG), 0, st, a, o);
   return hipGetLastError();
 }
 

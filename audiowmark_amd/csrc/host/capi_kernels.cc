@@ -16,6 +16,7 @@
 
 using namespace awm;
 namespace awm { Key capi_key (const uint8_t key[16]); }
+namespace awm { extern int g_key_tables_on_device; int clip_key_tables_check (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, long long mismatch_out[9]); }       // wmget.cc (also read by the clip batches of `get`)
 
 namespace {
 
@@ -1074,7 +1075,6 @@ awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payl
  * the previous group, and live in one batch buffer instead of the context's per-key cache. */
 /* (measurement knob) 1 (default): the frame_mod tables of a batch with one key per clip are built on the device (K16, hip/keytab.hip) |
  * 0: on host threads */
-static int g_key_tables_on_device = 1;
 extern "C" void awm_debug_set_key_tables_on_device (int on) { g_key_tables_on_device = on; }
 
 /* awm_add_watermark_batch_keys_d with the tables built by K16: groups of GROUP keys (one workgroup = one compute unit per key), two
@@ -1234,6 +1234,13 @@ awm_debug_frame_mod_tables_d (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, 
       AWM_HIP_CHECK (stream_wait (ctx->stream));
     }
   return 0;
+}
+
+int
+awm_debug_clip_key_tables_check_d (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, long long mismatch_out[9])
+{
+  AWM_ENTER (ctx);
+  return clip_key_tables_check (ctx, keys, n_keys, mismatch_out);
 }
 
 int

@@ -107,8 +107,13 @@ struct KeyTables
   // A batch of clips with ONE KEY PER CLIP (wmget.cc clip_batch_staged): this object then describes the tables of a whole group --
   // every device table above holds `slices` tables back to back (slice i = clip i of the group; only sync[1], the mix tables and
   // the bit order are filled), slice_want[i] = the want list of slice i.  0: one key, the normal case.
+  // Tables built on the device (K16g): the want lists come back in one page-locked block, slice_want_flat[i * n + w].
   int slices = 0;
   std::vector<std::vector<int>> slice_want;
+  const int *slice_want_flat = nullptr;
+  int        slice_want_n = 0;
+  const int *want_of_slice (int i) const { return slice_want_flat ? slice_want_flat + size_t (i) * slice_want_n : slice_want[i].data(); }
+  int        want_rows_of_slices() const { return slice_want_flat ? slice_want_n : int (slice_want[0].size()); }
 };
 
 // host side tables of ONE key for the clip batch path with a key per clip (CLIP mode sync tables in the kernels' formats, mix table,

@@ -454,7 +454,7 @@ SyncFinder::refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, Searc
 {
   const int clip = mode == Mode::CLIP;
   const auto& sync = kt->sync[clip];
-  const int NW = int (kt->slices ? kt->slice_want[0].size() : sync.want_list.size());
+  const int NW = kt->slices ? kt->want_rows_of_slices() : int (sync.want_list.size());
   const size_t n_cand = job.candidates.size();
   job.refined.clear();
   job.batch_pending = false;
@@ -486,7 +486,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
 {
   const int clip = mode == Mode::CLIP;
   const auto& sync = kt->sync[clip];
-  const int NW = int (kt->slices ? kt->slice_want[0].size() : sync.want_list.size());
+  const int NW = kt->slices ? kt->want_rows_of_slices() : int (sync.want_list.size());
   const long long total = total_frames (mode);
   const int TP = REFINE_TP, QS = REFINE_QS;
   hipStream_t st = m_lane->stream;
@@ -534,7 +534,7 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
       // per (candidate, sync frame): a (1024 + 8 (T - 1))-sample window read once, T rows of dB values written
       if (count)
         db_bytes += double (NW) * ((1024.0 + 8.0 * (count - 1)) * 4 * wav.n_channels + 4.0 * row_values * count);
-      const std::vector<int>& want_list = kt->slices ? kt->slice_want[job.cand_slice[c0 + c]] : sync.want_list;
+      const int *want_list = kt->slices ? kt->want_of_slice (job.cand_slice[c0 + c]) : sync.want_list.data();
       for (int w = 0; w < NW; w++)
         {
           stream_base[c * NW + w] = slice0 + start + (long long) want_list[w] * Params::frame_size;

@@ -3,6 +3,7 @@
 #include "wmspeed.hh"
 #include <atomic>
 #include <future>
+#include <chrono>
 #include <memory>
 #include <thread>
 #include "utils.hh"
@@ -11,6 +12,7 @@
 #include <map>
 
 namespace awm {
+int g_key_tables_on_device = 1;         // awm_debug_set_key_tables_on_device (capi_kernels.cc): batches with one key per clip build their tables on the device
 
 /* ---- soft bits ------------------------------------------------------------------------ */
 
@@ -1350,10 +1352,18 @@ get_watermark_device (awm_ctx *ctx, const std::vector<Key>& key_list, const Devi
  * 886-939).  Alone, such a clip is ~45 small launches and copies and 3 host round trips around a few hundred microseconds of GPU
  * work.  A batch of them is therefore processed in GROUPS: the padded copies of a group lie side by side in one buffer (equal
  * slices), and every stage -- pad + silence scan, dB matrices, approximate scan, local mean, peak selection, refinement, block dB +
- * soft bits, Viterbi -- is ONE launch for the whole group (SyncFinder::group_*), with one wait per stage.  Two host threads work on
- * their own lanes, so that the waits of one overlap the kernels of the other. */
+ * soft bits, Viterbi -- is ONE launch for the whole group (SyncFinder::group_*), with one wait per stage.  Two to four host threads work
+ * on their own lanes, so that the waits of one overlap the kernels of the others. */
 constexpr int CLIP_GROUP = 64;          // clips per group
-constexpr int STAGED_THREADS = 2;
+static std::atomic<long long> g_clip_key_us[3];
+extern "C" void awm_debug_clip_key_timing (double out[3]) { for (int i = 0; i < 3; i++) out[i] = double (g_clip_key_us[i].exchange (0)); }
+/* host threads (= lanes) of a batch: 0 = as shipped -- four (get of 1024 clips with one key: 203 / 199 / 195 / 193 ms with 2 / 3 / 4 / 6
+ * threads; with a key per clip and the tables from the device, K16g: 211 / 204 / 201 with 2 / 3 / 4), but two for a batch with a key per
+ * clip whose tables come from host threads: there every thread also builds and packs its groups' key tables (64 table threads
+ * each), and a third and fourth make the groups wait for their tables longer than they shorten the device's idle time (206 / 205 /
+ * 208 / 211 ms with 2 / 3 / 4 / 6; tools/gpu_clip_keys_ab.py) */
+static int g_staged_threads = 0;
+extern "C" void awm_debug_set_staged_threads (int n) { g_staged_threads = n < 0 ? 0 : (n > 8 ? 8 : n); }
 
 static bool
 clip_is_short (const DeviceWav& w)
@@ -1364,14 +1374,14 @@ clip_is_short (const DeviceWav& w)
 /* The key tables of a group of clips with ONE KEY PER CLIP: built on host threads (2226 up / down draws, three shuffles per key:
  * ~3 ms of one core), packed into one page-locked block, one copy to the device; `kt` then describes the group (KeyTables::slices). */
 namespace {
-constexpr int TABLE_THREADS = 64;
+int g_table_threads = 64;
 size_t align256 (size_t n) { return (n + 255) & ~size_t (255); }
 
 std::vector<ClipKeyHost>
 build_group_hosts (const std::vector<Key>& keys)
 {
   std::vector<ClipKeyHost> hosts (keys.size());
-  const size_t n_threads = std::max<size_t> (1, std::min<size_t> ({ keys.size(), size_t (TABLE_THREADS), size_t (std::max (1u, std::thread::hardware_concurrency())) }));
+  const size_t n_threads = std::max<size_t> (1, std::min<size_t> ({ keys.size(), size_t (g_table_threads), size_t (std::max (1u, std::thread::hardware_concurrency())) }));
   std::atomic<size_t> next { 0 };
   ParamValues *const pv = &params();
   auto work = [&] {
@@ -1387,6 +1397,25 @@ build_group_hosts (const std::vector<Key>& keys)
     t.join();
   return hosts;
 }
+
+}
+/* (measurement, host only) wall time in ms of the key tables of one group of n_keys clips, built as `get` builds them; threads <= 0: as shipped */
+extern "C" double
+awm_debug_time_group_key_tables (int n_keys, int threads)
+{
+  std::vector<Key> keys (std::max (n_keys, 1));
+  for (size_t i = 0; i < keys.size(); i++)
+    keys[i].set_test_key (1000 + i);
+  const int before = g_table_threads;
+  if (threads > 0)
+    g_table_threads = threads;
+  const auto t0 = std::chrono::steady_clock::now();
+  const auto hosts = build_group_hosts (keys);
+  const double ms = std::chrono::duration<double, std::milli> (std::chrono::steady_clock::now() - t0).count();
+  g_table_threads = before;
+  return hosts.size() == keys.size() ? ms : -1;
+}
+namespace {
 
 int
 upload_group_tables (WorkLane *lane, const std::vector<ClipKeyHost>& hosts, KeyTables& kt)
@@ -1437,6 +1466,193 @@ upload_group_tables (WorkLane *lane, const std::vector<ClipKeyHost>& hosts, KeyT
     kt.slice_want.push_back (k.want);
   return 0;
 }
+
+/* The same group tables built ON THE DEVICE (K16g, hip/keytab.hip): one workgroup per key on a stream of its own, one group ahead of the
+ * lane -- two table areas in turn.  What the host contributes per key is the AES key schedule (176 bytes); what comes back is the want
+ * list (4 KB per key: the host places the refinement's rows with it).  A key's tables cost 1.3 ms of a host core, and a process on the
+ * GPU box may use 16 cores (cgroup cpu.max): 1024 keys are 1.3 s of host time per call beside 0.2 s of device work -- the lanes
+ * waited 12 ms per call for their tables with two host threads and longer with more (tools/gpu_clip_keys_ab.py). */
+struct DeviceGroupTables
+{
+  static constexpr size_t N_CHAIN = size_t (12) * awmk::CLIP_KEY_ROWS * 8, NW = awmk::CLIP_KEY_WANT, N_POS = NW * Params::n_bands,
+                          N_MIX = awmk::CLIP_KEY_MIX, N_ORD = awmk::CLIP_KEY_CODED, G = CLIP_GROUP;
+  static constexpr size_t AUX_BYTES = 256 + G * 176, WANT_BYTES = G * NW * sizeof (int);
+  awm_ctx    *ctx = nullptr;
+  WorkLane   *lane = nullptr;
+  hipStream_t table_stream = nullptr;
+  hipEvent_t  ev[2] = { nullptr, nullptr };
+  size_t      off_chain = 0, off_perm = 0, off_pos = 0, off_mf = 0, off_mu = 0, off_md = 0, off_ord = 0, off_rf = 0, off_want = 0, half_bytes = 0, pin_half = 0;
+
+  static bool
+  possible()
+  {
+    return g_key_tables_on_device && params().mix && mark_block_frame_count() == 2226 && mark_sync_frame_count() == 510
+        && mark_data_frame_count() * Params::bands_per_frame == N_MIX && code_size (ConvBlockType::a, params().payload_size) == N_ORD;
+  }
+  ~DeviceGroupTables()
+  {
+    if (table_stream && (ev[0] || ev[1]))
+      (void) hipStreamSynchronize (table_stream);                       // (an early return: nothing of ours is left in flight)
+    for (hipEvent_t e : ev)
+      if (e)
+        (void) hipEventDestroy (e);
+  }
+  int
+  init (awm_ctx *c, WorkLane *l, WorkLane *table_lane)
+  {
+    ctx = c;
+    lane = l;
+    table_stream = table_lane->stream;
+    off_chain = 0;
+    off_perm = align256 (off_chain + G * N_CHAIN * sizeof (unsigned));
+    off_pos = align256 (off_perm + G * NW * sizeof (int));
+    off_mf = align256 (off_pos + G * N_POS);
+    off_mu = align256 (off_mf + G * N_MIX * sizeof (int16_t));
+    off_md = align256 (off_mu + G * N_MIX);
+    off_ord = align256 (off_md + G * N_MIX);
+    off_rf = align256 (off_ord + G * N_ORD * sizeof (int));
+    off_want = align256 (off_rf + G * NW * sizeof (int));
+    half_bytes = align256 (off_want + WANT_BYTES);
+    pin_half = align256 (AUX_BYTES) + align256 (WANT_BYTES);
+    if (int rc = lane->ws_keytab.reserve (2 * half_bytes)) return rc;
+    if (int rc = lane->ws_keytab_aux.reserve (2 * align256 (AUX_BYTES))) return rc;
+    if (int rc = lane->ws_keytab_scratch.reserve (G * awmk::key_table_scratch_bytes())) return rc;
+    if (int rc = lane->pin_keytab.reserve (2 * pin_half)) return rc;
+    for (hipEvent_t& e : ev)
+      AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
+    // (the lane's earlier work may still read these buffers; and the clips' producers are behind the lane's stream)
+    AWM_HIP_CHECK (hipEventRecord (ev[0], lane->stream));
+    AWM_HIP_CHECK (hipStreamWaitEvent (table_stream, ev[0], 0));
+    return 0;
+  }
+  /* queue the tables of `keys` (<= CLIP_GROUP) into area `half`; the area's previous group must be through on the lane */
+  int
+  launch (const std::vector<Key>& keys, int half)
+  {
+    unsigned char *aux = lane->pin_keytab.as<unsigned char>() + size_t (half) * pin_half;
+    std::memcpy (aux, Aes128::sbox(), 256);
+    for (size_t i = 0; i < keys.size(); i++)
+      {
+        Aes128 aes;
+        aes.set_key (keys[i].aes_key());
+        std::memcpy (aux + 256 + 176 * i, aes.round_keys(), 176);
+      }
+    unsigned char *d_aux = lane->ws_keytab_aux.as<unsigned char>() + size_t (half) * align256 (AUX_BYTES);
+    AWM_HIP_CHECK (hipMemcpyAsync (d_aux, aux, 256 + 176 * keys.size(), hipMemcpyHostToDevice, table_stream));
+    char *d = lane->ws_keytab.as<char>() + size_t (half) * half_bytes;
+    awmk::KeyTableArgs ka {};
+    ka.sbox = d_aux;
+    ka.round_keys = d_aux + 256;
+    ka.scratch = lane->ws_keytab_scratch.as<unsigned char>();
+    ka.scratch_slots = int (G);
+    ka.n_keys = (long long) keys.size();
+    awmk::ClipKeyTableOut o {};
+    o.chains = reinterpret_cast<unsigned int *> (d + off_chain);
+    o.perm = reinterpret_cast<int *> (d + off_perm);
+    o.pos = reinterpret_cast<unsigned char *> (d + off_pos);
+    o.mix_frame = reinterpret_cast<short *> (d + off_mf);
+    o.mix_up = reinterpret_cast<unsigned char *> (d + off_mu);
+    o.mix_down = reinterpret_cast<unsigned char *> (d + off_md);
+    o.inv_order = reinterpret_cast<int *> (d + off_ord);
+    o.row_frames = reinterpret_cast<int *> (d + off_rf);
+    o.want = reinterpret_cast<int *> (d + off_want);
+    {
+      ProfScope ps (ctx, PROF_KEYTAB, double (keys.size()) * double (half_bytes) / double (G), table_stream);
+      AWM_HIP_CHECK (awmk::launch_clip_key_tables (table_stream, ka, o));
+    }
+    AWM_HIP_CHECK (hipMemcpyAsync (aux + align256 (AUX_BYTES), d + off_want, keys.size() * NW * sizeof (int), hipMemcpyDeviceToHost, table_stream));
+    AWM_HIP_CHECK (hipEventRecord (ev[half], table_stream));
+    return 0;
+  }
+  /* the lane's stream waits for area `half`; kt describes it (want lists: want_ready) */
+  int
+  use (int half, size_t gn, KeyTables& kt)
+  {
+    AWM_HIP_CHECK (hipStreamWaitEvent (lane->stream, ev[half], 0));
+    char *d = lane->ws_keytab.as<char>() + size_t (half) * half_bytes;
+    auto view = [] (DevBuffer& b, void *ptr, size_t n) { b.ptr = ptr; b.bytes = n; };     // (non-owning: never released through kt)
+    kt = KeyTables();
+    kt.slices = int (gn);
+    kt.mix = params().mix;
+    kt.sync[1].host.rows_per_bit = awmk::CLIP_KEY_ROWS;
+    view (kt.sync[1].chains_approx, d + off_chain, gn * N_CHAIN * sizeof (unsigned));
+    view (kt.sync[1].refine_perm, d + off_perm, gn * NW * sizeof (int));
+    view (kt.sync[1].refine_pos, d + off_pos, gn * N_POS);
+    view (kt.mix_frame, d + off_mf, gn * N_MIX * sizeof (int16_t));
+    view (kt.mix_up, d + off_mu, gn * N_MIX);
+    view (kt.mix_down, d + off_md, gn * N_MIX);
+    view (kt.bit_order_inv_dev, d + off_ord, gn * N_ORD * sizeof (int));
+    view (kt.sync[1].row_frames, d + off_rf, gn * NW * sizeof (int));
+    kt.slice_want_flat = reinterpret_cast<const int *> (lane->pin_keytab.as<unsigned char>() + size_t (half) * pin_half + align256 (AUX_BYTES));
+    kt.slice_want_n = int (NW);
+    return 0;
+  }
+  /* before the host reads the want lists of area `half` */
+  int
+  want_ready (int half)
+  {
+    AWM_HIP_CHECK (hipEventSynchronize (ev[half]));
+    return 0;
+  }
+};
+}
+
+/* (test) the tables of n_keys keys from the device against the host's, group by group as `get` builds them: mismatch_out[0 .. 8] = number
+ * of differing elements in chains, row_frames, want, perm, pos, mix_frame, mix_up, mix_down, inv_order */
+int
+clip_key_tables_check (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, long long mismatch_out[9])
+{
+  if (!keys || !mismatch_out || !DeviceGroupTables::possible())
+    {
+      set_error ("awm_debug_clip_key_tables_check_d: bad argument, or parameters the device tables do not cover");
+      return AWM_ERR_ARG;
+    }
+  std::fill (mismatch_out, mismatch_out + 9, 0);
+  using D = DeviceGroupTables;
+  WorkLane *lane = ctx->lane (0), *table_lane = ctx->lane (1);
+  if (!table_lane)
+    return AWM_ERR_HIP;
+  AWM_HIP_CHECK (stream_wait (lane->stream));
+  D dev;
+  if (int rc = dev.init (ctx, lane, table_lane)) return rc;
+  std::vector<char> back (dev.half_bytes);
+  auto count = [] (const auto *a, const auto *b, size_t n) { long long bad = 0; for (size_t i = 0; i < n; i++) bad += a[i] != b[i]; return bad; };
+  size_t group = 0;
+  for (size_t g0 = 0; g0 < n_keys; g0 += D::G, group++)
+    {
+      const size_t gn = std::min (D::G, n_keys - g0);
+      std::vector<Key> group_keys (gn);
+      for (size_t i = 0; i < gn; i++)
+        group_keys[i].set_raw (keys + 16 * (g0 + i));
+      const int half = int (group & 1);
+      if (int rc = dev.launch (group_keys, half)) return rc;
+      KeyTables kt;
+      if (int rc = dev.use (half, gn, kt)) return rc;
+      if (int rc = dev.want_ready (half)) return rc;
+      AWM_HIP_CHECK (hipMemcpyAsync (back.data(), lane->ws_keytab.as<char>() + size_t (half) * dev.half_bytes, dev.half_bytes, hipMemcpyDeviceToHost, lane->stream));
+      AWM_HIP_CHECK (stream_wait (lane->stream));
+      const char *b = back.data();
+      for (size_t i = 0; i < gn; i++)
+        {
+          const ClipKeyHost h = build_clip_key_host (group_keys[i]);
+          if (h.chains.size() != D::N_CHAIN || h.want.size() != D::NW || h.pos.size() != D::N_POS || h.mix.frame.size() != D::N_MIX || h.inv_order.size() != D::N_ORD)
+            {
+              set_error ("clip key tables of unexpected shape");
+              return AWM_ERR_GENERIC;
+            }
+          mismatch_out[0] += count (h.chains.data(), reinterpret_cast<const unsigned *> (b + dev.off_chain) + i * D::N_CHAIN, D::N_CHAIN);
+          mismatch_out[1] += count (h.row_frames.data(), reinterpret_cast<const int *> (b + dev.off_rf) + i * D::NW, D::NW);
+          mismatch_out[2] += count (h.want.data(), kt.want_of_slice (int (i)), D::NW);
+          mismatch_out[2] += count (h.want.data(), reinterpret_cast<const int *> (b + dev.off_want) + i * D::NW, D::NW);
+          mismatch_out[3] += count (h.perm.data(), reinterpret_cast<const int *> (b + dev.off_perm) + i * D::NW, D::NW);
+          mismatch_out[4] += count (h.pos.data(), reinterpret_cast<const unsigned char *> (b + dev.off_pos) + i * D::N_POS, D::N_POS);
+          mismatch_out[5] += count (h.mix.frame.data(), reinterpret_cast<const int16_t *> (b + dev.off_mf) + i * D::N_MIX, D::N_MIX);
+          mismatch_out[6] += count (h.mix.up.data(), reinterpret_cast<const uint8_t *> (b + dev.off_mu) + i * D::N_MIX, D::N_MIX);
+          mismatch_out[7] += count (h.mix.down.data(), reinterpret_cast<const uint8_t *> (b + dev.off_md) + i * D::N_MIX, D::N_MIX);
+          mismatch_out[8] += count (h.inv_order.data(), reinterpret_cast<const int *> (b + dev.off_ord) + i * D::N_ORD, D::N_ORD);
+        }
+    }
+  return 0;
 }
 
 /* frames of zeros written on either side of a clip in its padded slice (kernels.hh launch_clip_pad: the consumers read at most
@@ -1452,7 +1668,7 @@ extern "C" void awm_debug_set_group_fallback (int on) { g_group_force_fallback =
 /* clip_keys (may be null): one key per clip -- clip i is searched and decoded with (*clip_keys)[i] alone (key_list is not used then) */
 static int
 clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips, const std::vector<size_t>& which,
-                   std::vector<ResultSet>& result_sets, const std::vector<Key> *clip_keys = nullptr)
+                   std::vector<ResultSet>& result_sets, const std::vector<Key> *clip_keys = nullptr, WorkLane *table_lane = nullptr)
 {
   const size_t count = mark_block_frame_count();
   const int n_bits_a = int (mark_data_frame_count() / params().frames_per_bit);
@@ -1479,7 +1695,17 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
     ~LaneDrain() { if (!ok) (void) hipStreamSynchronize (st); }
   } drain { st };
   std::vector<ResultSet> chunk_sets (which.size());
-  for (size_t g0 = 0; g0 < which.size(); )
+  // one key per clip: the groups' tables from the device (K16g), one group ahead on the table lane's stream -- or from host threads
+  DeviceGroupTables dev_tables;
+  const bool tables_on_device = clip_keys && table_lane && !which.empty() && DeviceGroupTables::possible();
+  if (tables_on_device)
+    {
+      AWM_HIP_CHECK (stream_wait (st));                      // (the lane's table buffers may be re-allocated: nothing of an earlier call reads them)
+      if (int rc = dev_tables.init (ctx, lane, table_lane)) return rc;
+      if (int rc = dev_tables.launch (group_keys (0, group_size (0)), 0)) return rc;
+    }
+  size_t group_index = 0;
+  for (size_t g0 = 0; g0 < which.size(); group_index++)
     {
       // a group: up to CLIP_GROUP clips with the same number of channels (the slices of a group are equal)
       const int C = clips[which[g0]].n_channels;
@@ -1525,10 +1751,21 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
         ptrs.push_back (&cs);
       KeyTables group_kt;
       std::vector<Key> keys_of_group;
-      if (clip_keys)
+      const int half = int (group_index & 1);
+      if (tables_on_device)
         {
           keys_of_group = group_keys (g0, gn);
+          // (the other area's group -- the previous one -- is through: its results have been waited for)
+          if (g0 + gn < which.size())
+            if (int rc = dev_tables.launch (group_keys (g0 + gn, group_size (g0 + gn)), half ^ 1)) return rc;
+          if (int rc = dev_tables.use (half, gn, group_kt)) return rc;
+        }
+      else if (clip_keys)
+        {
+          keys_of_group = group_keys (g0, gn);
+          const auto tk0 = std::chrono::steady_clock::now();
           std::vector<ClipKeyHost> hosts = next_hosts.valid() ? next_hosts.get() : build_group_hosts (keys_of_group);
+          const auto tk1 = std::chrono::steady_clock::now();
           if (g0 + gn < which.size())
             {
               const size_t n0 = g0 + gn;
@@ -1538,6 +1775,10 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
             }
           if (int rc = upload_group_tables (lane, hosts, group_kt))
             return rc;
+          const auto tk2 = std::chrono::steady_clock::now();
+          g_clip_key_us[0] += std::chrono::duration_cast<std::chrono::microseconds> (tk1 - tk0).count();
+          g_clip_key_us[1] += std::chrono::duration_cast<std::chrono::microseconds> (tk2 - tk1).count();
+          g_clip_key_us[2] += 1;
         }
       bool db_ready = false;                 // the group's dB matrices are shared by the keys
       const std::vector<Key> one_pass { Key() };
@@ -1551,6 +1792,8 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
           std::vector<std::vector<SyncFinder::Score>> scores;
           if (int rc = finder.group_approx_launch (kt, group, int (gn), d_range, gj, db_ready)) return rc;
           db_ready = gj.n_scores > 0;
+          if (tables_on_device)
+            if (int rc = dev_tables.want_ready (half)) return rc;
           if (int rc = finder.group_select_refine (gj)) return rc;
           if (int rc = finder.group_finish (gj, scores)) return rc;
           // soft bits and Viterbi decodes of ALL clips of the group in one batch
@@ -1666,7 +1909,7 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
       if (!ctx->ev_sync)
         AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_sync, hipEventDisableTiming));
       AWM_HIP_CHECK (hipEventRecord (ctx->ev_sync, ctx->stream));                   // the clips may still be in flight there
-      const int n_staged_threads = std::max (1, std::min<int> (STAGED_THREADS, int ((staged.size() + CLIP_GROUP - 1) / CLIP_GROUP)));
+      const int n_staged_threads = std::max (1, std::min<int> (g_staged_threads ? g_staged_threads : (clip_keys && !DeviceGroupTables::possible() ? 2 : 4), int ((staged.size() + CLIP_GROUP - 1) / CLIP_GROUP)));
       if (!clip_keys)
         for (const Key& key : key_list)
           if (!ctx->get_key_tables (key))               // built once, before the workers start
@@ -1684,6 +1927,15 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
             AWM_HIP_CHECK (hipStreamWaitEvent (l->stream, ctx->ev_sync, 0));
           staged_lanes.push_back (l);
         }
+      // one key per clip: every thread builds its groups' tables on a stream beside its lane's (lanes 8 ..: `add`'s batches use 0 .. 8)
+      std::vector<WorkLane *> table_lanes (n_staged_threads, nullptr);
+      if (clip_keys && DeviceGroupTables::possible())
+        for (int t = 0; t < n_staged_threads; t++)
+          if (!(table_lanes[t] = ctx->lane (std::min (8 + t, MAX_LANES - 1))))
+            {
+              set_error ("cannot create a work lane (stream)");
+              return AWM_ERR_HIP;
+            }
       // whole groups per thread, dealt round robin
       std::vector<std::vector<size_t>> share (n_staged_threads);
       for (size_t i = 0; i < staged.size(); i++)
@@ -1696,11 +1948,11 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
         workers.emplace_back ([&, t] {
           ParamsBind bind (pv);
           (void) hipSetDevice (ctx->device);
-          rcs[t] = clip_batch_staged (ctx, staged_lanes[t], key_list, clips, share[t], result_sets, clip_keys);
+          rcs[t] = clip_batch_staged (ctx, staged_lanes[t], key_list, clips, share[t], result_sets, clip_keys, table_lanes[t]);
           if (rcs[t])
             messages[t] = last_error();
         });
-      rcs[0] = clip_batch_staged (ctx, staged_lanes[0], key_list, clips, share[0], result_sets, clip_keys);
+      rcs[0] = clip_batch_staged (ctx, staged_lanes[0], key_list, clips, share[0], result_sets, clip_keys, table_lanes[0]);
       for (auto& w : workers)
         w.join();
       for (int t = 0; t < n_staged_threads; t++)

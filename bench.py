@@ -85,7 +85,7 @@ KERNELS = {
     "resample_var_kernel": ("resample_var_kernel", "VALU issue <-> LDS coefficient reads: 17 VALU (zita's 14 roundings + 3) and 3 LDS instructions per stereo tap pair"),
     "speed_mags_kernel": ("speed_mags_kernel", "LDS gathers in the reference's summation order (60 per time step and sync frame) + load latency"),
     "speed_compare_kernel": ("speed_compare_kernel", "VALU issue: 7 instructions per (column, speed); the matrix is served by L2 (11 relative speeds per centre share it)"),
-    "frame_mod_table_kernel": ("frame_mod_table_kernel", "the serial swap chain of the 51 480-entry shuffle: LDS round trips (64 / 16 / 4 / 1 swaps per trip)"),
+    "frame_mod_table_kernel": ("frame_mod_table_kernel (add: K16) | clip_key_table_kernel (get: K16g)", "the serial swap chain of the 51 480-entry shuffle: LDS round trips (64 / 16 / 4 / 1 swaps per trip)"),
     "viterbi_kernel": ("viterbi_super_kernel<0> (chain of 14 launches) | viterbi_persistent_kernel (one launch): see viterbi_form",
                        "latency: 143 dependent trellis steps, a chunk's ~37 decodes are one wave per SIMD; 8 workgroups per decode exchange their metrics every 12 steps "
                        "-- through 14 dependent launches where launches are cheap on the host, through per-decode counters inside ONE launch where they are not"),
@@ -551,7 +551,7 @@ def main():
         audio_seconds = args.clips * 30.0
         workload = (f"{args.clips} clips of 30 s stereo 44.1 kHz test-gen-noise (--test-key k, 16 bit) over {world} GPU(s) (replicas: {len(mine)} on rank 0), "
                     f"add + get per clip with the clip's own key k (awm_add_watermark_batch_keys_d / awm_get_watermark_batch_keys_d: groups of 64 clips, "
-                    f"`add`: the frame_mod tables of 256 keys per launch of the device's table kernel (K16) on its own stream while the previous 256 clips are watermarked; `get`: a group's tables on host threads while the device works on the previous group; one launch per stage and group)")
+                    f"`add`: the frame_mod tables of 256 keys per launch of the device's table kernel (K16) on its own stream while the previous 256 clips are watermarked; `get`: a group's sync / mix / bit order tables from the device as well (K16g, one group ahead on a stream beside the lane's); one launch per stage and group)")
 
         def step():
             ctx.add_watermark_batch_keys(keys, PAYLOAD, clips, outs)

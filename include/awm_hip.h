@@ -411,7 +411,11 @@ void awm_debug_set_speed_overlap (int on);   /* get with a speed search: 1 (defa
 int  awm_debug_frame_mod_tables_d (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, const char *payload_hex, int8_t *tables_out);
                                              /* the frame_mod tables as K16 builds them (wmadd.cc:86-162), n_keys x 2 x 2226 x 81 bytes to host memory:
                                               * for the test that they equal awm_tab_frame_mod key by key */
-void awm_debug_set_key_tables_on_device (int on);   /* batches with one key per clip: the frame_mod tables built by K16 on the device (default) | on host threads */
+int  awm_debug_clip_key_tables_check_d (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, long long mismatch_out[9]);
+                                             /* the tables `get` needs per key of a clip batch (K16g: sync chains, row frames, want list, gathered layout,
+                                              * mix entries, bit order) built on the device, group by group, against the host's build of the same tables:
+                                              * mismatch_out[i] = differing elements per table (all 0 = identical) */
+void awm_debug_set_key_tables_on_device (int on);   /* batches with one key per clip: `add`'s frame_mod tables (K16) and `get`'s sync / mix / bit order tables (K16g) built on the device (default) | on host threads */
 void awm_debug_set_merge_decodes (int on);  /* get of a stream of 2 - 4 chunks: the chunks' Viterbi jobs as ONE batch at the end | per chunk (default: the step is faster) */
 void awm_debug_set_add_slab_mb (int mb);   /* add: 0 (default) one fused add over the stream, then the limiter | > 0: in slabs of that many MB (cache experiment) */
 void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transforms pipelined in one wave (default) | one after the other */
@@ -419,6 +423,11 @@ void awm_debug_set_clip_poison (int on);    /* clip batches: the padded slices a
                                             * frames of zeros on either side, not the rest of the padding: a consumer that read further would change its result) */
 void awm_debug_set_clip_pad_margin (int frames); /* clip batches: frames of zeros written on either side of a clip (default and minimum 2048; one slice = 6693 frames
                                             * or more: whole slices, the A side of the measurement in tools/gpu_clip_margin_ab.py) */
+void awm_debug_set_staged_threads (int n);  /* clip batches: host threads (= lanes) working on groups of clips; 0 = default (4 with one key, 2 with a key per clip) */
+void awm_debug_clip_key_timing (double us_out[3]); /* get with a key per clip, summed over the batch's host threads since the last call: [0] microseconds waiting for
+                                            * a group's key tables (built on host threads one group ahead), [1] packing + uploading them, [2] groups */
+double awm_debug_time_group_key_tables (int n_keys, int threads); /* host only: wall milliseconds the key tables of one group of n_keys clips take to build
+                                            * (threads <= 0: 64 as shipped) */
 void awm_debug_set_group_fallback (int on); /* clip batches: every clip takes the sequential peak selection on its own slice (normally the rare clips whose peak
                                             * lists overflow the grouped selection) */
 void awm_debug_alloc_stats (long *dev_allocs, double *dev_ms, long *pinned_allocs, double *pinned_ms);

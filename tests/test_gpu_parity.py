@@ -532,6 +532,35 @@ def test_key_tables_on_the_device(gpu):
     assert all(gpu.torch.equal(a, b) for a, b in zip(host_side, device_side))
 
 
+def test_get_key_tables_on_the_device(gpu):
+    """K16g (hip/keytab.hip): the tables `get` needs per key of a clip batch -- K5w's sync chains and row frames, the want list, K4s's
+    gathered layout (perm, pos), the mix entries in shuffled order, the inverse bit order -- built on the device, group by group as the
+    batch path builds them, equal the host's build of the same tables element for element, for 1024 keys (test keys, the zero key, random
+    128 bit keys); and a batch `get` with one key per clip finds the same patterns with the tables from either side."""
+    import ctypes as C
+    rng = np.random.default_rng(98)
+    keys = [gpu.awm.test_key(k) for k in range(1, 1001)] + [bytes(16)] + [bytes(rng.integers(0, 256, 16, dtype=np.uint8)) for _ in range(23)]
+    flat = b"".join(gpu.awm.key_bytes(k) for k in keys)
+    bad = (C.c_longlong * 9)()
+    rc = gpu.awm.lib.awm_debug_clip_key_tables_check_d(gpu.ctx._h, flat, C.c_size_t(len(keys)), bad)
+    assert rc == 0, gpu.awm.lib.awm_last_error()
+    assert list(bad) == [0] * 9, dict(zip("chains row_frames want perm pos mix_frame mix_up mix_down inv_order".split(), bad))
+    # 150 clips = three groups on two lanes (one of them with two groups: both table areas in turn), lengths ragged, one clip silent
+    n = 150
+    clips = [noise(700 + i, (12 + i % 19) * 44100 + 11 * i, 2) for i in range(n)]
+    clips[40][:] = 0
+    marked = gpu.ctx.add_watermark_batch_keys(keys[:n], PAY2, [gpu.dev(c) for c in clips])
+    try:
+        gpu.awm.lib.awm_debug_set_key_tables_on_device(0)
+        host_side = gpu.ctx.get_watermark_batch_keys(keys[:n], marked)
+    finally:
+        gpu.awm.lib.awm_debug_set_key_tables_on_device(1)
+    device_side = gpu.ctx.get_watermark_batch_keys(keys[:n], marked)
+    assert device_side == host_side
+    assert device_side == gpu.ctx.get_watermark_batch_keys(keys[:n], marked)          # (and again: the areas are reused)
+    assert sum(any(p["bits"] == PAY2 for p in c) for c in device_side) >= 100
+
+
 def test_multi_context_clip_batches_equal_single_context(gpu):
     """awm_multi_add_watermark_batch_d / awm_multi_get_watermark_batch_d: 40 clips of 20 - 30 s dealt unevenly to three contexts (all on
     the one GPU of the box), every clip with its own key and, in a second pass, one key for all: PCM and pattern lists equal the
