@@ -12,8 +12,10 @@
 //     swaps are sequential -- but independent of each other far more often than not: a chunk of 64 steps whose targets all lie
 //     beyond the chunk and differ goes through in ONE LDS round trip, every lane its own swap (80 % of the chunks; the test is
 //     exact), else a quarter of 16 the same way, else four steps per round trip after a scalar test, else one by one.  The
-//     permutation lives in LDS (51 480 x u16 = 103 KB: one key per compute unit): 1.1 ms for the mix shuffle (one swap per round
-//     trip: 3.2 ms), 2.3 ms per launch of 256 keys; the tables of the next 256 are built while the first 256 clips are watermarked
+//     permutation lives in LDS (51 480 x u16 = 103 KB: one key per compute unit): 0.6 ms for the mix shuffle (one swap per round
+//     trip: 3.2 ms), 1.5 ms per launch of 256 keys (phases: targets 0.2, band shuffles 0.4, swaps 0.6, table 0.4; round 5: 512 lanes per
+//     key, the T-table once per LDS bank, four chunks of targets read ahead, the table's entries eight at a time with their loads first:
+//     2.1 -> 1.5 ms); the tables of the next 256 are built while the first 256 clips are watermarked
 //   the table itself: 2 x 2226 x 81 bytes, every (frame, band) written at most once -- all lanes.
 // Bit-identical to the host's tables (tests/test_gpu_parity.py::test_key_tables_on_the_device).
 #include "kernels.hh"
@@ -26,14 +28,19 @@ constexpr int KT_NB = 81, KT_MIN_BAND = 20, KT_BPF = 30;
 constexpr int KT_SYNC = 510, KT_DATA = 1716, KT_BLOCK = KT_SYNC + KT_DATA;        // frames
 constexpr int KT_SYNC_FPB = 85, KT_CODED = 858, KT_FPB = 2;
 constexpr int KT_MIX = KT_DATA * KT_BPF;                                           // 51 480
-constexpr int KT_WG = 256;
+constexpr int KT_WG = 512;
 
 struct Aes
 {
-  const unsigned int *te0;       // LDS: 256 words (2 s, s, s, 3 s)
-  const unsigned char *sbox;     // LDS
+  // The T-table (2 s, s, s, 3 s per S-box entry) once PER LDS BANK: te[32 x + bank], a lane reads the copy of its own bank (lane mod 32).
+  // The 64 lanes of a lookup name 64 unrelated entries: from ONE table they collide in the 32 banks five or six deep (measured: 2.1 us
+  // per block and wave, the 160 lookups of a block bound by the LDS); with the copies no two lanes of a half wave share a bank.  The
+  // S-box of the last round is the table's second byte.
+  const unsigned int *te;        // LDS: the lane's column of the 256 x 32 words
   unsigned int rk[44];           // big-endian round key words
 
+  __device__ __forceinline__ unsigned int te0 (unsigned int x) const { return te[x << 5]; }
+  __device__ __forceinline__ unsigned int sbox (unsigned int x) const { return (te[x << 5] >> 8) & 0xff; }
   __device__ __forceinline__ static unsigned int rotr (unsigned int v, int n) { return (v >> n) | (v << (32 - n)); }
 
   /* AES-128 of the block (s0 .. s3, big-endian words) */
@@ -44,14 +51,14 @@ struct Aes
 #pragma unroll
     for (int r = 1; r < 10; r++)                          // (unrolled: the round keys stay in scalar registers)
       {
-        const unsigned int t0 = te0[s0 >> 24] ^ rotr (te0[(s1 >> 16) & 0xff], 8) ^ rotr (te0[(s2 >> 8) & 0xff], 16) ^ rotr (te0[s3 & 0xff], 24) ^ rk[4 * r];
-        const unsigned int t1 = te0[s1 >> 24] ^ rotr (te0[(s2 >> 16) & 0xff], 8) ^ rotr (te0[(s3 >> 8) & 0xff], 16) ^ rotr (te0[s0 & 0xff], 24) ^ rk[4 * r + 1];
-        const unsigned int t2 = te0[s2 >> 24] ^ rotr (te0[(s3 >> 16) & 0xff], 8) ^ rotr (te0[(s0 >> 8) & 0xff], 16) ^ rotr (te0[s1 & 0xff], 24) ^ rk[4 * r + 2];
-        const unsigned int t3 = te0[s3 >> 24] ^ rotr (te0[(s0 >> 16) & 0xff], 8) ^ rotr (te0[(s1 >> 8) & 0xff], 16) ^ rotr (te0[s2 & 0xff], 24) ^ rk[4 * r + 3];
+        const unsigned int t0 = te0 (s0 >> 24) ^ rotr (te0 ((s1 >> 16) & 0xff), 8) ^ rotr (te0 ((s2 >> 8) & 0xff), 16) ^ rotr (te0 (s3 & 0xff), 24) ^ rk[4 * r];
+        const unsigned int t1 = te0 (s1 >> 24) ^ rotr (te0 ((s2 >> 16) & 0xff), 8) ^ rotr (te0 ((s3 >> 8) & 0xff), 16) ^ rotr (te0 (s0 & 0xff), 24) ^ rk[4 * r + 1];
+        const unsigned int t2 = te0 (s2 >> 24) ^ rotr (te0 ((s3 >> 16) & 0xff), 8) ^ rotr (te0 ((s0 >> 8) & 0xff), 16) ^ rotr (te0 (s1 & 0xff), 24) ^ rk[4 * r + 2];
+        const unsigned int t3 = te0 (s3 >> 24) ^ rotr (te0 ((s0 >> 16) & 0xff), 8) ^ rotr (te0 ((s1 >> 8) & 0xff), 16) ^ rotr (te0 (s2 & 0xff), 24) ^ rk[4 * r + 3];
         s0 = t0; s1 = t1; s2 = t2; s3 = t3;
       }
     auto sub = [&] (unsigned int a, unsigned int b, unsigned int c, unsigned int d) {
-      return (unsigned (sbox[a >> 24]) << 24) | (unsigned (sbox[(b >> 16) & 0xff]) << 16) | (unsigned (sbox[(c >> 8) & 0xff]) << 8) | unsigned (sbox[d & 0xff]);
+      return (sbox (a >> 24) << 24) | (sbox ((b >> 16) & 0xff) << 16) | (sbox ((c >> 8) & 0xff) << 8) | sbox (d & 0xff);
     };
     const unsigned int t0 = sub (s0, s1, s2, s3) ^ rk[40], t1 = sub (s1, s2, s3, s0) ^ rk[41], t2 = sub (s2, s3, s0, s1) ^ rk[42], t3 = sub (s3, s0, s1, s2) ^ rk[43];
     s0 = t0; s1 = t1; s2 = t2; s3 = t3;
@@ -126,14 +133,30 @@ clip_key_tables_tail (const ClipKeyTableOut& o, long long key, int tid, unsigned
 {
   constexpr int R = CLIP_KEY_ROWS, NW = CLIP_KEY_WANT;
   // ---- mix entries in shuffled order (wmcommon.cc build_mix_table) and the inverse bit order
-  for (int p = tid; p < KT_MIX; p += KT_WG)
+  // (eight entries per lane at a time, their loads ahead of the stores: see the table fill of K16)
+  constexpr int UB = 8;
+  for (int p0 = tid; p0 < KT_MIX; p0 += KT_WG * UB)
     {
-      const int e = s_perm[p];
-      const int f = e / KT_BPF, i = e % KT_BPF;
-      const unsigned char *ud = updown + size_t (KT_SYNC + f) * 60;
-      o.mix_frame[key * KT_MIX + p] = short (s_pos[KT_SYNC + f]);
-      o.mix_up[key * KT_MIX + p] = ud[i];
-      o.mix_down[key * KT_MIX + p] = ud[30 + i];
+      int pos[UB], up[UB], down[UB];
+#pragma unroll
+      for (int k = 0; k < UB; k++)
+        {
+          const int e = s_perm[min (p0 + k * KT_WG, KT_MIX - 1)];
+          const int f = e / KT_BPF, i = e % KT_BPF;
+          const unsigned char *ud = updown + size_t (KT_SYNC + f) * 60;
+          pos[k] = s_pos[KT_SYNC + f];
+          up[k] = ud[i];
+          down[k] = ud[30 + i];
+        }
+#pragma unroll
+      for (int k = 0; k < UB; k++)
+        if (p0 + k * KT_WG < KT_MIX)
+          {
+            const int p = p0 + k * KT_WG;
+            o.mix_frame[key * KT_MIX + p] = short (pos[k]);
+            o.mix_up[key * KT_MIX + p] = (unsigned char) up[k];
+            o.mix_down[key * KT_MIX + p] = (unsigned char) down[k];
+          }
     }
   for (int i = tid; i < KT_CODED; i += KT_WG)
     o.inv_order[key * KT_CODED + s_order[i]] = i;
@@ -210,8 +233,6 @@ clip_key_tables_tail (const ClipKeyTableOut& o, long long key, int tid, unsigned
 template<bool GET> __device__ __forceinline__ void
 key_tables_body (const KeyTableArgs& a, const ClipKeyTableOut& o)
 {
-  __shared__ unsigned int   s_te0[256];
-  __shared__ unsigned char  s_sbox[256];
   __shared__ unsigned short s_perm[KT_MIX];                // the mix shuffle's array: entry numbers
   __shared__ unsigned short s_pos[KT_BLOCK], s_pos_t[KT_BLOCK];      // frame positions and their swap targets
   __shared__ unsigned short s_order[KT_CODED], s_order_t[KT_CODED];  // bit order and its swap targets
@@ -222,16 +243,17 @@ key_tables_body (const KeyTableArgs& a, const ClipKeyTableOut& o)
   static_assert (sizeof (unsigned char[KT_WG][84]) <= sizeof (unsigned short[KT_MIX]), "the band arrays fit into the permutation's memory");
   const int tid = threadIdx.x;
   const long long key = blockIdx.x;
-  for (int i = tid; i < 256; i += KT_WG)
+  // (the 32 copies of the T-table live in the permutation's memory as well, behind the band arrays: the generator is done when the swaps start)
+  unsigned int *s_te = reinterpret_cast<unsigned int *> (s_perm) + 11264;                 // 32 KB from byte 45 056
+  static_assert (sizeof (unsigned char[KT_WG][84]) <= 45056 && 45056 + 32768 <= sizeof (unsigned short[KT_MIX]), "band arrays and T-tables fit into the permutation's memory");
+  for (int i = tid; i < 256 * 32; i += KT_WG)
     {
-      const unsigned int s = a.sbox[i];
+      const unsigned int s = a.sbox[i >> 5];
       const unsigned int s2 = ((s << 1) ^ ((s & 0x80) ? 0x1b : 0)) & 0xff;
-      s_sbox[i] = (unsigned char) s;
-      s_te0[i] = (s2 << 24) | (s << 16) | (s << 8) | (s2 ^ s);
+      s_te[i] = (s2 << 24) | (s << 16) | (s << 8) | (s2 ^ s);
     }
   Aes aes;
-  aes.te0 = s_te0;
-  aes.sbox = s_sbox;
+  aes.te = s_te + (tid & 31);
   {
     const unsigned char *rk = a.round_keys + key * 176;
 #pragma unroll
@@ -321,13 +343,29 @@ key_tables_body (const KeyTableArgs& a, const ClipKeyTableOut& o)
   if (tid < 64)
     {
       static_assert (KT_MIX % 4 == 0, "the swaps are taken four at a time");
-      unsigned int t_next = mix_t[tid];
-      for (int c = 0; c < (KT_MIX + 63) / 64; c++)
+      // (the targets of the NEXT FOUR chunks are on their way while four chunks are worked on: a chunk takes a few hundred nanoseconds, its
+      // targets a microsecond to arrive -- one chunk of read-ahead left the wave waiting for memory in every chunk: 1.1 ms of the 2.1 per key)
+      constexpr int N_CHUNKS = (KT_MIX + 63) / 64;
+      unsigned int t_ahead[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        t_ahead[q] = mix_t[min (q * 64 + tid, KT_MIX - 1)];
+      for (int c0 = 0; c0 < N_CHUNKS; c0 += 4)
+      {
+      unsigned int t_now[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        t_now[q] = t_ahead[q];
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        t_ahead[q] = mix_t[min ((c0 + 4 + q) * 64 + tid, KT_MIX - 1)];       // (clamped: no branch around a load in this loop)
+#pragma unroll
+      for (int cq = 0; cq < 4; cq++)
         {
-          const unsigned int t = t_next;
-          const int nx = (c + 1) * 64 + tid;
-          if (nx < KT_MIX)
-            t_next = mix_t[nx];
+          const int c = c0 + cq;
+          if (c >= N_CHUNKS)
+            break;
+          const unsigned int t = t_now[cq];
           /* A whole chunk of 64 swaps in ONE round trip, every lane its own, when they are independent: every target beyond the
            * chunk (or the step's own place) and all targets distinct -- 64 targets drawn from tens of thousands of places: most chunks.
            * The test is exact (32 rotations of the targets through the wave compare every pair); a chunk that fails it goes four
@@ -420,6 +458,7 @@ key_tables_body (const KeyTableArgs& a, const ClipKeyTableOut& o)
                 }
             }
         }
+      }
     }
   else if (tid == 64)
     apply_swaps (s_pos, s_pos_t, KT_BLOCK);
@@ -444,27 +483,60 @@ key_tables_body (const KeyTableArgs& a, const ClipKeyTableOut& o)
   __threadfence_block();
   __syncthreads();
   constexpr signed char UP = 1, DOWN = 2;
-  for (int ab = 0; ab < 2; ab++)
+  // Both blocks (A, B) in one pass, eight entries per lane at a time with all their loads ahead of the stores: an entry is a chain of
+  // dependent reads (permutation -> band bytes of its frame in global scratch, position, coded bit) in front of two byte stores, and one
+  // workgroup per compute unit has nothing else to cover their latency with (one entry after the other: 0.69 of 2.1 ms per key).
+  signed char *block_a = table, *block_b = table + size_t (KT_BLOCK) * KT_NB;
+  const unsigned char *coded_a = a.coded, *coded_b = a.coded + KT_CODED;      // conv code of the payload, block type A / B
+  constexpr int UB = 8;
+  for (int e0 = tid; e0 < KT_SYNC * KT_BPF; e0 += KT_WG * UB)
     {
-      signed char *block = table + size_t (ab) * KT_BLOCK * KT_NB;
-      const unsigned char *coded = a.coded + ab * KT_CODED;                   // conv code of the payload, block type A / B
-      for (int e = tid; e < KT_SYNC * KT_BPF; e += KT_WG)
+      int pos[UB], up[UB], down[UB], bit[UB];
+#pragma unroll
+      for (int k = 0; k < UB; k++)
         {
+          const int e = min (e0 + k * KT_WG, KT_SYNC * KT_BPF - 1);
           const int f = e / KT_BPF, i = e % KT_BPF;
-          const int bit = (f / KT_SYNC_FPB + ab) & 1;                         // A carries 010101, B 101010
-          signed char *row = block + size_t (s_pos[f]) * KT_NB;
-          row[updown[size_t (f) * 60 + i] - KT_MIN_BAND] = bit ? UP : DOWN;
-          row[updown[size_t (f) * 60 + 30 + i] - KT_MIN_BAND] = bit ? DOWN : UP;
+          bit[k] = (f / KT_SYNC_FPB) & 1;                                     // A carries 010101, B 101010
+          pos[k] = s_pos[f];
+          up[k] = updown[size_t (f) * 60 + i] - KT_MIN_BAND;
+          down[k] = updown[size_t (f) * 60 + 30 + i] - KT_MIN_BAND;
         }
-      for (int p = tid; p < KT_MIX; p += KT_WG)
+#pragma unroll
+      for (int k = 0; k < UB; k++)
+        if (e0 + k * KT_WG < KT_SYNC * KT_BPF)
+          {
+            block_a[pos[k] * KT_NB + up[k]] = bit[k] ? UP : DOWN;
+            block_a[pos[k] * KT_NB + down[k]] = bit[k] ? DOWN : UP;
+            block_b[pos[k] * KT_NB + up[k]] = bit[k] ? DOWN : UP;
+            block_b[pos[k] * KT_NB + down[k]] = bit[k] ? UP : DOWN;
+          }
+    }
+  for (int p0 = tid; p0 < KT_MIX; p0 += KT_WG * UB)
+    {
+      int pos[UB], up[UB], down[UB], bit_a[UB], bit_b[UB];
+#pragma unroll
+      for (int k = 0; k < UB; k++)
         {
+          const int p = min (p0 + k * KT_WG, KT_MIX - 1);
           const int e = s_perm[p];                                            // entry (data frame f, i) that the shuffle put at position p
           const int f = e / KT_BPF, i = e % KT_BPF;
-          const int bit = coded[s_order[p / (KT_BPF * KT_FPB)]];             // fec[p / 60], fec[k] = coded[order[k]]
-          signed char *row = block + size_t (s_pos[KT_SYNC + f]) * KT_NB;
-          row[updown[size_t (KT_SYNC + f) * 60 + i] - KT_MIN_BAND] = bit ? UP : DOWN;
-          row[updown[size_t (KT_SYNC + f) * 60 + 30 + i] - KT_MIN_BAND] = bit ? DOWN : UP;
+          const int o = s_order[p / (KT_BPF * KT_FPB)];                       // fec[p / 60], fec[k] = coded[order[k]]
+          bit_a[k] = coded_a[o];
+          bit_b[k] = coded_b[o];
+          pos[k] = s_pos[KT_SYNC + f];
+          up[k] = updown[size_t (KT_SYNC + f) * 60 + i] - KT_MIN_BAND;
+          down[k] = updown[size_t (KT_SYNC + f) * 60 + 30 + i] - KT_MIN_BAND;
         }
+#pragma unroll
+      for (int k = 0; k < UB; k++)
+        if (p0 + k * KT_WG < KT_MIX)
+          {
+            block_a[pos[k] * KT_NB + up[k]] = bit_a[k] ? UP : DOWN;
+            block_a[pos[k] * KT_NB + down[k]] = bit_a[k] ? DOWN : UP;
+            block_b[pos[k] * KT_NB + up[k]] = bit_b[k] ? UP : DOWN;
+            block_b[pos[k] * KT_NB + down[k]] = bit_b[k] ? DOWN : UP;
+          }
     }
 }
 
