@@ -12,10 +12,10 @@
 //     swaps are sequential -- but independent of each other far more often than not: a chunk of 64 steps whose targets all lie
 //     beyond the chunk and differ goes through in ONE LDS round trip, every lane its own swap (80 % of the chunks; the test is
 //     exact), else a quarter of 16 the same way, else four steps per round trip after a scalar test, else one by one.  The
-//     permutation lives in LDS (51 480 x u16 = 103 KB: one key per compute unit): 0.6 ms for the mix shuffle (one swap per round
-//     trip: 3.2 ms), 1.5 ms per launch of 256 keys (phases: targets 0.2, band shuffles 0.4, swaps 0.6, table 0.4; round 5: 512 lanes per
-//     key, the T-table once per LDS bank, four chunks of targets read ahead, the table's entries eight at a time with their loads first:
-//     2.1 -> 1.5 ms); the tables of the next 256 are built while the first 256 clips are watermarked
+//     permutation lives in LDS (51 480 x u16 = 103 KB: one key per compute unit): one swap per round trip took 3.2 ms, the chunks with
+//     their tests inside the sequential wave 1.1 ms; 1.16 ms per launch of 256 keys now (round 4: 1.95; round 5: 512 lanes per key, the
+//     T-table once per LDS bank, the independence tests by all waves ahead of the swaps, four chunks of targets read ahead, the
+//     table's entries eight at a time with their loads first); the tables of the next 256 are built while the first 256 clips are watermarked
 //   the table itself: 2 x 2226 x 81 bytes, every (frame, band) written at most once -- all lanes.
 // Bit-identical to the host's tables (tests/test_gpu_parity.py::test_key_tables_on_the_device).
 #include "kernels.hh"
@@ -335,130 +335,146 @@ key_tables_body (const KeyTableArgs& a, const ClipKeyTableOut& o)
   __syncthreads();
   for (int i = tid; i < KT_MIX; i += KT_WG)               // (the band arrays are done with: the memory becomes the permutation)
     s_perm[i] = (unsigned short) i;
+  /* Which swaps of the mix shuffle may go together is decided from the targets alone -- by all waves, before the sequential part:
+   * a chunk of 64 steps is INDEPENDENT when every target lies beyond the chunk (or is the step's own place) and all targets differ
+   * (the test is exact: 32 rotations of the targets through the wave compare every pair); the same for each quarter of 16 steps.
+   * s_chunk[c]: bit 0 = the whole chunk is independent, bits 1 .. 4 = quarter q is NOT.  (In round 4 the one wave that applies the
+   * swaps ran the tests itself, chunk by chunk: 0.59 ms of the kernel.) */
+  constexpr int N_CHUNKS = (KT_MIX + 63) / 64;
+  __shared__ __attribute__ ((aligned (4))) unsigned char s_chunk[(N_CHUNKS + 3) & ~3];
+  {
+    const int lane = tid & 63;
+    for (int c = tid >> 6; c < N_CHUNKS; c += KT_WG / 64)
+      {
+        const int i_mine = c * 64 + lane, last = c * 64 + 63;
+        const int j_mine = mix_t[min (i_mine, KT_MIX - 1)];
+        const bool valid = i_mine < KT_MIX;
+        // (a self swap keeps its place whatever the others do: it takes part with a target nobody else can have)
+        const int j_cmp = j_mine == i_mine ? -1 - lane : j_mine;
+        int others[32];
+#pragma unroll
+        for (int sft = 1; sft <= 32; sft++)                              // all rotations first, then the comparisons: no waits in between
+          others[sft - 1] = __shfl (j_cmp, (lane + sft) & 63);
+        int bad = (j_mine <= last) & (j_mine != i_mine);
+#pragma unroll
+        for (int sft = 0; sft < 32; sft++)
+          bad |= others[sft] == j_cmp;
+        const bool whole = !__any (bad != 0 && valid) && last < KT_MIX;
+        int q_bad = (j_mine <= (i_mine | 15)) & (j_mine != i_mine);
+#pragma unroll
+        for (int sft = 1; sft <= 8; sft++)
+          q_bad |= __shfl (j_cmp, (lane & ~15) | ((lane + sft) & 15)) == j_cmp;
+        const unsigned long long bad_lanes = __ballot (q_bad != 0 || !valid);
+        unsigned int flags = whole ? 1u : 0u;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          flags |= ((bad_lanes >> (16 * q)) & 0xffffull) ? 2u << q : 0u;
+        if (lane == 0)
+          s_chunk[c] = (unsigned char) flags;
+      }
+  }
   __syncthreads();
 
-  // ---- the sequential swaps: three waves, one shuffle each.  The mix shuffle's targets lie in global memory: the wave fetches 64 at a
-  // time (the next 64 are on their way meanwhile) and lane 0 takes them out of the registers one by one (v_readlane) -- a lane that
-  // loaded its own targets would wait a trip to memory per swap.  What remains per swap is one LDS round trip (read both, write both).
+  // ---- the sequential swaps: three waves, one shuffle each.  The mix shuffle's targets lie in global memory: the wave fetches them a
+  // few chunks ahead; an independent chunk is ONE LDS round trip, every lane its own swap; in a chunk that is not, an independent quarter
+  // is one round trip of 16 lanes, and the others go four steps per round trip after a scalar test (the targets are taken out of the
+  // registers with v_readlane -- a lane that loaded its own targets would wait a trip to memory per swap), else one by one.
   if (tid < 64)
     {
       static_assert (KT_MIX % 4 == 0, "the swaps are taken four at a time");
-      // (the targets of the NEXT FOUR chunks are on their way while four chunks are worked on: a chunk takes a few hundred nanoseconds, its
-      // targets a microsecond to arrive -- one chunk of read-ahead left the wave waiting for memory in every chunk: 1.1 ms of the 2.1 per key)
-      constexpr int N_CHUNKS = (KT_MIX + 63) / 64;
+      // (the targets and flags of the NEXT FOUR chunks are on their way while four chunks are worked on: a chunk takes a few hundred
+      // nanoseconds, its targets a microsecond to arrive)
       unsigned int t_ahead[4];
+      unsigned int f_ahead = *reinterpret_cast<const unsigned int *> (s_chunk);
 #pragma unroll
       for (int q = 0; q < 4; q++)
         t_ahead[q] = mix_t[min (q * 64 + tid, KT_MIX - 1)];
       for (int c0 = 0; c0 < N_CHUNKS; c0 += 4)
-      {
-      unsigned int t_now[4];
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        t_now[q] = t_ahead[q];
-#pragma unroll
-      for (int q = 0; q < 4; q++)
-        t_ahead[q] = mix_t[min ((c0 + 4 + q) * 64 + tid, KT_MIX - 1)];       // (clamped: no branch around a load in this loop)
-#pragma unroll
-      for (int cq = 0; cq < 4; cq++)
         {
-          const int c = c0 + cq;
-          if (c >= N_CHUNKS)
-            break;
-          const unsigned int t = t_now[cq];
-          /* A whole chunk of 64 swaps in ONE round trip, every lane its own, when they are independent: every target beyond the
-           * chunk (or the step's own place) and all targets distinct -- 64 targets drawn from tens of thousands of places: most chunks.
-           * The test is exact (32 rotations of the targets through the wave compare every pair); a chunk that fails it goes four
-           * steps at a time (below). */
-          {
-            const int i_mine = c * 64 + tid, last = c * 64 + 63;
-            const int j_mine = int (t);
-            const bool valid = i_mine < KT_MIX;
-            // (a self swap keeps its place whatever the others do: it takes part with a target nobody else can have)
-            const int j_cmp = j_mine == i_mine ? -1 - tid : j_mine;
-            int others[32];
-#pragma unroll
-            for (int sft = 1; sft <= 32; sft++)                              // all rotations first, then the comparisons: no waits in between
-              others[sft - 1] = __shfl (j_cmp, (tid + sft) & 63);
-            int bad = (j_mine <= last) & (j_mine != i_mine);
-#pragma unroll
-            for (int sft = 0; sft < 32; sft++)
-              bad |= others[sft] == j_cmp;
-            if (!__any (bad != 0 && valid) && last < KT_MIX)
-              {
-                const unsigned short x = s_perm[i_mine], y = s_perm[j_mine];
-                s_perm[i_mine] = y;
-                s_perm[j_mine] = x;
-                continue;
-              }
-          }
-          /* A chunk that is not independent as a whole: its four quarters of 16 steps one after the other, each one again all at once
-           * if its 16 steps are independent of each other (targets beyond the quarter, distinct -- decided from the targets alone, so
-           * for all four quarters up front), else four steps per LDS round trip: steps i .. i + 3 with targets j0 .. j3 read { i + k, jk }
-           * and write the same places; if no step reads what an earlier one of the four writes (jm != jk and jm != i + k for m < k;
-           * jk >= i + k > i + m anyway), all eight reads can go out before the first write -- a scalar test, the targets are in scalar
-           * registers; a clash takes the four steps one by one. */
-          const int i_mine = c * 64 + tid;
-          const int j_mine = int (t);
-          const int j_cmp = j_mine == i_mine ? -1 - tid : j_mine;
-          int q_bad = (j_mine <= (i_mine | 15)) & (j_mine != i_mine);
-#pragma unroll
-          for (int sft = 1; sft <= 8; sft++)
-            q_bad |= __shfl (j_cmp, (tid & ~15) | ((tid + sft) & 15)) == j_cmp;
-          const unsigned long long bad_lanes = __ballot (q_bad != 0 || i_mine >= KT_MIX);
+          unsigned int t_now[4];
 #pragma unroll
           for (int q = 0; q < 4; q++)
+            t_now[q] = t_ahead[q];
+          const unsigned int f_now = __builtin_amdgcn_readfirstlane (f_ahead);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            t_ahead[q] = mix_t[min ((c0 + 4 + q) * 64 + tid, KT_MIX - 1)];       // (clamped: no branch around a load in this loop)
+          f_ahead = *reinterpret_cast<const unsigned int *> (s_chunk + min (c0 + 4, ((N_CHUNKS + 3) & ~3) - 4));
+#pragma unroll
+          for (int cq = 0; cq < 4; cq++)
             {
-              if (c * 64 + 16 * q >= KT_MIX)
-                continue;
-              if (((bad_lanes >> (16 * q)) & 0xffffull) == 0)
+              const int c = c0 + cq;
+              if (c >= N_CHUNKS)
+                break;
+              const unsigned int t = t_now[cq];
+              const unsigned int flags = (f_now >> (8 * cq)) & 0xff;
+              const int i_mine = c * 64 + tid;
+              const int j_mine = int (t);
+              if (flags & 1)
                 {
-                  if ((tid >> 4) == q)
-                    {
-                      const unsigned short x = s_perm[i_mine], y = s_perm[j_mine];
-                      s_perm[i_mine] = y;
-                      s_perm[j_mine] = x;
-                    }
+                  const unsigned short x = s_perm[i_mine], y = s_perm[j_mine];
+                  s_perm[i_mine] = y;
+                  s_perm[j_mine] = x;
                   continue;
                 }
+              /* A chunk that is not independent as a whole: its four quarters of 16 steps one after the other, an independent quarter all
+               * at once, else four steps per LDS round trip: steps i .. i + 3 with targets j0 .. j3 read { i + k, jk } and write the same
+               * places; if no step reads what an earlier one of the four writes (jm != jk and jm != i + k for m < k; jk >= i + k > i + m
+               * anyway), all eight reads can go out before the first write -- a scalar test, the targets are in scalar registers; a clash
+               * takes the four steps one by one. */
 #pragma unroll
-              for (int g4 = 0; g4 < 4; g4++)
+              for (int q = 0; q < 4; q++)
                 {
-                  const int g = 4 * q + g4;
-                  const int i0 = c * 64 + 4 * g;
-                  const int j0 = __builtin_amdgcn_readlane (int (t), 4 * g), j1 = __builtin_amdgcn_readlane (int (t), 4 * g + 1);
-                  const int j2 = __builtin_amdgcn_readlane (int (t), 4 * g + 2), j3 = __builtin_amdgcn_readlane (int (t), 4 * g + 3);
-                  if (i0 >= KT_MIX)
+                  if (c * 64 + 16 * q >= KT_MIX)
                     continue;
-                  const bool clash = j0 == j1 || j0 == j2 || j0 == j3 || j1 == j2 || j1 == j3 || j2 == j3
-                                  || j0 == i0 + 1 || j0 == i0 + 2 || j0 == i0 + 3 || j1 == i0 + 2 || j1 == i0 + 3 || j2 == i0 + 3;
-                  if (tid == 0)
+                  if (!(flags & (2u << q)))
                     {
-                      if (!clash)
+                      if ((tid >> 4) == q)
                         {
-                          const unsigned short a0 = s_perm[i0], a1 = s_perm[i0 + 1], a2 = s_perm[i0 + 2], a3 = s_perm[i0 + 3];
-                          const unsigned short b0 = s_perm[j0], b1 = s_perm[j1], b2 = s_perm[j2], b3 = s_perm[j3];
-                          s_perm[i0] = b0;     s_perm[j0] = a0;
-                          s_perm[i0 + 1] = b1; s_perm[j1] = a1;
-                          s_perm[i0 + 2] = b2; s_perm[j2] = a2;
-                          s_perm[i0 + 3] = b3; s_perm[j3] = a3;
+                          const unsigned short x = s_perm[i_mine], y = s_perm[j_mine];
+                          s_perm[i_mine] = y;
+                          s_perm[j_mine] = x;
                         }
-                      else
-                        {
-                          const int js[4] = { j0, j1, j2, j3 };
+                      continue;
+                    }
 #pragma unroll
-                          for (int k = 0; k < 4; k++)
+                  for (int g4 = 0; g4 < 4; g4++)
+                    {
+                      const int g = 4 * q + g4;
+                      const int i0 = c * 64 + 4 * g;
+                      const int j0 = __builtin_amdgcn_readlane (int (t), 4 * g), j1 = __builtin_amdgcn_readlane (int (t), 4 * g + 1);
+                      const int j2 = __builtin_amdgcn_readlane (int (t), 4 * g + 2), j3 = __builtin_amdgcn_readlane (int (t), 4 * g + 3);
+                      if (i0 >= KT_MIX)
+                        continue;
+                      const bool clash = j0 == j1 || j0 == j2 || j0 == j3 || j1 == j2 || j1 == j3 || j2 == j3
+                                      || j0 == i0 + 1 || j0 == i0 + 2 || j0 == i0 + 3 || j1 == i0 + 2 || j1 == i0 + 3 || j2 == i0 + 3;
+                      if (tid == 0)
+                        {
+                          if (!clash)
                             {
-                              const unsigned short x = s_perm[i0 + k], y = s_perm[js[k]];
-                              s_perm[i0 + k] = y;
-                              s_perm[js[k]] = x;
+                              const unsigned short a0 = s_perm[i0], a1 = s_perm[i0 + 1], a2 = s_perm[i0 + 2], a3 = s_perm[i0 + 3];
+                              const unsigned short b0 = s_perm[j0], b1 = s_perm[j1], b2 = s_perm[j2], b3 = s_perm[j3];
+                              s_perm[i0] = b0;     s_perm[j0] = a0;
+                              s_perm[i0 + 1] = b1; s_perm[j1] = a1;
+                              s_perm[i0 + 2] = b2; s_perm[j2] = a2;
+                              s_perm[i0 + 3] = b3; s_perm[j3] = a3;
+                            }
+                          else
+                            {
+                              const int js[4] = { j0, j1, j2, j3 };
+#pragma unroll
+                              for (int k = 0; k < 4; k++)
+                                {
+                                  const unsigned short x = s_perm[i0 + k], y = s_perm[js[k]];
+                                  s_perm[i0 + k] = y;
+                                  s_perm[js[k]] = x;
+                                }
                             }
                         }
                     }
                 }
             }
         }
-      }
     }
   else if (tid == 64)
     apply_swaps (s_pos, s_pos_t, KT_BLOCK);
