@@ -52,12 +52,21 @@ struct AddMixArgs
   int          delta_only = 0;    // 1: write the watermark signal alone (out = d W..., without "+ in"): WatermarkGen::run for the resampled path
 };
 hipError_t launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a);
+/* a batch of STEREO clips in one launch: args_dev[n_clips] on the device (every clip a stream of its own: first_frame 0, no halos, its own
+ * block_max), max_spans = the largest ceil (ceil (n_frames / 1024) / frames_per_span) among them; block_frames / frames_pad_start as in the arguments */
+hipError_t launch_add_mix_batch (hipStream_t st, const DevTables& t, const AddMixArgs *args_dev, int n_clips, long long max_spans, int block_frames,
+                                 int frames_pad_start);
 int        add_mix_waves_per_simd();     // occupancy the stereo kernel is built for (sizes the spans: one round of resident waves)
 
 /* K3: limiter ramp, in place */
 hipError_t launch_limiter (hipStream_t st, float *data, long long n_frames, int n_channels, long long first_sample,
                            const float *block_max, long long first_block, long long n_blocks,
                            int limiter_block, float ceiling, float2 *scale_tab = nullptr, size_t scale_tab_entries = 0);
+/* K3 for a batch of clips (1 or 2 channels, data 16 byte aligned), every clip a stream that starts at sample 0 with its own block maxima
+ * and a ramp table of limiter_tab_entries (n_frames, 0, limiter_block) entries: two launches for the batch */
+struct LimiterClip { float *data; long long n_frames; const float *block_max; long long n_blocks; float2 *tab; long long n_tab; };
+hipError_t launch_limiter_batch (hipStream_t st, const LimiterClip *clips_dev, int n_clips, long long max_frames, int n_channels, int limiter_block,
+                                 float ceiling);
 /* entries launch_limiter needs in scale_tab for this span (one (scale_start, scale_step) pair per limiter block) */
 size_t     limiter_tab_entries (long long n_frames, long long first_sample, int limiter_block);
 hipError_t launch_fill_u32 (hipStream_t st, unsigned int *p, unsigned int v, size_t n);

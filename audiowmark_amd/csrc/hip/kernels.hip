@@ -649,6 +649,14 @@ add_mix_pair_kernel (DevTables t, AddMixArgs a, long long frame_number0, int blo
 {
   add_mix_body<2, true, true> (t, a, frame_number0, block_frames);
 }
+/* a batch of clips in ONE launch (stereo): blockIdx.y = clip, its arguments from an array on the device (uniform: scalar loads); the grid's
+ * x extent covers the clip with the most spans, the others' surplus workgroups return at once */
+__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+add_mix_pair_batch_kernel (DevTables t, const AddMixArgs *args, long long frame_number0, int block_frames)
+{
+  const AddMixArgs a = args[blockIdx.y];
+  add_mix_body<2, true, true> (t, a, frame_number0, block_frames);
+}
 int add_mix_waves_per_simd() { return 4; }
 int g_fft_pair = 1;              // (debug toggle: stereo add with frame_delta2)
 extern "C" void awm_debug_set_fft_pair (int on) { g_fft_pair = on; }
@@ -672,6 +680,17 @@ launch_add_mix (hipStream_t st, const DevTables& t, const AddMixArgs& a)
     hipLaunchKernelGGL (add_mix_kernel_w4<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
   else
     hipLaunchKernelGGL (add_mix_kernel<1>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a, frame_number0, block_frames);
+  return hipGetLastError();
+}
+
+hipError_t
+launch_add_mix_batch (hipStream_t st, const DevTables& t, const AddMixArgs *args_dev, int n_clips, long long max_spans, int block_frames, int frames_pad_start)
+{
+  if (n_clips <= 0 || max_spans <= 0)
+    return hipSuccess;
+  const long long frame_number0 = 2LL * block_frames - frames_pad_start;         // reference wmadd.cc:293-294
+  hipLaunchKernelGGL (add_mix_pair_batch_kernel, dim3 (unsigned ((max_spans + WAVES - 1) / WAVES), unsigned (n_clips)), dim3 (64 * WAVES), 0, st,
+                      t, args_dev, frame_number0, block_frames);
   return hipGetLastError();
 }
 
@@ -736,8 +755,8 @@ limiter_table_kernel (float2 *tab, long long tab_first_block, long long n_tab, c
 
 constexpr int LIMITER_RUN = 2048;       // float4 per workgroup (8 per thread)
 
-template<int C> __global__ void __launch_bounds__ (256)
-limiter_apply_kernel (float4 *data, long long n_vec, long long first_sample, const float2 *tab, long long tab_first_block, int BS)
+template<int C> __device__ __forceinline__ void
+limiter_apply_run (float4 *data, long long n_vec, long long first_sample, const float2 *tab, long long tab_first_block, int BS)
 {
   constexpr int FPV = 4 / C;            // frames per float4
   const long long base = (long long) blockIdx.x * LIMITER_RUN;
@@ -782,6 +801,65 @@ limiter_apply_kernel (float4 *data, long long n_vec, long long first_sample, con
       if (q < n_vec)
         data[q] = v[j];
     }
+}
+
+template<int C> __global__ void __launch_bounds__ (256)
+limiter_apply_kernel (float4 *data, long long n_vec, long long first_sample, const float2 *tab, long long tab_first_block, int BS)
+{
+  limiter_apply_run<C> (data, n_vec, first_sample, tab, tab_first_block, BS);
+}
+
+/* K3 for a batch of clips, every clip a stream of its own that starts at sample 0: blockIdx.y = clip */
+__global__ void
+limiter_table_batch_kernel (const LimiterClip *clips, int BS, float ceiling)
+{
+  const LimiterClip c = clips[blockIdx.y];
+  const long long k = (long long) blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= c.n_tab)
+    return;
+  auto M = [&] (long long bb) -> float {
+    if (bb < 0 || bb >= c.n_blocks)
+      return ceiling;
+    return fmaxf (c.block_max[bb], ceiling);
+  };
+  const float m_last = M (k - 1), m_cur = M (k), m_next = M (k + 1);
+  const float scale_start = __fdiv_rn (ceiling, fmaxf (m_last, m_cur));
+  const float scale_end   = __fdiv_rn (ceiling, fmaxf (m_cur, m_next));
+  c.tab[k] = make_float2 (scale_start, __fdiv_rn (__fsub_rn (scale_end, scale_start), float (BS)));
+}
+
+template<int C> __global__ void __launch_bounds__ (256)
+limiter_apply_batch_kernel (const LimiterClip *clips, int BS)
+{
+  const LimiterClip c = clips[blockIdx.y];
+  const long long n_values = c.n_frames * C, n_vec = n_values / 4;
+  if ((long long) blockIdx.x * LIMITER_RUN < n_vec)
+    limiter_apply_run<C> (reinterpret_cast<float4 *> (c.data), n_vec, 0, c.tab, 0, BS);
+  // the values behind the last whole float4 (stereo: an odd number of frames), with the same table entries and arithmetic
+  if (blockIdx.x == 0 && 4 * n_vec + threadIdx.x < n_values)
+    {
+      const long long v = 4 * n_vec + threadIdx.x, f = v / C, b = f / BS;
+      const float2 t = c.tab[b];
+      c.data[v] = __fmul_rn (c.data[v], __fadd_rn (t.x, __fmul_rn (float (int (f - b * BS)), t.y)));
+    }
+}
+
+hipError_t
+launch_limiter_batch (hipStream_t st, const LimiterClip *clips_dev, int n_clips, long long max_frames, int n_channels, int limiter_block, float ceiling)
+{
+  if (n_clips <= 0 || max_frames <= 0)
+    return hipSuccess;
+  if ((n_channels != 1 && n_channels != 2) || limiter_block < 4 * LIMITER_RUN)
+    return hipErrorInvalidValue;
+  const long long max_tab = limiter_tab_entries (max_frames, 0, limiter_block);
+  hipLaunchKernelGGL (limiter_table_batch_kernel, dim3 (unsigned ((max_tab + 255) / 256), unsigned (n_clips)), dim3 (256), 0, st, clips_dev, limiter_block, ceiling);
+  const long long max_vec = std::max<long long> (1, max_frames * n_channels / 4);
+  const dim3 grid (unsigned ((max_vec + LIMITER_RUN - 1) / LIMITER_RUN), unsigned (n_clips));
+  if (n_channels == 2)
+    hipLaunchKernelGGL (limiter_apply_batch_kernel<2>, grid, dim3 (256), 0, st, clips_dev, limiter_block);
+  else
+    hipLaunchKernelGGL (limiter_apply_batch_kernel<1>, grid, dim3 (256), 0, st, clips_dev, limiter_block);
+  return hipGetLastError();
 }
 
 size_t

@@ -1024,6 +1024,130 @@ fill_patterns_keys (const ResultSet& rs, const std::vector<Key>& list, size_t ma
 }
 } // extern "C++"
 
+/* Batches of clips, ONE launch per stage for many clips (fill of the block maxima, K2, K3a, K3b) instead of four launches per clip.
+ * A 30 s clip is 1292 frames: alone it is 323 spans of four frames (+ two halo frames each: 1.5 x the transforms) and four launches of
+ * 6 - 46 us -- 1024 clips on eight lanes were 26 ms of launches for ~8 ms of memory traffic.  Here the spans are sized for the whole batch
+ * (frames_per_span of the batch's frames: ~20 frames per span, 1.1 x the transforms), blockIdx.y is the clip, its arguments come from an
+ * array on the device.  Output bit-identical to the per-clip launches (a span's result does not depend on the span length).
+ * (measurement knob) awm_debug_set_add_batched (0): the per-clip launches on eight lanes */
+static int g_add_batched = 1;
+extern "C" void awm_debug_set_add_batched (int on) { g_add_batched = on; }
+
+static bool
+add_clips_batchable (awm_ctx *ctx, size_t n_clips, const float *const *pcm_in_d, float *const *out_d, int n_channels)
+{
+  if (!g_add_batched || n_channels != 2 || ctx->snr_on || n_clips < 2)
+    return false;
+  for (size_t i = 0; i < n_clips; i++)
+    if ((reinterpret_cast<uintptr_t> (pcm_in_d[i]) & 15) || (reinterpret_cast<uintptr_t> (out_d[i]) & 15))
+      return false;
+  return true;
+}
+
+/* Batched arguments of a whole call: staged once (page-locked), copied once; groups then launch on slices of the device arrays. */
+struct AddBatchArgs
+{
+  awmk::AddMixArgs  *d_mix = nullptr;
+  awmk::LimiterClip *d_lim = nullptr;
+  float             *block_max = nullptr;
+  size_t             nb_max = 0;
+  std::vector<long long> spans, frames;
+  int                L = 4;
+};
+
+/* tables: the device table of every clip, or ONE for all (known now; the kernels read them when a group runs) */
+static int
+add_batch_stage (awm_ctx *ctx, hipStream_t st, size_t n_clips, const float *const *pcm_in_d, float *const *out_d, const size_t *n_frames,
+                 const std::vector<const int8_t *>& tables, int use_limiter, AddBatchArgs& b)
+{
+  const int C = 2;
+  long long total_frames1024 = 0;
+  size_t max_frames = 0;
+  for (size_t i = 0; i < n_clips; i++)
+    {
+      total_frames1024 += (long long) (n_frames[i] + 1023) / 1024;
+      max_frames = std::max (max_frames, n_frames[i]);
+    }
+  b.L = frames_per_span (ctx, total_frames1024);
+  b.nb_max = max_frames / LIMITER_BLOCK + 2;
+  const size_t tab_max = awmk::limiter_tab_entries ((long long) max_frames, 0, LIMITER_BLOCK) + 1;
+  const size_t arg_bytes = n_clips * (sizeof (awmk::AddMixArgs) + sizeof (awmk::LimiterClip));
+  if (int rc = ctx->ws_add_batch.reserve (arg_bytes)) return rc;
+  if (int rc = ctx->ws_block_max.reserve (n_clips * b.nb_max * sizeof (float))) return rc;
+  if (int rc = ctx->ws_limit_tab.reserve (n_clips * tab_max * sizeof (float2))) return rc;
+  if (ctx->ev_add_batch)
+    AWM_HIP_CHECK (hipEventSynchronize (ctx->ev_add_batch));            // (an earlier batch's staging has been copied)
+  else
+    AWM_HIP_CHECK (hipEventCreateWithFlags (&ctx->ev_add_batch, hipEventDisableTiming));
+  if (int rc = ctx->pin_add_batch.reserve (arg_bytes)) return rc;
+  auto *h_mix = ctx->pin_add_batch.as<awmk::AddMixArgs>();
+  auto *h_lim = reinterpret_cast<awmk::LimiterClip *> (h_mix + n_clips);
+  b.d_mix = ctx->ws_add_batch.as<awmk::AddMixArgs>();
+  b.d_lim = reinterpret_cast<awmk::LimiterClip *> (b.d_mix + n_clips);
+  b.block_max = ctx->ws_block_max.as<float>();
+  float2 *tabs = ctx->ws_limit_tab.as<float2>();
+  b.spans.assign (n_clips, 0);
+  b.frames.assign (n_clips, 0);
+  for (size_t i = 0; i < n_clips; i++)
+    {
+      awmk::AddMixArgs a {};
+      a.pcm_in = pcm_in_d[i];
+      a.out = out_d[i];
+      a.n_frames = (long long) n_frames[i];
+      a.n_channels = C;
+      a.frame_mod = tables.size() == 1 ? tables[0] : tables[i];
+      a.neg_delta_up = float (-params().water_delta * 1);
+      a.neg_delta_down = float (-params().water_delta * -1);
+      a.block_max = use_limiter ? reinterpret_cast<unsigned int *> (b.block_max + i * b.nb_max) : nullptr;
+      a.n_blocks = (long long) (n_frames[i] / LIMITER_BLOCK + 2);
+      a.limiter_block = LIMITER_BLOCK;
+      a.block_frames = int (mark_block_frame_count());
+      a.frames_pad_start = int (Params::frames_pad_start);
+      a.frames_per_span = b.L;
+      h_mix[i] = a;
+      h_lim[i] = { out_d[i], (long long) n_frames[i], b.block_max + i * b.nb_max, a.n_blocks, tabs + i * tab_max,
+                   (long long) awmk::limiter_tab_entries ((long long) n_frames[i], 0, LIMITER_BLOCK) };
+      const long long F = (long long) (n_frames[i] + 1023) / 1024;
+      b.spans[i] = (F + b.L - 1) / b.L;
+      b.frames[i] = (long long) n_frames[i];
+    }
+  AWM_HIP_CHECK (hipMemcpyAsync (b.d_mix, h_mix, arg_bytes, hipMemcpyHostToDevice, st));
+  AWM_HIP_CHECK (hipEventRecord (ctx->ev_add_batch, st));
+  return 0;
+}
+
+/* clips [i0, i0 + n) of a staged batch on stream st */
+static int
+add_batch_run (awm_ctx *ctx, hipStream_t st, const AddBatchArgs& b, size_t i0, size_t n, int use_limiter)
+{
+  if (!n)
+    return 0;
+  long long max_spans = 0, max_frames = 0;
+  double values = 0;
+  for (size_t i = i0; i < i0 + n; i++)
+    {
+      max_spans = std::max (max_spans, b.spans[i]);
+      max_frames = std::max (max_frames, b.frames[i]);
+      values += double (b.frames[i]) * 2;
+    }
+  if (use_limiter)
+    {
+      unsigned int bits;
+      std::memcpy (&bits, &LIMITER_CEILING, sizeof (bits));
+      AWM_HIP_CHECK (awmk::launch_fill_u32 (st, reinterpret_cast<unsigned int *> (b.block_max + i0 * b.nb_max), bits, n * b.nb_max));
+    }
+  {
+    ProfScope ps (ctx, PROF_ADD_MIX, values * 8.0, st);                            // read + write every sample once
+    AWM_HIP_CHECK (awmk::launch_add_mix_batch (st, ctx->tabs, b.d_mix + i0, int (n), max_spans, int (mark_block_frame_count()), int (Params::frames_pad_start)));
+  }
+  if (use_limiter)
+    {
+      ProfScope ps (ctx, PROF_LIMITER, values * 8.0, st);
+      AWM_HIP_CHECK (awmk::launch_limiter_batch (st, b.d_lim + i0, int (n), max_frames, 2, LIMITER_BLOCK, LIMITER_CEILING));
+    }
+  return 0;
+}
+
 int
 awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, size_t n_clips, const float *const *pcm_in_d,
                            float *const *out_d, const size_t *n_frames, int n_channels)
@@ -1037,6 +1161,18 @@ awm_add_watermark_batch_d (awm_ctx *ctx, const uint8_t key[16], const char *payl
   FrameModTable *fm = ctx->get_frame_mod (capi_key (key), payload_hex ? payload_hex : "");
   if (!fm)
     return AWM_ERR_ARG;
+  if (add_clips_batchable (ctx, n_clips, pcm_in_d, out_d, n_channels))
+    {
+      const int use_limiter = !params().test_no_limiter;
+      AddBatchArgs batch;
+      if (int rc = add_batch_stage (ctx, ctx->stream, n_clips, pcm_in_d, out_d, n_frames, { fm->dev.as<int8_t>() }, use_limiter, batch))
+        return rc;
+      constexpr size_t PER_LAUNCH = 4096;                    // (blockIdx.y <= 65535; a launch of 4096 clips fills the device many times over)
+      for (size_t i0 = 0; i0 < n_clips; i0 += PER_LAUNCH)
+        if (int rc = add_batch_run (ctx, ctx->stream, batch, i0, std::min (PER_LAUNCH, n_clips - i0), use_limiter))
+          return rc;
+      return 0;
+    }
   constexpr int ADD_LANES = 8;
   const int n_lanes = int (std::min<size_t> (ADD_LANES, n_clips));
   std::vector<WorkLane *> lanes;
@@ -1087,7 +1223,10 @@ add_batch_keys_device_tables (awm_ctx *ctx, const uint8_t *keys, const std::vect
   constexpr size_t GROUP = 256;
   constexpr int ADD_LANES = 8;
   const size_t table_bytes = awmk::key_table_bytes();
-  const int n_lanes = int (std::min<size_t> (ADD_LANES, n_clips));
+  // a group of clips in one launch per stage on the context's stream (add_clips_batched above), or clip by clip on eight lanes
+  const bool batched = add_clips_batchable (ctx, n_clips, pcm_in_d, out_d, n_channels);
+  const int use_limiter = !params().test_no_limiter;
+  const int n_lanes = batched ? 1 : int (std::min<size_t> (ADD_LANES, n_clips));
   std::vector<WorkLane *> lanes;
   for (int i = 0; i <= n_lanes; i++)                       // lanes 0 .. n_lanes - 1 watermark, lane n_lanes builds tables
     {
@@ -1141,6 +1280,16 @@ add_batch_keys_device_tables (awm_ctx *ctx, const uint8_t *keys, const std::vect
     AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
   for (auto& e : lane_done)
     AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
+  AddBatchArgs batch;
+  if (batched)
+    {
+      // clip i of group g finds its table in area g mod 2, slot i of the group
+      std::vector<const int8_t *> tables (n_clips);
+      for (size_t i = 0; i < n_clips; i++)
+        tables[i] = ctx->ws_keytab.as<int8_t>() + (((i / GROUP) & 1) * GROUP + i % GROUP) * table_bytes;
+      if (int rc = add_batch_stage (ctx, ctx->stream, n_clips, pcm_in_d, out_d, n_frames, tables, use_limiter, batch))
+        return rc;
+    }
   AWM_HIP_CHECK (hipEventRecord (ev_aux, ctx->stream));    // (also orders everything behind the clips' producers on the context's stream)
   AWM_HIP_CHECK (hipStreamWaitEvent (table_stream, ev_aux, 0));
   for (int i = 1; i < n_lanes; i++)
@@ -1167,9 +1316,11 @@ add_batch_keys_device_tables (awm_ctx *ctx, const uint8_t *keys, const std::vect
       AWM_HIP_CHECK (hipEventRecord (ev_tab[half], table_stream));
       for (int i = 0; i < n_lanes; i++)
         AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ev_tab[half], 0));
-      for (size_t i = 0; i < gn && !rc; i++)
+      if (batched)
+        rc = add_batch_run (ctx, ctx->stream, batch, g0, gn, use_limiter);
+      for (size_t i = 0; i < gn && !rc && !batched; i++)
         rc = add_full (ctx, pcm_in_d[g0 + i], out_d[g0 + i], n_frames[g0 + i], n_channels, dev + i * table_bytes, params().water_delta,
-                       !params().test_no_limiter, lanes[(g0 + i) % n_lanes]);
+                       use_limiter, lanes[(g0 + i) % n_lanes]);
       for (int i = 0; i < n_lanes && !rc; i++)
         AWM_HIP_CHECK (hipEventRecord (lane_done[size_t (half) * n_lanes + i], lanes[i]->stream));
     }

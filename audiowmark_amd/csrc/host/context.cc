@@ -724,6 +724,11 @@ awm_ctx_destroy (awm_ctx *ctx)
     t->ctab.release();
   awm::speed_workspace_free (ctx);
   ctx->ws_snr.release();
+  ctx->ws_add_batch.release();
+  ctx->pin_add_batch.release();
+  if (ctx->ev_add_batch)
+    (void) hipEventDestroy (ctx->ev_add_batch);
+  ctx->ev_add_batch = nullptr;
   ctx->ws_merge_soft.release();
   for (hipEvent_t e : ctx->merge_events)
     if (e)

@@ -248,6 +248,9 @@ struct awm_ctx : awm::WorkLane
   std::unique_ptr<awm::ParamValues> own_params;   // settings of this context (awm_ctx_set_params); null: the process-wide ones
   awm::DevBuffer ws_merge_soft;          // raw soft bits of the chunks of one `get` whose decodes run as ONE batch at the end (wmget.cc: block_decoder_run)
   std::vector<hipEvent_t> merge_events;  // one per chunk in flight: its rows are in ws_merge_soft
+  awm::DevBuffer    ws_add_batch;        // batches of clips in one launch per stage (capi_kernels.cc add_clips_batched): the clips' kernel arguments,
+  awm::PinnedBuffer pin_add_batch;       // their page-locked staging,
+  hipEvent_t        ev_add_batch = nullptr;   // and "the staging has been copied" (the next batch may overwrite it)
   awm::DevBuffer ws_snr;                 // `add --snr`: { power of the watermark signal, power of the input } accumulated by every mix while snr_on
   bool           snr_on = false;
   int            chunk_lanes = awm::CHUNK_LANES;   // lanes the chunks of one stream may be spread over (awm_ctx_set_chunk_lanes)

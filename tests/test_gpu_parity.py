@@ -765,6 +765,42 @@ def test_clip_batch_on_lanes(gpu):
     assert gpu.ctx.add_watermark_batch(None, PAY1, []) == []
 
 
+def test_add_batch_in_one_launch_per_stage_equals_the_per_clip_launches(gpu):
+    """awm_add_watermark_batch_d / _batch_keys_d watermark a batch of stereo clips with ONE launch per stage (block maxima, K2, limiter
+    table, limiter; blockIdx.y = the clip, spans sized for the batch): bit-identical to four launches per clip (awm_debug_set_add_batched 0)
+    and to one call per clip -- ragged lengths, odd frame counts (the limiter's values behind the last whole float4), a clip shorter than
+    a frame, one of 70 s, digital silence, clips that reach the limiter's ceiling; more clips than one group of keys (256)."""
+    t = gpu.torch
+    lengths = [30 * 44100, 7 * 44100 + 1, 500, 70 * 44100 + 3, 1024, 1025, 12 * 44100 + 777] + [(3 + i % 5) * 44100 + 17 * i for i in range(270)]
+    clips = []
+    for i, n in enumerate(lengths):
+        x = noise(2000 + i, n, 2)
+        if i % 11 == 3:
+            x[:] = 0
+        if i % 7 == 2:
+            x *= 1.6                                      # beyond the ceiling: the limiter has work to do
+        clips.append(gpu.dev(x))
+    keys = [gpu.awm.test_key(1 + i) for i in range(len(clips))]
+    one_by_one = [gpu.ctx.add_watermark(None, PAY1, c) for c in clips[:12]]
+    try:
+        gpu.awm.lib.awm_debug_set_add_batched(0)
+        per_clip = gpu.ctx.add_watermark_batch(None, PAY1, clips)
+        per_clip_keys = gpu.ctx.add_watermark_batch_keys(keys, PAY2, clips)
+    finally:
+        gpu.awm.lib.awm_debug_set_add_batched(1)
+    batched = gpu.ctx.add_watermark_batch(None, PAY1, clips)
+    batched_keys = gpu.ctx.add_watermark_batch_keys(keys, PAY2, clips)
+    t.cuda.synchronize()
+    assert all(t.equal(a, b) for a, b in zip(per_clip, batched))
+    assert all(t.equal(a, b) for a, b in zip(per_clip_keys, batched_keys))
+    assert all(t.equal(a, b) for a, b in zip(one_by_one, batched[:12]))
+    assert not t.equal(batched[0], clips[0]) and float(batched[2 + 7].abs().max()) <= 1.0
+    # and again into the same outputs (the staging of the arguments is reused)
+    again = gpu.ctx.add_watermark_batch_keys(keys, PAY2, clips, outs=[t.empty_like(c) for c in clips])
+    t.cuda.synchronize()
+    assert all(t.equal(a, b) for a, b in zip(again, batched_keys))
+
+
 def test_clip_batch_groups(gpu):
     """The group path of awm_get_watermark_batch_d (padded clips side by side, one launch per stage and group): more clips than one
     group holds, lengths from 3 s to 50 s, mono and stereo mixed (groups are per channel count), digital silence (no candidate at
