@@ -551,7 +551,7 @@ def main():
         audio_seconds = args.clips * 30.0
         workload = (f"{args.clips} clips of 30 s stereo 44.1 kHz test-gen-noise (--test-key k, 16 bit) over {world} GPU(s) (replicas: {len(mine)} on rank 0), "
                     f"add + get per clip with the clip's own key k (awm_add_watermark_batch_keys_d / awm_get_watermark_batch_keys_d: groups of 64 clips, "
-                    f"`add`: the frame_mod tables of 256 keys per launch of the device's table kernel (K16) on its own stream while the previous 256 clips are watermarked; `get`: a group's sync / mix / bit order tables from the device as well (K16g, one group ahead on a stream beside the lane's); one launch per stage and group)")
+                    f"`add`: 256 clips per launch of every stage (block maxima, K2, limiter), their frame_mod tables from 256 keys per launch of the device's table kernel (K16) on its own stream while the previous 256 clips are watermarked; `get`: a group's sync / mix / bit order tables from the device as well (K16g, one group ahead on a stream beside the lane's); one launch per stage and group)")
 
         def step():
             ctx.add_watermark_batch_keys(keys, PAYLOAD, clips, outs)
@@ -691,7 +691,7 @@ def main():
             one_group = scope_table(read_prof(awm, ctx), calls)
             for k in one_group:
                 if k["scope"] in ("add_mix_kernel", "limiter_kernel"):
-                    k["note"] = "add runs one clip per lane on up to 16 lanes: concurrent duration, not a stand-alone one"
+                    k["note"] = "add of the group: ONE launch per stage for its 64 clips (blockIdx.y = clip; block maxima, K2, limiter table, limiter)"
             t0 = time.perf_counter()
             for k in mine[:8]:
                 awm.tab_frame_mod(awm.test_key(k), PAYLOAD); awm.tab_sync_bits(awm.test_key(k), True); awm.tab_mix_entries(awm.test_key(k))
