@@ -87,6 +87,18 @@ def test_no_cpu_fallback():
         awm.Context(0)
 
 
+def test_group_key_tables_build_on_host_threads():
+    """The host side of the per-clip-key tables of `get` (what the device's K16g is checked against, and the path of --linear): a group of
+    keys builds on several threads without a GPU, and the debug entry points that need one say so instead of computing on the CPU."""
+    import ctypes as C
+    f = awm.lib.awm_debug_time_group_key_tables
+    f.restype = C.c_double
+    assert f(8, 4) > 0
+    assert f(3, 0) > 0
+    bad = (C.c_longlong * 9)()
+    assert awm.lib.awm_debug_clip_key_tables_check_d(None, bytes(16), C.c_size_t(1), bad) != 0
+
+
 def test_plan_chunks_reference_semantics():
     # wavchunkloader.cc:75-84: 30 min chunks, overlap lrint(2 * 51.69 s * 1.3 * 44100) samples
     L, O = 79380000, 5926502
