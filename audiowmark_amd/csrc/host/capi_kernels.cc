@@ -1029,8 +1029,8 @@ fill_patterns_keys (const ResultSet& rs, const std::vector<Key>& list, size_t ma
  * 6 - 46 us -- 1024 clips on eight lanes were 26 ms of launches for ~8 ms of memory traffic.  Here the spans are sized for the whole batch
  * (frames_per_span of the batch's frames: ~20 frames per span, 1.1 x the transforms), blockIdx.y is the clip, its arguments come from an
  * array on the device.  Output bit-identical to the per-clip launches (a span's result does not depend on the span length).
- * (measurement knob) awm_debug_set_add_batched (0): the per-clip launches on eight lanes */
-static int g_add_batched = 1;
+ * (measurement knob) awm_debug_set_add_batched (0): the per-clip launches on eight lanes; (1) / (2, default): see add_batch_keys_tables_first */
+static int g_add_batched = 2;              // 2: with a key per clip, the tables of all keys first (add_batch_keys_tables_first) | 1: a group's tables while the previous group is watermarked
 extern "C" void awm_debug_set_add_batched (int on) { g_add_batched = on; }
 
 static bool
@@ -1216,6 +1216,80 @@ extern "C" void awm_debug_set_key_tables_on_device (int on) { g_key_tables_on_de
 /* awm_add_watermark_batch_keys_d with the tables built by K16: groups of GROUP keys (one workgroup = one compute unit per key), two
  * table areas in turn -- the tables of group g + 1 are built (on a lane of their own) while the clips of group g are watermarked on the
  * add lanes; what the host contributes per key is the AES key schedule (176 bytes). */
+/* Batched clips with a key per clip, everything on the context's stream: FIRST the tables of (up to 4096) keys, 256 per launch of K16, THEN the
+ * clips in one launch per stage.  K16 holds 116 KB of LDS on every compute unit it runs on: beside it K2 runs one workgroup per unit
+ * instead of four, and the first group's tables are waited for in any case -- building the next group's tables WHILE a group is
+ * watermarked (the loop below, awm_debug_set_add_batched (1)) cost more than it hid once the clips of a group took 3 ms instead of 8. */
+static int
+add_batch_keys_tables_first (awm_ctx *ctx, const uint8_t *keys, const std::vector<int>& bits, size_t n_clips, const float *const *pcm_in_d,
+                             float *const *out_d, const size_t *n_frames)
+{
+  constexpr size_t GROUP = 256, SUPER = 4096;
+  const size_t table_bytes = awmk::key_table_bytes();
+  const int use_limiter = !params().test_no_limiter;
+  hipStream_t st = ctx->stream;
+  // one page-locked block, one upload: [S-box 256][conv code of the payload, A then B: 2 x 858][key schedules: n x 176]
+  const size_t aux_bytes = 256 + 2 * 858 + n_clips * 176;
+  if (int rc = ctx->pin_keytab.reserve (aux_bytes)) return rc;
+  if (int rc = ctx->ws_keytab_aux.reserve (aux_bytes)) return rc;
+  if (int rc = ctx->ws_keytab.reserve (std::min (n_clips, SUPER) * table_bytes)) return rc;
+  if (int rc = ctx->ws_keytab_scratch.reserve (GROUP * awmk::key_table_scratch_bytes())) return rc;
+  unsigned char *aux = ctx->pin_keytab.as<unsigned char>();
+  std::memcpy (aux, Aes128::sbox(), 256);
+  for (int ab = 0; ab < 2; ab++)
+    {
+      const std::vector<int> coded = code_encode (ab ? ConvBlockType::b : ConvBlockType::a, bits);
+      if (coded.size() != 858)
+        {
+          set_error ("conv code of unexpected size");
+          return AWM_ERR_GENERIC;
+        }
+      for (size_t i = 0; i < coded.size(); i++)
+        aux[256 + 858 * ab + i] = (unsigned char) (coded[i] & 1);
+    }
+  for (size_t i = 0; i < n_clips; i++)
+    {
+      Aes128 aes;
+      aes.set_key (keys + 16 * i);
+      std::memcpy (aux + 256 + 2 * 858 + 176 * i, aes.round_keys(), 176);
+    }
+  unsigned char *d_aux = ctx->ws_keytab_aux.as<unsigned char>();
+  AWM_HIP_CHECK (hipMemcpyAsync (d_aux, aux, aux_bytes, hipMemcpyHostToDevice, st));
+  hipEvent_t ev_aux = nullptr;
+  struct Event { hipEvent_t& e; ~Event() { if (e) (void) hipEventDestroy (e); } } event { ev_aux };
+  AWM_HIP_CHECK (hipEventCreateWithFlags (&ev_aux, hipEventDisableTiming));
+  AWM_HIP_CHECK (hipEventRecord (ev_aux, st));
+  std::vector<const int8_t *> tables (n_clips);
+  for (size_t i = 0; i < n_clips; i++)
+    tables[i] = ctx->ws_keytab.as<int8_t>() + (i % SUPER) * table_bytes;
+  AddBatchArgs batch;
+  if (int rc = add_batch_stage (ctx, st, n_clips, pcm_in_d, out_d, n_frames, tables, use_limiter, batch))
+    return rc;
+  for (size_t s0 = 0; s0 < n_clips; s0 += SUPER)
+    {
+      const size_t sn = std::min (SUPER, n_clips - s0);
+      for (size_t g0 = s0; g0 < s0 + sn; g0 += GROUP)
+        {
+          const size_t gn = std::min (GROUP, s0 + sn - g0);
+          awmk::KeyTableArgs ka {};
+          ka.sbox = d_aux;
+          ka.coded = d_aux + 256;
+          ka.round_keys = d_aux + 256 + 2 * 858 + 176 * g0;
+          ka.scratch = ctx->ws_keytab_scratch.as<unsigned char>();
+          ka.scratch_slots = int (GROUP);
+          ka.tables = reinterpret_cast<signed char *> (ctx->ws_keytab.as<int8_t>() + (g0 - s0) * table_bytes);
+          ka.n_keys = (long long) gn;
+          ProfScope ps (ctx, PROF_KEYTAB, double (gn) * table_bytes, st);              // the table out, once (360 KB per key)
+          AWM_HIP_CHECK (awmk::launch_frame_mod_tables (st, ka));
+        }
+      if (int rc = add_batch_run (ctx, st, batch, s0, sn, use_limiter))
+        return rc;
+    }
+  // (the staging block is the context's: its upload has to be through before the next call refills it)
+  AWM_HIP_CHECK (hipEventSynchronize (ev_aux));
+  return 0;
+}
+
 static int
 add_batch_keys_device_tables (awm_ctx *ctx, const uint8_t *keys, const std::vector<int>& bits, size_t n_clips, const float *const *pcm_in_d,
                               float *const *out_d, const size_t *n_frames, int n_channels)
@@ -1225,6 +1299,8 @@ add_batch_keys_device_tables (awm_ctx *ctx, const uint8_t *keys, const std::vect
   const size_t table_bytes = awmk::key_table_bytes();
   // a group of clips in one launch per stage on the context's stream (add_clips_batched above), or clip by clip on eight lanes
   const bool batched = add_clips_batchable (ctx, n_clips, pcm_in_d, out_d, n_channels);
+  if (batched && g_add_batched == 2)
+    return add_batch_keys_tables_first (ctx, keys, bits, n_clips, pcm_in_d, out_d, n_frames);
   const int use_limiter = !params().test_no_limiter;
   const int n_lanes = batched ? 1 : int (std::min<size_t> (ADD_LANES, n_clips));
   std::vector<WorkLane *> lanes;

@@ -417,8 +417,10 @@ int  awm_debug_clip_key_tables_check_d (awm_ctx *ctx, const uint8_t *keys, size_
                                               * mismatch_out[i] = differing elements per table (all 0 = identical) */
 void awm_debug_set_key_tables_on_device (int on);   /* batches with one key per clip: `add`'s frame_mod tables (K16) and `get`'s sync / mix / bit order tables (K16g) built on the device (default) | on host threads */
 void awm_debug_set_merge_decodes (int on);  /* get of a stream of 2 - 4 chunks: the chunks' Viterbi jobs as ONE batch at the end | per chunk (default: the step is faster) */
-void awm_debug_set_add_batched (int on);   /* add of a batch of stereo clips: 1 (default) ONE launch per stage for many clips (block maxima, K2, limiter table, limiter: blockIdx.y =
-                                            * the clip, spans sized for the batch) | 0 four launches per clip on eight lanes; the outputs are the same */
+void awm_debug_set_add_batched (int on);   /* add of a batch of stereo clips: 2 (default) ONE launch per stage for many clips (block maxima, K2, limiter table, limiter: blockIdx.y =
+                                            * the clip, spans sized for the batch), with a key per clip after the tables of all (up to 4096) keys | 1 the same with a
+                                            * group's tables built while the previous group of 256 clips is watermarked | 0 four launches per clip on eight lanes; the
+                                            * outputs are the same */
 void awm_debug_set_add_slab_mb (int mb);   /* add: 0 (default) one fused add over the stream, then the limiter | > 0: in slabs of that many MB (cache experiment) */
 void awm_debug_set_fft_pair (int on);      /* stereo add: both channels' transforms pipelined in one wave (default) | one after the other */
 void awm_debug_set_clip_poison (int on);    /* clip batches: the padded slices are filled with NaNs before the copies are written (the copy writes a clip and 2048

@@ -786,13 +786,16 @@ def test_add_batch_in_one_launch_per_stage_equals_the_per_clip_launches(gpu):
         gpu.awm.lib.awm_debug_set_add_batched(0)
         per_clip = gpu.ctx.add_watermark_batch(None, PAY1, clips)
         per_clip_keys = gpu.ctx.add_watermark_batch_keys(keys, PAY2, clips)
+        gpu.awm.lib.awm_debug_set_add_batched(1)              # a group's tables while the previous group is watermarked
+        overlapped_keys = gpu.ctx.add_watermark_batch_keys(keys, PAY2, clips)
     finally:
-        gpu.awm.lib.awm_debug_set_add_batched(1)
+        gpu.awm.lib.awm_debug_set_add_batched(2)              # (default: the tables of all keys first)
     batched = gpu.ctx.add_watermark_batch(None, PAY1, clips)
     batched_keys = gpu.ctx.add_watermark_batch_keys(keys, PAY2, clips)
     t.cuda.synchronize()
     assert all(t.equal(a, b) for a, b in zip(per_clip, batched))
     assert all(t.equal(a, b) for a, b in zip(per_clip_keys, batched_keys))
+    assert all(t.equal(a, b) for a, b in zip(per_clip_keys, overlapped_keys))
     assert all(t.equal(a, b) for a, b in zip(one_by_one, batched[:12]))
     assert not t.equal(batched[0], clips[0]) and float(batched[2 + 7].abs().max()) <= 1.0
     # and again into the same outputs (the staging of the arguments is reused)

@@ -25,6 +25,7 @@ keys = [key] * n_clips
 legs = {
     "add, one key": lambda: ctx.add_watermark_batch(key, PAY, clips, outs),
     "add, key per clip": lambda: ctx.add_watermark_batch_keys(keys, PAY, clips, outs),
+    "add, key per clip, tables beside the clips": lambda: (awm.lib.awm_debug_set_add_batched(1), ctx.add_watermark_batch_keys(keys, PAY, clips, outs), awm.lib.awm_debug_set_add_batched(2))[1],
     "get, one key": lambda: ctx.get_watermark_batch(key, outs),
     "get, key per clip": lambda: ctx.get_watermark_batch_keys(keys, outs),
 }
@@ -50,7 +51,7 @@ for rep in range(6):
             first.setdefault("get", r)
             assert r == first["get"]
 for name, v in res.items():
-    print("%-36s ms per call of %d clips: median %.2f  min %.2f  (%.4f ms per clip)" % (name, n_clips, sorted(v)[len(v) // 2], min(v), sorted(v)[len(v) // 2] / n_clips))
+    print("%-60s ms per call of %d clips: median %.2f  min %.2f  (%.4f ms per clip)" % (name, n_clips, sorted(v)[len(v) // 2], min(v), sorted(v)[len(v) // 2] / n_clips))
 print("clips with the payload:", sum(any(p["bits"] == PAY for p in c) for c in first["get"]))
 for name, v in host.items():
     print("%-36s host, summed over the lane threads: waiting for a group's tables %.1f ms, packing + upload %.1f ms, %d groups" % (name, v[-1][0], v[-1][1], v[-1][2]))
