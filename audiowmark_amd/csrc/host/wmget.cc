@@ -13,6 +13,7 @@
 
 namespace awm {
 int g_key_tables_on_device = 1;         // awm_debug_set_key_tables_on_device (capi_kernels.cc): batches with one key per clip build their tables on the device
+                                        // (`get`: 1 = a group's one group ahead of its lane, 2 = those of all keys first; 0 = host threads)
 
 /* ---- soft bits ------------------------------------------------------------------------ */
 
@@ -1475,13 +1476,16 @@ upload_group_tables (WorkLane *lane, const std::vector<ClipKeyHost>& hosts, KeyT
 struct DeviceGroupTables
 {
   static constexpr size_t N_CHAIN = size_t (12) * awmk::CLIP_KEY_ROWS * 8, NW = awmk::CLIP_KEY_WANT, N_POS = NW * Params::n_bands,
-                          N_MIX = awmk::CLIP_KEY_MIX, N_ORD = awmk::CLIP_KEY_CODED, G = CLIP_GROUP;
-  static constexpr size_t AUX_BYTES = 256 + G * 176, WANT_BYTES = G * NW * sizeof (int);
+                          N_MIX = awmk::CLIP_KEY_MIX, N_ORD = awmk::CLIP_KEY_CODED, G = CLIP_GROUP, LAUNCH = 256;
   awm_ctx    *ctx = nullptr;
-  WorkLane   *lane = nullptr;
+  WorkLane   *lane = nullptr;            // owner of the buffers (ws_keytab, ws_keytab_aux, ws_keytab_scratch, pin_keytab)
   hipStream_t table_stream = nullptr;
   hipEvent_t  ev[2] = { nullptr, nullptr };
+  size_t      cap = G;                   // keys per table area: a group (two areas in turn), or ALL keys of a call (one area)
+  int         areas = 2;
   size_t      off_chain = 0, off_perm = 0, off_pos = 0, off_mf = 0, off_mu = 0, off_md = 0, off_ord = 0, off_rf = 0, off_want = 0, half_bytes = 0, pin_half = 0;
+  size_t aux_bytes() const { return 256 + cap * 176; }
+  size_t want_bytes() const { return cap * NW * sizeof (int); }
 
   static bool
   possible()
@@ -1497,35 +1501,41 @@ struct DeviceGroupTables
       if (e)
         (void) hipEventDestroy (e);
   }
+  /* table areas for `keys_per_area` keys each in the buffers of lane l, filled on table_stream */
   int
-  init (awm_ctx *c, WorkLane *l, WorkLane *table_lane)
+  init (awm_ctx *c, WorkLane *l, hipStream_t tables_on, size_t keys_per_area = G, int n_areas = 2)
   {
     ctx = c;
     lane = l;
-    table_stream = table_lane->stream;
+    table_stream = tables_on;
+    cap = keys_per_area;
+    areas = n_areas;
     off_chain = 0;
-    off_perm = align256 (off_chain + G * N_CHAIN * sizeof (unsigned));
-    off_pos = align256 (off_perm + G * NW * sizeof (int));
-    off_mf = align256 (off_pos + G * N_POS);
-    off_mu = align256 (off_mf + G * N_MIX * sizeof (int16_t));
-    off_md = align256 (off_mu + G * N_MIX);
-    off_ord = align256 (off_md + G * N_MIX);
-    off_rf = align256 (off_ord + G * N_ORD * sizeof (int));
-    off_want = align256 (off_rf + G * NW * sizeof (int));
-    half_bytes = align256 (off_want + WANT_BYTES);
-    pin_half = align256 (AUX_BYTES) + align256 (WANT_BYTES);
-    if (int rc = lane->ws_keytab.reserve (2 * half_bytes)) return rc;
-    if (int rc = lane->ws_keytab_aux.reserve (2 * align256 (AUX_BYTES))) return rc;
-    if (int rc = lane->ws_keytab_scratch.reserve (G * awmk::key_table_scratch_bytes())) return rc;
-    if (int rc = lane->pin_keytab.reserve (2 * pin_half)) return rc;
+    off_perm = align256 (off_chain + cap * N_CHAIN * sizeof (unsigned));
+    off_pos = align256 (off_perm + cap * NW * sizeof (int));
+    off_mf = align256 (off_pos + cap * N_POS);
+    off_mu = align256 (off_mf + cap * N_MIX * sizeof (int16_t));
+    off_md = align256 (off_mu + cap * N_MIX);
+    off_ord = align256 (off_md + cap * N_MIX);
+    off_rf = align256 (off_ord + cap * N_ORD * sizeof (int));
+    off_want = align256 (off_rf + cap * NW * sizeof (int));
+    half_bytes = align256 (off_want + want_bytes());
+    pin_half = align256 (aux_bytes()) + align256 (want_bytes());
+    if (int rc = lane->ws_keytab.reserve (areas * half_bytes)) return rc;
+    if (int rc = lane->ws_keytab_aux.reserve (areas * align256 (aux_bytes()))) return rc;
+    if (int rc = lane->ws_keytab_scratch.reserve (std::min (cap, LAUNCH) * awmk::key_table_scratch_bytes())) return rc;
+    if (int rc = lane->pin_keytab.reserve (areas * pin_half)) return rc;
     for (hipEvent_t& e : ev)
       AWM_HIP_CHECK (hipEventCreateWithFlags (&e, hipEventDisableTiming));
     // (the lane's earlier work may still read these buffers; and the clips' producers are behind the lane's stream)
-    AWM_HIP_CHECK (hipEventRecord (ev[0], lane->stream));
-    AWM_HIP_CHECK (hipStreamWaitEvent (table_stream, ev[0], 0));
+    if (table_stream != lane->stream)
+      {
+        AWM_HIP_CHECK (hipEventRecord (ev[0], lane->stream));
+        AWM_HIP_CHECK (hipStreamWaitEvent (table_stream, ev[0], 0));
+      }
     return 0;
   }
-  /* queue the tables of `keys` (<= CLIP_GROUP) into area `half`; the area's previous group must be through on the lane */
+  /* queue the tables of `keys` (<= cap) into area `half`; the area's previous group must be through on the lane */
   int
   launch (const std::vector<Key>& keys, int half)
   {
@@ -1537,59 +1547,62 @@ struct DeviceGroupTables
         aes.set_key (keys[i].aes_key());
         std::memcpy (aux + 256 + 176 * i, aes.round_keys(), 176);
       }
-    unsigned char *d_aux = lane->ws_keytab_aux.as<unsigned char>() + size_t (half) * align256 (AUX_BYTES);
+    unsigned char *d_aux = lane->ws_keytab_aux.as<unsigned char>() + size_t (half) * align256 (aux_bytes());
     AWM_HIP_CHECK (hipMemcpyAsync (d_aux, aux, 256 + 176 * keys.size(), hipMemcpyHostToDevice, table_stream));
     char *d = lane->ws_keytab.as<char>() + size_t (half) * half_bytes;
-    awmk::KeyTableArgs ka {};
-    ka.sbox = d_aux;
-    ka.round_keys = d_aux + 256;
-    ka.scratch = lane->ws_keytab_scratch.as<unsigned char>();
-    ka.scratch_slots = int (G);
-    ka.n_keys = (long long) keys.size();
-    awmk::ClipKeyTableOut o {};
-    o.chains = reinterpret_cast<unsigned int *> (d + off_chain);
-    o.perm = reinterpret_cast<int *> (d + off_perm);
-    o.pos = reinterpret_cast<unsigned char *> (d + off_pos);
-    o.mix_frame = reinterpret_cast<short *> (d + off_mf);
-    o.mix_up = reinterpret_cast<unsigned char *> (d + off_mu);
-    o.mix_down = reinterpret_cast<unsigned char *> (d + off_md);
-    o.inv_order = reinterpret_cast<int *> (d + off_ord);
-    o.row_frames = reinterpret_cast<int *> (d + off_rf);
-    o.want = reinterpret_cast<int *> (d + off_want);
-    {
-      ProfScope ps (ctx, PROF_KEYTAB, double (keys.size()) * double (half_bytes) / double (G), table_stream);
-      AWM_HIP_CHECK (awmk::launch_clip_key_tables (table_stream, ka, o));
-    }
-    AWM_HIP_CHECK (hipMemcpyAsync (aux + align256 (AUX_BYTES), d + off_want, keys.size() * NW * sizeof (int), hipMemcpyDeviceToHost, table_stream));
+    // (one workgroup = one compute unit per key: LAUNCH keys per launch, the launches of a stream one after the other share the scratch)
+    for (size_t k0 = 0; k0 < keys.size(); k0 += LAUNCH)
+      {
+        const size_t kn = std::min (LAUNCH, keys.size() - k0);
+        awmk::KeyTableArgs ka {};
+        ka.sbox = d_aux;
+        ka.round_keys = d_aux + 256 + 176 * k0;
+        ka.scratch = lane->ws_keytab_scratch.as<unsigned char>();
+        ka.scratch_slots = int (std::min (cap, LAUNCH));
+        ka.n_keys = (long long) kn;
+        awmk::ClipKeyTableOut o {};
+        o.chains = reinterpret_cast<unsigned int *> (d + off_chain) + k0 * N_CHAIN;
+        o.perm = reinterpret_cast<int *> (d + off_perm) + k0 * NW;
+        o.pos = reinterpret_cast<unsigned char *> (d + off_pos) + k0 * N_POS;
+        o.mix_frame = reinterpret_cast<short *> (d + off_mf) + k0 * N_MIX;
+        o.mix_up = reinterpret_cast<unsigned char *> (d + off_mu) + k0 * N_MIX;
+        o.mix_down = reinterpret_cast<unsigned char *> (d + off_md) + k0 * N_MIX;
+        o.inv_order = reinterpret_cast<int *> (d + off_ord) + k0 * N_ORD;
+        o.row_frames = reinterpret_cast<int *> (d + off_rf) + k0 * NW;
+        o.want = reinterpret_cast<int *> (d + off_want) + k0 * NW;
+        ProfScope ps (ctx, PROF_KEYTAB, double (kn) * double (half_bytes) / double (cap), table_stream);
+        AWM_HIP_CHECK (awmk::launch_clip_key_tables (table_stream, ka, o));
+      }
+    AWM_HIP_CHECK (hipMemcpyAsync (aux + align256 (aux_bytes()), d + off_want, keys.size() * NW * sizeof (int), hipMemcpyDeviceToHost, table_stream));
     AWM_HIP_CHECK (hipEventRecord (ev[half], table_stream));
     return 0;
   }
-  /* the lane's stream waits for area `half`; kt describes it (want lists: want_ready) */
+  /* stream `st` waits for area `half`; kt describes its keys [slot0, slot0 + gn) (want lists: want_ready) */
   int
-  use (int half, size_t gn, KeyTables& kt)
+  use (int half, size_t gn, KeyTables& kt, hipStream_t st = nullptr, size_t slot0 = 0) const
   {
-    AWM_HIP_CHECK (hipStreamWaitEvent (lane->stream, ev[half], 0));
+    AWM_HIP_CHECK (hipStreamWaitEvent (st ? st : lane->stream, ev[half], 0));
     char *d = lane->ws_keytab.as<char>() + size_t (half) * half_bytes;
     auto view = [] (DevBuffer& b, void *ptr, size_t n) { b.ptr = ptr; b.bytes = n; };     // (non-owning: never released through kt)
     kt = KeyTables();
     kt.slices = int (gn);
     kt.mix = params().mix;
     kt.sync[1].host.rows_per_bit = awmk::CLIP_KEY_ROWS;
-    view (kt.sync[1].chains_approx, d + off_chain, gn * N_CHAIN * sizeof (unsigned));
-    view (kt.sync[1].refine_perm, d + off_perm, gn * NW * sizeof (int));
-    view (kt.sync[1].refine_pos, d + off_pos, gn * N_POS);
-    view (kt.mix_frame, d + off_mf, gn * N_MIX * sizeof (int16_t));
-    view (kt.mix_up, d + off_mu, gn * N_MIX);
-    view (kt.mix_down, d + off_md, gn * N_MIX);
-    view (kt.bit_order_inv_dev, d + off_ord, gn * N_ORD * sizeof (int));
-    view (kt.sync[1].row_frames, d + off_rf, gn * NW * sizeof (int));
-    kt.slice_want_flat = reinterpret_cast<const int *> (lane->pin_keytab.as<unsigned char>() + size_t (half) * pin_half + align256 (AUX_BYTES));
+    view (kt.sync[1].chains_approx, d + off_chain + slot0 * N_CHAIN * sizeof (unsigned), gn * N_CHAIN * sizeof (unsigned));
+    view (kt.sync[1].refine_perm, d + off_perm + slot0 * NW * sizeof (int), gn * NW * sizeof (int));
+    view (kt.sync[1].refine_pos, d + off_pos + slot0 * N_POS, gn * N_POS);
+    view (kt.mix_frame, d + off_mf + slot0 * N_MIX * sizeof (int16_t), gn * N_MIX * sizeof (int16_t));
+    view (kt.mix_up, d + off_mu + slot0 * N_MIX, gn * N_MIX);
+    view (kt.mix_down, d + off_md + slot0 * N_MIX, gn * N_MIX);
+    view (kt.bit_order_inv_dev, d + off_ord + slot0 * N_ORD * sizeof (int), gn * N_ORD * sizeof (int));
+    view (kt.sync[1].row_frames, d + off_rf + slot0 * NW * sizeof (int), gn * NW * sizeof (int));
+    kt.slice_want_flat = reinterpret_cast<const int *> (lane->pin_keytab.as<unsigned char>() + size_t (half) * pin_half + align256 (aux_bytes())) + slot0 * NW;
     kt.slice_want_n = int (NW);
     return 0;
   }
   /* before the host reads the want lists of area `half` */
   int
-  want_ready (int half)
+  want_ready (int half) const
   {
     AWM_HIP_CHECK (hipEventSynchronize (ev[half]));
     return 0;
@@ -1614,7 +1627,7 @@ clip_key_tables_check (awm_ctx *ctx, const uint8_t *keys, size_t n_keys, long lo
     return AWM_ERR_HIP;
   AWM_HIP_CHECK (stream_wait (lane->stream));
   D dev;
-  if (int rc = dev.init (ctx, lane, table_lane)) return rc;
+  if (int rc = dev.init (ctx, lane, table_lane->stream)) return rc;
   std::vector<char> back (dev.half_bytes);
   auto count = [] (const auto *a, const auto *b, size_t n) { long long bad = 0; for (size_t i = 0; i < n; i++) bad += a[i] != b[i]; return bad; };
   size_t group = 0;
@@ -1668,7 +1681,8 @@ extern "C" void awm_debug_set_group_fallback (int on) { g_group_force_fallback =
 /* clip_keys (may be null): one key per clip -- clip i is searched and decoded with (*clip_keys)[i] alone (key_list is not used then) */
 static int
 clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_list, const std::vector<DeviceWav>& clips, const std::vector<size_t>& which,
-                   std::vector<ResultSet>& result_sets, const std::vector<Key> *clip_keys = nullptr, WorkLane *table_lane = nullptr)
+                   std::vector<ResultSet>& result_sets, const std::vector<Key> *clip_keys = nullptr, WorkLane *table_lane = nullptr,
+                   const DeviceGroupTables *all_tables = nullptr, const std::vector<int> *slot_of_clip = nullptr)
 {
   const size_t count = mark_block_frame_count();
   const int n_bits_a = int (mark_data_frame_count() / params().frames_per_bit);
@@ -1697,11 +1711,12 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
   std::vector<ResultSet> chunk_sets (which.size());
   // one key per clip: the groups' tables from the device (K16g), one group ahead on the table lane's stream -- or from host threads
   DeviceGroupTables dev_tables;
-  const bool tables_on_device = clip_keys && table_lane && !which.empty() && DeviceGroupTables::possible();
+  // (all_tables: the tables of ALL keys of the call were queued before the lanes started, clip c's at slot (*slot_of_clip)[c])
+  const bool tables_on_device = clip_keys && !all_tables && table_lane && !which.empty() && DeviceGroupTables::possible();
   if (tables_on_device)
     {
       AWM_HIP_CHECK (stream_wait (st));                      // (the lane's table buffers may be re-allocated: nothing of an earlier call reads them)
-      if (int rc = dev_tables.init (ctx, lane, table_lane)) return rc;
+      if (int rc = dev_tables.init (ctx, lane, table_lane->stream)) return rc;
       if (int rc = dev_tables.launch (group_keys (0, group_size (0)), 0)) return rc;
     }
   size_t group_index = 0;
@@ -1751,8 +1766,20 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
         ptrs.push_back (&cs);
       KeyTables group_kt;
       std::vector<Key> keys_of_group;
-      const int half = int (group_index & 1);
-      if (tables_on_device)
+      const int half = all_tables ? 0 : int (group_index & 1);
+      if (clip_keys && all_tables)
+        {
+          keys_of_group = group_keys (g0, gn);
+          const int slot0 = (*slot_of_clip)[which[g0]];
+          for (size_t i = 0; i < gn; i++)
+            if ((*slot_of_clip)[which[g0 + i]] != slot0 + int (i))
+              {
+                set_error ("clip batch: the tables of a group's keys are not consecutive");
+                return AWM_ERR_GENERIC;
+              }
+          if (int rc = all_tables->use (0, gn, group_kt, st, size_t (slot0))) return rc;
+        }
+      else if (tables_on_device)
         {
           keys_of_group = group_keys (g0, gn);
           // (the other area's group -- the previous one -- is through: its results have been waited for)
@@ -1794,6 +1821,8 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
           db_ready = gj.n_scores > 0;
           if (tables_on_device)
             if (int rc = dev_tables.want_ready (half)) return rc;
+          if (clip_keys && all_tables)
+            if (int rc = all_tables->want_ready (0)) return rc;
           if (int rc = finder.group_select_refine (gj)) return rc;
           if (int rc = finder.group_finish (gj, scores)) return rc;
           // soft bits and Viterbi decodes of ALL clips of the group in one batch
@@ -1936,6 +1965,27 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
               set_error ("cannot create a work lane (stream)");
               return AWM_ERR_HIP;
             }
+      // ... or (awm_debug_set_key_tables_on_device (2)), for up to 4096 keys (1.5 GB of tables), the tables of ALL keys first, on the context's
+      // stream in front of the lanes' work.  Measured: `get` of 1024 clips 201.8 ms against 202.1 with a group's tables one group ahead
+      // (193.2 with one key for all clips) -- what a key per clip costs `get` is not K16g beside the groups but every clip reading tables
+      // of its own; the default stays the group ahead (two table areas of 64 keys per lane instead of all keys' tables at once).
+      DeviceGroupTables all_tables;
+      std::vector<int> slot_of_clip;
+      const bool all_first = clip_keys && g_key_tables_on_device == 2 && DeviceGroupTables::possible() && staged.size() <= 4096;
+      if (all_first)
+        {
+          std::vector<Key> table_keys;
+          slot_of_clip.assign (clips.size(), -1);
+          for (size_t i = 0; i < staged.size(); i++)
+            {
+              slot_of_clip[staged[i]] = int (i);
+              table_keys.push_back ((*clip_keys)[staged[i]]);
+            }
+          AWM_HIP_CHECK (stream_wait (ctx->stream));            // (the table buffers may be re-allocated: nothing of an earlier call reads them)
+          if (int rc = all_tables.init (ctx, ctx, ctx->stream, staged.size(), 1)) return rc;
+          if (int rc = all_tables.launch (table_keys, 0)) return rc;
+        }
+      const DeviceGroupTables *all_ptr = all_first ? &all_tables : nullptr;
       // whole groups per thread, dealt round robin
       std::vector<std::vector<size_t>> share (n_staged_threads);
       for (size_t i = 0; i < staged.size(); i++)
@@ -1948,11 +1998,11 @@ get_watermark_batch_device (awm_ctx *ctx, const std::vector<Key>& key_list, cons
         workers.emplace_back ([&, t] {
           ParamsBind bind (pv);
           (void) hipSetDevice (ctx->device);
-          rcs[t] = clip_batch_staged (ctx, staged_lanes[t], key_list, clips, share[t], result_sets, clip_keys, table_lanes[t]);
+          rcs[t] = clip_batch_staged (ctx, staged_lanes[t], key_list, clips, share[t], result_sets, clip_keys, table_lanes[t], all_ptr, &slot_of_clip);
           if (rcs[t])
             messages[t] = last_error();
         });
-      rcs[0] = clip_batch_staged (ctx, staged_lanes[0], key_list, clips, share[0], result_sets, clip_keys, table_lanes[0]);
+      rcs[0] = clip_batch_staged (ctx, staged_lanes[0], key_list, clips, share[0], result_sets, clip_keys, table_lanes[0], all_ptr, &slot_of_clip);
       for (auto& w : workers)
         w.join();
       for (int t = 0; t < n_staged_threads; t++)

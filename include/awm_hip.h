@@ -415,7 +415,7 @@ int  awm_debug_clip_key_tables_check_d (awm_ctx *ctx, const uint8_t *keys, size_
                                              /* the tables `get` needs per key of a clip batch (K16g: sync chains, row frames, want list, gathered layout,
                                               * mix entries, bit order) built on the device, group by group, against the host's build of the same tables:
                                               * mismatch_out[i] = differing elements per table (all 0 = identical) */
-void awm_debug_set_key_tables_on_device (int on);   /* batches with one key per clip: `add`'s frame_mod tables (K16) and `get`'s sync / mix / bit order tables (K16g) built on the device (default) | on host threads */
+void awm_debug_set_key_tables_on_device (int on);   /* batches with one key per clip: 0 the tables from host threads | `add`'s frame_mod tables (K16) and `get`'s sync / mix / bit order tables (K16g) built on the device: 1 (default) `get` builds a group's tables one group ahead of its lane, 2 the tables of all (up to 4096) keys first (measured: the same time) */
 void awm_debug_set_merge_decodes (int on);  /* get of a stream of 2 - 4 chunks: the chunks' Viterbi jobs as ONE batch at the end | per chunk (default: the step is faster) */
 void awm_debug_set_add_batched (int on);   /* add of a batch of stereo clips: 2 (default) ONE launch per stage for many clips (block maxima, K2, limiter table, limiter: blockIdx.y =
                                             * the clip, spans sized for the batch), with a key per clip after the tables of all (up to 4096) keys | 1 the same with a

@@ -553,10 +553,13 @@ def test_get_key_tables_on_the_device(gpu):
     try:
         gpu.awm.lib.awm_debug_set_key_tables_on_device(0)
         host_side = gpu.ctx.get_watermark_batch_keys(keys[:n], marked)
+        gpu.awm.lib.awm_debug_set_key_tables_on_device(2)     # the tables of all keys first
+        all_first = gpu.ctx.get_watermark_batch_keys(keys[:n], marked)
     finally:
-        gpu.awm.lib.awm_debug_set_key_tables_on_device(1)
+        gpu.awm.lib.awm_debug_set_key_tables_on_device(1)     # (default: a group's tables one group ahead of its lane)
     device_side = gpu.ctx.get_watermark_batch_keys(keys[:n], marked)
     assert device_side == host_side
+    assert all_first == host_side
     assert device_side == gpu.ctx.get_watermark_batch_keys(keys[:n], marked)          # (and again: the areas are reused)
     assert sum(any(p["bits"] == PAY2 for p in c) for c in device_side) >= 100
 

@@ -28,6 +28,7 @@ legs = {
     "add, key per clip, tables beside the clips": lambda: (awm.lib.awm_debug_set_add_batched(1), ctx.add_watermark_batch_keys(keys, PAY, clips, outs), awm.lib.awm_debug_set_add_batched(2))[1],
     "get, one key": lambda: ctx.get_watermark_batch(key, outs),
     "get, key per clip": lambda: ctx.get_watermark_batch_keys(keys, outs),
+    "get, key per clip, the tables of all keys first": lambda: (awm.lib.awm_debug_set_key_tables_on_device(2), ctx.get_watermark_batch_keys(keys, outs), awm.lib.awm_debug_set_key_tables_on_device(1))[1],
 }
 res, first, host = {}, {}, {}
 import ctypes as C
