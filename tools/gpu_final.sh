@@ -29,6 +29,8 @@ python tools/pmc_traffic.py $(find $O/c2pmc_FETCH_SIZE $O/c2pmc_WRITE_SIZE -name
 rm -rf $O/c2pmc_*
 prof --kernel-trace --stats --output-format csv -d $O/c4 -o s -- python $R/tools/gpu_clips_one_group.py 3 > $O/clips_one_group.log 2>&1
 cp $(find $O/c4 -name "*kernel_stats.csv" | head -1) $O/rocprofv3_kernel_stats_clips_one_group.csv 2>/dev/null; rm -rf $O/c4; tail -1 $O/clips_one_group.log
+timeout 200 python tools/gpu_clip_keys_ab.py 1024 4 2>&1 | grep -v amdgpu > $O/clip_keys_ab.txt; cat $O/clip_keys_ab.txt
+[ -x tools/lds_b128_probe ] && tools/lds_b128_probe > $O/lds_b128_probe.txt 2>&1
 timeout 300 python tools/gpu_io_sweep.py 60 quick > $O/io_sweep.log 2>&1; cp gpurun_out/io_sweep.json $O/io_sweep.json; tail -1 $O/io_sweep.log | cut -c1-900
 timeout 300 python tools/gpu_first_calls.py > $O/first_calls.txt 2>&1; grep -v amdgpu $O/first_calls.txt
 timeout 1200 python tools/gpu_census_three_way.py 1 14 > $O/census_three_way.log 2>&1; echo "census rc $?"; tail -1 $O/census_three_way.log | cut -c1-1500; cp gpurun_out/census_three_way.json $O/ 2>/dev/null
