@@ -144,6 +144,8 @@ class RawFormat(C.Structure):
 
 
 lib.awm_add_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(RawFormat), C.POINTER(RawFormat)]
+lib.awm_add_stream_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(RawFormat), C.POINTER(RawFormat), C.c_size_t]
+lib.awm_add_stream_create_at.argtypes = [_vp, _vp, C.c_char_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_vp)]
 lib.awm_get_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.POINTER(RawFormat), C.c_size_t, _vp]
 lib.awm_add_stream_create.argtypes = [_vp, _vp, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(_vp)]
 lib.awm_add_stream_destroy.argtypes = [_vp]
@@ -536,8 +538,13 @@ class Context:
             max_out_per_clip = most
 
     # ---- file level: the reference's add_watermark / get_watermark (wmcommon.hh:226-228) ----
-    def add_watermark_file(self, key, payload_hex, in_path, out_path, raw_in=None, raw_out=None):
-        """infile -> outfile; raw_* = RawFormat for headerless PCM, None for WAV"""
+    def add_watermark_file(self, key, payload_hex, in_path, out_path, raw_in=None, raw_out=None, zero_frames=None):
+        """infile -> outfile; raw_* = RawFormat for headerless PCM, None for WAV; zero_frames: add_stream_watermark's start offset"""
+        if zero_frames is not None:
+            _check(lib.awm_add_stream_watermark_file(self._h, key_bytes(key), payload_hex.encode(), os.fsencode(in_path), os.fsencode(out_path),
+                                                     C.byref(raw_in) if raw_in is not None else None,
+                                                     C.byref(raw_out) if raw_out is not None else None, zero_frames), "awm_add_stream_watermark_file")
+            return
         _check(lib.awm_add_watermark_file(self._h, key_bytes(key), payload_hex.encode(), os.fsencode(in_path), os.fsencode(out_path),
                                           C.byref(raw_in) if raw_in is not None else None,
                                           C.byref(raw_out) if raw_out is not None else None), "awm_add_watermark_file")
@@ -546,13 +553,15 @@ class Context:
         return self._patterns(lib.awm_get_watermark_file, "awm_get_watermark_file", self._h, key_bytes(key), os.fsencode(in_path),
                               C.byref(raw_in) if raw_in is not None else None)
 
-    def add_watermark_tiles(self, key, payload_hex, pcm, tile_frames1024=128):
+    def add_watermark_tiles(self, key, payload_hex, pcm, tile_frames1024=128, zero_frames=0):
         """awm_add_stream: `add` as a tile loop over resident PCM (the bounded-memory form the file path uses); returns the
-        concatenated output -- bit-identical to add_watermark on the whole stream."""
+        concatenated output -- bit-identical to add_watermark on the whole stream.  zero_frames: the stream starts that many
+        samples into the frame / block grid (add_stream_watermark's zero_frames, reference wmadd.cc:501-526)."""
         import torch
         n, ch = _pcm_shape(pcm)
         h = C.c_void_p()
-        _check(lib.awm_add_stream_create(self._h, key_bytes(key), payload_hex.encode(), ch, tile_frames1024, C.byref(h)), "awm_add_stream_create")
+        _check(lib.awm_add_stream_create_at(self._h, key_bytes(key), payload_hex.encode(), ch, tile_frames1024, zero_frames, C.byref(h)),
+               "awm_add_stream_create_at")
         out = torch.empty_like(pcm)
         tile = tile_frames1024 * 1024
         done_p = (C.c_void_p * 3)()

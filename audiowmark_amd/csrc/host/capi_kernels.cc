@@ -550,6 +550,11 @@ struct awm_add_stream
   size_t    len[3] = { 0, 0, 0 };     // samples per channel in the input slots
   DevBuffer table, in[3], mix[3], block_max;
   size_t    n_blocks = 0;             // block maxima allocated (and initialised)
+  // a stream that starts `zero_frames` samples into its frame / limiter block grid (add_stream_watermark's zero_frames, reference
+  // wmadd.cc:501-526): whole frames of zeros are only counted (WatermarkGen::skip, Limiter::skip), the rest is a prefix of zeros
+  size_t    skipped = 0;              // zero_frames rounded down to whole 1024-sample frames
+  size_t    prefix = 0;               // zero_frames % 1024: zeros in front of the caller's first sample inside tile 0
+  size_t    first_block = 0;          // limiter block of sample `skipped`: block_max[0]
 };
 
 static int
@@ -574,8 +579,8 @@ add_stream_grow_blocks (awm_add_stream *s, size_t need)
 }
 
 int
-awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, int n_channels, size_t tile_frames1024,
-                       awm_add_stream **out)
+awm_add_stream_create_at (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, int n_channels, size_t tile_frames1024,
+                          size_t zero_frames, awm_add_stream **out)
 {
   AWM_ENTER (ctx);
   if (!out || n_channels < 1 || tile_frames1024 < 128)
@@ -591,6 +596,9 @@ awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_
   s->C = n_channels;
   s->tile = tile_frames1024 * Params::frame_size;
   s->limiter = !params().test_no_limiter;
+  s->prefix = zero_frames % Params::frame_size;
+  s->skipped = zero_frames - s->prefix;
+  s->first_block = s->skipped / LIMITER_BLOCK;
   const size_t table_bytes = 2 * mark_block_frame_count() * Params::n_bands;
   auto fail = [&] (int rc) { awm_add_stream_destroy (s.release()); return rc; };
   if (int rc = s->table.reserve (table_bytes)) return fail (rc);
@@ -598,13 +606,25 @@ awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_
   if (hipMemcpyAsync (s->table.ptr, fm->dev.ptr, table_bytes, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess
       || hipStreamSynchronize (ctx->stream) != hipSuccess)
     return fail (AWM_ERR_HIP);
+  // (one frame of room behind a tile: with a prefix the caller's tile lies `prefix` frames into the slot, what hangs over is
+  // carried to the next slot -- or, for the last tile, stays: the last tile may be up to prefix frames longer)
+  const size_t room = s->prefix ? Params::frame_size : 0;
   for (int i = 0; i < 3; i++)
     {
-      if (int rc = s->in[i].reserve (s->tile * s->C * sizeof (float))) return fail (rc);
-      if (int rc = s->mix[i].reserve (s->tile * s->C * sizeof (float))) return fail (rc);
+      if (int rc = s->in[i].reserve ((s->tile + room) * s->C * sizeof (float))) return fail (rc);
+      if (int rc = s->mix[i].reserve ((s->tile + room) * s->C * sizeof (float))) return fail (rc);
     }
+  if (s->prefix)
+    AWM_HIP_CHECK (hipMemsetAsync (s->in[0].ptr, 0, s->prefix * s->C * sizeof (float), ctx->stream));
   *out = s.release();
   return 0;
+}
+
+int
+awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, int n_channels, size_t tile_frames1024,
+                       awm_add_stream **out)
+{
+  return awm_add_stream_create_at (ctx, key, payload_hex, n_channels, tile_frames1024, 0, out);
 }
 
 void
@@ -627,7 +647,7 @@ awm_add_stream_destroy (awm_add_stream *s)
 float *
 awm_add_stream_input (awm_add_stream *s)
 {
-  return s && !s->finished ? s->in[s->t % 3].as<float>() : nullptr;
+  return s && !s->finished ? s->in[s->t % 3].as<float>() + s->prefix * s->C : nullptr;
 }
 
 int
@@ -662,27 +682,41 @@ awm_add_stream_push (awm_add_stream *s, size_t n_frames, int last, const float *
     const float *before = k > 0 ? s->in[slot (k - 1)].as<float>() + (s->tile - N) * C : nullptr;
     const float *after = has_next ? s->in[slot (k + 1)].as<float>() : nullptr;
     return add_mix_impl (ctx, s->in[slot (k)].as<float>(), s->mix[slot (k)].as<float>(), n, C, s->table.as<int8_t>(), params().water_delta,
-                         size_t (k) * (s->tile / N), before, after, s->limiter ? s->block_max.as<float>() : nullptr, 0, s->n_blocks);
+                         (s->skipped + size_t (k) * s->tile) / N, before, after, s->limiter ? s->block_max.as<float>() : nullptr,
+                         s->first_block, s->n_blocks);
   };
   auto limit_tile = [&] (long long k) -> int {
     const size_t n = s->len[slot (k)];
     if (!n)
       return 0;
     if (s->limiter)
-      if (int rc = awm_add_limit_d (ctx, s->mix[slot (k)].as<float>(), n, C, size_t (k) * s->tile, s->block_max.as<float>(), 0, s->n_blocks))
+      if (int rc = awm_add_limit_d (ctx, s->mix[slot (k)].as<float>(), n, C, s->skipped + size_t (k) * s->tile, s->block_max.as<float>(),
+                                    s->first_block, s->n_blocks))
         return rc;
-    out_d[n_out] = s->mix[slot (k)].as<float>();
-    out_frames[n_out++] = n;
+    // (the zeros in front of the caller's first sample are not part of the output: reference wmadd.cc:574-580)
+    const size_t cut = k == 0 ? s->prefix : 0;
+    if (n > cut)
+      {
+        out_d[n_out] = s->mix[slot (k)].as<float>() + cut * C;
+        out_frames[n_out++] = n - cut;
+      }
     return 0;
   };
 
-  s->len[slot (t)] = n_frames;
-  if (n_frames && n_frames < N)       // a next tile shorter than a frame: the halo the previous tile reads is zero extended
-    AWM_HIP_CHECK (hipMemsetAsync (s->in[slot (t)].as<float>() + n_frames * C, 0, (N - n_frames) * C * sizeof (float), ctx->stream));
+  // what the slot holds now: the prefix (tile 0: zeros; later: the frames that hung over the previous tile) and the caller's frames
+  // (every tile before this one was full, so `prefix` frames always lie in front of the caller's)
+  const size_t held = s->prefix + n_frames;
+  const size_t len = last ? held : s->tile;                        // (the last tile keeps what hangs over: at most prefix frames)
+  s->len[slot (t)] = len;
+  if (!last && s->prefix)
+    AWM_HIP_CHECK (hipMemcpyAsync (s->in[slot (t + 1)].ptr, s->in[slot (t)].as<float>() + s->tile * C, s->prefix * C * sizeof (float),
+                                   hipMemcpyDeviceToDevice, ctx->stream));
+  if (len && len < N)                 // a next tile shorter than a frame: the halo the previous tile reads is zero extended
+    AWM_HIP_CHECK (hipMemsetAsync (s->in[slot (t)].as<float>() + len * C, 0, (N - len) * C * sizeof (float), ctx->stream));
   if (s->limiter)
-    if (int rc = add_stream_grow_blocks (s, (size_t (t) * s->tile + n_frames) / LIMITER_BLOCK + 2)) return rc;
+    if (int rc = add_stream_grow_blocks (s, (s->skipped + size_t (t) * s->tile + len) / LIMITER_BLOCK + 2 - s->first_block)) return rc;
   if (t >= 1)
-    if (int rc = mix_tile (t - 1, n_frames > 0)) return rc;
+    if (int rc = mix_tile (t - 1, len > 0)) return rc;
   if (t >= 2)
     if (int rc = limit_tile (t - 2)) return rc;
   if (last)
@@ -1772,6 +1806,27 @@ awm_add_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload
     }
   file_fail_reset();
   return add_watermark (ctx, capi_key (key), in_path, out_path, payload_hex) ? file_fail_kind() : 0;
+}
+
+int
+awm_add_stream_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const char *in_path, const char *out_path,
+                               const awm_raw_format *raw_in, const awm_raw_format *raw_out, size_t zero_frames)
+{
+  AWM_ENTER (ctx);
+  if (!payload_hex || !in_path || !out_path)
+    {
+      set_error ("awm_add_stream_watermark_file: bad argument");
+      return AWM_ERR_ARG;
+    }
+  FormatScope scope;
+  if (!FormatScope::apply (raw_in, params().input_format, StreamParams::raw_input_format)
+      || !FormatScope::apply (raw_out, params().output_format, StreamParams::raw_output_format))
+    {
+      set_error ("awm_add_stream_watermark_file: unsupported raw format");
+      return AWM_ERR_ARG;
+    }
+  file_fail_reset();
+  return add_watermark_at (ctx, capi_key (key), in_path, out_path, payload_hex, zero_frames) ? file_fail_kind() : 0;
 }
 
 int

@@ -838,15 +838,37 @@ namespace {
 /* "Data Blocks" counter of WatermarkGen (reference wmadd.cc:311-313, 346-351): depends only on how many frames the
  * streaming loop of the reference pushes through the generator, i.e. on the latency of synth + limiter */
 int
-count_data_blocks (size_t n_frames, int sample_rate, bool limiter)
+count_data_blocks (size_t n_frames, int sample_rate, bool limiter, size_t zero_frames)
 {
   const size_t N = Params::frame_size, block = mark_block_frame_count();
   const size_t lim_block = size_t (sample_rate) * size_t (Params::limiter_block_size_ms) / 1000;
   size_t total_in = 0, total_out = 0, frame_number = 2 * block - Params::frames_pad_start, data_blocks = 0, lim_buffer = 0;
+  size_t zero_in = zero_frames, zero_out = zero_frames;
   bool first_frame = true;
+  auto limiter_out = [&] (size_t out) {                     // Limiter::process / Limiter::skip (limiter.cc:51-88): what comes out
+    lim_buffer += out;
+    const size_t buffered_blocks = lim_buffer / lim_block;
+    out = buffered_blocks < 2 ? 0 : (buffered_blocks - 1) * lim_block;
+    lim_buffer -= out;
+    return out;
+  };
+  if (zero_in >= N)
+    {
+      // whole frames of zeros are skipped, not run (wmadd.cc:501-517): the frame counter moves, the block counter does not
+      const size_t skip_frames = zero_in - zero_in % N;
+      total_in += skip_frames;
+      frame_number += skip_frames / N;
+      size_t out = skip_frames - N;                        // WatermarkSynth::skip: the first frame's latency (wmadd.cc:253-263)
+      first_frame = false;
+      out = limiter_out (out);
+      zero_out -= out;
+      total_out += out;
+      zero_in -= skip_frames;
+    }
   while (true)
     {
-      const size_t got = std::min (N, n_frames - total_in);
+      const size_t got = zero_in + std::min (N - zero_in, n_frames + zero_frames - total_in - zero_in);
+      zero_in = 0;
       total_in += got;
       if (got < N && total_in == total_out)
         break;
@@ -856,13 +878,11 @@ count_data_blocks (size_t n_frames, int sample_rate, bool limiter)
       size_t out = first_frame ? 0 : N;                    // WatermarkSynth emits nothing for the first frame
       first_frame = false;
       if (limiter)
-        {
-          lim_buffer += out;
-          const size_t buffered_blocks = lim_buffer / lim_block;
-          out = buffered_blocks < 2 ? 0 : (buffered_blocks - 1) * lim_block;
-          lim_buffer -= out;
-        }
-      total_out += std::min (out, total_in - total_out);
+        out = limiter_out (out);
+      out = std::min (out, total_in - total_out);
+      const size_t cut = std::min (out, zero_out);
+      zero_out -= cut;
+      total_out += out;
     }
   return std::max (int (data_blocks) - 1, 0);
 }
@@ -899,7 +919,7 @@ struct SnrMeter
  * (copy stream) -> file write (writer thread); the stages of neighbouring tiles overlap. */
 int
 add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutputStream *out_stream, const std::string& payload_hex,
-           size_t& n_frames)
+           size_t zero_frames, size_t& n_frames)
 {
   constexpr size_t TILE_FRAMES1024 = 4096;                 // 95 s of audio, 32 MiB of float32 stereo
   const size_t tile = TILE_FRAMES1024 * Params::frame_size;
@@ -910,7 +930,7 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   Lap lap;
   struct TeardownLap { Lap& l; ~TeardownLap() { l.to (6); } };
   awm_add_stream *add = nullptr;
-  if (awm_add_stream_create (ctx, key.aes_key(), payload_hex.c_str(), C, TILE_FRAMES1024, &add))
+  if (awm_add_stream_create_at (ctx, key.aes_key(), payload_hex.c_str(), C, TILE_FRAMES1024, zero_frames, &add))
     {
       error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
       return fail (AWM_ERR_HIP);
@@ -977,11 +997,13 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       lap.to (3);
       for (int i = 0; i < n_done; i++)
         {
-          if (!stage.put (done[i], done_frames[i]))
-            {
-              error ("audiowmark: GPU staging failed: %s\n", awm_last_error());
-              return fail (AWM_ERR_HIP);
-            }
+          // (with zero_frames the last tile carries what hung over the one before it: up to 1023 frames more than a ring slot takes)
+          for (size_t at = 0; at < done_frames[i]; at += tile)
+            if (!stage.put (done[i] + at * C, std::min (tile, done_frames[i] - at)))
+              {
+                error ("audiowmark: GPU staging failed: %s\n", awm_last_error());
+                return fail (AWM_ERR_HIP);
+              }
         }
       lap.to (7);                                          // (output tiles handed on: includes [2], the wait for a free slot)
       n_frames += got;
@@ -1011,7 +1033,7 @@ add_tiles (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
  * host side is still bounded (chunked staging both ways) */
 int
 add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutputStream *out_stream, const std::string& payload_hex,
-           size_t& n_frames)
+           size_t zero_frames, size_t& n_frames)
 {
   const int C = in_stream->n_channels();
   DevBuffer d_in, d_out;
@@ -1026,6 +1048,30 @@ add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
   n_frames = n_values / C;
   if (!n_values)
     return 0;
+  if (zero_frames)
+    {
+      // the resamplers' skip (resample.cc:150-168) leaves them in the state zeros would have: the stream behind zero_frames zeros
+      const size_t zero_values = zero_frames * C;
+      if (zero_frames > (DevBuffer::MAX_BYTES / sizeof (float) - n_values) / C)
+        {
+          error ("audiowmark: zero_frames is too large for device memory at this sample rate\n");
+          return fail (AWM_ERR_ARG);
+        }
+      DevBuffer shifted;
+      if (shifted.reserve ((zero_values + n_values) * sizeof (float))
+          || hipMemsetAsync (shifted.ptr, 0, zero_values * sizeof (float), ctx->stream) != hipSuccess
+          || hipMemcpyAsync (shifted.as<float>() + zero_values, d_in.ptr, n_values * sizeof (float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess
+          || hipStreamSynchronize (ctx->stream) != hipSuccess)
+        {
+          shifted.release();
+          error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
+          return fail (AWM_ERR_HIP);
+        }
+      d_in.release();
+      d_in = shifted;
+    }
+  const size_t in_values = n_values;
+  n_values += zero_frames * C;
   SnrMeter snr (ctx);
   if (params().snr && !snr.begin())
     {
@@ -1033,7 +1079,7 @@ add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       return fail (AWM_ERR_HIP);
     }
   if (d_out.reserve (n_values * sizeof (float))
-      || awm_add_watermark_d (ctx, key.aes_key(), payload_hex.c_str(), d_in.as<float>(), d_out.as<float>(), n_frames, C, in_stream->sample_rate()) != 0)
+      || awm_add_watermark_d (ctx, key.aes_key(), payload_hex.c_str(), d_in.as<float>(), d_out.as<float>(), n_values / C, C, in_stream->sample_rate()) != 0)
     {
       error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
       return fail (AWM_ERR_HIP);
@@ -1043,7 +1089,7 @@ add_whole (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutpu
       error ("audiowmark: GPU watermarking failed: %s\n", awm_last_error());
       return fail (AWM_ERR_HIP);
     }
-  err = store_device_to_stream (ctx, out_stream, d_out.as<float>(), n_values);
+  err = store_device_to_stream (ctx, out_stream, d_out.as<float>() + zero_frames * C, in_values);
   if (err)
     {
       error ("audiowmark output write failed: %s\n", err.message());
@@ -1071,11 +1117,6 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
       error ("audiowmark: input channels (%d) and output channels (%d) don't match\n", in_stream->n_channels(), out_stream->n_channels());
       return fail (AWM_ERR_ARG);
     }
-  if (zero_frames)
-    {
-      error ("audiowmark: zero_frames (HLS segment watermarking) is not supported by the GPU path\n");
-      return fail (AWM_ERR_HIP);
-    }
   if (in_stream->sample_rate() != Params::mark_sample_rate
       && (!awm_resample_frames (ctx, 1024, in_stream->sample_rate(), Params::mark_sample_rate)
           || !awm_resample_frames (ctx, 1024, Params::mark_sample_rate, in_stream->sample_rate())))
@@ -1099,15 +1140,15 @@ add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream,
   const int C = in_stream->n_channels();
   size_t n_frames = 0;
   int rc = in_stream->sample_rate() == Params::mark_sample_rate
-         ? add_tiles (ctx, key, in_stream, out_stream, bit_vec_to_str (bitvec), n_frames)
-         : add_whole (ctx, key, in_stream, out_stream, bit_vec_to_str (bitvec), n_frames);
+         ? add_tiles (ctx, key, in_stream, out_stream, bit_vec_to_str (bitvec), zero_frames, n_frames)
+         : add_whole (ctx, key, in_stream, out_stream, bit_vec_to_str (bitvec), zero_frames, n_frames);
   if (rc)
     return rc;
   (void) C;
-  info ("Data Blocks:  %d\n", count_data_blocks (n_frames, in_stream->sample_rate(), !params().test_no_limiter));
+  info ("Data Blocks:  %d\n", count_data_blocks (n_frames, in_stream->sample_rate(), !params().test_no_limiter, zero_frames));
   if (in_stream->n_frames() != AudioInputStream::N_FRAMES_UNKNOWN && n_frames != in_stream->n_frames())
     {
-      auto msg = string_printf ("unexpected EOF; input frames (%zd) != output frames (%zd)", in_stream->n_frames(), n_frames);
+      auto msg = string_printf ("unexpected EOF; input frames (%zd) != output frames (%zd)", in_stream->n_frames() + zero_frames, n_frames + zero_frames);
       if (params().strict)
         {
           error ("audiowmark: error: %s\n", msg.c_str());
@@ -1134,6 +1175,14 @@ info_format (const std::string& label, const RawFormat& format)
 
 int
 add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits)
+{
+  return add_watermark_at (ctx, key, infile, outfile, bits, 0);
+}
+
+/* add_watermark for a file that is the continuation of a stream `zero_frames` samples in (what hls.cc:279 does with a segment) */
+int
+add_watermark_at (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits,
+                  size_t zero_frames)
 {
   Error err;
   auto in_stream = AudioInputStream::create (infile, err);
@@ -1162,7 +1211,7 @@ add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const st
   info ("Output:       %s\n", outfile.c_str());
   if (params().output_format == Format::RAW)
     info_format ("Raw Output", StreamParams::raw_output_format);
-  return add_stream_watermark (ctx, key, in_stream.get(), out_stream.get(), bits, 0);
+  return add_stream_watermark (ctx, key, in_stream.get(), out_stream.get(), bits, zero_frames);
 }
 
 std::string& last_shard_debug_sync();      // wmshard.cc

@@ -12,6 +12,8 @@ namespace awm {
 int add_stream_watermark (awm_ctx *ctx, const Key& key, AudioInputStream *in_stream, AudioOutputStream *out_stream,
                           const std::string& bits, size_t zero_frames);
 int add_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits);
+int add_watermark_at (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits,
+                      size_t zero_frames);
 int get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::string& infile, const std::string& orig_pattern);
 class ResultSet;
 int get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInputStream *in_stream, bool print_speed, ResultSet& result_set,

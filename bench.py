@@ -152,40 +152,66 @@ def cpu_baseline_and_parity(torch, awm, ctx, sample_seconds):
     except Exception:
         pass
     usable = visible if quota is None else max(1, min(visible, int(round(quota))))
-    t0 = time.perf_counter()
-    w = impl.add(None, x, 2, PAYLOAD)
-    t1 = time.perf_counter()
-    t_add = t1 - t0
-    # `get` as upstream runs it: the reference's pool starts one worker per VISIBLE core (threadpool.cc:58-63) ...
-    os.environ.pop("AWM_REF_THREADS", None)
-    t1 = time.perf_counter()
-    pats = impl.get(None, w, 2)
-    t_get_upstream = time.perf_counter() - t1
-    # ... and with one worker per core the process may USE (oracle/ref_shim/threads_shim.cc; the reference's sources are unchanged):
-    # under a quota far below the visible count the upstream figure is handicapped by oversubscription, so the baseline is the better one
-    t_get, threads = t_get_upstream, (visible if kind == "reference" else 1)
-    upstream = None
-    if kind == "reference" and usable < visible:
-        os.environ["AWM_REF_THREADS"] = str(usable)
+
+    def timed_run(upstream_threads_too):
+        """add (single threaded, as upstream) + get; get with one worker per core the process may USE (oracle/ref_shim/threads_shim.cc; the
+        reference's sources are unchanged) and -- once -- as upstream starts its pool: one worker per VISIBLE core (threadpool.cc:58-63)"""
+        impl.add(None, x[:4 * RATE], 2, PAYLOAD)            # (untimed: the library is loaded and its FFT set up, as the GPU side's warm-up steps)
+        t0 = time.perf_counter()
+        w = impl.add(None, x, 2, PAYLOAD)
+        t_add = time.perf_counter() - t0
+        r = {"t_add": t_add, "w": w}
+        if kind == "reference" and usable < visible:
+            os.environ["AWM_REF_THREADS"] = str(usable)
         try:
             t1 = time.perf_counter()
-            pats_q = impl.get(None, w, 2)
-            t_q = time.perf_counter() - t1
+            r["pats"] = impl.get(None, w, 2)
+            r["t_get"] = time.perf_counter() - t1
         finally:
             os.environ.pop("AWM_REF_THREADS", None)
-        same = [(p["sync_index"], p["bits"]) for p in pats_q] == [(p["sync_index"], p["bits"]) for p in pats]
-        upstream = {"value": round(sample_seconds / (t_add + t_get_upstream), 2), "get_s": round(t_get_upstream, 2), "threads": visible,
-                    "note": "one worker per visible core, as upstream starts them"}
-        if same and t_q < t_get_upstream:
-            t_get, threads = t_q, usable
-    ok = sum(p["bits"] == PAYLOAD for p in pats)
-    cores = min(threads, usable)
-    base = {"value": round(sample_seconds / (t_add + t_get), 2), "unit": "xRT", "cores": cores, "kind": kind,
-            "sample": f"{sample_seconds / 60:.0f} min stereo 44.1 kHz test-gen-noise, add {t_add:.2f} s (1 thread) + get {t_get:.2f} s "
-                      f"({threads} threads" + (f", CPU quota of the process {quota:g} cores" if quota is not None else "") +
-                      f"), {ok} of {len(pats)} patterns carry the payload; FFTW replaced by the oracle's double-precision FFT"}
-    if upstream:
-        base["with_upstream_thread_count"] = upstream
+        r["threads"] = (usable if usable < visible else visible) if kind == "reference" else 1
+        if upstream_threads_too and kind == "reference" and usable < visible:
+            t1 = time.perf_counter()
+            pats_u = impl.get(None, w, 2)
+            r["t_get_upstream"] = time.perf_counter() - t1
+            r["upstream_same"] = [(p["sync_index"], p["bits"]) for p in pats_u] == [(p["sync_index"], p["bits"]) for p in r["pats"]]
+        return r
+
+    def line(r, fft):
+        ok = sum(p["bits"] == PAYLOAD for p in r["pats"])
+        return {"value": round(sample_seconds / (r["t_add"] + r["t_get"]), 2), "unit": "xRT", "cores": min(r["threads"], usable), "kind": kind,
+                "fft": fft,
+                "sample": f"{sample_seconds / 60:.0f} min stereo 44.1 kHz test-gen-noise" + (" (= the whole of configs[1])" if sample_seconds == 3600 else "") +
+                          f", add {r['t_add']:.2f} s (1 thread) + get {r['t_get']:.2f} s "
+                          f"({r['threads']} threads" + (f", CPU quota of the process {quota:g} cores" if quota is not None else "") +
+                          f"), {ok} of {len(r['pats'])} patterns carry the payload; FFT behind fftw3.h: {fft}"}
+
+    # the build the parity bars are pinned to: FFTW (absent from the image) replaced by the oracle's double-precision FFT
+    run_d = timed_run(upstream_threads_too=True)
+    base_d = line(run_d, "double-precision FFT stand-in, rounded once (oracle/ref_shim/fftw_shim.cc)")
+    base = base_d
+    # the headline baseline: the same unmodified sources with a FLOAT FFT behind fftw3.h, which is what FFTW's fftwf_* is
+    # (reference fft.cc:63,85): MKL's single-precision FFTW3 wrapper (oracle/_ref/libawm_ref_mkl.so, `make -C oracle ref_mkl`)
+    if kind == "reference" and os.path.exists(_ref.PATH_MKL):
+        os.environ.setdefault("MKL_THREADING_LAYER", "SEQUENTIAL")
+        try:
+            _ref.use_backend("mkl")
+            run_m = timed_run(upstream_threads_too=False)
+            base = line(run_m, "MKL single-precision FFTW3 wrapper (float, like FFTW's fftwf_*)")
+            base["with_double_fft_stand_in"] = {k: base_d[k] for k in ("value", "cores", "sample")}
+            same = [(p["sync_index"], p["type"], p["block_type"], p["bits"]) for p in run_m["pats"]] == \
+                   [(p["sync_index"], p["type"], p["block_type"], p["bits"]) for p in run_d["pats"]]
+            base["patterns_equal_to_the_double_fft_build"] = bool(same)
+        except Exception as e:                             # (MKL missing on the box: the double build stays the baseline)
+            base["float_fft_build"] = f"unavailable: {e}"
+        finally:
+            _ref.use_backend("double")
+    if "t_get_upstream" in run_d:
+        base["with_upstream_thread_count"] = {"value": round(sample_seconds / (run_d["t_add"] + run_d["t_get_upstream"]), 2),
+                                              "get_s": round(run_d["t_get_upstream"], 2), "threads": visible, "fft": "double-precision stand-in",
+                                              "same_patterns": bool(run_d["upstream_same"]),
+                                              "note": "one worker per visible core, as upstream starts them (oversubscribed under the quota)"}
+    w, pats = run_d["w"], run_d["pats"]
     # parity of the HIP path against this very run
     xd = torch.from_numpy(x.reshape(n, 2)).cuda()
     wg = ctx.add_watermark(None, PAYLOAD, xd).cpu().numpy().ravel()
@@ -199,7 +225,8 @@ def cpu_baseline_and_parity(torch, awm, ctx, sample_seconds):
     ties = sum(tie(a, b) for a, b in zip(got, pats)) if len(got) == len(pats) else 0
     same_pos = len(got) == len(pats) and all(key(a) == key(b) for a, b in zip(got, pats))
     watermark_bits_equal = same_pos and all(a["bits"] == b["bits"] for a, b in zip(got, pats) if b["decode_error"] < 0.6)
-    parity = {"parity_checked_against": kind, "sample": base["sample"].split(",")[0],
+    parity = {"parity_checked_against": kind + (" (double-precision FFT build: the one the test bars are pinned to)" if kind == "reference" else ""),
+              "sample": base["sample"].split(",")[0],
               "pcm_rms_diff": float(np.sqrt(np.mean(d * d))), "pcm_max_abs_diff": float(np.abs(d).max()),
               "patterns": len(pats), "pattern_positions_and_types_equal": bool(same_pos), "refinement_ties": int(ties),
               "payload_bits_equal_for_every_watermark": bool(watermark_bits_equal),
@@ -483,7 +510,7 @@ def main():
                          "scaling); clips: configs[4], 1024 x 30 s clips over all ranks")
     ap.add_argument("--minutes", type=float, default=None, help="audio minutes (60min: per GPU, default 60; 8h: in total, default 480)")
     ap.add_argument("--clips", type=int, default=1024, help="--config clips: clips in total")
-    ap.add_argument("--cpu-sample-seconds", type=float, default=1800.0)
+    ap.add_argument("--cpu-sample-seconds", type=float, default=3600.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-detect-speed-config", action="store_true", help="skip the 48 kHz --detect-speed configuration (BASELINE configs[2])")

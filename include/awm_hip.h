@@ -123,10 +123,18 @@ int awm_add_d (awm_ctx *ctx, const float *pcm_in_d, float *out_d, size_t n_frame
  *   push:    `n_frames` samples per channel were written there; every tile but the last must be full; last = 1 ends the
  *            stream (n_frames may be 0).  Work is enqueued on the context's stream.  Returns how many tiles became final
  *            (0..3, in stream order): out_d[i] / out_frames[i] point into the object and stay valid until the next push.
- * The concatenated output is bit-identical to awm_add_watermark_d on the whole stream (tests: spans + halo == whole). */
+ * The concatenated output is bit-identical to awm_add_watermark_d on the whole stream (tests: spans + halo == whole).
+ *   create_at: the `zero_frames` argument of add_stream_watermark (wmcommon.hh:226; wmadd.cc:501-526, 574-580, limiter.cc:69-88):
+ *            the stream starts `zero_frames` samples into the frame / watermark block / limiter block grid, as if that many zeros
+ *            had been pushed before the caller's first sample and cut from the output again.  Whole frames of zeros are only
+ *            counted (the table row of frame m becomes (4202 + zero_frames / 1024 + m) mod 4452, the limiter blocks keep their
+ *            phase); the remaining zero_frames % 1024 zeros sit in front of the caller's samples inside the object, so the
+ *            LAST tile's output may be up to 1023 frames longer than its input was (what hung over the tile before it). */
 typedef struct awm_add_stream awm_add_stream;
 int    awm_add_stream_create (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, int n_channels, size_t tile_frames1024,
                               awm_add_stream **out);
+int    awm_add_stream_create_at (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, int n_channels, size_t tile_frames1024,
+                                 size_t zero_frames, awm_add_stream **out);
 void   awm_add_stream_destroy (awm_add_stream *s);
 float *awm_add_stream_input (awm_add_stream *s);
 int    awm_add_stream_push (awm_add_stream *s, size_t n_frames, int last, const float *out_d[3], size_t out_frames[3]);
@@ -267,6 +275,12 @@ int awm_decode_chunks_d (awm_ctx *ctx, const uint8_t key[16], const float *pcm_d
 typedef struct { int n_channels, sample_rate, bit_depth, encoding /* 0 signed, 1 unsigned, 2 float */, big_endian; } awm_raw_format;
 int awm_add_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const char *in_path, const char *out_path,
                             const awm_raw_format *raw_in, const awm_raw_format *raw_out);
+/* add_stream_watermark (key, in_stream, out_stream, bits, zero_frames) (wmcommon.hh:226, wmadd.cc:448-618) on files: the input is the
+ * continuation of a stream that is `zero_frames` samples in (hls.cc:279 watermarks a segment this way); zero_frames = 0 is
+ * awm_add_watermark_file.  At 44.1 kHz the start offset costs nothing (a frame counter and a limiter block phase); at other rates the
+ * zeros are materialised in HBM in front of the input (the resamplers see them, resample.cc:150-168). */
+int awm_add_stream_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const char *in_path, const char *out_path,
+                                   const awm_raw_format *raw_in, const awm_raw_format *raw_out, size_t zero_frames);
 int awm_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *in_path, const awm_raw_format *raw_in,
                             size_t max_out, awm_pattern *out);
 int awm_get_watermark_keys_file (awm_ctx *ctx, const uint8_t *keys, int n_keys, const char *in_path, const awm_raw_format *raw_in,

@@ -45,6 +45,9 @@ void   ref_ifft (size_t n, const float *spect /* [(n/2+1)*2] */, float *out /* [
 /* wmadd.cc:448-618 through in-memory streams; returns rc of add_stream_watermark; out has n_frames*C values */
 int    ref_add (const uint8_t key[16], const float *samples, size_t n_frames, int n_channels, int sample_rate,
                 const char *payload_hex, float *out, size_t *out_frames, double *snr_db);
+/* the same with add_stream_watermark's zero_frames argument (wmadd.cc:448, 501-526, 574-580) */
+int    ref_add_at (const uint8_t key[16], const float *samples, size_t n_frames, int n_channels, int sample_rate,
+                   const char *payload_hex, size_t zero_frames, float *out, size_t *out_frames);
 
 /* RawConverter (rawconverter.cc:73-286): encoding 0 signed / 1 unsigned / 2 float; to_raw: floats -> bytes, else bytes -> floats */
 int    ref_raw_convert (int bit_depth, int encoding, int big_endian, int to_raw, const void *in, void *out, size_t n_values);

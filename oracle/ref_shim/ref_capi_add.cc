@@ -211,16 +211,23 @@ ref_fft_range (const float *samples, size_t n_values, int n_channels, size_t sta
   return (int) r.size();
 }
 int
-ref_add (const uint8_t key[16], const float *samples, size_t n_frames, int n_channels, int sample_rate,
-         const char *payload_hex, float *out, size_t *out_frames, double *snr_db)
+ref_add_at (const uint8_t key[16], const float *samples, size_t n_frames, int n_channels, int sample_rate,
+            const char *payload_hex, size_t zero_frames, float *out, size_t *out_frames)
 {
+  /* add_stream_watermark with its zero_frames argument (wmadd.cc:448, 501-526): what hls.cc:279 passes for a segment */
   MemInputStream in (samples, n_frames, n_channels, sample_rate);
   MemOutputStream os (n_channels, sample_rate);
-  (void) snr_db;
-  int rc = add_stream_watermark (make_key (key), &in, &os, payload_hex, 0);
+  int rc = add_stream_watermark (make_key (key), &in, &os, payload_hex, zero_frames);
   if (out_frames) *out_frames = os.data.size() / n_channels;
   std::copy (os.data.begin(), os.data.end(), out);
   return rc;
+}
+int
+ref_add (const uint8_t key[16], const float *samples, size_t n_frames, int n_channels, int sample_rate,
+         const char *payload_hex, float *out, size_t *out_frames, double *snr_db)
+{
+  (void) snr_db;
+  return ref_add_at (key, samples, n_frames, n_channels, sample_rate, payload_hex, 0, out, out_frames);
 }
 
 

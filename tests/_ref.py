@@ -178,6 +178,18 @@ def add(key, samples, n_channels, payload_hex, sample_rate=44100):
     return out[:of.value * n_channels]
 
 
+def add_at(key, samples, n_channels, payload_hex, zero_frames, sample_rate=44100):
+    """add_stream_watermark (..., zero_frames) of the reference (wmadd.cc:448): the stream starts zero_frames samples in"""
+    samples = np.ascontiguousarray(samples, np.float32).ravel()
+    n_frames = samples.size // n_channels
+    out = np.zeros(samples.size + 4096 * n_channels, np.float32)
+    of = C.c_size_t()
+    rc = lib().ref_add_at(_key(key), _p(samples), C.c_size_t(n_frames), n_channels, sample_rate, payload_hex.encode(),
+                          C.c_size_t(zero_frames), _p(out), C.byref(of))
+    assert rc == 0
+    return out[:of.value * n_channels]
+
+
 def sync_fft(samples, n_channels, index, frame_count, want_frames=None, first=0, last=None):
     samples = np.ascontiguousarray(samples, np.float32).ravel()
     if last is None:

@@ -59,6 +59,72 @@ def test_add_tiles_without_limiter_and_with_key(gpu):
     assert gpu.torch.equal(whole, tiles)
 
 
+ZERO_FRAMES = [0, 1, 1023, 1024, 44100, 3 * 1024 + 17, 44100 * 61 + 5, TILE * 1024 * 2 + 1023]
+
+
+@pytest.mark.parametrize("zero_frames", ZERO_FRAMES)
+def test_add_stream_zero_frames_equals_the_reference(gpu, zero_frames):
+    """add_stream_watermark (key, in, out, bits, zero_frames) (reference wmcommon.hh:226; wmadd.cc:501-526, 574-580; limiter.cc:69-88):
+    the stream starts zero_frames samples into the frame / block / limiter grid.  Against the compiled reference's own
+    add_stream_watermark with that argument (PCM RMS < 1e-6, max < 2e-6), and BIT-IDENTICAL to this library's whole-buffer add of
+    "zero_frames zeros, then the input" with the zeros cut again -- which is what the reference's skip logic amounts to."""
+    import _ref
+    t = gpu.torch
+    n = 3 * TILE * 1024 + 44100 + 311                          # three tiles and a bit: the carried prefix crosses every tile edge
+    x = noise(gpu, n, 2, 31 + zero_frames % 97) * 0.98          # (loud: the limiter is at work in every block)
+    got = gpu.ctx.add_watermark_tiles(None, PAY, x, TILE, zero_frames=zero_frames)
+    assert got.shape == x.shape
+    whole = gpu.ctx.add_watermark(None, PAY, t.cat([t.zeros((zero_frames, 2), device="cuda"), x]))[zero_frames:]
+    assert t.equal(got, whole)
+    if not _ref.available():
+        pytest.skip("oracle/_ref is not built")
+    ref = _ref.add_at(None, x.cpu().numpy(), 2, PAY, zero_frames).reshape(-1, 2)
+    assert ref.shape == (n, 2)
+    d = got.cpu().numpy().astype(np.float64) - ref
+    assert np.sqrt((d ** 2).mean()) < 1e-6 and np.abs(d).max() < 2e-6
+    # and the watermark it carries is the one a detector finds at that offset: not the one of zero_frames = 0
+    if zero_frames % (1024 * 2226 * 2) > 4096:
+        plain = gpu.ctx.add_watermark_tiles(None, PAY, x, TILE)
+        assert not t.equal(got, plain)
+
+
+@pytest.mark.parametrize("n,ch,zero_frames", [(0, 2, 5000), (1, 1, 1023), (500, 2, 700), (1024, 1, 1), (TILE * 1024, 2, 1023),
+                                              (TILE * 1024 - 1023, 2, 1023), (TILE * 1024 + 1, 3, 2048 + 9)])
+def test_add_stream_zero_frames_edge_lengths(gpu, n, ch, zero_frames):
+    """lengths around the tile size with a prefix that hangs over the last tile; empty input; mono and 3 channels"""
+    t = gpu.torch
+    x = noise(gpu, n, ch, 5 + n % 50)
+    got = gpu.ctx.add_watermark_tiles(None, PAY, x, TILE, zero_frames=zero_frames)
+    whole = gpu.ctx.add_watermark(None, PAY, t.cat([t.zeros((zero_frames, ch), device="cuda"), x]))[zero_frames:]
+    assert got.shape == x.shape and t.equal(got, whole)
+
+
+@pytest.mark.parametrize("fmt,rate,zero_frames", [("s16", 44100, 3 * 1024 + 17), ("s16", 44100, 44100 * 200), ("f32", 48000, 48000 * 3 + 100)])
+def test_file_add_with_zero_frames(gpu, tmp_path, fmt, rate, zero_frames):
+    """awm_add_stream_watermark_file: the file level form; at 48 kHz the zeros are materialised in front of the resamplers"""
+    import _ref
+    t, awm = gpu.torch, gpu.awm
+    bits, enc, big = {"s16": (16, 0, False), "f32": (32, 2, False)}[fmt]
+    n = int(130.3 * rate)
+    x = noise(gpu, n, 2, 41) * 0.9
+    raw_in = gpu.ctx.pcm_encode(x.reshape(-1), bits, enc, big, True).cpu().numpy()
+    src, dst = tmp_path / "in.raw", tmp_path / "out.raw"
+    raw_in.tofile(src)
+    rf = awm.binding.RawFormat(2, rate, bits, enc, int(big))
+    gpu.ctx.add_watermark_file(None, PAY, src, dst, rf, rf, zero_frames=zero_frames)
+    got = gpu.ctx.pcm_decode(t.from_numpy(np.fromfile(dst, np.uint8)).cuda(), bits, enc, big).reshape(-1, 2)
+    assert got.shape == (n, 2)
+    x_file = gpu.ctx.pcm_decode(t.from_numpy(raw_in).cuda(), bits, enc, big).reshape(n, 2)
+    if not _ref.available():
+        pytest.skip("oracle/_ref is not built")
+    ref = _ref.add_at(None, x_file.cpu().numpy(), 2, PAY, zero_frames, sample_rate=rate).reshape(-1, 2)
+    ref_q = gpu.ctx.pcm_decode(gpu.ctx.pcm_encode(t.from_numpy(ref).cuda().reshape(-1), bits, enc, big, True), bits, enc, big).reshape(-1, 2)
+    d = (got - ref_q).cpu().numpy().astype(np.float64)
+    # (16 bit output: the two pipelines may land on different sides of a quantisation step for a handful of samples)
+    tol = 1.01 / 32768 if bits == 16 else 4e-6
+    assert np.abs(d).max() <= tol and np.sqrt((d ** 2).mean()) < (2e-6 if bits == 16 else 1e-6)
+
+
 def test_add_tiles_rejects_bad_use(gpu):
     import ctypes as C
     lib = gpu.awm.lib
