@@ -146,6 +146,7 @@ class RawFormat(C.Structure):
 lib.awm_add_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(RawFormat), C.POINTER(RawFormat)]
 lib.awm_add_stream_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(RawFormat), C.POINTER(RawFormat), C.c_size_t]
 lib.awm_add_stream_create_at.argtypes = [_vp, _vp, C.c_char_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_vp)]
+lib.awm_debug_sync_db_sliding_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, _vp]
 lib.awm_get_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.POINTER(RawFormat), C.c_size_t, _vp]
 lib.awm_add_stream_create.argtypes = [_vp, _vp, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(_vp)]
 lib.awm_add_stream_destroy.argtypes = [_vp]
@@ -552,6 +553,17 @@ class Context:
     def get_watermark_file(self, key, in_path, raw_in=None):
         return self._patterns(lib.awm_get_watermark_file, "awm_get_watermark_file", self._h, key_bytes(key), os.fsencode(in_path),
                               C.byref(raw_in) if raw_in is not None else None)
+
+    def sync_db_sliding(self, pcm, bases, count, ld=72):
+        """K4s alone (awm_debug_sync_db_sliding_d): dB [stream][81][ld] of `count` windows advancing by 8 samples from every base"""
+        import torch
+        n, ch = _pcm_shape(pcm)
+        b = torch.as_tensor(bases, dtype=torch.int64, device=pcm.device).contiguous()
+        out = torch.zeros((b.numel(), 81, ld), dtype=torch.float32, device=pcm.device)
+        _check(lib.awm_debug_sync_db_sliding_d(self._h, _dev_ptr(pcm), n, ch, C.c_void_p(b.data_ptr()), b.numel(), count, ld, _dev_ptr(out)),
+               "awm_debug_sync_db_sliding_d")
+        self.synchronize()
+        return out
 
     def add_watermark_tiles(self, key, payload_hex, pcm, tile_frames1024=128, zero_frames=0):
         """awm_add_stream: `add` as a tile loop over resident PCM (the bounded-memory form the file path uses); returns the

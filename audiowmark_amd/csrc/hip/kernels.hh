@@ -23,6 +23,7 @@ struct DevTables
   const float  *synth;    // synthesis window, 3072 (reference wmadd.cc:177-206)
   const double2 *slide;   // [84 bins 19..102][9]: e^{-2 pi i k j / 1024}, j = 0..7, and e^{+2 pi i 8 k / 1024} at j = 8
   const double2 *tw512d;  // e^{-2 pi i k / 512} in double (first transform of a refinement row)
+  const float2 *slide32;  // [84 bins 19..102][8]: e^{-2 pi i k j / 1024} e^{+2 pi i 8 k / 1024}, j = 0..7, rounded to float (K4s with the update term in float)
 };
 
 /* K1: FFTAnalyzer::run_fft / fft_range */

@@ -19,6 +19,7 @@
 #include "awm_fft.hip.h"
 #include <cstdlib>
 #include <algorithm>
+#include <type_traits>
 
 namespace awmk {
 
@@ -2139,8 +2140,361 @@ sync_db_sliding3_kernel (DevTables t, SyncDbArgs a)
     a.have[out_slot * a.have_stream_stride + 64] = have_64;
 }
 
-int g_sliding3 = 1;          // (debug toggle: the three-bins-per-lane stereo kernel)
-extern "C" void awm_debug_set_sliding3 (int on) { g_sliding3 = on; }
+/* K4s for stereo, restructured (round 6).  The arithmetic of a fine offset is sync_db_sliding3_kernel's; what changes is how little
+ * else a step costs and -- behind U32 -- the precision of the UPDATE TERM only:
+ *   - a step is straight-line code: the output of offset t (Hann combination of R_t, dB) and the update R_t -> R_{t+1} are independent
+ *     and sit in one basic block, so the scheduler interleaves them (before: three exec-masked regions per step in between).  All the
+ *     rules that are the same for the whole wave -- a window of digital silence, a row inside the padding of a clip, the bins' reset
+ *     when the window runs empty, a power below 2^-96 that needs log2f's denormal scaling -- are decided on the SCALAR unit from masks
+ *     that are built once per block of 16 offsets, and share ONE rarely taken branch to the careful form of the output;
+ *   - the state is kept scaled by 2^-10 (exact: the first transform's result and the sample differences are scaled, everything
+ *     downstream is linear), which removes the two scalings per bin and offset;
+ *   - channel 1 lives in lanes 32..59 and hands its dB values to channel 0's lanes through ds_bpermute (the LDS crossbar, no VALU
+ *     slot): the tile in LDS holds the SUM, [offset][band] -- 5 KB instead of 10 per wave, so that the exchange tile of the first
+ *     transform (9 KB) is the wave's whole LDS footprint and 16 waves fit a compute unit;
+ *   - the flush walks the 60 rows a sync frame's bit sums (not the 81 bands: 15 instead of 21 rounds of 64 lanes, no idle lanes) with
+ *     32 bit offsets from a scalar base.
+ * U32 = false: every floating point operation and its order is the old kernel's: the output is BIT-IDENTICAL (pinned by
+ * tests/test_gpu_parity.py::test_refinement_kernel_forms).
+ * U32 = true: the update term U[k] = sum_j d[j] W^{jk} -- 16 of the 19 double precision operations per bin and offset -- is
+ * accumulated in FLOAT (d = x[s + N + j] - x[s + j] rounded to float, rotation folded into the table: T_j = W^{jk} rho_k as
+ * float2), converted once and added to R rho in double: R' = R rho + U'.  The state R itself, the recurrence and the Hann combination
+ * stay double.  What this costs in accuracy: an error of ~2^-24 |U| per offset that random-walks over at most 64 offsets, i.e.
+ * ~6e-8 of |R| at the far end -- the level of a float FFT (what FFTW's fftwf_* is in the reference build, fft.cc:63,85), where the
+ * double form sits at the level of the reference's float WINDOW rounding.  Gate: tools/gpu_census_three_way.py. */
+constexpr int S4_ROW          = NB + 3;                       // a tile row: bands -1 .. 82 (the lanes' 28 x 3 bins: three of them are never read)
+constexpr int S4_OFF_DUMMY   = SL_TILE * S4_ROW * 4;         // 64 x 3 floats: where channel 1's and the idle lanes' stores go
+constexpr int S4_OFF_DELTA   = S4_OFF_DUMMY + 64 * 3 * 4;
+constexpr int S4_OFF_ROWBAND = S4_OFF_DELTA + SL_TILE * 2 * 8 * 8;     // (room for doubles)
+constexpr int S4_BYTES       = XBUF_ELEMS * 16;              // the first transform's exchange tile (double2) covers it all
+static_assert (S4_OFF_ROWBAND + 96 <= S4_BYTES && S4_OFF_DELTA % 16 == 0, "K4s: LDS layout");
+
+template<bool U32> __device__ __forceinline__ void
+sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
+{
+  constexpr int CV = 2, LPC = 28;
+  typedef typename std::conditional<U32, float, double>::type delta_t;
+  __shared__ __attribute__ ((aligned (16))) unsigned char s_mem[WAVES][S4_BYTES];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
+  const long long stream = (long long) blockIdx.x * WAVES + wave;
+  if (stream >= a.n_streams)
+    return;
+  const long long tslice = a.tables_per_slice ? (a.range_index ? a.range_index[stream / a.range_div] : stream / a.range_div) : 0;
+  const long long out_slot = wave_uniform (a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane
+                                                        + a.row_perm[tslice * a.rows_per_plane + stream % a.rows_per_plane] : stream);
+  const long long base = wave_uniform (sync_stream_base (a, stream));
+  const int count = __builtin_amdgcn_readfirstlane (a.stream_count ? a.stream_count[stream] : a.count0);
+  if (count <= 0)
+    return;
+  long long sil_first, sil_last;
+  sync_stream_range (a, stream, sil_first, sil_last);
+  sil_first = wave_uniform (sil_first);
+  sil_last = wave_uniform (sil_last);
+  if (a.have && ((base + 8LL * (count - 1) + 1024) * CV < sil_first || base * CV > sil_last))
+    {
+      if (lane < count)
+        a.have[out_slot * a.have_stream_stride + lane] = 0;
+      if (lane == 0 && count > 64)
+        a.have[out_slot * a.have_stream_stride + 64] = 0;
+      return;
+    }
+  unsigned char *mem = s_mem[wave];
+  double2 *xbuf = reinterpret_cast<double2 *> (mem);
+  float *tile = reinterpret_cast<float *> (mem);
+  delta_t *delta = reinterpret_cast<delta_t *> (mem + S4_OFF_DELTA);          // [transition][channel][j]
+  unsigned char *rowband = mem + S4_OFF_ROWBAND;                               // row of the output -> band
+  const int ch = lane >> 5;                                    // channel 0: lanes 0..27, channel 1: lanes 32..59
+  const bool active = (lane & 31) < LPC;
+  const int li = active ? (lane & 31) : 0;                     // (idle lanes ride along with the bins of their channel's first lane)
+  const int kA = 19 + 3 * li;
+
+  // ---- first offset: plain (unwindowed) DFT bins from the wave FFT, in double (see sync_db_sliding_kernel), scaled by 2^-10
+  double2 R[3];
+  int nz0 = 0, nz1 = 0;                                        // non-zero samples of the current window, per channel (wave uniform)
+#pragma unroll
+  for (int c = 0; c < CV; c++)
+    {
+      float in[16];
+      fetch_channel (a.pcm, base, 1024, CV, c, lane, in);
+      int cnt = 0;
+#pragma unroll
+      for (int j = 0; j < 16; j++)
+        cnt += in[j] != 0.f;
+      for (int o = 32; o > 0; o >>= 1)
+        cnt += __shfl_xor (cnt, o);
+      (c == 0 ? nz0 : nz1) = __builtin_amdgcn_readfirstlane (cnt);
+      double2 z[8];
+#pragma unroll
+      for (int j = 0; j < 8; j++)
+        z[j] = make_double2 (double (in[2 * j]), double (in[2 * j + 1]));
+      fft512_forward_d (z, xbuf, t.tw512d, lane);
+      xbuf[0 * 64 + lane] = z[0];
+      xbuf[1 * 64 + lane] = z[1];
+      xbuf[6 * 64 + lane] = z[6];
+      xbuf[7 * 64 + lane] = z[7];
+      wave_sync();
+      if (ch == c)
+        {
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            {
+              const int k = kA + b;
+              const double2 r = real_split_d (xbuf[zpos (k)], xbuf[zpos (512 - k)], t.slide[(k - 19) * 9 + 1]);
+              R[b] = make_double2 (r.x * 0x1p-10, r.y * 0x1p-10);
+            }
+        }
+      wave_sync();
+    }
+  // ---- the lane's constants
+  int k_tab = kA - 19;
+  asm volatile ("" : "+v" (k_tab));                           // keep the tables' registers out of the transform above (no hoisting)
+  double2 rho[3];                                             // e^{+2 pi i 8 k / N}
+  double2 tw[U32 ? 1 : 3][U32 ? 1 : 7];                       // double form: e^{-2 pi i k j / N}, j = 1..7
+  float2  tf[U32 ? 3 : 1][U32 ? 8 : 1];                       // float form: e^{-2 pi i k j / N} e^{+2 pi i 8 k / N}, j = 0..7
+#pragma unroll
+  for (int b = 0; b < 3; b++)
+    {
+      rho[b] = t.slide[(k_tab + b) * 9 + 8];
+      if constexpr (U32)
+        {
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+            tf[b][j] = t.slide32[(k_tab + b) * 8 + j];
+        }
+      else
+        {
+#pragma unroll
+          for (int j = 0; j < 7; j++)
+            tw[b][j] = t.slide[(k_tab + b) * 9 + j + 1];
+        }
+    }
+  // where the lane's three dB values go: channel 0's lanes fill the tile (their bins are adjacent: one address, offsets 0, 4, 8; it
+  // moves on by a row per offset), every other lane keeps writing to three words of its own
+  const bool stores = active && ch == 0;
+  int tile_addr = stores ? li * 12 : S4_OFF_DUMMY + lane * 12;
+  const int tile_inc = stores ? S4_ROW * 4 : 0;
+  const int partner = ((lane + 32) & 63) * 4;                 // ds_bpermute address of the same bins' other channel
+  // rows of the output: the 60 values a sync frame's bit sums, in summation order (gathered) -- or the 81 bands as they are
+  const int n_rows = a.band_pos ? 60 : NB;
+  {
+    const unsigned char *pos = a.band_pos ? a.band_pos + (tslice * a.rows_per_plane + stream % a.rows_per_plane) * NB : nullptr;
+    for (int b = lane; b < NB; b += 64)
+      {
+        const int row = pos ? pos[b] : b;
+        if (row != 255)
+          rowband[row] = (unsigned char) b;
+      }
+  }
+  // Sample feed: the transition step -> step + 1 needs the 8 C samples entering the window and the 8 C leaving it.  Sixteen
+  // transitions are fetched at once (both blocks are contiguous: 128 C floats, 2 C per lane), a whole block of steps ahead.
+  constexpr int FPL = 2 * CV;
+  float f_in[FPL], f_out[FPL];
+  auto fetch_block = [&] (int q) {
+    const long long s0 = base + 128LL * q;
+#pragma unroll
+    for (int i = 0; i < FPL; i++)
+      {
+        const int e = lane * FPL + i;                             // (transition * 8 + j) * C + c
+        const int trans = SL_TILE * q + e / (8 * CV);
+        const bool need = trans + 1 < count;
+        f_in[i] = need ? a.pcm[(s0 + 1024) * CV + e] : 0.f;
+        f_out[i] = trans < count ? a.pcm[s0 * CV + e] : 0.f;      // the first 8 samples of the window of step `trans`
+      }
+  };
+  // per block of 16 offsets, one bit per offset at bit 4 * offset: the window carries no weighted non-zero sample (-96 dB exactly,
+  // wmcommon.hh:204-224: position 0 has weight 0) | the window after the transition is all zeros (the bins restart from 0)
+  unsigned long long zmask0 = 0, zmask1 = 0, rmask0 = 0, rmask1 = 0, skipmask = 0;
+  auto publish_block = [&] (int t0) {
+    const int tr = lane >> 2, jj = (lane & 3) * 2;
+#pragma unroll
+    for (int i = 0; i < FPL; i++)
+      {
+        delta_t d;
+        if constexpr (U32)
+          d = __fmul_rn (__fsub_rn (f_in[i], f_out[i]), 0x1p-10f);
+        else
+          d = (double (f_in[i]) - double (f_out[i])) * 0x1p-10;
+        delta[(tr * 2 + (i & 1)) * 8 + jj + (i >> 1)] = d;
+      }
+#pragma unroll
+    for (int c = 0; c < CV; c++)
+      {
+        int dn = (f_in[c] != 0.f) - (f_out[c] != 0.f) + (f_in[CV + c] != 0.f) - (f_out[CV + c] != 0.f);
+        dn += __shfl_xor (dn, 1);
+        dn += __shfl_xor (dn, 2);                                 // the transition's change of the non-zero count, in its four lanes
+        int incl = dn;                                            // ... summed over the transitions up to this one
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1)
+          {
+            const int v = __shfl_up (incl, o);
+            incl += lane >= o ? v : 0;
+          }
+        const int nz = c == 0 ? nz0 : nz1;
+        const bool first_lane = (lane & 3) == 0;                  // holds sample j = 0 of the window of step tr: f_out[c]
+        const unsigned long long z = __builtin_amdgcn_ballot_w64 (first_lane && nz + (incl - dn) - int (f_out[c] != 0.f) == 0);
+        const unsigned long long r = __builtin_amdgcn_ballot_w64 (first_lane && nz + incl == 0);
+        const int total = __builtin_amdgcn_readlane (incl, 63);
+        if (c == 0) { zmask0 = z; rmask0 = r; nz0 += total; } else { zmask1 = z; rmask1 = r; nz1 += total; }
+      }
+    // rows of a padded clip inside the padding (syncfinder.cc:583-585): decided for the block's 16 offsets at once
+    const long long idx = base + 8LL * (t0 + (lane >> 2));
+    skipmask = __builtin_amdgcn_ballot_w64 ((lane & 3) == 0 && (((idx + 1024) * CV < sil_first) || (idx * CV > sil_last)));
+  };
+  fetch_block (0);
+  unsigned long long have_mask = 0;      // offsets 0..63
+  bool have_64 = false;                  // offset 64 (a candidate has at most 65 fine offsets)
+  float *const out_base = a.out + out_slot * a.out_stream_stride;
+
+  for (int t0 = 0; t0 < count; t0 += SL_TILE)
+    {
+      wave_sync();                                                // the previous block's tile and differences have been read
+      publish_block (t0);                                         // fetched one block of steps ago
+      wave_sync();
+      fetch_block (t0 / SL_TILE + 1);
+      const int n_cols = count - t0 < SL_TILE ? count - t0 : SL_TILE;
+      for (int col = 0; col < n_cols; col++)
+        {
+          const int step = t0 + col;
+          const unsigned sh = 4u * unsigned (col);
+          const bool zero0 = (zmask0 >> sh) & 1, zero1 = (zmask1 >> sh) & 1, skip = (skipmask >> sh) & 1;
+          // ---- the differences of this transition (two 16 / 32 byte broadcast reads)
+          delta_t d[8];
+          {
+            const delta_t *dl = delta + (col * 2 + ch) * 8;
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+              d[j] = dl[j];
+          }
+          // ---- output for this fine offset: X[k] = (2 R[k] - (R[k-1] + R[k+1])) / 1024, the scaling is in R
+          // neighbours of the outer bins: R[kA - 1] is the third bin of lane - 1, R[kC + 1] the first bin of lane + 1
+          const double2 up = make_double2 (dpp_from_lower_lane (R[2].x), dpp_from_lower_lane (R[2].y));
+          const double2 dn = make_double2 (dpp_from_upper_lane (R[0].x), dpp_from_upper_lane (R[0].y));
+          float2 x[3];
+          x[0] = make_float2 (float (fma (2.0, R[0].x, -(up.x + R[1].x))), float (fma (2.0, R[0].y, -(up.y + R[1].y))));
+          x[1] = make_float2 (float (fma (2.0, R[1].x, -(R[0].x + R[2].x))), float (fma (2.0, R[1].y, -(R[0].y + R[2].y))));
+          x[2] = make_float2 (float (fma (2.0, R[2].x, -(R[1].x + dn.x))), float (fma (2.0, R[2].y, -(R[1].y + dn.y))));
+          float abs2[3], db[3];
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            abs2[b] = __fadd_rn (__fmul_rn (x[b].x, x[b].x), __fmul_rn (x[b].y, x[b].y));
+          // log2f scales arguments below the normal range; v_log_f32 alone is the same function from 2^-96 upwards: one test per
+          // lane, one branch per wave -- shared with the wave-uniform special cases, which are all rare
+          const bool small = fminf (fminf (abs2[0], abs2[1]), abs2[2]) < 0x1p-96f;
+          if (__builtin_expect (__builtin_amdgcn_ballot_w64 (small) != 0 || zero0 || zero1 || skip, 0))
+            {
+              const bool zero_frame = ch ? zero1 : zero0;
+#pragma unroll
+              for (int b = 0; b < 3; b++)
+                {
+                  const float v = abs2[b] > 0 ? __fmul_rn (log2f (abs2[b]), 3.01029995663981f) : -96.f;
+                  db[b] = skip ? 0.f : (zero_frame ? -96.f : v);
+                }
+            }
+          else
+            {
+#pragma unroll
+              for (int b = 0; b < 3; b++)
+                db[b] = __fmul_rn (__builtin_amdgcn_logf (abs2[b]), 3.01029995663981f);
+            }
+          if (!skip)
+            {
+              if (step < 64)
+                have_mask |= 1ULL << step;
+              else
+                have_64 = true;
+            }
+          // the other channel's values are asked for now and used behind the update below (the crossbar's latency is the update's time)
+          float other[3];
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            other[b] = __int_as_float (__builtin_amdgcn_ds_bpermute (partner, __float_as_int (db[b])));
+          // ---- advance by 8 samples
+          if (step + 1 < count)
+            {
+              if constexpr (U32)
+                {
+#pragma unroll
+                  for (int b = 0; b < 3; b++)
+                    {
+                      float ux = __fmul_rn (d[0], tf[b][0].x), uy = __fmul_rn (d[0], tf[b][0].y);
+#pragma unroll
+                      for (int j = 1; j < 8; j++)
+                        {
+                          ux = fmaf (d[j], tf[b][j].x, ux);
+                          uy = fmaf (d[j], tf[b][j].y, uy);
+                        }
+                      const double rx = R[b].x, ry = R[b].y;
+                      R[b].x = fma (-ry, rho[b].y, fma (rx, rho[b].x, double (ux)));
+                      R[b].y = fma (ry, rho[b].x, fma (rx, rho[b].y, double (uy)));
+                    }
+                }
+              else
+                {
+#pragma unroll
+                  for (int b = 0; b < 3; b++)
+                    {
+                      double ax = R[b].x + d[0], ay = R[b].y;
+#pragma unroll
+                      for (int j = 1; j < 8; j++)
+                        {
+                          ax = fma (d[j], tw[b][j - 1].x, ax);
+                          ay = fma (d[j], tw[b][j - 1].y, ay);
+                        }
+                      R[b].x = fma (ax, rho[b].x, -(ay * rho[b].y));
+                      R[b].y = fma (ax, rho[b].y, ay * rho[b].x);
+                    }
+                }
+              const bool reset0 = (rmask0 >> sh) & 1, reset1 = (rmask1 >> sh) & 1;
+              if (__builtin_expect (reset0 || reset1, 0))
+                if (ch ? reset1 : reset0)
+                  R[0] = R[1] = R[2] = make_double2 (0.0, 0.0);
+            }
+          // 0 + db0 + db1 in the reference's order (syncfinder.cc:594-599); channel 1's lanes compute a sum nobody reads.  (A skipped
+          // row is 0 in both channels: the sum is the +0 the plain kernel writes.)
+          __builtin_amdgcn_sched_barrier (0);
+#pragma unroll
+          for (int b = 0; b < 3; b++)
+            *reinterpret_cast<float *> (mem + tile_addr + 4 * b) = __fadd_rn (__fadd_rn (0.f, db[b]), other[b]);
+          tile_addr += tile_inc;
+        }
+      // ---- flush the block's tile: row r of the output = band rowband[r], 16 offsets side by side
+      wave_sync();
+      {
+        const int cc = lane & 15;
+        float *out = out_base + t0;                               // (wave uniform: the stores take a 32 bit offset from it)
+        const unsigned ld = unsigned (a.ld);
+        if (cc < n_cols)
+          for (int row = lane >> 4; row < n_rows; row += 4)
+            out[unsigned (row) * ld + unsigned (cc)] = tile[cc * S4_ROW + 1 + rowband[row]];
+      }
+      tile_addr -= n_cols * tile_inc;
+    }
+  if (a.have && lane < count)
+    a.have[out_slot * a.have_stream_stride + lane] = (have_mask >> lane) & 1;
+  if (a.have && lane == 0 && count > 64)
+    a.have[out_slot * a.have_stream_stride + 64] = have_64;
+}
+
+__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
+sync_db_sliding4_kernel (DevTables t, SyncDbArgs a)
+{
+  sync_db_sliding4_body<false> (t, a);
+}
+__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
+sync_db_sliding4f_kernel (DevTables t, SyncDbArgs a)
+{
+  sync_db_sliding4_body<true> (t, a);
+}
+
+/* which form of K4s runs for stereo streams (awm_debug_set_refine_form; the result of 0, 3 and 4 is the same to the last bit):
+ *   0  sync_db_sliding_kernel<2>    two bins of both channels per lane (42 lanes)
+ *   3  sync_db_sliding3_kernel      three bins of one channel per lane (56 lanes): rounds 3 - 5
+ *   4  sync_db_sliding4_kernel      the same arithmetic, restructured (above)
+ *   5  sync_db_sliding4f_kernel     the update term in float (above): NOT bit-identical, gated by the census of DESIGN.md section 4 */
+int g_refine_form = 4;
+extern "C" void awm_debug_set_refine_form (int form) { g_refine_form = (form == 0 || form == 3 || form == 4 || form == 5) ? form : 4; }
+extern "C" int  awm_debug_refine_form() { return g_refine_form; }
+extern "C" void awm_debug_set_sliding3 (int on) { g_refine_form = on ? 3 : 0; }     // (rounds 3 - 5's toggle, kept for tools/gpu_variants.py)
 
 hipError_t
 launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
@@ -2150,7 +2504,11 @@ launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
   if (a.hop != 8 || a.count0 > 65 || a.per_channel || (a.n_channels != 1 && a.n_channels != 2))
     return hipErrorInvalidValue;
   const unsigned grid = unsigned ((a.n_streams + WAVES - 1) / WAVES);
-  if (a.n_channels == 2 && g_sliding3)
+  if (a.n_channels == 2 && g_refine_form == 5)
+    hipLaunchKernelGGL (sync_db_sliding4f_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
+  else if (a.n_channels == 2 && g_refine_form == 4)
+    hipLaunchKernelGGL (sync_db_sliding4_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
+  else if (a.n_channels == 2 && g_refine_form == 3)
     hipLaunchKernelGGL (sync_db_sliding3_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
   else if (a.n_channels == 2)
     hipLaunchKernelGGL (sync_db_sliding_kernel<2>, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);

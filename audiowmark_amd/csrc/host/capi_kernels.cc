@@ -785,6 +785,34 @@ awm_pcm_encode_d (awm_ctx *ctx, const float *in_d, size_t n_values, int bit_dept
 }
 
 int
+awm_debug_sync_db_sliding_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, const long long *base_d, size_t n_streams,
+                             int count, int ld, float *out_d)
+{
+  AWM_ENTER (ctx);
+  if (!pcm_d || !base_d || !out_d || count < 1 || count > 65 || ld < count || (n_channels != 1 && n_channels != 2))
+    {
+      set_error ("awm_debug_sync_db_sliding_d: bad argument");
+      return AWM_ERR_ARG;
+    }
+  awmk::SyncDbArgs da {};
+  da.pcm = pcm_d;
+  da.n_frames = (long long) n_frames;
+  da.n_channels = n_channels;
+  da.stream_base = base_d;
+  da.count0 = count;
+  da.n_streams = (long long) n_streams;
+  da.hop = Params::sync_search_fine;
+  da.out = out_d;
+  da.out_stream_stride = (long long) Params::n_bands * ld;
+  da.ld = ld;
+  da.first = 0;
+  da.last = (long long) (n_frames * n_channels);
+  da.tile_frames = ld;
+  AWM_HIP_CHECK (awmk::launch_sync_db_sliding (ctx->stream, ctx->tabs, da));
+  return 0;
+}
+
+int
 awm_sync_fft_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, size_t index, size_t frame_count,
                 const char *want_frames, size_t first, size_t last, float *db_out_d, char *have_out_d)
 {

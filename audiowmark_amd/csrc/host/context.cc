@@ -679,10 +679,24 @@ ctx_create (int device, bool own_stream, hipStream_t given, awm_ctx **ctx_out)
       slide.push_back (std::cos (-2 * M_PI * k / 512));
       slide.push_back (std::sin (-2 * M_PI * k / 512));
     }
+  // ... and the update term's factors with the rotation folded in, as floats (two per double slot)
+  const size_t off_slide32 = slide.size();
+  {
+    std::vector<float> f;
+    for (int k = 19; k <= 102; k++)
+      for (int j = 0; j < 8; j++)
+        {
+          f.push_back (float (std::cos (2 * M_PI * k * (8 - j) / 1024)));
+          f.push_back (float (std::sin (2 * M_PI * k * (8 - j) / 1024)));
+        }
+    slide.resize (off_slide32 + f.size() / 2);
+    std::memcpy (slide.data() + off_slide32, f.data(), f.size() * sizeof (float));
+  }
   if (int rc = upload (ctx->tab_slide, slide.data(), slide.size() * sizeof (double), ctx->stream))
     return rc;
   ctx->tabs.slide = ctx->tab_slide.as<double2>();
   ctx->tabs.tw512d = reinterpret_cast<const double2 *> (ctx->tab_slide.as<double>() + off_tw512d);
+  ctx->tabs.slide32 = reinterpret_cast<const float2 *> (ctx->tab_slide.as<double>() + off_slide32);
   if (int rc = upload (ctx->tab_mem, blob.data(), blob.size() * sizeof (float), ctx->stream))
     return rc;
   const float *base = ctx->tab_mem.as<float>();

@@ -413,7 +413,18 @@ void awm_debug_set_viterbi_persistent (int on); /* K8: 1 ONE launch per batch of
                                                  * are cheap, the one-launch kernel where they are not.  Bits and error values are identical. */
 double awm_debug_dependent_launch_us (void);    /* the probe's result (microseconds per empty dependent launch; -1 before the first context) */
 int  awm_debug_viterbi_one_launch_in_use (void);
-void awm_debug_set_sliding3 (int on);
+void awm_debug_set_sliding3 (int on);          /* (rounds 3 - 5: refine form 3 / 0) */
+/* K4s, the refinement's sliding DFT for stereo streams (reference SyncFinder::search_refine -> sync_fft, syncfinder.cc:393-458, 560-605):
+ *   0  two bins of both channels per lane | 3  three bins of one channel per lane (rounds 3 - 5) | 4 (default) the same arithmetic in a
+ *   straight-line step with the wave-uniform rules on the scalar unit: outputs of 0, 3, 4 are identical to the last bit |
+ *   5  the update term of the recurrence accumulated in float (state, rotation and Hann combination stay double): the level of a float
+ *      FFT, which is what the reference's FFTW is; NOT bit-identical to 4 -- gated by the census in DESIGN.md section 4 */
+void awm_debug_set_refine_form (int form);
+int  awm_debug_refine_form (void);
+/* K4s alone on resident PCM (stereo or mono): stream i = `count` (<= 65) windows of 1024 samples starting at base_d[i] + 8 o; writes
+ * out_d[i][band 0..80][ld] (dB summed over the channels) in the form in force.  For the tests that pin forms 0 / 3 / 4 against each other. */
+int  awm_debug_sync_db_sliding_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, const long long *base_d, size_t n_streams,
+                                  int count, int ld, float *out_d);
 void awm_debug_set_soft_bits_generic (int on); /* K7: one thread per soft bit for every shape (the fallback kernel) | four bits per wave */
 void awm_debug_set_chunk_stagger (int mode); /* get: phase offset between the chunk lanes -- 0 all chunks start together | 1 chunk i + 1 behind chunk i's
                                              * dB kernel | 2 behind its scan | -1 (default) 1 for streams of up to `lanes` chunks, 2 for longer ones */

@@ -1064,3 +1064,65 @@ def test_add_get_as_one_call_equals_the_two_calls(gpu, minutes, limiter):
         assert [full(p) for p in gpu.ctx.get_watermark(None, out)] == want
     finally:
         gpu.awm.set_params()
+
+
+def test_refinement_kernel_forms(gpu):
+    """K4s (the refinement's sliding DFT, SyncFinder::search_refine -> sync_fft, reference syncfinder.cc:393-458, 560-605) exists in four
+    forms (awm_debug_set_refine_form): 0 and 3 are the kernels of rounds 2 - 5, 4 (the default) the restructured step of round 6 with the
+    SAME arithmetic -- its output must equal theirs to the last bit, on noise, on material with gaps of digital silence (the scalar
+    zero-window / reset rules), at 65 and at fewer offsets, and through the whole `get` (every quality a double equal).
+    Form 5 keeps the recurrence's state in double but accumulates the update term in float.  It is NOT the default and this test says why:
+    on stationary noise its dB values are within 1e-2 of form 4's (mean 1e-6) and the detector's positions and qualities agree, but its
+    error is relative to the UNWINDOWED content that slid through the window -- where a window slides into a gap of digital silence
+    (loud samples leave, little is left) the dB values are off by whole dB (measured: 4.1), where form 4 and the reference are exact."""
+    t, lib = gpu.torch, gpu.awm.lib
+    rng = np.random.default_rng(4242)
+    x = noise(901, 40 * 44100, 2)
+    plain = gpu.dev(x)
+    x[5 * 44100:5 * 44100 + 30000] = 0                          # a gap in both channels, one in the right channel only, a lone sample
+    x[11 * 44100:11 * 44100 + 9000, 1] = 0
+    x[17 * 44100:17 * 44100 + 5000] = 0
+    x[17 * 44100 + 2500, 0] = 0.25
+    x *= np.linspace(1.0, 1e-3, len(x), dtype=np.float32)[:, None]     # 60 dB of level across the stream
+    xd = gpu.dev(x)
+    bases = np.concatenate([rng.integers(0, len(x) - 1024 - 8 * 65, 300), 5 * 44100 + np.arange(-1600, 31000, 997),
+                            11 * 44100 + np.arange(-1200, 9500, 511), 17 * 44100 + np.arange(-1100, 5200, 333)]).astype(np.int64)
+    try:
+        outs = {}
+        for count in (65, 64, 17, 1):
+            for form in (3, 0, 4, 5):
+                lib.awm_debug_set_refine_form(form)
+                outs[form] = gpu.ctx.sync_db_sliding(xd, bases, count)
+            assert t.equal(outs[3], outs[0]) and t.equal(outs[3], outs[4]), count
+            assert (outs[4][:, :, :count] <= 0).any() and t.isfinite(outs[4]).all() and t.isfinite(outs[5]).all()
+        gap_error = (outs[5] - outs[4]).abs().max().item()
+        for form in (4, 5):
+            lib.awm_debug_set_refine_form(form)
+            outs[form] = gpu.ctx.sync_db_sliding(plain, bases, 65)
+        d = (outs[5] - outs[4]).abs()
+        assert d.max().item() < 1e-2 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
+        print("form 5 against form 4: max |d dB| on stationary noise %.3g (mean %.3g), next to gaps of digital silence %.3g"
+              % (d.max().item(), d.mean().item(), gap_error))
+        # mono streams take the generic kernel whatever the form
+        lib.awm_debug_set_refine_form(4)
+        m4 = gpu.ctx.sync_db_sliding(gpu.dev(x[:, :1].copy()), bases, 65)
+        lib.awm_debug_set_refine_form(3)
+        assert t.equal(m4, gpu.ctx.sync_db_sliding(gpu.dev(x[:, :1].copy()), bases, 65))
+        # the whole detector: BLOCK mode (three minutes) and CLIP mode (30 s, padded, rows inside the padding are skipped), with a gap
+        full = lambda p: pkey(p) + (p["sync_quality"], p["decode_error"])
+        for seconds in (185, 30):
+            w = orc.add(None, noise(902 + seconds, seconds * 44100, 2), 2, PAY1).reshape(-1, 2)
+            for gap in (False, True):
+                if gap:
+                    w[len(w) // 2:len(w) // 2 + 20000] = 0
+                wd = gpu.dev(w)
+                res = {}
+                for form in (3, 4, 5):
+                    lib.awm_debug_set_refine_form(form)
+                    res[form] = gpu.ctx.get_watermark(None, wd)
+                assert [full(p) for p in res[4]] == [full(p) for p in res[3]] and len(res[4]) > 0
+                if not gap:
+                    assert [pkey(p) for p in res[5]] == [pkey(p) for p in res[4]]
+                    assert max(abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(res[5], res[4])) < QUALITY_TOL
+    finally:
+        lib.awm_debug_set_refine_form(4)
