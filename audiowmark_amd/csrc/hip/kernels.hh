@@ -124,6 +124,10 @@ struct SyncDbArgs
   const int           *row_perm = nullptr;
   const unsigned char *band_pos = nullptr;
   int                  rows_per_plane = 0;
+  // ... and, with forms 4 / 5 of K4s, the rows' 65th value (fine offset 64) apart from the rows: tail[slot * tail_stream_stride + row],
+  // so that a row of `ld` = 64 floats is two whole cache lines (nullptr: offset 64 goes into the row like the others, ld >= 65)
+  float               *tail = nullptr;
+  long long            tail_stream_stride = 0;
   // a batch of clips with one KEY PER CLIP: the tables of slice i (range_index / range_div as below) follow those of slice i - 1:
   // row_perm + slice * rows_per_plane, band_pos + slice * rows_per_plane * 81
   int                  tables_per_slice = 0;
@@ -147,6 +151,8 @@ hipError_t launch_sync_db (hipStream_t st, const DevTables& t, const SyncDbArgs&
 /* K4s: same output as K4 for streams whose frames advance by 8 samples (search_refine): instead of one FFT per fine
  * offset the 83 needed bins are carried from offset to offset by a sliding DFT in double precision. n_channels <= 2. */
 hipError_t launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a);
+/* does the form of K4s in force (awm_debug_set_refine_form) write rows of 64 fine offsets + SyncDbArgs::tail for streams of this many channels? */
+bool sliding_rows_have_tail (int n_channels);
 
 /* K5: sync_decode (syncfinder.cc:116-153) for many candidates.
  * value(cand, row, band) = db[plane(cand) + row * row_stride + band * band_stride + lane(cand)],
@@ -200,6 +206,9 @@ struct GatheredScanArgs
   const char  *have;
   long long    plane_stride, have_plane_stride;
   int          ld;
+  int          have_ld = 0;     // row length of `have` if it is not ld
+  const float *tail = nullptr;  // K4s forms 4 / 5: the values of fine offsets >= ld (there is one: 64), [plane][6 bits][rows_per_bit][60]
+  long long    tail_plane_stride = 0;
   int          rows_per_bit;
   int          n_lanes;         // fine offsets (<= 128)
   const int   *lane_count;      // per plane

@@ -1645,6 +1645,15 @@ wave_uniform (long long v)
   return (long long) (((unsigned long long) (unsigned int) hi << 32) | (unsigned int) lo);
 }
 
+/* a wave-uniform address in GLOBAL memory as a scalar base: accesses through it take the base from scalar registers and a 32 bit offset
+ * per lane (global_load / global_store ... saddr) instead of a 64 bit address register pair per lane */
+typedef __attribute__ ((address_space (1))) float global_float;
+__device__ __forceinline__ global_float *
+uniform_global (const float *p)
+{
+  return (global_float *) (unsigned long long) wave_uniform ((long long) (unsigned long long) p);
+}
+
 template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
 sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 {
@@ -2141,7 +2150,7 @@ sync_db_sliding3_kernel (DevTables t, SyncDbArgs a)
 }
 
 /* K4s for stereo, restructured (round 6).  The arithmetic of a fine offset is sync_db_sliding3_kernel's; what changes is how little
- * else a step costs and -- behind U32 -- the precision of the UPDATE TERM only:
+ * else a step costs, how the rows leave the chip, and -- behind U32 -- the precision of the UPDATE TERM only:
  *   - a step is straight-line code: the output of offset t (Hann combination of R_t, dB) and the update R_t -> R_{t+1} are independent
  *     and sit in one basic block, so the scheduler interleaves them (before: three exec-masked regions per step in between).  All the
  *     rules that are the same for the whole wave -- a window of digital silence, a row inside the padding of a clip, the bins' reset
@@ -2150,31 +2159,37 @@ sync_db_sliding3_kernel (DevTables t, SyncDbArgs a)
  *   - the state is kept scaled by 2^-10 (exact: the first transform's result and the sample differences are scaled, everything
  *     downstream is linear), which removes the two scalings per bin and offset;
  *   - channel 1 lives in lanes 32..59 and hands its dB values to channel 0's lanes through ds_bpermute (the LDS crossbar, no VALU
- *     slot): the tile in LDS holds the SUM, [offset][band] -- 5 KB instead of 10 per wave, so that the exchange tile of the first
- *     transform (9 KB) is the wave's whole LDS footprint and 16 waves fit a compute unit;
- *   - the flush walks the 60 rows a sync frame's bit sums (not the 81 bands: 15 instead of 21 rounds of 64 lanes, no idle lanes) with
- *     32 bit offsets from a scalar base.
- * U32 = false: every floating point operation and its order is the old kernel's: the output is BIT-IDENTICAL (pinned by
+ *     slot); the tile in LDS holds the SUM, and only the rows a sync frame's bit sums: [60 rows][32 offsets];
+ *   - THE STORES.  Measured with the stores removed (tools/gpu_k4s_alone.py), the kernel of rounds 3 - 5 spent 108 of its 369 us
+ *     on them: a flush of 16 offsets wrote 64 byte pieces, 4 bytes per lane, at a row stride of 288 bytes -- half cache lines that
+ *     the L2 could not merge.  Now a row holds offsets 0..63 in 256 bytes (ld = 64, two whole 128 byte lines), a flush happens
+ *     every 32 offsets and writes 16 bytes per lane: eight lanes complete a line, an instruction eight rows; offset 64 (a candidate
+ *     has 65) goes to a compact array of its own (`tail`: 60 floats per stream, one coalesced store), which K5g's tail wave reads.
+ * U32 = false: every floating point operation and its order is the old kernel's: the values are BIT-IDENTICAL (pinned by
  * tests/test_gpu_parity.py::test_refinement_kernel_forms).
  * U32 = true: the update term U[k] = sum_j d[j] W^{jk} -- 16 of the 19 double precision operations per bin and offset -- is
  * accumulated in FLOAT (d = x[s + N + j] - x[s + j] rounded to float, rotation folded into the table: T_j = W^{jk} rho_k as
  * float2), converted once and added to R rho in double: R' = R rho + U'.  The state R itself, the recurrence and the Hann combination
- * stay double.  What this costs in accuracy: an error of ~2^-24 |U| per offset that random-walks over at most 64 offsets, i.e.
- * ~6e-8 of |R| at the far end -- the level of a float FFT (what FFTW's fftwf_* is in the reference build, fft.cc:63,85), where the
- * double form sits at the level of the reference's float WINDOW rounding.  Gate: tools/gpu_census_three_way.py. */
-constexpr int S4_ROW          = NB + 3;                       // a tile row: bands -1 .. 82 (the lanes' 28 x 3 bins: three of them are never read)
-constexpr int S4_OFF_DUMMY   = SL_TILE * S4_ROW * 4;         // 64 x 3 floats: where channel 1's and the idle lanes' stores go
-constexpr int S4_OFF_DELTA   = S4_OFF_DUMMY + 64 * 3 * 4;
-constexpr int S4_OFF_ROWBAND = S4_OFF_DELTA + SL_TILE * 2 * 8 * 8;     // (room for doubles)
-constexpr int S4_BYTES       = XBUF_ELEMS * 16;              // the first transform's exchange tile (double2) covers it all
-static_assert (S4_OFF_ROWBAND + 96 <= S4_BYTES && S4_OFF_DELTA % 16 == 0, "K4s: LDS layout");
+ * stay double.  Measured (profiles/r06/k4s_forms.txt): 14 % faster, 3e-3 dB off at most on stationary noise -- and WHOLE dB off
+ * where a window slides into a gap of digital silence: the error is relative to the unwindowed content that passed through the
+ * window, not to what is left in it.  Not the default. */
+constexpr int S4_FLUSH = 32;                                  // offsets per flush: 128 bytes of a row
+constexpr int S4_LD    = S4_FLUSH + 1;                        // tile row length: odd, the lanes' stores (one row each) take different banks
+template<int ROWS, int DELTA_BYTES> struct S4Lds
+{
+  static constexpr int OFF_DUMMY = ROWS * S4_LD * 4;          // where the stores nobody reads go: word 3 lane + bin + column (no two lanes of a store collide)
+  static constexpr int OFF_DELTA = ((OFF_DUMMY + (64 * 3 + S4_FLUSH) * 4 + 15) / 16) * 16;
+  static constexpr int TOTAL     = OFF_DELTA + SL_TILE * 2 * 8 * DELTA_BYTES;
+  static constexpr int BYTES     = TOTAL > XBUF_ELEMS * 16 ? TOTAL : XBUF_ELEMS * 16;   // the first transform's exchange tile lies over it all
+};
 
-template<bool U32> __device__ __forceinline__ void
+template<bool U32, int ROWS> __device__ __forceinline__ void
 sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
 {
   constexpr int CV = 2, LPC = 28;
   typedef typename std::conditional<U32, float, double>::type delta_t;
-  __shared__ __attribute__ ((aligned (16))) unsigned char s_mem[WAVES][S4_BYTES];
+  typedef S4Lds<ROWS, int (sizeof (delta_t))> L;
+  __shared__ __attribute__ ((aligned (16))) unsigned char s_mem[WAVES][L::BYTES];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
   const long long stream = (long long) blockIdx.x * WAVES + wave;
   if (stream >= a.n_streams)
@@ -2200,9 +2215,8 @@ sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
     }
   unsigned char *mem = s_mem[wave];
   double2 *xbuf = reinterpret_cast<double2 *> (mem);
-  float *tile = reinterpret_cast<float *> (mem);
-  delta_t *delta = reinterpret_cast<delta_t *> (mem + S4_OFF_DELTA);          // [transition][channel][j]
-  unsigned char *rowband = mem + S4_OFF_ROWBAND;                               // row of the output -> band
+  float *tile = reinterpret_cast<float *> (mem);                               // [row][S4_LD]
+  delta_t *delta = reinterpret_cast<delta_t *> (mem + L::OFF_DELTA);           // [transition][channel][j]
   const int ch = lane >> 5;                                    // channel 0: lanes 0..27, channel 1: lanes 32..59
   const bool active = (lane & 31) < LPC;
   const int li = active ? (lane & 31) : 0;                     // (idle lanes ride along with the bins of their channel's first lane)
@@ -2268,44 +2282,64 @@ sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
             tw[b][j] = t.slide[(k_tab + b) * 9 + j + 1];
         }
     }
-  // where the lane's three dB values go: channel 0's lanes fill the tile (their bins are adjacent: one address, offsets 0, 4, 8; it
-  // moves on by a row per offset), every other lane keeps writing to three words of its own
-  const bool stores = active && ch == 0;
-  int tile_addr = stores ? li * 12 : S4_OFF_DUMMY + lane * 12;
-  const int tile_inc = stores ? S4_ROW * 4 : 0;
-  const int partner = ((lane + 32) & 63) * 4;                 // ds_bpermute address of the same bins' other channel
-  // rows of the output: the 60 values a sync frame's bit sums, in summation order (gathered) -- or the 81 bands as they are
-  const int n_rows = a.band_pos ? 60 : NB;
+  // where the lane's three dB values go: channel 0's lanes write the rows of their bands (the row of the output a band belongs to:
+  // the 60 values a sync frame's bit sums in summation order -- gathered -- or the band itself), one column further per offset;
+  // every other store (channel 1, idle lanes, bins 19 / 101 / 102, bands the frame does not use) keeps hitting a word of its own
+  int tile_addr[3];
   {
     const unsigned char *pos = a.band_pos ? a.band_pos + (tslice * a.rows_per_plane + stream % a.rows_per_plane) * NB : nullptr;
-    for (int b = lane; b < NB; b += 64)
+#pragma unroll
+    for (int b = 0; b < 3; b++)
       {
-        const int row = pos ? pos[b] : b;
-        if (row != 255)
-          rowband[row] = (unsigned char) b;
+        const int band = kA + b - MIN_BAND;
+        const bool in_range = active && ch == 0 && band >= 0 && band < NB;
+        const int row = in_range ? (pos ? int (pos[band]) : band) : 255;
+        const bool stores = row < ROWS;
+        tile_addr[b] = stores ? row * S4_LD * 4 : L::OFF_DUMMY + (lane * 3 + b) * 4;
       }
   }
+  int tile_col = 0;                                            // (wave uniform: column of the tile the next offset goes to, in bytes)
+  const int partner = ((lane + 32) & 63) * 4;                 // ds_bpermute address of the same bins' other channel
   // Sample feed: the transition step -> step + 1 needs the 8 C samples entering the window and the 8 C leaving it.  Sixteen
   // transitions are fetched at once (both blocks are contiguous: 128 C floats, 2 C per lane), a whole block of steps ahead.
   constexpr int FPL = 2 * CV;
   float f_in[FPL], f_out[FPL];
+  typedef float v2f __attribute__ ((ext_vector_type (2)));
+  typedef __attribute__ ((address_space (1))) v2f global_v2f;
   auto fetch_block = [&] (int q) {
-    const long long s0 = base + 128LL * q;
+    // The block's two runs of samples start at wave-uniform addresses: scalar bases, one 32 bit lane offset -- no 64 bit address
+    // registers to keep alive across the steps.  The loads are unconditional (a load behind a per-lane test makes the compiler
+    // drain the memory counter -- the previous flush's stores -- before it may preset the register): lanes whose transition lies
+    // beyond the stream read a valid place instead and publish_block drops what they got.
+    if (SL_TILE * q >= count)
+      return;
+    const global_float *p_out = uniform_global (a.pcm + (base + 128LL * q) * CV);
+    const int trans = SL_TILE * q + (lane >> 2);                  // lane * FPL + i = (transition * 8 + j) * C + c
+    const unsigned at_out = trans < count ? unsigned (lane * FPL) : 0u;
+    const unsigned at_in = trans + 1 < count ? unsigned (lane * FPL + 1024 * CV) : at_out;
 #pragma unroll
-    for (int i = 0; i < FPL; i++)
+    for (int i = 0; i < FPL; i += 2)
       {
-        const int e = lane * FPL + i;                             // (transition * 8 + j) * C + c
-        const int trans = SL_TILE * q + e / (8 * CV);
-        const bool need = trans + 1 < count;
-        f_in[i] = need ? a.pcm[(s0 + 1024) * CV + e] : 0.f;
-        f_out[i] = trans < count ? a.pcm[s0 * CV + e] : 0.f;      // the first 8 samples of the window of step `trans`
+        const v2f vo = *(const global_v2f *) (p_out + at_out + i), vi = *(const global_v2f *) (p_out + at_in + i);
+        f_out[i] = vo.x; f_out[i + 1] = vo.y;                     // the first 8 samples of the window of step `trans`
+        f_in[i] = vi.x;  f_in[i + 1] = vi.y;
       }
   };
   // per block of 16 offsets, one bit per offset at bit 4 * offset: the window carries no weighted non-zero sample (-96 dB exactly,
-  // wmcommon.hh:204-224: position 0 has weight 0) | the window after the transition is all zeros (the bins restart from 0)
+  // wmcommon.hh:204-224: position 0 has weight 0) | the window after the transition is all zeros (the bins restart from 0) | the
+  // row lies in the padding of a padded clip (syncfinder.cc:583-585)
   unsigned long long zmask0 = 0, zmask1 = 0, rmask0 = 0, rmask1 = 0, skipmask = 0;
   auto publish_block = [&] (int t0) {
     const int tr = lane >> 2, jj = (lane & 3) * 2;
+    {
+      const bool need = t0 + tr + 1 < count, have_out = t0 + tr < count;
+#pragma unroll
+      for (int i = 0; i < FPL; i++)
+        {
+          f_in[i] = need ? f_in[i] : 0.f;
+          f_out[i] = have_out ? f_out[i] : 0.f;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < FPL; i++)
       {
@@ -2336,7 +2370,6 @@ sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
         const int total = __builtin_amdgcn_readlane (incl, 63);
         if (c == 0) { zmask0 = z; rmask0 = r; nz0 += total; } else { zmask1 = z; rmask1 = r; nz1 += total; }
       }
-    // rows of a padded clip inside the padding (syncfinder.cc:583-585): decided for the block's 16 offsets at once
     const long long idx = base + 8LL * (t0 + (lane >> 2));
     skipmask = __builtin_amdgcn_ballot_w64 ((lane & 3) == 0 && (((idx + 1024) * CV < sil_first) || (idx * CV > sil_last)));
   };
@@ -2344,13 +2377,16 @@ sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
   unsigned long long have_mask = 0;      // offsets 0..63
   bool have_64 = false;                  // offset 64 (a candidate has at most 65 fine offsets)
   float *const out_base = a.out + out_slot * a.out_stream_stride;
+  const int no_store = a.xcd_interleave & 8;                  // (measurement only: tools/gpu_k4s_alone.py)
 
+  // Order of a block's end: the NEXT block's differences are published first (their loads were issued a block of steps ago, and so
+  // were the previous flush's stores: the wait for the vector memory counter finds everything done), then the tile is flushed,
+  // then the loads of the block after next go out.
+  publish_block (0);
+  wave_sync();
+  fetch_block (1);
   for (int t0 = 0; t0 < count; t0 += SL_TILE)
     {
-      wave_sync();                                                // the previous block's tile and differences have been read
-      publish_block (t0);                                         // fetched one block of steps ago
-      wave_sync();
-      fetch_block (t0 / SL_TILE + 1);
       const int n_cols = count - t0 < SL_TILE ? count - t0 : SL_TILE;
       for (int col = 0; col < n_cols; col++)
         {
@@ -2454,20 +2490,58 @@ sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
           __builtin_amdgcn_sched_barrier (0);
 #pragma unroll
           for (int b = 0; b < 3; b++)
-            *reinterpret_cast<float *> (mem + tile_addr + 4 * b) = __fadd_rn (__fadd_rn (0.f, db[b]), other[b]);
-          tile_addr += tile_inc;
+            *reinterpret_cast<float *> (mem + tile_addr[b] + tile_col) = __fadd_rn (__fadd_rn (0.f, db[b]), other[b]);
+          tile_col += 4;
         }
-      // ---- flush the block's tile: row r of the output = band rowband[r], 16 offsets side by side
-      wave_sync();
-      {
-        const int cc = lane & 15;
-        float *out = out_base + t0;                               // (wave uniform: the stores take a 32 bit offset from it)
-        const unsigned ld = unsigned (a.ld);
-        if (cc < n_cols)
-          for (int row = lane >> 4; row < n_rows; row += 4)
-            out[unsigned (row) * ld + unsigned (cc)] = tile[cc * S4_ROW + 1 + rowband[row]];
-      }
-      tile_addr -= n_cols * tile_inc;
+      // Everything this wave has in flight in vector memory was issued a block of steps ago (the next block's samples, the previous
+      // flush's stores): waiting for it HERE costs nothing -- and tells the compiler so, which otherwise drains the counter at the
+      // worst place: behind the flush's stores, in front of the loads of the block after next.
+      __builtin_amdgcn_s_waitcnt (0x0f70);                        // vmcnt (0)
+      wave_sync();                                                // the block's columns are written, its differences have been read
+      const int t_end = t0 + n_cols;                              // offsets done so far
+      if (t_end < count)
+        publish_block (t_end);
+      // ---- flush: whole rows of 32 offsets (or what the stream has of them), 16 bytes per lane, eight lanes per 128 byte line
+      if (t_end % S4_FLUSH == 0 || t_end == count)
+        {
+          const int f0 = (t_end - 1) / S4_FLUSH * S4_FLUSH, cols = t_end - f0;     // the flush covers offsets f0 .. f0 + cols - 1
+          if (!no_store)
+            {
+              if (f0 == 64 && a.tail)
+                {
+                  // the 65th offset: ROWS values side by side in the compact array
+                  global_float *tl = uniform_global (a.tail + out_slot * a.tail_stream_stride);
+                  for (int row = lane; row < ROWS; row += 64)
+                    tl[unsigned (row)] = tile[row * S4_LD];
+                }
+              else
+                {
+                  const int c4 = (lane & 7) * 4;
+                  global_float *out = uniform_global (out_base + f0);                  // (the stores take a 32 bit offset from it)
+                  const unsigned ld = unsigned (a.ld);
+                  const bool vec = ((reinterpret_cast<uintptr_t> (out) | (ld * 4u)) & 15) == 0;
+                  for (int row = lane >> 3; row < ROWS; row += 8)
+                    {
+                      const float *src = tile + row * S4_LD + c4;
+                      const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
+                      global_float *dst = out + (unsigned (row) * ld + unsigned (c4));
+                      typedef float v4f __attribute__ ((ext_vector_type (4)));
+                      if (vec && c4 + 3 < cols)
+                        *(__attribute__ ((address_space (1))) v4f *) dst = (v4f) { v0, v1, v2, v3 };
+                      else
+                        {
+                          if (c4 + 0 < cols) dst[0] = v0;
+                          if (c4 + 1 < cols) dst[1] = v1;
+                          if (c4 + 2 < cols) dst[2] = v2;
+                          if (c4 + 3 < cols) dst[3] = v3;
+                        }
+                    }
+                }
+            }
+          tile_col = 0;
+          wave_sync();
+        }
+      fetch_block (t0 / SL_TILE + 2);
     }
   if (a.have && lane < count)
     a.have[out_slot * a.have_stream_stride + lane] = (have_mask >> lane) & 1;
@@ -2475,15 +2549,26 @@ sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
     a.have[out_slot * a.have_stream_stride + 64] = have_64;
 }
 
+// (gathered: 60 rows; rows = the 81 bands: awm_debug_sync_db_sliding_d and nothing else)
 __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
 sync_db_sliding4_kernel (DevTables t, SyncDbArgs a)
 {
-  sync_db_sliding4_body<false> (t, a);
+  sync_db_sliding4_body<false, 60> (t, a);
 }
 __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (4, 4)))
 sync_db_sliding4f_kernel (DevTables t, SyncDbArgs a)
 {
-  sync_db_sliding4_body<true> (t, a);
+  sync_db_sliding4_body<true, 60> (t, a);
+}
+__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (2, 3)))
+sync_db_sliding4_bands_kernel (DevTables t, SyncDbArgs a)
+{
+  sync_db_sliding4_body<false, NB> (t, a);
+}
+__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (2, 3)))
+sync_db_sliding4f_bands_kernel (DevTables t, SyncDbArgs a)
+{
+  sync_db_sliding4_body<true, NB> (t, a);
 }
 
 /* which form of K4s runs for stereo streams (awm_debug_set_refine_form; the result of 0, 3 and 4 is the same to the last bit):
@@ -2496,6 +2581,8 @@ extern "C" void awm_debug_set_refine_form (int form) { g_refine_form = (form == 
 extern "C" int  awm_debug_refine_form() { return g_refine_form; }
 extern "C" void awm_debug_set_sliding3 (int on) { g_refine_form = on ? 3 : 0; }     // (rounds 3 - 5's toggle, kept for tools/gpu_variants.py)
 
+bool sliding_rows_have_tail (int n_channels) { return n_channels == 2 && (g_refine_form == 4 || g_refine_form == 5); }
+
 hipError_t
 launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
 {
@@ -2504,10 +2591,14 @@ launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
   if (a.hop != 8 || a.count0 > 65 || a.per_channel || (a.n_channels != 1 && a.n_channels != 2))
     return hipErrorInvalidValue;
   const unsigned grid = unsigned ((a.n_streams + WAVES - 1) / WAVES);
-  if (a.n_channels == 2 && g_refine_form == 5)
+  if (a.n_channels == 2 && g_refine_form == 5 && a.band_pos)
     hipLaunchKernelGGL (sync_db_sliding4f_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
-  else if (a.n_channels == 2 && g_refine_form == 4)
+  else if (a.n_channels == 2 && g_refine_form == 5)
+    hipLaunchKernelGGL (sync_db_sliding4f_bands_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
+  else if (a.n_channels == 2 && g_refine_form == 4 && a.band_pos)
     hipLaunchKernelGGL (sync_db_sliding4_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
+  else if (a.n_channels == 2 && g_refine_form == 4)
+    hipLaunchKernelGGL (sync_db_sliding4_bands_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
   else if (a.n_channels == 2 && g_refine_form == 3)
     hipLaunchKernelGGL (sync_db_sliding3_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
   else if (a.n_channels == 2)
@@ -2662,19 +2753,25 @@ sync_scan_gathered_kernel (GatheredScanArgs a)
   const int bit = chain >> 1, down = chain & 1;
   const int R = a.rows_per_bit;
   const int ld = a.ld;
-  const float *p = a.db + plane * a.plane_stride + ((long long) bit * R * 60 + down * 30) * ld + cand;
-  const char *hv = HAVE ? a.have + plane * a.have_plane_stride + (long long) bit * R * ld + cand : nullptr;
+  // (forms 4 / 5 of K4s: a row holds fine offsets 0..63, offset 64 of every row lies in the compact `tail` array: the tail wave's
+  // lanes walk it with a stride of one value instead of a row)
+  const bool from_tail = a.tail && cand >= ld;
+  const long long step = from_tail ? 1 : ld;
+  const float *p = from_tail ? a.tail + plane * a.tail_plane_stride + ((long long) bit * R * 60 + down * 30)
+                             : a.db + plane * a.plane_stride + ((long long) bit * R * 60 + down * 30) * ld + cand;
+  const int hld = a.have_ld ? a.have_ld : ld;
+  const char *hv = HAVE ? a.have + plane * a.have_plane_stride + (long long) bit * R * hld + cand : nullptr;
 
   float mag = 0.f;
   int n = 0;
   auto issue = [&] (int r, float (&v)[30], bool& present) {
-    const float *q = p + (long long) r * 60 * ld;
-    present = HAVE ? hv[r * ld] != 0 : true;
+    const float *q = p + (long long) r * 60 * step;
+    present = HAVE ? hv[r * hld] != 0 : true;
     if (HAVE && !__any (present))
       return;                                             // nothing of this row is used by any candidate of the wave
 #pragma unroll
     for (int i = 0; i < 30; i++)
-      v[i] = q[i * ld];
+      v[i] = q[i * step];
   };
   auto accumulate = [&] (const float (&v)[30], bool present) {
     if (present)

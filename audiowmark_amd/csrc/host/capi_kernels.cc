@@ -784,12 +784,14 @@ awm_pcm_encode_d (awm_ctx *ctx, const float *in_d, size_t n_values, int bit_dept
   return 0;
 }
 
+static int g_k4s_ablate = 0;
+extern "C" void awm_debug_set_k4s_ablate (int f) { g_k4s_ablate = f; }
 int
 awm_debug_sync_db_sliding_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, const long long *base_d, size_t n_streams,
                              int count, int ld, float *out_d)
 {
   AWM_ENTER (ctx);
-  if (!pcm_d || !base_d || !out_d || count < 1 || count > 65 || ld < count || (n_channels != 1 && n_channels != 2))
+  if (!pcm_d || !base_d || !out_d || count < 1 || count > 65 || (ld < count && ld != 64) || (n_channels != 1 && n_channels != 2))
     {
       set_error ("awm_debug_sync_db_sliding_d: bad argument");
       return AWM_ERR_ARG;
@@ -808,6 +810,33 @@ awm_debug_sync_db_sliding_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, 
   da.first = 0;
   da.last = (long long) (n_frames * n_channels);
   da.tile_frames = ld;
+  da.xcd_interleave = g_k4s_ablate;
+  if (ld == 64)
+    {
+      // (measurement, tools/gpu_k4s_alone.py: the refinement's gathered layout with a synthetic table -- bands 0..59 are the rows --, rows
+      // of 64 offsets at out_d[i][60][64] and the 65th values behind them at out_d + n_streams * 60 * 64)
+      std::vector<unsigned char> pos (Params::n_bands, 255);
+      for (int b = 0; b < 60; b++)
+        pos[b] = (unsigned char) b;
+      if (int rc = ctx->ws_misc.reserve (Params::n_bands + sizeof (int))) return rc;
+      const int zero = 0;
+      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_misc.ptr, &zero, sizeof (int), hipMemcpyHostToDevice, ctx->stream));
+      AWM_HIP_CHECK (hipMemcpyAsync (ctx->ws_misc.as<char>() + sizeof (int), pos.data(), pos.size(), hipMemcpyHostToDevice, ctx->stream));
+      da.row_perm = ctx->ws_misc.as<int>();
+      da.band_pos = ctx->ws_misc.as<unsigned char>() + sizeof (int);
+      da.rows_per_plane = 1;
+      da.out_stream_stride = 60 * 64;
+      if (awmk::sliding_rows_have_tail (n_channels))
+        {
+          da.tail = out_d + n_streams * 60 * 64;
+          da.tail_stream_stride = 60;
+        }
+      else if (count > 64)
+        {
+          set_error ("awm_debug_sync_db_sliding_d: rows of 64 offsets take 65 only with forms 4 / 5");
+          return AWM_ERR_ARG;
+        }
+    }
   AWM_HIP_CHECK (awmk::launch_sync_db_sliding (ctx->stream, ctx->tabs, da));
   return 0;
 }

@@ -446,6 +446,7 @@ SyncFinder::search_refine (KeyTables *kt, const DeviceWav& wav, Mode mode, std::
 
 namespace {
 constexpr int REFINE_TP = 72;            // padded fine-offset axis (<= 65 used)
+constexpr int REFINE_TP_LINES = 64;      // ... of the rows K4s writes in forms 4 / 5 (fine offset 64 apart: SyncDbArgs::tail)
 constexpr int REFINE_QS = 128;
 }
 
@@ -462,11 +463,14 @@ SyncFinder::refine_launch (KeyTables *kt, const DeviceWav& wav, Mode mode, Searc
     return 0;
   const bool gathered = wav.n_channels <= 2;
   const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
-  const size_t per_cand = size_t (NW) * row_values * REFINE_TP;
+  // (K4s forms 4 / 5: rows of 64 fine offsets = two whole cache lines, the 65th value of every row in a compact array behind the rows)
+  const bool tail_layout = gathered && awmk::sliding_rows_have_tail (wav.n_channels);
+  const size_t per_cand = size_t (NW) * row_values * (tail_layout ? REFINE_TP_LINES : REFINE_TP);
+  const size_t tail_per_cand = tail_layout ? size_t (NW) * row_values : 0;
   // <= 3 GiB of dB rows at a time (a group of clips: 12 GiB, every further batch is one more wait for the whole group)
   size_t batch = std::max<size_t> (1, (size_t (job.slice_frames ? 12 : 3) << 30) / (per_cand * sizeof (float)));
   batch = std::min (batch, n_cand);
-  if (int rc = m_lane->ws_refine.reserve (batch * per_cand * sizeof (float))) return rc;
+  if (int rc = m_lane->ws_refine.reserve (batch * (per_cand + tail_per_cand) * sizeof (float))) return rc;
   if (int rc = m_lane->ws_refine_have.reserve (batch * NW * REFINE_TP)) return rc;
   if (int rc = m_lane->ws_q.reserve (batch * (REFINE_QS * sizeof (double) + awmk::GATHERED_SCRATCH_BYTES_PER_PLANE))) return rc;    // qualities, then K5g's chain sums
   if (int rc = m_lane->ws_idx.reserve (batch * NW * (sizeof (long long) + sizeof (int)) + 2 * batch * sizeof (int))) return rc;
@@ -488,12 +492,16 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
   const auto& sync = kt->sync[clip];
   const int NW = kt->slices ? kt->want_rows_of_slices() : int (sync.want_list.size());
   const long long total = total_frames (mode);
-  const int TP = REFINE_TP, QS = REFINE_QS;
+  const int QS = REFINE_QS;
   hipStream_t st = m_lane->stream;
   const bool gathered = wav.n_channels <= 2;
   const int row_values = gathered ? 2 * int (Params::bands_per_frame) : Params::n_bands;
+  const bool tail_layout = gathered && awmk::sliding_rows_have_tail (wav.n_channels);
+  const int TP = tail_layout ? REFINE_TP_LINES : REFINE_TP;           // row length of the dB rows
+  const int HP = REFINE_TP;                                           // ... of the have flags
   const size_t per_cand = size_t (NW) * row_values * TP;
-  (void) batch;
+  const size_t tail_per_cand = tail_layout ? size_t (NW) * row_values : 0;
+  float *const d_tail = tail_layout ? m_lane->ws_refine.as<float>() + batch * per_cand : nullptr;   // (behind the rows of a full batch)
 
   // stream tables: [nb * NW] long long base, [nb * NW] int count, [nb] int lanes, [nb] int slice -- one page-locked block, one copy
   const size_t in_bytes = nb * NW * (sizeof (long long) + sizeof (int)) + 2 * nb * sizeof (int);
@@ -570,8 +578,10 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           da.rows_per_plane = NW;
         }
       da.ld = TP;
+      da.tail = d_tail;
+      da.tail_stream_stride = row_values;
       da.have = m_lane->ws_refine_have.as<char>();
-      da.have_stream_stride = TP;
+      da.have_stream_stride = HP;
       da.first = (long long) m_first;
       da.last = (long long) m_last;
       if (slices)
@@ -595,8 +605,11 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           ga.db = m_lane->ws_refine.as<float>();
           ga.have = clip ? m_lane->ws_refine_have.as<char>() : nullptr;
           ga.plane_stride = (long long) per_cand;
-          ga.have_plane_stride = (long long) NW * TP;
+          ga.have_plane_stride = (long long) NW * HP;
           ga.ld = TP;
+          ga.have_ld = HP;
+          ga.tail = d_tail;
+          ga.tail_plane_stride = (long long) tail_per_cand;
           ga.rows_per_bit = sync.host.rows_per_bit;
           ga.n_lanes = max_count;
           ga.lane_count = d_lanes;
@@ -615,10 +628,10 @@ SyncFinder::refine_batch_launch (KeyTables *kt, const DeviceWav& wav, Mode mode,
           sa.db = m_lane->ws_refine.as<float>();
           sa.have = clip ? m_lane->ws_refine_have.as<char>() : nullptr;
           sa.plane_stride = (long long) per_cand;
-          sa.have_plane_stride = (long long) NW * TP;
+          sa.have_plane_stride = (long long) NW * HP;
           sa.row_stride = (long long) Params::n_bands * TP;
           sa.band_stride = TP;
-          sa.have_row_stride = TP;
+          sa.have_row_stride = HP;
           sa.n_lanes = max_count;
           sa.lane_count = d_lanes;
           sa.n_planes = (long long) nb;

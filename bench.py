@@ -76,8 +76,8 @@ KERNELS = {
     "sync_db_kernel(approx)": ("sync_db_kernel<2, false, 33>", "FP32 issue and LDS round trips in turn (VALU issues 55 - 60 % of the time; both channels' transforms pipelined over one LDS tile; the 4 shifts of a tile share one XCD's L2: PCM read once)"),
     "sync_scan_kernel(approx)": ("sync_scan_stream_kernel<false>", "works out of LDS, not HBM: 30 ds_read_b128 gathers + 120 float additions per sync frame and wave in the reference's summation order (LDS active 51 %, VALU issuing 42 % of the cycles); 3.3 rounds of tiles"),
     "local_mean_kernel": ("local_mean_kernel", "latency"),
-    "sync_db_kernel(refine)": ("sync_db_sliding3_kernel", "VALU issue (a third of it FP64) + sequential recurrence (65 steps per wave); three bins of one channel per lane, 56 of 64 lanes busy"),
-    "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (300 single-wave workgroups, 60 loads in flight each)"),
+    "sync_db_kernel(refine)": ("sync_db_sliding4_kernel", "VALU issue (half of it FP64: 69 of ~115 instructions per wave and fine offset) + the first transform in double per row (a third of the duration); three bins of one channel per lane, 56 of 64 lanes busy, 3 waves / SIMD"),
+    "sync_scan_kernel(refine)": ("sync_scan_gathered_kernel<false>", "HBM latency (300 single-wave workgroups, 60 loads in flight each; rows of 64 offsets = two whole cache lines)"),
     "sync_db_kernel(block)": ("sync_db_kernel<2, true, 33>", "FP32 issue and LDS round trips in turn"),
     "soft_bits_kernel": ("soft_bits_wave_kernel", "latency of scattered reads + sequential double precision sums (four bits per wave)"),
     "resample_kernel": ("resample_phase_kernel<147, 160, 18> / <160, 147, 16> (stereo 48 <-> 44.1 kHz) | resample_kernel",

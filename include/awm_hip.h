@@ -421,8 +421,11 @@ void awm_debug_set_sliding3 (int on);          /* (rounds 3 - 5: refine form 3 /
  *      FFT, which is what the reference's FFTW is; NOT bit-identical to 4 -- gated by the census in DESIGN.md section 4 */
 void awm_debug_set_refine_form (int form);
 int  awm_debug_refine_form (void);
+void awm_debug_set_k4s_ablate (int flags);     /* measurement only (tools/gpu_k4s_alone.py): 8 = awm_debug_sync_db_sliding_d runs forms 4 / 5 without their stores */
 /* K4s alone on resident PCM (stereo or mono): stream i = `count` (<= 65) windows of 1024 samples starting at base_d[i] + 8 o; writes
- * out_d[i][band 0..80][ld] (dB summed over the channels) in the form in force.  For the tests that pin forms 0 / 3 / 4 against each other. */
+ * out_d[i][band 0..80][ld] (dB summed over the channels) in the form in force.  For the tests that pin forms 0 / 3 / 4 against each other.
+ * ld = 64 (measurement): the refinement's gathered layout with a synthetic table instead (bands 0..59 are the rows): out_d[i][60][64], and with
+ * forms 4 / 5 the 65th values at out_d + n_streams * 60 * 64 (n_streams * 60 floats more). */
 int  awm_debug_sync_db_sliding_d (awm_ctx *ctx, const float *pcm_d, size_t n_frames, int n_channels, const long long *base_d, size_t n_streams,
                                   int count, int ld, float *out_d);
 void awm_debug_set_soft_bits_generic (int on); /* K7: one thread per soft bit for every shape (the fallback kernel) | four bits per wave */
