@@ -438,6 +438,39 @@ fft512_forward_d (double2 (&z)[8], double2 *xbuf, const double2 *tw512, int lane
   radix8_fwd_d (z);
 }
 
+// the same transform with the lane's two sets of twiddle factors handed in (tw1[kb - 1] = tw512[lane * kb], tw2[kd - 1] =
+// tw512[8 * (lane & 7) * kd]): a caller that transforms several channels reads them once.  Same operations in the same order.
+__device__ __forceinline__ void
+fft512_forward_d (double2 (&z)[8], double2 *xbuf, const double2 (&tw1)[7], const double2 (&tw2)[7], int lane)
+{
+  radix8_fwd_d (z);
+#pragma unroll
+  for (int kb = 1; kb < 8; kb++)
+    z[kb] = cmuld (z[kb], tw1[kb - 1]);
+#pragma unroll
+  for (int kb = 0; kb < 8; kb++)
+    xbuf[kb * XROW + lane] = z[kb];
+  wave_sync();
+  const int lo = lane & 7, hi = lane >> 3;
+#pragma unroll
+  for (int nd = 0; nd < 8; nd++)
+    z[nd] = xbuf[hi * XROW + nd * 8 + lo];
+  wave_sync();
+  radix8_fwd_d (z);
+#pragma unroll
+  for (int kd = 1; kd < 8; kd++)
+    z[kd] = cmuld (z[kd], tw2[kd - 1]);
+#pragma unroll
+  for (int kd = 0; kd < 8; kd++)
+    xbuf[hi * XROW + 9 * kd + lo] = z[kd];
+  wave_sync();
+#pragma unroll
+  for (int nc = 0; nc < 8; nc++)
+    z[nc] = xbuf[hi * XROW + 9 * lo + nc];
+  wave_sync();
+  radix8_fwd_d (z);
+}
+
 __device__ __forceinline__ double2
 real_split_d (double2 zk, double2 zm, double2 w)
 {

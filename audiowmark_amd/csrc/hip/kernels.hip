@@ -2222,43 +2222,63 @@ sync_db_sliding4_body (const DevTables& t, const SyncDbArgs& a)
   const int li = active ? (lane & 31) : 0;                     // (idle lanes ride along with the bins of their channel's first lane)
   const int kA = 19 + 3 * li;
 
-  // ---- first offset: plain (unwindowed) DFT bins from the wave FFT, in double (see sync_db_sliding_kernel), scaled by 2^-10
+  // ---- first offset: plain (unwindowed) DFT bins from the wave FFT, in double (see sync_db_sliding_kernel), scaled by 2^-10.
+  // Both channels' samples come with one set of wide loads, the transform's twiddle factors are read once for both, the non-zero
+  // counts are ballots (scalar population counts: no trips through the LDS crossbar).
   double2 R[3];
   int nz0 = 0, nz1 = 0;                                        // non-zero samples of the current window, per channel (wave uniform)
+  {
+    float in[CV][16];
+    fetch_stereo (a.pcm, base, 1024, lane, in[0], in[1]);
+    // (at four waves per SIMD -- the float form -- there is no room for the 56 registers of the two twiddle sets: read per channel)
+    double2 tw1[U32 ? 1 : 7], tw2[U32 ? 1 : 7], ws[3];
+    if constexpr (!U32)
+      {
 #pragma unroll
-  for (int c = 0; c < CV; c++)
-    {
-      float in[16];
-      fetch_channel (a.pcm, base, 1024, CV, c, lane, in);
-      int cnt = 0;
+        for (int k = 1; k < 8; k++)
+          {
+            tw1[k - 1] = t.tw512d[lane * k];
+            tw2[k - 1] = t.tw512d[8 * (lane & 7) * k];
+          }
+      }
 #pragma unroll
-      for (int j = 0; j < 16; j++)
-        cnt += in[j] != 0.f;
-      for (int o = 32; o > 0; o >>= 1)
-        cnt += __shfl_xor (cnt, o);
-      (c == 0 ? nz0 : nz1) = __builtin_amdgcn_readfirstlane (cnt);
-      double2 z[8];
+    for (int b = 0; b < 3; b++)
+      ws[b] = t.slide[(kA + b - 19) * 9 + 1];
 #pragma unroll
-      for (int j = 0; j < 8; j++)
-        z[j] = make_double2 (double (in[2 * j]), double (in[2 * j + 1]));
-      fft512_forward_d (z, xbuf, t.tw512d, lane);
-      xbuf[0 * 64 + lane] = z[0];
-      xbuf[1 * 64 + lane] = z[1];
-      xbuf[6 * 64 + lane] = z[6];
-      xbuf[7 * 64 + lane] = z[7];
-      wave_sync();
-      if (ch == c)
-        {
+    for (int j = 0; j < 16; j++)
+      {
+        nz0 += __builtin_popcountll (__builtin_amdgcn_ballot_w64 (in[0][j] != 0.f));
+        nz1 += __builtin_popcountll (__builtin_amdgcn_ballot_w64 (in[1][j] != 0.f));
+      }
 #pragma unroll
-          for (int b = 0; b < 3; b++)
-            {
-              const int k = kA + b;
-              const double2 r = real_split_d (xbuf[zpos (k)], xbuf[zpos (512 - k)], t.slide[(k - 19) * 9 + 1]);
-              R[b] = make_double2 (r.x * 0x1p-10, r.y * 0x1p-10);
-            }
-        }
-      wave_sync();
-    }
+    for (int c = 0; c < CV; c++)
+      {
+        double2 z[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+          z[j] = make_double2 (double (in[c][2 * j]), double (in[c][2 * j + 1]));
+        if constexpr (U32)
+          fft512_forward_d (z, xbuf, t.tw512d, lane);
+        else
+          fft512_forward_d (z, xbuf, tw1, tw2, lane);
+        xbuf[0 * 64 + lane] = z[0];
+        xbuf[1 * 64 + lane] = z[1];
+        xbuf[6 * 64 + lane] = z[6];
+        xbuf[7 * 64 + lane] = z[7];
+        wave_sync();
+        if (ch == c)
+          {
+#pragma unroll
+            for (int b = 0; b < 3; b++)
+              {
+                const int k = kA + b;
+                const double2 r = real_split_d (xbuf[zpos (k)], xbuf[zpos (512 - k)], ws[b]);
+                R[b] = make_double2 (r.x * 0x1p-10, r.y * 0x1p-10);
+              }
+          }
+        wave_sync();
+      }
+  }
   // ---- the lane's constants
   int k_tab = kA - 19;
   asm volatile ("" : "+v" (k_tab));                           // keep the tables' registers out of the transform above (no hoisting)

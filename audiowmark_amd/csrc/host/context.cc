@@ -626,16 +626,20 @@ ctx_create (int device, bool own_stream, hipStream_t given, awm_ctx **ctx_out)
     }
   AWM_HIP_CHECK (hipSetDevice (device));
   {
-    // the code object holds gfx950 code only, and several kernels need its 160 KB of LDS per workgroup: say so here instead of
-    // failing at the first launch
+    // the code object holds gfx950 code only: say so here instead of failing at the first launch.  (The architecture name is the
+    // test; what a runtime release reports as sharedMemPerBlock is not -- some report the 64 KB default instead of the 160 KB a
+    // gfx950 workgroup may ask for -- so a small figure there is only worth a warning.)
     hipDeviceProp_t prop;
     AWM_HIP_CHECK (hipGetDeviceProperties (&prop, device));
-    if (std::strncmp (prop.gcnArchName, "gfx950", 6) != 0 || prop.sharedMemPerBlock < size_t (160) * 1024)
+    if (std::strncmp (prop.gcnArchName, "gfx950", 6) != 0)
       {
-        set_error (std::string ("device ") + std::to_string (device) + " is " + prop.gcnArchName + " with " + std::to_string (prop.sharedMemPerBlock)
-                   + " bytes of LDS per workgroup; this library is built for gfx950 (MI355X, 160 KB) only");
+        set_error (std::string ("device ") + std::to_string (device) + " is " + prop.gcnArchName + "; this library is built for gfx950 (MI355X) only");
         return AWM_ERR_NO_DEVICE;
       }
+    static std::atomic<bool> warned { false };
+    if (prop.sharedMemPerBlock < size_t (160) * 1024 && !warned.exchange (true))
+      warning ("audiowmark: device %d reports %zu bytes of LDS per workgroup (a gfx950 has 160 KB: K5w and the key table kernels use them)\n",
+               device, size_t (prop.sharedMemPerBlock));
   }
   auto ctx = std::make_unique<awm_ctx>();
   ctx->device = device;
@@ -720,6 +724,40 @@ awm_ctx_set_chunk_lanes (awm_ctx *ctx, int n_lanes)
   if (!ctx || n_lanes < 1)
     return AWM_ERR_ARG;
   ctx->chunk_lanes = std::min (n_lanes, awm::CHUNK_LANES);
+  return 0;
+}
+
+/* Give back what the context keeps between calls for speed: the workspaces of its lanes, the file level staging rings (page-locked
+ * tiles + their device twins) and the whole-stream PCM buffer of the file level `get` -- about 1.3 GB per hour of the longest file
+ * seen so far.  Key tables, the constant tables and the streams stay; the next call allocates what it needs again. */
+int
+awm_ctx_trim (awm_ctx *ctx)
+{
+  if (!ctx)
+    return AWM_ERR_ARG;
+  AWM_HIP_CHECK (hipSetDevice (ctx->device));
+  AWM_HIP_CHECK (hipStreamSynchronize (ctx->stream));
+  for (auto& l : ctx->extra_lanes)
+    if (l)
+      {
+        if (l->stream)
+          AWM_HIP_CHECK (hipStreamSynchronize (l->stream));
+        l->release_lane();
+      }
+  if (ctx->copy_stream)
+    AWM_HIP_CHECK (hipStreamSynchronize (ctx->copy_stream));
+  ctx->release_lane();
+  ctx->file_staging.release();
+  awm::speed_workspace_free (ctx);
+  ctx->ws_add_batch.release();
+  ctx->pin_add_batch.release();
+  ctx->ws_merge_soft.release();
+  ctx->ws_rate_a.release();
+  ctx->ws_rate_b.release();
+  ctx->ws_rate_c.release();
+  for (awm_ctx *h : ctx->helpers)
+    if (h && h != ctx)
+      if (int rc = awm_ctx_trim (h)) return rc;
   return 0;
 }
 

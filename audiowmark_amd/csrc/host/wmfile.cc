@@ -361,7 +361,8 @@ public:
     if (m_region && m_consumed)
       m_in->raw_region_consume (m_consumed);
     if (copy)
-      (void) hipStreamSynchronize (copy);               // (the rings stay with the context; nothing of this call may still use them)
+      (void) hipStreamSynchronize (copy);               // (the rings stay with the context; nothing of this call may still use them:
+    (void) hipStreamSynchronize (m_ctx->stream);        //  on an error return sample decodes of this call may still be queued)
   }
   size_t announced_frames() const { return m_region ? m_total_frames : m_in->n_frames(); }
   unsigned char *host (int slot) { return m_slots[slot].host; }
@@ -777,7 +778,8 @@ struct OutputStage
   {
     writer.reset();
     if (copy)
-      (void) hipStreamSynchronize (copy);                 // (the ring stays with the context)
+      (void) hipStreamSynchronize (copy);                 // (the ring stays with the context: on an error return encodes of this call
+    (void) hipStreamSynchronize (ctx->stream);            //  may still be queued on the compute stream)
   }
   /* n_frames <= chunk_frames of finished float32 samples at d_pcm (produced on ctx->stream) */
   bool

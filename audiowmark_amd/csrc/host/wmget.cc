@@ -1692,9 +1692,13 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
       keys.push_back ((*clip_keys)[which[g0 + i]]);
     return keys;
   };
+  // a group: up to CLIP_GROUP clips with the same number of channels (the slices of a group are equal) -- and, with the tables of all
+  // keys built first, with consecutive table slots (a group cut short by a change of channels would otherwise let the next one reach
+  // across two strides of the lane's share of the slots)
   auto group_size = [&] (size_t g0) {
     size_t gn = 0;
-    while (g0 + gn < which.size() && gn < size_t (CLIP_GROUP) && clips[which[g0 + gn]].n_channels == clips[which[g0]].n_channels)
+    while (g0 + gn < which.size() && gn < size_t (CLIP_GROUP) && clips[which[g0 + gn]].n_channels == clips[which[g0]].n_channels
+           && (!(clip_keys && all_tables) || (*slot_of_clip)[which[g0 + gn]] == (*slot_of_clip)[which[g0]] + int (gn)))
       gn++;
     return gn;
   };
@@ -1722,11 +1726,8 @@ clip_batch_staged (awm_ctx *ctx, WorkLane *lane, const std::vector<Key>& key_lis
   size_t group_index = 0;
   for (size_t g0 = 0; g0 < which.size(); group_index++)
     {
-      // a group: up to CLIP_GROUP clips with the same number of channels (the slices of a group are equal)
       const int C = clips[which[g0]].n_channels;
-      size_t gn = 0;
-      while (g0 + gn < which.size() && gn < size_t (CLIP_GROUP) && clips[which[g0 + gn]].n_channels == C)
-        gn++;
+      const size_t gn = group_size (g0);
       const size_t n = (count + 5) * Params::frame_size * C;                       // in values
       const size_t slice_values = 3 * n;                                            // pad_start + len + n with pad_start = n + (n - len)
       const size_t slice_frames = slice_values / C;

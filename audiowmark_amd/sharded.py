@@ -80,6 +80,9 @@ class TorchComm:
         self.nccl = dist.get_backend() == "nccl"
         self.device = device
         self.error = None
+        # what this rank has sent since the last reset_stats(): bytes and rounds, device records (samples, scores: over xGMI with nccl) and
+        # host records apart, and the max-reductions (bench.py: config.shard_plan)
+        self.stats = {"device_bytes_sent": 0, "device_rounds": 0, "host_bytes_sent": 0, "host_rounds": 0, "max_reductions": 0, "max_reduction_bytes": 0}
         # The protocol's host-side records (refined scores, soft bits, pattern lists: a few KB per round, six rounds per `get`) over RCCL
         # would each be staged through device memory with two blocking copies; a second group over gloo (the same ranks, loopback / the
         # launcher's rendezvous address) carries them as they are.  Every rank creates it (new_group is collective); if that fails
@@ -119,8 +122,15 @@ class TorchComm:
         # (the null stream has handle 0: torch's default stream of the device is that stream)
         return self.torch.cuda.ExternalStream(h, device=self.device) if h else self.torch.cuda.default_stream(self.device)
 
+    def reset_stats(self):
+        for k in self.stats:
+            self.stats[k] = 0
+
     def _exchange(self, on_device, user, n_send, send, send_bytes, send_to, n_recv, recv, recv_bytes, recv_from):
         try:
+            kind = "device" if on_device else "host"
+            self.stats[kind + "_bytes_sent"] += sum(int(send_bytes[i]) for i in range(n_send))
+            self.stats[kind + "_rounds"] += 1
             stream = self._ctx_stream()
             if stream is None:
                 return self._exchange_on_current(on_device, n_send, send, send_bytes, send_to, n_recv, recv, recv_bytes, recv_from, False)
@@ -176,6 +186,8 @@ class TorchComm:
 
     def _reduce(self, user, data, n):
         try:
+            self.stats["max_reductions"] += 1
+            self.stats["max_reduction_bytes"] += int(n) * 4
             torch, dist = self.torch, self.dist
             stream = self._ctx_stream()
             # non-negative floats order like their bit patterns: max of the words

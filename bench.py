@@ -642,6 +642,8 @@ def main():
     t0 = time.perf_counter()
     pats = None
     for i in range(args.steps):
+        if i == args.steps - 1 and sharded_path and args.config != "clips":
+            pipe.comm.reset_stats()
         pats = step()
     sync()
     elapsed = time.perf_counter() - t0
@@ -659,6 +661,32 @@ def main():
         matches_local = int(t[1].item())
         ranks_seen = int(t[2].item())
 
+    # one stream over several ranks: what every rank held, worked on and sent in the LAST timed step, so that a scaling curve explains
+    # itself (plan: awm_sharded_plan, pure host; bytes: counted by the transport)
+    shard_plan = None
+    if sharded_path and args.config != "clips":
+        from audiowmark_amd import sharded as _sh
+        lengths = list(pipe.part.lengths)
+        entries = _sh.plan(lengths)
+        per_chunk = {}
+        for c, r, _, k in entries:
+            if k:
+                per_chunk.setdefault(c, set()).add(r)
+        mine_stats = dict(pipe.comm.stats)
+        rows = [None] * world
+        if dist is not None and world > 1:
+            dist.all_gather_object(rows, mine_stats)
+        else:
+            rows = [mine_stats]
+        shard_plan = {"span_frames": lengths, "chunks": len(per_chunk),
+                      "chunks_shared_by_several_ranks": sum(1 for v in per_chunk.values() if len(v) > 1),
+                      "per_rank": [{"rank": r, "span_seconds": round(lengths[r] / RATE, 1),
+                                    "start_frames": sum(k for _, rr, _, k in entries if rr == r),
+                                    "chunks_local": sum(1 for v in per_chunk.values() if v == {r}),
+                                    "chunks_shared": sum(1 for v in per_chunk.values() if r in v and len(v) > 1),
+                                    "sent_in_the_last_step": rows[r]} for r in range(world)],
+                      "transport": "RCCL (device records) + gloo side group (host records)" if pipe.comm.nccl and pipe.comm.host_group is not None
+                                   else ("RCCL" if pipe.comm.nccl else "gloo")}
     single_stream = args.config == "60min" and world == 1 and not args.sharded
     prof = read_prof(awm, ctx)
     two_calls_ms = None
@@ -744,6 +772,8 @@ def main():
                    (" -- DEBUG: all ranks on ONE device over gloo (--same-device), not a scaling measurement" if args.same_device else ""),
                    "patterns": len(pats or []), "payload_matches": matches}
         cfg["ranks_seen"] = ranks_seen
+        if shard_plan is not None:
+            cfg["shard_plan"] = shard_plan
         if dist is not None:
             try:
                 cfg["rccl_version"] = ".".join(str(v) for v in torch.cuda.nccl.version())

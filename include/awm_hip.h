@@ -47,6 +47,11 @@ int   awm_ctx_create (int device, awm_ctx **ctx_out);
  * (every HIP stream costs ~190 MB of resident host memory on this runtime: the command line uses this) */
 int   awm_ctx_create_on_stream (int device, void *hip_stream, awm_ctx **ctx_out);
 void  awm_ctx_destroy (awm_ctx *ctx);
+/* A context keeps its workspaces between calls (a call's set-up is then ~1.5 ms instead of 20 - 25): the lanes' scratch buffers, the
+ * file level staging rings (4 + 4 page-locked tiles of up to 32 MiB and their device twins) and the float32 PCM of the longest stream the
+ * file level `get` has decoded (1.3 GB per hour).  awm_ctx_trim gives all of that back (also for the context's helpers); key tables and
+ * streams stay.  For long-lived services after an unusually long file. */
+int   awm_ctx_trim (awm_ctx *ctx);
 int   awm_ctx_device (const awm_ctx *ctx);
 int   awm_ctx_synchronize (awm_ctx *ctx);
 /* opaque hipStream_t of the context (for callers that bracket work with HIP events) */
@@ -455,7 +460,8 @@ void awm_debug_set_clip_poison (int on);    /* clip batches: the padded slices a
                                             * frames of zeros on either side, not the rest of the padding: a consumer that read further would change its result) */
 void awm_debug_set_clip_pad_margin (int frames); /* clip batches: frames of zeros written on either side of a clip (default and minimum 2048; one slice = 6693 frames
                                             * or more: whole slices, the A side of the measurement in tools/gpu_clip_margin_ab.py) */
-void awm_debug_set_staged_threads (int n);  /* clip batches: host threads (= lanes) working on groups of clips; 0 = default (4 with one key, 2 with a key per clip) */
+void awm_debug_set_staged_threads (int n);  /* clip batches: host threads (= lanes) working on groups of clips; 0 = default (4; 2 with a key per clip only where the
+                                            * tables cannot come from the device and host threads build them) */
 void awm_debug_clip_key_timing (double us_out[3]); /* get with a key per clip, summed over the batch's host threads since the last call: [0] microseconds waiting for
                                             * a group's key tables (built on host threads one group ahead), [1] packing + uploading them, [2] groups */
 double awm_debug_time_group_key_tables (int n_keys, int threads); /* host only: wall milliseconds the key tables of one group of n_keys clips take to build

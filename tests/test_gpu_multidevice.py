@@ -182,6 +182,10 @@ def test_bench_two_gpus_over_rccl():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["ranks_seen"] == 2 and line["value"] > 0
     assert line["config"]["payload_matches"] >= 200                      # 2 h of audio: 139 blocks + AB pairs + the chunks' "all" patterns
+    assert line["config"].get("rccl_version"), "the two ranks must have talked over RCCL"
+    plan = line["config"]["shard_plan"]                                  # what every rank held, worked on and sent (the last timed step)
+    assert len(plan["per_rank"]) == 2 and plan["chunks_shared_by_several_ranks"] >= 1 and "RCCL" in plan["transport"]
+    assert all(r["start_frames"] > 0 and r["sent_in_the_last_step"]["device_bytes_sent"] > 0 for r in plan["per_rank"])
 
 
 @needs_two

@@ -67,7 +67,9 @@ def main():
     assert _ref.available(), "oracle/_ref is not built"
     import glob
     recorded = {}
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r05", "ref_backend_census_scores*.json"))):     # (every batch of the census)
+    # (every batch of the census: round 5's noise kinds, round 6's harmonic / bursts / clipped / dc_offset; AWM_CENSUS_GLOB narrows it)
+    pattern = os.environ.get("AWM_CENSUS_GLOB", "r0[56]/ref_backend_census_scores*.json")
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern))):
         with open(path) as f:
             recorded.update({(r["kind"], r["piece"]): r for r in json.load(f)})
     items = [k for k in recorded if k[0] != "testgen_8h"]

@@ -14,8 +14,16 @@ Material, every piece 30 minutes of stereo 44.1 kHz, watermarked by the referenc
      numpy's PCG64 with a seed per piece (so tools/gpu_census_three_way.py regenerates the same bytes on the GPU box).
 Both backends run `SyncFinder::search` (BLOCK mode) on every piece; every sync score pair is compared.
 
-  python tools/ref_backend_census.py [pieces per synthetic kind = 8] [workers = 6] [skip_8h = 0] [first piece = 0]
-      -> profiles/r05/ref_backend_census.json  (summary + every differing position + the complete score lists of both backends)
+  python tools/ref_backend_census.py [pieces per synthetic kind = 8] [workers = 6] [skip_8h = 0] [first piece = 0] [kinds = noise] [dir = r05]
+      -> profiles/<dir>/ref_backend_census.json  (summary + every differing position + the complete score lists of both backends)
+
+Round 6 adds material that is NOT stationary noise (kinds = other): where `mag > 1e-7` (wmadd.cc:64-84), `umag == 0 || dmag == 0`
+(syncfinder.cc:101) and exactly zero power (wmcommon.hh:207-214) fire in bulk and the limiter works in every block:
+   * "harmonic": stacks of 30 harmonics (1 / h) on slow chirps between 110 and 440 Hz, another chirp per channel: a sparse spectrum,
+   * "bursts": speech-like bursts of low-passed noise (0.2 - 1.5 s, raised-cosine edges, a level per burst) with DIGITAL SILENCE between them,
+   * "clipped": white noise three times over full scale, hard clipped: two thirds of the samples sit on the rails, the limiter never rests,
+   * "dc_offset": a constant 0.25 with white noise at -60 dB on it.
+      -> profiles/r06/ref_backend_census_other.json, ref_backend_census_scores_other.json
 """
 import concurrent.futures
 import hashlib
@@ -33,6 +41,8 @@ PAY = "0123456789abcdef0011223344556677"
 RATE = 44100
 PIECE = 30 * 60 * RATE                       # frames per piece
 KINDS = ("white", "pink", "lowpass_3k", "white_minus_40dB")
+KINDS_OTHER = ("harmonic", "bursts", "clipped", "dc_offset")
+ALL_KINDS = KINDS + KINDS_OTHER
 SHM = "/dev/shm/awm_census_8h.i16"
 
 
@@ -52,10 +62,61 @@ def shaped(x, amp_of_f):
     return out * np.float32(0.5 / float(np.abs(out).max()))
 
 
+def harmonic(rng, n):
+    """two channels of harmonic stacks on slow chirps (float64 phase carried from block to block; sin (h theta) by the Chebyshev recurrence)"""
+    out = np.empty((n, 2), np.float32)
+    B = 1 << 22
+    for c in range(2):
+        period = 97.0 + 16.0 * c + float(rng.random()) * 5.0
+        phi = float(rng.random()) * 6.28
+        phase0 = 0.0
+        for a in range(0, n, B):
+            t = np.arange(a, min(n, a + B), dtype=np.float64) / RATE
+            f0 = 110.0 * 2.0 ** (1.0 + np.sin(2 * np.pi * t / period + phi))                          # 110 .. 440 Hz
+            theta = phase0 + 2 * np.pi * np.cumsum(f0) / RATE
+            phase0 = float(theta[-1]) % (2 * np.pi)
+            c1, s_prev, s_cur = 2.0 * np.cos(theta), np.zeros(len(t)), np.sin(theta)
+            acc = s_cur.copy()
+            for h in range(2, 31):
+                s_prev, s_cur = s_cur, c1 * s_cur - s_prev
+                acc += s_cur * (np.where(h * f0 < 20000.0, 1.0, 0.0) / h)
+            out[a:a + B, c] = (acc * 0.28).astype(np.float32)                                         # (sum of 1 / h sines stays below 1.8)
+    return out
+
+
+def bursts(rng, n):
+    """bursts of low-passed noise with digital silence between them, the same envelope in both channels"""
+    x = rng.random((n, 2), dtype=np.float32) * np.float32(2) - np.float32(1)
+    x = shaped(x, lambda f: 1.0 / (1.0 + (f / 1500.0) ** 2))
+    env = np.zeros(n, np.float32)
+    pos = int(0.3 * RATE)
+    edge = int(0.010 * RATE)
+    ramp = (0.5 - 0.5 * np.cos(np.pi * np.arange(edge) / edge)).astype(np.float32)
+    while pos < n:
+        length = int((0.2 + 1.3 * float(rng.random())) * RATE)
+        level = np.float32(0.1 + 0.8 * float(rng.random()))
+        a, b = pos, min(n, pos + length)
+        seg = np.full(b - a, level, np.float32)
+        k = min(edge, (b - a) // 2)
+        seg[:k] *= ramp[:k]
+        seg[len(seg) - k:] *= ramp[:k][::-1]
+        env[a:b] = seg
+        pos = b + int((0.1 + 0.7 * float(rng.random())) * RATE)
+    return (x * (np.float32(2.0) * env)[:, None]).astype(np.float32)
+
+
 def material(kind, piece, n=PIECE):
     """deterministic: numpy PCG64 seeded by (kind, piece); the same bytes wherever numpy 2.x runs"""
-    rng = np.random.Generator(np.random.PCG64(1000 * (KINDS.index(kind) + 1) + piece))
+    rng = np.random.Generator(np.random.PCG64(1000 * (ALL_KINDS.index(kind) + 1) + piece))
+    if kind == "harmonic":
+        return harmonic(rng, n)
+    if kind == "bursts":
+        return bursts(rng, n)
     x = rng.random((n, 2), dtype=np.float32) * np.float32(2) - np.float32(1)
+    if kind == "clipped":
+        return np.clip(x * np.float32(3), np.float32(-1), np.float32(1))
+    if kind == "dc_offset":
+        return np.float32(0.25) + x * np.float32(0.001)
     if kind == "white":
         return x
     if kind == "white_minus_40dB":
@@ -126,6 +187,9 @@ def main():
     workers = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     skip_8h = bool(int(sys.argv[3])) if len(sys.argv) > 3 else False
     first_piece = int(sys.argv[4]) if len(sys.argv) > 4 else 0           # a second batch: other seeds, results into *_from<N>.json
+    which = sys.argv[5] if len(sys.argv) > 5 else "noise"                # "noise": round 5's four kinds | "other": round 6's
+    out_dir = sys.argv[6] if len(sys.argv) > 6 else "r05"
+    kinds = KINDS if which == "noise" else KINDS_OTHER
     os.environ.setdefault("MKL_THREADING_LAYER", "SEQUENTIAL")
     os.environ["AWM_REF_THREADS"] = "1"
     import _ref
@@ -143,8 +207,8 @@ def main():
         timing["testgen_8h_generate_and_reference_add_s"] = round(time.perf_counter() - t0, 1)
         print("8 h stream ready", timing, flush=True)
         items += [("testgen_8h", p) for p in range(16)]
-    items += [(k, p) for p in range(first_piece, first_piece + pieces) for k in KINDS]
-    suffix = "_from%d" % first_piece if first_piece else ""
+    items += [(k, p) for p in range(first_piece, first_piece + pieces) for k in kinds]
+    suffix = ("_from%d" % first_piece if first_piece else "") + ("" if which == "noise" else "_" + which)
     out = {}
     lists = []
     t0 = time.perf_counter()
@@ -173,10 +237,10 @@ def main():
                "note": "two builds of the UNMODIFIED reference on byte-identical 16 bit input; they differ only in the FFT behind fftw3.h "
                        "(double-precision FFT rounded once vs MKL's float FFTW wrapper); a tie = same block type, sync index <= 16 samples "
                        "apart, qualities < 1e-5 apart"}
-    os.makedirs(os.path.join(ROOT, "profiles", "r05"), exist_ok=True)
-    with open(os.path.join(ROOT, "profiles", "r05", "ref_backend_census%s.json" % suffix), "w") as f:
+    os.makedirs(os.path.join(ROOT, "profiles", out_dir), exist_ok=True)
+    with open(os.path.join(ROOT, "profiles", out_dir, "ref_backend_census%s.json" % suffix), "w") as f:
         json.dump({"summary": summary, "materials": out, "timing": timing, "piece_minutes": 30, "payload": PAY}, f, indent=1)
-    with open(os.path.join(ROOT, "profiles", "r05", "ref_backend_census_scores%s.json" % suffix), "w") as f:
+    with open(os.path.join(ROOT, "profiles", out_dir, "ref_backend_census_scores%s.json" % suffix), "w") as f:
         json.dump(lists, f, separators=(",", ":"))
     print(json.dumps(summary))
 
