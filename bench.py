@@ -92,11 +92,36 @@ KERNELS = {
 }
 
 
+def hip_sources_digest():
+    """sha256 over the device sources (audiowmark_amd/csrc/hip/*): what `profiles/rNN/HIP_SOURCES_SHA256` records when the PMC passes are
+    taken (tools/gpu_final.sh), so that a traffic figure is never reported for kernels that changed afterwards (no git on the GPU box)"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "audiowmark_amd", "csrc", "hip")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".hh")):
+            h.update(name.encode())
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()
+
+
+def traffic_is_stale():
+    """True if the newest profile directory's PMC passes were taken with other device sources than the ones in the tree (or does not say)"""
+    if not PROFILE_DIR:
+        return True
+    try:
+        recorded = open(os.path.join(PROFILE_DIR, "HIP_SOURCES_SHA256")).read().split()[0]
+    except Exception:
+        return True
+    return recorded != hip_sources_digest()
+
+
 def pmc_traffic(prof_name, minutes):
     """HBM bytes per launch of the kernel behind a profiling scope: FETCH_SIZE (x2, gfx950 calibration) + WRITE_SIZE from the
     separate rocprofv3 --pmc passes of this very command (tools/pmc_traffic.py -> profiles/r02/traffic.json; counters cannot be
     read from inside the process).  None if the summary is not there or was taken for another workload."""
-    if minutes != 60.0 or not PROFILE_DIR:
+    if minutes != 60.0 or not PROFILE_DIR or traffic_is_stale():
         return None
     try:
         with open(os.path.join(PROFILE_DIR, "traffic.json")) as f:
@@ -112,10 +137,13 @@ def traffic_provenance():
     if not PROFILE_DIR:
         return None
     try:
-        commit = open(os.path.join(PROFILE_DIR, "COMMIT")).read().strip()
+        commit = open(os.path.join(PROFILE_DIR, "COMMIT")).read().split()[0]
     except Exception:
         commit = None
-    return {"profile_dir": os.path.relpath(PROFILE_DIR, ROOT), "traffic_from_commit": commit}
+    stale = traffic_is_stale()
+    return {"profile_dir": os.path.relpath(PROFILE_DIR, ROOT), "traffic_from_commit": commit, "traffic_stale": stale,
+            "note": ("the device sources changed since these PMC passes (or the directory does not record their digest): every `traffic` is null"
+                     if stale else "HBM bytes per launch from separate rocprofv3 --pmc passes (FETCH_SIZE x 2, WRITE_SIZE) of this command with these device sources")}
 
 
 def quantise16(np, x):
@@ -807,6 +835,15 @@ def main():
                                                               "Per sync frame and wave 30 gathers feed 120 float additions in the reference's order: the VALU issues 42 % of the cycles (one "
                                                               "wave64 FP32 instruction per ~2.5 cycles is the SIMD's rate, tools/valu_rate.hip), the LDS is active 51 %; its 846 tiles are "
                                                               "3.3 rounds on 256 CUs: the stand-alone time includes a 17 % tail that the other lanes fill in the timed configuration"}
+            # the single-launch kernels one by one, same definition, with their measured traffic: the dominant kernel above works out of
+            # LDS (its HBM fraction says little), these are the ones the 8 TB/s are the yardstick for
+            roofline["single_launch_kernels"] = [
+                {"kernel": KERNELS.get(v[0], (v[0], ""))[0], "scope": v[0], "bound": "hbm", "achieved": round(v[3] / (v[1] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS,
+                 "unit": "GB/s", "frac": round(v[3] / (v[1] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "avg_ms": round(v[1] / v[2], 4),
+                 "algorithmic_bytes_per_launch": int(v[3] / v[2]),
+                 "traffic": pmc_traffic(v[0], args.minutes if args.minutes is not None else 60.0) if single_stream else None,
+                 "share_of_gpu_time_alone": round(v[1] / total_alone, 3)}
+                for v in sorted(singles, key=lambda v: -v[1])]
             # every kernel above 5 % of the stand-alone GPU time, same definition (algorithmic bytes / stand-alone duration / 8 TB/s)
             roofline["all_kernels_above_5_percent"] = [
                 {"kernel": KERNELS.get(k, (k, ""))[0], "scope": k, "single_launch_scope": k in SINGLE_KERNEL_SCOPES,

@@ -3,7 +3,7 @@
 # lines of every configuration, stand-alone kernel stats + counter passes of configs[2] and configs[4], the three-way tie census, the multi-GPU
 # protocol on one device, the whole GPU suite.   usage (GPU box, repository root): tools/gpu_final.sh r05
 set -u
-TAG=${1:-r05}
+TAG=${1:-r06}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
@@ -35,4 +35,5 @@ timeout 300 python tools/gpu_io_sweep.py 60 quick > $O/io_sweep.log 2>&1; cp gpu
 timeout 300 python tools/gpu_first_calls.py > $O/first_calls.txt 2>&1; grep -v amdgpu $O/first_calls.txt
 timeout 1200 python tools/gpu_census_three_way.py 1 14 > $O/census_three_way.log 2>&1; echo "census rc $?"; tail -1 $O/census_three_way.log | cut -c1-1500; cp gpurun_out/census_three_way.json $O/ 2>/dev/null
 timeout 1500 python -m pytest tests -q -m gpu > $O/gpu_tests.log 2>&1; echo "gpu tests rc $?"; tail -4 $O/gpu_tests.log; cp gpurun_out/fullsize_parity.json $O/ 2>/dev/null
-git -C $R rev-parse HEAD > $O/COMMIT 2>/dev/null || true
+git -C $R rev-parse HEAD > $O/COMMIT 2>/dev/null || true       # (no .git on the GPU box: written again, from the container, when the files are copied to profiles/)
+python -c "import sys; sys.argv = ['x']; import bench; print (bench.hip_sources_digest())" > $O/HIP_SOURCES_SHA256

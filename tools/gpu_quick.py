@@ -1,6 +1,6 @@
 """Ad-hoc GPU sanity script (not a pytest file): first contact of every kernel with the reference."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))      # (_ref, _oracle)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 import _ref, audiowmark_amd as awm
