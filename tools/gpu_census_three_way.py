@@ -85,6 +85,10 @@ def main():
         print("8 h stream rebuilt in %.0f s" % (time.perf_counter() - t0), flush=True)
         items = [k for k in recorded if k[0] == "testgen_8h"] + items
     ctx = awm.Context(0)
+    form = int(os.environ.get("AWM_REFINE_FORM", "-1"))                 # (which form of K4s: default = the library's; 5 = update term in float)
+    if form >= 0:
+        awm.lib.awm_debug_set_refine_form(form)
+    form = awm.lib.awm_debug_refine_form()
     pairs = {"hip_vs_double": {}, "hip_vs_mkl": {}, "double_vs_mkl": {}}
     new = lambda: {"scores": 0, "blocks": 0, "ties": [], "ties_on_blocks": 0, "other_differences": [], "max_abs_quality_diff": 0.0}
     skipped = []
@@ -114,14 +118,14 @@ def main():
                          "scores_compared": sum(v["scores"] for v in kinds.values()), "scores_at_another_fine_offset": sum(len(v["ties"]) for v in kinds.values()),
                          "other_differences": sum(len(v["other_differences"]) for v in kinds.values()),
                          "max_abs_quality_diff": max((v["max_abs_quality_diff"] for v in kinds.values()), default=0.0)}
-    res = {"summary": summary, "pieces_compared": done, "pieces_skipped_md5_mismatch": skipped, "pairs": pairs,
+    res = {"summary": summary, "refine_form": form, "pieces_compared": done, "pieces_skipped_md5_mismatch": skipped, "pairs": pairs,
            "wall_s": round(time.perf_counter() - t_all, 1),
            "note": "identical 16 bit input for all three detectors (md5 checked per piece); a tie = same block type, sync index <= 16 samples apart, qualities "
                    "< 1e-5 apart; 'double' / 'mkl' = the two builds of the unmodified reference (oracle/Makefile: ref, ref_mkl)"}
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "census_three_way.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", os.environ.get("AWM_CENSUS_OUT", "census_three_way.json")), "w") as f:
         json.dump(res, f, indent=1)
-    print(json.dumps({"summary": summary, "pieces_compared": done, "skipped": len(skipped)}))
+    print(json.dumps({"refine_form": form, "summary": summary, "pieces_compared": done, "skipped": len(skipped)}))
 
 
 if __name__ == "__main__":
