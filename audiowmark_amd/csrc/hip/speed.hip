@@ -540,6 +540,11 @@ speed_compare_kernel (SpeedCompareArgs a)
     }
 }
 
+// (A / B, tools/gpu_speed_compare_ab.py, round 6: 1 = all 11 relative speeds of a centre in one thread -- the matrix gathered once, but 179
+// registers = two waves per SIMD for a kernel that lives on the latency of its gathers: 0.482 against 0.447 ms per launch; off)
+int g_speed_compare_wide = 0;
+extern "C" void awm_debug_set_speed_compare_wide (int on) { g_speed_compare_wide = on; }
+
 hipError_t
 launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items)
 {
@@ -552,7 +557,12 @@ launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items)
   // six speeds per thread where that still leaves enough workgroups to fill the chip (the first pass: 57 centres x 11 or 23
   // speeds); the small refinement passes get one speed per thread and more workgroups instead
   const unsigned groups6 = unsigned ((per + 5) / 6);
-  if ((long long) ranges * a.n_centers * groups6 >= 1024)
+  // ... and ALL of a centre's relative speeds (11 in the first pass of a stereo stream) in one thread where they fit: the centre's
+  // matrix is then gathered once instead of once per group of six (round 5's counters: 2.18 GB fetched per launch for 1.0 GB of
+  // matrices, the two groups of a centre run on different XCDs)
+  if (g_speed_compare_wide && per > 6 && per <= 12 && (long long) ranges * a.n_centers >= 1024)
+    hipLaunchKernelGGL (speed_compare_kernel<12>, dim3 (ranges, unsigned (a.n_centers), 1), dim3 (256), 0, st, a);
+  else if ((long long) ranges * a.n_centers * groups6 >= 1024)
     hipLaunchKernelGGL (speed_compare_kernel<6>, dim3 (ranges, unsigned (a.n_centers), groups6), dim3 (256), 0, st, a);
   else
     hipLaunchKernelGGL (speed_compare_kernel<1>, dim3 (ranges, unsigned (a.n_centers), unsigned (per)), dim3 (256), 0, st, a);

@@ -437,6 +437,7 @@ void awm_debug_set_soft_bits_generic (int on); /* K7: one thread per soft bit fo
 void awm_debug_set_chunk_stagger (int mode); /* get: phase offset between the chunk lanes -- 0 all chunks start together | 1 chunk i + 1 behind chunk i's
                                              * dB kernel | 2 behind its scan | -1 (default) 1 for streams of up to `lanes` chunks, 2 for longer ones */
 void awm_debug_set_resample_phase (int on);  /* K10: 1 (default) the phase-per-thread kernel for stereo 48 <-> 44.1 kHz | 0 the generic kernel (outputs identical) */
+void awm_debug_set_speed_compare_wide (int on); /* K14: 1 all relative speeds of a centre (<= 12) in one thread / 0 (default) groups of six: measured slower, see hip/speed.hip */
 void awm_debug_set_resample_var_mode (int mode); /* K12: bit 0 the stereo input window of a tile through LDS | bit 1 a workgroup keeps its coefficient
                                              * table for several tiles (default 2; outputs identical) */
 void awm_debug_set_speed_overlap (int on);   /* get with a speed search: 1 (default) the plain decode of the chunks runs beside the speed part, on lanes

@@ -1126,3 +1126,29 @@ def test_refinement_kernel_forms(gpu):
                     assert max(abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(res[5], res[4])) < QUALITY_TOL
     finally:
         lib.awm_debug_set_refine_form(4)
+
+
+@pytest.mark.parametrize("kind", ["harmonic", "bursts", "clipped", "dc_offset"])
+def test_add_and_get_on_material_that_is_not_noise(gpu, kind):
+    """The material of tools/ref_backend_census.py's round 6 kinds, three minutes each, 16 bit: a sparse spectrum (harmonic stacks on slow
+    chirps), speech-like bursts with DIGITAL SILENCE between them, hard clipped full scale noise (the limiter at work in every block), a DC
+    offset with noise at -60 dB -- where `mag > 1e-7` (wmadd.cc:64-84; here abs2 > 1e-14f with v_log / v_exp for powf (hypotf)), exactly zero
+    power (wmcommon.hh:207-214) and `umag == 0 || dmag == 0` (syncfinder.cc:101) fire in bulk.  `add` against the reference: PCM RMS < 1e-6,
+    max < 4e-6; `get` of the reference's output: same positions, types and payloads, qualities within the tolerance the two builds of
+    the reference keep between themselves on this material (profiles/r06/ref_backend_census_other.json: 1.2e-4 on the harmonic stacks,
+    where the float rounding of the reference's own window shows against the little power between the partials)."""
+    import sys
+    sys.path.insert(0, os.path.join(HERE, "..", "tools"))
+    import ref_backend_census as rbc
+    n = 180 * 44100
+    x = rbc.quantise16(rbc.material(kind, 0, n))
+    ref = orc.add(None, x, 2, PAY1).reshape(-1, 2)
+    got = gpu.ctx.add_watermark(None, PAY1, gpu.dev(x)).cpu().numpy()
+    d = got.astype(np.float64) - ref
+    assert np.sqrt((d ** 2).mean()) < RMS_TOL and np.abs(d).max() < 4e-6, (np.sqrt((d ** 2).mean()), np.abs(d).max())
+    w = rbc.quantise16(ref)
+    want = orc.get(None, w, 2)
+    have = gpu.ctx.get_watermark(None, gpu.dev(w))
+    assert [pkey(p) for p in have] == [pkey(p) for p in want] and len(want) > 0
+    tol = 3e-4 if kind in ("harmonic", "dc_offset") else QUALITY_TOL
+    assert max(abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(have, want)) < tol
