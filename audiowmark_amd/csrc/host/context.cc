@@ -727,6 +727,31 @@ awm_ctx_set_chunk_lanes (awm_ctx *ctx, int n_lanes)
   return 0;
 }
 
+/* The opposite of awm_ctx_trim: pay NOW what the first call of a fresh context would pay -- HIP streams (the runtime takes 4 - 10 ms to
+ * create one, profiles/r05/stream_create_probe.txt): the chunk lanes of `get`, with detect_speed the second set of lanes the plain decode
+ * runs on beside the speed search, and the copy stream of the file level calls.  A service creates its contexts at start-up and calls this
+ * once; the first request then runs like the second. */
+int
+awm_ctx_warm_up (awm_ctx *ctx, int detect_speed, int file_level)
+{
+  if (!ctx)
+    return AWM_ERR_ARG;
+  AWM_HIP_CHECK (hipSetDevice (ctx->device));
+  const int lanes = std::max (1, std::min (ctx->chunk_lanes, awm::CHUNK_LANES)) * (detect_speed ? 2 : 1);
+  for (int i = 0; i < lanes && i < awm::MAX_LANES; i++)
+    if (!ctx->lane (i))
+      {
+        awm::set_error ("cannot create a work lane (stream)");
+        return AWM_ERR_HIP;
+      }
+  if (file_level && !ctx->get_copy_stream())
+    {
+      awm::set_error ("cannot create the copy stream");
+      return AWM_ERR_HIP;
+    }
+  return 0;
+}
+
 /* Give back what the context keeps between calls for speed: the workspaces of its lanes, the file level staging rings (page-locked
  * tiles + their device twins) and the whole-stream PCM buffer of the file level `get` -- about 1.3 GB per hour of the longest file
  * seen so far.  Key tables, the constant tables and the streams stay; the next call allocates what it needs again. */

@@ -12,8 +12,10 @@ namespace awm {
 void
 SpeedWorkspace::release()
 {
-  for (auto& t : var_tables)
-    t->ctab.release();
+  for (auto& sl : table_slabs)
+    sl.buf.release();
+  table_slabs.clear();
+  var_tables.clear();
   for (auto& t : key_tables)
     {
       t->cols.release();
@@ -143,24 +145,47 @@ get_var_tables (awm_ctx *ctx, const std::vector<double>& ratios, std::vector<Var
     });
   for (auto& th : threads)
     th.join();
-  for (size_t k = 0; k < missing.size(); k++)
+  if (!missing.empty())
     {
-      auto vt = std::make_unique<VarResampleTable>();
-      vt->ratio = ratios[missing[k]];
-      vt->hl = int (geo[k].hl);
-      if (int rc = upload_sync (vt->ctab, tabs[k].data(), tabs[k].size() * sizeof (float), ctx->stream))
-        return rc;
-      ws->var_tables.push_back (std::move (vt));
-      // Bounded cache.  The grids of the first pass (57 centres each for the normal and the patient search) never change
-      // and are the first entries ever made: they stay; the oldest of the data dependent refinement ratios goes.
-      // (Nothing handed out by this call is dropped: a call either finds all its ratios, or adds the missing ones last.  Up to
-      // CHUNK_LANES searches run side by side, each with ~100 ratios of its own in use: the cache is an order of magnitude
-      // larger than that, so the oldest entry is never one a running search holds.  A table is ~20 KB.)
-      constexpr size_t keep_first = 128, max_tables = 4096;
-      if (ws->var_tables.size() > max_tables)
+      // one device allocation and one copy for all tables this call adds (every table 16 byte aligned inside the slab)
+      std::vector<size_t> at (missing.size());
+      size_t total = 0;
+      for (size_t k = 0; k < missing.size(); k++)
         {
-          ws->var_tables[keep_first]->ctab.release();
-          ws->var_tables.erase (ws->var_tables.begin() + keep_first);
+          at[k] = total;
+          total += (tabs[k].size() + 3) & ~size_t (3);
+        }
+      std::vector<float> blob (total, 0.f);
+      for (size_t k = 0; k < missing.size(); k++)
+        std::copy (tabs[k].begin(), tabs[k].end(), blob.begin() + at[k]);
+      VarTableSlab slab;
+      slab.serial = ws->next_slab++;
+      if (int rc = upload_sync (slab.buf, blob.data(), blob.size() * sizeof (float), ctx->stream))
+        return rc;
+      for (size_t k = 0; k < missing.size(); k++)
+        {
+          auto vt = std::make_unique<VarResampleTable>();
+          vt->ratio = ratios[missing[k]];
+          vt->hl = int (geo[k].hl);
+          vt->ctab = slab.buf.as<float>() + at[k];
+          vt->slab = slab.serial;
+          ws->var_tables.push_back (std::move (vt));
+        }
+      ws->table_slabs.push_back (slab);
+      // Bounded cache.  The grids of the first pass (57 centres each for the normal and the patient search) never change and are in
+      // the first slabs ever made: those stay; beyond max_tables the OLDEST of the data dependent refinement slabs goes, with all
+      // its tables.  (Nothing handed out by this call is dropped: a call either finds all its ratios, or adds the missing ones
+      // last.  Up to CHUNK_LANES searches run side by side, each with ~100 ratios of its own in use: the cache is an order of
+      // magnitude larger than that, so the oldest slab is never one a running search holds.  A table is ~20 KB.)
+      constexpr size_t keep_slabs = 2, max_tables = 4096;
+      while (ws->var_tables.size() > max_tables && ws->table_slabs.size() > keep_slabs + 1)
+        {
+          const size_t gone = ws->table_slabs[keep_slabs].serial;
+          ws->table_slabs[keep_slabs].buf.release();
+          ws->table_slabs.erase (ws->table_slabs.begin() + keep_slabs);
+          ws->var_tables.erase (std::remove_if (ws->var_tables.begin(), ws->var_tables.end(),
+                                                [&] (const std::unique_ptr<VarResampleTable>& t) { return t->slab == gone; }),
+                                ws->var_tables.end());
         }
     }
   for (size_t i = 0; i < ratios.size(); i++)
@@ -179,7 +204,7 @@ center_dev (const VarResampleTable *vt, double ratio, long long n_in, long long 
   const double step = 256 / ratio;
   int e = 0;
   const double f = std::frexp (step, &e);                  // step = f * 2^e, 0.5 <= f < 1
-  cd.ctab = vt->ctab.as<float>();
+  cd.ctab = vt->ctab;
   cd.hl = vt->hl;
   cd.stride = vt->hl | 1;
   cd.mant = (unsigned long long) std::ldexp (f, 53);       // step = mant * 2^(e - 53)

@@ -36,9 +36,17 @@ struct SpeedScore           // reference wmspeed.cc:99-103
 // cached per ratio: VResampler::setup (ratio, nchan, hlen = 16)
 struct VarResampleTable
 {
-  double    ratio = 0;
-  int       hl = 0;
-  DevBuffer ctab;
+  double       ratio = 0;
+  int          hl = 0;
+  const float *ctab = nullptr;      // inside a slab of SpeedWorkspace::table_slabs
+  size_t       slab = 0;            // serial number of that slab
+};
+// the tables a call of get_var_tables had to build, side by side in ONE device allocation (a first `get --detect-speed` builds ~230
+// tables of ~20 KB: as allocations of their own they were 27 ms of its 62)
+struct VarTableSlab
+{
+  size_t    serial = 0;
+  DevBuffer buf;
 };
 
 // per key: the 510 sync frames of a block in the column order of the magnitude matrix ([bit][frame ascending])
@@ -54,6 +62,8 @@ struct SpeedKeyTables
 struct SpeedWorkspace
 {
   std::vector<std::unique_ptr<VarResampleTable>> var_tables;
+  std::vector<VarTableSlab>                      table_slabs;
+  size_t                                         next_slab = 0;
   std::vector<std::unique_ptr<SpeedKeyTables>>   key_tables;
   DevBuffer    window512;
   void release();

@@ -52,6 +52,10 @@ void  awm_ctx_destroy (awm_ctx *ctx);
  * file level `get` has decoded (1.3 GB per hour).  awm_ctx_trim gives all of that back (also for the context's helpers); key tables and
  * streams stay.  For long-lived services after an unusually long file. */
 int   awm_ctx_trim (awm_ctx *ctx);
+/* ... and the other way round: create NOW the HIP streams a first call would create (4 - 10 ms each in this runtime): the chunk lanes of
+ * `get` (twice as many with detect_speed != 0: the plain decode runs beside the speed search), with file_level != 0 the copy stream of the
+ * file level calls.  For services that create their contexts at start-up. */
+int   awm_ctx_warm_up (awm_ctx *ctx, int detect_speed, int file_level);
 int   awm_ctx_device (const awm_ctx *ctx);
 int   awm_ctx_synchronize (awm_ctx *ctx);
 /* opaque hipStream_t of the context (for callers that bracket work with HIP events) */

@@ -261,3 +261,38 @@ def test_file_shorter_than_its_header_says_and_input_from_a_pipe(gpu, tmp_path):
     feeder.join()
     want_raw = gpu.ctx.pcm_encode(gpu.ctx.add_watermark(None, PAY, x_file).reshape(-1), 16, 0, False, True).cpu().numpy().tobytes()
     assert dst.read_bytes() == want_raw
+
+
+def test_ctx_warm_up_and_trim(gpu, tmp_path):
+    """awm_ctx_warm_up creates the streams a first call would create, awm_ctx_trim gives the kept workspaces back (lanes' scratch buffers, the
+    file level rings, the stream's PCM buffer): results before, between and after are the same, a trimmed context allocates again by itself"""
+    import ctypes as C
+    awm, t = gpu.awm, gpu.torch
+    lib = awm.lib
+    lib.awm_ctx_warm_up.argtypes = [C.c_void_p, C.c_int, C.c_int]
+    lib.awm_ctx_trim.argtypes = [C.c_void_p]
+    ctx = awm.Context(0)
+    try:
+        assert lib.awm_ctx_warm_up(ctx._h, 1, 1) == 0
+        n = 200 * 44100
+        x = noise(gpu, n, 2, 61) * 0.9
+        raw = ctx.pcm_encode(x.reshape(-1), 16, 0, False, True).cpu().numpy()
+        src, dst = tmp_path / "in.raw", tmp_path / "out.raw"
+        raw.tofile(src)
+        rf = awm.binding.RawFormat(2, 44100, 16, 0, 0)
+        key = lambda p: (round(p["time"], 6), p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
+        ctx.add_watermark_file(None, PAY, src, dst, rf, rf)
+        first_bytes = dst.read_bytes()
+        first = [key(p) for p in ctx.get_watermark_file(None, dst, rf)]
+        assert any(p[4] == PAY for p in first)
+        free0 = t.cuda.mem_get_info()[0]
+        assert lib.awm_ctx_trim(ctx._h) == 0
+        assert t.cuda.mem_get_info()[0] > free0                       # something came back
+        ctx.add_watermark_file(None, PAY, src, dst, rf, rf)
+        assert dst.read_bytes() == first_bytes
+        assert [key(p) for p in ctx.get_watermark_file(None, dst, rf)] == first
+        assert lib.awm_ctx_trim(ctx._h) == 0 and lib.awm_ctx_trim(ctx._h) == 0
+        w = ctx.add_watermark(None, PAY, x)
+        assert [key(p) for p in ctx.get_watermark(None, w)] == [key(p) for p in gpu.ctx.get_watermark(None, w)]
+    finally:
+        ctx.close()
