@@ -148,6 +148,7 @@ lib.awm_add_stream_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.c_char_p, 
 lib.awm_add_stream_create_at.argtypes = [_vp, _vp, C.c_char_p, C.c_int, C.c_size_t, C.c_size_t, C.POINTER(_vp)]
 lib.awm_debug_sync_db_sliding_d.argtypes = [_vp, _vp, C.c_size_t, C.c_int, _vp, C.c_size_t, C.c_int, C.c_int, _vp]
 lib.awm_get_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.POINTER(RawFormat), C.c_size_t, _vp]
+lib.awm_add_get_watermark_file.argtypes = [_vp, _vp, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(RawFormat), C.POINTER(RawFormat), C.c_size_t, _vp]
 lib.awm_add_stream_create.argtypes = [_vp, _vp, C.c_char_p, C.c_int, C.c_size_t, C.POINTER(_vp)]
 lib.awm_add_stream_destroy.argtypes = [_vp]
 lib.awm_add_stream_destroy.restype = None
@@ -549,6 +550,12 @@ class Context:
         _check(lib.awm_add_watermark_file(self._h, key_bytes(key), payload_hex.encode(), os.fsencode(in_path), os.fsencode(out_path),
                                           C.byref(raw_in) if raw_in is not None else None,
                                           C.byref(raw_out) if raw_out is not None else None), "awm_add_watermark_file")
+
+    def add_get_watermark_file(self, key, payload_hex, in_path, out_path, raw_in=None, raw_out=None):
+        """awm_add_get_watermark_file: infile -> outfile, and the pattern list of `get` on what was written (never read back)"""
+        return self._patterns(lib.awm_add_get_watermark_file, "awm_add_get_watermark_file", self._h, key_bytes(key), payload_hex.encode(),
+                              os.fsencode(in_path), os.fsencode(out_path), C.byref(raw_in) if raw_in is not None else None,
+                              C.byref(raw_out) if raw_out is not None else None)
 
     def get_watermark_file(self, key, in_path, raw_in=None):
         return self._patterns(lib.awm_get_watermark_file, "awm_get_watermark_file", self._h, key_bytes(key), os.fsencode(in_path),

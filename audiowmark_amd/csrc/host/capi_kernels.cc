@@ -1887,6 +1887,32 @@ awm_add_stream_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *
 }
 
 int
+awm_add_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const char *in_path, const char *out_path,
+                            const awm_raw_format *raw_in, const awm_raw_format *raw_out, size_t max_out, awm_pattern *out)
+{
+  AWM_ENTER (ctx);
+  if (!payload_hex || !in_path || !out_path || (max_out && !out))
+    {
+      set_error ("awm_add_get_watermark_file: bad argument");
+      return AWM_ERR_ARG;
+    }
+  FormatScope scope;
+  if (!FormatScope::apply (raw_in, params().input_format, StreamParams::raw_input_format)
+      || !FormatScope::apply (raw_out, params().output_format, StreamParams::raw_output_format))
+    {
+      set_error ("awm_add_get_watermark_file: unsupported raw format");
+      return AWM_ERR_ARG;
+    }
+  ResultSet rs;
+  file_fail_reset();
+  if (add_get_watermark (ctx, capi_key (key), in_path, out_path, payload_hex, rs))
+    return file_fail_kind();
+  for (size_t i = 0; i < rs.patterns.size() && i < max_out; i++)
+    fill_pattern (rs.patterns[i], out[i]);
+  return int (rs.patterns.size());
+}
+
+int
 awm_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *in_path, const awm_raw_format *raw_in,
                         size_t max_out, awm_pattern *out)
 {

@@ -1,6 +1,8 @@
 // awm_ctx: per-GPU state of the watermark path -- HIP stream, constant tables in HBM,
 // per-key device tables (cached) and grow-only workspaces sized for 288 GB parts.
 #pragma once
+#include <condition_variable>
+#include <mutex>
 #include <hip/hip_runtime.h>
 #include <map>
 #include <mutex>
@@ -159,6 +161,11 @@ struct FileStaging
   PinnedBuffer in_host[RING], out_host[RING];
   DevBuffer    in_dev[RING], out_dev[RING];
   DevBuffer    pcm;
+  // awm_add_get_watermark_file ("watermark, then verify"): the output stage also leaves what it writes -- the samples as the file holds
+  // them, i.e. after the sample format's quantisation -- in `pcm` as float32, so that `get` never reads the file back
+  bool         keep = false;
+  size_t       kept_values = 0;
+  int          kept_channels = 0, kept_rate = 0;
   hipEvent_t   in_copied[RING] = {}, in_used[RING] = {}, out_encoded[RING] = {}, out_copied[RING] = {};
   bool         have_events = false;
   bool         ensure_events();
@@ -177,7 +184,12 @@ struct ReadyMarks
   std::vector<hipEvent_t> pool;          // events kept between calls
   size_t       used = 0;
   hipEvent_t   next_event();             // nullptr on failure
-  void         disarm() { armed = false; marks.clear(); used = 0; base = nullptr; n_frames = 0; }
+  // LIVE marks (the file level `get`: a loader thread is still bringing the stream in while the chunks start): marks appear over
+  // time, under `mu`; a chunk that needs samples nobody has marked yet waits on `cv` -- until the mark is there or the loader is done
+  bool         live = false, live_done = false;
+  std::mutex   mu;
+  std::condition_variable cv;
+  void         disarm() { armed = false; live = live_done = false; marks.clear(); used = 0; base = nullptr; n_frames = 0; }
   void         release();
 };
 

@@ -431,9 +431,26 @@ public:
 };
 
 /* Whole stream -> float32 PCM in HBM (288 GB hold days of audio; what is bounded is the HOST side: the ring of staging tiles). */
+/* live != nullptr: the caller decodes the stream's chunks WHILE this function (on a thread of its own) brings the stream in: the buffer
+ * has its final size (announced frames + 1) and never moves, copies AND sample decodes run on the copy stream (the compute stream
+ * belongs to the decoder), and behind every tile a mark "the stream is final up to frame n" with an event on the copy stream is
+ * published under live->mu (ReadyMarks, context.hh).  The last act, on every path out, is live_done. */
 Error
-load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_pcm, size_t& n_values)
+load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_pcm, size_t& n_values, ReadyMarks *live = nullptr)
 {
+  struct Done
+  {
+    ReadyMarks *live;
+    ~Done()
+    {
+      if (live)
+        {
+          std::lock_guard<std::mutex> lock (live->mu);
+          live->live_done = true;
+          live->cv.notify_all();
+        }
+    }
+  } done { live };
   const int C = in_stream->n_channels();
   n_values = 0;
   RawFormat fmt;
@@ -460,6 +477,8 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
         return err;
       if (!got)
         break;
+      if (frames + got > cap_frames && live)
+        return Error ("input stream is longer than announced");      // (the caller starts over without the overlap)
       if (frames + got > cap_frames)
         {
           // stream of unknown (or understated) length: move to a buffer twice the size
@@ -476,7 +495,15 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
         }
       float *dst = d_pcm.as<float>() + frames * C;
       bool ok;
-      if (raw)
+      if (raw && live)
+        {
+          // everything on the copy stream, in order: copy, sample decode (the staging buffer is free again behind it)
+          const awmk::PcmFormatDev f { fmt.bit_depth / 8, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, 0 };
+          ok = hipMemcpyAsync (rd.dev (b), rd.host (b), got * unit, hipMemcpyHostToDevice, rd.copy) == hipSuccess
+            && hipEventRecord (rd.ev_copied (b), rd.copy) == hipSuccess
+            && awmk::launch_pcm_decode (rd.copy, static_cast<const unsigned char *> (rd.dev (b)), dst, (long long) (got * C), f) == hipSuccess;
+        }
+      else if (raw)
         {
           // (dev[b] was last read by the decode of the tile IN_RING earlier: the copy stream waits for that decode)
           ok = (k < size_t (IN_RING) || hipStreamWaitEvent (rd.copy, rd.ev_used (b), 0) == hipSuccess)
@@ -493,10 +520,19 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
         return Error (std::string ("GPU staging failed: ") + awm_last_error());
       rd.recycle (b, rd.ev_copied (b));
       frames += got;
+      if (live)
+        {
+          hipEvent_t ev = live->next_event();                 // (only this thread takes events while the marks are live)
+          if (!ev || hipEventRecord (ev, rd.copy) != hipSuccess)
+            return Error ("GPU staging failed: cannot record an event");
+          std::lock_guard<std::mutex> lock (live->mu);
+          live->marks.push_back ({ frames, ev });
+          live->cv.notify_all();
+        }
       if (got < STAGE_FRAMES)
         break;
     }
-  if (hipStreamSynchronize (rd.copy) != hipSuccess || hipStreamSynchronize (ctx->stream) != hipSuccess)
+  if (hipStreamSynchronize (rd.copy) != hipSuccess || (!live && hipStreamSynchronize (ctx->stream) != hipSuccess))
     return Error ("GPU transfer failed");
   n_values = frames * C;
   return Error::Code::NONE;
@@ -771,6 +807,13 @@ struct OutputStage
     dev = fs.out_dev;
     for (int i = 0; i < SLOTS && ok; i++)
       ok = host[i].reserve (chunk_frames * unit) == 0 && (!raw || dev[i].reserve (chunk_frames * unit) == 0);
+    if (fs.keep)
+      {
+        fs.kept_channels = C;
+        fs.kept_rate = o->sample_rate();
+        if (total_frames != AudioInputStream::N_FRAMES_UNKNOWN && ok)
+          ok = fs.pcm.reserve (std::max<size_t> (1, (total_frames + 1) * C * sizeof (float))) == 0;
+      }
     if (ok)
       writer = std::make_unique<ChunkWriter> (out, SLOTS, ctx->device, raw, unit, total_frames);
   }
@@ -794,15 +837,36 @@ struct OutputStage
       lap.to (2);
     }
     bool good;
+    FileStaging& fs = ctx->file_staging;
+    if (fs.keep)
+      {
+        // (grow-only; a stream longer than announced moves to a buffer twice the size)
+        const size_t need = (fs.kept_values + n_frames * C) * sizeof (float);
+        if (need > fs.pcm.bytes)
+          {
+            DevBuffer bigger;
+            if (bigger.reserve (std::max (need, 2 * fs.pcm.bytes))
+                || (fs.kept_values && hipMemcpyAsync (bigger.ptr, fs.pcm.ptr, fs.kept_values * sizeof (float), hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess)
+                || hipStreamSynchronize (ctx->stream) != hipSuccess)
+              return false;
+            fs.pcm.release();
+            fs.pcm = bigger;
+          }
+      }
     if (raw)
       good = awm_pcm_encode_d (ctx, d_pcm, n_frames * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG, direct16, dev[b].ptr) == 0
+          && (!fs.keep || awm_pcm_decode_d (ctx, dev[b].ptr, n_frames * C, fmt.bit_depth, encoding_id (fmt.encoding), fmt.endian == RawFormat::BIG,
+                                            fs.pcm.as<float>() + fs.kept_values) == 0)
           && hipEventRecord (ev_encoded[b], ctx->stream) == hipSuccess
           && hipStreamWaitEvent (copy, ev_encoded[b], 0) == hipSuccess
           && hipMemcpyAsync (host[b].ptr, dev[b].ptr, n_frames * unit, hipMemcpyDeviceToHost, copy) == hipSuccess;
     else
-      good = hipEventRecord (ev_encoded[b], ctx->stream) == hipSuccess
+      good = (!fs.keep || hipMemcpyAsync (fs.pcm.as<float>() + fs.kept_values, d_pcm, n_frames * C * sizeof (float), hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess)
+          && hipEventRecord (ev_encoded[b], ctx->stream) == hipSuccess
           && hipStreamWaitEvent (copy, ev_encoded[b], 0) == hipSuccess
           && hipMemcpyAsync (host[b].ptr, d_pcm, n_frames * unit, hipMemcpyDeviceToHost, copy) == hipSuccess;
+    if (fs.keep && good)
+      fs.kept_values += n_frames * C;
     good = good && hipEventRecord (ev_copied[b], copy) == hipSuccess
         // the producer may overwrite d_pcm / dev[b] only after the copy: later work on the compute stream waits for it
         && hipStreamWaitEvent (ctx->stream, ev_copied[b], 0) == hipSuccess;
@@ -1216,6 +1280,30 @@ add_watermark_at (awm_ctx *ctx, const Key& key, const std::string& infile, const
   return add_stream_watermark (ctx, key, in_stream.get(), out_stream.get(), bits, zero_frames);
 }
 
+/* add_watermark (key, infile, outfile, bits) followed by get_watermark (key, outfile) -- "watermark, then verify that the payload decodes"
+ * -- with the input read once and the output never read back: the output stage decodes what it has just encoded for the file (the
+ * samples as the file holds them) into the context's stream buffer, and `get` runs on that (reference wmadd.cc:620-657, wmget.cc:971-1013). */
+int
+add_get_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits,
+                   ResultSet& result_set)
+{
+  FileStaging& fs = ctx->file_staging;
+  fs.keep = true;
+  fs.kept_values = 0;
+  fs.kept_channels = fs.kept_rate = 0;
+  struct Off { FileStaging& f; ~Off() { f.keep = false; } } off { fs };
+  if (int rc = add_watermark_at (ctx, key, infile, outfile, bits, 0))
+    return rc;
+  fs.keep = false;
+  if (!fs.kept_channels || !fs.kept_rate)
+    {
+      result_set.sort ({ key });
+      return 0;
+    }
+  size_t n_values = 0;
+  return get_watermark_loaded (ctx, { key }, fs.kept_values, fs.kept_channels, fs.kept_rate, false, result_set, n_values);
+}
+
 std::string& last_shard_debug_sync();      // wmshard.cc
 
 /* A long stream over the context and its helpers (other GPUs, awm_ctx_set_helpers): equal frame spans, the helpers' spans copied
@@ -1295,6 +1383,13 @@ get_watermark_multi (awm_ctx *ctx, const std::vector<Key>& key_list, const Devic
   return 0;
 }
 
+/* 1: the chunks of a file level `get` start while the rest of the stream is still crossing PCIe (below) | 0 (default): the whole stream
+ * first.  Measured in round 6 (bench.py e2e, 60 min s16 stereo from tmpfs): 33.3 ms with the overlap against 21.6 without -- of the three
+ * chunks of an hour only the first can start before the stream is (nearly) complete, and then its kernels share the GPU with the copies
+ * and the sample decodes, which take longer than the chunk saves.  Kept behind the switch (results identical, tested both ways). */
+static int g_get_overlap = 0;
+extern "C" void awm_debug_set_get_overlap (int on) { g_get_overlap = on; }
+
 /* body of get_watermark (reference wmget.cc:971-1013): stream -> HBM (bounded host memory), loader resampling, chunk loop */
 int
 get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInputStream *in_stream, bool print_speed, ResultSet& result_set,
@@ -1305,22 +1400,102 @@ get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInput
   // 1.3 GB per hour of audio costs 1 - 70 ms, its hipFree as much again)
   DevBuffer& d_in = ctx->file_staging.pcm;
   size_t n_values = 0;
+  /* A stream of announced length at the watermark rate with two chunks or more: the chunks start WHILE the stream is still crossing
+   * PCIe.  The chunk plan follows from the length (wavchunkloader.cc:75-84); a loader thread brings the tiles in and leaves a mark
+   * behind each; chunk k is queued on its lane the moment the mark that covers its last sample is there (block_decoder_run, live
+   * marks).  If the stream turns out shorter or longer than announced, the result is thrown away and the plain order takes over. */
+  size_t announced = in_stream->n_frames();
+  {
+    // (headerless PCM does not announce a length -- audiostream.hh, like the reference's RawInputStream -- but a regular file has one)
+    int fd = -1;
+    uint64_t offset = 0;
+    size_t frames = 0;
+    if (announced == AudioInputStream::N_FRAMES_UNKNOWN && in_stream->raw_region (fd, offset, frames))
+      announced = frames;
+  }
+  const bool speed = params().detect_speed || params().detect_speed_patient || params().try_speed > 0;
+  const size_t max_frames = DevBuffer::MAX_BYTES / (size_t (C) * sizeof (float));
+  if (g_get_overlap && announced != AudioInputStream::N_FRAMES_UNKNOWN && announced + 1 < max_frames && in_stream->sample_rate() == Params::mark_sample_rate
+      && !params().test_truncate && !speed && ctx->helpers.empty() && !key_list.empty() && ctx->chunk_lanes > 1
+      && plan_chunks (announced, C).size() >= 2 && d_in.reserve ((announced + 1) * C * sizeof (float)) == 0)
+    {
+      ReadyMarks& rm = ctx->ready;
+      rm.disarm();
+      rm.base = d_in.as<float>();
+      rm.n_frames = announced;
+      rm.live = true;
+      rm.armed = true;
+      Error load_err;
+      size_t loaded_values = 0;
+      ParamValues *const pv = &params();
+      std::thread loader ([&, pv] {
+        ParamsBind bind (pv);
+        if (hipSetDevice (ctx->device) != hipSuccess)
+          {
+            load_err = Error ("cannot select the device");
+            std::lock_guard<std::mutex> lock (rm.mu);
+            rm.live_done = true;
+            rm.cv.notify_all();
+            return;
+          }
+        load_err = load_stream_to_device (ctx, in_stream, d_in, loaded_values, &rm);
+      });
+      DeviceWav wav;
+      wav.data = d_in.as<float>();
+      wav.n_frames = announced;
+      wav.n_channels = C;
+      wav.sample_rate = Params::mark_sample_rate;
+      speed_print_results = print_speed;
+      ResultSet early;
+      const int rc = get_watermark_device (ctx, key_list, wav, early);
+      loader.join();
+      rm.disarm();
+      if (load_err)
+        {
+          error ("audiowmark: error loading %s: %s\n", what.c_str(), load_err.message());
+          return fail (AWM_ERR_IO);
+        }
+      if (loaded_values == announced * C)
+        {
+          if (rc)
+            {
+              error ("audiowmark: GPU detection failed: %s\n", awm_last_error());
+              return fail (AWM_ERR_HIP);
+            }
+          result_set = early;
+          n_values_out = loaded_values;
+          return 0;
+        }
+      // (the file ends before the length its header announces: what the chunks saw beyond the end was not the stream)
+      if (hipStreamSynchronize (ctx->stream) != hipSuccess)
+        return fail (AWM_ERR_HIP);
+      return get_watermark_loaded (ctx, key_list, loaded_values, C, in_stream->sample_rate(), print_speed, result_set, n_values_out);
+    }
   Error err = load_stream_to_device (ctx, in_stream, d_in, n_values);
   if (err)
     {
       error ("audiowmark: error loading %s: %s\n", what.c_str(), err.message());
       return fail (AWM_ERR_IO);
     }
-  if (in_stream->sample_rate() != Params::mark_sample_rate)
+  return get_watermark_loaded (ctx, key_list, n_values, C, in_stream->sample_rate(), print_speed, result_set, n_values_out);
+}
+
+/* ... from the stream's float32 PCM in the context's buffer (file_staging.pcm: n_values samples at `rate`) on */
+int
+get_watermark_loaded (awm_ctx *ctx, const std::vector<Key>& key_list, size_t n_values, int C, int rate, bool print_speed, ResultSet& result_set,
+                      size_t& n_values_out)
+{
+  DevBuffer& d_in = ctx->file_staging.pcm;
+  if (rate != Params::mark_sample_rate)
     {
       // WavChunkLoader resamples the whole stream to the watermark rate before anything else (wavchunkloader.cc:70-71, 200-216)
       const size_t in_frames = n_values / C;
-      const size_t out_frames = awm_resample_frames (ctx, in_frames, in_stream->sample_rate(), Params::mark_sample_rate);
+      const size_t out_frames = awm_resample_frames (ctx, in_frames, rate, Params::mark_sample_rate);
       DevBuffer d_res;
       if ((in_frames && !out_frames) || d_res.reserve (std::max<size_t> (1, out_frames * C * sizeof (float)))
-          || awm_resample_d (ctx, d_in.as<float>(), in_frames, C, in_stream->sample_rate(), Params::mark_sample_rate, d_res.as<float>(), out_frames))
+          || awm_resample_d (ctx, d_in.as<float>(), in_frames, C, rate, Params::mark_sample_rate, d_res.as<float>(), out_frames))
         {
-          error ("audiowmark: resampling from old_rate=%d to new_rate=%d not implemented\n", in_stream->sample_rate(), Params::mark_sample_rate);
+          error ("audiowmark: resampling from old_rate=%d to new_rate=%d not implemented\n", rate, Params::mark_sample_rate);
           d_res.release();
           return fail (AWM_ERR_ARG);
         }

@@ -18,6 +18,11 @@ int get_watermark (awm_ctx *ctx, const std::vector<Key>& key_list, const std::st
 class ResultSet;
 int get_watermark_stream (awm_ctx *ctx, const std::vector<Key>& key_list, AudioInputStream *in_stream, bool print_speed, ResultSet& result_set,
                           size_t& n_values_out, const std::string& what);
+int get_watermark_loaded (awm_ctx *ctx, const std::vector<Key>& key_list, size_t n_values, int n_channels, int sample_rate, bool print_speed,
+                          ResultSet& result_set, size_t& n_values_out);
+// add_watermark, and get_watermark of what it wrote without reading the file back (the output stage keeps the quantised samples in HBM)
+int add_get_watermark (awm_ctx *ctx, const Key& key, const std::string& infile, const std::string& outfile, const std::string& bits,
+                       ResultSet& result_set);
 
 // kind of the last failure of the functions above on this thread (AWM_ERR_ARG / AWM_ERR_IO / AWM_ERR_HIP) for the C ABI
 int  file_fail_kind();

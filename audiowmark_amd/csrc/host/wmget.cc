@@ -611,9 +611,12 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
   // awm_add_get_watermark_d: the stream is the output of the `add` this call queued, with marks "final up to sample n" on the
   // context's stream -- a chunk starts behind the mark that covers its last sample.  The context's own stream (lane 0) is behind
   // the whole add anyway: it gets the LAST of the first round of chunks.
-  const ReadyMarks *marks = (spread && lane_base == 0 && lanes.size() > 1 && ctx->ready.armed && ctx->ready.base == stream.data
-                             && ctx->ready.n_frames == stream.n_frames && !ctx->ready.marks.empty()) ? &ctx->ready : nullptr;
-  if (marks)
+  // The file level `get` (host/wmfile.cc) arms LIVE marks: a loader thread is still bringing the stream in (its copies and sample decodes
+  // on the copy stream, a mark behind every tile) while this function starts the chunks: every lane, the context's own included, waits for
+  // the mark that covers its chunk -- on the host first, until the loader has recorded it.
+  ReadyMarks *marks = (spread && lane_base == 0 && lanes.size() > 1 && ctx->ready.armed && ctx->ready.base == stream.data
+                       && ctx->ready.n_frames == stream.n_frames && (ctx->ready.live || !ctx->ready.marks.empty())) ? &ctx->ready : nullptr;
+  if (marks && !marks->live)
     std::rotate (lanes.begin(), lanes.begin() + 1, lanes.end());
   else if (lanes.size() > 1 && lane_base == 0)
     {
@@ -625,7 +628,27 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
         AWM_HIP_CHECK (hipStreamWaitEvent (lanes[i]->stream, ctx->ev_sync, 0));
     }
   auto wait_for_mark = [&] (WorkLane *lane, size_t last_sample_plus_one) -> int {
-    if (!marks || lane->stream == ctx->stream)
+    if (!marks)
+      return 0;
+    if (marks->live)
+      {
+        std::unique_lock<std::mutex> lock (marks->mu);
+        marks->cv.wait (lock, [&] { return marks->live_done || (!marks->marks.empty() && marks->marks.back().first >= last_sample_plus_one); });
+        hipEvent_t ev = nullptr;
+        for (const auto& m : marks->marks)
+          if (m.first >= last_sample_plus_one)
+            {
+              ev = m.second;
+              break;
+            }
+        if (!ev && !marks->marks.empty())
+          ev = marks->marks.back().second;                     // (the stream ended short of what was announced: the caller will start over)
+        lock.unlock();
+        if (ev)
+          AWM_HIP_CHECK (hipStreamWaitEvent (lane->stream, ev, 0));
+        return 0;
+      }
+    if (lane->stream == ctx->stream)
       return 0;
     for (const auto& m : marks->marks)
       if (m.first >= last_sample_plus_one)
@@ -829,8 +852,15 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
   while (next_chunk < chunks.size() || !active.empty())
     {
       bool progressed = false;
-      // start chunks on free lanes, in order
-      while (next_chunk < chunks.size() && !lane_busy[next_chunk % lanes.size()] && !key_list.empty())
+      // start chunks on free lanes, in order (with live marks: once the loader has brought the chunk's last sample in -- until then
+      // the chunks that are running keep being served)
+      auto chunk_is_loaded = [&] (size_t c) {
+        if (!marks || !marks->live)
+          return true;
+        std::lock_guard<std::mutex> lock (marks->mu);
+        return marks->live_done || (!marks->marks.empty() && marks->marks.back().first >= chunks[c].first_frame + chunks[c].n_frames);
+      };
+      while (next_chunk < chunks.size() && !lane_busy[next_chunk % lanes.size()] && !key_list.empty() && chunk_is_loaded (next_chunk))
         {
           ChunkState cs;
           cs.c = next_chunk;
@@ -869,7 +899,18 @@ block_decoder_run (awm_ctx *ctx, WorkLane *home, bool spread, const std::vector<
         else
           i++;
       if (!progressed)
-        std::this_thread::yield();
+        {
+          if (marks && marks->live && active.empty() && next_chunk < chunks.size())
+            {
+              // nothing in flight and the next chunk is not there yet: sleep until the loader says so
+              std::unique_lock<std::mutex> lock (marks->mu);
+              const size_t need = chunks[next_chunk].first_frame + chunks[next_chunk].n_frames;
+              marks->cv.wait_for (lock, std::chrono::milliseconds (2),
+                                  [&] { return marks->live_done || (!marks->marks.empty() && marks->marks.back().first >= need); });
+            }
+          else
+            std::this_thread::yield();
+        }
     }
   for (size_t ki = 0; ki < key_list.size(); ki++)
     {

@@ -371,6 +371,29 @@ def e2e_leg(torch, awm, ctx, x, resident_ms):
         out["file_to_file_xRT"] = round(seconds / (best_add + best_get), 1)
         out["add_file_ms"] = round(best_add * 1e3, 2)
         out["get_file_ms"] = round(best_get * 1e3, 2)
+        # the file level `get` with the chunks starting while the stream is still crossing PCIe (awm_debug_set_get_overlap: measured slower,
+        # off by default); and "watermark, then verify" as ONE call: the output is never read back
+        key = lambda p: (p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
+        awm.lib.awm_debug_set_get_overlap(1)
+        best_plain = None
+        for _ in range(3):
+            t1 = time.perf_counter()
+            pats_plain = ctx.get_watermark_file(None, dst, rf)
+            best_plain = min(best_plain or 1e9, time.perf_counter() - t1)
+        awm.lib.awm_debug_set_get_overlap(0)
+        out["get_file_ms_chunks_started_during_the_load"] = round(best_plain * 1e3, 2)      # (the switch that is off by default)
+        out["get_file_same_patterns_either_way"] = [key(p) for p in pats_plain] == [key(p) for p in pats]
+        best_both = None
+        for _ in range(3):
+            if os.path.exists(dst2):
+                os.unlink(dst2)
+            t0 = time.perf_counter()
+            pats_both = ctx.add_get_watermark_file(None, PAYLOAD, src, dst2, rf, rf)
+            best_both = min(best_both or 1e9, time.perf_counter() - t0)
+        out["add_get_file_as_one_call_ms"] = round(best_both * 1e3, 2)
+        out["add_get_file_as_one_call_xRT"] = round(seconds / best_both, 1)
+        out["add_get_file_as_one_call_same_file_and_patterns"] = bool(open(dst, "rb").read() == open(dst2, "rb").read()
+                                                                      and [key(p) for p in pats_both] == [key(p) for p in pats])
         out["file_bytes"] = int(raw.numel())
         out["payload_matches"] = sum(p["bits"] == PAYLOAD for p in pats)
         # (2) page-locked host buffers instead of files

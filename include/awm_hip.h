@@ -292,6 +292,12 @@ int awm_add_stream_watermark_file (awm_ctx *ctx, const uint8_t key[16], const ch
                                    const awm_raw_format *raw_in, const awm_raw_format *raw_out, size_t zero_frames);
 int awm_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *in_path, const awm_raw_format *raw_in,
                             size_t max_out, awm_pattern *out);
+/* add_watermark (key, infile, outfile, bits) followed by get_watermark (key, outfile) ("watermark, then verify that the payload decodes":
+ * wmadd.cc:620-657 + wmget.cc:971-1013; the file twin of awm_add_get_watermark_d): the input is read once and the output is never read
+ * back -- the output stage decodes the bytes it has just encoded for the file (the samples as the file holds them, after its sample format's
+ * quantisation) into HBM and `get` runs there.  Same file and same pattern list as the two calls; returns the number of patterns. */
+int awm_add_get_watermark_file (awm_ctx *ctx, const uint8_t key[16], const char *payload_hex, const char *in_path, const char *out_path,
+                                const awm_raw_format *raw_in, const awm_raw_format *raw_out, size_t max_out, awm_pattern *out);
 int awm_get_watermark_keys_file (awm_ctx *ctx, const uint8_t *keys, int n_keys, const char *in_path, const awm_raw_format *raw_in,
                                  size_t max_out, awm_pattern *out, int *key_of_pattern);
 
@@ -441,6 +447,8 @@ void awm_debug_set_soft_bits_generic (int on); /* K7: one thread per soft bit fo
 void awm_debug_set_chunk_stagger (int mode); /* get: phase offset between the chunk lanes -- 0 all chunks start together | 1 chunk i + 1 behind chunk i's
                                              * dB kernel | 2 behind its scan | -1 (default) 1 for streams of up to `lanes` chunks, 2 for longer ones */
 void awm_debug_set_resample_phase (int on);  /* K10: 1 (default) the phase-per-thread kernel for stereo 48 <-> 44.1 kHz | 0 the generic kernel (outputs identical) */
+void awm_debug_set_get_overlap (int on);    /* file level get: 1 the chunks start while the rest of the stream is still crossing PCIe (a loader thread, a mark per tile;
+                                             * streams of announced length at 44.1 kHz with two chunks or more) | 0 (default) the whole stream first: measured faster */
 void awm_debug_set_speed_compare_wide (int on); /* K14: 1 all relative speeds of a centre (<= 12) in one thread / 0 (default) groups of six: measured slower, see hip/speed.hip */
 void awm_debug_set_resample_var_mode (int mode); /* K12: bit 0 the stereo input window of a tile through LDS | bit 1 a workgroup keeps its coefficient
                                              * table for several tiles (default 2; outputs identical) */

@@ -296,3 +296,36 @@ def test_ctx_warm_up_and_trim(gpu, tmp_path):
         assert [key(p) for p in ctx.get_watermark(None, w)] == [key(p) for p in gpu.ctx.get_watermark(None, w)]
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("seconds,fmt,rate", [(200.5, "s16", 44100), (3700.0, "s16", 44100), (96.0, "s24be", 44100), (40.0, "f32", 44100), (120.0, "s16", 48000)])
+def test_file_add_then_get_as_one_call(gpu, tmp_path, seconds, fmt, rate):
+    """awm_add_get_watermark_file ("watermark, then verify"): the file of awm_add_watermark_file byte for byte and the pattern list of
+    awm_get_watermark_file on it -- without reading the file back: the output stage keeps the samples as the file holds them (after the
+    sample format's quantisation).  Tile loop (44.1 kHz: 3 tiles; 62 minutes: 40 tiles, four chunks), 24 bit big endian, float samples,
+    and the resampled path (48 kHz)."""
+    t, awm = gpu.torch, gpu.awm
+    bits, enc, big = {"s16": (16, 0, False), "s24be": (24, 0, True), "f32": (32, 2, False)}[fmt]
+    n = int(seconds * rate)
+    x = noise(gpu, n, 2, 7 + int(seconds)) * 0.9
+    raw_in = gpu.ctx.pcm_encode(x.reshape(-1), bits, enc, big, True).cpu().numpy()
+    del x
+    src, dst, dst2 = tmp_path / "in.raw", tmp_path / "out.raw", tmp_path / "out2.raw"
+    raw_in.tofile(src)
+    rf = awm.binding.RawFormat(2, rate, bits, enc, int(big))
+    key = lambda p: (round(p["time"], 6), p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
+    gpu.ctx.add_watermark_file(None, PAY, src, dst, rf, rf)
+    want = [key(p) for p in gpu.ctx.get_watermark_file(None, dst, rf)]
+    got = [key(p) for p in gpu.ctx.add_get_watermark_file(None, PAY, src, dst2, rf, rf)]
+    assert dst2.read_bytes() == dst.read_bytes()
+    assert got == want and any(p[4] == PAY for p in got)
+    # the same list with the chunks starting while the stream is still being loaded (the switch that is off by default)
+    awm.lib.awm_debug_set_get_overlap(1)
+    try:
+        assert [key(p) for p in gpu.ctx.get_watermark_file(None, dst, rf)] == want
+    finally:
+        awm.lib.awm_debug_set_get_overlap(0)
+    # and the context is back to normal: a plain `add` afterwards keeps nothing
+    gpu.ctx.add_watermark_file(None, PAY, src, dst2, rf, rf)
+    assert dst2.read_bytes() == dst.read_bytes()
+    assert [key(p) for p in gpu.ctx.get_watermark_file(None, dst2, rf)] == want
