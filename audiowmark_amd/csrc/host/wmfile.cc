@@ -1383,11 +1383,11 @@ get_watermark_multi (awm_ctx *ctx, const std::vector<Key>& key_list, const Devic
   return 0;
 }
 
-/* 1: the chunks of a file level `get` start while the rest of the stream is still crossing PCIe (below) | 0 (default): the whole stream
- * first.  Measured in round 6 (bench.py e2e, 60 min s16 stereo from tmpfs): 33.3 ms with the overlap against 21.6 without -- of the three
- * chunks of an hour only the first can start before the stream is (nearly) complete, and then its kernels share the GPU with the copies
- * and the sample decodes, which take longer than the chunk saves.  Kept behind the switch (results identical, tested both ways). */
-static int g_get_overlap = 0;
+/* 1 (default): the chunks of a file level `get` start while the rest of the stream is still crossing PCIe (below) | 0: the whole stream
+ * first, as in rounds 1 - 5.  Measured alternating on one file in the page cache (tools/gpu_get_overlap_ab.py, profiles/r06/get_overlap_ab.txt):
+ * 60 min of s16 stereo 15.8 - 17.5 against 17.1 - 17.7 ms, 8 h 111 - 113 against 134 - 135 ms (two boxes); pattern lists identical.  (Inside bench.py's add -> get loop the `get`
+ * that follows a fresh `add` is 8 - 10 ms slower either way: the output file's pages were created a moment ago.) */
+static int g_get_overlap = 1;
 extern "C" void awm_debug_set_get_overlap (int on) { g_get_overlap = on; }
 
 /* body of get_watermark (reference wmget.cc:971-1013): stream -> HBM (bounded host memory), loader resampling, chunk loop */

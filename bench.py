@@ -371,18 +371,22 @@ def e2e_leg(torch, awm, ctx, x, resident_ms):
         out["file_to_file_xRT"] = round(seconds / (best_add + best_get), 1)
         out["add_file_ms"] = round(best_add * 1e3, 2)
         out["get_file_ms"] = round(best_get * 1e3, 2)
-        # the file level `get` with the chunks starting while the stream is still crossing PCIe (awm_debug_set_get_overlap: measured slower,
-        # off by default); and "watermark, then verify" as ONE call: the output is never read back
+        # the file level `get` with the whole stream loaded before the first chunk starts (rounds 1 - 5) and with the chunks started while the
+        # stream is still crossing PCIe (default), ALTERNATING on the file in the page cache (the `get` behind a fresh `add` above is slower
+        # either way: the file's pages were created a moment ago); and "watermark, then verify" as ONE call: the output is never read back
         key = lambda p: (p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
+        alt = {0: [], 1: []}
+        same = True
+        for _ in range(4):
+            for mode in (0, 1):
+                awm.lib.awm_debug_set_get_overlap(mode)
+                t1 = time.perf_counter()
+                pats_m = ctx.get_watermark_file(None, dst, rf)
+                alt[mode].append(time.perf_counter() - t1)
+                same = same and [key(p) for p in pats_m] == [key(p) for p in pats]
         awm.lib.awm_debug_set_get_overlap(1)
-        best_plain = None
-        for _ in range(3):
-            t1 = time.perf_counter()
-            pats_plain = ctx.get_watermark_file(None, dst, rf)
-            best_plain = min(best_plain or 1e9, time.perf_counter() - t1)
-        awm.lib.awm_debug_set_get_overlap(0)
-        out["get_file_ms_chunks_started_during_the_load"] = round(best_plain * 1e3, 2)      # (the switch that is off by default)
-        out["get_file_same_patterns_either_way"] = [key(p) for p in pats_plain] == [key(p) for p in pats]
+        out["get_file_ms_alternating"] = {"whole_stream_first": round(min(alt[0]) * 1e3, 2), "chunks_started_during_the_load": round(min(alt[1]) * 1e3, 2),
+                                          "same_patterns": bool(same)}
         best_both = None
         for _ in range(3):
             if os.path.exists(dst2):

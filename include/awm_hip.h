@@ -447,8 +447,8 @@ void awm_debug_set_soft_bits_generic (int on); /* K7: one thread per soft bit fo
 void awm_debug_set_chunk_stagger (int mode); /* get: phase offset between the chunk lanes -- 0 all chunks start together | 1 chunk i + 1 behind chunk i's
                                              * dB kernel | 2 behind its scan | -1 (default) 1 for streams of up to `lanes` chunks, 2 for longer ones */
 void awm_debug_set_resample_phase (int on);  /* K10: 1 (default) the phase-per-thread kernel for stereo 48 <-> 44.1 kHz | 0 the generic kernel (outputs identical) */
-void awm_debug_set_get_overlap (int on);    /* file level get: 1 the chunks start while the rest of the stream is still crossing PCIe (a loader thread, a mark per tile;
-                                             * streams of announced length at 44.1 kHz with two chunks or more) | 0 (default) the whole stream first: measured faster */
+void awm_debug_set_get_overlap (int on);    /* file level get: 1 (default) the chunks start while the rest of the stream is still crossing PCIe (a loader thread, a mark per
+                                             * tile; streams of announced length at 44.1 kHz with two chunks or more) | 0 the whole stream first (rounds 1 - 5) */
 void awm_debug_set_speed_compare_wide (int on); /* K14: 1 all relative speeds of a centre (<= 12) in one thread / 0 (default) groups of six: measured slower, see hip/speed.hip */
 void awm_debug_set_resample_var_mode (int mode); /* K12: bit 0 the stereo input window of a tile through LDS | bit 1 a workgroup keeps its coefficient
                                              * table for several tiles (default 2; outputs identical) */

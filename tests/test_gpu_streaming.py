@@ -319,12 +319,12 @@ def test_file_add_then_get_as_one_call(gpu, tmp_path, seconds, fmt, rate):
     got = [key(p) for p in gpu.ctx.add_get_watermark_file(None, PAY, src, dst2, rf, rf)]
     assert dst2.read_bytes() == dst.read_bytes()
     assert got == want and any(p[4] == PAY for p in got)
-    # the same list with the chunks starting while the stream is still being loaded (the switch that is off by default)
-    awm.lib.awm_debug_set_get_overlap(1)
+    # the same list with the whole stream loaded before the first chunk starts (default: the chunks start during the load)
+    awm.lib.awm_debug_set_get_overlap(0)
     try:
         assert [key(p) for p in gpu.ctx.get_watermark_file(None, dst, rf)] == want
     finally:
-        awm.lib.awm_debug_set_get_overlap(0)
+        awm.lib.awm_debug_set_get_overlap(1)
     # and the context is back to normal: a plain `add` afterwards keeps nothing
     gpu.ctx.add_watermark_file(None, PAY, src, dst2, rf, rf)
     assert dst2.read_bytes() == dst.read_bytes()
