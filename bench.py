@@ -566,6 +566,7 @@ def main():
     ap.add_argument("--minutes", type=float, default=None, help="audio minutes (60min: per GPU, default 60; 8h: in total, default 480)")
     ap.add_argument("--clips", type=int, default=1024, help="--config clips: clips in total")
     ap.add_argument("--cpu-sample-seconds", type=float, default=3600.0)
+    ap.add_argument("--refine-form", type=int, default=-1, help="A / B only: the form of K4s (awm_debug_set_refine_form): 3 = rounds 3 - 5, 4 = default, 5 = update term in float")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-e2e", action="store_true")
     ap.add_argument("--no-detect-speed-config", action="store_true", help="skip the 48 kHz --detect-speed configuration (BASELINE configs[2])")
@@ -613,6 +614,8 @@ def main():
     ctx = awm.Context(local_rank)
     awm.lib.awm_debug_set_viterbi_persistent({"auto": -1, "chain": 0, "one-launch": 1}[args.viterbi_form])
     awm.lib.awm_ctx_set_chunk_lanes(ctx._h, args.lanes)
+    if args.refine_form >= 0:
+        awm.lib.awm_debug_set_refine_form(args.refine_form)
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     strong = args.config == "8h"
