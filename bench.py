@@ -535,6 +535,35 @@ def ensure_ranks(args, argv):
     os.execv(sys.executable, cmd)
 
 
+def _shard_plan(args, sharded_path, pipe, dist, world, rate):
+    """one stream over several ranks: what every rank held, worked on and sent in the LAST timed step (plan: awm_sharded_plan, pure host;
+    bytes: counted by the transport), so that a scaling curve explains itself"""
+    if pipe is None:
+        return None
+    from audiowmark_amd import sharded as _sh
+    lengths = list(pipe.part.lengths)
+    entries = _sh.plan(lengths)
+    per_chunk = {}
+    for c, r, _, k in entries:
+        if k:
+            per_chunk.setdefault(c, set()).add(r)
+    mine_stats = dict(pipe.comm.stats)
+    rows = [None] * world
+    if dist is not None and world > 1:
+        dist.all_gather_object(rows, mine_stats)
+    else:
+        rows = [mine_stats]
+    return {"span_frames": lengths, "chunks": len(per_chunk),
+            "chunks_shared_by_several_ranks": sum(1 for v in per_chunk.values() if len(v) > 1),
+            "per_rank": [{"rank": r, "span_seconds": round(lengths[r] / rate, 1),
+                          "start_frames": sum(k for _, rr, _, k in entries if rr == r),
+                          "chunks_local": sum(1 for v in per_chunk.values() if v == {r}),
+                          "chunks_shared": sum(1 for v in per_chunk.values() if r in v and len(v) > 1),
+                          "sent_in_the_last_step": rows[r]} for r in range(world)],
+            "transport": "RCCL (device records) + gloo side group (host records)" if pipe.comm.nccl and pipe.comm.host_group is not None
+                         else ("RCCL" if pipe.comm.nccl else "gloo")}
+
+
 def rank_check(args):
     """--rank-check-only: the rendezvous of the N ranks and nothing else, over gloo, without touching a GPU (CPU test of the
     launch path: `python bench.py --gpus 2 --rank-check-only` must report ranks_seen == 2)."""
@@ -722,29 +751,10 @@ def main():
     # one stream over several ranks: what every rank held, worked on and sent in the LAST timed step, so that a scaling curve explains
     # itself (plan: awm_sharded_plan, pure host; bytes: counted by the transport)
     shard_plan = None
-    if sharded_path and args.config != "clips":
-        from audiowmark_amd import sharded as _sh
-        lengths = list(pipe.part.lengths)
-        entries = _sh.plan(lengths)
-        per_chunk = {}
-        for c, r, _, k in entries:
-            if k:
-                per_chunk.setdefault(c, set()).add(r)
-        mine_stats = dict(pipe.comm.stats)
-        rows = [None] * world
-        if dist is not None and world > 1:
-            dist.all_gather_object(rows, mine_stats)
-        else:
-            rows = [mine_stats]
-        shard_plan = {"span_frames": lengths, "chunks": len(per_chunk),
-                      "chunks_shared_by_several_ranks": sum(1 for v in per_chunk.values() if len(v) > 1),
-                      "per_rank": [{"rank": r, "span_seconds": round(lengths[r] / RATE, 1),
-                                    "start_frames": sum(k for _, rr, _, k in entries if rr == r),
-                                    "chunks_local": sum(1 for v in per_chunk.values() if v == {r}),
-                                    "chunks_shared": sum(1 for v in per_chunk.values() if r in v and len(v) > 1),
-                                    "sent_in_the_last_step": rows[r]} for r in range(world)],
-                      "transport": "RCCL (device records) + gloo side group (host records)" if pipe.comm.nccl and pipe.comm.host_group is not None
-                                   else ("RCCL" if pipe.comm.nccl else "gloo")}
+    try:
+        shard_plan = _shard_plan(args, sharded_path, pipe if (sharded_path and args.config != "clips") else None, dist, world, RATE)
+    except Exception as e:                                   # (an explanation, never a reason to lose the line)
+        shard_plan = {"error": repr(e)}
     single_stream = args.config == "60min" and world == 1 and not args.sharded
     prof = read_prof(awm, ctx)
     two_calls_ms = None
