@@ -437,6 +437,7 @@ struct SpeedCompareArgs
   int                   frames_per_block, steps_per_frame, pad_start, rows_per_bit;
   double                min_delta;
   unsigned long long   *best;          // [items] bits of the best quality (zero initialised)
+  int                   fold_groups = 0, n_ranges = 0;   // set by the launcher: groups of speeds folded into blockIdx.x (see launch_speed_compare)
 };
 hipError_t launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items);
 

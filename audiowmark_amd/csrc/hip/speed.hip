@@ -373,12 +373,24 @@ speed_compare_kernel (SpeedCompareArgs a)
   __shared__ int2   s_fo[NS][BIT_COLS];                        // frame offsets in Q16 (whole rows x 8, fraction) of the current bit
   __shared__ double s_best[NS][4];
   const int center = blockIdx.y;
+  // fold_groups = G: the G groups of speeds of a (state range, centre) are the workgroups x = 8 G (r / 8) + 8 g + r % 8 -- G workgroups
+  // that are dispatched within 8 G places of each other AND on the same XCD (x mod 8, the grid's width is a multiple of 8), so that
+  // the second group finds the rows of the matrix in that XCD's L2
+  int range = blockIdx.x, group = blockIdx.z;
+  if (a.fold_groups)
+    {
+      const int span = 8 * a.fold_groups, rem = range % span;
+      group = rem >> 3;
+      range = (range / span) * 8 + (rem & 7);
+      if (range >= a.n_ranges)
+        return;                                                // (uniform for the workgroup)
+    }
   const SpeedCenterDev cd = a.centers[center];
-  const int s0 = blockIdx.z * NS;
+  const int s0 = group * NS;
   const int ns = a.items_per_center - s0 < NS ? a.items_per_center - s0 : NS;       // speeds this workgroup has
   const SpeedItemDev *items = a.items + center * a.items_per_center + s0;
-  const int state = blockIdx.x * blockDim.x + threadIdx.x;
-  const int wave_state = blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+  const int state = range * blockDim.x + threadIdx.x;
+  const int wave_state = range * blockDim.x + (threadIdx.x & ~63);
   const long long rows = cd.rows;
   const unsigned n_rows8 = unsigned (rows) * 8u;
   const bool active = state < a.pad_start && rows > 0;
@@ -544,6 +556,10 @@ speed_compare_kernel (SpeedCompareArgs a)
 // registers = two waves per SIMD for a kernel that lives on the latency of its gathers: 0.482 against 0.447 ms per launch; off)
 int g_speed_compare_wide = 0;
 extern "C" void awm_debug_set_speed_compare_wide (int on) { g_speed_compare_wide = on; }
+// (A / B, same tool: 1 = the groups of six of a (state range, centre) as neighbours on one XCD instead of a grid dimension of their own --
+// the second group's gathers find the first one's lines in that XCD's L2: 0.447 against 0.454 ms per launch, results identical; on)
+int g_speed_compare_fold = 1;
+extern "C" void awm_debug_set_speed_compare_fold (int on) { g_speed_compare_fold = on; }
 
 hipError_t
 launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items)
@@ -562,6 +578,13 @@ launch_speed_compare (hipStream_t st, const SpeedCompareArgs& a, int n_items)
   // matrices, the two groups of a centre run on different XCDs)
   if (g_speed_compare_wide && per > 6 && per <= 12 && (long long) ranges * a.n_centers >= 1024)
     hipLaunchKernelGGL (speed_compare_kernel<12>, dim3 (ranges, unsigned (a.n_centers), 1), dim3 (256), 0, st, a);
+  else if ((long long) ranges * a.n_centers * groups6 >= 1024 && g_speed_compare_fold && groups6 > 1)
+    {
+      SpeedCompareArgs f = a;
+      f.fold_groups = int (groups6);
+      f.n_ranges = int (ranges);
+      hipLaunchKernelGGL (speed_compare_kernel<6>, dim3 ((ranges + 7) / 8 * 8 * groups6, unsigned (a.n_centers), 1), dim3 (256), 0, st, f);
+    }
   else if ((long long) ranges * a.n_centers * groups6 >= 1024)
     hipLaunchKernelGGL (speed_compare_kernel<6>, dim3 (ranges, unsigned (a.n_centers), groups6), dim3 (256), 0, st, a);
   else

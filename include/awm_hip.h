@@ -450,6 +450,7 @@ void awm_debug_set_resample_phase (int on);  /* K10: 1 (default) the phase-per-t
 void awm_debug_set_get_overlap (int on);    /* file level get: 1 (default) the chunks start while the rest of the stream is still crossing PCIe (a loader thread, a mark per
                                              * tile; streams of announced length at 44.1 kHz with two chunks or more) | 0 the whole stream first (rounds 1 - 5) */
 void awm_debug_set_speed_compare_wide (int on); /* K14: 1 all relative speeds of a centre (<= 12) in one thread / 0 (default) groups of six: measured slower, see hip/speed.hip */
+void awm_debug_set_speed_compare_fold (int on); /* K14: 1 (default) the groups of six of a (state range, centre) are neighbouring workgroups on one XCD / 0 a grid dimension of their own */
 void awm_debug_set_resample_var_mode (int mode); /* K12: bit 0 the stereo input window of a tile through LDS | bit 1 a workgroup keeps its coefficient
                                              * table for several tiles (default 2; outputs identical) */
 void awm_debug_set_speed_overlap (int on);   /* get with a speed search: 1 (default) the plain decode of the chunks runs beside the speed part, on lanes

@@ -8,6 +8,7 @@
 #         k4s              tools/gpu_k4s_forms.py + tools/gpu_k4s_alone.py (forms of the refinement's sliding DFT)
 #         census           tools/gpu_census_three_way.py (this library against both builds of the reference, identical bytes)
 #         io               tools/gpu_io_sweep.py 60 quick + tools/gpu_first_calls.py
+#         k14              tools/gpu_speed_compare_ab.py (forms of K14 inside configs[2])        stagger   tools/gpu_stagger.py
 #         final            tools/gpu_final.sh <tag>: the measurements behind profiles/<tag>
 set -u
 TAG=${1:?tag}; shift
@@ -28,6 +29,8 @@ for step in "$@"; do
     census)     timeout 1800 python tools/gpu_census_three_way.py 1 14 > $O/census_three_way.log 2>&1; echo "census rc $?"; tail -1 $O/census_three_way.log | cut -c1-1500; cp gpurun_out/census_three_way.json $O/ 2>/dev/null ;;
     io)         timeout 300 python tools/gpu_io_sweep.py 60 quick > $O/io_sweep.log 2>&1; cp gpurun_out/io_sweep.json $O/ 2>/dev/null; tail -1 $O/io_sweep.log | cut -c1-900
                 timeout 300 python tools/gpu_first_calls.py 2>&1 | grep -v amdgpu > $O/first_calls.txt; tail -5 $O/first_calls.txt ;;
+    k14)        timeout 600 python tools/gpu_speed_compare_ab.py 2>&1 | grep -v amdgpu > $O/speed_compare_ab.txt; cat $O/speed_compare_ab.txt | cut -c1-420 ;;
+    stagger)    timeout 600 python tools/gpu_stagger.py 2>&1 | grep -v amdgpu > $O/chunk_stagger.txt; cat $O/chunk_stagger.txt ;;
     final)      bash tools/gpu_final.sh $TAG ;;
     *)          echo "unknown step $step" ;;
   esac

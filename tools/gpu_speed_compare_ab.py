@@ -10,13 +10,15 @@ import bench
 import audiowmark_amd as awm
 ctx = awm.Context(0)
 first = None
-for wide in (1, 0, 1, 0):
-    awm.lib.awm_debug_set_speed_compare_wide(wide)
+for wide in (2, 0, 2, 0, 1, 0):
+    awm.lib.awm_debug_set_speed_compare_wide(1 if wide == 1 else 0)
+    awm.lib.awm_debug_set_speed_compare_fold(1 if wide == 2 else 0)
     r = bench.detect_speed_config(torch, awm, ctx, None, bench.PAYLOAD, 60.0, 4)
     k14 = [k for k in (r.get("kernels_one_lane") or []) if "speed_compare" in k.get("scope", "")]
     sig = (r.get("patterns"), r.get("payload_matches"), r.get("detected_speeds"))
     if first is None:
         first = sig
-    print("wide %d: get --detect-speed %.3f ms, first call %s, K14 %s, same results as the first run: %s"
+    print("form %d (0 groups of six, 1 all speeds in one thread, 2 groups of six folded onto one XCD): get --detect-speed %.3f ms, first call %s, K14 %s, same results as the first run: %s"
           % (wide, r.get("get_detect_speed_ms", -1), (r.get("first_call_ms") or {}).get("get_detect_speed"), json.dumps(k14)[:300], sig == first), flush=True)
-awm.lib.awm_debug_set_speed_compare_wide(1)
+awm.lib.awm_debug_set_speed_compare_wide(0)
+awm.lib.awm_debug_set_speed_compare_fold(1)
