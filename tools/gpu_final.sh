@@ -10,6 +10,10 @@ mkdir -p $O
 cd $R
 export GPU_MAX_HW_QUEUES=16
 bash tools/profile_bench.sh $TAG > $O/profile.log 2>&1; tail -14 $O/profile.log
+# the bench lines below shall carry the traffic of THESE passes: put it where bench.py looks (the box's copy of profiles/; the container copies the
+# same files to profiles/$TAG afterwards)
+mkdir -p profiles/$TAG && cp $O/traffic.json profiles/$TAG/traffic.json && \
+  python -c "import sys; sys.argv = ['x']; import bench; print (bench.hip_sources_digest())" > profiles/$TAG/HIP_SOURCES_SHA256
 timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 400 $O/bench_n1.json
 timeout 600 python bench.py --steps 10 --warmup 3 --sharded --no-e2e --no-cpu-baseline --no-detect-speed-config > $O/bench_n1_sharded.json 2>/dev/null
 timeout 900 python bench.py --config 8h --steps 8 --warmup 5 > $O/bench_8h.json 2>/dev/null; tail -c 300 $O/bench_8h.json
