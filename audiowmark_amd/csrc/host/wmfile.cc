@@ -462,7 +462,9 @@ load_stream_to_device (awm_ctx *ctx, AudioInputStream *in_stream, DevBuffer& d_p
   // The announced length only sizes the first allocation (the loop below grows the buffer when more arrives).  A length whose
   // float32 size would not fit a device buffer -- a crafted ds64 / RIFF size on a pipe, where it cannot be checked against the
   // file -- is treated like an unknown one: cap_frames * C * 4 must never wrap.
-  const size_t announced = rd.announced_frames();
+  size_t announced = rd.announced_frames();
+  if (live && announced == AudioInputStream::N_FRAMES_UNKNOWN)
+    announced = live->n_frames;                  // (headerless PCM read by ONE thread, awm_debug_set_io_flags (0): the caller took the length from the file)
   const size_t max_frames = DevBuffer::MAX_BYTES / (size_t (C) * sizeof (float));
   size_t cap_frames = (announced != AudioInputStream::N_FRAMES_UNKNOWN && announced < max_frames) ? announced + 1 : STAGE_FRAMES * 4;
   if (d_pcm.reserve (cap_frames * C * sizeof (float)))

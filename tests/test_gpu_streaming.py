@@ -325,6 +325,13 @@ def test_file_add_then_get_as_one_call(gpu, tmp_path, seconds, fmt, rate):
         assert [key(p) for p in gpu.ctx.get_watermark_file(None, dst, rf)] == want
     finally:
         awm.lib.awm_debug_set_get_overlap(1)
+    # ... and with ONE reader thread instead of the I/O workers (headerless PCM then announces no length itself: the chunks during the load
+    # take it from the file -- round 6: "input stream is longer than announced" for streams of two chunks or more)
+    awm.lib.awm_debug_set_io_flags(0)
+    try:
+        assert [key(p) for p in gpu.ctx.get_watermark_file(None, dst, rf)] == want
+    finally:
+        awm.lib.awm_debug_set_io_flags(1)
     # and the context is back to normal: a plain `add` afterwards keeps nothing
     gpu.ctx.add_watermark_file(None, PAY, src, dst2, rf, rf)
     assert dst2.read_bytes() == dst.read_bytes()
