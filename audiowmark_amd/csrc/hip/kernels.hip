@@ -2591,457 +2591,21 @@ sync_db_sliding4f_bands_kernel (DevTables t, SyncDbArgs a)
   sync_db_sliding4_body<true, NB> (t, a);
 }
 
-/* K4s with the UPDATE TERM ON THE MATRIX CORES (form 6, round 6).  Per bin and offset the recurrence
- *   acc = R + sum_{j<8} d[j] W^{jk},  R' = acc rho
- * spends 15 of its 23 double precision operations on the sum -- a [bins x 8] . [8 x columns] product whose left factor (the twiddle
- * factors) is the same for every stream and channel.  v_mfma_f64_4x4x4f64 computes four independent D = A B + C of 4 x 4 x 4 per
- * instruction; its additions run from C in ascending k with one rounding per step (tools/mfma_f64_probe.hip), i.e.
- *   fma (a3, b3, fma (a2, b2, fma (a1, b1, fma (a0, b0, c))))
- * -- with C = R, k = the sample index and two chained instructions for the eight samples that IS the chain above, operation by
- * operation: the values are those of forms 0 / 3 / 4 to the last bit (tests/test_gpu_parity.py::test_refinement_kernel_forms).
- * What it takes is four COLUMNS that share the twiddles: a wave carries TWO streams (two sync frames of a candidate) x two channels.
- *   D / C lane l: row l >> 2 (of 16), column l & 3 = 2 stream + channel.  A row holds six adjacent bins (19 + 6 row + g, g < 6: 14 rows =
- *   the 84 bins; rows 14, 15 repeat rows 12, 13 and store nowhere), one instruction pair per g and per real / imaginary part:
- *   24 matrix instructions per offset for 336 bin-channels, beside 60 vector operations per lane (rotation, von Hann combination,
- *   conversions) instead of 138 for the same work in form 4.
- *   The neighbours of a row's outer bins come from the lanes 4 below / above through ds_bpermute, channel 1's dB values from the lane
- *   next door (DPP); the rows leave every 16 offsets, 16 bytes per lane (half a line per row: LDS has room for 16 columns of two streams). */
-template<int ROWS> struct S6Lds
-{
-  static constexpr int LD        = SL_TILE + 1;                // tile row length in floats
-  static constexpr int OFF_TILE1 = ROWS * LD * 4;              // the second stream's tile
-  static constexpr int OFF_DUMMY = 2 * ROWS * LD * 4;          // where the stores nobody reads go: word lane + column
-  static constexpr int OFF_DELTA = ((OFF_DUMMY + (64 + SL_TILE) * 4 + 15) / 16) * 16;
-  static constexpr int TOTAL     = OFF_DELTA + SL_TILE * 4 * 8 * 8;      // [transition][column][j] doubles
-  static constexpr int BYTES     = TOTAL > XBUF_ELEMS * 16 ? TOTAL : XBUF_ELEMS * 16;
-};
-
-// lane -> element of the operands of v_mfma_f64_4x4x4f64 (tools/mfma_f64_probe.hip)
-// D / C: lane 16 i + 4 b + j holds element (i, j) of block b; A: lane 16 k + 4 b + i holds A_b[i][k]; B: lane 16 k + 4 b + j holds B_b[k][j].
-// The 16 rows of the four blocks are numbered 4 i + b = (D lane) >> 2, so that the next row is always four lanes up.
-__device__ __forceinline__ int mfma4_a_row (int lane) { return (lane & 3) * 4 + ((lane >> 2) & 3); }
-__device__ __forceinline__ int mfma4_a_k (int lane)   { return lane >> 4; }
-__device__ __forceinline__ int mfma4_b_k (int lane)   { return lane >> 4; }
-__device__ __forceinline__ int mfma4_b_col (int lane) { return lane & 3; }
-
-template<int ROWS> __device__ __forceinline__ void
-sync_db_sliding6_body (const DevTables& t, const SyncDbArgs& a)
-{
-  constexpr int CV = 2, NG = 6;
-  typedef S6Lds<ROWS> L;
-  __shared__ __attribute__ ((aligned (16))) unsigned char s_mem[WAVES][L::BYTES];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane (threadIdx.x >> 6);
-  const long long stream0 = 2 * ((long long) blockIdx.x * WAVES + wave);
-  if (stream0 >= a.n_streams)
-    return;
-  // ---- the two streams of the wave (wave uniform)
-  long long out_slot[2], base[2], sil_first[2], sil_last[2], tslice[2];
-  int count[2];
-#pragma unroll
-  for (int s = 0; s < 2; s++)
-    {
-      const long long stream = stream0 + s < a.n_streams ? stream0 + s : stream0;
-      tslice[s] = wave_uniform (a.tables_per_slice ? (a.range_index ? a.range_index[stream / a.range_div] : stream / a.range_div) : 0);
-      out_slot[s] = wave_uniform (a.row_perm ? (stream / a.rows_per_plane) * a.rows_per_plane
-                                               + a.row_perm[tslice[s] * a.rows_per_plane + stream % a.rows_per_plane] : stream);
-      base[s] = wave_uniform (sync_stream_base (a, stream));
-      count[s] = stream0 + s < a.n_streams ? __builtin_amdgcn_readfirstlane (a.stream_count ? a.stream_count[stream] : a.count0) : 0;
-      if (count[s] < 0)
-        count[s] = 0;
-      sync_stream_range (a, stream, sil_first[s], sil_last[s]);
-      sil_first[s] = wave_uniform (sil_first[s]);
-      sil_last[s] = wave_uniform (sil_last[s]);
-      // every window of the stream lies in the silence around the material: no row, no flag (as the other forms)
-      if (count[s] > 0 && a.have && ((base[s] + 8LL * (count[s] - 1) + 1024) * CV < sil_first[s] || base[s] * CV > sil_last[s]))
-        {
-          if (lane < count[s])
-            a.have[out_slot[s] * a.have_stream_stride + lane] = 0;
-          if (lane == 0 && count[s] > 64)
-            a.have[out_slot[s] * a.have_stream_stride + 64] = 0;
-          count[s] = 0;
-        }
-    }
-  if (count[0] <= 0 && count[1] <= 0)
-    return;
-  if (count[0] <= 0)
-    base[0] = base[1];                                        // (a stream without offsets reads where the other one reads and drops it)
-  if (count[1] <= 0)
-    base[1] = base[0];
-  const int maxcount = count[0] > count[1] ? count[0] : count[1];
-  unsigned char *mem = s_mem[wave];
-  double2 *xbuf = reinterpret_cast<double2 *> (mem);
-  double *delta = reinterpret_cast<double *> (mem + L::OFF_DELTA);
-  // ---- the lane in the result: row (six adjacent bins), column = (stream, channel)
-  const int col = lane & 3, sl = col >> 1, ch = col & 1, row16 = lane >> 2;
-  const int kA = 19 + NG * (row16 < 14 ? row16 : row16 - 2);
-
-  // ---- first offset: the plain DFT bins from the wave FFT in double, scaled by 2^-10 (as form 4), stream after stream
-  double2 R[NG];
-#pragma unroll
-  for (int g = 0; g < NG; g++)
-    R[g] = make_double2 (0.0, 0.0);
-  int nz[2][2] = { { 0, 0 }, { 0, 0 } };                       // non-zero samples of the current window, per stream and channel (wave uniform)
-  {
-    double2 tw1[7], tw2[7], ws[NG];
-#pragma unroll
-    for (int k = 1; k < 8; k++)
-      {
-        tw1[k - 1] = t.tw512d[lane * k];
-        tw2[k - 1] = t.tw512d[8 * (lane & 7) * k];
-      }
-#pragma unroll
-    for (int g = 0; g < NG; g++)
-      ws[g] = t.slide[(kA + g - 19) * 9 + 1];
-#pragma unroll
-    for (int s = 0; s < 2; s++)
-      {
-        if (count[s] <= 0)
-          continue;
-        float in[CV][16];
-        fetch_stereo (a.pcm, base[s], 1024, lane, in[0], in[1]);
-#pragma unroll
-        for (int j = 0; j < 16; j++)
-          {
-            nz[s][0] += __builtin_popcountll (__builtin_amdgcn_ballot_w64 (in[0][j] != 0.f));
-            nz[s][1] += __builtin_popcountll (__builtin_amdgcn_ballot_w64 (in[1][j] != 0.f));
-          }
-#pragma unroll
-        for (int c = 0; c < CV; c++)
-          {
-            double2 z[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++)
-              z[j] = make_double2 (double (in[c][2 * j]), double (in[c][2 * j + 1]));
-            fft512_forward_d (z, xbuf, tw1, tw2, lane);
-            xbuf[0 * 64 + lane] = z[0];
-            xbuf[1 * 64 + lane] = z[1];
-            xbuf[6 * 64 + lane] = z[6];
-            xbuf[7 * 64 + lane] = z[7];
-            wave_sync();
-            if (col == 2 * s + c)
-              {
-#pragma unroll
-                for (int g = 0; g < NG; g++)
-                  {
-                    const int k = kA + g;
-                    const double2 r = real_split_d (xbuf[zpos (k)], xbuf[zpos (512 - k)], ws[g]);
-                    R[g] = make_double2 (r.x * 0x1p-10, r.y * 0x1p-10);
-                  }
-              }
-            wave_sync();
-          }
-      }
-  }
-  // ---- the lane's constants
-  int k_tab = kA - 19;
-  asm volatile ("" : "+v" (k_tab));                           // keep the tables' registers out of the transform above (no hoisting)
-  double2 rho[NG];                                            // e^{+2 pi i 8 k / N}
-#pragma unroll
-  for (int g = 0; g < NG; g++)
-    rho[g] = t.slide[(k_tab + g) * 9 + 8];
-  // the lane in the left factor: A[row][k] = real / imaginary part of e^{-2 pi i bin j / N}, j = k (first instruction), 4 + k (second)
-  double a_re[NG][2], a_im[NG][2];
-  {
-    const int arow = mfma4_a_row (lane), ak = mfma4_a_k (lane);
-    int a_tab = NG * (arow < 14 ? arow : arow - 2);
-    asm volatile ("" : "+v" (a_tab));
-#pragma unroll
-    for (int g = 0; g < NG; g++)
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-        {
-          const double2 w = t.slide[(a_tab + g) * 9 + 4 * h + ak];
-          a_re[g][h] = w.x;
-          a_im[g][h] = w.y;
-        }
-  }
-  // ... in the right factor: B[k][column] = the sample difference j = k / 4 + k of the column's stream and channel
-  const int b_at = (mfma4_b_col (lane) * 8 + mfma4_b_k (lane)) * 8;             // byte offset inside a transition's 4 x 8 doubles
-  // where the lane's six dB values go: channel 0's lanes write the rows of their bands into their stream's tile, one column further
-  // per offset; every other store keeps hitting a word of its own
-  int tile_addr[NG];
-  {
-    const long long stream = stream0 + sl < a.n_streams ? stream0 + sl : stream0;
-    const long long ts = sl ? tslice[1] : tslice[0];
-    const unsigned char *pos = a.band_pos ? a.band_pos + (ts * a.rows_per_plane + stream % a.rows_per_plane) * NB : nullptr;
-#pragma unroll
-    for (int g = 0; g < NG; g++)
-      {
-        const int band = kA + g - MIN_BAND;
-        const bool in_range = row16 < 14 && ch == 0 && band >= 0 && band < NB;
-        const int row = in_range ? (pos ? int (pos[band]) : band) : 255;
-        tile_addr[g] = row < ROWS ? sl * L::OFF_TILE1 + row * L::LD * 4 : L::OFF_DUMMY + lane * 4;
-      }
-  }
-  int tile_col = 0;                                            // (wave uniform, bytes)
-  const int my_count = sl ? count[1] : count[0];
-  const int lower = ((lane - 4) & 63) * 4, upper = ((lane + 4) & 63) * 4;      // ds_bpermute addresses of the rows below / above (same column)
-  // ---- sample feed, per stream as in form 4: sixteen transitions at once, a block of steps ahead
-  constexpr int FPL = 2 * CV;
-  float f_in[2][FPL], f_out[2][FPL];
-  typedef float v2f __attribute__ ((ext_vector_type (2)));
-  typedef __attribute__ ((address_space (1))) v2f global_v2f;
-  auto fetch_block = [&] (auto sc, int q) {
-    constexpr int s = decltype (sc)::value;
-    if (SL_TILE * q >= maxcount)
-      return;
-    const global_float *p_out = uniform_global (a.pcm + (base[s] + 128LL * q) * CV);
-    const int trans = SL_TILE * q + (lane >> 2);
-    const unsigned at_out = trans < count[s] ? unsigned (lane * FPL) : 0u;
-    const unsigned at_in = trans + 1 < count[s] ? unsigned (lane * FPL + 1024 * CV) : at_out;
-#pragma unroll
-    for (int i = 0; i < FPL; i += 2)
-      {
-        const v2f vo = *(const global_v2f *) (p_out + at_out + i), vi = *(const global_v2f *) (p_out + at_in + i);
-        f_out[s][i] = vo.x; f_out[s][i + 1] = vo.y;
-        f_in[s][i] = vi.x;  f_in[s][i + 1] = vi.y;
-      }
-  };
-  // per block of 16 offsets, one bit per offset at bit 4 * offset (see form 4), per column / stream
-  unsigned long long zmask[4] = { 0, 0, 0, 0 }, rmask[4] = { 0, 0, 0, 0 }, skipmask[2] = { 0, 0 };
-  auto publish_block = [&] (auto sc, int t0) {
-    constexpr int s = decltype (sc)::value;
-    const int tr = lane >> 2, jj = (lane & 3) * 2;
-    {
-      const bool need = t0 + tr + 1 < count[s], have_out = t0 + tr < count[s];
-#pragma unroll
-      for (int i = 0; i < FPL; i++)
-        {
-          f_in[s][i] = need ? f_in[s][i] : 0.f;
-          f_out[s][i] = have_out ? f_out[s][i] : 0.f;
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < FPL; i++)
-      delta[(tr * 4 + 2 * s + (i & 1)) * 8 + jj + (i >> 1)] = (double (f_in[s][i]) - double (f_out[s][i])) * 0x1p-10;
-#pragma unroll
-    for (int c = 0; c < CV; c++)
-      {
-        int dn = (f_in[s][c] != 0.f) - (f_out[s][c] != 0.f) + (f_in[s][CV + c] != 0.f) - (f_out[s][CV + c] != 0.f);
-        dn += __shfl_xor (dn, 1);
-        dn += __shfl_xor (dn, 2);
-        int incl = dn;
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1)
-          {
-            const int v = __shfl_up (incl, o);
-            incl += lane >= o ? v : 0;
-          }
-        const bool first_lane = (lane & 3) == 0;
-        zmask[2 * s + c] = __builtin_amdgcn_ballot_w64 (first_lane && nz[s][c] + (incl - dn) - int (f_out[s][c] != 0.f) == 0);
-        rmask[2 * s + c] = __builtin_amdgcn_ballot_w64 (first_lane && nz[s][c] + incl == 0);
-        nz[s][c] += __builtin_amdgcn_readlane (incl, 63);
-      }
-    const long long idx = base[s] + 8LL * (t0 + (lane >> 2));
-    skipmask[s] = __builtin_amdgcn_ballot_w64 ((lane & 3) == 0 && (((idx + 1024) * CV < sil_first[s]) || (idx * CV > sil_last[s])));
-  };
-  const std::integral_constant<int, 0> S0;
-  const std::integral_constant<int, 1> S1;
-  fetch_block (S0, 0);
-  fetch_block (S1, 0);
-  unsigned long long have_mask[2] = { 0, 0 };
-  bool have_64[2] = { false, false };
-  const int no_store = a.xcd_interleave & 8;                  // (measurement only: tools/gpu_k4s_alone.py)
-  publish_block (S0, 0);
-  publish_block (S1, 0);
-  wave_sync();
-  fetch_block (S0, 1);
-  fetch_block (S1, 1);
-  for (int t0 = 0; t0 < maxcount; t0 += SL_TILE)
-    {
-      const int n_cols = maxcount - t0 < SL_TILE ? maxcount - t0 : SL_TILE;
-      for (int cc = 0; cc < n_cols; cc++)
-        {
-          const int step = t0 + cc;
-          const unsigned sh = 4u * unsigned (cc);
-          // (a stream that has no such offset -- the shorter of the two, an odd stream's missing partner -- must not send the wave down the
-          // careful path with its all-zero window)
-          const unsigned live_bits = unsigned (step < count[0]) | unsigned (step < count[1]) << 1;
-          const unsigned zero_bits = (unsigned ((zmask[0] >> sh) & 1) | unsigned ((zmask[1] >> sh) & 1) << 1 | unsigned ((zmask[2] >> sh) & 1) << 2
-                                      | unsigned ((zmask[3] >> sh) & 1) << 3) & ((live_bits & 1 ? 3u : 0u) | (live_bits & 2 ? 12u : 0u));
-          const unsigned skip_bits = (unsigned ((skipmask[0] >> sh) & 1) | unsigned ((skipmask[1] >> sh) & 1) << 1) & live_bits;
-          // ---- the right factor of this transition
-          const double b_lo = *reinterpret_cast<const double *> (reinterpret_cast<const unsigned char *> (delta) + cc * 4 * 8 * 8 + b_at);
-          const double b_hi = *reinterpret_cast<const double *> (reinterpret_cast<const unsigned char *> (delta) + cc * 4 * 8 * 8 + b_at + 4 * 8);
-          // ---- output for this fine offset: X[k] = (2 R[k] - (R[k-1] + R[k+1])) / 1024, the scaling is in R
-          double2 up, dn;
-          {
-            const int ux0 = __builtin_amdgcn_ds_bpermute (lower, __double2loint (R[NG - 1].x)), ux1 = __builtin_amdgcn_ds_bpermute (lower, __double2hiint (R[NG - 1].x));
-            const int uy0 = __builtin_amdgcn_ds_bpermute (lower, __double2loint (R[NG - 1].y)), uy1 = __builtin_amdgcn_ds_bpermute (lower, __double2hiint (R[NG - 1].y));
-            const int dx0 = __builtin_amdgcn_ds_bpermute (upper, __double2loint (R[0].x)), dx1 = __builtin_amdgcn_ds_bpermute (upper, __double2hiint (R[0].x));
-            const int dy0 = __builtin_amdgcn_ds_bpermute (upper, __double2loint (R[0].y)), dy1 = __builtin_amdgcn_ds_bpermute (upper, __double2hiint (R[0].y));
-            up = make_double2 (__hiloint2double (ux1, ux0), __hiloint2double (uy1, uy0));
-            dn = make_double2 (__hiloint2double (dx1, dx0), __hiloint2double (dy1, dy0));
-          }
-          float abs2[NG], db[NG];
-#pragma unroll
-          for (int g = 0; g < NG; g++)
-            {
-              const double2 lo = g == 0 ? up : R[g - 1], hi = g == NG - 1 ? dn : R[g + 1];
-              const float xr = float (fma (2.0, R[g].x, -(lo.x + hi.x))), xi = float (fma (2.0, R[g].y, -(lo.y + hi.y)));
-              abs2[g] = __fadd_rn (__fmul_rn (xr, xr), __fmul_rn (xi, xi));
-            }
-          float least = abs2[0];
-#pragma unroll
-          for (int g = 1; g < NG; g++)
-            least = fminf (least, abs2[g]);
-          if (__builtin_expect (__builtin_amdgcn_ballot_w64 (least < 0x1p-96f && step < my_count) != 0 || zero_bits || skip_bits, 0))
-            {
-              const bool zero_frame = (zero_bits >> col) & 1, skip = (skip_bits >> sl) & 1;
-#pragma unroll
-              for (int g = 0; g < NG; g++)
-                {
-                  const float v = abs2[g] > 0 ? __fmul_rn (log2f (abs2[g]), 3.01029995663981f) : -96.f;
-                  db[g] = skip ? 0.f : (zero_frame ? -96.f : v);
-                }
-            }
-          else
-            {
-#pragma unroll
-              for (int g = 0; g < NG; g++)
-                db[g] = __fmul_rn (__builtin_amdgcn_logf (abs2[g]), 3.01029995663981f);
-            }
-#pragma unroll
-          for (int s = 0; s < 2; s++)
-            if (!((skip_bits >> s) & 1) && step < count[s])
-              {
-                if (step < 64)
-                  have_mask[s] |= 1ULL << step;
-                else
-                  have_64[s] = true;
-              }
-          // ---- advance by 8 samples: acc = R + sum_j d[j] W^{jk} on the matrix cores, the rotation on the vector unit
-          {
-            double ax[NG], ay[NG];
-#pragma unroll
-            for (int g = 0; g < NG; g++)
-              {
-                ax[g] = __builtin_amdgcn_mfma_f64_4x4x4f64 (a_re[g][0], b_lo, R[g].x, 0, 0, 0);
-                ay[g] = __builtin_amdgcn_mfma_f64_4x4x4f64 (a_im[g][0], b_lo, R[g].y, 0, 0, 0);
-              }
-#pragma unroll
-            for (int g = 0; g < NG; g++)
-              {
-                ax[g] = __builtin_amdgcn_mfma_f64_4x4x4f64 (a_re[g][1], b_hi, ax[g], 0, 0, 0);
-                ay[g] = __builtin_amdgcn_mfma_f64_4x4x4f64 (a_im[g][1], b_hi, ay[g], 0, 0, 0);
-              }
-            // channel 1's dB values reach channel 0's lanes while the matrix cores work (0 + db0 + db1 in the reference's order,
-            // syncfinder.cc:594-599; a skipped row is 0 in both channels)
-            float sum[NG];
-#pragma unroll
-            for (int g = 0; g < NG; g++)
-              {
-                const float other = __int_as_float (__builtin_amdgcn_update_dpp (0, __float_as_int (db[g]), 0xf5 /* quad_perm:[1,1,3,3] */, 0xf, 0xf, true));
-                sum[g] = __fadd_rn (__fadd_rn (0.f, db[g]), other);
-              }
-#pragma unroll
-            for (int g = 0; g < NG; g++)
-              *reinterpret_cast<float *> (mem + tile_addr[g] + tile_col) = sum[g];
-#pragma unroll
-            for (int g = 0; g < NG; g++)
-              {
-                R[g].x = fma (ax[g], rho[g].x, -(ay[g] * rho[g].y));
-                R[g].y = fma (ax[g], rho[g].y, ay[g] * rho[g].x);
-              }
-            const unsigned reset_bits = unsigned ((rmask[0] >> sh) & 1) | unsigned ((rmask[1] >> sh) & 1) << 1 | unsigned ((rmask[2] >> sh) & 1) << 2
-                                      | unsigned ((rmask[3] >> sh) & 1) << 3;
-            if (__builtin_expect (reset_bits != 0, 0))
-              if ((reset_bits >> col) & 1)
-                {
-#pragma unroll
-                  for (int g = 0; g < NG; g++)
-                    R[g] = make_double2 (0.0, 0.0);
-                }
-          }
-          tile_col += 4;
-        }
-      __builtin_amdgcn_s_waitcnt (0x0f70);                        // vmcnt (0): everything in flight was issued a block of steps ago
-      wave_sync();
-      const int t_end = t0 + n_cols;
-      if (t_end < maxcount)
-        {
-          publish_block (S0, t_end);
-          publish_block (S1, t_end);
-        }
-      // ---- flush: the block's 16 offsets of every row, 16 bytes per lane, four lanes per row
-      if (!no_store)
-        {
-#pragma unroll
-          for (int s = 0; s < 2; s++)
-            {
-              const int cols = (t_end < count[s] ? t_end : count[s]) - t0;      // offsets of this block the stream has
-              if (cols <= 0)
-                continue;
-              const float *tile = reinterpret_cast<const float *> (mem + s * L::OFF_TILE1);
-              if (t0 == 64 && a.tail)
-                {
-                  global_float *tl = uniform_global (a.tail + out_slot[s] * a.tail_stream_stride);
-                  for (int row = lane; row < ROWS; row += 64)
-                    tl[unsigned (row)] = tile[row * L::LD];
-                }
-              else
-                {
-                  const int c4 = (lane & 3) * 4;
-                  global_float *out = uniform_global (a.out + out_slot[s] * a.out_stream_stride + t0);
-                  const unsigned ld = unsigned (a.ld);
-                  const bool vec = ((reinterpret_cast<uintptr_t> (out) | (ld * 4u)) & 15) == 0;
-                  for (int row = lane >> 2; row < ROWS; row += 16)
-                    {
-                      const float *src = tile + row * L::LD + c4;
-                      const float v0 = src[0], v1 = src[1], v2 = src[2], v3 = src[3];
-                      global_float *dst = out + (unsigned (row) * ld + unsigned (c4));
-                      typedef float v4f __attribute__ ((ext_vector_type (4)));
-                      if (vec && c4 + 3 < cols)
-                        *(__attribute__ ((address_space (1))) v4f *) dst = (v4f) { v0, v1, v2, v3 };
-                      else
-                        {
-                          if (c4 + 0 < cols) dst[0] = v0;
-                          if (c4 + 1 < cols) dst[1] = v1;
-                          if (c4 + 2 < cols) dst[2] = v2;
-                          if (c4 + 3 < cols) dst[3] = v3;
-                        }
-                    }
-                }
-            }
-        }
-      tile_col = 0;
-      wave_sync();
-      fetch_block (S0, t0 / SL_TILE + 2);
-      fetch_block (S1, t0 / SL_TILE + 2);
-    }
-#pragma unroll
-  for (int s = 0; s < 2; s++)
-    {
-      if (a.have && lane < count[s])
-        a.have[out_slot[s] * a.have_stream_stride + lane] = (have_mask[s] >> lane) & 1;
-      if (a.have && lane == 0 && count[s] > 64)
-        a.have[out_slot[s] * a.have_stream_stride + 64] = have_64[s];
-    }
-}
-
-__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
-sync_db_sliding6_kernel (DevTables t, SyncDbArgs a)
-{
-  sync_db_sliding6_body<60> (t, a);
-}
-__global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (2, 3)))
-sync_db_sliding6_bands_kernel (DevTables t, SyncDbArgs a)
-{
-  sync_db_sliding6_body<NB> (t, a);
-}
-
 /* which form of K4s runs for stereo streams (awm_debug_set_refine_form; the result of 0, 3 and 4 is the same to the last bit):
  *   0  sync_db_sliding_kernel<2>    two bins of both channels per lane (42 lanes)
  *   3  sync_db_sliding3_kernel      three bins of one channel per lane (56 lanes): rounds 3 - 5
  *   4  sync_db_sliding4_kernel      the same arithmetic, restructured (above)
  *   5  sync_db_sliding4f_kernel     the update term in float (above): NOT bit-identical, gated by the census of DESIGN.md section 4
- *   6  sync_db_sliding6_kernel      the update term on the matrix cores, two streams per wave (above): the arithmetic of 0 / 3 / 4 */
+ * (A form 6 -- the update term on the matrix cores, v_mfma_f64_4x4x4f64 with C = R, two streams x two channels per wave -- was built and
+ * measured in round 6: bit-identical, 335 against 292 us for 12 750 streams alone.  FP64 matrix instructions run on the FP64 vector
+ * pipeline of gfx950 and do 256 multiply-adds per ~18 cycles where v_fma_f64 does 64 per ~5: nothing to gain.  profiles/r06/k4s_form6.txt,
+ * tools/mfma_f64_probe.hip; the kernel is in the history: "K4s form 6".) */
 int g_refine_form = 4;
-extern "C" void awm_debug_set_refine_form (int form) { g_refine_form = (form == 0 || form == 3 || form == 4 || form == 5 || form == 6) ? form : 4; }
+extern "C" void awm_debug_set_refine_form (int form) { g_refine_form = (form == 0 || form == 3 || form == 4 || form == 5) ? form : 4; }
 extern "C" int  awm_debug_refine_form() { return g_refine_form; }
 extern "C" void awm_debug_set_sliding3 (int on) { g_refine_form = on ? 3 : 0; }     // (rounds 3 - 5's toggle, kept for tools/gpu_variants.py)
 
-bool sliding_rows_have_tail (int n_channels) { return n_channels == 2 && (g_refine_form == 4 || g_refine_form == 5 || g_refine_form == 6); }
+bool sliding_rows_have_tail (int n_channels) { return n_channels == 2 && (g_refine_form == 4 || g_refine_form == 5); }
 
 hipError_t
 launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
@@ -3051,12 +2615,7 @@ launch_sync_db_sliding (hipStream_t st, const DevTables& t, const SyncDbArgs& a)
   if (a.hop != 8 || a.count0 > 65 || a.per_channel || (a.n_channels != 1 && a.n_channels != 2))
     return hipErrorInvalidValue;
   const unsigned grid = unsigned ((a.n_streams + WAVES - 1) / WAVES);
-  const unsigned grid_pairs = unsigned (((a.n_streams + 1) / 2 + WAVES - 1) / WAVES);
-  if (a.n_channels == 2 && g_refine_form == 6 && a.band_pos)
-    hipLaunchKernelGGL (sync_db_sliding6_kernel, dim3 (grid_pairs), dim3 (64 * WAVES), 0, st, t, a);
-  else if (a.n_channels == 2 && g_refine_form == 6)
-    hipLaunchKernelGGL (sync_db_sliding6_bands_kernel, dim3 (grid_pairs), dim3 (64 * WAVES), 0, st, t, a);
-  else if (a.n_channels == 2 && g_refine_form == 5 && a.band_pos)
+  if (a.n_channels == 2 && g_refine_form == 5 && a.band_pos)
     hipLaunchKernelGGL (sync_db_sliding4f_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
   else if (a.n_channels == 2 && g_refine_form == 5)
     hipLaunchKernelGGL (sync_db_sliding4f_bands_kernel, dim3 (grid), dim3 (64 * WAVES), 0, st, t, a);
