@@ -758,6 +758,7 @@ def main():
     single_stream = args.config == "60min" and world == 1 and not args.sharded
     prof = read_prof(awm, ctx)
     two_calls_ms = None
+    one_call_equal = None
     if world == 1 and not args.sharded and args.config != "clips" and not args.one_call:
         # the same step as ONE call (awm_add_get_watermark_d; untimed extra): what the add -> get hand-over per chunk is worth
         awm.lib.awm_prof_enable(ctx._h, 0)
@@ -771,8 +772,9 @@ def main():
         sync()
         two_calls_ms = round((time.perf_counter() - t0) / max(3, args.steps // 2) * 1e3, 3)
         key2 = lambda p: (p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
-        if [key2(p) for p in pats2] != [key2(p) for p in (pats or [])]:
-            raise SystemExit("bench.py: awm_add_get_watermark_d and the two separate calls disagree")
+        one_call_equal = [key2(p) for p in pats2] == [key2(p) for p in (pats or [])]
+        if not one_call_equal:                               # (a bug to report -- in the line, which it must not cost)
+            print("bench.py: awm_add_get_watermark_d and the two separate calls disagree", file=sys.stderr)
     serial, serial_steps = {}, 3
     if args.config != "clips":
         # the same kernels one after the other (a single lane), outside the timed region: the duration a kernel has when it
@@ -901,6 +903,7 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "first_step_ms": first_step_ms,
             "ms_per_step_as_one_call": two_calls_ms,
+            "one_call_patterns_equal_two_calls": one_call_equal,
             "higher_is_better": True,
             "scaling": "strong" if strong or args.config == "clips" else "weak",
             "vs_baseline": None,
