@@ -716,7 +716,8 @@ limiter_scale (long long gs, const float *block_max, long long first_block, long
   return __fadd_rn (scale_start, __fmul_rn (float (i), scale_step));
 }
 
-// generic: one value per thread
+// GENERIC FORM (what runs for 3+ channels, unaligned spans and the values behind the last whole float4; the stereo / mono streams of
+// the bench take limiter_table_kernel + limiter_apply_kernel below): one value per thread
 __global__ void __launch_bounds__ (256)
 limiter_kernel (float *data, long long n_frames, int C, long long first_sample, const float *block_max,
                 long long first_block, long long n_blocks, int BS, float ceiling)
@@ -1654,6 +1655,8 @@ uniform_global (const float *p)
   return (global_float *) (unsigned long long) wave_uniform ((long long) (unsigned long long) p);
 }
 
+// STATUS: <1> is the product path for MONO streams; <2> ("form 0", round 2) only runs behind awm_debug_set_refine_form (0) as one of the
+// three kernels test_refinement_kernel_forms holds against each other bit for bit -- stereo streams take sync_db_sliding4_kernel.
 template<int CV> __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
 sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
 {
@@ -1916,7 +1919,9 @@ sync_db_sliding_kernel (DevTables t, SyncDbArgs a)
  * (at the seam between the channels the neighbours are wrong, but only for bins 19 and 102, which are neighbours themselves and
  * never output).  The channels' dB values meet in the LDS tile ([offset][channel][band]) and are added when the tile is flushed:
  * 0 + db0 + db1 in the reference's order.  Everything else -- first transform in double, recurrence in double, non-zero sample
- * counts, skip rules, output layout -- is sync_db_sliding_kernel's. */
+ * counts, skip rules, output layout -- is sync_db_sliding_kernel's.
+ * STATUS: superseded by sync_db_sliding4_kernel (round 6, same values); kept behind awm_debug_set_refine_form (3) as the pinned
+ * reference of test_refinement_kernel_forms and of tools/gpu_k4s_forms.py's before / after. */
 __global__ void __launch_bounds__ (64 * WAVES) __attribute__ ((amdgpu_waves_per_eu (3, 3)))
 sync_db_sliding3_kernel (DevTables t, SyncDbArgs a)
 {
@@ -2943,6 +2948,8 @@ launch_local_mean (hipStream_t st, const double *q, long long q_stride, long lon
 
 /* ==========================================================================================
  * K7: mix_decode -- one thread per soft bit, double accumulators in the reference's order
+ * GENERIC FORM: what runs when frames_per_bit x channels x 30 items of a bit do not fit soft_bits_wave_kernel's tile (3+ channels,
+ * --frames-per-bit > 2) or behind awm_debug_set_soft_bits_generic; the streams of the bench take soft_bits_wave_kernel.
  * ========================================================================================== */
 __global__ void __launch_bounds__ (128)
 soft_bits_kernel (SoftBitsArgs a)

@@ -585,6 +585,8 @@ viterbi_trace_wave (const TracePlan& plan, int final_parity, const unsigned char
     }
 }
 
+// FALLBACK: the walk back as a launch of its own (one lane per decode) -- only for chains without the sync workspace or whose last round is
+// not a single round of <= 4 steps (awm_debug_set_viterbi_super (0), K = 5 rounds); the chains of the product end in viterbi_last_round_kernel.
 __global__ void __launch_bounds__ (64)
 viterbi_trace_kernel (ViterbiBatch b, TracePlan plan)
 {

@@ -92,17 +92,42 @@ KERNELS = {
 }
 
 
+def _code_only(text):
+    """C / C++ source without comments and with runs of white space collapsed (string and character literals kept as they are)"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if c in "\"'":
+            j = i + 1
+            while j < n and text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append(text[i:j + 1])
+            i = j + 1
+        elif text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            i = n if j < 0 else j + 2
+            out.append(" ")
+        else:
+            out.append(c)
+            i += 1
+    return " ".join("".join(out).split())
+
+
 def hip_sources_digest():
-    """sha256 over the device sources (audiowmark_amd/csrc/hip/*): what `profiles/rNN/HIP_SOURCES_SHA256` records when the PMC passes are
-    taken (tools/gpu_final.sh), so that a traffic figure is never reported for kernels that changed afterwards (no git on the GPU box)"""
+    """sha256 over the CODE of the device sources (audiowmark_amd/csrc/hip/*, comments and white space aside): what
+    `profiles/rNN/HIP_SOURCES_SHA256` records when the PMC passes are taken (tools/gpu_final.sh), so that a traffic figure is never
+    reported for kernels that changed afterwards (no git on the GPU box)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(ROOT, "audiowmark_amd", "csrc", "hip")
     for name in sorted(os.listdir(d)):
         if name.endswith((".hip", ".h", ".hh")):
             h.update(name.encode())
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(f.read())
+            with open(os.path.join(d, name), "r", encoding="utf-8", errors="replace") as f:
+                h.update(_code_only(f.read()).encode())
     return h.hexdigest()
 
 
