@@ -263,6 +263,31 @@ def test_file_shorter_than_its_header_says_and_input_from_a_pipe(gpu, tmp_path):
     assert dst.read_bytes() == want_raw
 
 
+def test_get_of_a_long_file_that_ends_before_its_header_says(gpu, tmp_path):
+    """the file level `get` starts its chunks while the stream is still being loaded, with the chunk plan of the ANNOUNCED length (two chunks
+    or more: > 30 min).  A WAV whose header announces 62 min and that holds 33.5: what the chunks saw beyond the end was not the stream --
+    the result is thrown away and the plain order takes over: the pattern list is that of the same samples under a truthful header, with
+    the chunks started during the load and with the whole stream loaded first."""
+    awm, t = gpu.awm, gpu.torch
+    n_have, n_said = int(33.5 * 60 * 44100), 62 * 60 * 44100
+    x = gpu.ctx.add_watermark(None, PAY, noise(gpu, n_have, 2, 29) * 0.9)
+    pcm = gpu.ctx.pcm_encode(x.reshape(-1), 16, 0, False, True).cpu().numpy().tobytes()
+    del x
+    cut, whole = tmp_path / "cut.wav", tmp_path / "whole.wav"
+    cut.write_bytes(_wav(pcm, announce=n_said * 4))
+    whole.write_bytes(_wav(pcm))
+    key = lambda p: (round(p["time"], 6), p["sync_index"], p["type"], p["block_type"], p["bits"], p["sync_quality"], p["decode_error"])
+    want = [key(p) for p in gpu.ctx.get_watermark_file(None, whole)]
+    assert sum(p[4] == PAY for p in want) > 30
+    assert [key(p) for p in gpu.ctx.get_watermark_file(None, cut)] == want
+    awm.lib.awm_debug_set_get_overlap(0)
+    try:
+        assert [key(p) for p in gpu.ctx.get_watermark_file(None, cut)] == want
+        assert [key(p) for p in gpu.ctx.get_watermark_file(None, whole)] == want
+    finally:
+        awm.lib.awm_debug_set_get_overlap(1)
+
+
 def test_ctx_warm_up_and_trim(gpu, tmp_path):
     """awm_ctx_warm_up creates the streams a first call would create, awm_ctx_trim gives the kept workspaces back (lanes' scratch buffers, the
     file level rings, the stream's PCM buffer): results before, between and after are the same, a trimmed context allocates again by itself"""
