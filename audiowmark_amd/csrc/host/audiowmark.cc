@@ -159,8 +159,8 @@ shared_options()
   return {
     { Option::VALUE, "--short", [] (const string&) { die ("audiowmark: --short payloads are not supported by the GPU path\n"); } },
     { Option::VALUE, "--frames-per-bit", [] (const string& v) {
-        if (to_int (v) != params().frames_per_bit)
-          die (string_printf ("audiowmark: --frames-per-bit other than %d is not supported by the GPU path\n", params().frames_per_bit));
+        // (reference audiowmark.cc:675: any integer; the compute entry points take 1 .. 8 and say so otherwise)
+        params().frames_per_bit = to_int (v);
       } },
     { Option::FLAG, "--linear", [] (const string&) { params().mix = false; } },
   };

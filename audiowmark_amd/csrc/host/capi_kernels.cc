@@ -23,6 +23,8 @@ namespace {
 constexpr int LIMITER_BLOCK = Params::mark_sample_rate * int (Params::limiter_block_size_ms) / 1000;   // Limiter::set_block_size_ms
 const float LIMITER_CEILING = float (Params::limiter_ceiling);
 
+constexpr int MAX_FRAMES_PER_BIT = 8;
+
 int
 check_ctx (awm_ctx *ctx)
 {
@@ -37,11 +39,12 @@ check_ctx (awm_ctx *ctx)
       set_error ("hipSetDevice: " + hip_error_string (e));
       return AWM_ERR_HIP;
     }
-  if (params().frames_per_bit != 2 || params().payload_size != 128)
+  if (params().frames_per_bit < 1 || params().frames_per_bit > MAX_FRAMES_PER_BIT || params().payload_size != 128)
     {
-      // the kernels are specialised for the default block geometry (2226 frames); the reference's undocumented
-      // --frames-per-bit and the deprecated --short payloads are out of scope
-      set_error ("unsupported watermark parameters (frames_per_bit != 2 or short payload)");
+      // --frames-per-bit (audiowmark.cc:675-679) sets the block's geometry -- 510 sync + 858 x frames_per_bit data frames --, which every
+      // kernel takes as an argument; the tables that are BUILT on the device (K16 / K16g: clip batches with a key per clip) are laid
+      // out for the default and hand over to the host builders otherwise.  The deprecated --short payloads are out of scope.
+      set_error ("unsupported watermark parameters (frames_per_bit outside 1 .. 8 or a short payload)");
       return AWM_ERR_ARG;
     }
   return 0;

@@ -35,9 +35,9 @@ enter (awm_ctx *ctx, const awm_comm *comm, const uint64_t *span_frames, int n_ch
       set_error ("hipSetDevice failed");
       return AWM_ERR_HIP;
     }
-  if (params().frames_per_bit != 2 || params().payload_size != 128)
+  if (params().frames_per_bit < 1 || params().frames_per_bit > 8 || params().payload_size != 128)      // (as check_ctx, capi_kernels.cc)
     {
-      set_error ("unsupported watermark parameters (frames_per_bit != 2 or short payload)");
+      set_error ("unsupported watermark parameters (frames_per_bit outside 1 .. 8 or a short payload)");
       return AWM_ERR_ARG;
     }
   return 0;

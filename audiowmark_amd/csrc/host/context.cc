@@ -357,7 +357,7 @@ awm_ctx::get_key_tables (const Key& key)
   std::lock_guard<std::mutex> lock (table_mutex);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& kt : key_tables)
-    if (kt->key == kb && kt->mix == params().mix)
+    if (kt->key == kb && kt->mix == params().mix && kt->frames_per_bit == params().frames_per_bit)
       {
         kt->last_use = ++table_clock;
         return kt.get();
@@ -376,6 +376,7 @@ awm_ctx::get_key_tables (const Key& key)
   kt->last_use = ++table_clock;
   kt->key = kb;
   kt->mix = params().mix;
+  kt->frames_per_bit = params().frames_per_bit;
   for (int clip = 0; clip < 2; clip++)
     {
       auto& s = kt->sync[clip];
@@ -492,7 +493,7 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
   std::lock_guard<std::mutex> lock (table_mutex);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& t : frame_mod_tables)
-    if (t->key == kb && t->payload == payload_hex && t->mix == params().mix)
+    if (t->key == kb && t->payload == payload_hex && t->mix == params().mix && t->frames_per_bit == params().frames_per_bit)
       {
         t->last_use = ++table_clock;
         return t.get();
@@ -508,6 +509,7 @@ awm_ctx::get_frame_mod (const Key& key, const std::string& payload_hex)
   t->key = kb;
   t->payload = payload_hex;
   t->mix = params().mix;
+  t->frames_per_bit = params().frames_per_bit;
   t->last_use = ++table_clock;
   if (upload (t->dev, table.data(), table.size(), stream))
     return nullptr;

@@ -89,6 +89,7 @@ struct KeyTables
   std::vector<unsigned char> key;
   unsigned long last_use = 0;
   bool mix = true;                 // params().mix the data tables were built for (--linear: per-frame up / down bands)
+  int  frames_per_bit = 2;         // ... and params().frames_per_bit (the block's geometry: 510 sync + 858 frames_per_bit data frames)
   // sync tables, BLOCK and CLIP flavour
   struct Sync
   {
@@ -198,8 +199,9 @@ struct FrameModTable
   std::vector<unsigned char> key;
   std::string payload;
   bool        mix = true;
+  int         frames_per_bit = 2;
   unsigned long last_use = 0;
-  DevBuffer   dev;                 // [2*2226][81] int8
+  DevBuffer   dev;                 // [2 * block frames][81] int8 (2226 frames with two frames per bit)
 };
 
 } // namespace awm

@@ -223,7 +223,7 @@ get_speed_key_tables (awm_ctx *ctx, const Key& key)
   SpeedWorkspace *ws = workspace (ctx);
   std::vector<unsigned char> kb (key.aes_key(), key.aes_key() + Key::SIZE);
   for (auto& t : ws->key_tables)
-    if (t->key == kb)
+    if (t->key == kb && t->frames_per_bit == params().frames_per_bit)
       return t.get();
   KeyTables *kt = ctx->get_key_tables (key);
   if (!kt)
@@ -254,6 +254,7 @@ get_speed_key_tables (awm_ctx *ctx, const Key& key)
       }
   auto t = std::make_unique<SpeedKeyTables>();
   t->key = kb;
+  t->frames_per_bit = params().frames_per_bit;
   if (upload_sync (t->col_first, col_first.data(), col_first.size(), ctx->stream))
     return nullptr;
   if (upload_sync (t->cols, cols.data(), cols.size() * sizeof (unsigned int), ctx->stream))

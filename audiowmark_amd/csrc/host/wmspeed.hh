@@ -53,6 +53,7 @@ struct VarTableSlab
 struct SpeedKeyTables
 {
   std::vector<unsigned char> key;
+  int       frames_per_bit = 2;     // params().frames_per_bit the block's layout was drawn for
   DevBuffer cols;           // [510][16] words: 30 up + 30 down band indices
   DevBuffer col_frame;      // [510] int
   DevBuffer col_first;      // [6][block frames + 2] uint8: columns of the bit with frame < f

@@ -522,7 +522,7 @@ typedef struct
   int    strict;                 /* --strict: message length must equal payload_size, `add` refuses clipped input (Params::strict, 0) */
   int    snr;                    /* --snr: `add` reports the SNR (Params::snr, 0; file level only) */
   int    payload_size;           /* bits (Params::payload_size, 128; other sizes are refused by the compute entry points) */
-  int    frames_per_bit;         /* (Params::frames_per_bit, 2; other values are refused by the compute entry points) */
+  int    frames_per_bit;         /* (Params::frames_per_bit, 2: --frames-per-bit, reference audiowmark.cc:675; the compute entry points take 1 .. 8) */
   double sync_threshold2;        /* --sync-threshold (Params::sync_threshold2, 0.35) */
   int    get_n_best;             /* (Params::get_n_best, 8) */
   double get_chunk_size;         /* --chunk-size, minutes (Params::get_chunk_size, 30) */

@@ -145,6 +145,29 @@ def test_against_reference_binary(work):
         same_report(ours, theirs, str(f), max_tie_lines=tie_lines)
 
 
+@pytest.mark.skipif(not os.path.exists(_ref.BIN), reason="oracle/_ref/audiowmark_ref not built")
+def test_frames_per_bit_option_against_reference_binary(tmp_path):
+    """--frames-per-bit (reference audiowmark.cc:675: a block of 510 + 858 x N frames) through both command lines: 90 s of test-gen-noise
+    watermarked with N = 3 by either binary differ by quantisation-boundary flips only, both detectors print the same report for both files,
+    and neither finds the payload without the option (the blocks do not line up)."""
+    noise = tmp_path / "noise.wav"
+    noise.write_bytes(run([AWM, "test-gen-noise", "-", "90", "44100"]).stdout)
+    ours_marked, ref_marked = tmp_path / "ours.wav", tmp_path / "ref.wav"
+    ours_marked.write_bytes(run([AWM, "add", "--frames-per-bit", "3", "--format", "wav-pipe", str(noise), "-", PAY]).stdout)
+    ref_marked.write_bytes(run([_ref.BIN, "add", "--frames-per-bit", "3", "--format", "wav-pipe", str(noise), "-", PAY]).stdout)
+    a, b = wav_samples(str(ours_marked)).astype(np.int32), wav_samples(str(ref_marked)).astype(np.int32)
+    assert a.shape == b.shape
+    diff = np.abs(a - b)
+    assert diff.max() <= 1 and (diff != 0).mean() < 1e-3
+    for f in (ours_marked, ref_marked):
+        ours = run([AWM, "get", "--frames-per-bit", "3", "--input-format", "wav-pipe", str(f)]).stdout.decode().splitlines()
+        theirs = run([_ref.BIN, "get", "--frames-per-bit", "3", "--x-in-wav-pipe", str(f)]).stdout.decode().splitlines()
+        same_report(ours, theirs, str(f))
+        assert any(PAY in l for l in ours)
+    plain = run([AWM, "get", "--input-format", "wav-pipe", str(ours_marked)]).stdout.decode()
+    assert PAY not in plain
+
+
 @pytest.mark.skipif(not _ref.available(), reason="oracle/_ref (compiled reference) not built")
 def test_the_known_refinement_tie_is_exactly_that_one(work):
     """The fixture's tie, pinned by its sync indices: on the file watermarked by this library every pattern of the compiled
@@ -358,7 +381,7 @@ def test_hard_option_through_the_c_abi(work):
     hard_ctx.set_params()                                                       # back to the process-wide set
     assert [p["decode_error"] for p in hard_ctx.get_watermark_file(None, str(marked))] == [p["decode_error"] for p in soft]
     # a parameter the kernels are not built for is refused at the entry point, not silently ignored
-    soft_ctx.set_params(frames_per_bit=3)
+    soft_ctx.set_params(frames_per_bit=9)
     with pytest.raises(awm.AwmError):
         soft_ctx.get_watermark_file(None, str(marked))
 

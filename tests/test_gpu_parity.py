@@ -407,12 +407,77 @@ def test_unmarked_audio_uses_n_best_fallback(gpu):
 
 
 def test_unsupported_parameters_are_refused(gpu):
-    gpu.awm.set_params(frames_per_bit=3)
+    for fpb in (0, 9, -2):                                    # --frames-per-bit: 1 .. 8 are block geometries the kernels take
+        gpu.awm.set_params(frames_per_bit=fpb)
+        try:
+            with pytest.raises(gpu.awm.AwmError):
+                gpu.ctx.add_watermark(None, PAY1, gpu.dev(noise(1, 5000, 2)))
+        finally:
+            gpu.awm.set_params()
+
+
+@pytest.mark.parametrize("fpb", [1, 3, 4])
+def test_frames_per_bit_other_than_two(gpu, fpb):
+    """--frames-per-bit (reference audiowmark.cc:675, wmcommon.cc:36-48: a block is 510 sync + 858 x frames_per_bit data frames: 1368 / 3084 /
+    3942 instead of 2226).  Every kernel takes the geometry as an argument; the tables that are built on the device for clip batches with
+    a key per clip hand over to the host builders.  `add` against the oracle and the compiled reference (PCM), `get` of the oracle's
+    output in BLOCK mode (200 s) and in CLIP mode (40 s): positions, types, payloads equal, qualities within the tolerance; the tile loop
+    equals the whole buffer; a batch of clips with a key per clip equals the single calls; and the tables cached per key follow the
+    parameter (the same key with two geometries in one process)."""
+    import _ref as ref
+    t = gpu.torch
+    base = gpu.ctx.get_watermark(None, gpu.dev(orc.add(None, noise(440, 60 * 44100, 2), 2, PAY1).reshape(-1, 2)))     # default geometry first
+    gpu.awm.set_params(frames_per_bit=fpb)
+    orc.set_params(frames_per_bit=fpb)
+    ref.set_params(frames_per_bit=fpb)
     try:
-        with pytest.raises(gpu.awm.AwmError):
-            gpu.ctx.add_watermark(None, PAY1, gpu.dev(noise(1, 5000, 2)))
+        for seconds in (200, 40):
+            x = noise(441 + fpb + seconds, seconds * 44100 + 321, 2)
+            want = orc.add(None, x, 2, PAY1).reshape(-1, 2)
+            got = gpu.ctx.add_watermark(None, PAY1, gpu.dev(x)).cpu().numpy()
+            assert rms(got, want) < RMS_TOL and np.abs(got - want).max() < 2e-6, (fpb, seconds)
+            if seconds == 40:
+                assert rms(got, np.asarray(ref.add(None, x, 2, PAY1)).reshape(-1, 2)) < RMS_TOL
+            ours, theirs = gpu.ctx.get_watermark(None, gpu.dev(want)), orc.get(None, want, 2)
+            assert [pkey(p) for p in ours] == [pkey(p) for p in theirs] and len(ours) > 0, (fpb, seconds)
+            assert max(abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(ours, theirs)) < QUALITY_TOL
+            assert any(p["bits"] == PAY1 for p in ours), (fpb, seconds)
+            if seconds == 200:
+                assert t.equal(gpu.ctx.add_watermark_tiles(None, PAY1, gpu.dev(x), tile_frames1024=128), gpu.ctx.add_watermark(None, PAY1, gpu.dev(x)))
+        if fpb == 3:
+            # a stream that starts inside the frame / block grid (zero_frames), and one stream over two contexts
+            from audiowmark_amd import sharded
+            x = noise(470, 150 * 44100 + 5, 2)
+            for zf in (1, 44100 + 17):
+                want = np.asarray(ref.add_at(None, x, 2, PAY1, zf)).reshape(-1, 2)
+                assert rms(gpu.ctx.add_watermark_tiles(None, PAY1, gpu.dev(x), tile_frames1024=128, zero_frames=zf).cpu().numpy(), want) < RMS_TOL, zf
+            other = gpu.awm.Context(0)
+            try:
+                xd = gpu.dev(x)
+                cut = 71 * 1024
+                outs = [t.empty_like(xd[:cut]), t.empty_like(xd[cut:])]
+                sharded.multi_add([gpu.ctx, other], None, PAY1, [xd[:cut].contiguous(), xd[cut:].contiguous()], outs)
+                whole = gpu.ctx.add_watermark(None, PAY1, xd)
+                assert t.equal(t.cat(outs), whole)
+                assert [pkey(p) for p in sharded.multi_get([gpu.ctx, other], None, outs)] == [pkey(p) for p in gpu.ctx.get_watermark(None, whole)]
+            finally:
+                other.close()
+        # clips with a key per clip: the batch entry points against the single calls
+        keys = [gpu.awm.test_key(k) for k in range(1, 6)]
+        clips = [gpu.dev(noise(460 + k, (25 + 3 * k) * 44100, 2)) for k in range(5)]
+        marked = gpu.ctx.add_watermark_batch_keys(keys, PAY2, clips)
+        for k in range(5):
+            assert t.equal(marked[k], gpu.ctx.add_watermark(keys[k], PAY2, clips[k])), k
+        batch = gpu.ctx.get_watermark_batch_keys(keys, marked)
+        for k in range(5):
+            assert [pkey(p) for p in batch[k]] == [pkey(p) for p in gpu.ctx.get_watermark(keys[k], marked[k])], k
+        assert sum(any(p["bits"] == PAY2 for p in c) for c in batch) >= 4
     finally:
         gpu.awm.set_params()
+        orc.set_params()
+        ref.set_params()
+    again = gpu.ctx.get_watermark(None, gpu.dev(orc.add(None, noise(440, 60 * 44100, 2), 2, PAY1).reshape(-1, 2)))
+    assert [pkey(p) + (p["sync_quality"],) for p in again] == [pkey(p) + (p["sync_quality"],) for p in base] and len(base) > 0
 
 
 def _sharded_worker(rank, world, port, lengths, q):
@@ -641,12 +706,12 @@ def test_multi_context_short_stream_and_errors(gpu):
                           [t.empty_like(whole[:cut + 5]), t.empty_like(whole[cut + 5:])])
     # the MAIN context's settings are in force on every rank (helpers with other settings would build other plans and wait for messages
     # that never come): a helper's own parameter set is ignored ...
-    ctxs[1].set_params(frames_per_bit=3)
+    ctxs[1].set_params(frames_per_bit=9)
     again = sharded.multi_get(ctxs, None, [whole[:cut].contiguous(), whole[cut:].contiguous()])
     assert [pkey(p) for p in again] == [pkey(p) for p in want]
     ctxs[1].set_params()
     # ... and the main context's unsupported ones fail the call
-    ctxs[0].set_params(frames_per_bit=3)
+    ctxs[0].set_params(frames_per_bit=9)
     try:
         with pytest.raises(gpu.awm.AwmError):
             sharded.multi_get(ctxs, None, [whole[:cut].contiguous(), whole[cut:].contiguous()])

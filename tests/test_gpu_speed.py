@@ -173,6 +173,34 @@ def test_mono_and_long_input_against_oracle(gpu):
     assert sum(p["bits"] == "f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0" and p["speed"] != 1 for p in got) >= 2
 
 
+def test_detect_speed_with_three_frames_per_bit(gpu):
+    """--frames-per-bit 3 (blocks of 3084 frames): the speed search's tables follow the geometry (the sync frames are drawn over the whole
+    block), the tables cached per key are keyed by it: 130 s stereo replayed 4 % slow, `get --detect-speed` against the oracle, then the
+    default geometry again with the same key."""
+    pay = "f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0f0"
+    pk = lambda p: (p["sync_index"], p["type"], p["block_type"], p["bits"])
+
+    def both(fpb):
+        gpu.awm.set_params(frames_per_bit=fpb)
+        orc.set_params(frames_per_bit=fpb)
+        gpu.awm.set_speed_params(detect_speed=True)
+        orc.set_speed_params(True, False, -1)
+        try:
+            y = orc.add(KEY, orc.gen_noise(KEY, 130 * 44100 * 2), 2, pay)
+            z = orc.resample_ratio(y, 2, 1 / 0.96)
+            return gpu.ctx.get_watermark(KEY, gpu.dev(z)), orc.get(KEY, z, 2)
+        finally:
+            gpu.awm.set_speed_params()
+            orc.set_speed_params(False, False, -1)
+            gpu.awm.set_params()
+            orc.set_params()
+    for fpb in (3, 2):
+        got, want = both(fpb)
+        assert [pk(p) for p in got] == [pk(p) for p in want], fpb
+        assert all(abs(g["speed"] - w["speed"]) <= SPEED_TOL for g, w in zip(got, want))
+        assert sum(p["bits"] == pay and abs(p["speed"] - 0.96) < 3e-4 for p in got) >= 1, fpb
+
+
 def test_short_silent_and_one_silent_channel(gpu):
     assert gpu.ctx.detect_speed(KEY, gpu.dev(np.zeros((5000, 2), np.float32)))[0] is None        # < 0.25 s
     # digital silence: every score is 0, the second pass searches around "speed 0": the reference exits with
