@@ -47,18 +47,32 @@ for case in range(n_cases):
     got = ctx.get_watermark(None, xd)
     kept.setdefault(ch, []).append((xd, got))
     want = orc.get(None, x, ch)
-    dq = max([abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(got, want)] + [0.0])
+    # The lists are ordered by quality: two patterns whose qualities are closer than the two float pipelines' rounding (1e-5) may swap places
+    # (seed 709 case 18: 0.186087469 / 0.186087433 here, 0.186088433 / 0.186086967 there).  Compared as the SAME patterns in any order if
+    # the positional comparison fails; everything else is reported with what it is.
+    if [key(p) for p in got] != [key(p) for p in want] and sorted(key(p) for p in got) == sorted(key(p) for p in want):
+        got_cmp, want_cmp = sorted(got, key=key), sorted(want, key=key)
+        reordered = True
+    else:
+        got_cmp, want_cmp, reordered = got, want, False
+    dq = max([abs(a["sync_quality"] - b["sync_quality"]) for a, b in zip(got_cmp, want_cmp)] + [0.0])
     # (the bits of a decode of NOISE -- decode error >= 0.6 on both sides -- may differ with the FFT's rounding: position and types count)
     junk = lambda a, b: key(a)[:4] == key(b)[:4] and a["decode_error"] >= 0.6 and b["decode_error"] >= 0.6
-    ok = len(got) == len(want) and all(key(a) == key(b) or junk(a, b) for a, b in zip(got, want)) and dq < 1e-4
+    ok = len(got) == len(want) and all(key(a) == key(b) or junk(a, b) for a, b in zip(got_cmp, want_cmp)) and dq < 1e-4
     hits = sum(p["bits"] == PAY for p in got)
     print("case %2d: %d ch %5.1f s lead %6d trail %6d marked %d -> %2d patterns, %d with the payload, max |dq| %.2g, %s"
-          % (case, ch, len(x) / 44100, lead, trail, marked, len(got), hits, dq, "identical" if ok else "DIFFERENT"), flush=True)
+          % (case, ch, len(x) / 44100, lead, trail, marked, len(got), hits, dq,
+             ("identical" + (" (two patterns of near-equal quality in the other order)" if reordered else "")) if ok else "DIFFERENT"), flush=True)
     if not ok:
         bad += 1
-        for g, w in zip(got, want):
+        for g, w in zip(got_cmp, want_cmp):
             if (key(g) != key(w) and not junk(g, w)) or abs(g["sync_quality"] - w["sync_quality"]) >= 1e-4:
-                print("    gpu", key(g), g["sync_quality"], "\n    orc", key(w), w["sync_quality"])
+                kind = ""
+                if g["type"] == w["type"] and g["sync_index"] != w["sync_index"] and abs(g["sync_index"] - w["sync_index"]) <= 64 and abs(g["sync_quality"] - w["sync_quality"]) < 1e-5:
+                    kind = "   [neighbouring fine offsets closer than the rounding: DESIGN.md section 4]"
+                elif key(g)[:4] == key(w)[:4]:
+                    kind = "   [same position and type, other bits: decode errors %.3f / %.3f]" % (g["decode_error"], w["decode_error"])
+                print("    gpu", key(g), g["sync_quality"], "\n    orc", key(w), w["sync_quality"], kind)
                 break
 # the same material through awm_get_watermark_batch_d (groups of padded clips for the short ones, one per lane for the others)
 for ch, items in kept.items():
