@@ -280,10 +280,16 @@ def test_get_of_a_long_file_that_ends_before_its_header_says(gpu, tmp_path):
     want = [key(p) for p in gpu.ctx.get_watermark_file(None, whole)]
     assert sum(p[4] == PAY for p in want) > 30
     assert [key(p) for p in gpu.ctx.get_watermark_file(None, cut)] == want
+    # headerless samples with three stray bytes behind the last whole frame (the length comes from the file's size)
+    ragged = tmp_path / "ragged.raw"
+    ragged.write_bytes(pcm + b"\x01\x02\x03")
+    rf = awm.binding.RawFormat(2, 44100, 16, 0, 0)
+    assert [key(p) for p in gpu.ctx.get_watermark_file(None, ragged, rf)] == want
     awm.lib.awm_debug_set_get_overlap(0)
     try:
         assert [key(p) for p in gpu.ctx.get_watermark_file(None, cut)] == want
         assert [key(p) for p in gpu.ctx.get_watermark_file(None, whole)] == want
+        assert [key(p) for p in gpu.ctx.get_watermark_file(None, ragged, rf)] == want
     finally:
         awm.lib.awm_debug_set_get_overlap(1)
 
